@@ -1,0 +1,89 @@
+"""ctypes mirror of include/cirs_hip.h and the loader of libcirs_hip.so.
+
+The HIP library is the product: there is NO CPU fallback.  `lib()` raises if the shared object is missing or
+does not export every symbol the header declares.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcirs_hip.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_u8p = C.POINTER(C.c_uint8)
+c_u32p = C.POINTER(C.c_uint32)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+
+
+class EnvCfg(C.Structure):
+    _fields_ = [("n_users", C.c_int32), ("n_items", C.c_int32), ("max_turn", C.c_int32),
+                ("num_leave_compute", C.c_int32), ("leave_threshold", C.c_int32), ("version", C.c_int32),
+                ("use_exposure", C.c_int32), ("has_ab", C.c_int32), ("dist_mode", C.c_int32),
+                ("simulated", C.c_int32), ("tau", C.c_double), ("gamma_exposure", C.c_double),
+                ("r_decay", C.c_double)]
+
+
+class EnvTables(C.Structure):
+    _fields_ = [("mat", C.c_void_p), ("normed_mat", C.c_void_p), ("dist", C.c_void_p),
+                ("item_cats", C.c_void_p), ("alpha_env", C.c_void_p), ("beta_env", C.c_void_p)]
+
+
+class EnvState(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("turn", C.c_void_p), ("done", C.c_void_p),
+                ("hist_action", C.c_void_p), ("cum_reward", C.c_void_p)]
+
+
+# name -> (restype, argtypes).  Must list every symbol include/cirs_hip.h declares (tests check this).
+_P = C.c_void_p
+SIGNATURES = {
+    "cirs_last_error": (C.c_char_p, []),
+    "cirs_version": (C.c_int, []),
+    "cirs_env_reset": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvState), _P, _P, C.c_int32, _P, _P]),
+    "cirs_env_step": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState), _P, _P, C.c_int32,
+                                _P, _P, _P, _P, _P, _P]),
+    "cirs_dist_jaccard": (C.c_int, [_P, C.c_int32, _P, _P]),
+}
+
+_lib = None
+
+
+class CirsHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libcirs_hip.so (built in-tree by `__graft_entry__.build()` / `cirs_hip.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CirsHipError(
+            f"{LIB_PATH} not found: the HIP extension is the only implementation of this path (no CPU fallback). "
+            "Build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950).")
+    handle = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as exc:
+            raise CirsHipError(f"libcirs_hip.so does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cirs_last_error()
+        raise CirsHipError(f"{what} failed rc={rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / numpy array as an int, 0 for None."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

@@ -1,0 +1,43 @@
+"""ctypes loader for the CPU oracle (oracle/_build/libcirs_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Importable only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product
+package.  Struct layouts come from the product's ABI mirror so both sides are called with identical arguments
+(host pointers here, device pointers there).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+sys.path.insert(0, os.path.join(_ROOT, "cirs-codes_amd"))
+
+from cirs_hip import abi  # noqa: E402
+
+LIB_PATH = os.path.join(_HERE, "_build", "libcirs_oracle.so")
+_P = C.c_void_p
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        h = C.CDLL(LIB_PATH)
+        h.oracle_env_reset.restype = C.c_int
+        h.oracle_env_reset.argtypes = [C.POINTER(abi.EnvCfg), C.POINTER(abi.EnvState), _P, _P, C.c_int32, _P]
+        h.oracle_env_step.restype = C.c_int
+        h.oracle_env_step.argtypes = [C.POINTER(abi.EnvCfg), C.POINTER(abi.EnvTables), C.POINTER(abi.EnvState),
+                                      _P, _P, C.c_int32, _P, _P, _P, _P, _P]
+        h.oracle_dist_jaccard.restype = C.c_int
+        h.oracle_dist_jaccard.argtypes = [_P, C.c_int32, _P]
+        h.oracle_gae_return.restype = C.c_int
+        h.oracle_gae_return.argtypes = [_P, _P, _P, _P, C.c_long, C.c_double, C.c_double, _P]
+        _lib = h
+    return _lib
