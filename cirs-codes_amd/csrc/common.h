@@ -1,0 +1,90 @@
+// common.h -- shared device/host helpers for libcirs_hip (gfx950 only; wavefront = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <string>
+
+#include "../../include/cirs_hip.h"
+
+#define CIRS_WAVE 64
+
+namespace cirs {
+
+void set_error(const std::string& msg);
+
+inline int fail(int code, const std::string& msg) {
+    set_error(msg);
+    return code;
+}
+
+#define CIRS_REQUIRE(cond, msg)                                             \
+    do {                                                                    \
+        if (!(cond)) return ::cirs::fail(CIRS_E_INVALID, std::string(msg)); \
+    } while (0)
+
+#define CIRS_CHECK_LAUNCH(what)                                                                          \
+    do {                                                                                                 \
+        hipError_t _e = hipGetLastError();                                                               \
+        if (_e != hipSuccess)                                                                            \
+            return ::cirs::fail(CIRS_E_LAUNCH, std::string(what) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+#define CIRS_HIP(call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t _e = (call);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return ::cirs::fail(CIRS_E_LAUNCH, std::string(#call) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wavefront (64-lane) reductions -------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, CIRS_WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, CIRS_WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, CIRS_WAVE));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, CIRS_WAVE);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, CIRS_WAVE);
+    return v;
+}
+
+// category bitmask of an item's packed 4 x u8 category ids (CIRS_CAT_NONE = empty slot)
+__device__ __forceinline__ unsigned long long cat_mask(uint32_t packed) {
+    unsigned long long m = 0;
+#pragma unroll
+    for (int k = 0; k < CIRS_MAX_CATS_PER_ITEM; ++k) {
+        uint32_t c = (packed >> (8 * k)) & 0xFFu;
+        if (c != CIRS_CAT_NONE) m |= 1ull << (c & 63u);
+    }
+    return m;
+}
+
+// 1/Jaccard exactly as the reference computes it in float64: sim = |A&B|/|A|B|, dist = 1.0/sim (inf if disjoint)
+__device__ __forceinline__ double jaccard_dist(uint32_t pa, uint32_t pb) {
+    unsigned long long ma = cat_mask(pa), mb = cat_mask(pb);
+    double inter = (double)__popcll(ma & mb);
+    double uni = (double)__popcll(ma | mb);
+    double sim = inter / uni;
+    return 1.0 / sim;
+}
+
+}  // namespace cirs

@@ -1,0 +1,215 @@
+// env.hip -- batched SimulatedEnv(KuaishouEnv) step for gfx950.
+//
+// One 64-lane wavefront per environment, 4 envs per 256-thread workgroup.  Lanes stride over the episode
+// history (t <= max_turn <= ~100), so the three per-step scans of the reference
+//   (a) exit rule: multiset of categories over the recent-N window  (kuaishouEnv.py:199-218)
+//   (b) exposure effect: sum_k exp(-(t-k) * dist[a, hist_k] / tau)   (simulated_env.py:147-168, util.py:34-46)
+//   (c) repeat count of the chosen item                              (simulated_env.py:129-132,188)
+// are each one gather per lane followed by a wavefront butterfly reduction.  All reward arithmetic is float64 like
+// the reference's NumPy scalars; exit decisions are integer and bit-exact.
+//
+// HBM traffic per env-step (table mode): 4*t B history + 8*t B dist gathers (one 32 B sector each, physically)
+// + 4*(N+1) B category words + 16 B (mat, normed_mat) + 16 B (alpha, beta) + ~40 B state/outputs.  The path is
+// latency-bound, not bandwidth-bound: the design goal is one launch for all envs and no host sync.
+#include "common.h"
+
+namespace cirs {
+
+constexpr int kEnvsPerBlock = 4;
+
+__global__ __launch_bounds__(256) void env_step_kernel(cirs_env_cfg cfg, cirs_env_tables tab, cirs_env_state st,
+                                                       const int64_t* __restrict__ actions,
+                                                       const int32_t* __restrict__ env_ids, int n,
+                                                       int64_t* __restrict__ obs_out, double* __restrict__ rew_out,
+                                                       uint8_t* __restrict__ done_out, double* __restrict__ ctr_out,
+                                                       double* __restrict__ expo_out) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * kEnvsPerBlock + (threadIdx.x >> 6);
+    if (j >= n) return;  // wave-uniform
+    const int e = env_ids ? env_ids[j] : j;
+    const int64_t action = actions[j];
+    const int T = cfg.max_turn;
+    const long I = cfg.n_items;
+    int32_t* hist = st.hist_action + (size_t)e * T;
+
+    if (st.done[e] || action < 0 || action >= I) {  // finished envs are never stepped by the collector: no-op
+        if (lane == 0) {
+            obs_out[j] = action;
+            rew_out[j] = 0.0;
+            done_out[j] = 1;
+            ctr_out[j] = 0.0;
+            if (expo_out) expo_out[j] = 0.0;
+        }
+        return;
+    }
+    const int u = st.user[e];
+    const int t = st.turn[e];
+    const uint32_t cats_a = tab.item_cats[action];
+
+    // ---- (a) exit rule + (c) repeat count: integer scans over the history ---------------------------------
+    // window = sequence_action[t-N : t] with Python negative-start wrap
+    long start = (long)t - cfg.num_leave_compute;
+    if (start < 0) {
+        start += t;
+        if (start < 0) start = 0;
+    }
+    if (start > t) start = t;
+    // counts of each of the action's (<=4) categories inside the window, 16 bits each, packed in a u64
+    unsigned long long packed_counts = 0;
+    int repeat = 0;
+    const bool want_exposure = cfg.simulated && cfg.use_exposure && t > 0 && cfg.tau > 0;
+    double expo_part = 0.0;
+    for (int k = lane; k < t; k += CIRS_WAVE) {
+        const int32_t hk = hist[k];
+        repeat += (hk == (int32_t)action);
+        uint32_t cats_h = 0;
+        const bool in_window = k >= start;
+        if (in_window || (want_exposure && cfg.dist_mode == 1)) cats_h = tab.item_cats[hk];
+        if (in_window) {
+#pragma unroll
+            for (int ia = 0; ia < CIRS_MAX_CATS_PER_ITEM; ++ia) {
+                const uint32_t ca = (cats_a >> (8 * ia)) & 0xFFu;
+                if (ca == CIRS_CAT_NONE) continue;
+                int c = 0;
+#pragma unroll
+                for (int ih = 0; ih < CIRS_MAX_CATS_PER_ITEM; ++ih) c += (((cats_h >> (8 * ih)) & 0xFFu) == ca);
+                packed_counts += (unsigned long long)c << (16 * ia);
+            }
+        }
+        // ---- (b) exposure effect term, float64 -----------------------------------------------------------
+        if (want_exposure) {
+            const double d = cfg.dist_mode == 0 ? tab.dist[(size_t)action * I + hk] : jaccard_dist(cats_a, cats_h);
+            const double t_diff = (double)(t - k);
+            expo_part += exp(-t_diff * d / cfg.tau);
+        }
+    }
+    packed_counts = wave_sum_u64(packed_counts);
+    repeat = wave_sum_i32(repeat);
+    const double exposure_effect = want_exposure ? wave_sum_f64(expo_part) : 0.0;
+
+    if (lane != 0) return;
+
+    int done = 0;
+    if (t > 0) {
+#pragma unroll
+        for (int ia = 0; ia < CIRS_MAX_CATS_PER_ITEM; ++ia) {
+            const uint32_t ca = (cats_a >> (8 * ia)) & 0xFFu;
+            const int cnt = (int)((packed_counts >> (16 * ia)) & 0xFFFFull);
+            if (ca != CIRS_CAT_NONE && cnt > cfg.leave_threshold) done = 1;
+        }
+    }
+    if (t >= T - 1) done = 1;
+
+    double reward, exposure_gamma = 0.0;
+    if (cfg.simulated) {
+        if (cfg.use_exposure && t > 0) {
+            double e_new = exposure_effect;
+            if (cfg.has_ab) e_new = exposure_effect * tab.alpha_env[u] * tab.beta_env[action];
+            exposure_gamma = e_new * cfg.gamma_exposure;
+        }
+        const double pred = tab.normed_mat[(size_t)u * I + action];
+        reward = cfg.version == 1 ? pred / (1.0 + exposure_gamma) : pred - exposure_gamma;
+        // num_actions[action] - 1 == occurrences before this step (this step's own append is guarded by t < T)
+        const int num_repeat = (t < T) ? repeat : repeat - 1;
+        reward = reward * pow(cfg.r_decay, (double)num_repeat);
+    } else {
+        reward = tab.mat[(size_t)u * I + action];
+    }
+    if (t < T) hist[t] = (int32_t)action;
+    const double cum = st.cum_reward[e] + reward;
+    st.cum_reward[e] = cum;
+    st.turn[e] = t + 1;
+    st.done[e] = (uint8_t)done;
+
+    obs_out[j] = action;
+    rew_out[j] = reward;
+    done_out[j] = (uint8_t)done;
+    ctr_out[j] = cfg.simulated ? cum / (double)(t + 1) / 10.0 : cum;
+    if (expo_out) expo_out[j] = exposure_gamma;
+}
+
+__global__ __launch_bounds__(256) void env_reset_kernel(cirs_env_cfg cfg, cirs_env_state st,
+                                                        const int32_t* __restrict__ users,
+                                                        const int32_t* __restrict__ env_ids, int n,
+                                                        int64_t* __restrict__ obs_out) {
+    const int T = cfg.max_turn;
+    const long total = (long)n * T;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i / T), k = (int)(i % T);
+        const int e = env_ids ? env_ids[j] : j;
+        st.hist_action[(size_t)e * T + k] = 0;
+        if (k == 0) {
+            st.user[e] = users[j];
+            st.turn[e] = 0;
+            st.done[e] = 0;
+            st.cum_reward[e] = 0.0;
+            if (obs_out) obs_out[j] = users[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dist_jaccard_kernel(const uint32_t* __restrict__ item_cats, int n_items,
+                                                           double* __restrict__ dist_out) {
+    const long total = (long)n_items * n_items;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx / n_items), j = (int)(idx % n_items);
+        dist_out[idx] = jaccard_dist(item_cats[i], item_cats[j]);
+    }
+}
+
+static int validate_cfg(const cirs_env_cfg* cfg) {
+    CIRS_REQUIRE(cfg != nullptr, "cfg is null");
+    CIRS_REQUIRE(cfg->n_users > 0 && cfg->n_items > 0, "n_users/n_items must be positive");
+    CIRS_REQUIRE(cfg->max_turn > 0 && cfg->max_turn <= 16383, "max_turn out of range (1..16383)");
+    CIRS_REQUIRE(cfg->num_leave_compute >= 0, "num_leave_compute must be >= 0");
+    CIRS_REQUIRE(cfg->version == 1 || cfg->version == 2, "version must be 1 (v1) or 2 (v2)");
+    CIRS_REQUIRE(cfg->dist_mode == 0 || cfg->dist_mode == 1, "dist_mode must be 0 (table) or 1 (jaccard)");
+    return CIRS_OK;
+}
+
+}  // namespace cirs
+
+extern "C" int cirs_env_reset(const cirs_env_cfg* cfg, cirs_env_state* st, const int32_t* users,
+                              const int32_t* env_ids, int32_t n, int64_t* obs_out, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_cfg(cfg)) return rc;
+    CIRS_REQUIRE(st && st->user && st->turn && st->done && st->hist_action && st->cum_reward, "env state has null field");
+    CIRS_REQUIRE(users != nullptr, "users is null");
+    if (n <= 0) return CIRS_OK;
+    const long total = (long)n * cfg->max_turn;
+    const int grid = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
+    hipLaunchKernelGGL(env_reset_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *cfg, *st, users, env_ids, n,
+                       obs_out);
+    CIRS_CHECK_LAUNCH("env_reset_kernel");
+    return CIRS_OK;
+}
+
+extern "C" int cirs_env_step(const cirs_env_cfg* cfg, const cirs_env_tables* tab, cirs_env_state* st,
+                             const int64_t* actions, const int32_t* env_ids, int32_t n, int64_t* obs_out,
+                             double* rew_out, uint8_t* done_out, double* ctr_out, double* expo_out, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_cfg(cfg)) return rc;
+    CIRS_REQUIRE(tab && tab->item_cats, "tables: item_cats is null");
+    CIRS_REQUIRE(tab->mat || cfg->simulated, "tables: mat is null");
+    CIRS_REQUIRE(!cfg->simulated || tab->normed_mat, "tables: normed_mat is null (simulated env)");
+    CIRS_REQUIRE(cfg->dist_mode == 1 || tab->dist || !(cfg->simulated && cfg->use_exposure),
+                 "tables: dist is null in table mode");
+    CIRS_REQUIRE(!(cfg->simulated && cfg->has_ab) || (tab->alpha_env && tab->beta_env), "tables: alpha/beta null");
+    CIRS_REQUIRE(st && st->user && st->turn && st->done && st->hist_action && st->cum_reward, "env state has null field");
+    CIRS_REQUIRE(actions && obs_out && rew_out && done_out && ctr_out, "null action/output pointer");
+    if (n <= 0) return CIRS_OK;
+    hipLaunchKernelGGL(env_step_kernel, dim3(cdiv(n, kEnvsPerBlock)), dim3(256), 0, (hipStream_t)stream, *cfg, *tab,
+                       *st, actions, env_ids, n, obs_out, rew_out, done_out, ctr_out, expo_out);
+    CIRS_CHECK_LAUNCH("env_step_kernel");
+    return CIRS_OK;
+}
+
+extern "C" int cirs_dist_jaccard(const uint32_t* item_cats, int32_t n_items, double* dist_out, void* stream) {
+    using namespace cirs;
+    CIRS_REQUIRE(item_cats && dist_out && n_items > 0, "bad arguments");
+    const long total = (long)n_items * n_items;
+    const int grid = cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192;
+    hipLaunchKernelGGL(dist_jaccard_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, item_cats, n_items, dist_out);
+    CIRS_CHECK_LAUNCH("dist_jaccard_kernel");
+    return CIRS_OK;
+}
