@@ -106,4 +106,4 @@ def test_env_vs_oracle_at_baseline_sizes(U, I, B, T, N, thr):
     env = GpuEnv(dt, B, **_kw(p))
     got = envcase.run_teacher_forced(env, users, acts, T)
     envcase.compare_env_run(got, want, rtol=1e-12, what=f"{U}x{I}")
-    assert want["length"].min() < T <= want["length"].max() + 0  # both early exits and full-length episodes
+    assert want["length"].min() < want["length"].max()  # exits fire at different turns
