@@ -35,6 +35,38 @@ class EnvState(C.Structure):
                 ("hist_action", C.c_void_p), ("cum_reward", C.c_void_p)]
 
 
+MAX_TRACKER_LAYERS = 4
+
+
+class TrackerCfg(C.Structure):
+    _fields_ = [("n_users", C.c_int32), ("n_items", C.c_int32), ("dim_model", C.c_int32), ("dim_state", C.c_int32),
+                ("nhead", C.c_int32), ("d_hid", C.c_int32), ("nlayers", C.c_int32), ("max_len", C.c_int32),
+                ("n_env", C.c_int32)]
+
+
+class TrackerLayer(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b",
+                                          "lin2_w", "lin2_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b")]
+
+
+class TrackerWeights(C.Structure):
+    _fields_ = [("emb_user", C.c_void_p), ("emb_item", C.c_void_p), ("ffn_user_w", C.c_void_p),
+                ("ffn_user_b", C.c_void_p), ("gate_w", C.c_void_p), ("gate_b", C.c_void_p), ("pe", C.c_void_p),
+                ("layer", TrackerLayer * MAX_TRACKER_LAYERS), ("dec_w", C.c_void_p), ("dec_b", C.c_void_p)]
+
+
+class TrackerState(C.Structure):
+    _fields_ = [("x_hist", C.c_void_p), ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("len", C.c_void_p)]
+
+
+class PolicyCfg(C.Structure):
+    _fields_ = [("n_items", C.c_int32), ("dim_state", C.c_int32), ("hidden", C.c_int32)]
+
+
+class PolicyWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc")]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/cirs_hip.h declares (tests check this).
 _P = C.c_void_p
 SIGNATURES = {
@@ -44,6 +76,13 @@ SIGNATURES = {
     "cirs_env_step": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState), _P, _P, C.c_int32,
                                 _P, _P, _P, _P, _P, _P]),
     "cirs_dist_jaccard": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "cirs_tracker_init": (C.c_int, [C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState), _P, _P,
+                                    C.c_int32, _P, C.c_int64, _P]),
+    "cirs_tracker_step": (C.c_int, [C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState), _P, _P,
+                                    _P, _P, C.c_int32, _P, C.c_int64, _P]),
+    "cirs_policy_workspace_bytes": (C.c_int64, [C.POINTER(PolicyCfg), C.c_int32]),
+    "cirs_actor_sample": (C.c_int, [C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), _P, C.c_int64, C.c_int32, _P,
+                                    C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
 }
 
 _lib = None

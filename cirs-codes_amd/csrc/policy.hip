@@ -1,0 +1,333 @@
+// policy.hip -- shared trunk (20->64->64), critic head and the full-catalogue actor head with a fused sampler.
+//
+// Rollout-side policy forward for gfx950 (reference: tianshou/utils/net/{common,discrete}.py, core/policy/ppo.py:111-163).
+//
+//   trunk_kernel       one wavefront per env row: h1 = relu(W1 s + b1), h2 = relu(W2 h1 + b2), value = wc.h2 + bc.
+//                      Sequential-k fmaf chains (the order the oracle restates), lane o owns output feature o.
+//   actor_head_kernel  logits tile = H2[32 envs x 64] * Wa^T[64 x 32 items] on the fp32 matrix cores
+//                      (v_mfma_f32_32x32x2_f32: exact f32 fma chain, D = fma(a_k1,b_k1, fma(a_k0,b_k0,C))), accumulator
+//                      initialised with the bias.  Operand k-relabelling: MFMA step kk pairs k0 = kk with
+//                      k1 = 32+kk so every lane streams 32 CONTIGUOUS floats (one 128-B line) of its row of Wa --
+//                      no LDS staging, no strided reads.  The epilogue never writes logits: per (env,item) it adds
+//                      Gumbel noise (Philox, or harness-supplied), keeps a lane-local running arg-max and an
+//                      online log-sum-exp, and reduces across the 32 lanes that share an env row at the end of the
+//                      item chunk.  Per-chunk partials {score, idx, z, m, s} go to the caller's workspace.
+//   actor_merge_kernel merges partials across chunks: action id (ties -> lowest id), logp with Categorical's clamp.
+//
+// Roofline: 2*64*I flop per env row (1.37 MFLOP at I = 10728) against 4*64*I bytes of Wa re-read per 32-env tile
+// from L2/MALL (2.7 MB, cache resident) -> MFMA-bound at fp32 (157 TF peak), HBM traffic ~ Wa once per launch.
+#include "common.h"
+#include "rng.h"
+
+namespace cirs {
+
+constexpr int kH = 64;            // hidden width (checked at the ABI)
+constexpr int kTileM = 32;        // env rows per MFMA tile
+constexpr int kTileN = 32;        // items per MFMA tile
+constexpr int kTilesPerChunk = 4; // item tiles handled by one wave before the cross-lane reduction
+constexpr int kChunkItems = kTileN * kTilesPerChunk;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ActorPartialView {  // SoA in the workspace, each array [n_chunks][n_pad]
+    float* score;
+    int32_t* idx;
+    float* m;
+    float* s;
+};
+
+__host__ __device__ inline int n_chunks_of(int n_items) { return (n_items + kChunkItems - 1) / kChunkItems; }
+__host__ __device__ inline int n_pad_of(int n) { return ((n + kTileM - 1) / kTileM) * kTileM; }
+
+__host__ inline size_t ws_h2_floats(int n) { return (size_t)n_pad_of(n) * kH; }
+__host__ inline size_t ws_partial_elems(int n, int n_items) { return (size_t)n_chunks_of(n_items) * n_pad_of(n); }
+
+__host__ __device__ inline ActorPartialView partial_view(void* ws, int n, int n_items) {
+    float* base = (float*)ws + (size_t)n_pad_of(n) * kH;
+    const size_t e = (size_t)n_chunks_of(n_items) * n_pad_of(n);
+    ActorPartialView v;
+    v.score = base;
+    v.idx = (int32_t*)(base + e);
+    v.m = base + 2 * e;
+    v.s = base + 3 * e;
+    return v;
+}
+
+// ---- trunk: one wave per row ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, cirs_policy_weights w,
+                                                    const float* __restrict__ state, long state_stride, int n,
+                                                    const uint8_t* __restrict__ skip, float* __restrict__ h2_out,
+                                                    float* __restrict__ value_out) {
+    __shared__ float lds[4][2][kH];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wv;
+    if (j >= n) return;
+    float* xs = lds[wv][0];
+    float* hs = lds[wv][1];
+    const int S = cfg.dim_state;
+    if (skip && skip[j]) {
+        h2_out[(size_t)j * kH + lane] = 0.f;
+        if (lane == 0 && value_out) value_out[j] = 0.f;
+        return;
+    }
+    if (lane < S) xs[lane] = state[(size_t)j * state_stride + lane];
+    __builtin_amdgcn_wave_barrier();
+    // layer 1: lane o, chain over k = 0..S-1 starting from the bias
+    float acc = w.b1[lane];
+    const float* w1r = w.w1 + (size_t)lane * S;
+    for (int k = 0; k < S; ++k) acc = __builtin_fmaf(w1r[k], xs[k], acc);
+    hs[lane] = fmaxf(acc, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    // layer 2
+    acc = w.b2[lane];
+    const float4* w2r = reinterpret_cast<const float4*>(w.w2 + (size_t)lane * kH);
+#pragma unroll
+    for (int k4 = 0; k4 < kH / 4; ++k4) {
+        const float4 wv4 = w2r[k4];
+        acc = __builtin_fmaf(wv4.x, hs[4 * k4 + 0], acc);
+        acc = __builtin_fmaf(wv4.y, hs[4 * k4 + 1], acc);
+        acc = __builtin_fmaf(wv4.z, hs[4 * k4 + 2], acc);
+        acc = __builtin_fmaf(wv4.w, hs[4 * k4 + 3], acc);
+    }
+    const float h2 = fmaxf(acc, 0.f);
+    h2_out[(size_t)j * kH + lane] = h2;
+    __builtin_amdgcn_wave_barrier();
+    xs[lane] = h2;  // S <= 64
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && value_out) {  // critic: sequential chain (bit-reproducible), 64 fma
+        float v = w.bc[0];
+        for (int k = 0; k < kH; ++k) v = __builtin_fmaf(w.wc[k], xs[k], v);
+        value_out[j] = v;
+    }
+}
+
+// ---- actor head ------------------------------------------------------------------------------------------------
+// grid = (n_chunks, ceil(n_pad/32/4)); block = 4 waves, wave wv owns env tile blockIdx.y*4+wv; all four waves walk
+// the same item chunk so the rows of Wa they stream are shared through L1/L2.
+// kIdentity: env id == row index (the device-resident rollout never compacts envs), which lets one Philox block
+// serve the 4 consecutive env rows a lane holds per accumulator group.
+template <bool kIdentity>
+__global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa,
+                                                            const float* __restrict__ ba,
+                                                            const float* __restrict__ h2, int n,
+                                                            const float* __restrict__ gumbel, uint64_t seed,
+                                                            uint32_t rng_step, const int32_t* __restrict__ env_ids,
+                                                            const uint32_t* __restrict__ visited,
+                                                            const uint8_t* __restrict__ skip, ActorPartialView pv,
+                                                            int n_pad) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int env_tile = blockIdx.y * 4 + wv;
+    const int row0 = env_tile * kTileM;
+    if (row0 >= n_pad) return;
+    const int I = cfg.n_items;
+    const int chunk = blockIdx.x;
+    const int vis_words = (I + 31) / 32;
+
+    // A operand: this lane's env row, k = hi*32 + kk  (32 contiguous floats)
+    float a[32];
+    {
+        const int r = row0 + lo;
+        if (r < n) {
+            const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)r * kH + hi * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = src[q];
+                a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) a[q] = 0.f;
+        }
+    }
+    // rows this lane sees in the C/D layout: row(r) = (r&3) + 8*(r>>2) + 4*hi ; bit r of `active` = row is live
+    uint32_t active = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int jr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (jr < n && !(skip && skip[jr])) active |= 1u << r;
+    }
+    float best_score[16], run_m[16], run_s[16];
+    int best_idx[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        best_score[r] = -INFINITY; best_idx[r] = 0x7FFFFFFF; run_m[r] = -INFINITY; run_s[r] = 0.f;
+    }
+
+    for (int it = 0; it < kTilesPerChunk; ++it) {
+        const int item = chunk * kChunkItems + it * kTileN + lo;
+        const bool item_ok = item < I;
+        float b[32];
+        if (item_ok) {
+            const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item * kH + hi * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = src[q];
+                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) b[q] = 0.f;
+        }
+        const float bias = item_ok ? ba[item] : 0.f;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+
+        if (item_ok) {
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int jr0 = row0 + 8 * grp + 4 * hi;  // 4 consecutive rows jr0..jr0+3 (jr0 % 4 == 0)
+                float g4[4];
+                if (!gumbel && kIdentity) {
+                    const u32x4 rr = philox4x32_10((uint32_t)item, (uint32_t)jr0 >> 2, rng_step, CIRS_RNG_STREAM_ACTOR,
+                                                   (uint32_t)seed, (uint32_t)(seed >> 32));
+                    g4[0] = gumbel_from_bits(rr.x); g4[1] = gumbel_from_bits(rr.y);
+                    g4[2] = gumbel_from_bits(rr.z); g4[3] = gumbel_from_bits(rr.w);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = grp * 4 + q;
+                    if (!((active >> r) & 1u)) continue;
+                    const int jr = jr0 + q;
+                    const int e = kIdentity ? jr : env_ids[jr];
+                    if (visited && ((visited[(size_t)e * vis_words + (item >> 5)] >> (item & 31)) & 1u)) continue;
+                    const float z = acc[r];
+                    float g;
+                    if (gumbel) g = gumbel[(size_t)jr * I + item];
+                    else if (kIdentity) g = g4[q];
+                    else g = actor_gumbel(seed, rng_step, (uint32_t)e, (uint32_t)item);
+                    const float sc = z + g;
+                    if (sc > best_score[r]) {  // items ascend within a lane: strict > keeps the lowest id on ties
+                        best_score[r] = sc; best_idx[r] = item;
+                    }
+                    const float mn = fmaxf(run_m[r], z);
+                    run_s[r] = run_s[r] * __expf(run_m[r] - mn) + __expf(z - mn);
+                    run_m[r] = mn;
+                }
+            }
+        }
+    }
+    // reduce across the 32 lanes (same hi) that hold the 32 items of each env row
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float bs = best_score[r], m = run_m[r], s = run_s[r];
+        int bi = best_idx[r];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off, CIRS_WAVE);
+            const int oi = __shfl_xor(bi, off, CIRS_WAVE);
+            if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+            const float om = __shfl_xor(m, off, CIRS_WAVE), osum = __shfl_xor(s, off, CIRS_WAVE);
+            const float mn = fmaxf(m, om);
+            if (mn > -INFINITY) {
+                s = s * __expf(m - mn) + osum * __expf(om - mn);
+                m = mn;
+            }
+        }
+        if (lo == 0) {
+            const int jr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const size_t o = (size_t)chunk * n_pad + jr;
+            pv.score[o] = bs; pv.idx[o] = bi; pv.m[o] = m; pv.s[o] = s;
+        }
+    }
+}
+
+// merge partials across chunks; recompute the chosen item's logit with the SAME k-order as the MFMA chain
+// (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with the sampled distribution.
+__global__ __launch_bounds__(256) void actor_merge_kernel(int n, int n_pad, int n_chunks, ActorPartialView pv,
+                                                          const float* __restrict__ wa, const float* __restrict__ ba,
+                                                          const float* __restrict__ h2,
+                                                          const uint8_t* __restrict__ skip,
+                                                          int64_t* __restrict__ act_out, float* __restrict__ logp_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (skip && skip[j]) {
+        act_out[j] = -1;
+        if (logp_out) logp_out[j] = 0.f;
+        return;
+    }
+    float bs = -INFINITY, m = -INFINITY, s = 0.f;
+    int bi = 0x7FFFFFFF;
+    for (int c = 0; c < n_chunks; ++c) {  // ascending chunks == ascending item ids: strict > keeps the lowest id
+        const size_t o = (size_t)c * n_pad + j;
+        const float os = pv.score[o];
+        if (os > bs) { bs = os; bi = pv.idx[o]; }
+        const float om = pv.m[o], osum = pv.s[o];
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            s = s * __expf(m - mn) + osum * __expf(om - mn);
+            m = mn;
+        }
+    }
+    act_out[j] = bi == 0x7FFFFFFF ? -1 : (int64_t)bi;
+    if (logp_out) {
+        float lp = 0.f;
+        if (bi != 0x7FFFFFFF) {
+            const float* wr = wa + (size_t)bi * kH;
+            const float* hr = h2 + (size_t)j * kH;
+            float z = ba[bi];
+            for (int kk = 0; kk < 32; ++kk) {
+                z = __builtin_fmaf(hr[kk], wr[kk], z);
+                z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
+            }
+            const float lse = m + __logf(s);
+            float p = __expf(z - lse);  // softmax prob of the chosen item (over unmasked items)
+            const float eps = 1.1920928955078125e-7f;
+            p = fminf(fmaxf(p, eps), 1.0f - eps);  // torch probs_to_logits clamp
+            lp = __logf(p);
+        }
+        logp_out[j] = lp;
+    }
+}
+
+static int validate_policy(const cirs_policy_cfg* cfg, const cirs_policy_weights* w) {
+    CIRS_REQUIRE(cfg && w, "policy cfg/weights null");
+    CIRS_REQUIRE(cfg->n_items > 0, "n_items must be positive");
+    if (cfg->hidden != kH) return fail(CIRS_E_UNSUPPORTED, "this build supports hidden == 64 only");
+    CIRS_REQUIRE(cfg->dim_state > 0 && cfg->dim_state <= 64, "dim_state must be in 1..64");
+    CIRS_REQUIRE(w->w1 && w->b1 && w->w2 && w->b2 && w->wa && w->ba && w->wc && w->bc, "policy weight pointer null");
+    return CIRS_OK;
+}
+
+}  // namespace cirs
+
+extern "C" int64_t cirs_policy_workspace_bytes(const cirs_policy_cfg* cfg, int32_t n) {
+    using namespace cirs;
+    if (!cfg || n <= 0) return 0;
+    return (int64_t)(ws_h2_floats(n) + 4 * ws_partial_elems(n, cfg->n_items)) * 4;
+}
+
+extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state,
+                                 int64_t state_stride, int32_t n, const float* gumbel, uint64_t seed,
+                                 uint32_t rng_step, const int32_t* env_ids, const uint32_t* visited,
+                                 const uint8_t* skip, int64_t* act_out, float* logp_out, float* value_out,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_policy(cfg, w)) return rc;
+    CIRS_REQUIRE(state && act_out && workspace, "null state/act/workspace");
+    CIRS_REQUIRE(state_stride >= cfg->dim_state, "state_stride < dim_state");
+    if (n <= 0) return CIRS_OK;
+    CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(cfg, n), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* h2 = (float*)workspace;
+    const int n_pad = n_pad_of(n), n_chunks = n_chunks_of(cfg->n_items);
+    ActorPartialView pv = partial_view(workspace, n, cfg->n_items);
+    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, *cfg, *w, state, (long)state_stride, n, skip, h2,
+                       value_out);
+    CIRS_CHECK_LAUNCH("trunk_kernel");
+    const dim3 grid(n_chunks, cdiv(n_pad / kTileM, 4));
+    if (env_ids)
+        hipLaunchKernelGGL(actor_head_kernel<false>, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
+                           rng_step, env_ids, visited, skip, pv, n_pad);
+    else
+        hipLaunchKernelGGL(actor_head_kernel<true>, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
+                           rng_step, env_ids, visited, skip, pv, n_pad);
+    CIRS_CHECK_LAUNCH("actor_head_kernel");
+    hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, n_pad, n_chunks, pv, w->wa, w->ba,
+                       h2, skip, act_out, logp_out);
+    CIRS_CHECK_LAUNCH("actor_merge_kernel");
+    return CIRS_OK;
+}

@@ -1,0 +1,82 @@
+// rng.h -- counter-based sampler noise (device).  Philox4x32-10 (Salmon et al., SC'11) + a branch-free,
+// fmaf-only natural log so that the Gumbel noise is BIT-REPRODUCIBLE on any IEEE-754 machine: the CPU oracle
+// restates the same formulas and must produce identical bits (tests/test_gpu_policy.py).
+//
+// Why Gumbel-max: torch.multinomial(probs, 1) draws q_i ~ Exp(1) and returns argmax_i probs_i / q_i
+// (the "exponential race").  argmax_i (logit_i - log q_i) is the same draw expressed on logits, so the sampler
+// needs no normalised probabilities and fuses into the head GEMM epilogue (reference: core/policy/ppo.py:148-155).
+#pragma once
+#include <stdint.h>
+
+namespace cirs {
+
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                        uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0;
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+// natural log of a positive normal float; Cephes-style minimax polynomial evaluated with explicit fmaf in a fixed
+// order (relative error ~1e-7).  No table, no division, no library call -> identical bits on CPU and GPU.
+__host__ __device__ __forceinline__ float det_logf(float x) {
+    uint32_t bits = __builtin_bit_cast(uint32_t, x);
+    int e = (int)(bits >> 23) - 127;
+    float m = __builtin_bit_cast(float, (bits & 0x007FFFFFu) | 0x3F800000u);  // [1,2)
+    if (m > 1.41421356237f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, f, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, f, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, f, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, f, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, f, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, f, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, f, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    const float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = f + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+// uniform in (0,1) with 23 random bits, exactly representable: (k + 0.5) * 2^-23
+__host__ __device__ __forceinline__ float u01_from_bits(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-7f; }
+
+__host__ __device__ __forceinline__ float gumbel_from_bits(uint32_t x) {
+    const float u = u01_from_bits(x);
+    return -det_logf(-det_logf(u));
+}
+
+#define CIRS_RNG_STREAM_ACTOR 0x43495253u /* 'CIRS' */
+
+// noise for (env e, item i) at rng_step: Philox counter (i, e>>2, rng_step, stream), key = seed; lane e&3 of the block
+__host__ __device__ __forceinline__ float actor_gumbel(uint64_t seed, uint32_t rng_step, uint32_t env, uint32_t item) {
+    const u32x4 r = philox4x32_10(item, env >> 2, rng_step, CIRS_RNG_STREAM_ACTOR, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t sel = env & 3u;
+    const uint32_t x = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
+    return gumbel_from_bits(x);
+}
+
+}  // namespace cirs

@@ -1,0 +1,272 @@
+// tracker.hip -- incremental StateTrackerTransformer for gfx950 (reference: core/state_tracker.py:170-250).
+//
+// The reference recomputes a 2-layer causal TransformerEncoder over the whole episode prefix at every step and keeps
+// only the last position.  With a causal mask and dropout off that equals a decode step with per-layer K/V caches,
+// which is what this kernel does: per env and step it
+//   1. builds the new input slot      x = ffn_user(Emb_user[u])                     (state_tracker.py:205-215)
+//                                  or x = sigmoid(fnn_gate([r, a])) * a, a = Emb_item[item]   (:225-242)
+//   2. h = x*sqrt(D) + pe[pos]                                                      (:180-181, PositionalEncoding)
+//   3. for each post-norm encoder layer: q,k,v = in_proj(h); append k,v to the cache; causal attention of q over
+//      cache[0..pos]; out_proj; LayerNorm; FF(relu); LayerNorm                       (torch.nn.TransformerEncoderLayer)
+//   4. s = decoder(h)                                                                (:183-186)
+// One 64-lane wavefront per env (4 envs per workgroup).  Lane o owns output feature o of every mat-vec; the input
+// vector is broadcast from a per-wave LDS scratch; attention lanes stride over cached positions.  fp32 throughout.
+//
+// Bytes per env-step: 128 B embedding row + 2 layers x (pos x 256 B K/V reads + 256 B K/V writes) + 128 B x_hist
+// + 80 B state; weights (~118 KB) are shared by all envs and stay in L2.  ~60 kFLOP per env-step: latency-bound.
+#include "common.h"
+
+namespace cirs {
+
+constexpr int kD = 32;    // dim_model
+constexpr int kHid = 128; // d_hid
+
+template <int K>
+__device__ __forceinline__ float dot_row(const float* __restrict__ wrow, const float* xs, float acc) {
+    const float4* w4 = reinterpret_cast<const float4*>(wrow);
+#pragma unroll
+    for (int k4 = 0; k4 < K / 4; ++k4) {
+        const float4 w = w4[k4];
+        acc = __builtin_fmaf(w.x, xs[4 * k4 + 0], acc);
+        acc = __builtin_fmaf(w.y, xs[4 * k4 + 1], acc);
+        acc = __builtin_fmaf(w.z, xs[4 * k4 + 2], acc);
+        acc = __builtin_fmaf(w.w, xs[4 * k4 + 3], acc);
+    }
+    return acc;
+}
+
+// LayerNorm over the 32 values held by lanes 0..31 (lanes >= 32 pass 0 and get garbage they never use)
+__device__ __forceinline__ float layer_norm32(float v, int lane, const float* __restrict__ w, const float* __restrict__ b) {
+    const float vv = lane < kD ? v : 0.f;
+    const float mean = wave_sum_f32(vv) * (1.0f / kD);
+    const float dlt = lane < kD ? v - mean : 0.f;
+    const float var = wave_sum_f32(dlt * dlt) * (1.0f / kD);
+    const float inv = 1.0f / sqrtf(var + 1e-5f);
+    const int o = lane & (kD - 1);
+    return dlt * inv * w[o] + b[o];
+}
+
+template <int NHEAD>
+__global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w,
+                                                           cirs_tracker_state st, const int32_t* __restrict__ users,
+                                                           const int64_t* __restrict__ items,
+                                                           const double* __restrict__ rew,
+                                                           const int32_t* __restrict__ env_ids,
+                                                           const uint8_t* __restrict__ skip, int n,
+                                                           float* __restrict__ state_out, long state_stride,
+                                                           int lpad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HD = kD / NHEAD;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wv;
+    if (j >= n) return;
+    if (skip && skip[j]) return;
+    const int e = env_ids ? env_ids[j] : j;
+    const int B = cfg.n_env, L = cfg.max_len;
+    // per-wave scratch
+    float* base = smem + (size_t)wv * (6 * kD + kHid + NHEAD * lpad);
+    float* xs = base;            // [32] current vector (mat-vec input)
+    float* qs = base + kD;       // [32] scaled query
+    float* kcur = base + 2 * kD; // [32]
+    float* vcur = base + 3 * kD; // [32]
+    float* att = base + 4 * kD;  // [32]
+    float* tmp = base + 5 * kD;  // [32]
+    float* ffs = base + 6 * kD;  // [128]
+    float* ps = ffs + kHid;      // [NHEAD][lpad] attention probabilities
+    const int o32 = lane & (kD - 1);
+
+    const bool is_init = users != nullptr;
+    const int pos = is_init ? 0 : st.len[e];
+    if (pos >= L) return;  // history full: the caller never steps past max_turn (collector drops finished envs)
+
+    // ---- 1. new input slot --------------------------------------------------------------------------------
+    float x;
+    if (is_init) {
+        const int u = users[j];
+        if (lane < kD) xs[lane] = w.emb_user[(size_t)u * kD + lane];
+        __builtin_amdgcn_wave_barrier();
+        x = dot_row<kD>(w.ffn_user_w + (size_t)o32 * kD, xs, w.ffn_user_b[o32]);
+    } else {
+        const long it = items[j];
+        const float r = (float)rew[j];
+        float a = 0.f;
+        if (lane < kD) {
+            a = w.emb_item[(size_t)it * kD + lane];
+            xs[lane] = a;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* gw = w.gate_w + (size_t)o32 * (kD + 1);  // input order [r, a_0..a_31]
+        float acc = w.gate_b[o32];
+        acc = __builtin_fmaf(gw[0], r, acc);
+        for (int k = 0; k < kD; ++k) acc = __builtin_fmaf(gw[1 + k], xs[k], acc);
+        const float g = 1.0f / (1.0f + expf(-acc));
+        x = g * a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kD) st.x_hist[((size_t)e * L + pos) * kD + lane] = x;
+    // ---- 2. scale + positional encoding ---------------------------------------------------------------------
+    float h = x * 5.656854249492381f + w.pe[(size_t)pos * kD + o32];  // sqrt(32)
+
+    // ---- 3. encoder layers ----------------------------------------------------------------------------------
+    for (int l = 0; l < cfg.nlayers; ++l) {
+        const cirs_tracker_layer& ly = w.layer[l];
+        if (lane < kD) xs[lane] = h;
+        __builtin_amdgcn_wave_barrier();
+        // in_proj: 96 outputs; lanes 0..63 -> rows 0..63 (q,k), lanes 0..31 -> rows 64..95 (v)
+        {
+            const float r0 = dot_row<kD>(ly.in_proj_w + (size_t)lane * kD, xs, ly.in_proj_b[lane]);
+            if (lane < kD) qs[lane] = r0 * (1.0f / sqrtf((float)HD));  // torch scales q before QK^T
+            else kcur[lane - kD] = r0;
+            if (lane < kD) vcur[lane] = dot_row<kD>(ly.in_proj_w + (size_t)(2 * kD + lane) * kD, xs, ly.in_proj_b[2 * kD + lane]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float* kc = st.kcache + (((size_t)l * B + e) * L) * kD;
+        float* vc = st.vcache + (((size_t)l * B + e) * L) * kD;
+        if (lane < kD) kc[(size_t)pos * kD + lane] = kcur[lane];
+        else vc[(size_t)pos * kD + (lane - kD)] = vcur[lane - kD];
+        // scores: lanes stride over positions 0..pos
+        float mx[NHEAD];
+#pragma unroll
+        for (int hh = 0; hh < NHEAD; ++hh) mx[hh] = -INFINITY;
+        for (int jp = lane; jp <= pos; jp += CIRS_WAVE) {
+            float kv[kD];
+            if (jp == pos) {
+#pragma unroll
+                for (int d = 0; d < kD; ++d) kv[d] = kcur[d];
+            } else {
+                const float4* k4 = reinterpret_cast<const float4*>(kc + (size_t)jp * kD);
+#pragma unroll
+                for (int q4 = 0; q4 < kD / 4; ++q4) {
+                    const float4 t4 = k4[q4];
+                    kv[4 * q4] = t4.x; kv[4 * q4 + 1] = t4.y; kv[4 * q4 + 2] = t4.z; kv[4 * q4 + 3] = t4.w;
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < NHEAD; ++hh) {
+                float sc = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) sc = __builtin_fmaf(qs[hh * HD + d], kv[hh * HD + d], sc);
+                ps[hh * lpad + jp] = sc;
+                mx[hh] = fmaxf(mx[hh], sc);
+            }
+        }
+        float sm[NHEAD];
+#pragma unroll
+        for (int hh = 0; hh < NHEAD; ++hh) {
+            mx[hh] = wave_max_f32(mx[hh]);
+            sm[hh] = 0.f;
+        }
+        for (int jp = lane; jp <= pos; jp += CIRS_WAVE) {
+#pragma unroll
+            for (int hh = 0; hh < NHEAD; ++hh) {
+                const float pexp = expf(ps[hh * lpad + jp] - mx[hh]);
+                ps[hh * lpad + jp] = pexp;
+                sm[hh] += pexp;
+            }
+        }
+#pragma unroll
+        for (int hh = 0; hh < NHEAD; ++hh) sm[hh] = 1.0f / wave_sum_f32(sm[hh]);
+        __builtin_amdgcn_wave_barrier();
+        // weighted sum of V: lane (half, d): positions jp = half, half+2, ...
+        {
+            const int half = lane >> 5, d = o32, hh = d / HD;
+            float acc = 0.f;
+            for (int jp = half; jp <= pos; jp += 2) {
+                const float vv = jp == pos ? vcur[d] : vc[(size_t)jp * kD + d];
+                acc = __builtin_fmaf(ps[hh * lpad + jp], vv, acc);
+            }
+            acc += __shfl_xor(acc, 32, CIRS_WAVE);
+            float norm = sm[0];
+#pragma unroll
+            for (int q = 1; q < NHEAD; ++q) norm = hh == q ? sm[q] : norm;
+            if (lane < kD) att[d] = acc * norm;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // out_proj + residual + LN1
+        const float sa = dot_row<kD>(ly.out_proj_w + (size_t)o32 * kD, att, ly.out_proj_b[o32]);
+        const float h1 = layer_norm32(h + sa, lane, ly.norm1_w, ly.norm1_b);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kD) tmp[lane] = h1;
+        __builtin_amdgcn_wave_barrier();
+        // FF: 128 hidden = 2 rows per lane
+        ffs[lane] = fmaxf(dot_row<kD>(ly.lin1_w + (size_t)lane * kD, tmp, ly.lin1_b[lane]), 0.f);
+        ffs[64 + lane] = fmaxf(dot_row<kD>(ly.lin1_w + (size_t)(64 + lane) * kD, tmp, ly.lin1_b[64 + lane]), 0.f);
+        __builtin_amdgcn_wave_barrier();
+        // lin2: 32 outputs x 128 inputs, split k in two halves across the half-waves
+        {
+            const int half = lane >> 5;
+            float acc = dot_row<64>(ly.lin2_w + (size_t)o32 * kHid + half * 64, ffs + half * 64, half == 0 ? ly.lin2_b[o32] : 0.f);
+            acc += __shfl_xor(acc, 32, CIRS_WAVE);
+            h = layer_norm32(h1 + acc, lane, ly.norm2_w, ly.norm2_b);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- 4. decoder ------------------------------------------------------------------------------------------
+    if (lane < kD) xs[lane] = h;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cfg.dim_state)
+        state_out[(size_t)j * state_stride + lane] = dot_row<kD>(w.dec_w + (size_t)lane * kD, xs, w.dec_b[lane]);
+    if (lane == 0) st.len[e] = pos + 1;
+}
+
+static int validate_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st) {
+    CIRS_REQUIRE(cfg && w && st, "tracker cfg/weights/state null");
+    if (cfg->dim_model != kD || cfg->d_hid != kHid) return fail(CIRS_E_UNSUPPORTED, "this build supports dim_model == 32 and d_hid == 128");
+    if (!(cfg->nhead == 1 || cfg->nhead == 2 || cfg->nhead == 4 || cfg->nhead == 8)) return fail(CIRS_E_UNSUPPORTED, "nhead must be 1, 2, 4 or 8");
+    CIRS_REQUIRE(cfg->nlayers >= 1 && cfg->nlayers <= CIRS_MAX_TRACKER_LAYERS, "nlayers out of range");
+    CIRS_REQUIRE(cfg->dim_state >= 1 && cfg->dim_state <= 32, "dim_state must be in 1..32");
+    CIRS_REQUIRE(cfg->max_len >= 1 && cfg->max_len <= 4096, "max_len out of range");
+    CIRS_REQUIRE(cfg->n_env >= 1, "n_env must be positive");
+    CIRS_REQUIRE(w->emb_user && w->emb_item && w->ffn_user_w && w->ffn_user_b && w->gate_w && w->gate_b && w->pe && w->dec_w && w->dec_b, "tracker weight pointer null");
+    for (int l = 0; l < cfg->nlayers; ++l) {
+        const cirs_tracker_layer& y = w->layer[l];
+        CIRS_REQUIRE(y.in_proj_w && y.in_proj_b && y.out_proj_w && y.out_proj_b && y.lin1_w && y.lin1_b && y.lin2_w && y.lin2_b && y.norm1_w && y.norm1_b && y.norm2_w && y.norm2_b, "tracker layer weight pointer null");
+    }
+    CIRS_REQUIRE(st->x_hist && st->kcache && st->vcache && st->len, "tracker state pointer null");
+    return CIRS_OK;
+}
+
+static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
+                          const int32_t* users, const int64_t* items, const double* rew, const int32_t* env_ids,
+                          const uint8_t* skip, int n, float* state_out, long state_stride, hipStream_t s) {
+    const int lpad = (cfg->max_len + 3) & ~3;
+    const size_t shmem = 4 * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad);
+    if (shmem > 160 * 1024) return fail(CIRS_E_UNSUPPORTED, "max_len too large for the LDS score buffer");
+    const dim3 grid(cdiv(n, 4)), block(256);
+#define CIRS_TRK(NH)                                                                                              \
+    hipLaunchKernelGGL(tracker_step_kernel<NH>, grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
+                       n, state_out, state_stride, lpad)
+    switch (cfg->nhead) {
+        case 1: CIRS_TRK(1); break;
+        case 2: CIRS_TRK(2); break;
+        case 4: CIRS_TRK(4); break;
+        default: CIRS_TRK(8); break;
+    }
+#undef CIRS_TRK
+    CIRS_CHECK_LAUNCH("tracker_step_kernel");
+    return CIRS_OK;
+}
+
+}  // namespace cirs
+
+extern "C" int cirs_tracker_init(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
+                                 const int32_t* users, const int32_t* env_ids, int32_t n, float* state_out,
+                                 int64_t state_stride, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_tracker(cfg, w, st)) return rc;
+    CIRS_REQUIRE(users && state_out, "users/state_out null");
+    CIRS_REQUIRE(state_stride >= cfg->dim_state, "state_stride < dim_state");
+    if (n <= 0) return CIRS_OK;
+    return launch_tracker(cfg, w, st, users, nullptr, nullptr, env_ids, nullptr, n, state_out, (long)state_stride, (hipStream_t)stream);
+}
+
+extern "C" int cirs_tracker_step(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
+                                 const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip,
+                                 int32_t n, float* state_out, int64_t state_stride, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_tracker(cfg, w, st)) return rc;
+    CIRS_REQUIRE(items && rew && state_out, "items/rew/state_out null");
+    CIRS_REQUIRE(state_stride >= cfg->dim_state, "state_stride < dim_state");
+    if (n <= 0) return CIRS_OK;
+    return launch_tracker(cfg, w, st, nullptr, items, rew, env_ids, skip, n, state_out, (long)state_stride, (hipStream_t)stream);
+}

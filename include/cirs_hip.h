@@ -93,6 +93,102 @@ int cirs_env_step(const cirs_env_cfg* cfg, const cirs_env_tables* tab, cirs_env_
  * get_similarity_mat restricted to the env items).  dist_out is [I,I] float64. */
 int cirs_dist_jaccard(const uint32_t* item_cats, int32_t n_items, double* dist_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * State tracker: incremental (KV-cached) StateTrackerTransformer
+ * replaces  core/state_tracker.py:89-115 (get_embedding), :170-186 (forward), :188-250 (build_state)
+ *           torch.nn.TransformerEncoder(2 x post-norm TransformerEncoderLayer, relu, eps 1e-5), eval mode
+ * The reference re-runs the causal transformer over the whole prefix every step (O(L^2) per step); because the
+ * mask is causal and only output[-1] is used, caching each layer's K/V per position is exact.
+ * Fixed dims of this build: dim_model == 32, d_hid == 128, dim_state <= 32, nhead in {1,2,4,8}, nlayers <= 4.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define CIRS_MAX_TRACKER_LAYERS 4
+
+typedef struct cirs_tracker_cfg {
+    int32_t n_users, n_items;
+    int32_t dim_model; /* D = 32 */
+    int32_t dim_state; /* S = 20 */
+    int32_t nhead;     /* 4 */
+    int32_t d_hid;     /* 128 */
+    int32_t nlayers;   /* 2 */
+    int32_t max_len;   /* MAX_TURN + 1 (state_tracker.py:144) */
+    int32_t n_env;     /* B: leading dimension of the state arrays */
+} cirs_tracker_cfg;
+
+typedef struct cirs_tracker_layer { /* names: transformer_encoder.layers.<l>.*  */
+    const float *in_proj_w, *in_proj_b;   /* [3D,D], [3D] */
+    const float *out_proj_w, *out_proj_b; /* [D,D], [D]   */
+    const float *lin1_w, *lin1_b;         /* [H,D], [H]   */
+    const float *lin2_w, *lin2_b;         /* [D,H], [D]   */
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b; /* [D] */
+} cirs_tracker_layer;
+
+typedef struct cirs_tracker_weights {
+    const float* emb_user;                 /* embedding_dict.feat_user.weight [U,D] */
+    const float* emb_item;                 /* embedding_dict.feat_item.weight [I,D] */
+    const float *ffn_user_w, *ffn_user_b;  /* [D,D], [D]   */
+    const float *gate_w, *gate_b;          /* fnn_gate [D,1+D] (input order [r, a], state_tracker.py:240), [D] */
+    const float* pe;                       /* pos_encoder.pe [max_len, D] */
+    cirs_tracker_layer layer[CIRS_MAX_TRACKER_LAYERS];
+    const float *dec_w, *dec_b;            /* decoder [S,D], [S] */
+} cirs_tracker_weights;
+
+typedef struct cirs_tracker_state {
+    float* x_hist;  /* [B, max_len, D]  self.data: slot 0 = user projection, slot k = gated action (state_tracker.py:198,215,242) */
+    float* kcache;  /* [nlayers, B, max_len, D] */
+    float* vcache;  /* [nlayers, B, max_len, D] */
+    int32_t* len;   /* [B] self.len_data */
+} cirs_tracker_state;
+
+/* build_state(obs=users): len=1, slot 0, s0 -> state_out[j*state_stride + 0..S) for j in [0,n). */
+int cirs_tracker_init(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
+                      const int32_t* users, const int32_t* env_ids, int32_t n, float* state_out,
+                      int64_t state_stride, void* stream);
+/* build_state(obs_next=items, rew): append one position, return s_t.  `rew` is the env's float64 reward (cast to
+ * float32 like FloatTensor(rew), state_tracker.py:97).  state_out row stride = state_stride floats.
+ * skip (nullable, [n]): rows with skip != 0 are left untouched (finished envs). */
+int cirs_tracker_step(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
+                      const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int32_t n,
+                      float* state_out, int64_t state_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Policy: shared trunk + actor head over the full catalogue + fused sampler + critic
+ * replaces  tianshou/utils/net/common.py:87-92,184-197 (MLP/Net), utils/net/discrete.py:56-67 (Actor), :113-114 (Critic)
+ *           core/policy/ppo.py:111-163 (PPOPolicy.forward: softmax, optional mask of recommended ids, Categorical.sample)
+ *           core/policy/utils.py:30-58 (removed_recommended_id_from_embedding)
+ * The B x I probability matrix is never written to HBM: the head GEMM (fp32 MFMA 32x32x2), the Gumbel-max
+ * sampler (== torch.multinomial's exponential race) and the log-sum-exp are fused; per-chunk partials are merged
+ * by a second tiny kernel.  Arithmetic order is fixed (see oracle) so action indices are bit-reproducible.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct cirs_policy_cfg {
+    int32_t n_items;   /* I */
+    int32_t dim_state; /* 20 */
+    int32_t hidden;    /* 64 (two hidden layers of this width) */
+} cirs_policy_cfg;
+
+typedef struct cirs_policy_weights {
+    const float *w1, *b1; /* actor.preprocess.model.model.0 [H,S],[H] */
+    const float *w2, *b2; /* actor.preprocess.model.model.2 [H,H],[H] */
+    const float *wa, *ba; /* actor.last.model.0 [I,H],[I] */
+    const float *wc, *bc; /* critic.last.model.0 [1,H],[1] */
+} cirs_policy_weights;
+
+/* bytes of caller-provided scratch for cirs_actor_sample / cirs_actor_logp with batch n */
+int64_t cirs_policy_workspace_bytes(const cirs_policy_cfg* cfg, int32_t n);
+
+/* For rows j in [0,n): h2 = trunk(state[j]); value = critic; act = argmax_i (logit_i + g_i) over unmasked items,
+ * logp = log(clamp(softmax(logits)[act], eps, 1-eps)) (Categorical(probs).log_prob).
+ *   state        [n, state_stride] f32
+ *   gumbel       nullable [n, I] f32 harness-supplied noise g = -log(q); NULL -> counter-based Philox4x32-10 keyed by
+ *                (seed, rng_step) with counter (item, env_id>>2, ...) so results do not depend on batch composition
+ *   env_ids      nullable [n] global env id of each row (RNG key + visited row); NULL -> j
+ *   visited      nullable [B, ceil(I/32)] u32 bitmap of already recommended ids (remove_recommended_ids)
+ *   skip         nullable [n]: rows with skip != 0 produce act = -1 and are not computed
+ *   act_out [n] i64, logp_out [n] f32 (nullable), value_out [n] f32 (nullable), h2_out [n,H] f32 (nullable) */
+int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state,
+                      int64_t state_stride, int32_t n, const float* gumbel, uint64_t seed, uint32_t rng_step,
+                      const int32_t* env_ids, const uint32_t* visited, const uint8_t* skip, int64_t* act_out,
+                      float* logp_out, float* value_out, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,7 +157,119 @@ def gen_env():
     print("env_step.npz: cases", len(cfgs), "mean episode lengths", np.round(cases, 1))
 
 
-FAMILIES = {"env": gen_env}
+# --------------------------------------------------------------------------------------------------
+# tracker family: StateTrackerTransformer.build_state, eval mode (dropout off)
+# --------------------------------------------------------------------------------------------------
+def make_reference_tracker(n_users, n_items, max_turn, seed, dim_model=32, dim_state=20, nhead=4, randomize=True):
+    from core.inputs import SparseFeatP
+    from core.state_tracker import StateTrackerTransformer
+    from deepctr_torch.inputs import DenseFeat
+    user_columns = [SparseFeatP("feat_user", n_users, embedding_dim=dim_model)]
+    action_columns = [SparseFeatP("feat_item", n_items, embedding_dim=dim_model)]
+    feedback_columns = [DenseFeat("feat_feedback", 1)]
+    st = StateTrackerTransformer(user_columns, action_columns, feedback_columns, dim_model=dim_model,
+                                 dim_state=dim_state, dim_max_batch=64, dataset="KuaishouEnv-v0",
+                                 has_user_embedding=False, has_action_embedding=False, has_feedback_embedding=True,
+                                 nhead=nhead, d_hid=128, nlayers=2, dropout=0.1, device="cpu", seed=seed,
+                                 MAX_TURN=max_turn)
+    if randomize:  # the stock init (N(0,1e-4) embeddings) makes the output almost input-independent; stress it
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for name, p in st.named_parameters():
+                if "norm" in name and name.endswith("weight"):
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                elif "embedding_dict" in name:
+                    p.copy_(0.5 * torch.randn(p.shape, generator=g))
+                elif p.dim() >= 2:
+                    p.copy_(torch.randn(p.shape, generator=g) * (1.5 / np.sqrt(p.shape[1])))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    return st
+
+
+def gen_tracker():
+    U, I, B, T = 48, 96, 8, 12
+    st = make_reference_tracker(U, I, T, seed=11)
+    st.eval()
+    rng = np.random.RandomState(5)
+    users = rng.randint(0, U, size=B)
+    acts = rng.randint(0, I, size=(B, T))
+    rews = rng.uniform(0, 1, size=(B, T))
+    # live-set schedule: envs 5..7 stop after turn 4, envs 2..4 after turn 8 (collector drops finished envs)
+    last_turn = np.array([T, T, 8, 8, 8, 4, 4, 4])
+    states = np.full((B, T + 1, 20), np.nan, dtype=np.float32)
+    with torch.no_grad():
+        st.build_state(dim_batch=B, reset=True)
+        s0 = st.build_state(obs=users.reshape(-1, 1), env_id=np.arange(B))["obs"]
+        states[:, 0] = s0.numpy()
+        for t in range(T):
+            live = np.where(last_turn > t)[0]
+            out = st.build_state(obs_next=acts[live, t].reshape(-1, 1), rew=rews[live, t], done=None, info=None,
+                                 policy=None, env_id=live)["obs_next"]
+            states[live, t + 1] = out.numpy()
+    sd = {"sd_" + k: v.detach().numpy() for k, v in st.state_dict().items()}
+    np.savez_compressed(os.path.join(GOLDEN, "tracker.npz"), users=users, acts=acts, rews=rews, last_turn=last_turn,
+                        states=states, dims=np.array([U, I, B, T, 32, 20, 4, 128, 2]), **sd)
+    print("tracker.npz: states", states.shape, "finite", np.isfinite(states).mean())
+
+
+# --------------------------------------------------------------------------------------------------
+# policy family: Net/Actor/Critic forward + Categorical sampling under harness-supplied noise
+# --------------------------------------------------------------------------------------------------
+def make_reference_policy(n_items, seed, dim_state=20, hidden=(64, 64), lr=1e-3, **ppo_kw):
+    from core.policy.ppo import PPOPolicy
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.discrete import Actor, Critic
+    import gym
+    torch.manual_seed(seed)
+    net = Net(dim_state, hidden_sizes=list(hidden), device="cpu")
+    actor = Actor(net, n_items, device="cpu")
+    critic = Critic(net, device="cpu")
+    for m in list(actor.modules()) + list(critic.modules()):  # CIRS-RL-kuaishou.py:250-254
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight)
+            torch.nn.init.zeros_(m.bias)
+    return net, actor, critic
+
+
+def gen_policy():
+    I, B = 96, 24
+    net, actor, critic = make_reference_policy(I, seed=3)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():  # non-zero biases + a sharper head so probabilities are far from uniform
+        for p in list(actor.parameters()) + list(critic.parameters()):
+            if p.dim() == 1:
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+        actor.last.model[0].weight.mul_(4.0)
+    s = torch.randn(B, 20, generator=g)
+    q = torch.empty(B, I).exponential_(1.0, generator=g)  # torch.multinomial's race noise
+    visited = np.stack([np.random.RandomState(100 + b).choice(I, size=7, replace=False) for b in range(B)])
+    with torch.no_grad():
+        probs, _ = actor(s)
+        value = critic(s).flatten()
+        act = torch.argmax(probs / q, dim=-1)  # == multinomial(probs, 1) with exponential noise q
+        dist = torch.distributions.Categorical(probs)
+        logp = dist.log_prob(act)
+        ent = dist.entropy()
+        # masked path (core/policy/utils.py:30-58 + ppo.py:141-159): drop visited ids, renormalise, sample, map back
+        from core.policy.utils import removed_recommended_id_from_embedding
+        pm, idxm = removed_recommended_id_from_embedding(probs, visited)
+        qm = q.masked_select(torch.ones_like(probs, dtype=torch.bool).scatter(1, torch.as_tensor(visited), 0)).reshape(B, -1)
+        act_m_local = torch.argmax(pm / qm, dim=-1)
+        act_m = idxm.gather(1, act_m_local.unsqueeze(-1)).squeeze(1)
+    sd = {}
+    for k, v in actor.state_dict().items():
+        sd["actor_" + k] = v.numpy()
+    for k, v in critic.state_dict().items():
+        sd["critic_" + k] = v.numpy()
+    top2 = torch.topk(torch.log(probs) - torch.log(q), 2, dim=-1).values
+    np.savez_compressed(os.path.join(GOLDEN, "policy.npz"), s=s.numpy(), q=q.numpy(), visited=visited,
+                        probs=probs.numpy(), value=value.numpy(), act=act.numpy(), logp=logp.numpy(),
+                        ent=ent.numpy(), act_masked=act_m.numpy(), margin=(top2[:, 0] - top2[:, 1]).numpy(), **sd)
+    print("policy.npz: min top-2 margin", float((top2[:, 0] - top2[:, 1]).min()), "keys", list(sd))
+
+
+FAMILIES = {"env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

@@ -39,5 +39,10 @@ def lib():
         h.oracle_dist_jaccard.argtypes = [_P, C.c_int32, _P]
         h.oracle_gae_return.restype = C.c_int
         h.oracle_gae_return.argtypes = [_P, _P, _P, _P, C.c_long, C.c_double, C.c_double, _P]
+        h.oracle_actor_gumbel.restype = C.c_float
+        h.oracle_actor_gumbel.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        h.oracle_actor_sample.restype = C.c_int
+        h.oracle_actor_sample.argtypes = [C.POINTER(abi.PolicyCfg), C.POINTER(abi.PolicyWeights), _P, C.c_int64,
+                                          C.c_int32, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P]
         _lib = h
     return _lib

@@ -1,0 +1,72 @@
+"""GPU: MFMA actor head + fused sampler vs the C oracle (bit-exact action ids) and the reference golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import policycase
+
+pytestmark = pytest.mark.gpu
+
+PNAME = dict(w1="actor.preprocess.model.model.0.weight", b1="actor.preprocess.model.model.0.bias",
+             w2="actor.preprocess.model.model.2.weight", b2="actor.preprocess.model.model.2.bias",
+             wa="actor.last.model.0.weight", ba="actor.last.model.0.bias",
+             wc="critic.last.model.0.weight", bc="critic.last.model.0.bias")
+
+
+def dev_policy(arrs):
+    from cirs_hip.policy import DevicePolicy
+    params = {PNAME[k]: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).cuda().contiguous() for k, v in arrs.items()}
+    return DevicePolicy(params, arrs["wa"].shape[0], dim_state=arrs["w1"].shape[1])
+
+
+def test_matches_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "policy.npz"))
+    arrs = policycase.weights_from_golden(z)
+    pol = dev_policy(arrs)
+    g = torch.as_tensor((-np.log(z["q"])).astype(np.float32)).cuda()
+    s = torch.as_tensor(z["s"]).cuda()
+    act, logp, value = pol.sample(s, gumbel=g)
+    assert np.array_equal(act.cpu().numpy(), z["act"])
+    np.testing.assert_allclose(logp.cpu().numpy(), z["logp"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), z["value"], rtol=1e-5, atol=1e-5)
+    bm = torch.as_tensor(policycase.visited_bitmap(z["visited"], len(z["s"]), arrs["wa"].shape[0]).view(np.int32)).cuda()
+    act_m, _, _ = pol.sample(s, gumbel=g, visited=bm)
+    assert np.array_equal(act_m.cpu().numpy(), z["act_masked"])
+
+
+@pytest.mark.parametrize("n,I", [(5, 33), (64, 3327), (1024, 10728), (77, 1000)])
+def test_bit_exact_vs_oracle_counter_rng(n, I):
+    """Same counter-based noise on both sides -> identical action ids at BASELINE sizes (C2: 64x3327, C3: 1024x10728)."""
+    rng = np.random.RandomState(n + I)
+    arrs = policycase.random_weights(rng, I, head_scale=2.0)
+    s = rng.normal(size=(n, 20)).astype(np.float32)
+    pol = dev_policy(arrs)
+    for step in (0, 7):
+        want_act, want_logp, want_val, _ = policycase.oracle_sample(arrs, s, seed=0xC0FFEE12345, rng_step=step)
+        act, logp, value = pol.sample(torch.as_tensor(s).cuda(), seed=0xC0FFEE12345, rng_step=step)
+        assert np.array_equal(act.cpu().numpy(), want_act), f"step {step}: {(act.cpu().numpy() != want_act).sum()} mismatches"
+        assert np.array_equal(value.cpu().numpy(), want_val)  # same fma chain -> same bits
+        np.testing.assert_allclose(logp.cpu().numpy(), want_logp, rtol=1e-4, atol=1e-4)
+
+
+def test_env_ids_skip_and_mask():
+    rng = np.random.RandomState(3)
+    n, I, B = 40, 500, 64
+    arrs = policycase.random_weights(rng, I)
+    s = rng.normal(size=(n, 20)).astype(np.float32)
+    env_ids = rng.choice(B, size=n, replace=False).astype(np.int32)
+    skip = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    vis_ids = [rng.choice(I, size=20, replace=False) for _ in range(B)]
+    bm = policycase.visited_bitmap(vis_ids, B, I)
+    want_act, want_logp, _, _ = policycase.oracle_sample(arrs, s, seed=9, rng_step=2, env_ids=env_ids, visited=bm, skip=skip)
+    pol = dev_policy(arrs)
+    act, logp, _ = pol.sample(torch.as_tensor(s).cuda(), seed=9, rng_step=2, env_ids=torch.as_tensor(env_ids).cuda(),
+                              visited=torch.as_tensor(bm.view(np.int32)).cuda(), skip=torch.as_tensor(skip).cuda())
+    act = act.cpu().numpy()
+    assert np.array_equal(act, want_act)
+    live = skip == 0
+    for j in np.where(live)[0]:
+        assert act[j] not in set(vis_ids[env_ids[j]])
+    np.testing.assert_allclose(logp.cpu().numpy()[live], want_logp[live], rtol=1e-4, atol=1e-4)
