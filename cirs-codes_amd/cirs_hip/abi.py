@@ -67,6 +67,10 @@ class PolicyWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc")]
 
 
+class Traj(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "act", "rew", "done", "logp", "value", "ctr")]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/cirs_hip.h declares (tests check this).
 _P = C.c_void_p
 SIGNATURES = {
@@ -83,6 +87,10 @@ SIGNATURES = {
     "cirs_policy_workspace_bytes": (C.c_int64, [C.POINTER(PolicyCfg), C.c_int32]),
     "cirs_actor_sample": (C.c_int, [C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), _P, C.c_int64, C.c_int32, _P,
                                     C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "cirs_rollout_steps": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState),
+                                     C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
+                                     C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, _P, C.c_int32, _P, C.c_int64, _P]),
 }
 
 _lib = None

@@ -1,0 +1,89 @@
+"""Device-resident Collector loop (csrc/rollout.hip): whole episodes are collected without a host round trip per step.
+
+Host-side counterpart of reference core/collector.py:147-367 for the case the reference scripts use
+(n_episode == env_num, finished envs are dropped).  The time-major trajectory tensors double as the
+replay buffer (VectorReplayBuffer order = env-major concatenation of the per-env episodes).
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import abi
+from .env import DeviceEnv
+from .policy import DevicePolicy
+from .tracker import DeviceTracker
+
+
+class Trajectory:
+    def __init__(self, n_env, max_turn, dim_state, device):
+        T, B, S = max_turn, n_env, dim_state
+        self.T, self.B, self.S = T, B, S
+        self.obs = torch.zeros((T + 1, B, S), dtype=torch.float32, device=device)
+        self.act = torch.full((T, B), -1, dtype=torch.int64, device=device)
+        self.rew = torch.zeros((T, B), dtype=torch.float64, device=device)
+        self.done = torch.zeros((T, B), dtype=torch.uint8, device=device)
+        self.logp = torch.zeros((T, B), dtype=torch.float32, device=device)
+        self.value = torch.zeros((T, B), dtype=torch.float32, device=device)
+        self.ctr = torch.zeros((T, B), dtype=torch.float64, device=device)
+        self.struct = abi.Traj(obs=self.obs.data_ptr(), act=self.act.data_ptr(), rew=self.rew.data_ptr(),
+                               done=self.done.data_ptr(), logp=self.logp.data_ptr(), value=self.value.data_ptr(),
+                               ctr=self.ctr.data_ptr())
+
+    def clear(self):
+        self.act.fill_(-1)
+        self.done.zero_()
+
+
+class DeviceRollout:
+    def __init__(self, env: DeviceEnv, tracker: DeviceTracker, policy: DevicePolicy, *, remove_recommended_ids=False,
+                 force_length=0):
+        assert env.n_env == tracker.cfg.n_env
+        self.env, self.tracker, self.policy = env, tracker, policy
+        self.device = env.device
+        self.traj = Trajectory(env.n_env, env.max_turn, tracker.dim_state, self.device)
+        self.remove_recommended_ids = remove_recommended_ids
+        self.force_length = int(force_length)
+        words = (policy.n_items + 31) // 32
+        self.visited = torch.zeros((env.n_env, words), dtype=torch.int32, device=self.device) if remove_recommended_ids else None
+        self._lib = abi.lib()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def reset(self, users: torch.Tensor):
+        """Collector.reset_env (collector.py:123-134): tracker reset, env.reset, preprocess_fn(obs=...)."""
+        self.traj.clear()
+        self.tracker.reset()
+        if self.visited is not None:
+            self.visited.zero_()
+        self.env.reset(users)
+        B, S = self.env.n_env, self.tracker.dim_state
+        self.tracker.init(users, out=self.traj.obs[0], out_stride=S)
+
+    def run_steps(self, t_begin, t_end, seed, rng_base):
+        ws = self.policy.workspace(self.env.n_env)
+        abi.check(self._lib.cirs_rollout_steps(
+            C.byref(self.env.cfg), C.byref(self.env._tab), C.byref(self.env._st), C.byref(self.tracker.cfg),
+            C.byref(self.tracker.w), C.byref(self.tracker.st), C.byref(self.policy.cfg), C.byref(self.policy.w),
+            C.byref(self.traj.struct), self.env.n_env, t_begin, t_end, seed, rng_base, abi.ptr(self.visited),
+            self.force_length, ws.data_ptr(), ws.numel(), self._stream()), "cirs_rollout_steps")
+
+    def collect(self, users: torch.Tensor, *, seed=0, rng_base=0, sync_every: Optional[int] = None):
+        """One `collect(n_episode = n_env)`: all envs run to the end of their episode.  Returns (n_steps, lengths).
+        sync_every: poll the live-env count every that many steps to stop early (None: run all max_turn steps
+        without any host sync; idle steps of finished envs are no-ops)."""
+        self.reset(users)
+        T = self.env.max_turn
+        if sync_every is None:
+            self.run_steps(0, T, seed, rng_base)
+        else:
+            t = 0
+            while t < T:
+                t2 = min(T, t + sync_every)
+                self.run_steps(t, t2, seed, rng_base)
+                t = t2
+                if t < T and bool(self.env.done.all()):
+                    break
+        lengths = self.env.turn.clone()
+        return lengths

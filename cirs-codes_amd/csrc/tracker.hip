@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     const int o32 = lane & (kD - 1);
 
     const bool is_init = users != nullptr;
+    if (!is_init && items[j] < 0) return;  // act = -1: env finished earlier in this rollout
     const int pos = is_init ? 0 : st.len[e];
     if (pos >= L) return;  // history full: the caller never steps past max_turn (collector drops finished envs)
 

@@ -189,6 +189,38 @@ int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, 
                       const int32_t* env_ids, const uint32_t* visited, const uint8_t* skip, int64_t* act_out,
                       float* logp_out, float* value_out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Device-resident rollout: the Collector hot loop with no host round trip per step
+ * replaces  core/collector.py:219-317 (policy forward -> env.step -> preprocess_fn -> buffer.add, per vector step)
+ *           tianshou/data/buffer/manager.py:91-142 (ReplayBufferManager.add) -- the trajectory IS the buffer
+ *           core/policy/utils.py:7-27 (get_recommended_ids) via the visited bitmap
+ * Trajectory tensors are TIME-MAJOR so every step reads/writes contiguous [B, .] rows (the reference's tracker
+ * history `data` is (L, B, D) too, state_tracker.py:198).  Row t of act/rew/done/logp/value/ctr belongs to the
+ * transition (s_t, a_t, r_t, s_{t+1}); obs has T+1 rows.  Finished envs keep act = -1 from their first idle step.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct cirs_traj {
+    float* obs;     /* [T+1, B, S] tracker states; row 0 written by cirs_tracker_init                         */
+    int64_t* act;   /* [T, B]     env-encoded item id, -1 = env already finished                               */
+    double* rew;    /* [T, B]     */
+    uint8_t* done;  /* [T, B]     */
+    float* logp;    /* [T, B]     log pi(a_t | s_t) at rollout time (== logp_old of ppo.py:104-108)            */
+    float* value;   /* [T, B]     V(s_t) at rollout time    (== v_s of a2c.py:83-88)                           */
+    double* ctr;    /* [T, B]     info['CTR'] (simulated) / cum_reward (bare env)                              */
+} cirs_traj;
+
+/* Run vector steps t in [t_begin, t_end) for all n_env envs: actor_sample(obs[t]) -> env_step -> tracker_step -> obs[t+1].
+ *   rng_base      step t draws its sampler noise with rng_step = rng_base + t
+ *   visited       nullable [B, ceil(I/32)] bitmap; when given, chosen ids are masked from later draws of the same
+ *                 env (remove_recommended_ids, the NX_* test collectors) and the bitmap is updated each step
+ *   force_length  > 0: done is overridden to (t+1 >= force_length) for every env (core/collector.py:253-258)
+ *   workspace     >= cirs_policy_workspace_bytes(policy_cfg, n_env) */
+int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                       const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                       const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj,
+                       int32_t n_env, int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base,
+                       uint32_t* visited, int32_t force_length, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

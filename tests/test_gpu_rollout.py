@@ -1,0 +1,85 @@
+"""GPU: the fused device-resident rollout, checked stage by stage against the oracle on the SAME inputs:
+   actions  <- C oracle actor_sample on the rollout's own states (bit-exact, same counter RNG)
+   rew/done <- C oracle env step teacher-forced with the rollout's actions (done bit-exact, rew 1e-12)
+   states   <- torch-fp32 tracker restatement on the rollout's actions/rewards (1e-4)"""
+import numpy as np
+import pytest
+import torch
+
+import envcase
+import nn_oracle
+import policycase
+import rolloutcase
+
+pytestmark = pytest.mark.gpu
+
+
+def check_rollout(U, I, B, T, seed, *, sync_every=None, **kw):
+    from cirs_hip.synthetic import make_tables
+    tab = make_tables(U, I, seed=0, build_dist=False)
+    ro, tp, arrs, envp = rolloutcase.build_device_stack(tab, B, T, **kw)
+    rng = np.random.RandomState(1)
+    users = rng.randint(0, U, B)
+    lengths = ro.collect(torch.as_tensor(users), seed=seed, rng_base=100, sync_every=sync_every).cpu().numpy()
+    tr = ro.traj
+    act = tr.act.cpu().numpy(); rew = tr.rew.cpu().numpy(); done = tr.done.cpu().numpy().astype(bool)
+    obs = tr.obs.cpu().numpy(); logp = tr.logp.cpu().numpy(); value = tr.value.cpu().numpy()
+    assert lengths.min() >= 1 and lengths.max() <= T
+    # structure: act >= 0 exactly for t < length, done exactly at t == length-1
+    tt = np.arange(T)[:, None]
+    assert np.array_equal(act >= 0, tt < lengths[None, :])
+    assert np.array_equal(done & (act >= 0), (tt == lengths[None, :] - 1))
+    # --- env: teacher-forced oracle ---
+    a_env, b_env = envp.pop("a_env"), envp.pop("b_env")
+    cfg = envcase.env_cfg(U, I, dist_mode=1, **envp)
+    host = envcase.HostEnv(cfg, tab.mat, tab.normed_mat, None, tab.item_cats, a_env, b_env, B)
+    want = envcase.run_teacher_forced(host, users, np.maximum(act.T, 0), T)
+    assert np.array_equal(want["length"], lengths)
+    m = (act >= 0).T
+    np.testing.assert_allclose(rew.T[m], want["rew"][m], rtol=1e-12)
+    assert np.array_equal(done.T[m], want["done"][m])
+    np.testing.assert_allclose(tr.ctr.cpu().numpy().T[m], want["ctr"][m], rtol=1e-12)
+    # --- policy: oracle on the device's own states, step by step ---
+    mism = 0
+    for t in range(int(lengths.max())):
+        live = act[t] >= 0
+        oa, ol, ov, _ = policycase.oracle_sample(arrs, obs[t], seed=seed, rng_step=100 + t, skip=(~live).astype(np.uint8))
+        mism += int((oa[live] != act[t][live]).sum())
+        assert np.array_equal(ov[live], value[t][live])
+        np.testing.assert_allclose(logp[t][live], ol[live], rtol=1e-4, atol=1e-4)
+    assert mism == 0, f"{mism} action ids differ from the oracle"
+    # --- tracker: restatement over the recorded episodes ---
+    states = nn_oracle.tracker_states(tp, users, np.maximum(act.T, 0), rew.T).numpy()  # [B, T+1, S]
+    for b in range(B):
+        L = lengths[b]
+        np.testing.assert_allclose(obs[:L + 1, b], states[b, :L + 1], atol=1e-4, rtol=1e-4)
+    return lengths
+
+
+def test_rollout_small():
+    lengths = check_rollout(60, 150, 24, 12, seed=5, N=3, thr=1)
+    assert lengths.min() < lengths.max()
+
+
+def test_rollout_c2_shapes():
+    check_rollout(1411, 3327, 64, 30, seed=7)
+
+
+def test_rollout_early_stop_polling_is_equivalent():
+    a = check_rollout(200, 400, 40, 30, seed=9, N=4, thr=2, sync_every=4)
+    b = check_rollout(200, 400, 40, 30, seed=9, N=4, thr=2)
+    assert np.array_equal(a, b)
+
+
+def test_rollout_remove_recommended_ids_and_force_length():
+    from cirs_hip.synthetic import make_tables
+    U, I, B, T = 60, 90, 16, 20
+    tab = make_tables(U, I, seed=0, build_dist=False)
+    ro, tp, arrs, envp = rolloutcase.build_device_stack(tab, B, T, N=2, thr=10, remove_recommended_ids=True, force_length=10)
+    users = np.random.RandomState(0).randint(0, U, B)
+    lengths = ro.collect(torch.as_tensor(users), seed=3).cpu().numpy()
+    assert (lengths == 10).all()  # force_length overrides the env's own done (collector.py:253-258)
+    act = ro.traj.act.cpu().numpy()
+    for b in range(B):
+        a = act[:10, b]
+        assert len(set(a.tolist())) == 10, "an id was recommended twice although remove_recommended_ids is on"
