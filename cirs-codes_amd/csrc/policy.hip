@@ -147,6 +147,17 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
         const int jr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (jr < n && !(skip && skip[jr])) active |= 1u << r;
     }
+    if (__ballot(active != 0) == 0ull) {  // every row of this env tile is finished: publish neutral partials
+        if (lo == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const size_t o = (size_t)chunk * n_pad + jr;
+                pv.score[o] = -INFINITY; pv.idx[o] = 0x7FFFFFFF; pv.m[o] = -INFINITY; pv.s[o] = 0.f;
+            }
+        }
+        return;
+    }
     float best_score[16], run_m[16], run_s[16];
     int best_idx[16];
 #pragma unroll
@@ -203,9 +214,11 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
                     if (sc > best_score[r]) {  // items ascend within a lane: strict > keeps the lowest id on ties
                         best_score[r] = sc; best_idx[r] = item;
                     }
-                    const float mn = fmaxf(run_m[r], z);
-                    run_s[r] = run_s[r] * __expf(run_m[r] - mn) + __expf(z - mn);
-                    run_m[r] = mn;
+                    // online log-sum-exp with ONE exp per element: e = exp(-|z - m|)
+                    const float dlt = z - run_m[r];
+                    const float ex = __expf(-fabsf(dlt));
+                    run_s[r] = dlt > 0.f ? __builtin_fmaf(run_s[r], ex, 1.0f) : run_s[r] + ex;
+                    run_m[r] = fmaxf(run_m[r], z);
                 }
             }
         }
@@ -235,26 +248,31 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
     }
 }
 
-// merge partials across chunks; recompute the chosen item's logit with the SAME k-order as the MFMA chain
-// (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with the sampled distribution.
+// merge partials across chunks (one wavefront per env row, lanes stride over chunks); recompute the chosen item's
+// logit with the SAME k-order as the MFMA chain (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with
+// the sampled distribution.
 __global__ __launch_bounds__(256) void actor_merge_kernel(int n, int n_pad, int n_chunks, ActorPartialView pv,
                                                           const float* __restrict__ wa, const float* __restrict__ ba,
                                                           const float* __restrict__ h2,
                                                           const uint8_t* __restrict__ skip,
                                                           int64_t* __restrict__ act_out, float* __restrict__ logp_out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n) return;
     if (skip && skip[j]) {
-        act_out[j] = -1;
-        if (logp_out) logp_out[j] = 0.f;
+        if (lane == 0) {
+            act_out[j] = -1;
+            if (logp_out) logp_out[j] = 0.f;
+        }
         return;
     }
     float bs = -INFINITY, m = -INFINITY, s = 0.f;
     int bi = 0x7FFFFFFF;
-    for (int c = 0; c < n_chunks; ++c) {  // ascending chunks == ascending item ids: strict > keeps the lowest id
+    for (int c = lane; c < n_chunks; c += CIRS_WAVE) {  // within a lane chunks ascend: strict > keeps the lowest id
         const size_t o = (size_t)c * n_pad + j;
         const float os = pv.score[o];
-        if (os > bs) { bs = os; bi = pv.idx[o]; }
+        const int oi = pv.idx[o];
+        if (os > bs) { bs = os; bi = oi; }
         const float om = pv.m[o], osum = pv.s[o];
         const float mn = fmaxf(m, om);
         if (mn > -INFINITY) {
@@ -262,6 +280,19 @@ __global__ __launch_bounds__(256) void actor_merge_kernel(int n, int n_pad, int 
             m = mn;
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float os = __shfl_xor(bs, off, CIRS_WAVE);
+        const int oi = __shfl_xor(bi, off, CIRS_WAVE);
+        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+        const float om = __shfl_xor(m, off, CIRS_WAVE), osum = __shfl_xor(s, off, CIRS_WAVE);
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            s = s * __expf(m - mn) + osum * __expf(om - mn);
+            m = mn;
+        }
+    }
+    if (lane != 0) return;
     act_out[j] = bi == 0x7FFFFFFF ? -1 : (int64_t)bi;
     if (logp_out) {
         float lp = 0.f;
@@ -326,7 +357,7 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
         hipLaunchKernelGGL(actor_head_kernel<true>, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
                            rng_step, env_ids, visited, skip, pv, n_pad);
     CIRS_CHECK_LAUNCH("actor_head_kernel");
-    hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, n_pad, n_chunks, pv, w->wa, w->ba,
+    hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, n_chunks, pv, w->wa, w->ba,
                        h2, skip, act_out, logp_out);
     CIRS_CHECK_LAUNCH("actor_merge_kernel");
     return CIRS_OK;

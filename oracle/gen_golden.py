@@ -269,7 +269,88 @@ def gen_policy():
     print("policy.npz: min top-2 margin", float((top2[:, 0] - top2[:, 1]).min()), "keys", list(sd))
 
 
-FAMILIES = {"env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+# --------------------------------------------------------------------------------------------------
+# learn family: reference Collector.collect + PPOPolicy.update (process_fn + learn) on a tiny problem
+# --------------------------------------------------------------------------------------------------
+def gen_learn():
+    import gym
+    from core.collector import Collector
+    from core.policy.ppo import PPOPolicy
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.env import DummyVectorEnv
+
+    U, I, B, T = 48, 96, 12, 10
+    tab = make_tables(U, I, seed=0, with_ab=True, build_dist=True)
+    envp = dict(num_leave_compute=3, leave_threshold=1, max_turn=T, tau=10.0, gamma_exposure=10.0, version="v1",
+                r_decay=1.0, with_ab=True)
+    register_envs(tab, **envp)
+    st = make_reference_tracker(U, I, T, seed=21)
+    st.eval()  # parity fixtures are recorded with dropout disabled
+    net, actor, critic = make_reference_policy(I, seed=4)
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        for p_ in list(actor.parameters()) + list(critic.parameters()):
+            if p_.dim() == 1:
+                p_.copy_(0.2 * torch.randn(p_.shape, generator=g))
+        actor.last.model[0].weight.mul_(3.0)
+    import warnings
+    warnings.simplefilter("ignore")
+    optim_RL = torch.optim.Adam(list(actor.parameters()) + list(critic.parameters()), lr=1e-3)
+    optim_state = torch.optim.Adam(st.parameters(), lr=1e-3)
+    sim_env = gym.make("SimulatedEnv-v0")
+    policy = PPOPolicy(actor, critic, [optim_RL, optim_state], torch.distributions.Categorical, discount_factor=0.95,
+                       max_grad_norm=0.5, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, reward_normalization=1,
+                       advantage_normalization=1, recompute_advantage=0, value_clip=1, gae_lambda=0.95,
+                       action_space=sim_env.action_space, action_bound_method="", action_scaling=False)
+    random.seed(123); np.random.seed(123); torch.manual_seed(123)
+    train_envs = DummyVectorEnv([lambda: gym.make("SimulatedEnv-v0") for _ in range(B)])
+    collector = Collector(policy, train_envs, VectorReplayBuffer(B * T, B), preprocess_fn=st.build_state)
+    policy.train()
+    random.seed(321)
+    res = collector.collect(n_episode=B)
+    buf = collector.buffer
+    users = np.array([int(w.env.cur_user[0]) for w in train_envs.workers])
+    lens = np.array([len(b_) for b_ in buf.buffers])
+    acts = np.full((B, T), -1, np.int64); rews = np.zeros((B, T)); dones = np.zeros((B, T), bool)
+    obs = np.zeros((B, T + 1, 20), np.float32)
+    for b in range(B):
+        sl = slice(buf._offset[b], buf._offset[b] + lens[b])
+        acts[b, :lens[b]] = buf.act[sl]; rews[b, :lens[b]] = buf.rew[sl]; dones[b, :lens[b]] = buf.done[sl]
+        obs[b, :lens[b]] = buf.obs[sl].detach().numpy()
+        obs[b, lens[b]] = buf.obs_next[sl][-1].detach().numpy()
+    pre = {"pol_" + k: v.detach().clone().numpy() for k, v in policy.state_dict().items()}
+    pre.update({"trk_" + k: v.detach().clone().numpy() for k, v in st.state_dict().items()})
+    # record permutations and the processed batch
+    perms = []
+    orig_perm = np.random.permutation
+    def rec_perm(n):
+        r = orig_perm(n); perms.append(np.array(r)); return r
+    np.random.permutation = rec_perm
+    stash = {}
+    orig_learn = policy.learn
+    def learn_wrap(batch, **kw):
+        stash.update(returns=batch.returns.detach().numpy().copy(), adv=batch.adv.detach().numpy().copy(),
+                     v_s=batch.v_s.detach().numpy().copy(), logp_old=batch.logp_old.detach().numpy().copy(),
+                     act=batch.act.detach().numpy().copy())
+        return orig_learn(batch, **kw)
+    policy.learn = learn_wrap
+    np.random.seed(77)
+    losses = policy.update(0, buf, batch_size=16, repeat=2)
+    np.random.permutation = orig_perm
+    post = {"post_pol_" + k: v.detach().numpy() for k, v in policy.state_dict().items()}
+    post.update({"post_trk_" + k: v.detach().numpy() for k, v in st.state_dict().items()})
+    out = dict(users=users, lens=lens, acts=acts, rews=rews, dones=dones, obs=obs,
+               n_perm=np.int64(len(perms)), ret_rms=np.array([policy.ret_rms.mean, policy.ret_rms.var, policy.ret_rms.count], dtype=np.float64),
+               loss=np.array(losses["loss"]), loss_clip=np.array(losses["loss/clip"]), loss_vf=np.array(losses["loss/vf"]),
+               loss_ent=np.array(losses["loss/ent"]),
+               hyper=np.array([0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, 16, 2]), dims=np.array([U, I, B, T]),
+               **{f"perm{i}": p_ for i, p_ in enumerate(perms)}, **{"b_" + k: v for k, v in stash.items()}, **pre, **post)
+    np.savez_compressed(os.path.join(GOLDEN, "learn.npz"), **out)
+    print("learn.npz: N =", int(lens.sum()), "lens", lens.tolist(), "minibatches", len(losses["loss"]), "losses", np.round(losses["loss"], 4),
+          "perms", [len(p_) for p_ in perms])
+
+
+FAMILIES = {"learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

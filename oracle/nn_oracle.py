@@ -110,3 +110,149 @@ def sample_with_gumbel(logits, gumbel, visited=None):
     if visited is not None:
         score = score.scatter(1, _t(visited).long(), float("-inf"))
     return torch.argmax(score, dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# PPO update restatement (process_fn + learn), including the reference's quirks.  Pinned to tests/golden/learn.npz.
+#   returns / GAE : tianshou/policy/modelfree/a2c.py:80-109, policy/base.py:271-313,380-396, utils/statistics.py:80-95
+#   learn         : core/policy/ppo.py:166-246
+# Quirks restated here (SURVEY Q8 and §3.4):
+#   * actor and critic share the trunk and the optimiser / clip_grad_norm_ receive the trunk parameters TWICE
+#     (list(actor.parameters()) + list(critic.parameters())): the total norm counts the trunk gradient twice, the
+#     clip coefficient multiplies trunk gradients twice, and Adam applies two sequential sub-steps to trunk
+#     parameters per optimiser step (state['step'] advances by 2).
+#   * gradients reach the state tracker through the stored obs; they are accumulated over the minibatches of the
+#     LAST repeat only and applied by one Adam step at the end.
+# ------------------------------------------------------------------------------------------------------------
+def flatten_episodes(x_bt, lens, shift=0):
+    """[B, T(+1), ...] -> buffer order (env-major concatenation of each env's first len transitions)."""
+    return torch.cat([x_bt[b, shift:shift + int(lens[b])] for b in range(len(lens))], dim=0)
+
+
+def gae_numpy(v_s, v_s_, rew, end_flag, gamma, lam):
+    returns = np.zeros(rew.shape)
+    delta = rew + v_s_ * gamma - v_s
+    m = (1.0 - end_flag) * (gamma * lam)
+    gae = 0.0
+    for i in range(len(rew) - 1, -1, -1):
+        gae = delta[i] + m[i] * gae
+        returns[i] = gae
+    return returns
+
+
+class RunningMeanStd:
+    def __init__(self):
+        self.mean, self.var, self.count = 0.0, 1.0, 0
+
+    def update(self, x):
+        bm, bv, bc = np.mean(x), np.var(x), len(x)
+        delta = bm - self.mean
+        tot = self.count + bc
+        new_mean = self.mean + delta * bc / tot
+        m2 = self.var * self.count + bv * bc + delta ** 2 * self.count * bc / tot
+        self.mean, self.var, self.count = new_mean, m2 / tot, tot
+
+
+def adam_substeps(p, g, state, lr, n_sub, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam single-tensor update applied n_sub times with the same gradient (duplicate-param quirk)."""
+    for _ in range(n_sub):
+        state["step"] += 1
+        t = state["step"]
+        state["m"].lerp_(g, 1 - b1)
+        state["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        denom = (state["v"].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(state["m"], denom, value=-lr / bc1)
+
+
+def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam=0.95, eps_clip=0.2, vf_coef=0.25,
+               ent_coef=0.0, max_grad_norm=0.5, lr=1e-3, batch_size=16, repeat=2, ret_rms=None, nhead=4):
+    """Runs one policy.update on teacher-forced episodes.  tp/pp are dicts of torch fp32 tensors and are updated
+    IN PLACE.  Returns dict(losses..., returns, adv, v_s, logp_old, ret_rms)."""
+    lens = np.asarray(lens)
+    ret_rms = ret_rms or RunningMeanStd()
+    tparams = {k: v for k, v in tp.items() if k != "pos_encoder.pe"}
+    for v in tparams.values():
+        v.requires_grad_(True)
+    states = tracker_forward_all(tp, tracker_inputs(tp, users, np.maximum(acts, 0), rews), nhead)
+    obs = flatten_episodes(states, lens, 0)          # carries the graph into the tracker
+    obs_next = flatten_episodes(states, lens, 1).detach()
+    act = flatten_episodes(_t(acts), lens).long()
+    rew = flatten_episodes(_t(rews), lens).double().numpy()
+    done = flatten_episodes(_t(dones), lens).bool().numpy()
+    N = len(act)
+    with torch.no_grad():
+        _, v_s_t = policy_forward(pp, obs.detach())
+        _, v_ns_t = policy_forward(pp, obs_next)
+        logits_old, _ = policy_forward(pp, obs.detach())
+        _, logp_old, _ = categorical_logp_entropy(logits_old, act)
+    scale = np.sqrt(ret_rms.var + 1e-8)
+    v_s = v_s_t.numpy().astype(np.float64) * scale
+    v_ns = v_ns_t.numpy().astype(np.float64) * scale * (~done)
+    end_flag = done.copy()  # every episode in the buffer is finished (n_episode == env_num)
+    adv = gae_numpy(v_s, v_ns, rew, end_flag.astype(np.float64), gamma, lam)
+    unnorm_returns = adv + v_s
+    returns = torch.as_tensor(unnorm_returns / scale).float()
+    ret_rms.update(unnorm_returns)
+    adv_t = torch.as_tensor(adv).float()
+
+    names_trunk = ["w1", "b1", "w2", "b2"]
+    names_head = ["wa", "ba", "wc", "bc"]
+    st_pol = {k: dict(step=0, m=torch.zeros_like(pp[k]), v=torch.zeros_like(pp[k])) for k in pp}
+    st_trk = {k: dict(step=0, m=torch.zeros_like(v), v=torch.zeros_like(v)) for k, v in tparams.items()}
+    out = dict(loss=[], clip=[], vf=[], ent=[])
+    pi = 0
+    trk_grads = None
+    for rep in range(repeat):
+        trk_grads = {k: torch.zeros_like(v) for k, v in tparams.items()}  # optim_state.zero_grad()
+        perm = np.asarray(perms[pi]); pi += 1
+        starts = list(range(0, N, batch_size))
+        merge_last = N % batch_size > 0
+        idx_list = []
+        for s0 in starts:
+            if merge_last and s0 + 2 * batch_size >= N:
+                idx_list.append(perm[s0:]); break
+            idx_list.append(perm[s0:s0 + batch_size])
+        for idx in idx_list:
+            idx_t = torch.as_tensor(idx).long()
+            for k in pp:
+                pp[k].requires_grad_(True)
+            b_obs = obs[idx_t]
+            logits, value = policy_forward(pp, b_obs)
+            _, logp, ent = categorical_logp_entropy(logits, act[idx_t])
+            a = adv_t[idx_t]
+            a = (a - a.mean()) / a.std()
+            ratio = (logp - logp_old[idx_t]).exp()
+            surr1, surr2 = ratio * a, ratio.clamp(1 - eps_clip, 1 + eps_clip) * a
+            clip_loss = -torch.min(surr1, surr2).mean()
+            vs = v_s_t[idx_t]
+            v_clip = vs + (value - vs).clamp(-eps_clip, eps_clip)
+            vf_loss = torch.max((returns[idx_t] - value).pow(2), (returns[idx_t] - v_clip).pow(2)).mean()
+            ent_loss = ent.mean()
+            loss = clip_loss + vf_coef * vf_loss - ent_coef * ent_loss
+            plist = [pp[k] for k in names_trunk + names_head]
+            tlist = list(tparams.values())
+            grads = torch.autograd.grad(loss, plist + tlist, retain_graph=True, allow_unused=True)
+            gp = dict(zip(names_trunk + names_head, grads[:len(plist)]))
+            for k, gk in zip(tparams.keys(), grads[len(plist):]):
+                if gk is not None:
+                    trk_grads[k] += gk
+            for k in pp:
+                pp[k].requires_grad_(False)
+            # clip_grad_norm_ over [trunk..., wa, ba, trunk..., wc, bc]: trunk counted twice, scaled twice
+            sq = sum(2.0 * float(gp[k].pow(2).sum()) for k in names_trunk) + sum(float(gp[k].pow(2).sum()) for k in names_head)
+            total_norm = math.sqrt(sq)
+            coef = min(max_grad_norm / (total_norm + 1e-6), 1.0)
+            with torch.no_grad():
+                for k in names_trunk:
+                    adam_substeps(pp[k], gp[k] * coef * coef, st_pol[k], lr, 2)
+                for k in names_head:
+                    adam_substeps(pp[k], gp[k] * coef, st_pol[k], lr, 1)
+            out["loss"].append(float(loss)); out["clip"].append(float(clip_loss)); out["vf"].append(float(vf_loss)); out["ent"].append(float(ent_loss))
+    with torch.no_grad():
+        for k, v in tparams.items():
+            v.requires_grad_(False)
+            adam_substeps(v, trk_grads[k], st_trk[k], lr, 1)
+    out.update(returns=returns.numpy(), adv=adv_t.numpy(), v_s=v_s_t.numpy(), logp_old=logp_old.numpy(), ret_rms=ret_rms,
+               trk_grads={k: g.clone() for k, g in trk_grads.items()}, obs=obs.detach().numpy())
+    return out
