@@ -4,14 +4,14 @@
 //
 //   trunk_kernel       one wavefront per env row: h1 = relu(W1 s + b1), h2 = relu(W2 h1 + b2), value = wc.h2 + bc.
 //                      Sequential-k fmaf chains (the order the oracle restates), lane o owns output feature o.
-//   actor_head_kernel  logits tile = H2[32 envs x 64] * Wa^T[64 x 32 items] on the fp32 matrix cores
+//   actor_head_kernel  logits^T tile = Wa[32 items x 64] * H2^T[64 x 32 envs] on the fp32 matrix cores
 //                      (v_mfma_f32_32x32x2_f32: exact f32 fma chain, D = fma(a_k1,b_k1, fma(a_k0,b_k0,C))), accumulator
 //                      initialised with the bias.  Operand k-relabelling: MFMA step kk pairs k0 = kk with
 //                      k1 = 32+kk so every lane streams 32 CONTIGUOUS floats (one 128-B line) of its row of Wa --
 //                      no LDS staging, no strided reads.  The epilogue never writes logits: per (env,item) it adds
-//                      Gumbel noise (Philox, or harness-supplied), keeps a lane-local running arg-max and an
-//                      online log-sum-exp, and reduces across the 32 lanes that share an env row at the end of the
-//                      item chunk.  Per-chunk partials {score, idx, z, m, s} go to the caller's workspace.
+//                      Gumbel noise (Philox, or harness-supplied) and keeps a per-lane scalar running arg-max and
+//                      online log-sum-exp (a lane owns one env row).  Per-chunk partials {score, idx, m, s} go to
+//                      the caller's workspace.
 //   actor_merge_kernel merges partials across chunks: action id (ties -> lowest id), logp with Categorical's clamp.
 //
 // Roofline: 2*64*I flop per env row (1.37 MFLOP at I = 10728) against 4*64*I bytes of Wa re-read per 32-env tile
@@ -102,11 +102,15 @@ __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, cirs_po
 }
 
 // ---- actor head ------------------------------------------------------------------------------------------------
-// grid = (n_chunks, ceil(n_pad/32/4)); block = 4 waves, wave wv owns env tile blockIdx.y*4+wv; all four waves walk
-// the same item chunk so the rows of Wa they stream are shared through L1/L2.
-// kIdentity: env id == row index (the device-resident rollout never compacts envs), which lets one Philox block
-// serve the 4 consecutive env rows a lane holds per accumulator group.
-template <bool kIdentity>
+// Transposed tile: ZT[32 items x 32 rows] = Wa_tile[32 x 64] * H2_tile^T[64 x 32].  MFMA A operand = this lane's ITEM
+// row of Wa, B operand = this lane's ENV row of H2 (both 32 contiguous floats, k = hi*32 + kk).  In the C/D layout a
+// lane then owns ONE env row (col = lane & 31) and 16 items (item(s) = (s&3) + 8*(s>>2) + 4*hi), so the running
+// arg-max and the online log-sum-exp are per-lane SCALARS; the only cross-lane step is one exchange between the
+// two half-waves at the end of the chunk.  Per accumulator group (s>>2) the 4 items are consecutive -> one Philox
+// block and one float4 bias load serve them.
+// grid = (n_chunks, ceil(n_pad/32/4)); block = 4 waves = 4 env tiles walking the same item chunk (shared Wa lines).
+// kSample: true  -> Gumbel-max sampling + LSE (rollout);  false -> LSE (+ sum exp(z-m) z for the entropy) only.
+template <bool kSample>
 __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa,
                                                             const float* __restrict__ ba,
                                                             const float* __restrict__ h2, int n,
@@ -117,134 +121,123 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
                                                             int n_pad) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int hi = lane >> 5, lo = lane & 31;
-    const int env_tile = blockIdx.y * 4 + wv;
-    const int row0 = env_tile * kTileM;
+    const int row0 = (blockIdx.y * 4 + wv) * kTileM;
     if (row0 >= n_pad) return;
     const int I = cfg.n_items;
     const int chunk = blockIdx.x;
     const int vis_words = (I + 31) / 32;
-
-    // A operand: this lane's env row, k = hi*32 + kk  (32 contiguous floats)
-    float a[32];
-    {
-        const int r = row0 + lo;
-        if (r < n) {
-            const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)r * kH + hi * 32);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = src[q];
-                a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) a[q] = 0.f;
-        }
-    }
-    // rows this lane sees in the C/D layout: row(r) = (r&3) + 8*(r>>2) + 4*hi ; bit r of `active` = row is live
-    uint32_t active = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int jr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (jr < n && !(skip && skip[jr])) active |= 1u << r;
-    }
-    if (__ballot(active != 0) == 0ull) {  // every row of this env tile is finished: publish neutral partials
-        if (lo == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const size_t o = (size_t)chunk * n_pad + jr;
-                pv.score[o] = -INFINITY; pv.idx[o] = 0x7FFFFFFF; pv.m[o] = -INFINITY; pv.s[o] = 0.f;
-            }
+    const int jr = row0 + lo;  // this lane's env row
+    const bool active = jr < n && !(skip && skip[jr]);
+    const size_t po = (size_t)chunk * n_pad + jr;
+    if (__ballot(active) == 0ull) {  // every row of this env tile is finished: publish neutral partials
+        if (hi == 0) {
+            pv.score[po] = -INFINITY; pv.idx[po] = 0x7FFFFFFF; pv.m[po] = -INFINITY; pv.s[po] = 0.f;
+            if (!kSample) pv.score[po] = 0.f;
         }
         return;
     }
-    float best_score[16], run_m[16], run_s[16];
-    int best_idx[16];
+    const int e = active ? (env_ids ? env_ids[jr] : jr) : 0;
+
+    // B operand: this lane's env row of H2, k = hi*32 + kk
+    float hrow[32];
+    if (jr < n) {
+        const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)jr * kH + hi * 32);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        best_score[r] = -INFINITY; best_idx[r] = 0x7FFFFFFF; run_m[r] = -INFINITY; run_s[r] = 0.f;
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = src[q];
+            hrow[4 * q + 0] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) hrow[q] = 0.f;
     }
+    float best_score = -INFINITY, run_m = -INFINITY, run_s = 0.f, run_t = 0.f;
+    int best_idx = 0x7FFFFFFF;
 
     for (int it = 0; it < kTilesPerChunk; ++it) {
-        const int item = chunk * kChunkItems + it * kTileN + lo;
-        const bool item_ok = item < I;
-        float b[32];
-        if (item_ok) {
-            const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item * kH + hi * 32);
+        const int tile0 = chunk * kChunkItems + it * kTileN;  // multiple of 32
+        if (tile0 >= I) break;
+        const int item_a = tile0 + lo;  // A-operand item of this lane
+        float wrow[32];
+        if (item_a < I) {
+            const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item_a * kH + hi * 32);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float4 v = src[q];
-                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+                wrow[4 * q + 0] = v.x; wrow[4 * q + 1] = v.y; wrow[4 * q + 2] = v.z; wrow[4 * q + 3] = v.w;
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 32; ++q) b[q] = 0.f;
+            for (int q = 0; q < 32; ++q) wrow[q] = 0.f;
         }
-        const float bias = item_ok ? ba[item] : 0.f;
         f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias;
+        for (int g = 0; g < 4; ++g) {  // bias of the 4 consecutive items of accumulator group g
+            const int i0 = tile0 + 8 * g + 4 * hi;
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = (i0 + q) < I ? ba[i0 + q] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
 
-        if (item_ok) {
+        if (!active) continue;
+        const uint32_t vis = (kSample && visited) ? visited[(size_t)e * vis_words + (tile0 >> 5)] : 0u;
 #pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                const int jr0 = row0 + 8 * grp + 4 * hi;  // 4 consecutive rows jr0..jr0+3 (jr0 % 4 == 0)
-                float g4[4];
-                if (!gumbel && kIdentity) {
-                    const u32x4 rr = philox4x32_10((uint32_t)item, (uint32_t)jr0 >> 2, rng_step, CIRS_RNG_STREAM_ACTOR,
-                                                   (uint32_t)seed, (uint32_t)(seed >> 32));
-                    g4[0] = gumbel_from_bits(rr.x); g4[1] = gumbel_from_bits(rr.y);
-                    g4[2] = gumbel_from_bits(rr.z); g4[3] = gumbel_from_bits(rr.w);
-                }
+        for (int g = 0; g < 4; ++g) {
+            const int i0 = tile0 + 8 * g + 4 * hi;
+            float g4[4];
+            if (kSample && !gumbel) {
+                const u32x4 rr = philox4x32_10((uint32_t)i0 >> 2, (uint32_t)e, rng_step, CIRS_RNG_STREAM_ACTOR,
+                                               (uint32_t)seed, (uint32_t)(seed >> 32));
+                g4[0] = gumbel_from_bits(rr.x); g4[1] = gumbel_from_bits(rr.y);
+                g4[2] = gumbel_from_bits(rr.z); g4[3] = gumbel_from_bits(rr.w);
+            }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = grp * 4 + q;
-                    if (!((active >> r) & 1u)) continue;
-                    const int jr = jr0 + q;
-                    const int e = kIdentity ? jr : env_ids[jr];
-                    if (visited && ((visited[(size_t)e * vis_words + (item >> 5)] >> (item & 31)) & 1u)) continue;
-                    const float z = acc[r];
-                    float g;
-                    if (gumbel) g = gumbel[(size_t)jr * I + item];
-                    else if (kIdentity) g = g4[q];
-                    else g = actor_gumbel(seed, rng_step, (uint32_t)e, (uint32_t)item);
-                    const float sc = z + g;
-                    if (sc > best_score[r]) {  // items ascend within a lane: strict > keeps the lowest id on ties
-                        best_score[r] = sc; best_idx[r] = item;
+            for (int q = 0; q < 4; ++q) {
+                const int item = i0 + q;
+                if (item >= I) continue;
+                if (kSample && ((vis >> (item & 31)) & 1u)) continue;
+                const float z = acc[4 * g + q];
+                if (kSample) {
+                    const float gn = gumbel ? gumbel[(size_t)jr * I + item] : g4[q];
+                    const float sc = z + gn;
+                    if (sc > best_score) {  // items ascend within a lane: strict > keeps the lowest id on ties
+                        best_score = sc; best_idx = item;
                     }
-                    // online log-sum-exp with ONE exp per element: e = exp(-|z - m|)
-                    const float dlt = z - run_m[r];
-                    const float ex = __expf(-fabsf(dlt));
-                    run_s[r] = dlt > 0.f ? __builtin_fmaf(run_s[r], ex, 1.0f) : run_s[r] + ex;
-                    run_m[r] = fmaxf(run_m[r], z);
+                }
+                // online log-sum-exp with ONE exp per element: ex = exp(-|z - m|)
+                const float dlt = z - run_m;
+                const float ex = __expf(-fabsf(dlt));
+                if (dlt > 0.f) {
+                    run_s = __builtin_fmaf(run_s, ex, 1.0f);
+                    if (!kSample) run_t = __builtin_fmaf(run_t, ex, z);
+                    run_m = z;
+                } else {
+                    run_s += ex;
+                    if (!kSample) run_t = __builtin_fmaf(ex, z, run_t);
                 }
             }
         }
     }
-    // reduce across the 32 lanes (same hi) that hold the 32 items of each env row
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float bs = best_score[r], m = run_m[r], s = run_s[r];
-        int bi = best_idx[r];
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-            const float os = __shfl_xor(bs, off, CIRS_WAVE);
-            const int oi = __shfl_xor(bi, off, CIRS_WAVE);
-            if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
-            const float om = __shfl_xor(m, off, CIRS_WAVE), osum = __shfl_xor(s, off, CIRS_WAVE);
-            const float mn = fmaxf(m, om);
-            if (mn > -INFINITY) {
-                s = s * __expf(m - mn) + osum * __expf(om - mn);
-                m = mn;
-            }
+    // combine the two half-waves (same env row, disjoint items)
+    {
+        const float os = __shfl_xor(best_score, 32, CIRS_WAVE);
+        const int oi = __shfl_xor(best_idx, 32, CIRS_WAVE);
+        if (os > best_score || (os == best_score && oi < best_idx)) { best_score = os; best_idx = oi; }
+        const float om = __shfl_xor(run_m, 32, CIRS_WAVE), osum = __shfl_xor(run_s, 32, CIRS_WAVE);
+        const float ot = __shfl_xor(run_t, 32, CIRS_WAVE);
+        const float mn = fmaxf(run_m, om);
+        if (mn > -INFINITY) {
+            const float fa = __expf(run_m - mn), fb = __expf(om - mn);
+            run_s = run_s * fa + osum * fb;
+            run_t = run_t * fa + ot * fb;
+            run_m = mn;
         }
-        if (lo == 0) {
-            const int jr = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const size_t o = (size_t)chunk * n_pad + jr;
-            pv.score[o] = bs; pv.idx[o] = bi; pv.m[o] = m; pv.s[o] = s;
-        }
+    }
+    if (hi == 0) {
+        if (kSample) { pv.score[po] = best_score; pv.idx[po] = best_idx; }
+        else { pv.score[po] = run_t; }
+        pv.m[po] = run_m; pv.s[po] = run_s;
     }
 }
 
@@ -350,12 +343,8 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
                        value_out);
     CIRS_CHECK_LAUNCH("trunk_kernel");
     const dim3 grid(n_chunks, cdiv(n_pad / kTileM, 4));
-    if (env_ids)
-        hipLaunchKernelGGL(actor_head_kernel<false>, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
-                           rng_step, env_ids, visited, skip, pv, n_pad);
-    else
-        hipLaunchKernelGGL(actor_head_kernel<true>, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
-                           rng_step, env_ids, visited, skip, pv, n_pad);
+    hipLaunchKernelGGL(actor_head_kernel<true>, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
+                       rng_step, env_ids, visited, skip, pv, n_pad);
     CIRS_CHECK_LAUNCH("actor_head_kernel");
     hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, n_chunks, pv, w->wa, w->ba,
                        h2, skip, act_out, logp_out);

@@ -71,10 +71,11 @@ __host__ __device__ __forceinline__ float gumbel_from_bits(uint32_t x) {
 
 #define CIRS_RNG_STREAM_ACTOR 0x43495253u /* 'CIRS' */
 
-// noise for (env e, item i) at rng_step: Philox counter (i, e>>2, rng_step, stream), key = seed; lane e&3 of the block
+// noise for (env e, item i) at rng_step: Philox counter (i>>2, e, rng_step, stream), key = seed; output word i&3.
+// Four consecutive items of one env share a Philox block (the head kernel holds 4 consecutive items per lane).
 __host__ __device__ __forceinline__ float actor_gumbel(uint64_t seed, uint32_t rng_step, uint32_t env, uint32_t item) {
-    const u32x4 r = philox4x32_10(item, env >> 2, rng_step, CIRS_RNG_STREAM_ACTOR, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const uint32_t sel = env & 3u;
+    const u32x4 r = philox4x32_10(item >> 2, env, rng_step, CIRS_RNG_STREAM_ACTOR, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t sel = item & 3u;
     const uint32_t x = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
     return gumbel_from_bits(x);
 }
