@@ -67,6 +67,17 @@ class PolicyWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc")]
 
 
+class PpoCfg(C.Structure):
+    _fields_ = [("n_items", C.c_int32), ("dim_state", C.c_int32), ("hidden", C.c_int32), ("norm_adv", C.c_int32),
+                ("value_clip", C.c_int32), ("rew_norm", C.c_int32), ("gamma", C.c_float), ("gae_lambda", C.c_float),
+                ("eps_clip", C.c_float), ("vf_coef", C.c_float), ("ent_coef", C.c_float), ("max_grad_norm", C.c_float),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float)]
+
+
+class PpoBatch(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "act", "adv", "ret", "v_s", "logp_old", "row_env", "row_t")]
+
+
 class Traj(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "act", "rew", "done", "logp", "value", "ctr")]
 
@@ -91,6 +102,14 @@ SIGNATURES = {
                                      C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
                                      C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
                                      C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, _P, C.c_int32, _P, C.c_int64, _P]),
+    "cirs_ppo_param_count": (C.c_int64, [C.POINTER(PpoCfg)]),
+    "cirs_ppo_workspace_bytes": (C.c_int64, [C.POINTER(PpoCfg), C.c_int32]),
+    "cirs_ppo_prepare": (C.c_int, [C.POINTER(PpoCfg), C.POINTER(Traj), _P, _P, C.c_int32, C.c_int32, C.c_int32, _P,
+                                   C.POINTER(PpoBatch), _P]),
+    "cirs_ppo_minibatch": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32,
+                                     _P, C.c_int32, _P, _P, C.c_int64, _P]),
+    "cirs_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, _P, C.c_int32, _P]),
 }
 
 _lib = None

@@ -1,0 +1,135 @@
+"""Device engine of the PPO learner (csrc/ppo.hip): flat parameter / gradient / Adam buffers, process_fn + learn."""
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import abi
+from .policy import POLICY_FIELDS
+
+# flat layout of include/cirs_hip.h: [w1 | b1 | w2 | b2 | wa | ba | wc | bc]
+FLAT_ORDER = ["w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc"]
+FIELD_TO_NAME = dict(POLICY_FIELDS)
+
+
+def flat_policy_params(n_items, dim_state=20, hidden=64, device="cuda", init: Optional[Dict[str, torch.Tensor]] = None):
+    """Allocate the flat fp32 parameter buffer and return (flat, {reference state_dict name: view})."""
+    shapes = dict(w1=(hidden, dim_state), b1=(hidden,), w2=(hidden, hidden), b2=(hidden,), wa=(n_items, hidden),
+                  ba=(n_items,), wc=(1, hidden), bc=(1,))
+    total = sum(int(np.prod(shapes[k])) for k in FLAT_ORDER)
+    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    views, off = {}, 0
+    for k in FLAT_ORDER:
+        n = int(np.prod(shapes[k]))
+        views[FIELD_TO_NAME[k]] = flat[off:off + n].view(shapes[k])
+        off += n
+    if init is not None:
+        for name, t in init.items():
+            if name in views:
+                views[name].copy_(t.to(device=device, dtype=torch.float32).reshape(views[name].shape))
+    return flat, views
+
+
+def minibatch_slices(n, batch_size):
+    """Batch.split(size, merge_last=True) index ranges (tianshou/data/batch.py:734-744)."""
+    merge_last = n % batch_size > 0
+    out = []
+    for s0 in range(0, n, batch_size):
+        if merge_last and s0 + 2 * batch_size >= n:
+            out.append((s0, n))
+            break
+        out.append((s0, min(n, s0 + batch_size)))
+    return out
+
+
+class DeviceLearner:
+    def __init__(self, flat_params: torch.Tensor, n_items, n_env, max_turn, *, dim_state=20, hidden=64, gamma=0.99,
+                 gae_lambda=0.95, eps_clip=0.2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=None, lr=1e-3, norm_adv=True,
+                 value_clip=False, rew_norm=False, betas=(0.9, 0.999), adam_eps=1e-8):
+        self.device = flat_params.device
+        self.cfg = abi.PpoCfg(n_items=n_items, dim_state=dim_state, hidden=hidden, norm_adv=int(bool(norm_adv)),
+                              value_clip=int(bool(value_clip)), rew_norm=int(bool(rew_norm)), gamma=gamma,
+                              gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
+                              max_grad_norm=float(max_grad_norm or 0.0), lr=lr, beta1=betas[0], beta2=betas[1],
+                              adam_eps=adam_eps)
+        self._lib = abi.lib()
+        assert flat_params.numel() == self._lib.cirs_ppo_param_count(C.byref(self.cfg))
+        self.params = flat_params
+        self.grads = torch.zeros_like(flat_params)
+        self.adam_m = torch.zeros_like(flat_params)
+        self.adam_v = torch.zeros_like(flat_params)
+        self.opt_step = 0
+        self.n_env, self.max_turn, self.S = n_env, max_turn, dim_state
+        self.rms_state = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64, device=self.device)  # RunningMeanStd()
+        self._ws = None
+        self._batch_cap = 0
+        self.dobs = torch.zeros((max_turn + 1, n_env, dim_state), dtype=torch.float32, device=self.device)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _alloc_batch(self, n):
+        if n > self._batch_cap:
+            dev, S = self.device, self.S
+            self.b_obs = torch.empty((n, S), dtype=torch.float32, device=dev)
+            self.b_act = torch.empty(n, dtype=torch.int32, device=dev)
+            self.b_adv = torch.empty(n, dtype=torch.float32, device=dev)
+            self.b_ret = torch.empty(n, dtype=torch.float32, device=dev)
+            self.b_vs = torch.empty(n, dtype=torch.float32, device=dev)
+            self.b_logp = torch.empty(n, dtype=torch.float32, device=dev)
+            self.b_env = torch.empty(n, dtype=torch.int32, device=dev)
+            self.b_t = torch.empty(n, dtype=torch.int32, device=dev)
+            self._batch_cap = n
+        self.batch = abi.PpoBatch(obs=self.b_obs.data_ptr(), act=self.b_act.data_ptr(), adv=self.b_adv.data_ptr(),
+                                  ret=self.b_ret.data_ptr(), v_s=self.b_vs.data_ptr(), logp_old=self.b_logp.data_ptr(),
+                                  row_env=self.b_env.data_ptr(), row_t=self.b_t.data_ptr())
+
+    def prepare(self, traj, lens_host: np.ndarray):
+        """process_fn: GAE + return normalisation + compaction into buffer order.  lens_host: episode lengths [B]."""
+        lens_host = np.asarray(lens_host, dtype=np.int32)
+        offsets = np.concatenate([[0], np.cumsum(lens_host)[:-1]]).astype(np.int32)
+        n = int(lens_host.sum())
+        self._alloc_batch(n)
+        self.n_rows = n
+        lens_d = torch.as_tensor(lens_host).to(self.device)
+        off_d = torch.as_tensor(offsets).to(self.device)
+        abi.check(self._lib.cirs_ppo_prepare(C.byref(self.cfg), C.byref(traj.struct), lens_d.data_ptr(), off_d.data_ptr(),
+                                             self.n_env, self.max_turn, n, self.rms_state.data_ptr(), C.byref(self.batch),
+                                             self._stream()), "cirs_ppo_prepare")
+        return n
+
+    def workspace(self, mb):
+        need = self._lib.cirs_ppo_workspace_bytes(C.byref(self.cfg), mb)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def learn(self, batch_size, repeat, perms: Optional[List[np.ndarray]] = None, want_tracker_grad=True):
+        """learn(): `repeat` passes of shuffled minibatches.  Returns loss arrays + leaves d loss / d obs of the LAST
+        repeat in self.dobs ([T+1, B, S]) for the tracker backward.  perms: recorded permutations (parity tests);
+        default np.random.permutation like Batch.split."""
+        n = self.n_rows
+        slices = minibatch_slices(n, batch_size)
+        max_mb = max(e - s for s, e in slices)
+        ws = self.workspace(max_mb)
+        n_steps = repeat * len(slices)
+        losses = torch.zeros((n_steps, 4), dtype=torch.float32, device=self.device)
+        k = 0
+        for rep in range(repeat):
+            perm = np.asarray(perms[rep]) if perms is not None else np.random.permutation(n)
+            perm_d = torch.as_tensor(perm.astype(np.int32)).to(self.device)
+            last = rep == repeat - 1
+            if last and want_tracker_grad:
+                self.dobs.zero_()  # optim_state.zero_grad() at the top of each repeat (ppo.py:174)
+            for s0, e0 in slices:
+                mb = e0 - s0
+                abi.check(self._lib.cirs_ppo_minibatch(
+                    C.byref(self.cfg), self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                    self.adam_v.data_ptr(), self.opt_step, C.byref(self.batch), perm_d.data_ptr() + 4 * s0, mb,
+                    self.dobs.data_ptr() if (last and want_tracker_grad) else None, self.n_env,
+                    losses.data_ptr() + 16 * k, ws.data_ptr(), ws.numel(), self._stream()), "cirs_ppo_minibatch")
+                self.opt_step += 1
+                k += 1
+        return losses

@@ -1,0 +1,762 @@
+// ppo.hip -- the PPO learner for gfx950 (reference: core/policy/ppo.py:96-246, tianshou a2c/base/statistics).
+//
+// prepare   gae_kernel          one thread per env: float64 reverse scan delta_t + gamma*lambda*gae (base.py:380-396),
+//                               v_s/v_s_ un-normalised by sqrt(ret_rms.var + eps) (a2c.py:95-97), compaction to buffer order
+//           returns_kernel      single workgroup: mean / population variance of the un-normalised returns (float64, fixed
+//                               order), normalised returns, RunningMeanStd merge (statistics.py:80-95)
+// minibatch gather -> adv norm -> trunk fwd -> head stats (MFMA, transposed tile, no logits in HBM) -> row scalars
+//           -> head backward: dWa/dba (item-tile owners, Z layout) and dH2 + entropy (row-tile owners, Z^T layout); both
+//              recompute the logits tile on the matrix cores instead of reading a B x I probability matrix
+//           -> trunk / critic backward (small dense kernels) -> d obs scatter (gradient into the state tracker)
+//           -> clip_grad_norm_ (trunk counted twice) -> Adam (trunk: coefficient squared, two sub-steps)
+// Every reduction has a fixed order: two runs (or two ranks of a replicated learner) produce identical bits.
+//
+// Roofline of one minibatch step (mb x I x 64): forward stats 2*mb*I*64 flop + two backward kernels of
+// 2 * 2*mb*I*64 flop each = 10*mb*I*64 flop = 7.0 GFLOP at mb = 1024, I = 10728 on the fp32 MFMA pipe (157 TF peak);
+// HBM traffic is Wa (2.7 MB) + dWa partials (8 x 2.7 MB) + dH2 partials (n_chunks x mb x 256 B = 22 MB): MFMA-bound.
+#include "policy_kernels.h"
+
+namespace cirs {
+
+constexpr int kRowSplits = 8;  // dWa partial slabs (rows of the minibatch split 8 ways)
+
+struct PpoLayout {  // offsets (floats) into the flat parameter buffer
+    long w1, b1, w2, b2, wa, ba, wc, bc, total, trunk;
+};
+__host__ __device__ inline PpoLayout ppo_layout(int I, int S) {
+    PpoLayout L;
+    L.w1 = 0; L.b1 = L.w1 + (long)kH * S; L.w2 = L.b1 + kH; L.b2 = L.w2 + (long)kH * kH;
+    L.trunk = L.b2 + kH;
+    L.wa = L.trunk; L.ba = L.wa + (long)I * kH; L.wc = L.ba + I; L.bc = L.wc + kH; L.total = L.bc + 1;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// prepare
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gae_kernel(cirs_ppo_cfg cfg, cirs_traj traj, const int32_t* __restrict__ lens,
+                                                  const int32_t* __restrict__ offsets, int B, int S,
+                                                  const double* __restrict__ rms_state, cirs_ppo_batch out,
+                                                  double* __restrict__ unnorm_ret) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int L = lens[b], off = offsets[b];
+    const double scale = cfg.rew_norm ? sqrt(rms_state[1] + 1e-8) : 1.0;  // a2c.py:95-97, pg.py:60 (_eps = 1e-8)
+    const double gamma = (double)cfg.gamma, gl = (double)cfg.gamma * (double)cfg.gae_lambda;
+    double gae = 0.0;
+    for (int t = L - 1; t >= 0; --t) {
+        const size_t ti = (size_t)t * B + b;
+        const bool done = traj.done[ti] != 0;
+        const double v_s = (double)traj.value[ti] * scale;
+        // value_mask (base.py:264): V(s') is zeroed on done; otherwise V(s_{t+1}) recorded at the next step
+        const double v_ns = (done || t + 1 >= L) ? 0.0 : (double)traj.value[(size_t)(t + 1) * B + b] * scale;
+        const double end_flag = (done || t == L - 1) ? 1.0 : 0.0;  // done OR unfinished_index (base.py:307-308)
+        const double delta = traj.rew[ti] + v_ns * gamma - v_s;
+        gae = delta + (1.0 - end_flag) * gl * gae;
+        const int row = off + t;
+        out.adv[row] = (float)gae;
+        unnorm_ret[row] = gae + v_s;
+        out.v_s[row] = traj.value[ti];
+        out.logp_old[row] = traj.logp[ti];
+        out.act[row] = (int32_t)traj.act[ti];
+        out.row_env[row] = b;
+        out.row_t[row] = t;
+        for (int k = 0; k < S; ++k) out.obs[(size_t)row * S + k] = traj.obs[ti * S + k];
+    }
+}
+
+// single workgroup, fixed-order float64 reductions
+__global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const double* __restrict__ unnorm_ret, int N,
+                                                       double* __restrict__ rms_state, float* __restrict__ ret_out) {
+    __shared__ double red[1024];
+    __shared__ double s_mean;
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int i = tid; i < N; i += 1024) acc += unnorm_ret[i];
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) s_mean = red[0] / (double)N;
+    __syncthreads();
+    const double mean = s_mean;
+    acc = 0.0;
+    for (int i = tid; i < N; i += 1024) {
+        const double d = unnorm_ret[i] - mean;
+        acc += d * d;
+    }
+    __syncthreads();
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double var = red[0] / (double)N;  // np.var: population variance
+    const double scale = cfg.rew_norm ? sqrt(rms_state[1] + 1e-8) : 1.0;  // OLD variance (a2c.py:101-103)
+    for (int i = tid; i < N; i += 1024) ret_out[i] = (float)(unnorm_ret[i] / scale);
+    __syncthreads();
+    if (tid == 0 && cfg.rew_norm) {  // RunningMeanStd.update (statistics.py:80-95)
+        const double o_mean = rms_state[0], o_var = rms_state[1], o_cnt = rms_state[2];
+        const double bc = (double)N, delta = mean - o_mean, tot = o_cnt + bc;
+        const double new_mean = o_mean + delta * bc / tot;
+        const double m2 = o_var * o_cnt + var * bc + delta * delta * o_cnt * bc / tot;
+        rms_state[0] = new_mean; rms_state[1] = m2 / tot; rms_state[2] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// minibatch: gather + advantage normalisation
+// ------------------------------------------------------------------------------------------------------------
+struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad rows)
+    float *obs, *adv, *ret, *v_s, *logp_old;  // gathered
+    int32_t* act;
+    float *h1, *h2, *value;                   // trunk forward
+    float *lse, *ez, *za;                     // head stats: log-sum-exp, E_p[z], logit of the taken action
+    float *c_logp, *c_ent, *h_ent, *dvalue;   // row coefficients for the backward pass
+    float *ent_row;                           // entropy per row (from the backward pass)
+    float *da2, *da1;                         // [n_pad,64] pre-activation gradients
+    float *dh2p;                              // [n_chunks, n_pad, 64] partial d h2
+    float *entp;                              // [n_chunks, n_pad]
+    float *dwap;                              // [kRowSplits, I*64 + I] partial dWa | dba
+    float *red;                               // [16] scalars: adv mean/std, loss sums, grad norm coef
+    void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
+};
+
+__host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
+    const size_t nch = n_chunks_of(I);
+    size_t f = 0;
+    f += (size_t)n_pad * S + 4 * (size_t)n_pad;       // obs, adv, ret, v_s, logp_old
+    f += n_pad;                                        // act
+    f += 2 * (size_t)n_pad * kH + n_pad;               // h1, h2, value
+    f += 3 * (size_t)n_pad;                            // lse, ez, za
+    f += 4 * (size_t)n_pad + n_pad;                    // c_logp, c_ent, h_ent, dvalue, ent_row
+    f += 2 * (size_t)n_pad * kH;                       // da2, da1
+    f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
+    f += (size_t)kRowSplits * ((size_t)I * kH + I);    // dwap
+    f += 64;                                           // red
+    f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
+    return f;
+}
+
+__host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
+    float* p = (float*)ws;
+    const size_t nch = n_chunks_of(I);
+    MbView v;
+    auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~(size_t)3; return r; };
+    v.obs = take((size_t)n_pad * S); v.adv = take(n_pad); v.ret = take(n_pad); v.v_s = take(n_pad); v.logp_old = take(n_pad);
+    v.act = (int32_t*)take(n_pad);
+    v.h1 = take((size_t)n_pad * kH); v.h2 = take((size_t)n_pad * kH); v.value = take(n_pad);
+    v.lse = take(n_pad); v.ez = take(n_pad); v.za = take(n_pad);
+    v.c_logp = take(n_pad); v.c_ent = take(n_pad); v.h_ent = take(n_pad); v.dvalue = take(n_pad); v.ent_row = take(n_pad);
+    v.da2 = take((size_t)n_pad * kH); v.da1 = take((size_t)n_pad * kH);
+    v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
+    v.dwap = take((size_t)kRowSplits * ((size_t)I * kH + I));
+    v.red = take(64);
+    v.head_ws = (void*)p;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(cirs_ppo_batch b, const int32_t* __restrict__ idx, int mb, int n_pad,
+                                                     int S, MbView v) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    if (r < mb) {
+        const int src = idx[r];
+        for (int k = 0; k < S; ++k) v.obs[(size_t)r * S + k] = b.obs[(size_t)src * S + k];
+        v.adv[r] = b.adv[src]; v.ret[r] = b.ret[src]; v.v_s[r] = b.v_s[src]; v.logp_old[r] = b.logp_old[src];
+        v.act[r] = b.act[src];
+    } else {
+        for (int k = 0; k < S; ++k) v.obs[(size_t)r * S + k] = 0.f;
+        v.adv[r] = 0.f; v.ret[r] = 0.f; v.v_s[r] = 0.f; v.logp_old[r] = 0.f; v.act[r] = 0;
+    }
+}
+
+// b.adv = (b.adv - mean) / std, torch.Tensor.std = unbiased (ppo.py:185-186).  One workgroup, fixed order.
+__global__ __launch_bounds__(1024) void adv_norm_kernel(float* __restrict__ adv, int mb, int enable,
+                                                        float* __restrict__ red) {
+    __shared__ float sh[1024];
+    __shared__ float s_mean;
+    const int tid = threadIdx.x;
+    if (!enable) return;
+    float acc = 0.f;
+    for (int i = tid; i < mb; i += 1024) acc += adv[i];
+    sh[tid] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) s_mean = sh[0] / (float)mb;
+    __syncthreads();
+    const float mean = s_mean;
+    acc = 0.f;
+    for (int i = tid; i < mb; i += 1024) {
+        const float d = adv[i] - mean;
+        acc += d * d;
+    }
+    __syncthreads();
+    sh[tid] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const float stdv = sqrtf(sh[0] / (float)(mb - 1));
+    for (int i = tid; i < mb; i += 1024) adv[i] = (adv[i] - mean) / stdv;
+    if (tid == 0) { red[0] = mean; red[1] = stdv; }
+}
+
+// merge the head-stats partials: lse, E_p[z] (for the entropy), z of the taken action (same k-order as the MFMA)
+__global__ __launch_bounds__(256) void head_stats_merge_kernel(int mb, int n_pad, int n_chunks, ActorPartialView pv,
+                                                               const float* __restrict__ wa, const float* __restrict__ ba,
+                                                               MbView v) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= mb) return;
+    float m = -INFINITY, s = 0.f, t = 0.f;
+    for (int c = lane; c < n_chunks; c += CIRS_WAVE) {
+        const size_t o = (size_t)c * n_pad + j;
+        const float om = pv.m[o], os = pv.s[o], ot = pv.score[o];
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            const float fa = __expf(m - mn), fb = __expf(om - mn);
+            s = s * fa + os * fb; t = t * fa + ot * fb; m = mn;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(m, off, CIRS_WAVE), os = __shfl_xor(s, off, CIRS_WAVE), ot = __shfl_xor(t, off, CIRS_WAVE);
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            const float fa = __expf(m - mn), fb = __expf(om - mn);
+            s = s * fa + os * fb; t = t * fa + ot * fb; m = mn;
+        }
+    }
+    if (lane != 0) return;
+    const int a = v.act[j];
+    const float* wr = wa + (size_t)a * kH;
+    const float* hr = v.h2 + (size_t)j * kH;
+    float z = ba[a];
+    for (int kk = 0; kk < 32; ++kk) {
+        z = __builtin_fmaf(hr[kk], wr[kk], z);
+        z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
+    }
+    v.lse[j] = m + __logf(s);
+    v.ez[j] = t / s;
+    v.za[j] = z;
+}
+
+// per-row loss terms and backward coefficients (ppo.py:183-212); one workgroup, fixed-order loss sums
+__global__ __launch_bounds__(1024) void row_scalar_kernel(cirs_ppo_cfg cfg, int mb, int n_pad, MbView v) {
+    __shared__ float sh_clip[1024], sh_vf[1024];
+    const int tid = threadIdx.x;
+    const float inv_mb = 1.0f / (float)mb;
+    const float eps = 1.1920928955078125e-7f;
+    float a_clip = 0.f, a_vf = 0.f;
+    for (int r = tid; r < n_pad; r += 1024) {
+        if (r >= mb) {
+            v.c_logp[r] = 0.f; v.c_ent[r] = 0.f; v.h_ent[r] = 0.f; v.dvalue[r] = 0.f; v.lse[r] = 1e30f;  // p = exp(z - lse) = 0
+            continue;
+        }
+        const float praw = __expf(v.za[r] - v.lse[r]);
+        const bool clamped = praw < eps || praw > 1.0f - eps;  // probs_to_logits clamp blocks the gradient
+        const float logp = __logf(fminf(fmaxf(praw, eps), 1.0f - eps));
+        const float ratio = __expf(logp - v.logp_old[r]);
+        const float A = v.adv[r];
+        const float s1 = ratio * A;
+        const float s2 = fminf(fmaxf(ratio, 1.0f - cfg.eps_clip), 1.0f + cfg.eps_clip) * A;
+        a_clip += -fminf(s1, s2);
+        // d(-min(s1,s2))/d logp: s1 path when s1 <= s2 (a tie passes the full gradient), else clamp blocks it
+        v.c_logp[r] = (s1 <= s2 && !clamped) ? -inv_mb * A * ratio : 0.f;
+        // value loss
+        const float val = v.value[r], vs = v.v_s[r], ret = v.ret[r];
+        const float d1 = ret - val;
+        float vf = d1 * d1, dv = -2.0f * d1;
+        if (cfg.value_clip) {
+            const float dlt = val - vs;
+            const float vclip = vs + fminf(fmaxf(dlt, -cfg.eps_clip), cfg.eps_clip);
+            const float d2 = ret - vclip;
+            const float vf2 = d2 * d2;
+            const float dv2 = (dlt >= -cfg.eps_clip && dlt <= cfg.eps_clip) ? -2.0f * d2 : 0.f;
+            if (vf2 > vf) { vf = vf2; dv = dv2; }
+            else if (vf2 == vf) dv = 0.5f * (dv + dv2);  // torch.max splits ties
+        }
+        a_vf += vf;
+        v.dvalue[r] = cfg.vf_coef * inv_mb * dv;
+        // entropy gradient coefficient: dL/dz_i += c_ent * p_i * (z_i - lse + H), H = lse - E_p[z]
+        v.c_ent[r] = cfg.ent_coef * inv_mb;
+        v.h_ent[r] = v.lse[r] - v.ez[r];
+    }
+    sh_clip[tid] = a_clip; sh_vf[tid] = a_vf;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) { sh_clip[tid] += sh_clip[tid + s]; sh_vf[tid] += sh_vf[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) { v.red[2] = sh_clip[0] * inv_mb; v.red[3] = sh_vf[0] * inv_mb; }
+}
+
+__device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c_ent, float h_ent, bool is_act, float& p_out) {
+    const float p = __expf(z - lse);
+    p_out = p;
+    return c_logp * ((is_act ? 1.0f : 0.0f) - p) + c_ent * p * (z - lse + h_ent);
+}
+
+// ---- head backward 1: dWa, dba.  Z layout (lane owns an ITEM column, registers are rows) -----------------------
+// grid = (ceil(n_item_tiles/4), kRowSplits); wave = one item tile; loops over the row tiles of its split.
+//   Z[32 rows x 32 items]   = H2_tile * Wa_tile^T           (A = H2 rows, B = Wa rows)
+//   dWa_tile[32 items x 64] += dZ^T[items x rows] * H2_tile   (A = dZ registers AS THEY ARE, B = H2[row(s,hi)][n])
+__global__ __launch_bounds__(256, 2) void head_bwd_dwa_kernel(int I, int mb, int n_pad, const float* __restrict__ wa,
+                                                              const float* __restrict__ ba, MbView v,
+                                                              float* __restrict__ dwap) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int tile0 = (blockIdx.x * 4 + wv) * kTileN;
+    if (tile0 >= I) return;
+    const int split = blockIdx.y;
+    const int item = tile0 + lo;
+    const bool item_ok = item < I;
+    float wrow[32];
+    if (item_ok) {
+        const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item * kH + hi * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t4 = src[q];
+            wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) wrow[q] = 0.f;
+    }
+    const float bias = item_ok ? ba[item] : 0.f;
+    f32x16 dw0, dw1;  // dWa^T accumulators: items x k[0..31], items x k[32..63]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
+    float db = 0.f;
+    const int n_row_tiles = n_pad / kTileM;
+    const int per = (n_row_tiles + kRowSplits - 1) / kRowSplits;
+    const int rt_beg = split * per, rt_end = min(n_row_tiles, rt_beg + per);
+    for (int rt = rt_beg; rt < rt_end; ++rt) {
+        const int row0 = rt * kTileM;
+        float hrow[32];
+        {
+            const float4* src = reinterpret_cast<const float4*>(v.h2 + (size_t)(row0 + lo) * kH + hi * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 t4 = src[q];
+                hrow[4 * q] = t4.x; hrow[4 * q + 1] = t4.y; hrow[4 * q + 2] = t4.z; hrow[4 * q + 3] = t4.w;
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[kk], wrow[kk], acc, 0, 0, 0);
+        // dZ in place (rows beyond mb have c = 0 -> dZ = 0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float p;
+            const float d = item_ok ? dz_of(acc[r], v.lse[row], v.c_logp[row], v.c_ent[row], v.h_ent[row], v.act[row] == item, p) : 0.f;
+            acc[r] = d;
+            db += d;
+        }
+        // dWa^T += dZ^T * H2 : step r pairs rows row(r,0), row(r,1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float b0 = v.h2[(size_t)row * kH + lo];
+            const float b1 = v.h2[(size_t)row * kH + 32 + lo];
+            dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dw0, 0, 0, 0);
+            dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dw1, 0, 0, 0);
+        }
+    }
+    // store partial slab: C layout col = k (lane lo), rows = items (r&3)+8*(r>>2)+4*hi
+    float* slab = dwap + (size_t)split * ((size_t)I * kH + I);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int it = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (it < I) {
+            slab[(size_t)it * kH + lo] = dw0[r];
+            slab[(size_t)it * kH + 32 + lo] = dw1[r];
+        }
+    }
+    db += __shfl_xor(db, 32, CIRS_WAVE);
+    if (hi == 0 && item_ok) slab[(size_t)I * kH + item] = db;
+}
+
+// ---- head backward 2: d h2 + entropy.  Z^T layout (lane owns a ROW, registers are items) -----------------------
+// grid = (n_chunks, ceil(n_pad/32/4)); wave = one row tile x one item chunk.
+//   ZT[32 items x 32 rows] = Wa_tile * H2_tile^T
+//   dH2_tile[32 rows x 64] += dZ[rows x items] * Wa_tile      (A = dZT registers AS THEY ARE, B = Wa[item(s,hi)][n])
+__global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int n_pad, const float* __restrict__ wa,
+                                                              const float* __restrict__ ba, MbView v) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int row0 = (blockIdx.y * 4 + wv) * kTileM;
+    if (row0 >= n_pad) return;
+    const int chunk = blockIdx.x;
+    const int jr = row0 + lo;
+    float hrow[32];
+    {
+        const float4* src = reinterpret_cast<const float4*>(v.h2 + (size_t)jr * kH + hi * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t4 = src[q];
+            hrow[4 * q] = t4.x; hrow[4 * q + 1] = t4.y; hrow[4 * q + 2] = t4.z; hrow[4 * q + 3] = t4.w;
+        }
+    }
+    const float lse = v.lse[jr], c_logp = v.c_logp[jr], c_ent = v.c_ent[jr], h_ent = v.h_ent[jr];
+    const int act = v.act[jr];
+    const bool row_ok = jr < mb;
+    f32x16 dh0, dh1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dh0[r] = 0.f; dh1[r] = 0.f; }
+    float ent = 0.f;
+    const float eps = 1.1920928955078125e-7f;
+    for (int it = 0; it < kTilesPerChunk; ++it) {
+        const int tile0 = chunk * kChunkItems + it * kTileN;
+        if (tile0 >= I) break;
+        const int item_a = tile0 + lo;
+        float wrow[32];
+        if (item_a < I) {
+            const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item_a * kH + hi * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 t4 = src[q];
+                wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) wrow[q] = 0.f;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i0 = tile0 + 8 * g + 4 * hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[4 * g + q] = (i0 + q) < I ? ba[i0 + q] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int item = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float d = 0.f;
+            if (item < I && row_ok) {
+                float p;
+                d = dz_of(acc[r], lse, c_logp, c_ent, h_ent, item == act, p);
+                ent -= p * __logf(fminf(fmaxf(p, eps), 1.0f - eps));  // Categorical.entropy with the clamped log
+            }
+            acc[r] = d;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int item = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float b0 = 0.f, b1 = 0.f;
+            if (item < I) {
+                b0 = wa[(size_t)item * kH + lo];
+                b1 = wa[(size_t)item * kH + 32 + lo];
+            }
+            dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dh0, 0, 0, 0);
+            dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dh1, 0, 0, 0);
+        }
+    }
+    float* slab = v.dh2p + (size_t)chunk * n_pad * kH;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        slab[(size_t)row * kH + lo] = dh0[r];
+        slab[(size_t)row * kH + 32 + lo] = dh1[r];
+    }
+    ent += __shfl_xor(ent, 32, CIRS_WAVE);
+    if (hi == 0) v.entp[(size_t)chunk * n_pad + jr] = ent;
+}
+
+// sum the dWa slabs in fixed order into the flat gradient buffer (wa | ba segments are contiguous)
+__global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict__ dwap, long seg, float* __restrict__ g_wa_ba) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= seg) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < kRowSplits; ++s) acc += dwap[(size_t)s * seg + i];
+    g_wa_ba[i] = acc;
+}
+
+// d a2 = (sum_chunks d h2 partial + dvalue * wc) * relu'(h2) ; entropy per row
+__global__ __launch_bounds__(256) void finalize_dh2_kernel(int mb, int n_pad, int n_chunks, const float* __restrict__ wc, MbView v) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)n_pad * kH) return;
+    const int r = (int)(i / kH), k = (int)(i % kH);
+    float acc = 0.f;
+    for (int c = 0; c < n_chunks; ++c) acc += v.dh2p[(size_t)c * n_pad * kH + i];
+    acc = __builtin_fmaf(v.dvalue[r], wc[k], acc);
+    v.da2[i] = (r < mb && v.h2[i] > 0.f) ? acc : 0.f;
+    if (k == 0) {
+        float e = 0.f;
+        for (int c = 0; c < n_chunks; ++c) e += v.entp[(size_t)c * n_pad + r];
+        v.ent_row[r] = r < mb ? e : 0.f;
+    }
+}
+
+// dX[r,k] = sum_o dY[r,o] * W[o,k]  (optionally masked by relu'(act[r,k]))
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dY, const float* __restrict__ W, int R,
+                                                            int O, int K, const float* __restrict__ relu_of,
+                                                            float* __restrict__ dX) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)R * K) return;
+    const int r = (int)(i / K), k = (int)(i % K);
+    float acc = 0.f;
+    for (int o = 0; o < O; ++o) acc = __builtin_fmaf(dY[(size_t)r * O + o], W[(size_t)o * K + k], acc);
+    if (relu_of && !(relu_of[i] > 0.f)) acc = 0.f;
+    dX[i] = acc;
+}
+
+// dW[o,k] = sum_r dY[r,o] * X[r,k] ; db[o] = sum_r dY[r,o]   (sequential over r: fixed order)
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, int R,
+                                                            int O, int K, float* __restrict__ dW, float* __restrict__ db) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)O * (K + 1)) return;
+    const int o = (int)(i / (K + 1)), k = (int)(i % (K + 1));
+    float acc = 0.f;
+    if (k < K) {
+        for (int r = 0; r < R; ++r) acc = __builtin_fmaf(dY[(size_t)r * O + o], X[(size_t)r * K + k], acc);
+        dW[(size_t)o * K + k] = acc;
+    } else {
+        for (int r = 0; r < R; ++r) acc += dY[(size_t)r * O + o];
+        db[o] = acc;
+    }
+}
+
+// critic head: d wc[k] = sum_r dvalue_r * h2[r,k], d bc = sum_r dvalue_r
+__global__ __launch_bounds__(128) void critic_bwd_kernel(int mb, MbView v, float* __restrict__ g_wc, float* __restrict__ g_bc) {
+    const int k = threadIdx.x;
+    if (k < kH) {
+        float acc = 0.f;
+        for (int r = 0; r < mb; ++r) acc = __builtin_fmaf(v.dvalue[r], v.h2[(size_t)r * kH + k], acc);
+        g_wc[k] = acc;
+    } else if (k == kH) {
+        float acc = 0.f;
+        for (int r = 0; r < mb; ++r) acc += v.dvalue[r];
+        g_bc[0] = acc;
+    }
+}
+
+// d obs rows -> tracker gradient tensor [T+1, B, S] at (row_t, row_env)
+__global__ __launch_bounds__(256) void scatter_dobs_kernel(const float* __restrict__ dobs, const int32_t* __restrict__ idx,
+                                                           cirs_ppo_batch b, int mb, int S, int n_env,
+                                                           float* __restrict__ accum) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)mb * S) return;
+    const int r = (int)(i / S), k = (int)(i % S);
+    const int row = idx[r];
+    accum[((size_t)b.row_t[row] * n_env + b.row_env[row]) * S + k] = dobs[i];
+}
+
+// clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1); also the
+// entropy mean and the total loss.  One workgroup, fixed order.
+__global__ __launch_bounds__(1024) void gradnorm_kernel(cirs_ppo_cfg cfg, const float* __restrict__ g, long n_trunk, long n_total,
+                                                        int mb, MbView v, float* __restrict__ loss_out) {
+    __shared__ float sh[1024];
+    const int tid = threadIdx.x;
+    float acc = 0.f;
+    for (long i = tid; i < n_total; i += 1024) {
+        const float x = g[i];
+        acc += (i < n_trunk ? 2.0f : 1.0f) * x * x;
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const float total_norm = sqrtf(sh[0]);
+    __syncthreads();
+    float e = 0.f;
+    for (int r = tid; r < mb; r += 1024) e += v.ent_row[r];
+    sh[tid] = e;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float coef = 1.0f;
+        if (cfg.max_grad_norm > 0.f) coef = fminf(cfg.max_grad_norm / (total_norm + 1e-6f), 1.0f);
+        v.red[4] = coef;
+        v.red[5] = total_norm;
+        const float ent = sh[0] / (float)mb;
+        const float clip = v.red[2], vf = v.red[3];
+        loss_out[0] = clip + cfg.vf_coef * vf - cfg.ent_coef * ent;
+        loss_out[1] = clip; loss_out[2] = vf; loss_out[3] = ent;
+    }
+}
+
+// torch.optim.Adam (_single_tensor_adam): lerp_, mul_/addcmul_, bias corrections from the step count
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, int n_sub, float beta1, float beta2, float eps,
+                                                   float step_size0, float bc2s0, float step_size1, float bc2s1,
+                                                   const float* __restrict__ grad_scale, int scale_pow) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    if (grad_scale) {
+        const float c = grad_scale[0];
+        for (int q = 0; q < scale_pow; ++q) gi *= c;  // clip coefficient applied once per occurrence in the param list
+    }
+    float pi = p[i], mi = m[i], vi = v[i];
+    for (int sub = 0; sub < n_sub; ++sub) {
+        mi = mi + (1.0f - beta1) * (gi - mi);                 // exp_avg.lerp_(grad, 1 - beta1)
+        vi = vi * beta2 + (1.0f - beta2) * gi * gi;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float ss = sub == 0 ? step_size0 : step_size1;
+        const float b2 = sub == 0 ? bc2s0 : bc2s1;
+        const float denom = sqrtf(vi) / b2 + eps;
+        pi = pi - ss * (mi / denom);                          // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+static int launch_adam(float* p, const float* g, float* m, float* v, long n, long step_before, int n_sub, float lr, float b1,
+                       float b2, float eps, const float* grad_scale, int scale_pow, hipStream_t s) {
+    CIRS_REQUIRE(n_sub == 1 || n_sub == 2, "n_sub must be 1 or 2");
+    double ss[2] = {0, 0}, bs[2] = {1, 1};
+    for (int q = 0; q < n_sub; ++q) {
+        const double t = (double)(step_before + 1 + q);
+        ss[q] = (double)lr / (1.0 - pow((double)b1, t));
+        bs[q] = sqrt(1.0 - pow((double)b2, t));
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, g, m, v, n, n_sub, b1, b2, eps, (float)ss[0],
+                       (float)bs[0], (float)ss[1], (float)bs[1], grad_scale, scale_pow);
+    CIRS_CHECK_LAUNCH("adam_kernel");
+    return CIRS_OK;
+}
+
+static int validate_ppo(const cirs_ppo_cfg* cfg) {
+    CIRS_REQUIRE(cfg, "ppo cfg null");
+    if (cfg->hidden != kH) return fail(CIRS_E_UNSUPPORTED, "this build supports hidden == 64 only");
+    CIRS_REQUIRE(cfg->n_items > 0 && cfg->dim_state > 0 && cfg->dim_state <= 64, "bad n_items/dim_state");
+    return CIRS_OK;
+}
+
+}  // namespace cirs
+
+extern "C" int64_t cirs_ppo_param_count(const cirs_ppo_cfg* cfg) {
+    if (!cfg) return 0;
+    return cirs::ppo_layout(cfg->n_items, cfg->dim_state).total;
+}
+
+extern "C" int64_t cirs_ppo_workspace_bytes(const cirs_ppo_cfg* cfg, int32_t max_minibatch) {
+    using namespace cirs;
+    if (!cfg || max_minibatch <= 0) return 0;
+    return (int64_t)(mb_ws_floats(n_pad_of(max_minibatch), cfg->n_items, cfg->dim_state) + 64 * 32) * 4;
+}
+
+extern "C" int cirs_ppo_prepare(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens,
+                                const int32_t* offsets, int32_t n_env, int32_t max_turn, int32_t n_rows,
+                                double* rms_state, const cirs_ppo_batch* out, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_ppo(cfg)) return rc;
+    CIRS_REQUIRE(traj && lens && offsets && rms_state && out, "null argument");
+    CIRS_REQUIRE(out->obs && out->act && out->adv && out->ret && out->v_s && out->logp_old && out->row_env && out->row_t, "batch pointer null");
+    CIRS_REQUIRE(n_env > 0 && max_turn > 0 && n_rows > 0, "bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    // float64 scratch for the un-normalised returns lives in the ret buffer's shadow: allocate on the stream
+    double* unnorm = nullptr;
+    CIRS_HIP(hipMallocAsync((void**)&unnorm, sizeof(double) * (size_t)n_rows, s));
+    hipLaunchKernelGGL(gae_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, *cfg, *traj, lens, offsets, n_env, cfg->dim_state,
+                       rms_state, *out, unnorm);
+    CIRS_CHECK_LAUNCH("gae_kernel");
+    hipLaunchKernelGGL(returns_kernel, dim3(1), dim3(1024), 0, s, *cfg, unnorm, n_rows, rms_state, out->ret);
+    CIRS_CHECK_LAUNCH("returns_kernel");
+    CIRS_HIP(hipFreeAsync(unnorm, s));
+    return CIRS_OK;
+}
+
+extern "C" int cirs_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t step_before,
+                              int32_t n_sub, float lr, float beta1, float beta2, float eps, const float* grad_scale,
+                              int32_t scale_pow, void* stream) {
+    using namespace cirs;
+    CIRS_REQUIRE(params && grads && m && v && n > 0, "bad arguments");
+    return launch_adam(params, grads, m, v, n, step_before, n_sub, lr, beta1, beta2, eps, grad_scale, scale_pow, (hipStream_t)stream);
+}
+
+extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
+                                  int64_t opt_step, const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb,
+                                  float* dobs_accum, int32_t n_env, float* loss_out, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_ppo(cfg)) return rc;
+    CIRS_REQUIRE(params && grads && adam_m && adam_v && batch && idx && loss_out && workspace, "null argument");
+    CIRS_REQUIRE(mb >= 2, "minibatch needs >= 2 rows (unbiased std)");
+    CIRS_REQUIRE(workspace_bytes >= cirs_ppo_workspace_bytes(cfg, mb), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int I = cfg->n_items, S = cfg->dim_state;
+    const int n_pad = n_pad_of(mb), n_chunks = n_chunks_of(I);
+    const PpoLayout L = ppo_layout(I, S);
+    MbView v = carve(workspace, n_pad, I, S);
+    cirs_policy_cfg pcfg{I, S, kH};
+    cirs_policy_weights w{params + L.w1, params + L.b1, params + L.w2, params + L.b2,
+                          params + L.wa, params + L.ba, params + L.wc, params + L.bc};
+    // 1. gather + advantage normalisation
+    hipLaunchKernelGGL(gather_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, s, *batch, idx, mb, n_pad, S, v);
+    CIRS_CHECK_LAUNCH("gather_kernel");
+    hipLaunchKernelGGL(adv_norm_kernel, dim3(1), dim3(1024), 0, s, v.adv, mb, cfg->norm_adv, v.red);
+    CIRS_CHECK_LAUNCH("adv_norm_kernel");
+    // 2. trunk forward (same fma chains as the rollout -> ratio == 1 exactly while the weights are unchanged)
+    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, pcfg, w, v.obs, (long)S, n_pad, (const uint8_t*)nullptr,
+                       v.h2, v.value, v.h1);
+    CIRS_CHECK_LAUNCH("trunk_kernel");
+    // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores
+    ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
+    hipLaunchKernelGGL(actor_head_kernel<false>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, pcfg, w.wa, w.ba,
+                       v.h2, mb, (const float*)nullptr, (uint64_t)0, 0u, (const int32_t*)nullptr, (const uint32_t*)nullptr,
+                       (const uint8_t*)nullptr, pv, n_pad);
+    CIRS_CHECK_LAUNCH("actor_head_kernel<stats>");
+    hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(mb, 4)), dim3(256), 0, s, mb, n_pad, n_chunks, pv, w.wa, w.ba, v);
+    CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
+    // 4. row losses + backward coefficients
+    hipLaunchKernelGGL(row_scalar_kernel, dim3(1), dim3(1024), 0, s, *cfg, mb, n_pad, v);
+    CIRS_CHECK_LAUNCH("row_scalar_kernel");
+    // 5. head backward
+    const int n_item_tiles = cdiv(I, kTileN);
+    hipLaunchKernelGGL(head_bwd_dwa_kernel, dim3(cdiv(n_item_tiles, 4), kRowSplits), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v, v.dwap);
+    CIRS_CHECK_LAUNCH("head_bwd_dwa_kernel");
+    hipLaunchKernelGGL(head_bwd_dh2_kernel, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v);
+    CIRS_CHECK_LAUNCH("head_bwd_dh2_kernel");
+    const long seg = (long)I * kH + I;
+    hipLaunchKernelGGL(reduce_dwa_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, s, v.dwap, seg, grads + L.wa);
+    CIRS_CHECK_LAUNCH("reduce_dwa_kernel");
+    hipLaunchKernelGGL(finalize_dh2_kernel, dim3(cdiv((long)n_pad * kH, 256)), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
+    CIRS_CHECK_LAUNCH("finalize_dh2_kernel");
+    // 6. critic + trunk backward
+    hipLaunchKernelGGL(critic_bwd_kernel, dim3(1), dim3(128), 0, s, mb, v, grads + L.wc, grads + L.bc);
+    CIRS_CHECK_LAUNCH("critic_bwd_kernel");
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv((long)kH * (kH + 1), 256)), dim3(256), 0, s, v.da2, v.h1, mb, kH, kH,
+                       grads + L.w2, grads + L.b2);
+    CIRS_CHECK_LAUNCH("linear_bwd_dw_kernel(w2)");
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv((long)n_pad * kH, 256)), dim3(256), 0, s, v.da2, w.w2, n_pad, kH, kH,
+                       v.h1, v.da1);
+    CIRS_CHECK_LAUNCH("linear_bwd_dx_kernel(h1)");
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv((long)kH * (S + 1), 256)), dim3(256), 0, s, v.da1, v.obs, mb, kH, S,
+                       grads + L.w1, grads + L.b1);
+    CIRS_CHECK_LAUNCH("linear_bwd_dw_kernel(w1)");
+    if (dobs_accum) {
+        float* dobs = v.dh2p;  // reuse: partial slabs are consumed
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv((long)mb * S, 256)), dim3(256), 0, s, v.da1, w.w1, mb, kH, S,
+                           (const float*)nullptr, dobs);
+        CIRS_CHECK_LAUNCH("linear_bwd_dx_kernel(obs)");
+        hipLaunchKernelGGL(scatter_dobs_kernel, dim3(cdiv((long)mb * S, 256)), dim3(256), 0, s, dobs, idx, *batch, mb, S, n_env, dobs_accum);
+        CIRS_CHECK_LAUNCH("scatter_dobs_kernel");
+    }
+    // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps; heads: once)
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(1), dim3(1024), 0, s, *cfg, grads, L.trunk, L.total, mb, v, loss_out);
+    CIRS_CHECK_LAUNCH("gradnorm_kernel");
+    if (int rc = launch_adam(params, grads, adam_m, adam_v, L.trunk, 2 * opt_step, 2, cfg->lr, cfg->beta1, cfg->beta2,
+                             cfg->adam_eps, v.red + 4, 2, s))
+        return rc;
+    return launch_adam(params + L.trunk, grads + L.trunk, adam_m + L.trunk, adam_v + L.trunk, L.total - L.trunk, opt_step, 1,
+                       cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps, v.red + 4, 1, s);
+}

@@ -221,6 +221,64 @@ int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_t
                        uint32_t* visited, int32_t force_length, void* workspace, int64_t workspace_bytes,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Learner: PPO update over the collected trajectories
+ * replaces  tianshou/policy/base.py:219-244 (update), :271-313 (compute_episodic_return), :380-396 (_gae_return)
+ *           tianshou/policy/modelfree/a2c.py:80-109 (_compute_returns), tianshou/utils/statistics.py:80-95 (RunningMeanStd)
+ *           core/policy/ppo.py:96-109 (process_fn), :166-246 (learn), torch.optim.Adam, clip_grad_norm_
+ * Rows are kept in BUFFER ORDER (VectorReplayBuffer: env-major concatenation of each env's episode), so minibatch
+ * index arrays drawn from np.random.permutation(N) mean the same rows as in the reference (batch.py:734-744).
+ * v_s / v_s_ / logp_old are the values recorded at rollout time: the policy has not changed since, so they equal
+ * what process_fn recomputes (a2c.py:83-88, ppo.py:104-108).
+ * Reference quirks kept: the shared trunk appears twice in the optimiser and in clip_grad_norm_ ->
+ * its squared gradient norm counts twice, the clip coefficient is applied twice and every optimiser step runs two
+ * sequential Adam sub-steps on the trunk.
+ * Parameter / gradient / Adam-moment buffers are FLAT fp32 with the layout
+ *   [ w1 (H*S) | b1 (H) | w2 (H*H) | b2 (H) | wa (I*H) | ba (I) | wc (H) | bc (1) ]     (trunk = first four)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct cirs_ppo_cfg {
+    int32_t n_items, dim_state, hidden;
+    int32_t norm_adv, value_clip, rew_norm;
+    float gamma, gae_lambda, eps_clip, vf_coef, ent_coef, max_grad_norm;
+    float lr, beta1, beta2, adam_eps;
+} cirs_ppo_cfg;
+
+typedef struct cirs_ppo_batch { /* N rows, buffer order */
+    float* obs;        /* [N,S]  s_t                                    */
+    int32_t* act;      /* [N]                                           */
+    float* adv;        /* [N]    GAE advantage (float32 of the float64) */
+    float* ret;        /* [N]    normalised returns                     */
+    float* v_s;        /* [N]    old value (normalised scale)           */
+    float* logp_old;   /* [N]                                           */
+    int32_t* row_env;  /* [N]    env of the row                         */
+    int32_t* row_t;    /* [N]    turn of the row                        */
+} cirs_ppo_batch;
+
+int64_t cirs_ppo_param_count(const cirs_ppo_cfg* cfg);
+int64_t cirs_ppo_workspace_bytes(const cirs_ppo_cfg* cfg, int32_t max_minibatch);
+
+/* process_fn: GAE (float64) per env, return normalisation with the running variance, RunningMeanStd update, and
+ * compaction of the time-major trajectory into buffer order.  lens[B] = episode lengths, offsets[B] = exclusive
+ * prefix sum of lens (row of env b's first transition).  rms_state = {mean, var, count} (float64, device). */
+int cirs_ppo_prepare(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, const int32_t* offsets,
+                     int32_t n_env, int32_t max_turn, int32_t n_rows, double* rms_state, const cirs_ppo_batch* out,
+                     void* stream);
+
+/* one minibatch gradient step of learn(): forward, clipped surrogate + clipped value loss + entropy, backward,
+ * clip_grad_norm_, Adam.  idx[mb] are buffer-order row ids.  opt_step = optimiser steps taken so far.
+ * dobs_accum (nullable) [T+1, B, S]: d loss / d obs rows are written at (row_t, row_env) -- the gradient that flows
+ * into the state tracker through the stored obs (ppo.py:215 retain_graph).  loss_out[4] = {loss, clip, vf, ent}. */
+int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
+                       int64_t opt_step, const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb,
+                       float* dobs_accum, int32_t n_env, float* loss_out, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+
+/* torch.optim.Adam single-tensor update over a flat buffer, `n_sub` sequential sub-steps with the same gradient
+ * starting at step `step_before`+1; grad is multiplied by (*grad_scale)^scale_pow when grad_scale != NULL. */
+int cirs_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t step_before,
+                   int32_t n_sub, float lr, float beta1, float beta2, float eps, const float* grad_scale,
+                   int32_t scale_pow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -205,6 +205,7 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
     trk_grads = None
     for rep in range(repeat):
         trk_grads = {k: torch.zeros_like(v) for k, v in tparams.items()}  # optim_state.zero_grad()
+        dobs_rows = torch.zeros(N, obs.shape[1])
         perm = np.asarray(perms[pi]); pi += 1
         starts = list(range(0, N, batch_size))
         merge_last = N % batch_size > 0
@@ -232,11 +233,12 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
             loss = clip_loss + vf_coef * vf_loss - ent_coef * ent_loss
             plist = [pp[k] for k in names_trunk + names_head]
             tlist = list(tparams.values())
-            grads = torch.autograd.grad(loss, plist + tlist, retain_graph=True, allow_unused=True)
+            grads = torch.autograd.grad(loss, plist + tlist + [obs], retain_graph=True, allow_unused=True)
             gp = dict(zip(names_trunk + names_head, grads[:len(plist)]))
-            for k, gk in zip(tparams.keys(), grads[len(plist):]):
+            for k, gk in zip(tparams.keys(), grads[len(plist):-1]):
                 if gk is not None:
                     trk_grads[k] += gk
+            dobs_rows += grads[-1]
             for k in pp:
                 pp[k].requires_grad_(False)
             # clip_grad_norm_ over [trunk..., wa, ba, trunk..., wc, bc]: trunk counted twice, scaled twice
@@ -254,5 +256,6 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
             v.requires_grad_(False)
             adam_substeps(v, trk_grads[k], st_trk[k], lr, 1)
     out.update(returns=returns.numpy(), adv=adv_t.numpy(), v_s=v_s_t.numpy(), logp_old=logp_old.numpy(), ret_rms=ret_rms,
-               trk_grads={k: g.clone() for k, g in trk_grads.items()}, obs=obs.detach().numpy())
+               trk_grads={k: g.clone() for k, g in trk_grads.items()}, obs=obs.detach().numpy(),
+               dobs_rows=dobs_rows.numpy(), logits_old=None)
     return out
