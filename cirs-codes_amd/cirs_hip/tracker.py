@@ -43,6 +43,39 @@ def weights_struct(params: Dict[str, torch.Tensor], pe: torch.Tensor, nlayers: i
     return w
 
 
+def tracker_param_shapes(n_users, n_items, dim_model=32, dim_state=20, d_hid=128, nlayers=2):
+    """Ordered {reference state_dict name: shape} of the trainable tracker tensors."""
+    D, S, H = dim_model, dim_state, d_hid
+    sh = {"embedding_dict.feat_user.weight": (n_users, D), "embedding_dict.feat_item.weight": (n_items, D),
+          "ffn_user.weight": (D, D), "ffn_user.bias": (D,), "fnn_gate.weight": (D, D + 1), "fnn_gate.bias": (D,)}
+    for l in range(nlayers):
+        pre = f"transformer_encoder.layers.{l}."
+        sh.update({pre + "self_attn.in_proj_weight": (3 * D, D), pre + "self_attn.in_proj_bias": (3 * D,),
+                   pre + "self_attn.out_proj.weight": (D, D), pre + "self_attn.out_proj.bias": (D,),
+                   pre + "linear1.weight": (H, D), pre + "linear1.bias": (H,), pre + "linear2.weight": (D, H),
+                   pre + "linear2.bias": (D,), pre + "norm1.weight": (D,), pre + "norm1.bias": (D,),
+                   pre + "norm2.weight": (D,), pre + "norm2.bias": (D,)})
+    sh.update({"decoder.weight": (S, D), "decoder.bias": (S,)})
+    return sh
+
+
+def flat_tracker_params(shapes, device="cuda", init=None):
+    """One flat fp32 buffer + named views (so a single Adam launch covers every tracker tensor)."""
+    import numpy as np
+    total = sum(int(np.prod(v)) for v in shapes.values())
+    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    views, off = {}, 0
+    for k, shp in shapes.items():
+        n = int(np.prod(shp))
+        views[k] = flat[off:off + n].view(shp)
+        off += n
+    if init is not None:
+        for k, t in init.items():
+            if k in views:
+                views[k].copy_(t.to(device=device, dtype=torch.float32).reshape(views[k].shape))
+    return flat, views
+
+
 class DeviceTracker:
     """KV-cached tracker state for B envs.  `params` maps reference state_dict names to device tensors."""
 
@@ -71,6 +104,40 @@ class DeviceTracker:
 
     def refresh_weights(self):
         self.w = weights_struct(self.params, self.pe, self.nlayers)
+
+    # ---- training side: gradient through the stored obs + Adam ------------------------------------------------
+    def enable_training(self, flat_params: torch.Tensor, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        """`flat_params` must be the flat buffer self.params' tensors are views of (flat_tracker_params)."""
+        shapes = {k: tuple(v.shape) for k, v in self.params.items() if k != "pos_encoder.pe"}
+        self.flat = flat_params
+        self.flat_grad, self.grad_views = flat_tracker_params(shapes, device=self.device)
+        assert self.flat_grad.numel() == flat_params.numel()
+        self.g = weights_struct({**self.grad_views}, self.pe, self.nlayers)  # same field layout, pe unused
+        self.adam_m = torch.zeros_like(flat_params)
+        self.adam_v = torch.zeros_like(flat_params)
+        self.adam_steps = 0
+        self.lr, self.betas, self.adam_eps = lr, betas, eps
+        self._bws = None
+
+    def backward(self, users, traj, row_env, row_t, offsets, lens, n_rows, dstate):
+        """d loss / d tracker params from d loss / d obs (dstate [T+1,B,S]); fills self.flat_grad."""
+        users = users.to(self.device, torch.int32).contiguous()
+        need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(self.cfg), n_rows)
+        if self._bws is None or self._bws.numel() < need:
+            self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        abi.check(self._lib.cirs_tracker_backward(
+            C.byref(self.cfg), C.byref(self.w), C.byref(self.st), users.data_ptr(), traj.act.data_ptr(),
+            traj.rew.data_ptr(), row_env.data_ptr(), row_t.data_ptr(), offsets.data_ptr(), lens.data_ptr(), n_rows,
+            dstate.data_ptr(), C.byref(self.g), self._bws.data_ptr(), self._bws.numel(), self._stream()),
+            "cirs_tracker_backward")
+
+    def adam_update(self):
+        """optim_state.step(): one torch.optim.Adam step over every tracker tensor (ppo.py:235)."""
+        abi.check(self._lib.cirs_adam_step(self.flat.data_ptr(), self.flat_grad.data_ptr(), self.adam_m.data_ptr(),
+                                           self.adam_v.data_ptr(), self.flat.numel(), self.adam_steps, 1, self.lr,
+                                           self.betas[0], self.betas[1], self.adam_eps, None, 0, self._stream()),
+                  "cirs_adam_step")
+        self.adam_steps += 1
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream

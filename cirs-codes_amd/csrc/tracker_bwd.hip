@@ -1,0 +1,515 @@
+// tracker_bwd.hip -- gradient of the PPO loss w.r.t. the state tracker (reference: the autograd graph kept alive by
+// core/policy/ppo.py:215 loss.backward(retain_graph=True); structure of the tracker: core/state_tracker.py:170-250).
+//
+// Rows = buffer rows (env b, position p = t, p < len_b), env-major, so the keys/values an attention row needs are
+// the contiguous rows offsets[b] .. offsets[b]+p.  Forward activations are recomputed layer by layer into row-major
+// scratch and the backward walks the layers in reverse.  Kernels are "one thread per (row, feature)" dense ops and
+// "one wavefront per row" attention ops: the tensors are tiny (<= 128 features) and the work is latency-bound, what
+// matters is that everything stays on device and every reduction has a fixed order.
+//   weight gradients : chunk-partial sums over 256-row chunks, then an ordered sum over chunks (two launches)
+//   embedding tables : zeroed, then one atomicAdd per (row, dim) -- the only order-dependent float sum in the path
+#include "common.h"
+
+namespace cirs {
+
+constexpr int tD = 32, tH = 128;
+constexpr int kChunkRows = 256;
+
+// Y[r,o] = b[o] + sum_k X[r,k] W[o,k]   (optional relu)
+__global__ __launch_bounds__(256) void lin_fwd(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
+                                               int R, int O, int K, int relu, float* __restrict__ Y) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)R * O) return;
+    const int r = (int)(i / O), o = (int)(i % O);
+    float acc = b ? b[o] : 0.f;
+    const float* x = X + (size_t)r * K;
+    const float* w = W + (size_t)o * K;
+    for (int k = 0; k < K; ++k) acc = __builtin_fmaf(x[k], w[k], acc);
+    Y[i] = relu ? fmaxf(acc, 0.f) : acc;
+}
+
+// dX[r,k] (+)= sum_o dY[r,o] W[o,k]   ; mask: zero where relu_of[r,k] <= 0
+__global__ __launch_bounds__(256) void lin_bwd_dx(const float* __restrict__ dY, const float* __restrict__ W, int R, int O, int K,
+                                                  const float* __restrict__ relu_of, int accumulate, float* __restrict__ dX) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)R * K) return;
+    const int r = (int)(i / K), k = (int)(i % K);
+    float acc = 0.f;
+    const float* dy = dY + (size_t)r * O;
+    for (int o = 0; o < O; ++o) acc = __builtin_fmaf(dy[o], W[(size_t)o * K + k], acc);
+    if (relu_of && !(relu_of[i] > 0.f)) acc = 0.f;
+    dX[i] = accumulate ? dX[i] + acc : acc;
+}
+
+// stage 1: partial[c][o*(K+1)+k] = sum over the 256 rows of chunk c of dY[r,o]*X[r,k] (k == K: bias column)
+__global__ __launch_bounds__(256) void lin_bwd_dw_partial(const float* __restrict__ dY, const float* __restrict__ X, int R, int O,
+                                                          int K, float* __restrict__ partial) {
+    const int c = blockIdx.y;
+    const int r0 = c * kChunkRows, r1 = min(R, r0 + kChunkRows);
+    const int n_out = O * (K + 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += gridDim.x * blockDim.x) {
+        const int o = i / (K + 1), k = i % (K + 1);
+        float acc = 0.f;
+        if (k < K) for (int r = r0; r < r1; ++r) acc = __builtin_fmaf(dY[(size_t)r * O + o], X[(size_t)r * K + k], acc);
+        else for (int r = r0; r < r1; ++r) acc += dY[(size_t)r * O + o];
+        partial[(size_t)c * n_out + i] = acc;
+    }
+}
+// stage 2: ordered sum over chunks -> dW[o,k], db[o]
+__global__ __launch_bounds__(256) void lin_bwd_dw_final(const float* __restrict__ partial, int n_chunks, int O, int K,
+                                                        float* __restrict__ dW, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_out = O * (K + 1);
+    if (i >= n_out) return;
+    float acc = 0.f;
+    for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n_out + i];
+    const int o = i / (K + 1), k = i % (K + 1);
+    if (k < K) dW[(size_t)o * K + k] = acc;
+    else if (db) db[o] = acc;
+}
+
+// slot gather + scale + positional encoding: X0[r] = x_hist[b,p], H0 = X0*sqrt(D) + pe[p]
+__global__ __launch_bounds__(256) void embed_rows(const float* __restrict__ x_hist, const float* __restrict__ pe,
+                                                  const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t, int R,
+                                                  int L, float* __restrict__ H0) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)R * tD) return;
+    const int r = (int)(i / tD), d = (int)(i % tD);
+    const int b = row_env[r], p = row_t[r];
+    H0[i] = x_hist[((size_t)b * L + p) * tD + d] * 5.656854249492381f + pe[(size_t)p * tD + d];
+}
+
+// causal attention forward, one wavefront per row; Q/K/V live in QKV[R,96]; P[R,NH,Lp] keeps the probabilities for
+// the backward.  The probabilities are exchanged between lanes through a per-wave LDS strip (not through global).
+template <int NH>
+__global__ __launch_bounds__(256) void attn_fwd(const float* __restrict__ QKV, const int32_t* __restrict__ row_env,
+                                                const int32_t* __restrict__ row_t, const int32_t* __restrict__ offsets, int R,
+                                                int Lp, float* __restrict__ P, float* __restrict__ ATT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HD = tD / NH;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float* ps = smem + (size_t)(threadIdx.x >> 6) * NH * Lp;
+    const int p = row_t[r], base = offsets[row_env[r]];
+    const float scale = 1.0f / sqrtf((float)HD);
+    float q[tD];
+#pragma unroll
+    for (int d = 0; d < tD; ++d) q[d] = QKV[(size_t)r * 96 + d] * scale;
+    float mx[NH], sm[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) mx[h] = -INFINITY;
+    float* Pr = P + (size_t)r * NH * Lp;
+    for (int jp = lane; jp <= p; jp += CIRS_WAVE) {
+        const float* k = QKV + (size_t)(base + jp) * 96 + tD;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sc = __builtin_fmaf(q[h * HD + d], k[h * HD + d], sc);
+            ps[h * Lp + jp] = sc;
+            mx[h] = fmaxf(mx[h], sc);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { mx[h] = wave_max_f32(mx[h]); sm[h] = 0.f; }
+    for (int jp = lane; jp <= p; jp += CIRS_WAVE) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float e = expf(ps[h * Lp + jp] - mx[h]);
+            ps[h * Lp + jp] = e;
+            sm[h] += e;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) sm[h] = 1.0f / wave_sum_f32(sm[h]);
+    for (int jp = lane; jp <= p; jp += CIRS_WAVE) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float pr = ps[h * Lp + jp] * sm[h];
+            ps[h * Lp + jp] = pr;
+            Pr[h * Lp + jp] = pr;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int half = lane >> 5, d = lane & 31, h = d / HD;
+    float acc = 0.f;
+    for (int jp = half; jp <= p; jp += 2) acc = __builtin_fmaf(ps[h * Lp + jp], QKV[(size_t)(base + jp) * 96 + 2 * tD + d], acc);
+    acc += __shfl_xor(acc, 32, CIRS_WAVE);
+    if (lane < tD) ATT[(size_t)r * tD + d] = acc;
+}
+
+// query side of the attention backward: dS (stored over P's twin buffer) and dQ
+template <int NH>
+__global__ __launch_bounds__(256) void attn_bwd_q(const float* __restrict__ QKV, const float* __restrict__ P, const float* __restrict__ dATT,
+                                                  const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t,
+                                                  const int32_t* __restrict__ offsets, int R, int Lp, float* __restrict__ dS,
+                                                  float* __restrict__ dQKV) {
+    constexpr int HD = tD / NH;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int p = row_t[r], base = offsets[row_env[r]];
+    const float scale = 1.0f / sqrtf((float)HD);
+    float da[tD];
+#pragma unroll
+    for (int d = 0; d < tD; ++d) da[d] = dATT[(size_t)r * tD + d];
+    const float* Pr = P + (size_t)r * NH * Lp;
+    float* dSr = dS + (size_t)r * NH * Lp;
+    float dot[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) dot[h] = 0.f;
+    for (int jp = lane; jp <= p; jp += CIRS_WAVE) {
+        const float* v = QKV + (size_t)(base + jp) * 96 + 2 * tD;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dp = __builtin_fmaf(da[h * HD + d], v[h * HD + d], dp);
+            dSr[h * Lp + jp] = dp;  // dP for now
+            dot[h] = __builtin_fmaf(Pr[h * Lp + jp], dp, dot[h]);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) dot[h] = wave_sum_f32(dot[h]);
+    float dq[tD];
+#pragma unroll
+    for (int d = 0; d < tD; ++d) dq[d] = 0.f;
+    for (int jp = lane; jp <= p; jp += CIRS_WAVE) {
+        const float* k = QKV + (size_t)(base + jp) * 96 + tD;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float ds = Pr[h * Lp + jp] * (dSr[h * Lp + jp] - dot[h]);  // softmax backward
+            dSr[h * Lp + jp] = ds;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dq[h * HD + d] = __builtin_fmaf(ds, k[h * HD + d], dq[h * HD + d]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < tD; ++d) dq[d] = wave_sum_f32(dq[d]);
+    if (lane < tD) {
+        float val = 0.f;
+#pragma unroll
+        for (int d = 0; d < tD; ++d) val = lane == d ? dq[d] : val;
+        dQKV[(size_t)r * 96 + lane] = val * scale;  // scores used q*scale
+    }
+}
+
+// key side: dK[p'] = sum_{p >= p'} dS[p,p'] * q[p]*scale ; dV[p'] = sum_{p >= p'} P[p,p'] * dATT[p]
+template <int NH>
+__global__ __launch_bounds__(256) void attn_bwd_kv(const float* __restrict__ QKV, const float* __restrict__ P, const float* __restrict__ dS,
+                                                   const float* __restrict__ dATT, const int32_t* __restrict__ row_env,
+                                                   const int32_t* __restrict__ row_t, const int32_t* __restrict__ offsets,
+                                                   const int32_t* __restrict__ lens, int R, int Lp, float* __restrict__ dQKV) {
+    constexpr int HD = tD / NH;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int b = row_env[r], pk = row_t[r], base = offsets[b], len = lens[b];
+    const float scale = 1.0f / sqrtf((float)HD);
+    float dk[tD], dv[tD];
+#pragma unroll
+    for (int d = 0; d < tD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int p = pk + lane; p < len; p += CIRS_WAVE) {
+        const size_t rq = (size_t)(base + p);
+        const float* q = QKV + rq * 96;
+        const float* da = dATT + rq * tD;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float ds = dS[(rq * NH + h) * Lp + pk] * scale;
+            const float pr = P[(rq * NH + h) * Lp + pk];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                dk[h * HD + d] = __builtin_fmaf(ds, q[h * HD + d], dk[h * HD + d]);
+                dv[h * HD + d] = __builtin_fmaf(pr, da[h * HD + d], dv[h * HD + d]);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < tD; ++d) { dk[d] = wave_sum_f32(dk[d]); dv[d] = wave_sum_f32(dv[d]); }
+    if (lane < tD) {
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int d = 0; d < tD; ++d) { a = lane == d ? dk[d] : a; c = lane == d ? dv[d] : c; }
+        dQKV[(size_t)r * 96 + tD + lane] = a;
+        dQKV[(size_t)r * 96 + 2 * tD + lane] = c;
+    }
+}
+
+// Y = A + B (pre-LayerNorm residual sum), one thread per element
+__global__ __launch_bounds__(256) void add_rows(const float* __restrict__ A, const float* __restrict__ B, long n, float* __restrict__ Y) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) Y[i] = A[i] + B[i];
+}
+
+// LayerNorm(32) forward, one thread per row: out = (y - mean) * rstd * g + b ; xhat kept for the backward
+__global__ __launch_bounds__(256) void ln_fwd(const float* __restrict__ Y, const float* __restrict__ g, const float* __restrict__ b, int R,
+                                              float* __restrict__ xhat, float* __restrict__ rstd, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* y = Y + (size_t)r * tD;
+    float mean = 0.f;
+    for (int d = 0; d < tD; ++d) mean += y[d];
+    mean *= (1.0f / tD);
+    float var = 0.f;
+    for (int d = 0; d < tD; ++d) { const float t = y[d] - mean; var += t * t; }
+    var *= (1.0f / tD);
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    rstd[r] = rs;
+    for (int d = 0; d < tD; ++d) {
+        const float xh = (y[d] - mean) * rs;
+        xhat[(size_t)r * tD + d] = xh;
+        out[(size_t)r * tD + d] = xh * g[d] + b[d];
+    }
+}
+// LayerNorm backward per row: dY = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)), dxh = dOut * g
+__global__ __launch_bounds__(256) void ln_bwd(const float* __restrict__ dOut, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                              const float* __restrict__ g, int R, float* __restrict__ dY) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float m1 = 0.f, m2 = 0.f;
+    for (int d = 0; d < tD; ++d) {
+        const float dxh = dOut[(size_t)r * tD + d] * g[d];
+        m1 += dxh;
+        m2 += dxh * xhat[(size_t)r * tD + d];
+    }
+    m1 *= (1.0f / tD); m2 *= (1.0f / tD);
+    const float rs = rstd[r];
+    for (int d = 0; d < tD; ++d) {
+        const float dxh = dOut[(size_t)r * tD + d] * g[d];
+        dY[(size_t)r * tD + d] = rs * (dxh - m1 - xhat[(size_t)r * tD + d] * m2);
+    }
+}
+// d gamma[d] = sum_r dOut*xhat, d beta[d] = sum_r dOut  -- chunk partials then ordered sum
+__global__ __launch_bounds__(64) void ln_dgb_partial(const float* __restrict__ dOut, const float* __restrict__ xhat, int R,
+                                                     float* __restrict__ partial) {
+    const int c = blockIdx.x, t = threadIdx.x;  // t < 64: 0..31 gamma, 32..63 beta
+    const int r0 = c * kChunkRows, r1 = min(R, r0 + kChunkRows);
+    const int d = t & 31;
+    float acc = 0.f;
+    if (t < 32) for (int r = r0; r < r1; ++r) acc = __builtin_fmaf(dOut[(size_t)r * tD + d], xhat[(size_t)r * tD + d], acc);
+    else for (int r = r0; r < r1; ++r) acc += dOut[(size_t)r * tD + d];
+    partial[(size_t)c * 64 + t] = acc;
+}
+__global__ __launch_bounds__(64) void ln_dgb_final(const float* __restrict__ partial, int n_chunks, float* __restrict__ dg, float* __restrict__ db) {
+    const int t = threadIdx.x;
+    float acc = 0.f;
+    for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * 64 + t];
+    if (t < 32) dg[t] = acc; else db[t - 32] = acc;
+}
+
+// upstream gradient rows: G[r, s] = dstate[row_t, row_env, s]
+__global__ __launch_bounds__(256) void gather_dstate(const float* __restrict__ dstate, const int32_t* __restrict__ row_env,
+                                                     const int32_t* __restrict__ row_t, int R, int S, int B, float* __restrict__ G) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)R * S) return;
+    const int r = (int)(i / S), s = (int)(i % S);
+    G[i] = dstate[((size_t)row_t[r] * B + row_env[r]) * S + s];
+}
+
+// input slots: rows with p == 0 are the user slot, p >= 1 the gated action slot (state_tracker.py:205-215,225-242).
+// Produces, per row, the "pre" gradient vectors the two small weight-gradient GEMMs need and scatters into the
+// embedding tables:   user rows : DU[r] = dX0 (for ffn_user), EU[r] = Emb_user[u]
+//                     item rows : DPRE[r] = dX0 * a * g(1-g), GIN[r] = [rew, a]  (for fnn_gate)
+__global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const float* __restrict__ dH0, const int32_t* __restrict__ users,
+                                                const int64_t* __restrict__ act, const double* __restrict__ rew,
+                                                const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t, int R, int B,
+                                                float* __restrict__ DU, float* __restrict__ EU, float* __restrict__ DPRE,
+                                                float* __restrict__ GIN, float* __restrict__ g_emb_user, float* __restrict__ g_emb_item) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int b = row_env[r], p = row_t[r];
+    const int d = lane & 31;
+    const float dx = dH0[(size_t)r * tD + d] * 5.656854249492381f;  // d/dx of x*sqrt(D)
+    if (p == 0) {
+        const int u = users[b];
+        const float eu = w.emb_user[(size_t)u * tD + d];
+        if (lane < tD) {
+            DU[(size_t)r * tD + d] = dx; EU[(size_t)r * tD + d] = eu;
+            DPRE[(size_t)r * tD + d] = 0.f;
+        }
+        if (lane <= tD) GIN[(size_t)r * (tD + 1) + lane] = 0.f;
+        // dEmb_user[u, k] += sum_o dx[o] * ffn_user_w[o, k] : lane k
+        float acc = 0.f;
+        for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(__shfl(dx, o, CIRS_WAVE), w.ffn_user_w[(size_t)o * tD + d], acc);
+        if (lane < tD) atomicAdd(&g_emb_user[(size_t)u * tD + d], acc);
+    } else {
+        const size_t ti = (size_t)(p - 1) * B + b;
+        const long it = act[ti];
+        const float rw = (float)rew[ti];
+        const float a = w.emb_item[(size_t)it * tD + d];
+        // recompute the gate for feature d (lane o = d)
+        const float* gw = w.gate_w + (size_t)d * (tD + 1);
+        float pre = w.gate_b[d];
+        pre = __builtin_fmaf(gw[0], rw, pre);
+        for (int k = 0; k < tD; ++k) pre = __builtin_fmaf(gw[1 + k], __shfl(a, k, CIRS_WAVE), pre);
+        const float g = 1.0f / (1.0f + expf(-pre));
+        const float dpre = dx * a * g * (1.0f - g);
+        if (lane < tD) {
+            DPRE[(size_t)r * tD + d] = dpre;
+            DU[(size_t)r * tD + d] = 0.f; EU[(size_t)r * tD + d] = 0.f;
+            GIN[(size_t)r * (tD + 1) + 1 + d] = a;
+        }
+        if (lane == 0) GIN[(size_t)r * (tD + 1)] = rw;
+        // d a[k] = dx[k]*g[k] + sum_o dpre[o] * gate_w[o, 1+k]
+        float acc = dx * g;
+        for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(__shfl(dpre, o, CIRS_WAVE), w.gate_w[(size_t)o * (tD + 1) + 1 + d], acc);
+        if (lane < tD) atomicAdd(&g_emb_item[(size_t)it * tD + d], acc);
+    }
+}
+
+struct BwdScratch {
+    float *G, *H[CIRS_MAX_TRACKER_LAYERS + 1];
+    float *QKV[CIRS_MAX_TRACKER_LAYERS], *P[CIRS_MAX_TRACKER_LAYERS], *ATT[CIRS_MAX_TRACKER_LAYERS];
+    float *XH1[CIRS_MAX_TRACKER_LAYERS], *RS1[CIRS_MAX_TRACKER_LAYERS], *H1N[CIRS_MAX_TRACKER_LAYERS], *FF1[CIRS_MAX_TRACKER_LAYERS];
+    float *XH2[CIRS_MAX_TRACKER_LAYERS], *RS2[CIRS_MAX_TRACKER_LAYERS];
+    float *T0, *T1, *T2, *dQKV, *dFF1, *dS, *partial, *GIN;
+};
+
+static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
+    const long nl = cfg->nlayers, Lp = cfg->max_len, NH = cfg->nhead;
+    size_t f = 0;
+    f += (size_t)R * 32;                          // G (S <= 32)
+    f += (size_t)(nl + 1) * R * tD;               // H
+    f += (size_t)nl * R * (96 + NH * Lp + tD + tD + 1 + tD + tH + tD + 1);
+    f += 3 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp;  // T0..2, dQKV, dFF1, dS
+    const size_t chunks = (size_t)((R + kChunkRows - 1) / kChunkRows);
+    f += chunks * (size_t)tH * (tD + 1) + 4096;  // partial (largest: 128 x 33)
+    f += (size_t)R * (tD + 1);                    // GIN
+    return f + 64 * 32;
+}
+
+static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
+    float* p = (float*)ws;
+    auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~(size_t)3; return r; };
+    const long nl = cfg->nlayers, Lp = cfg->max_len, NH = cfg->nhead;
+    BwdScratch s;
+    s.G = take((size_t)R * 32);
+    for (int l = 0; l <= nl; ++l) s.H[l] = take((size_t)R * tD);
+    for (int l = 0; l < nl; ++l) {
+        s.QKV[l] = take((size_t)R * 96); s.P[l] = take((size_t)R * NH * Lp); s.ATT[l] = take((size_t)R * tD);
+        s.XH1[l] = take((size_t)R * tD); s.RS1[l] = take(R); s.H1N[l] = take((size_t)R * tD); s.FF1[l] = take((size_t)R * tH);
+        s.XH2[l] = take((size_t)R * tD); s.RS2[l] = take(R);
+    }
+    s.T0 = take((size_t)R * tD); s.T1 = take((size_t)R * tD); s.T2 = take((size_t)R * tD);
+    s.dQKV = take((size_t)R * 96); s.dFF1 = take((size_t)R * tH); s.dS = take((size_t)R * NH * Lp);
+    const size_t chunks = (size_t)((R + kChunkRows - 1) / kChunkRows);
+    s.partial = take(chunks * (size_t)tH * (tD + 1) + 4096);
+    s.GIN = take((size_t)R * (tD + 1));
+    return s;
+}
+
+}  // namespace cirs
+
+extern "C" int64_t cirs_tracker_backward_workspace_bytes(const cirs_tracker_cfg* cfg, int32_t n_rows) {
+    if (!cfg || n_rows <= 0) return 0;
+    return (int64_t)cirs::bwd_floats(cfg, n_rows) * 4;
+}
+
+extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
+                                     const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
+                                     const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
+                                     const float* dstate, const cirs_tracker_grads* grads, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    using namespace cirs;
+    CIRS_REQUIRE(cfg && w && st && users && act && rew && row_env && row_t && offsets && lens && dstate && grads && workspace, "null argument");
+    if (cfg->dim_model != tD || cfg->d_hid != tH) return fail(CIRS_E_UNSUPPORTED, "dim_model == 32 and d_hid == 128 only");
+    CIRS_REQUIRE(cfg->nhead == 1 || cfg->nhead == 2 || cfg->nhead == 4 || cfg->nhead == 8, "nhead must be 1,2,4,8");
+    CIRS_REQUIRE(n_rows > 0, "n_rows must be positive");
+    CIRS_REQUIRE(workspace_bytes >= cirs_tracker_backward_workspace_bytes(cfg, n_rows), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int R = n_rows, B = cfg->n_env, S = cfg->dim_state, L = cfg->max_len, NH = cfg->nhead, nl = cfg->nlayers;
+    BwdScratch sc = carve_bwd(workspace, cfg, R);
+    const int n_chunks = cdiv(R, kChunkRows);
+    auto g1 = [&](long n) { return dim3(cdiv(n, 256)); };
+
+#define DW(dY, X, O, K, dWp, dbp)                                                                                        \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL(lin_bwd_dw_partial, dim3(cdiv((O) * ((K) + 1), 256), n_chunks), dim3(256), 0, s, dY, X, R, O, K, sc.partial); \
+        hipLaunchKernelGGL(lin_bwd_dw_final, g1((O) * ((K) + 1)), dim3(256), 0, s, sc.partial, n_chunks, O, K, dWp, dbp);  \
+    } while (0)
+#define ATT_DISPATCH_SH(KERNEL, SHMEM, ...)                                                               \
+    do {                                                                                                  \
+        switch (NH) {                                                                                     \
+            case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(cdiv(R, 4)), dim3(256), SHMEM, s, __VA_ARGS__); break; \
+            case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(cdiv(R, 4)), dim3(256), SHMEM, s, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(cdiv(R, 4)), dim3(256), SHMEM, s, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL(KERNEL<8>, dim3(cdiv(R, 4)), dim3(256), SHMEM, s, __VA_ARGS__); break; \
+        }                                                                                                 \
+    } while (0)
+#define ATT_DISPATCH(KERNEL, ...) ATT_DISPATCH_SH(KERNEL, 0, __VA_ARGS__)
+
+    // ---------------- forward recompute ----------------
+    hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0]);
+    for (int l = 0; l < nl; ++l) {
+        const cirs_tracker_layer& y = w->layer[l];
+        hipLaunchKernelGGL(lin_fwd, g1((long)R * 96), dim3(256), 0, s, sc.H[l], y.in_proj_w, y.in_proj_b, R, 96, tD, 0, sc.QKV[l]);
+        ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l]);
+        hipLaunchKernelGGL(lin_fwd, g1((long)R * tD), dim3(256), 0, s, sc.ATT[l], y.out_proj_w, y.out_proj_b, R, tD, tD, 0, sc.T0);
+        hipLaunchKernelGGL(add_rows, g1((long)R * tD), dim3(256), 0, s, sc.H[l], sc.T0, (long)R * tD, sc.T1);
+        hipLaunchKernelGGL(ln_fwd, g1(R), dim3(256), 0, s, sc.T1, y.norm1_w, y.norm1_b, R, sc.XH1[l], sc.RS1[l], sc.H1N[l]);
+        hipLaunchKernelGGL(lin_fwd, g1((long)R * tH), dim3(256), 0, s, sc.H1N[l], y.lin1_w, y.lin1_b, R, tH, tD, 1, sc.FF1[l]);
+        hipLaunchKernelGGL(lin_fwd, g1((long)R * tD), dim3(256), 0, s, sc.FF1[l], y.lin2_w, y.lin2_b, R, tD, tH, 0, sc.T0);
+        hipLaunchKernelGGL(add_rows, g1((long)R * tD), dim3(256), 0, s, sc.H1N[l], sc.T0, (long)R * tD, sc.T1);
+        hipLaunchKernelGGL(ln_fwd, g1(R), dim3(256), 0, s, sc.T1, y.norm2_w, y.norm2_b, R, sc.XH2[l], sc.RS2[l], sc.H[l + 1]);
+    }
+    CIRS_CHECK_LAUNCH("tracker forward recompute");
+    // ---------------- backward ----------------
+    hipLaunchKernelGGL(gather_dstate, g1((long)R * S), dim3(256), 0, s, dstate, row_env, row_t, R, S, B, sc.G);
+    DW(sc.G, sc.H[nl], S, tD, grads->dec_w, grads->dec_b);
+    float* dH = sc.T0;  // gradient w.r.t. the current layer output
+    hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tD), dim3(256), 0, s, sc.G, w->dec_w, R, S, tD, (const float*)nullptr, 0, dH);
+    for (int l = nl - 1; l >= 0; --l) {
+        const cirs_tracker_layer& y = w->layer[l];
+        const cirs_tracker_layer_grads& gy = grads->layer[l];
+        // LN2
+        hipLaunchKernelGGL(ln_dgb_partial, dim3(n_chunks), dim3(64), 0, s, dH, sc.XH2[l], R, sc.partial);
+        hipLaunchKernelGGL(ln_dgb_final, dim3(1), dim3(64), 0, s, sc.partial, n_chunks, gy.norm2_w, gy.norm2_b);
+        float* dY2 = sc.T1;
+        hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2);
+        // FF
+        DW(dY2, sc.FF1[l], tD, tH, gy.lin2_w, gy.lin2_b);
+        hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tH), dim3(256), 0, s, dY2, y.lin2_w, R, tD, tH, sc.FF1[l], 0, sc.dFF1);
+        DW(sc.dFF1, sc.H1N[l], tH, tD, gy.lin1_w, gy.lin1_b);
+        // d H1N = dY2 (residual) + dFF1 * W1
+        hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tD), dim3(256), 0, s, sc.dFF1, y.lin1_w, R, tH, tD, (const float*)nullptr, 1, dY2);
+        // LN1
+        hipLaunchKernelGGL(ln_dgb_partial, dim3(n_chunks), dim3(64), 0, s, dY2, sc.XH1[l], R, sc.partial);
+        hipLaunchKernelGGL(ln_dgb_final, dim3(1), dim3(64), 0, s, sc.partial, n_chunks, gy.norm1_w, gy.norm1_b);
+        float* dY1 = sc.T2;
+        hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dY2, sc.XH1[l], sc.RS1[l], y.norm1_w, R, dY1);
+        // out_proj
+        DW(dY1, sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b);
+        float* dATT = sc.T1;
+        hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tD), dim3(256), 0, s, dY1, y.out_proj_w, R, tD, tD, (const float*)nullptr, 0, dATT);
+        // attention
+        ATT_DISPATCH(attn_bwd_q, sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV);
+        ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
+        // in_proj
+        DW(sc.dQKV, sc.H[l], 96, tD, gy.in_proj_w, gy.in_proj_b);
+        // d H_l = dY1 (residual) + dQKV * W_in
+        hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tD), dim3(256), 0, s, sc.dQKV, y.in_proj_w, R, 96, tD, (const float*)nullptr, 1, dY1);
+        dH = dY1;
+        if (l > 0) {  // keep dH in T0 for the next iteration (T2 is reused as dY1)
+            CIRS_HIP(hipMemcpyAsync(sc.T0, dY1, sizeof(float) * (size_t)R * tD, hipMemcpyDeviceToDevice, s));
+            dH = sc.T0;
+        }
+    }
+    CIRS_CHECK_LAUNCH("tracker backward layers");
+    // input slots + embeddings
+    CIRS_HIP(hipMemsetAsync(grads->emb_user, 0, sizeof(float) * (size_t)cfg->n_users * tD, s));
+    CIRS_HIP(hipMemsetAsync(grads->emb_item, 0, sizeof(float) * (size_t)cfg->n_items * tD, s));
+    float* DU = sc.T1;
+    float* EU = sc.H[nl];   // forward activations are no longer needed
+    float* DPRE = sc.H[0] == dH ? sc.H[1] : sc.H[0];
+    hipLaunchKernelGGL(slot_bwd, dim3(cdiv(R, 4)), dim3(256), 0, s, *w, dH, users, act, rew, row_env, row_t, R, B, DU, EU, DPRE,
+                       sc.GIN, grads->emb_user, grads->emb_item);
+    DW(DU, EU, tD, tD, grads->ffn_user_w, grads->ffn_user_b);
+    DW(DPRE, sc.GIN, tD, tD + 1, grads->gate_w, grads->gate_b);
+    CIRS_CHECK_LAUNCH("tracker backward slots");
+#undef DW
+#undef ATT_DISPATCH
+#undef ATT_DISPATCH_SH
+    return CIRS_OK;
+}

@@ -279,6 +279,38 @@ int cirs_adam_step(float* params, const float* grads, float* m, float* v, int64_
                    int32_t n_sub, float lr, float beta1, float beta2, float eps, const float* grad_scale,
                    int32_t scale_pow, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * State-tracker backward: the gradient PPO sends into the tracker through the stored obs
+ * replaces  the retained autograd graph of core/collector.py:261-269 + core/policy/ppo.py:174,215,235
+ *           (loss.backward(retain_graph=True) accumulating into state_tracker.parameters(), one optim_state.step()).
+ * Because the mask is causal and dropout is off, the per-step recomputations of the reference are one causal
+ * transformer pass over each episode; rows are the buffer rows (env b, position p = t), p < len_b.  The forward is
+ * recomputed from the stored slots (x_hist) and back-propagated analytically down to the embedding tables.
+ * All weight-gradient reductions over rows are two-stage with a fixed order (no float atomics), except the
+ * embedding-table scatter which uses one atomic add per (row, dim).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct cirs_tracker_layer_grads {
+    float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b;
+    float *norm1_w, *norm1_b, *norm2_w, *norm2_b;
+} cirs_tracker_layer_grads;
+
+typedef struct cirs_tracker_grads { /* same tensors as cirs_tracker_weights (pe is a buffer: no gradient) */
+    float *emb_user, *emb_item, *ffn_user_w, *ffn_user_b, *gate_w, *gate_b;
+    float* pe_unused;
+    cirs_tracker_layer_grads layer[CIRS_MAX_TRACKER_LAYERS];
+    float *dec_w, *dec_b;
+} cirs_tracker_grads;
+
+int64_t cirs_tracker_backward_workspace_bytes(const cirs_tracker_cfg* cfg, int32_t n_rows);
+
+/* users[B]; act/rew are the time-major trajectory rows [T,B]; row_env/row_t/offsets/lens describe the buffer rows
+ * (see cirs_ppo_prepare); dstate [T+1,B,S] = d loss / d obs.  Every gradient tensor is OVERWRITTEN. */
+int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
+                          const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
+                          const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
+                          const float* dstate, const cirs_tracker_grads* grads, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
