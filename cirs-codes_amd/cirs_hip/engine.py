@@ -1,0 +1,156 @@
+"""CirsEngine: the whole hot path on one GPU (or one rank of a multi-GPU job): device-resident rollout + PPO update.
+
+Wires csrc/{env,tracker,policy,rollout,ppo,tracker_bwd}.hip through the C ABI.  Host-side counterpart of what
+CIRS-RL-kuaishou.py builds (reference :141-292) and of onpolicy_trainer's inner loop
+(core/trainer/onpolicy.py:170-209):   collect(n_episode = n_env)  ->  policy.update(0, buffer, batch_size, repeat).
+"""
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import abi, distributed
+from .env import DeviceEnv, DeviceEnvTables
+from .learner import DeviceLearner, flat_policy_params
+from .policy import DevicePolicy
+from .rollout import DeviceRollout, Trajectory
+from .tracker import DeviceTracker, flat_tracker_params, positional_encoding, tracker_param_shapes
+
+
+def init_tracker_params(n_users, n_items, max_turn, seed=2021, dim_model=32, dim_state=20, nhead=4, d_hid=128, nlayers=2,
+                        init_std=1e-4) -> Dict[str, torch.Tensor]:
+    """Fresh parameters with the reference's initialisers (core/state_tracker.py:129-168, core/user_model.py:559-581):
+    embeddings ~ N(0, init_std), nn.Linear / nn.TransformerEncoderLayer defaults, decoder ~ U(-0.1, 0.1), bias 0.
+    torch modules are used as parameter factories only (their forward is never called)."""
+    g = torch.Generator().manual_seed(seed)
+    torch_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        D = dim_model
+        p = {"embedding_dict.feat_user.weight": torch.randn(n_users, D, generator=g) * init_std,
+             "embedding_dict.feat_item.weight": torch.randn(n_items, D, generator=g) * init_std}
+        ffn_user = torch.nn.Linear(D, D)
+        gate = torch.nn.Linear(1 + D, D)
+        layer = torch.nn.TransformerEncoderLayer(D, nhead, d_hid, 0.1)
+        enc = torch.nn.TransformerEncoder(layer, nlayers, enable_nested_tensor=False)
+        dec = torch.nn.Linear(D, dim_state)
+        dec.bias.data.zero_()
+        dec.weight.data.uniform_(-0.1, 0.1)
+        p.update({"ffn_user.weight": ffn_user.weight.data, "ffn_user.bias": ffn_user.bias.data,
+                  "fnn_gate.weight": gate.weight.data, "fnn_gate.bias": gate.bias.data,
+                  "decoder.weight": dec.weight.data, "decoder.bias": dec.bias.data})
+        for k, v in enc.state_dict().items():
+            p["transformer_encoder." + k] = v
+        p["pos_encoder.pe"] = positional_encoding(max_turn + 1, D).unsqueeze(1)
+    finally:
+        torch.random.set_rng_state(torch_state)
+    return {k: v.detach().clone().float() for k, v in p.items()}
+
+
+def init_policy_params(n_items, seed=0, dim_state=20, hidden=64) -> Dict[str, torch.Tensor]:
+    """Orthogonal weights, zero biases (CIRS-RL-kuaishou.py:250-254)."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"actor.preprocess.model.model.0": (hidden, dim_state), "actor.preprocess.model.model.2": (hidden, hidden),
+              "actor.last.model.0": (n_items, hidden), "critic.last.model.0": (1, hidden)}
+    out = {}
+    for k, shp in shapes.items():
+        w = torch.empty(shp)
+        torch.nn.init.orthogonal_(w, generator=g)
+        out[k + ".weight"] = w
+        out[k + ".bias"] = torch.zeros(shp[0])
+    return out
+
+
+class CirsEngine:
+    def __init__(self, tables: DeviceEnvTables, n_env: int, *, max_turn=30, num_leave_compute=1, leave_threshold=0,
+                 tau=100.0, gamma_exposure=10.0, version="v1", r_decay=1.0, dim_model=32, dim_state=20, nhead=4,
+                 hidden=64, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
+                 lr=1e-3, rew_norm=True, value_clip=True, norm_adv=True, seed=2023, tracker_params=None,
+                 policy_params=None, dist_group=None, world_size=1, rank=0):
+        self.device = tables.device
+        self.tables = tables
+        self.n_env, self.max_turn, self.S, self.D = n_env, max_turn, dim_state, dim_model
+        U, I = tables.n_users, tables.n_items
+        self.n_items = I
+        self.world, self.rank, self.group = world_size, rank, dist_group
+        self.env = DeviceEnv(tables, n_env, num_leave_compute=num_leave_compute, leave_threshold=leave_threshold,
+                             max_turn=max_turn, tau=tau, gamma_exposure=gamma_exposure, version=version, r_decay=r_decay)
+        tp = tracker_params or init_tracker_params(U, I, max_turn, seed=seed, dim_model=dim_model, dim_state=dim_state, nhead=nhead)
+        self.tracker_flat, tviews = flat_tracker_params(tracker_param_shapes(U, I, dim_model, dim_state), device=self.device, init=tp)
+        tparams = dict(tviews)
+        tparams["pos_encoder.pe"] = tp["pos_encoder.pe"].to(self.device).float().contiguous()
+        self.tracker = DeviceTracker(tparams, U, I, n_env, max_turn, dim_model=dim_model, dim_state=dim_state, nhead=nhead, device=self.device)
+        self.tracker.enable_training(self.tracker_flat, lr=lr)
+        pp = policy_params or init_policy_params(I, seed=seed, dim_state=dim_state, hidden=hidden)
+        self.policy_flat, pviews = flat_policy_params(I, dim_state, hidden, device=self.device, init=pp)
+        self.policy_views = pviews
+        self.tracker_views = tviews
+        self.policy = DevicePolicy(pviews, I, dim_state=dim_state, hidden=hidden, device=self.device)
+        self.rollout = DeviceRollout(self.env, self.tracker, self.policy)
+        self.B_total = n_env * world_size
+        self.learner = DeviceLearner(self.policy_flat, I, self.B_total, max_turn, dim_state=dim_state, hidden=hidden, gamma=gamma,
+                                     gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
+                                     max_grad_norm=max_grad_norm, lr=lr, norm_adv=norm_adv, value_clip=value_clip, rew_norm=rew_norm)
+        self.seed = seed
+        self.collect_count = 0
+        self.users = None
+        self.lengths = None
+        self._gtraj = None
+        # user draws: the reference uses Python's (unseeded) random.randint per env reset (kuaishouEnv.py:155-159);
+        # here a seeded generator per rank
+        self._user_rng = np.random.RandomState(seed * 1000003 + rank)
+
+    # ---- rollout ------------------------------------------------------------------------------------------------
+    def collect(self, users: Optional[torch.Tensor] = None, sync_every: Optional[int] = None):
+        if users is None:
+            users = torch.as_tensor(self._user_rng.randint(0, self.tables.n_users, self.n_env))
+        self.users = users.to(self.device, torch.int32)
+        rng_base = (self.collect_count * self.max_turn) & 0xFFFFFFFF
+        # RNG key = (seed, rank) so ranks draw independent noise; counter = (item, local env id, step)
+        self.lengths = self.rollout.collect(self.users, seed=(self.seed << 8) + self.rank, rng_base=rng_base, sync_every=sync_every)
+        self.collect_count += 1
+        return self.lengths
+
+    def collect_stats(self):
+        """Collector.collect's result dict (collector.py:343-362) from the device trajectory (one host sync)."""
+        tr = self.rollout.traj
+        lens = self.lengths.cpu().numpy()
+        valid = (tr.act >= 0)
+        rews = (tr.rew * valid).sum(0).cpu().numpy()
+        return {"n/ep": int(len(lens)), "n/st": int(lens.sum()), "rews": rews, "lens": lens, "rew": float(rews.mean()),
+                "len": float(lens.mean()), "rew_std": float(rews.std()), "len_std": float(lens.std())}
+
+    # ---- learner ------------------------------------------------------------------------------------------------
+    def _gather(self):
+        """All ranks' trajectories -> one global buffer (single all-gather); world == 1: zero-copy views."""
+        tr = self.rollout.traj
+        if self.world == 1:
+            return tr, self.tracker.x_hist, self.lengths, self.users
+        fields = dict(obs=tr.obs, act=tr.act, rew=tr.rew, done=tr.done, logp=tr.logp, value=tr.value, ctr=tr.ctr,
+                      x_hist=self.tracker.x_hist, lens=self.lengths.to(torch.int32), users=self.users)
+        g = distributed.all_gather_records(fields, self.max_turn, self.n_env, self.S, self.D, group=self.group)
+        if self._gtraj is None:
+            self._gtraj = Trajectory(self.B_total, self.max_turn, self.S, self.device)
+        gt = self._gtraj
+        for name in ("obs", "act", "rew", "done", "logp", "value", "ctr"):
+            getattr(gt, name).copy_(g[name])
+        return gt, g["x_hist"], g["lens"], g["users"]
+
+    def update(self, batch_size=1024, repeat=2, perms=None):
+        """policy.update(0, buffer, batch_size, repeat): process_fn + learn + tracker step (base.py:219-244)."""
+        traj, x_hist, lens_d, users = self._gather()
+        lens = lens_d.cpu().numpy().astype(np.int32)   # host needs N to schedule minibatches (the only sync)
+        ln = self.learner
+        n = ln.prepare(traj, lens)
+        if perms is None and self.world > 1:
+            # identical permutations on every rank: replicated learners stay bit-identical
+            rs = np.random.RandomState((self.seed * 7919 + self.collect_count) & 0x7FFFFFFF)
+            perms = [rs.permutation(n) for _ in range(repeat)]
+        losses = ln.learn(batch_size, repeat, perms=perms)
+        offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        self.tracker.backward(users, traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).to(self.device),
+                              torch.as_tensor(lens).to(self.device), n, ln.dobs,
+                              x_hist=x_hist if self.world > 1 else None)
+        self.tracker.adam_update()
+        return losses, n

@@ -119,14 +119,22 @@ class DeviceTracker:
         self.lr, self.betas, self.adam_eps = lr, betas, eps
         self._bws = None
 
-    def backward(self, users, traj, row_env, row_t, offsets, lens, n_rows, dstate):
-        """d loss / d tracker params from d loss / d obs (dstate [T+1,B,S]); fills self.flat_grad."""
+    def backward(self, users, traj, row_env, row_t, offsets, lens, n_rows, dstate, x_hist=None):
+        """d loss / d tracker params from d loss / d obs (dstate [T+1,B,S]); fills self.flat_grad.
+        x_hist: stored input slots [B', max_len, D] when the rows come from a gathered (multi-rank) buffer whose
+        env count B' = traj.B differs from this tracker's own n_env."""
         users = users.to(self.device, torch.int32).contiguous()
-        need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(self.cfg), n_rows)
+        cfg, st = self.cfg, self.st
+        if x_hist is not None:
+            cfg = abi.TrackerCfg.from_buffer_copy(self.cfg)
+            cfg.n_env = x_hist.shape[0]
+            st = abi.TrackerState(x_hist=x_hist.data_ptr(), kcache=self.kcache.data_ptr(), vcache=self.vcache.data_ptr(),
+                                  len=self.len.data_ptr())
+        need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(cfg), n_rows)
         if self._bws is None or self._bws.numel() < need:
             self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
         abi.check(self._lib.cirs_tracker_backward(
-            C.byref(self.cfg), C.byref(self.w), C.byref(self.st), users.data_ptr(), traj.act.data_ptr(),
+            C.byref(cfg), C.byref(self.w), C.byref(st), users.data_ptr(), traj.act.data_ptr(),
             traj.rew.data_ptr(), row_env.data_ptr(), row_t.data_ptr(), offsets.data_ptr(), lens.data_ptr(), n_rows,
             dstate.data_ptr(), C.byref(self.g), self._bws.data_ptr(), self._bws.numel(), self._stream()),
             "cirs_tracker_backward")
