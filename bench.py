@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Benchmark of the CIRS hot path on MI355X: one step = Collector.collect(n_episode = n_env) + policy.update(...)
+(rollout of every env to the end of its episode, then the full PPO update incl. the tracker BPTT and both Adam steps).
+
+  python bench.py --gpus 1 --steps K --warmup W                 (single GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  metric = simulator env-steps/s of the whole job (all ranks), with the PPO update
+inside the timed region; PPO minibatch-steps/s and the rollout/update split are reported alongside.
+Workloads (BASELINE.json configs): c3 (default) KuaishouEnv big_matrix-shaped 7176 x 10728, 1024 envs per GPU,
+recent-N = 10 (C4 = the same with 8 ranks: 8192 envs, weak scaling); c2 = 1411 x 3327, 64 envs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    "c3": dict(U=7176, I=10728, B=1024, T=30, N=10, thr=4, tau=10.0, gamma_exposure=10.0,
+               name="KuaishouEnv big_matrix-shaped synthetic 7176x10728, 1024 envs/GPU, tracker dim 32, recent-N=10, max_turn=30, PPO batch 1024 x repeat 2"),
+    "c2": dict(U=1411, I=3327, B=64, T=30, N=10, thr=4, tau=10.0, gamma_exposure=10.0,
+               name="KuaishouEnv small_matrix-shaped synthetic 1411x3327, 64 envs/GPU, tracker dim 32, recent-N=10, max_turn=30, PPO batch 1024 x repeat 2"),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def build_engine(wl, rank, world, device):
+    from cirs_hip.engine import CirsEngine
+    from cirs_hip.env import DeviceEnvTables
+    from cirs_hip.synthetic import make_tables
+    tab = make_tables(wl["U"], wl["I"], seed=0, build_dist=False)
+    a_env = tab.alpha_u[tab.raw_uid, 0].astype(np.float64)
+    b_env = tab.beta_i[tab.raw_pid, 0].astype(np.float64)
+    # table mode like the reference (df_dist_small): the I x I float64 1/Jaccard table is built on device
+    dt = DeviceEnvTables(tab.mat, tab.normed_mat, tab.item_cats, alpha_env=a_env, beta_env=b_env, device=device,
+                         build_dist_on_device=True)
+    eng = CirsEngine(dt, wl["B"], max_turn=wl["T"], num_leave_compute=wl["N"], leave_threshold=wl["thr"], tau=wl["tau"],
+                     gamma_exposure=wl["gamma_exposure"], seed=2023, world_size=world, rank=rank,
+                     dist_group=None)
+    return eng, tab
+
+
+def hip_event_kernel_time(eng, wl, reps=20):
+    """Average duration (HIP events on the launch stream) of the dominant kernel pair of a PPO minibatch step:
+    the two MFMA head-backward kernels, launched exactly as inside the timed region."""
+    from cirs_hip import abi
+    import ctypes as C
+    ln = eng.learner
+    n = ln.n_rows
+    mb = min(1024, n)
+    ws = ln.workspace(mb)
+    idx = torch.arange(mb, dtype=torch.int32, device=eng.device)
+    losses = torch.zeros(4, dtype=torch.float32, device=eng.device)
+    # snapshot optimiser state so the probe does not advance training
+    snap = [t.clone() for t in (ln.params, ln.adam_m, ln.adam_v)]
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        abi.check(ln._lib.cirs_ppo_minibatch(C.byref(ln.cfg), ln.params.data_ptr(), ln.grads.data_ptr(), ln.adam_m.data_ptr(),
+                                             ln.adam_v.data_ptr(), ln.opt_step, C.byref(ln.batch), idx.data_ptr(), mb, None,
+                                             ln.n_env, losses.data_ptr(), ws.data_ptr(), ws.numel(), ln._stream()), "probe")
+    stop.record()
+    torch.cuda.synchronize()
+    for t, s in zip((ln.params, ln.adam_m, ln.adam_v), snap):
+        t.copy_(s)
+    return start.elapsed_time(stop) / reps * 1e-3, mb  # seconds per minibatch step
+
+
+def cpu_baseline(wl, budget_envs=32):
+    """The oracle port of the same step on the host cores, bounded sample (fewer envs, same tables / episode rule)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_path
+    import policycase
+    import rolloutcase
+    from cirs_hip.synthetic import make_tables
+    tab = make_tables(wl["U"], wl["I"], seed=0, build_dist=False)
+    tp = rolloutcase.tracker_param_dict(wl["U"], wl["I"], wl["T"], seed=2, emb_scale=0.01)
+    arrs = policycase.random_weights(np.random.RandomState(2), wl["I"])
+    B = min(budget_envs, wl["B"])
+    torch.set_num_threads(os.cpu_count() or 1)
+    cpu_path.run_cpu_step(tab, tp, arrs, 4, wl["T"], N=wl["N"], thr=wl["thr"], do_update=False)  # warm-up
+    t0 = time.perf_counter()
+    r = cpu_path.run_cpu_step(tab, tp, arrs, B, wl["T"], N=wl["N"], thr=wl["thr"], tau=wl["tau"],
+                              gamma_exposure=wl["gamma_exposure"], batch_size=1024, repeat=2)
+    dt = time.perf_counter() - t0
+    return {"value": r["env_steps"] / dt, "unit": "env-steps/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"1 step (collect + update) with {B} envs on the same {wl['U']}x{wl['I']} tables: {r['env_steps']} env-steps, "
+                      f"{r['minibatches']} PPO minibatch steps, collect {r['t_collect']:.2f}s + update {r['t_update']:.2f}s "
+                      "(C oracle env/actor via OpenMP, torch-fp32 tracker/PPO restatement)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+
+    eng, tab = build_engine(wl, rank, world, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        eng.collect()
+        losses, n = eng.update(batch_size=1024, repeat=2)
+        return losses.shape[0]
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    steps_local = 0
+    mb_steps = 0
+    t_collect = 0.0
+    for _ in range(args.steps):
+        eng.collect()
+        steps_local += int(eng.lengths.sum())  # lengths are read back by update() anyway
+        losses, n = eng.update(batch_size=1024, repeat=2)
+        mb_steps += losses.shape[0]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+        c = torch.tensor([steps_local], dtype=torch.float64, device=device)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_steps = float(c)
+    else:
+        total_steps = float(steps_local)
+
+    # split (untimed extra pass, same state): rollout-only and update-only rates
+    barrier()
+    ta = time.perf_counter(); eng.collect(); torch.cuda.synchronize(); tb = time.perf_counter()
+    l2, n2 = eng.update(1024, 2); torch.cuda.synchronize(); tc = time.perf_counter()
+
+    if rank == 0:
+        t_mb, mb = hip_event_kernel_time(eng, wl)
+        I = wl["I"]
+        # ALGORITHMIC flop of one PPO minibatch step on the actor head: forward statistics 2*mb*I*64,
+        # two backward kernels that each recompute the logits tile and contract it once more: 2 * (2*2*mb*I*64)
+        flop = 10.0 * mb * I * 64
+        achieved = flop / t_mb / 1e12
+        out = {
+            "metric": "simulator env-steps/s (collect + PPO update in the timed region), KuaishouEnv",
+            "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (policy/tracker, fp32 MFMA) + f64 (env rewards, GAE)", "data": "synthetic",
+            "config": {"workload": wl["name"], "envs_total": wl["B"] * world,
+                       "parallelism": f"env-sharded x{world}, one all-gather of trajectories per update, replicated learner"},
+            "ppo_minibatch_steps_per_s": mb_steps / elapsed,
+            "rollout_only_env_steps_per_s": int(eng.lengths.sum()) / (tb - ta),
+            "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
+            "roofline": {"bound": "mfma", "kernel": "PPO minibatch step: actor_head_kernel<stats> + head_bwd_dwa_kernel + head_bwd_dh2_kernel (+ small kernels)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "seconds_per_launch": t_mb, "rows": mb},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

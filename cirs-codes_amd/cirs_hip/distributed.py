@@ -55,6 +55,6 @@ def all_gather_records(fields: Dict[str, torch.Tensor], T: int, B_local: int, S:
     local = pack_records(fields)
     if world == 1:
         return unpack_records(local.unsqueeze(0), 1, T, B_local, S, D)
-    gathered = torch.empty((world, local.numel()), dtype=torch.uint8, device=local.device)
+    gathered = torch.empty(world * local.numel(), dtype=torch.uint8, device=local.device)
     dist.all_gather_into_tensor(gathered, local, group=group)
-    return unpack_records(gathered, world, T, B_local, S, D)
+    return unpack_records(gathered.view(world, local.numel()), world, T, B_local, S, D)

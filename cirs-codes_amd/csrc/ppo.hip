@@ -14,6 +14,7 @@
 // Roofline of one minibatch step (mb x I x 64): forward stats 2*mb*I*64 flop + two backward kernels of
 // 2 * 2*mb*I*64 flop each = 10*mb*I*64 flop = 7.0 GFLOP at mb = 1024, I = 10728 on the fp32 MFMA pipe (157 TF peak);
 // HBM traffic is Wa (2.7 MB) + dWa partials (8 x 2.7 MB) + dH2 partials (n_chunks x mb x 256 B = 22 MB): MFMA-bound.
+#include "dense_small.h"
 #include "policy_kernels.h"
 
 namespace cirs {
@@ -122,6 +123,8 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     float *entp;                              // [n_chunks, n_pad]
     float *dwap;                              // [kRowSplits, I*64 + I] partial dWa | dba
     float *red;                               // [16] scalars: adv mean/std, loss sums, grad norm coef
+    float *normp;                             // [256] sum-of-squares partials
+    float *dwp;                               // weight-gradient slab partials
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
 };
 
@@ -136,7 +139,8 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 2 * (size_t)n_pad * kH;                       // da2, da1
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)kRowSplits * ((size_t)I * kH + I);    // dwap
-    f += 64;                                           // red
+    f += 64 + 256;                                     // red + sum-of-squares partials
+    f += dw_partial_floats(n_pad, kH, kH) + 64;        // weight-gradient slab partials (largest: 64 x 65)
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
     return f;
 }
@@ -155,6 +159,8 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
     v.dwap = take((size_t)kRowSplits * ((size_t)I * kH + I));
     v.red = take(64);
+    v.normp = take(256);
+    v.dwp = take(dw_partial_floats(n_pad, kH, kH) + 64);
     v.head_ws = (void*)p;
     return v;
 }
@@ -515,36 +521,6 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restr
     dX[i] = acc;
 }
 
-// dW[o,k] = sum_r dY[r,o] * X[r,k] ; db[o] = sum_r dY[r,o]   (sequential over r: fixed order)
-__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, int R,
-                                                            int O, int K, float* __restrict__ dW, float* __restrict__ db) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= (long)O * (K + 1)) return;
-    const int o = (int)(i / (K + 1)), k = (int)(i % (K + 1));
-    float acc = 0.f;
-    if (k < K) {
-        for (int r = 0; r < R; ++r) acc = __builtin_fmaf(dY[(size_t)r * O + o], X[(size_t)r * K + k], acc);
-        dW[(size_t)o * K + k] = acc;
-    } else {
-        for (int r = 0; r < R; ++r) acc += dY[(size_t)r * O + o];
-        db[o] = acc;
-    }
-}
-
-// critic head: d wc[k] = sum_r dvalue_r * h2[r,k], d bc = sum_r dvalue_r
-__global__ __launch_bounds__(128) void critic_bwd_kernel(int mb, MbView v, float* __restrict__ g_wc, float* __restrict__ g_bc) {
-    const int k = threadIdx.x;
-    if (k < kH) {
-        float acc = 0.f;
-        for (int r = 0; r < mb; ++r) acc = __builtin_fmaf(v.dvalue[r], v.h2[(size_t)r * kH + k], acc);
-        g_wc[k] = acc;
-    } else if (k == kH) {
-        float acc = 0.f;
-        for (int r = 0; r < mb; ++r) acc += v.dvalue[r];
-        g_bc[0] = acc;
-    }
-}
-
 // d obs rows -> tracker gradient tensor [T+1, B, S] at (row_t, row_env)
 __global__ __launch_bounds__(256) void scatter_dobs_kernel(const float* __restrict__ dobs, const int32_t* __restrict__ idx,
                                                            cirs_ppo_batch b, int mb, int S, int n_env,
@@ -556,30 +532,46 @@ __global__ __launch_bounds__(256) void scatter_dobs_kernel(const float* __restri
     accum[((size_t)b.row_t[row] * n_env + b.row_env[row]) * S + k] = dobs[i];
 }
 
-// clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1); also the
-// entropy mean and the total loss.  One workgroup, fixed order.
-__global__ __launch_bounds__(1024) void gradnorm_kernel(cirs_ppo_cfg cfg, const float* __restrict__ g, long n_trunk, long n_total,
-                                                        int mb, MbView v, float* __restrict__ loss_out) {
-    __shared__ float sh[1024];
+// clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1).
+// stage 1: kNormBlocks workgroups, each a contiguous slice, fixed-order tree -> partial sums of squares
+constexpr int kNormBlocks = 256;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n_trunk, long n_total,
+                                                            float* __restrict__ partial) {
+    __shared__ float sh[256];
     const int tid = threadIdx.x;
+    const long per = (n_total + kNormBlocks - 1) / kNormBlocks;
+    const long lo = blockIdx.x * per, hi = min(n_total, lo + per);
     float acc = 0.f;
-    for (long i = tid; i < n_total; i += 1024) {
+    for (long i = lo + tid; i < hi; i += 256) {
         const float x = g[i];
-        acc += (i < n_trunk ? 2.0f : 1.0f) * x * x;
+        acc += (i < n_trunk ? 2.0f : 1.0f) * x * x;  // trunk parameters appear twice in the reference's list
     }
     sh[tid] = acc;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) partial[blockIdx.x] = sh[0];
+}
+// stage 2: one workgroup: norm, clip coefficient, entropy mean, total loss
+__global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, const float* __restrict__ partial, int mb, MbView v,
+                                                             float* __restrict__ loss_out) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x;
+    sh[tid] = tid < kNormBlocks ? partial[tid] : 0.f;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
     const float total_norm = sqrtf(sh[0]);
     __syncthreads();
     float e = 0.f;
-    for (int r = tid; r < mb; r += 1024) e += v.ent_row[r];
+    for (int r = tid; r < mb; r += 256) e += v.ent_row[r];
     sh[tid] = e;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
@@ -732,17 +724,15 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
     hipLaunchKernelGGL(finalize_dh2_kernel, dim3(cdiv((long)n_pad * kH, 256)), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
     CIRS_CHECK_LAUNCH("finalize_dh2_kernel");
     // 6. critic + trunk backward
-    hipLaunchKernelGGL(critic_bwd_kernel, dim3(1), dim3(128), 0, s, mb, v, grads + L.wc, grads + L.bc);
-    CIRS_CHECK_LAUNCH("critic_bwd_kernel");
-    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv((long)kH * (kH + 1), 256)), dim3(256), 0, s, v.da2, v.h1, mb, kH, kH,
-                       grads + L.w2, grads + L.b2);
-    CIRS_CHECK_LAUNCH("linear_bwd_dw_kernel(w2)");
+    launch_dw(v.dvalue, v.h2, mb, 1, kH, grads + L.wc, grads + L.bc, v.dwp, s);  // d wc = sum_r dvalue_r h2[r], d bc
+    CIRS_CHECK_LAUNCH("dw(critic)");
+    launch_dw(v.da2, v.h1, mb, kH, kH, grads + L.w2, grads + L.b2, v.dwp, s);
+    CIRS_CHECK_LAUNCH("dw(w2)");
     hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv((long)n_pad * kH, 256)), dim3(256), 0, s, v.da2, w.w2, n_pad, kH, kH,
                        v.h1, v.da1);
     CIRS_CHECK_LAUNCH("linear_bwd_dx_kernel(h1)");
-    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdiv((long)kH * (S + 1), 256)), dim3(256), 0, s, v.da1, v.obs, mb, kH, S,
-                       grads + L.w1, grads + L.b1);
-    CIRS_CHECK_LAUNCH("linear_bwd_dw_kernel(w1)");
+    launch_dw(v.da1, v.obs, mb, kH, S, grads + L.w1, grads + L.b1, v.dwp, s);
+    CIRS_CHECK_LAUNCH("dw(w1)");
     if (dobs_accum) {
         float* dobs = v.dh2p;  // reuse: partial slabs are consumed
         hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv((long)mb * S, 256)), dim3(256), 0, s, v.da1, w.w1, mb, kH, S,
@@ -752,8 +742,9 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
         CIRS_CHECK_LAUNCH("scatter_dobs_kernel");
     }
     // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps; heads: once)
-    hipLaunchKernelGGL(gradnorm_kernel, dim3(1), dim3(1024), 0, s, *cfg, grads, L.trunk, L.total, mb, v, loss_out);
-    CIRS_CHECK_LAUNCH("gradnorm_kernel");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, v.normp);
+    hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, s, *cfg, v.normp, mb, v, loss_out);
+    CIRS_CHECK_LAUNCH("gradnorm");
     if (int rc = launch_adam(params, grads, adam_m, adam_v, L.trunk, 2 * opt_step, 2, cfg->lr, cfg->beta1, cfg->beta2,
                              cfg->adam_eps, v.red + 4, 2, s))
         return rc;

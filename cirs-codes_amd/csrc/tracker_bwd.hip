@@ -8,7 +8,7 @@
 // matters is that everything stays on device and every reduction has a fixed order.
 //   weight gradients : chunk-partial sums over 256-row chunks, then an ordered sum over chunks (two launches)
 //   embedding tables : zeroed, then one atomicAdd per (row, dim) -- the only order-dependent float sum in the path
-#include "common.h"
+#include "dense_small.h"
 
 namespace cirs {
 
@@ -39,33 +39,6 @@ __global__ __launch_bounds__(256) void lin_bwd_dx(const float* __restrict__ dY, 
     for (int o = 0; o < O; ++o) acc = __builtin_fmaf(dy[o], W[(size_t)o * K + k], acc);
     if (relu_of && !(relu_of[i] > 0.f)) acc = 0.f;
     dX[i] = accumulate ? dX[i] + acc : acc;
-}
-
-// stage 1: partial[c][o*(K+1)+k] = sum over the 256 rows of chunk c of dY[r,o]*X[r,k] (k == K: bias column)
-__global__ __launch_bounds__(256) void lin_bwd_dw_partial(const float* __restrict__ dY, const float* __restrict__ X, int R, int O,
-                                                          int K, float* __restrict__ partial) {
-    const int c = blockIdx.y;
-    const int r0 = c * kChunkRows, r1 = min(R, r0 + kChunkRows);
-    const int n_out = O * (K + 1);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += gridDim.x * blockDim.x) {
-        const int o = i / (K + 1), k = i % (K + 1);
-        float acc = 0.f;
-        if (k < K) for (int r = r0; r < r1; ++r) acc = __builtin_fmaf(dY[(size_t)r * O + o], X[(size_t)r * K + k], acc);
-        else for (int r = r0; r < r1; ++r) acc += dY[(size_t)r * O + o];
-        partial[(size_t)c * n_out + i] = acc;
-    }
-}
-// stage 2: ordered sum over chunks -> dW[o,k], db[o]
-__global__ __launch_bounds__(256) void lin_bwd_dw_final(const float* __restrict__ partial, int n_chunks, int O, int K,
-                                                        float* __restrict__ dW, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_out = O * (K + 1);
-    if (i >= n_out) return;
-    float acc = 0.f;
-    for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n_out + i];
-    const int o = i / (K + 1), k = i % (K + 1);
-    if (k < K) dW[(size_t)o * K + k] = acc;
-    else if (db) db[o] = acc;
 }
 
 // slot gather + scale + positional encoding: X0[r] = x_hist[b,p], H0 = X0*sqrt(D) + pe[p]
@@ -374,8 +347,7 @@ static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     f += (size_t)(nl + 1) * R * tD;               // H
     f += (size_t)nl * R * (96 + NH * Lp + tD + tD + 1 + tD + tH + tD + 1);
     f += 3 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp;  // T0..2, dQKV, dFF1, dS
-    const size_t chunks = (size_t)((R + kChunkRows - 1) / kChunkRows);
-    f += chunks * (size_t)tH * (tD + 1) + 4096;  // partial (largest: 128 x 33)
+    f += dw_partial_floats(R, tH, tD) + dw_partial_floats(R, 2, tD) + 4096;  // partial (largest: 128 x 33)
     f += (size_t)R * (tD + 1);                    // GIN
     return f + 64 * 32;
 }
@@ -394,8 +366,7 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
     }
     s.T0 = take((size_t)R * tD); s.T1 = take((size_t)R * tD); s.T2 = take((size_t)R * tD);
     s.dQKV = take((size_t)R * 96); s.dFF1 = take((size_t)R * tH); s.dS = take((size_t)R * NH * Lp);
-    const size_t chunks = (size_t)((R + kChunkRows - 1) / kChunkRows);
-    s.partial = take(chunks * (size_t)tH * (tD + 1) + 4096);
+    s.partial = take(dw_partial_floats(R, tH, tD) + dw_partial_floats(R, 2, tD) + 4096);
     s.GIN = take((size_t)R * (tD + 1));
     return s;
 }
@@ -424,11 +395,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     const int n_chunks = cdiv(R, kChunkRows);
     auto g1 = [&](long n) { return dim3(cdiv(n, 256)); };
 
-#define DW(dY, X, O, K, dWp, dbp)                                                                                        \
-    do {                                                                                                                 \
-        hipLaunchKernelGGL(lin_bwd_dw_partial, dim3(cdiv((O) * ((K) + 1), 256), n_chunks), dim3(256), 0, s, dY, X, R, O, K, sc.partial); \
-        hipLaunchKernelGGL(lin_bwd_dw_final, g1((O) * ((K) + 1)), dim3(256), 0, s, sc.partial, n_chunks, O, K, dWp, dbp);  \
-    } while (0)
+#define DW(dY, X, O, K, dWp, dbp) launch_dw(dY, X, R, O, K, dWp, dbp, sc.partial, s)
 #define ATT_DISPATCH_SH(KERNEL, SHMEM, ...)                                                               \
     do {                                                                                                  \
         switch (NH) {                                                                                     \
