@@ -76,8 +76,11 @@ def hip_event_kernel_time(eng, wl, reps=20):
     return start.elapsed_time(stop) / reps * 1e-3, mb  # seconds per minibatch step
 
 
-def cpu_baseline(wl, budget_envs=32):
-    """The oracle port of the same step on the host cores, bounded sample (fewer envs, same tables / episode rule)."""
+def cpu_baseline(wl, budget_envs=256, threads=None):
+    """The oracle port of the same step on the host cores, bounded sample (fewer envs, same tables / episode rule).
+    Threads are capped: the per-step tensors are tiny and oversubscribing a 256-core host makes the port slower."""
+    threads = threads or min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_path
@@ -88,13 +91,13 @@ def cpu_baseline(wl, budget_envs=32):
     tp = rolloutcase.tracker_param_dict(wl["U"], wl["I"], wl["T"], seed=2, emb_scale=0.01)
     arrs = policycase.random_weights(np.random.RandomState(2), wl["I"])
     B = min(budget_envs, wl["B"])
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     cpu_path.run_cpu_step(tab, tp, arrs, 4, wl["T"], N=wl["N"], thr=wl["thr"], do_update=False)  # warm-up
     t0 = time.perf_counter()
     r = cpu_path.run_cpu_step(tab, tp, arrs, B, wl["T"], N=wl["N"], thr=wl["thr"], tau=wl["tau"],
                               gamma_exposure=wl["gamma_exposure"], batch_size=1024, repeat=2)
     dt = time.perf_counter() - t0
-    return {"value": r["env_steps"] / dt, "unit": "env-steps/s", "cores": os.cpu_count() or 1, "kind": "port",
+    return {"value": r["env_steps"] / dt, "unit": "env-steps/s", "cores": threads, "host_cores": os.cpu_count() or 1, "kind": "port",
             "sample": f"1 step (collect + update) with {B} envs on the same {wl['U']}x{wl['I']} tables: {r['env_steps']} env-steps, "
                       f"{r['minibatches']} PPO minibatch steps, collect {r['t_collect']:.2f}s + update {r['t_update']:.2f}s "
                       "(C oracle env/actor via OpenMP, torch-fp32 tracker/PPO restatement)"}
@@ -160,7 +163,7 @@ def main():
 
     # split (untimed extra pass, same state): rollout-only and update-only rates
     barrier()
-    ta = time.perf_counter(); eng.collect(); torch.cuda.synchronize(); tb = time.perf_counter()
+    ta = time.perf_counter(); eng.collect(); n_ro = int(eng.lengths.sum()); torch.cuda.synchronize(); tb = time.perf_counter()
     l2, n2 = eng.update(1024, 2); torch.cuda.synchronize(); tc = time.perf_counter()
 
     if rank == 0:
@@ -178,7 +181,7 @@ def main():
             "config": {"workload": wl["name"], "envs_total": wl["B"] * world,
                        "parallelism": f"env-sharded x{world}, one all-gather of trajectories per update, replicated learner"},
             "ppo_minibatch_steps_per_s": mb_steps / elapsed,
-            "rollout_only_env_steps_per_s": int(eng.lengths.sum()) / (tb - ta),
+            "rollout_only_env_steps_per_s": n_ro / (tb - ta),
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
             "roofline": {"bound": "mfma", "kernel": "PPO minibatch step: actor_head_kernel<stats> + head_bwd_dwa_kernel + head_bwd_dh2_kernel (+ small kernels)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
