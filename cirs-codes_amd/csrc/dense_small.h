@@ -1,7 +1,7 @@
 // dense_small.h -- small dense helpers shared by ppo.hip and tracker_bwd.hip.
 //
 // dW[o,k] = sum_r dY[r,o] * X[r,k]  (k == K is the bias column: db[o] = sum_r dY[r,o]) for O, K <= 129 and thousands
-// of rows.  Stage 1: each workgroup stages a 128-row slab of dY and X in LDS (coalesced loads) and every thread
+// of rows.  Stage 1: each workgroup stages a 32-row slab of dY and X in LDS (coalesced loads) and every thread
 // accumulates its outputs from LDS; stage 2 sums the slab partials in slab order.  Two launches, fixed order, no
 // atomics -- the order (and therefore the bits) does not depend on the launch geometry.
 #pragma once
@@ -9,7 +9,7 @@
 
 namespace cirs {
 
-constexpr int kDwRows = 128;
+constexpr int kDwRows = 32;
 
 __host__ inline int dw_chunks(long R) { return (int)((R + kDwRows - 1) / kDwRows); }
 __host__ inline size_t dw_partial_floats(long R, int O, int K) { return (size_t)dw_chunks(R) * O * (K + 1); }

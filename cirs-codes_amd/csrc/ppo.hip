@@ -492,20 +492,32 @@ __global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict
     g_wa_ba[i] = acc;
 }
 
-// d a2 = (sum_chunks d h2 partial + dvalue * wc) * relu'(h2) ; entropy per row
+// d a2 = (sum_chunks d h2 partial + dvalue * wc) * relu'(h2) ; entropy per row.
+// One workgroup per row: thread (g, k) sums the chunk slabs c = g, g+4, ... for feature k, the four group sums are
+// then added in group order (fixed order, independent of timing).
 __global__ __launch_bounds__(256) void finalize_dh2_kernel(int mb, int n_pad, int n_chunks, const float* __restrict__ wc, MbView v) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= (long)n_pad * kH) return;
-    const int r = (int)(i / kH), k = (int)(i % kH);
+    __shared__ float sh[4][kH];
+    __shared__ float she[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int g = tid >> 6, k = tid & 63;
     float acc = 0.f;
-    for (int c = 0; c < n_chunks; ++c) acc += v.dh2p[(size_t)c * n_pad * kH + i];
-    acc = __builtin_fmaf(v.dvalue[r], wc[k], acc);
-    v.da2[i] = (r < mb && v.h2[i] > 0.f) ? acc : 0.f;
-    if (k == 0) {
-        float e = 0.f;
-        for (int c = 0; c < n_chunks; ++c) e += v.entp[(size_t)c * n_pad + r];
-        v.ent_row[r] = r < mb ? e : 0.f;
+    for (int c = g; c < n_chunks; c += 4) acc += v.dh2p[((size_t)c * n_pad + r) * kH + k];
+    sh[g][k] = acc;
+    float e = 0.f;
+    for (int c = tid; c < n_chunks; c += 256) e += v.entp[(size_t)c * n_pad + r];
+    she[tid] = e;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) she[tid] += she[tid + s];
+        __syncthreads();
     }
+    if (tid < kH) {
+        float t = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
+        t = __builtin_fmaf(v.dvalue[r], wc[k], t);
+        const size_t i = (size_t)r * kH + k;
+        v.da2[i] = (r < mb && v.h2[i] > 0.f) ? t : 0.f;
+    }
+    if (tid == 0) v.ent_row[r] = r < mb ? she[0] : 0.f;
 }
 
 // dX[r,k] = sum_o dY[r,o] * W[o,k]  (optionally masked by relu'(act[r,k]))
@@ -721,7 +733,7 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
     const long seg = (long)I * kH + I;
     hipLaunchKernelGGL(reduce_dwa_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, s, v.dwap, seg, grads + L.wa);
     CIRS_CHECK_LAUNCH("reduce_dwa_kernel");
-    hipLaunchKernelGGL(finalize_dh2_kernel, dim3(cdiv((long)n_pad * kH, 256)), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
+    hipLaunchKernelGGL(finalize_dh2_kernel, dim3(n_pad), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
     CIRS_CHECK_LAUNCH("finalize_dh2_kernel");
     // 6. critic + trunk backward
     launch_dw(v.dvalue, v.h2, mb, 1, kH, grads + L.wc, grads + L.bc, v.dwp, s);  // d wc = sum_r dvalue_r h2[r], d bc
