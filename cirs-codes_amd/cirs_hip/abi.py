@@ -78,6 +78,19 @@ class PpoBatch(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "act", "adv", "ret", "v_s", "logp_old", "row_env", "row_t")]
 
 
+class DeepFMCfg(C.Structure):
+    _fields_ = [("n_user_vocab", C.c_int32), ("n_item_vocab", C.c_int32), ("n_feat_vocab", C.c_int32),
+                ("emb_dim", C.c_int32), ("hidden", C.c_int32)]
+
+
+DEEPFM_FIELDS = ("emb_user", "emb_item", "emb_feat", "lin_user", "lin_item", "lin_feat", "lin_dense", "w1", "b1", "w2", "b2",
+                 "last", "out_bias")
+
+
+class DeepFMWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in DEEPFM_FIELDS]
+
+
 class Traj(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "act", "rew", "done", "logp", "value", "ctr")]
 
@@ -111,6 +124,11 @@ SIGNATURES = {
     "cirs_tracker_backward_workspace_bytes": (C.c_int64, [C.POINTER(TrackerCfg), C.c_int32]),
     "cirs_tracker_backward": (C.c_int, [C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState), _P, _P,
                                         _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(TrackerWeights), _P, C.c_int64, _P]),
+    "cirs_deepfm_forward": (C.c_int, [C.POINTER(DeepFMCfg), C.POINTER(DeepFMWeights), _P, _P, _P, _P, C.c_int32, _P, _P]),
+    "cirs_deepfm_sweep_workspace_bytes": (C.c_int64, [C.POINTER(DeepFMCfg), C.c_int32, C.c_int32]),
+    "cirs_deepfm_sweep": (C.c_int, [C.POINTER(DeepFMCfg), C.POINTER(DeepFMWeights), _P, C.c_int32, _P, _P, _P, C.c_int32,
+                                    _P, _P, C.c_int32, _P, C.c_int64, _P]),
+    "cirs_normed_reward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "cirs_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float,
                                  C.c_float, _P, C.c_int32, _P]),
 }

@@ -311,6 +311,50 @@ int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
                           const float* dstate, const cirs_tracker_grads* grads, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * DeepFM user model (UserModel_Pairwise) and the full-catalogue sweep
+ * replaces  core/user_model_pairwise.py:98-154 (_deepfm/forward), core/user_model.py:419-447 (input_from_feature_columns),
+ *           core/layers.py:43-72 (Linear), DeepCTR-Torch deepctr_torch/layers/interaction.py:26-34 (FM),
+ *           layers/core.py:120-134 (DNN), :155-161 (PredictionLayer, regression), inputs.py:126-138 (combined_dnn_input)
+ *           environments/KuaishouRec/env/kuaishouEnv.py:113-145 (compute_normed_reward)
+ * y = sum_f w_f[x_f] + dur*w_d  +  FM(v_user, v_item, v_f0..3)  +  last . DNN([v_user, v_item, v_f0..3, dur]) + bias
+ * Feature order in X: user_id, photo_id, feat0..feat3, photo_duration; the `feat` table is
+ * shared by feat0..3 (row 0 = padding, trained to stay zero).  hidden == 64 (two DNN layers), emb_dim in {8,16,32,64}.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct cirs_deepfm_cfg {
+    int32_t n_user_vocab, n_item_vocab, n_feat_vocab;
+    int32_t emb_dim; /* E */
+    int32_t hidden;  /* 64 */
+} cirs_deepfm_cfg;
+
+typedef struct cirs_deepfm_weights {
+    const float *emb_user, *emb_item, *emb_feat; /* embedding_dict.{user_id,photo_id,feat}.weight [V,E]            */
+    const float *lin_user, *lin_item, *lin_feat; /* linear.embedding_dict.*.weight [V] (Q12: `linear`, not linear_model) */
+    const float* lin_dense;                      /* linear.weight [1] (photo_duration)                              */
+    const float *w1, *b1;                        /* dnn.linears.0 [H, 6E+1], [H]                                     */
+    const float *w2, *b2;                        /* dnn.linears.1 [H, H], [H]                                        */
+    const float* last;                           /* last.weight [H]                                                  */
+    const float* out_bias;                       /* out.bias [1]                                                     */
+} cirs_deepfm_weights;
+
+/* UserModel_Pairwise.forward on n (user,item) rows: ids index the vocab tables directly (raw ids), feats[n,4]. */
+int cirs_deepfm_forward(const cirs_deepfm_cfg* cfg, const cirs_deepfm_weights* w, const int64_t* uid, const int64_t* pid,
+                        const int32_t* feats, const float* dur, int32_t n, float* out, void* stream);
+
+int64_t cirs_deepfm_sweep_workspace_bytes(const cirs_deepfm_cfg* cfg, int32_t n_users, int32_t n_items);
+
+/* Scores every (user, item) pair of users x items: pred_out[nu, ni] fp32 (nullable) and the global {min, max}
+ * (minmax[2], device; must be initialised to {+inf, -inf} by the caller or by passing init_minmax != 0).
+ * The DNN's first layer is split into a per-user and a per-item partial sum (each computed once), the 64x64 second
+ * layer runs on the fp32 matrix cores for 32 pairs at a time, the FM cross term is one E-long dot per pair. */
+int cirs_deepfm_sweep(const cirs_deepfm_cfg* cfg, const cirs_deepfm_weights* w, const int64_t* user_ids, int32_t nu,
+                      const int64_t* item_ids, const int32_t* item_feats, const float* item_dur, int32_t ni,
+                      float* pred_out, float* minmax, int32_t init_minmax, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
+/* normed = (pred - min) / (max - min) in float64 (kuaishouEnv.py:139-143) */
+int cirs_normed_reward(const float* pred, int64_t n, const float* minmax, double* normed_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

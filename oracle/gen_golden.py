@@ -350,7 +350,61 @@ def gen_learn():
           "perms", [len(p_) for p_ in perms])
 
 
-FAMILIES = {"learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+# --------------------------------------------------------------------------------------------------
+# deepfm family: UserModel_Pairwise.forward with the SHIPPED trained weights + compute_normed_reward
+# --------------------------------------------------------------------------------------------------
+def gen_deepfm():
+    import pickle
+    from core.user_model_pairwise import UserModel_Pairwise
+    from environments.KuaishouRec.env.kuaishouEnv import KuaishouEnv
+    base = os.path.join(ref_harness.REF_ROOT, "reproduce_results_of_our_paper", "results_alpha_beta")
+    with open(os.path.join(base, "DeepFM_params_Pair11.pickle"), "rb") as f:
+        params = pickle.load(f)
+    params["device"] = "cpu"
+    model = UserModel_Pairwise(**params)
+    model.load_state_dict(torch.load(os.path.join(base, "DeepFM_Pair11.pt"), map_location="cpu"))
+    model.eval()
+    sd = model.state_dict()
+    rng = np.random.RandomState(42)
+    n_u, n_i = 48, 200
+    raw_u = np.sort(rng.choice(7176, n_u, replace=False))
+    raw_i = np.sort(rng.choice(10729, n_i, replace=False))
+    n_cat = rng.randint(1, 5, size=n_i)
+    feats = np.zeros((n_i, 4), np.int64)  # 0 = padding (kuaishouEnv.py:94-96: categories shifted by +1)
+    for i in range(n_i):
+        feats[i, :n_cat[i]] = rng.choice(31, n_cat[i], replace=False) + 1
+    dur = rng.uniform(2, 60, n_i)
+    # pair scoring: random (user, item) pairs
+    n = 512
+    pu = rng.randint(0, n_u, n); pi = rng.randint(0, n_i, n)
+    X = np.concatenate([raw_u[pu, None], raw_i[pi, None], feats[pi], dur[pi, None]], axis=1)
+    with torch.no_grad():
+        y = model.forward(torch.tensor(X, dtype=torch.float)).squeeze(1).numpy()
+    # full sweep + normalisation through the reference's own routine
+    lbe_user = LabelEncoder().fit(raw_u); lbe_photo = LabelEncoder().fit(raw_i)
+    df_photo_env = pd.DataFrame(feats, index=raw_i, columns=["feat0", "feat1", "feat2", "feat3"])
+    df_photo_env.index.name = "photo_id"
+    df_photo_env["photo_duration"] = dur
+    normed = KuaishouEnv.compute_normed_reward(model, lbe_user, lbe_photo, df_photo_env)
+    with torch.no_grad():
+        pred = np.stack([model.forward(torch.tensor(np.concatenate([np.ones((n_i, 1)) * u, raw_i[:, None], feats, dur[:, None]], axis=1),
+                                                    dtype=torch.float)).squeeze(1).numpy() for u in raw_u])
+    out = dict(pu=pu, pi=pi, y=y, feats=feats, dur=dur.astype(np.float32), dur64=dur, normed=normed, pred=pred,
+               raw_u=raw_u, raw_i=raw_i,
+               emb_user=sd["embedding_dict.user_id.weight"].numpy()[raw_u], emb_item=sd["embedding_dict.photo_id.weight"].numpy()[raw_i],
+               emb_feat=sd["embedding_dict.feat.weight"].numpy(),
+               lin_user=sd["linear.embedding_dict.user_id.weight"].numpy()[raw_u, 0], lin_item=sd["linear.embedding_dict.photo_id.weight"].numpy()[raw_i, 0],
+               lin_feat=sd["linear.embedding_dict.feat.weight"].numpy()[:, 0], lin_dense=sd["linear.weight"].numpy().reshape(-1),
+               w1=sd["dnn.linears.0.weight"].numpy(), b1=sd["dnn.linears.0.bias"].numpy(),
+               w2=sd["dnn.linears.1.weight"].numpy(), b2=sd["dnn.linears.1.bias"].numpy(),
+               last=sd["last.weight"].numpy().reshape(-1), out_bias=sd["out.bias"].numpy().reshape(-1),
+               alpha_u=sd["ab_embedding_dict.alpha_u.weight"].numpy()[raw_u, 0], beta_i=sd["ab_embedding_dict.beta_i.weight"].numpy()[raw_i, 0])
+    np.savez_compressed(os.path.join(GOLDEN, "deepfm.npz"), **out)
+    print("deepfm.npz: y range", float(y.min()), float(y.max()), "pred", pred.shape, "normed range", float(normed.min()), float(normed.max()),
+          "feat row0 norm", float(np.abs(out["emb_feat"][0]).max()), "keys", [k for k in sd.keys()][:30])
+
+
+FAMILIES = {"deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)
