@@ -1,0 +1,87 @@
+"""Collector (reference core/collector.py:25-367) on the fused device rollout.
+
+Keeps the constructor and `collect(n_episode=...)` contract incl. the result dict (collector.py:343-362), the fresh
+buffer per collect (:113-121), `remove_recommended_ids` and `force_length` (:253-258).  The per-step Python loop
+(policy -> env.step -> preprocess_fn -> buffer.add) is one call to cirs_rollout_steps; the replay buffer is filled
+from the device trajectory afterwards.  Like the reference's scripts it requires n_episode == env_num (finished envs
+are dropped, never reset: SURVEY Q4)."""
+import time
+from typing import Any, Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from cirs_hip.rollout import DeviceRollout
+from tianshou.data import Batch, VectorReplayBuffer
+
+
+class Collector:
+    def __init__(self, policy, env, buffer: Optional[VectorReplayBuffer] = None, preprocess_fn: Optional[Callable[..., Any]] = None,
+                 exploration_noise: bool = False, remove_recommended_ids=False, force_length=0):
+        assert hasattr(env, "__len__"), "pass a tianshou.env.DummyVectorEnv"
+        assert preprocess_fn is not None and hasattr(preprocess_fn, "__self__"), \
+            "preprocess_fn must be StateTrackerTransformer.build_state (CIRS-RL-kuaishou.py:291)"
+        assert not exploration_noise
+        self.env, self.env_num = env, len(env)
+        self.policy = policy
+        self.preprocess_fn = preprocess_fn
+        self.tracker = preprocess_fn.__self__
+        self.remove_recommended_ids = remove_recommended_ids
+        self.force_length = force_length
+        self._action_space = env.action_space
+        self.buffer = buffer if buffer is not None else VectorReplayBuffer(self.env_num, self.env_num)
+        assert self.buffer.buffer_num >= self.env_num
+        self._rollout: Optional[DeviceRollout] = None
+        self._collect_count = 0
+        self.data = Batch()
+        if hasattr(policy, "_tracker") and env.workers[0].simulated:
+            policy._tracker = self.tracker  # the gradient through the stored obs goes to this tracker (ppo.py:215)
+        self.reset_stat()
+
+    def reset_stat(self):
+        self.collect_step, self.collect_episode, self.collect_time = 0, 0, 0.0
+
+    def reset_buffer(self, keep_statistics: bool = False):
+        self.buffer = VectorReplayBuffer(self.buffer.maxsize, self.buffer.buffer_num)  # a brand-new buffer per collect
+
+    def reset_env(self):
+        pass  # env reset + tracker init happen at the start of the fused rollout
+
+    def reset(self):
+        self.reset_env()
+        self.reset_buffer()
+        self.reset_stat()
+
+    def _get_rollout(self) -> DeviceRollout:
+        if self._rollout is None:
+            dev_env = self.env.device_env()
+            trk = self.tracker.engine(self.env_num)
+            self._rollout = DeviceRollout(dev_env, trk, self.policy.device_policy(), remove_recommended_ids=self.remove_recommended_ids,
+                                          force_length=self.force_length)
+        return self._rollout
+
+    def collect(self, n_step: Optional[int] = None, n_episode: Optional[int] = None, random: bool = False, render=None,
+                no_grad: bool = True, users=None) -> Dict[str, Any]:
+        assert n_step is None and n_episode is not None, "the CIRS scripts collect whole episodes (n_episode)"
+        assert n_episode == self.env_num, "n_episode must equal the number of envs (finished envs are not reset, SURVEY Q4)"
+        assert not random
+        start = time.time()
+        ro = self._get_rollout()
+        self.reset_buffer()
+        if users is None:
+            users = self.env.draw_users(self.env_num)
+        users_t = torch.as_tensor(np.asarray(users))
+        T = ro.env.max_turn
+        lengths = ro.collect(users_t, seed=self.policy.seed, rng_base=(self._collect_count * T) & 0xFFFFFFFF).cpu().numpy()
+        self._collect_count += 1
+        self.buffer.fill_from_trajectory(ro.traj, lengths)
+        self.policy._rollout = ro
+        self.policy._users = users_t
+        tr = ro.traj
+        ep_rew = (tr.rew * (tr.act >= 0)).sum(0).cpu().numpy()
+        step_count, episode_count = int(lengths.sum()), self.env_num
+        self.collect_step += step_count
+        self.collect_episode += episode_count
+        self.collect_time += max(time.time() - start, 1e-9)
+        return {"n/ep": episode_count, "n/st": step_count, "rews": ep_rew, "lens": lengths, "idxs": self.buffer._offset.copy(),
+                "rew": float(ep_rew.mean()), "len": float(lengths.mean()), "rew_std": float(ep_rew.std()), "len_std": float(lengths.std())}

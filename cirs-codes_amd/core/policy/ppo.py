@@ -1,0 +1,116 @@
+"""PPOPolicy (reference core/policy/ppo.py:14-246 on top of tianshou A2CPolicy/PGPolicy/BasePolicy) on the device engines.
+
+Same constructor keywords as the reference script passes (CIRS-RL-kuaishou.py:267-285) and the same protocol:
+  policy(batch, buffer, state=None, remove_recommended_ids=False) -> Batch(act, ...)        (collector.py:233)
+  policy.update(0, buffer, batch_size=, repeat=) -> {"loss", "loss/clip", "loss/vf", "loss/ent"}   (onpolicy.py:199-201)
+`optim` is the list [optim_RL, optim_state]; the torch optimisers are used for their hyper-parameters only -- the
+update itself (clip_grad_norm_ + Adam, incl. the duplicated-trunk quirk) runs in csrc/ppo.hip on flat buffers."""
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from cirs_hip.learner import DeviceLearner, flat_policy_params
+from cirs_hip.policy import DevicePolicy
+from tianshou.data import Batch
+
+
+class PPOPolicy(nn.Module):
+    def __init__(self, actor, critic, optim, dist_fn=None, eps_clip=0.2, dual_clip=None, value_clip=False,
+                 advantage_normalization=True, recompute_advantage=False, discount_factor=0.99, vf_coef=0.5, ent_coef=0.01,
+                 max_grad_norm=None, gae_lambda=0.95, max_batchsize=256, reward_normalization=False, action_scaling=True,
+                 action_bound_method="clip", action_space=None, lr_scheduler=None, deterministic_eval=False, **kwargs):
+        super().__init__()
+        assert dual_clip is None, "dual-clip PPO is not used by CIRS (CIRS-RL-kuaishou.py:279-280) and not built"
+        assert not recompute_advantage, "recompute_advantage=0 in the reference's runs; not built"
+        assert not deterministic_eval, "the reference never enables deterministic_eval for KuaishouEnv (SURVEY Q10)"
+        if not reward_normalization:
+            assert not value_clip, "value clip is available only when `reward_normalization` is True"
+        self.actor, self.critic = actor, critic
+        self.optim = optim
+        self.callbacks: List[Any] = []
+        self.updating = False
+        self.lr_scheduler = lr_scheduler
+        self._hyper = dict(gamma=discount_factor, gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
+                           max_grad_norm=max_grad_norm, norm_adv=advantage_normalization, value_clip=value_clip,
+                           rew_norm=reward_normalization)
+        optim_RL = optim[0] if isinstance(optim, (list, tuple)) else optim
+        g = optim_RL.param_groups[0]
+        self._hyper.update(lr=g["lr"], betas=tuple(g.get("betas", (0.9, 0.999))), adam_eps=g.get("eps", 1e-8))
+        self._tracker_lr = optim[1].param_groups[0]["lr"] if isinstance(optim, (list, tuple)) and len(optim) > 1 else g["lr"]
+        # bind the modules' parameters into one flat device buffer (layout of include/cirs_hip.h)
+        net = actor.preprocess
+        assert critic.preprocess is net, "CIRS shares the trunk between actor and critic (CIRS-RL-kuaishou.py:245-247)"
+        lin1, lin2 = net.model.model[0], net.model.model[2]
+        head_a, head_c = actor.last.model[0], critic.last.model[0]
+        self.n_items, self.dim_state, self.hidden = head_a.out_features, lin1.in_features, lin1.out_features
+        dev = torch.device("cuda")
+        init = {"actor.preprocess.model.model.0.weight": lin1.weight.data, "actor.preprocess.model.model.0.bias": lin1.bias.data,
+                "actor.preprocess.model.model.2.weight": lin2.weight.data, "actor.preprocess.model.model.2.bias": lin2.bias.data,
+                "actor.last.model.0.weight": head_a.weight.data, "actor.last.model.0.bias": head_a.bias.data,
+                "critic.last.model.0.weight": head_c.weight.data, "critic.last.model.0.bias": head_c.bias.data}
+        self.flat, self.views = flat_policy_params(self.n_items, self.dim_state, self.hidden, device=dev, init=init)
+        for mod, pre in ((lin1, "actor.preprocess.model.model.0"), (lin2, "actor.preprocess.model.model.2"),
+                         (head_a, "actor.last.model.0"), (head_c, "critic.last.model.0")):
+            mod.weight.data = self.views[pre + ".weight"]
+            mod.bias.data = self.views[pre + ".bias"]
+        self._dev_policy = DevicePolicy(self.views, self.n_items, dim_state=self.dim_state, hidden=self.hidden, device=dev)
+        self._learner: Optional[DeviceLearner] = None
+        self._tracker = None      # set by the Collector (preprocess_fn's owner)
+        self._rollout = None      # the collector's DeviceRollout (trajectory + lens of the last collect)
+        self._users = None
+        self.seed = int(torch.initial_seed() & 0x7FFFFFFF)
+
+    # ---- protocol pieces the Collector / trainer call ----------------------------------------------------------------
+    def device_policy(self) -> DevicePolicy:
+        return self._dev_policy
+
+    def map_action(self, act):
+        return act  # action_scaling=False, action_bound_method="" for KuaishouEnv (CIRS-RL-kuaishou.py:283-284)
+
+    def exploration_noise(self, act, batch):
+        return act
+
+    def forward(self, batch, buffer=None, remove_recommended_ids=False, state=None, **kwargs):
+        if remove_recommended_ids:
+            raise NotImplementedError("id masking runs inside the fused rollout (Collector(remove_recommended_ids=True))")
+        obs = batch.obs
+        self._step_counter = getattr(self, "_step_counter", 0) + 1
+        act, logp, value = self._dev_policy.sample(obs.contiguous(), seed=self.seed, rng_step=self._step_counter & 0xFFFFFFFF)
+        return Batch(logits=None, act=act, state=None, dist=None, policy=Batch(logp=logp, value=value))
+
+    def _get_learner(self, n_env, max_turn):
+        if self._learner is None or self._learner.n_env != n_env or self._learner.max_turn != max_turn:
+            h = self._hyper
+            rms = None if self._learner is None else self._learner.rms_state
+            self._learner = DeviceLearner(self.flat, self.n_items, n_env, max_turn, dim_state=self.dim_state, hidden=self.hidden,
+                                          gamma=h["gamma"], gae_lambda=h["gae_lambda"], eps_clip=h["eps_clip"], vf_coef=h["vf_coef"],
+                                          ent_coef=h["ent_coef"], max_grad_norm=h["max_grad_norm"], lr=h["lr"], norm_adv=h["norm_adv"],
+                                          value_clip=h["value_clip"], rew_norm=h["rew_norm"], betas=h["betas"], adam_eps=h["adam_eps"])
+            if rms is not None:
+                self._learner.rms_state.copy_(rms)
+        return self._learner
+
+    def update(self, sample_size: int, buffer, batch_size: int = 1024, repeat: int = 2, perms=None, **kwargs) -> Dict[str, List[float]]:
+        """BasePolicy.update (base.py:219-244): process_fn + learn on the whole buffer, then the tracker's Adam step."""
+        if buffer is None:
+            return {}
+        assert sample_size == 0, "on-policy: the whole buffer is used (onpolicy.py:199-201)"
+        ro = self._rollout
+        assert ro is not None and buffer._traj is ro.traj, "update() consumes the buffer of the last Collector.collect()"
+        self.updating = True
+        lens = np.asarray(buffer._lengths, dtype=np.int32)
+        ln = self._get_learner(ro.env.n_env, ro.env.max_turn)
+        n = ln.prepare(ro.traj, lens)
+        losses = ln.learn(batch_size, repeat, perms=perms, want_tracker_grad=self._tracker is not None)
+        if self._tracker is not None:
+            eng = self._tracker.engine()
+            eng.lr = self._tracker_lr
+            offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+            dev = self.flat.device
+            eng.backward(self._users, ro.traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).to(dev), torch.as_tensor(lens).to(dev), n, ln.dobs)
+            eng.adam_update()
+        self.updating = False
+        lo = losses.cpu().numpy()
+        return {"loss": lo[:, 0].tolist(), "loss/clip": lo[:, 1].tolist(), "loss/vf": lo[:, 2].tolist(), "loss/ent": lo[:, 3].tolist()}

@@ -1,0 +1,82 @@
+"""StateTrackerTransformer (reference core/state_tracker.py:128-250) on the device engine.
+
+Same constructor keywords and the same three `build_state` call forms the Collector uses (collector.py:127-134,261-269).
+Parameters are exposed under the reference's state_dict names but live in ONE flat device buffer; the forward is the
+KV-cached decode kernel (csrc/tracker.hip) and the gradient arrives through cirs_tracker_backward (no autograd graph)."""
+import numpy as np
+import torch
+from torch import nn
+
+from cirs_hip.engine import init_tracker_params
+from cirs_hip.tracker import DeviceTracker, flat_tracker_params, tracker_param_shapes
+
+
+class StateTrackerTransformer(nn.Module):
+    def __init__(self, user_columns, action_columns, feedback_columns, dim_model, dim_state, dim_max_batch, dropout=0.1,
+                 dataset="KuaishouEnv-v0", has_user_embedding=True, has_action_embedding=True, has_feedback_embedding=False,
+                 nhead=8, d_hid=128, nlayers=2, device="cpu", seed=2021, init_std=0.0001, padding_idx=None, MAX_TURN=100):
+        super().__init__()
+        if dataset != "KuaishouEnv-v0":
+            raise NotImplementedError("only the KuaishouEnv tracker is on the MI355X path")
+        self.dataset, self.device = dataset, torch.device(device if str(device) != "cpu" else "cuda")
+        self.dim_model, self.dim_state, self.nhead, self.d_hid, self.nlayers = dim_model, dim_state, nhead, d_hid, nlayers
+        self.MAX_TURN = MAX_TURN + 1
+        self.n_users, self.n_items = user_columns[0].vocabulary_size, action_columns[0].vocabulary_size
+        self.dropout_p = dropout  # the device path runs with dropout off
+        init = init_tracker_params(self.n_users, self.n_items, MAX_TURN, seed=seed, dim_model=dim_model, dim_state=dim_state,
+                                   nhead=nhead, d_hid=d_hid, nlayers=nlayers, init_std=init_std)
+        shapes = tracker_param_shapes(self.n_users, self.n_items, dim_model, dim_state, d_hid, nlayers)
+        self.flat, views = flat_tracker_params(shapes, device=self.device, init=init)
+        self._views = views
+        for name, v in views.items():  # register under the reference's names (dots -> nested attribute path)
+            self._register(name, nn.Parameter(v, requires_grad=False))
+        self.register_buffer("pe", init["pos_encoder.pe"].to(self.device))
+        self._engine = None
+        self._n_env = None
+
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], param)
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        sd["pos_encoder.pe"] = sd.pop("pe")
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        with torch.no_grad():
+            for k, v in self._views.items():
+                v.copy_(torch.as_tensor(sd[k]).to(v.device, v.dtype).reshape(v.shape))
+
+    def engine(self, n_env=None) -> DeviceTracker:
+        n_env = n_env or self._n_env
+        if self._engine is None or self._engine.cfg.n_env != n_env:
+            params = dict(self._views)
+            params["pos_encoder.pe"] = self.pe
+            self._engine = DeviceTracker(params, self.n_users, self.n_items, n_env, self.MAX_TURN - 1, dim_model=self.dim_model,
+                                         dim_state=self.dim_state, nhead=self.nhead, d_hid=self.d_hid, nlayers=self.nlayers,
+                                         device=self.device)
+            self._engine.enable_training(self.flat)
+            self._n_env = n_env
+        return self._engine
+
+    def build_state(self, obs=None, env_id=None, obs_next=None, rew=None, done=None, info=None, policy=None, dim_batch=None,
+                    reset=False):
+        if reset and dim_batch:
+            self.engine(dim_batch).reset()
+            return
+        eng = self.engine()
+        ids = None if env_id is None else torch.as_tensor(np.asarray(env_id).astype(np.int32)).to(self.device)
+        if obs is not None:
+            users = torch.as_tensor(np.asarray(obs).reshape(-1))
+            return {"obs": eng.init(users, ids)}
+        if obs_next is not None:
+            items = torch.as_tensor(np.asarray(obs_next).reshape(-1))
+            r = torch.as_tensor(np.asarray(rew, dtype=np.float64).reshape(-1))
+            return {"obs_next": eng.step(items, r, ids)}
+        return {}

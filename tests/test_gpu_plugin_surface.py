@@ -1,0 +1,78 @@
+"""GPU: the mirrored plugin surface (core.collector / core.state_tracker / core.policy.ppo / tianshou.* /
+environments.*) wired like CIRS-RL-kuaishou.py is a thin layer: collect + update give bit-identical trajectories
+and parameters to driving the engines directly."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_example():
+    spec = importlib.util.spec_from_file_location("cirs_rl_kuaishou_synth", os.path.join(ROOT, "examples", "cirs_rl_kuaishou_synth.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_script_wiring_runs_and_matches_engine():
+    ex = load_example()
+    args = ex.get_args(["--n-users", "200", "--n-items", "500", "--training-num", "32", "--episode-per-collect", "32",
+                        "--batch-size", "64", "--max_turn", "15", "--tau", "10"])
+    tab, train_envs, st, policy, coll = ex.build(args)
+    # state_dict names of the reference
+    assert "embedding_dict.feat_item.weight" in st.state_dict() and "transformer_encoder.layers.1.linear2.weight" in st.state_dict()
+    assert "actor.last.model.0.weight" in policy.state_dict() and "critic.preprocess.model.model.2.bias" in policy.state_dict()
+    assert coll.env.mat[0].shape == (200, 500)  # BaseVectorEnv.__getattr__ fan-out the callbacks rely on (evaluation.py:289)
+    tp0 = {k: v.detach().clone() for k, v in st.state_dict().items()}
+    pp0 = {k: v.detach().clone() for k, v in policy.views.items()}
+
+    users = np.random.RandomState(5).randint(0, 200, 32)
+    res = coll.collect(n_episode=32, users=users)
+    assert res["n/ep"] == 32 and res["n/st"] == int(res["lens"].sum()) and len(res["rews"]) == 32
+    buf = coll.buffer
+    assert len(buf) == res["n/st"]
+    batch, idx = buf.sample(0)
+    assert batch.obs.shape == (res["n/st"], 20) and batch.act.shape == (res["n/st"],)
+    assert bool(batch.done[np.cumsum(res["lens"]) - 1].all()) and int(batch.done.sum()) == 32
+    n = res["n/st"]
+    perms = [np.random.RandomState(9 + k).permutation(n) for k in range(2)]
+    losses = policy.update(0, buf, batch_size=64, repeat=2, perms=perms)
+    assert set(losses) == {"loss", "loss/clip", "loss/vf", "loss/ent"} and np.isfinite(losses["loss"]).all()
+
+    # the same thing through the engine, from the same initial parameters / users / seeds / permutations
+    from cirs_hip.engine import CirsEngine
+    dt = coll.env.workers[0].env_task.device_tables(normed_mat=tab.normed_mat, alpha_u=tab.alpha_u, beta_i=tab.beta_i)
+    eng = CirsEngine(dt, 32, max_turn=15, num_leave_compute=args.num_leave_compute, leave_threshold=args.leave_threshold, tau=10.0,
+                     gamma_exposure=args.gamma_exposure, seed=0, tracker_params=tp0, policy_params=pp0)
+    eng.users = torch.as_tensor(users).to(eng.device, torch.int32)
+    eng.lengths = eng.rollout.collect(eng.users, seed=policy.seed, rng_base=0)
+    assert torch.equal(eng.rollout.traj.act, coll._rollout.traj.act)
+    assert torch.equal(eng.rollout.traj.rew, coll._rollout.traj.rew)
+    assert torch.equal(eng.rollout.traj.obs, coll._rollout.traj.obs)
+    eng.update(batch_size=64, repeat=2, perms=perms)
+    assert torch.equal(eng.policy_flat, policy.flat)
+    assert torch.equal(eng.tracker_flat, st.flat)
+
+
+def test_vector_env_protocol_and_test_envs():
+    """env.reset/step with numpy in/out (venvs.py:153-252) and the bare KuaishouEnv used by the test collectors."""
+    ex = load_example()
+    args = ex.get_args(["--n-users", "100", "--n-items", "300", "--training-num", "8", "--max_turn", "10"])
+    tab, train_envs, st, policy, coll = ex.build(args)
+    obs = train_envs.reset(users=np.arange(8))
+    assert obs.shape == (8, 1) and obs.dtype == np.int64 and np.array_equal(obs[:, 0], np.arange(8))
+    o, r, d, info = train_envs.step(np.arange(8) * 3, np.arange(8))
+    assert o.shape == (8, 1) and r.dtype == np.float64 and d.dtype == bool and "CTR" in info[0] and info[3]["env_id"] == 3
+    np.testing.assert_array_equal(o[:, 0], np.arange(8) * 3)
+    from tianshou.env import DummyVectorEnv
+    import gym
+    test_envs = DummyVectorEnv([lambda: gym.make(args.env) for _ in range(4)])
+    test_envs.reset(users=np.arange(4))
+    o, r, d, info = test_envs.step(np.array([5, 6, 7, 8]), np.arange(4))
+    np.testing.assert_array_equal(r, tab.mat[np.arange(4), [5, 6, 7, 8]])  # reward = mat[u, a] (kuaishouEnv.py:172)
+    assert "cum_reward" in info[0]
