@@ -35,7 +35,7 @@ class Collector:
         self._collect_count = 0
         self.data = Batch()
         if hasattr(policy, "_tracker") and env.workers[0].simulated:
-            policy._tracker = self.tracker  # the gradient through the stored obs goes to this tracker (ppo.py:215)
+            policy.__dict__["_tracker"] = self.tracker  # the gradient through the stored obs goes to this tracker (ppo.py:215)
         self.reset_stat()
 
     def reset_stat(self):
@@ -75,8 +75,8 @@ class Collector:
         lengths = ro.collect(users_t, seed=self.policy.seed, rng_base=(self._collect_count * T) & 0xFFFFFFFF).cpu().numpy()
         self._collect_count += 1
         self.buffer.fill_from_trajectory(ro.traj, lengths)
-        self.policy._rollout = ro
-        self.policy._users = users_t
+        self.policy.__dict__["_rollout"] = ro
+        self.policy.__dict__["_users"] = users_t
         tr = ro.traj
         ep_rew = (tr.rew * (tr.act >= 0)).sum(0).cpu().numpy()
         step_count, episode_count = int(lengths.sum()), self.env_num

@@ -57,9 +57,10 @@ class PPOPolicy(nn.Module):
             mod.bias.data = self.views[pre + ".bias"]
         self._dev_policy = DevicePolicy(self.views, self.n_items, dim_state=self.dim_state, hidden=self.hidden, device=dev)
         self._learner: Optional[DeviceLearner] = None
-        self._tracker = None      # set by the Collector (preprocess_fn's owner)
-        self._rollout = None      # the collector's DeviceRollout (trajectory + lens of the last collect)
-        self._users = None
+        # plain attributes (NOT sub-modules: the reference's policy does not own the tracker, CIRS-RL-kuaishou.py:267-285)
+        self.__dict__["_tracker"] = None   # set by the Collector (preprocess_fn's owner)
+        self.__dict__["_rollout"] = None   # the collector's DeviceRollout (trajectory + lens of the last collect)
+        self.__dict__["_users"] = None
         self.seed = int(torch.initial_seed() & 0x7FFFFFFF)
 
     # ---- protocol pieces the Collector / trainer call ----------------------------------------------------------------

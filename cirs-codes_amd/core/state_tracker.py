@@ -45,7 +45,9 @@ class StateTrackerTransformer(nn.Module):
 
     def state_dict(self, *args, **kwargs):
         sd = super().state_dict(*args, **kwargs)
-        sd["pos_encoder.pe"] = sd.pop("pe")
+        prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+        if prefix + "pe" in sd:
+            sd[prefix + "pos_encoder.pe"] = sd.pop(prefix + "pe")
         return sd
 
     def load_state_dict(self, sd, strict=True):
