@@ -7,7 +7,7 @@
 // "one wavefront per row" attention ops: the tensors are tiny (<= 128 features) and the work is latency-bound, what
 // matters is that everything stays on device and every reduction has a fixed order.
 //   weight gradients : chunk-partial sums over 256-row chunks, then an ordered sum over chunks (two launches)
-//   embedding tables : zeroed, then one atomicAdd per (row, dim) -- the only order-dependent float sum in the path
+//   embedding tables : per-row contributions, then one wavefront per table row sums its rows in a fixed order
 #include "dense_small.h"
 
 namespace cirs {
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
                                                 const int64_t* __restrict__ act, const double* __restrict__ rew,
                                                 const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t, int R, int B,
                                                 float* __restrict__ DU, float* __restrict__ EU, float* __restrict__ DPRE,
-                                                float* __restrict__ GIN, float* __restrict__ g_emb_user, float* __restrict__ g_emb_item) {
+                                                float* __restrict__ GIN, float* __restrict__ CU, float* __restrict__ CI,
+                                                int32_t* __restrict__ key_user, int32_t* __restrict__ key_item) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
         // dEmb_user[u, k] += sum_o dx[o] * ffn_user_w[o, k] : lane k
         float acc = 0.f;
         for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(__shfl(dx, o, CIRS_WAVE), w.ffn_user_w[(size_t)o * tD + d], acc);
-        if (lane < tD) atomicAdd(&g_emb_user[(size_t)u * tD + d], acc);
+        if (lane < tD) { CU[(size_t)r * tD + d] = acc; CI[(size_t)r * tD + d] = 0.f; }
+        if (lane == 0) { key_user[r] = u; key_item[r] = -1; }
     } else {
         const size_t ti = (size_t)(p - 1) * B + b;
         const long it = act[ti];
@@ -328,7 +330,45 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
         // d a[k] = dx[k]*g[k] + sum_o dpre[o] * gate_w[o, 1+k]
         float acc = dx * g;
         for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(__shfl(dpre, o, CIRS_WAVE), w.gate_w[(size_t)o * (tD + 1) + 1 + d], acc);
-        if (lane < tD) atomicAdd(&g_emb_item[(size_t)it * tD + d], acc);
+        if (lane < tD) { CI[(size_t)r * tD + d] = acc; CU[(size_t)r * tD + d] = 0.f; }
+        if (lane == 0) { key_item[r] = (int32_t)it; key_user[r] = -1; }
+    }
+}
+
+// Deterministic embedding-gradient scatter: one wavefront per table row scans the row keys; lane l accumulates the
+// matching rows r = l, l+64, ... in ascending order and the 64 lane sums are combined by a fixed butterfly, so the
+// result does not depend on scheduling (no float atomics).  O(rows x table) key reads, all from L2.
+__global__ __launch_bounds__(256) void emb_scatter_kernel(const int32_t* __restrict__ keys, const float* __restrict__ contrib, int R,
+                                                          int n_table, float* __restrict__ g_emb) {
+    const int lane = threadIdx.x & 63;
+    const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= n_table) return;
+    float acc[tD];
+#pragma unroll
+    for (int d = 0; d < tD; ++d) acc[d] = 0.f;
+    bool any = false;
+    for (int r = lane; r < R; r += CIRS_WAVE) {
+        if (keys[r] == id) {
+            any = true;
+            const float4* c4 = reinterpret_cast<const float4*>(contrib + (size_t)r * tD);
+#pragma unroll
+            for (int q = 0; q < tD / 4; ++q) {
+                const float4 t4 = c4[q];
+                acc[4 * q] += t4.x; acc[4 * q + 1] += t4.y; acc[4 * q + 2] += t4.z; acc[4 * q + 3] += t4.w;
+            }
+        }
+    }
+    if (__ballot(any) == 0ull) {
+        if (lane < tD) g_emb[(size_t)id * tD + lane] = 0.f;
+        return;
+    }
+#pragma unroll
+    for (int d = 0; d < tD; ++d) acc[d] = wave_sum_f32(acc[d]);
+    if (lane < tD) {
+        float val = 0.f;
+#pragma unroll
+        for (int d = 0; d < tD; ++d) val = lane == d ? acc[d] : val;
+        g_emb[(size_t)id * tD + lane] = val;
     }
 }
 
@@ -464,14 +504,18 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         }
     }
     CIRS_CHECK_LAUNCH("tracker backward layers");
-    // input slots + embeddings
-    CIRS_HIP(hipMemsetAsync(grads->emb_user, 0, sizeof(float) * (size_t)cfg->n_users * tD, s));
-    CIRS_HIP(hipMemsetAsync(grads->emb_item, 0, sizeof(float) * (size_t)cfg->n_items * tD, s));
+    // input slots + embeddings (forward activations are no longer needed: reuse their scratch)
     float* DU = sc.T1;
-    float* EU = sc.H[nl];   // forward activations are no longer needed
-    float* DPRE = sc.H[0] == dH ? sc.H[1] : sc.H[0];
+    float* EU = sc.H[nl];
+    float* DPRE = sc.H[0];
+    float* CU = sc.QKV[0];                 // [R,32] per-row contribution to Emb_user
+    float* CI = sc.QKV[0] + (size_t)R * tD; // [R,32] per-row contribution to Emb_item  (QKV is [R,96])
+    int32_t* key_user = (int32_t*)sc.RS1[0];
+    int32_t* key_item = (int32_t*)sc.RS2[0];
     hipLaunchKernelGGL(slot_bwd, dim3(cdiv(R, 4)), dim3(256), 0, s, *w, dH, users, act, rew, row_env, row_t, R, B, DU, EU, DPRE,
-                       sc.GIN, grads->emb_user, grads->emb_item);
+                       sc.GIN, CU, CI, key_user, key_item);
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(cfg->n_users, 4)), dim3(256), 0, s, key_user, CU, R, cfg->n_users, grads->emb_user);
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(cfg->n_items, 4)), dim3(256), 0, s, key_item, CI, R, cfg->n_items, grads->emb_item);
     DW(DU, EU, tD, tD, grads->ffn_user_w, grads->ffn_user_b);
     DW(DPRE, sc.GIN, tD, tD + 1, grads->gate_w, grads->gate_b);
     CIRS_CHECK_LAUNCH("tracker backward slots");

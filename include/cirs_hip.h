@@ -286,8 +286,8 @@ int cirs_adam_step(float* params, const float* grads, float* m, float* v, int64_
  * Because the mask is causal and dropout is off, the per-step recomputations of the reference are one causal
  * transformer pass over each episode; rows are the buffer rows (env b, position p = t), p < len_b.  The forward is
  * recomputed from the stored slots (x_hist) and back-propagated analytically down to the embedding tables.
- * All weight-gradient reductions over rows are two-stage with a fixed order (no float atomics), except the
- * embedding-table scatter which uses one atomic add per (row, dim).
+ * Every reduction over rows (weight gradients and the embedding-table scatter) has a fixed order: no float atomics,
+ * so replicated learners on different ranks produce identical bits.
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct cirs_tracker_layer_grads {
     float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b;
