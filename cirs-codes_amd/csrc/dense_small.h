@@ -9,30 +9,37 @@
 
 namespace cirs {
 
-constexpr int kDwRows = 32;
+constexpr int kDwRows = 32;       // rows staged in LDS at a time
+constexpr int kDwMaxChunks = 64;  // at most this many partial slabs (each workgroup walks several 32-row slabs)
 
-__host__ inline int dw_chunks(long R) { return (int)((R + kDwRows - 1) / kDwRows); }
+__host__ inline int dw_slabs(long R) { return (int)((R + kDwRows - 1) / kDwRows); }
+__host__ inline int dw_chunks(long R) { const int s = dw_slabs(R); return s < kDwMaxChunks ? s : kDwMaxChunks; }
 __host__ inline size_t dw_partial_floats(long R, int O, int K) { return (size_t)dw_chunks(R) * O * (K + 1); }
 
 static __global__ __launch_bounds__(256) void dw_partial_kernel(const float* __restrict__ dY, const float* __restrict__ X, int R,
-                                                                int O, int K, float* __restrict__ partial) {
+                                                                int O, int K, int slabs_per_chunk, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sY = sm;                        // [kDwRows][O]
     float* sX = sm + (size_t)kDwRows * O;  // [kDwRows][K]
     const int c = blockIdx.y;
-    const int r0 = c * kDwRows;
-    const int nr = min(kDwRows, R - r0);
-    for (int i = threadIdx.x; i < nr * O; i += blockDim.x) sY[i] = dY[(size_t)r0 * O + i];
-    for (int i = threadIdx.x; i < nr * K; i += blockDim.x) sX[i] = X[(size_t)r0 * K + i];
-    __syncthreads();
     const int n_out = O * (K + 1);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += gridDim.x * blockDim.x) {
-        const int o = i / (K + 1), k = i % (K + 1);
-        float acc = 0.f;
-        if (k < K) for (int r = 0; r < nr; ++r) acc = __builtin_fmaf(sY[r * O + o], sX[r * K + k], acc);
-        else for (int r = 0; r < nr; ++r) acc += sY[r * O + o];
-        partial[(size_t)c * n_out + i] = acc;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one output per thread
+    const int o = i / (K + 1), k = i % (K + 1);
+    float acc = 0.f;
+    for (int sl = 0; sl < slabs_per_chunk; ++sl) {
+        const int r0 = (c * slabs_per_chunk + sl) * kDwRows;
+        if (r0 >= R) break;
+        const int nr = min(kDwRows, R - r0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < nr * O; j += blockDim.x) sY[j] = dY[(size_t)r0 * O + j];
+        for (int j = threadIdx.x; j < nr * K; j += blockDim.x) sX[j] = X[(size_t)r0 * K + j];
+        __syncthreads();
+        if (i < n_out) {
+            if (k < K) for (int r = 0; r < nr; ++r) acc = __builtin_fmaf(sY[r * O + o], sX[r * K + k], acc);
+            else for (int r = 0; r < nr; ++r) acc += sY[r * O + o];
+        }
     }
+    if (i < n_out) partial[(size_t)c * n_out + i] = acc;
 }
 
 static __global__ __launch_bounds__(256) void dw_final_kernel(const float* __restrict__ partial, int n_chunks, int O, int K,
@@ -51,8 +58,9 @@ static __global__ __launch_bounds__(256) void dw_final_kernel(const float* __res
 static inline int launch_dw(const float* dY, const float* X, int R, int O, int K, float* dW, float* db, float* partial,
                             hipStream_t s) {
     const int n_out = O * (K + 1), chunks = dw_chunks(R);
+    const int slabs_per_chunk = (dw_slabs(R) + chunks - 1) / chunks;
     const size_t shmem = sizeof(float) * (size_t)kDwRows * (O + K);
-    hipLaunchKernelGGL(dw_partial_kernel, dim3(cdiv(n_out, 256), chunks), dim3(256), shmem, s, dY, X, R, O, K, partial);
+    hipLaunchKernelGGL(dw_partial_kernel, dim3(cdiv(n_out, 256), chunks), dim3(256), shmem, s, dY, X, R, O, K, slabs_per_chunk, partial);
     hipLaunchKernelGGL(dw_final_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, s, partial, chunks, O, K, dW, db);
     return CIRS_OK;
 }

@@ -167,17 +167,18 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
 
 __global__ __launch_bounds__(256) void gather_kernel(cirs_ppo_batch b, const int32_t* __restrict__ idx, int mb, int n_pad,
                                                      int S, MbView v) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_pad) return;
-    if (r < mb) {
-        const int src = idx[r];
-        for (int k = 0; k < S; ++k) v.obs[(size_t)r * S + k] = b.obs[(size_t)src * S + k];
-        v.adv[r] = b.adv[src]; v.ret[r] = b.ret[src]; v.v_s[r] = b.v_s[src]; v.logp_old[r] = b.logp_old[src];
-        v.act[r] = b.act[src];
-    } else {
-        for (int k = 0; k < S; ++k) v.obs[(size_t)r * S + k] = 0.f;
-        v.adv[r] = 0.f; v.ret[r] = 0.f; v.v_s[r] = 0.f; v.logp_old[r] = 0.f; v.act[r] = 0;
-    }
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;  // one thread per (row, column); columns S.. are the scalars
+    const int W = S + 5;
+    if (i >= (long)n_pad * W) return;
+    const int r = (int)(i / W), k = (int)(i % W);
+    const bool ok = r < mb;
+    const int src = ok ? idx[r] : 0;
+    if (k < S) v.obs[(size_t)r * S + k] = ok ? b.obs[(size_t)src * S + k] : 0.f;
+    else if (k == S) v.adv[r] = ok ? b.adv[src] : 0.f;
+    else if (k == S + 1) v.ret[r] = ok ? b.ret[src] : 0.f;
+    else if (k == S + 2) v.v_s[r] = ok ? b.v_s[src] : 0.f;
+    else if (k == S + 3) v.logp_old[r] = ok ? b.logp_old[src] : 0.f;
+    else v.act[r] = ok ? b.act[src] : 0;
 }
 
 // b.adv = (b.adv - mean) / std, torch.Tensor.std = unbiased (ppo.py:185-186).  One workgroup, fixed order.
@@ -421,8 +422,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
     f32x16 dh0, dh1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dh0[r] = 0.f; dh1[r] = 0.f; }
-    float ent = 0.f;
+    float ent = 0.f;  // clamp correction of the entropy (see below)
     const float eps = 1.1920928955078125e-7f;
+    const float kLogEps = -15.942385152878742f, kLog1mEps = -1.1920929665620834e-7f;
     for (int it = 0; it < kTilesPerChunk; ++it) {
         const int tile0 = chunk * kChunkItems + it * kTileN;
         if (tile0 >= I) break;
@@ -455,7 +457,10 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
             if (item < I && row_ok) {
                 float p;
                 d = dz_of(acc[r], lse, c_logp, c_ent, h_ent, item == act, p);
-                ent -= p * __logf(fminf(fmaxf(p, eps), 1.0f - eps));  // Categorical.entropy with the clamped log
+                // Categorical.entropy uses log(clamp(p, eps, 1-eps)): the un-clamped entropy lse - E_p[z] comes from the
+                // forward statistics; only the (rare) clamped elements contribute a correction here
+                if (p < eps) ent -= p * (kLogEps - (acc[r] - lse));
+                else if (p > 1.0f - eps) ent -= p * (kLog1mEps - (acc[r] - lse));
             }
             acc[r] = d;
         }
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256) void finalize_dh2_kernel(int mb, int n_pad, in
         const size_t i = (size_t)r * kH + k;
         v.da2[i] = (r < mb && v.h2[i] > 0.f) ? t : 0.f;
     }
-    if (tid == 0) v.ent_row[r] = r < mb ? she[0] : 0.f;
+    if (tid == 0) v.ent_row[r] = r < mb ? v.h_ent[r] + she[0] : 0.f;  // (lse - E_p[z]) + clamp correction
 }
 
 // dX[r,k] = sum_o dY[r,o] * W[o,k]  (optionally masked by relu'(act[r,k]))
@@ -705,7 +710,7 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
     cirs_policy_weights w{params + L.w1, params + L.b1, params + L.w2, params + L.b2,
                           params + L.wa, params + L.ba, params + L.wc, params + L.bc};
     // 1. gather + advantage normalisation
-    hipLaunchKernelGGL(gather_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, s, *batch, idx, mb, n_pad, S, v);
+    hipLaunchKernelGGL(gather_kernel, dim3(cdiv((long)n_pad * (S + 5), 256)), dim3(256), 0, s, *batch, idx, mb, n_pad, S, v);
     CIRS_CHECK_LAUNCH("gather_kernel");
     hipLaunchKernelGGL(adv_norm_kernel, dim3(1), dim3(1024), 0, s, v.adv, mb, cfg->norm_adv, v.red);
     CIRS_CHECK_LAUNCH("adv_norm_kernel");
