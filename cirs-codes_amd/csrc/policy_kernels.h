@@ -98,6 +98,8 @@ static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, 
 // block and one float4 bias load serve them.
 // grid = (n_chunks, ceil(n_pad/32/4)); block = 4 waves = 4 env tiles walking the same item chunk (shared Wa lines).
 // kSample: true  -> Gumbel-max sampling + LSE (rollout);  false -> LSE (+ sum exp(z-m) z for the entropy) only.
+constexpr int kLdsStride = 68;  // row stride (floats) of a staged 32 x 64 tile: ds_read_b128 of 16 lanes x 16 rows -> 64 banks
+
 template <bool kSample>
 __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa,
                                                             const float* __restrict__ ba,
@@ -107,28 +109,26 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
                                                             const uint32_t* __restrict__ visited,
                                                             const uint8_t* __restrict__ skip, ActorPartialView pv,
                                                             int n_pad) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // The Wa tile (32 items x 64) is staged in LDS once per workgroup and shared by its four env tiles; double
+    // buffered: global loads of tile t+1 are issued before the MFMAs of tile t (one barrier per tile).
+    __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
+    __shared__ float sB[2][kTileN];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * 4 + wv) * kTileM;
-    if (row0 >= n_pad) return;
     const int I = cfg.n_items;
     const int chunk = blockIdx.x;
     const int vis_words = (I + 31) / 32;
     const int jr = row0 + lo;  // this lane's env row
-    const bool active = jr < n && !(skip && skip[jr]);
+    const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
+    const bool wave_live = __ballot(active) != 0ull;  // some row of this env tile still runs
     const size_t po = (size_t)chunk * n_pad + jr;
-    if (__ballot(active) == 0ull) {  // every row of this env tile is finished: publish neutral partials
-        if (hi == 0) {
-            pv.score[po] = -INFINITY; pv.idx[po] = 0x7FFFFFFF; pv.m[po] = -INFINITY; pv.s[po] = 0.f;
-            if (!kSample) pv.score[po] = 0.f;
-        }
-        return;
-    }
     const int e = active ? (env_ids ? env_ids[jr] : jr) : 0;
 
     // B operand: this lane's env row of H2, k = hi*32 + kk
     float hrow[32];
-    if (jr < n) {
+    if (wave_live && jr < n) {
         const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)jr * kH + hi * 32);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -142,71 +142,104 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
     float best_score = -INFINITY, run_m = -INFINITY, run_s = 0.f, run_t = 0.f;
     int best_idx = 0x7FFFFFFF;
 
-    for (int it = 0; it < kTilesPerChunk; ++it) {
-        const int tile0 = chunk * kChunkItems + it * kTileN;  // multiple of 32
-        if (tile0 >= I) break;
-        const int item_a = tile0 + lo;  // A-operand item of this lane
-        float wrow[32];
-        if (item_a < I) {
-            const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item_a * kH + hi * 32);
+    const int st_item = tid >> 3, st_col = (tid & 7) * 8;  // staging role: 2 float4 of the tile
+    const int first_tile = chunk * kChunkItems;
+    int n_tiles = 0;
+    for (int it = 0; it < kTilesPerChunk; ++it) n_tiles += (first_tile + it * kTileN) < I;
+    // a workgroup whose four env tiles are all finished only publishes neutral partials
+    __shared__ int s_any;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    if (wave_live && lane == 0) s_any = 1;
+    __syncthreads();
+    const bool block_live = s_any != 0;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    float gb = 0.f;
+#define CIRS_ISSUE(TILE0)                                                                                  \
+    do {                                                                                                   \
+        const int item_ = (TILE0) + st_item;                                                               \
+        if (item_ < I) {                                                                                   \
+            const float4* src_ = reinterpret_cast<const float4*>(wa + (size_t)item_ * kH + st_col);        \
+            g0 = src_[0]; g1 = src_[1];                                                                    \
+        } else {                                                                                           \
+            g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0;                                                 \
+        }                                                                                                  \
+        if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
+    } while (0)
+#define CIRS_COMMIT(BUF)                                                                                   \
+    do {                                                                                                   \
+        float4* dst_ = reinterpret_cast<float4*>(&sW[BUF][st_item * kLdsStride + st_col]);                 \
+        dst_[0] = g0; dst_[1] = g1;                                                                        \
+        if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
+    } while (0)
+    if (block_live) {
+        if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
+        __syncthreads();
+        for (int it = 0; it < n_tiles; ++it) {
+            const int buf = it & 1;
+            const int tile0 = first_tile + it * kTileN;  // multiple of 32
+            if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);
+            if (wave_live) {
+                const float* tw = sW[buf];
+                float wrow[32];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = src[q];
-                wrow[4 * q + 0] = v.x; wrow[4 * q + 1] = v.y; wrow[4 * q + 2] = v.z; wrow[4 * q + 3] = v.w;
-            }
-        } else {
+                for (int q = 0; q < 8; ++q) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&tw[lo * kLdsStride + hi * 32 + 4 * q]);
+                    wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
+                }
+                f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) wrow[q] = 0.f;
-        }
-        f32x16 acc;
+                for (int r = 0; r < 16; ++r) acc[r] = sB[buf][(r & 3) + 8 * (r >> 2) + 4 * hi];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // bias of the 4 consecutive items of accumulator group g
-            const int i0 = tile0 + 8 * g + 4 * hi;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g + q] = (i0 + q) < I ? ba[i0 + q] : 0.f;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
+                for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
 
-        if (!active) continue;
-        const uint32_t vis = (kSample && visited) ? visited[(size_t)e * vis_words + (tile0 >> 5)] : 0u;
+                if (active) {
+                    const uint32_t vis = (kSample && visited) ? visited[(size_t)e * vis_words + (tile0 >> 5)] : 0u;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int i0 = tile0 + 8 * g + 4 * hi;
-            float g4[4];
-            if (kSample && !gumbel) {
-                const u32x4 rr = philox4x32_10((uint32_t)i0 >> 2, (uint32_t)e, rng_step, CIRS_RNG_STREAM_ACTOR,
-                                               (uint32_t)seed, (uint32_t)(seed >> 32));
-                g4[0] = gumbel_from_bits(rr.x); g4[1] = gumbel_from_bits(rr.y);
-                g4[2] = gumbel_from_bits(rr.z); g4[3] = gumbel_from_bits(rr.w);
-            }
+                    for (int g = 0; g < 4; ++g) {
+                        const int i0 = tile0 + 8 * g + 4 * hi;
+                        float g4[4];
+                        if (kSample && !gumbel) {
+                            const u32x4 rr = philox4x32_10((uint32_t)i0 >> 2, (uint32_t)e, rng_step, CIRS_RNG_STREAM_ACTOR,
+                                                           (uint32_t)seed, (uint32_t)(seed >> 32));
+                            g4[0] = gumbel_from_bits(rr.x); g4[1] = gumbel_from_bits(rr.y);
+                            g4[2] = gumbel_from_bits(rr.z); g4[3] = gumbel_from_bits(rr.w);
+                        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int item = i0 + q;
-                if (item >= I) continue;
-                if (kSample && ((vis >> (item & 31)) & 1u)) continue;
-                const float z = acc[4 * g + q];
-                if (kSample) {
-                    const float gn = gumbel ? gumbel[(size_t)jr * I + item] : g4[q];
-                    const float sc = z + gn;
-                    if (sc > best_score) {  // items ascend within a lane: strict > keeps the lowest id on ties
-                        best_score = sc; best_idx = item;
+                        for (int q = 0; q < 4; ++q) {
+                            const int item = i0 + q;
+                            if (item >= I) continue;
+                            if (kSample && ((vis >> (item & 31)) & 1u)) continue;
+                            const float z = acc[4 * g + q];
+                            if (kSample) {
+                                const float gn = gumbel ? gumbel[(size_t)jr * I + item] : g4[q];
+                                const float sc = z + gn;
+                                if (sc > best_score) {  // items ascend within a lane: strict > keeps the lowest id on ties
+                                    best_score = sc; best_idx = item;
+                                }
+                            }
+                            // online log-sum-exp with ONE exp per element: ex = exp(-|z - m|)
+                            const float dlt = z - run_m;
+                            const float ex = __expf(-fabsf(dlt));
+                            if (dlt > 0.f) {
+                                run_s = __builtin_fmaf(run_s, ex, 1.0f);
+                                if (!kSample) run_t = __builtin_fmaf(run_t, ex, z);
+                                run_m = z;
+                            } else {
+                                run_s += ex;
+                                if (!kSample) run_t = __builtin_fmaf(ex, z, run_t);
+                            }
+                        }
                     }
                 }
-                // online log-sum-exp with ONE exp per element: ex = exp(-|z - m|)
-                const float dlt = z - run_m;
-                const float ex = __expf(-fabsf(dlt));
-                if (dlt > 0.f) {
-                    run_s = __builtin_fmaf(run_s, ex, 1.0f);
-                    if (!kSample) run_t = __builtin_fmaf(run_t, ex, z);
-                    run_m = z;
-                } else {
-                    run_s += ex;
-                    if (!kSample) run_t = __builtin_fmaf(ex, z, run_t);
-                }
             }
+            if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);
+            __syncthreads();
         }
     }
+#undef CIRS_ISSUE
+#undef CIRS_COMMIT
+    if (row0 >= n_pad) return;
     // combine the two half-waves (same env row, disjoint items)
     {
         const float os = __shfl_xor(best_score, 32, CIRS_WAVE);

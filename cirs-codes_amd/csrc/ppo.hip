@@ -313,19 +313,25 @@ __device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c
 }
 
 // ---- head backward 1: dWa, dba.  Z layout (lane owns an ITEM column, registers are rows) -----------------------
-// grid = (ceil(n_item_tiles/4), kRowSplits); wave = one item tile; loops over the row tiles of its split.
+// grid = (ceil(n_item_tiles/4), kRowSplits); workgroup = 4 waves = 4 item tiles walking the row tiles of one split.
 //   Z[32 rows x 32 items]   = H2_tile * Wa_tile^T           (A = H2 rows, B = Wa rows)
 //   dWa_tile[32 items x 64] += dZ^T[items x rows] * H2_tile   (A = dZ registers AS THEY ARE, B = H2[row(s,hi)][n])
+// The H2 row tile (32 x 64) and the per-row coefficients are staged in LDS once per workgroup (double-buffered) and
+// serve both products of all four waves.
 __global__ __launch_bounds__(256, 2) void head_bwd_dwa_kernel(int I, int mb, int n_pad, const float* __restrict__ wa,
                                                               const float* __restrict__ ba, MbView v,
                                                               float* __restrict__ dwap) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float sH[2][kTileM * kLdsStride];
+    __shared__ __attribute__((aligned(16))) float4 sR[2][kTileM];  // {lse, c_logp, c_ent, h_ent} per row
+    __shared__ int sA[2][kTileM];                                   // action id per row
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int tile0 = (blockIdx.x * 4 + wv) * kTileN;
-    if (tile0 >= I) return;
+    const bool wave_ok = tile0 < I;
     const int split = blockIdx.y;
     const int item = tile0 + lo;
-    const bool item_ok = item < I;
+    const bool item_ok = wave_ok && item < I;
     float wrow[32];
     if (item_ok) {
         const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item * kH + hi * 32);
@@ -346,41 +352,69 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dwa_kernel(int I, int mb, int
     const int n_row_tiles = n_pad / kTileM;
     const int per = (n_row_tiles + kRowSplits - 1) / kRowSplits;
     const int rt_beg = split * per, rt_end = min(n_row_tiles, rt_beg + per);
+    const int st_row = tid >> 3, st_col = (tid & 7) * 8;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, gr = g0;
+    int ga = 0;
+#define CIRS_ISSUE(RT)                                                                                       \
+    do {                                                                                                     \
+        const float4* src_ = reinterpret_cast<const float4*>(v.h2 + (size_t)((RT) * kTileM + st_row) * kH + st_col); \
+        g0 = src_[0]; g1 = src_[1];                                                                          \
+        if (tid < kTileM) {                                                                                  \
+            const int row_ = (RT) * kTileM + tid;                                                            \
+            gr = make_float4(v.lse[row_], v.c_logp[row_], v.c_ent[row_], v.h_ent[row_]);                     \
+            ga = v.act[row_];                                                                                \
+        }                                                                                                    \
+    } while (0)
+#define CIRS_COMMIT(BUF)                                                                                     \
+    do {                                                                                                     \
+        float4* dst_ = reinterpret_cast<float4*>(&sH[BUF][st_row * kLdsStride + st_col]);                    \
+        dst_[0] = g0; dst_[1] = g1;                                                                          \
+        if (tid < kTileM) { sR[BUF][tid] = gr; sA[BUF][tid] = ga; }                                          \
+    } while (0)
+    if (rt_beg < rt_end) { CIRS_ISSUE(rt_beg); CIRS_COMMIT(0); }
+    __syncthreads();
     for (int rt = rt_beg; rt < rt_end; ++rt) {
-        const int row0 = rt * kTileM;
-        float hrow[32];
-        {
-            const float4* src = reinterpret_cast<const float4*>(v.h2 + (size_t)(row0 + lo) * kH + hi * 32);
+        const int buf = (rt - rt_beg) & 1;
+        if (rt + 1 < rt_end) CIRS_ISSUE(rt + 1);
+        if (wave_ok) {
+            const float* th = sH[buf];
+            float hrow[32];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float4 t4 = src[q];
+                const float4 t4 = *reinterpret_cast<const float4*>(&th[lo * kLdsStride + hi * 32 + 4 * q]);
                 hrow[4 * q] = t4.x; hrow[4 * q + 1] = t4.y; hrow[4 * q + 2] = t4.z; hrow[4 * q + 3] = t4.w;
             }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[kk], wrow[kk], acc, 0, 0, 0);
+            // dZ in place (rows beyond mb have c = 0 and lse = 1e30 -> dZ = 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float4 rs = sR[buf][rl];
+                float p;
+                const float d = item_ok ? dz_of(acc[r], rs.x, rs.y, rs.z, rs.w, sA[buf][rl] == item, p) : 0.f;
+                acc[r] = d;
+                db += d;
+            }
+            // dWa^T += dZ^T * H2 : step r pairs rows row(r,0), row(r,1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float b0 = th[rl * kLdsStride + lo];
+                const float b1 = th[rl * kLdsStride + 32 + lo];
+                dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dw0, 0, 0, 0);
+                dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dw1, 0, 0, 0);
+            }
         }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias;
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[kk], wrow[kk], acc, 0, 0, 0);
-        // dZ in place (rows beyond mb have c = 0 -> dZ = 0)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float p;
-            const float d = item_ok ? dz_of(acc[r], v.lse[row], v.c_logp[row], v.c_ent[row], v.h_ent[row], v.act[row] == item, p) : 0.f;
-            acc[r] = d;
-            db += d;
-        }
-        // dWa^T += dZ^T * H2 : step r pairs rows row(r,0), row(r,1)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float b0 = v.h2[(size_t)row * kH + lo];
-            const float b1 = v.h2[(size_t)row * kH + 32 + lo];
-            dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dw0, 0, 0, 0);
-            dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dw1, 0, 0, 0);
-        }
+        if (rt + 1 < rt_end) CIRS_COMMIT(buf ^ 1);
+        __syncthreads();
     }
+#undef CIRS_ISSUE
+#undef CIRS_COMMIT
+    if (!wave_ok) return;
     // store partial slab: C layout col = k (lane lo), rows = items (r&3)+8*(r>>2)+4*hi
     float* slab = dwap + (size_t)split * ((size_t)I * kH + I);
 #pragma unroll
@@ -396,17 +430,24 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dwa_kernel(int I, int mb, int
 }
 
 // ---- head backward 2: d h2 + entropy.  Z^T layout (lane owns a ROW, registers are items) -----------------------
-// grid = (n_chunks, ceil(n_pad/32/4)); wave = one row tile x one item chunk.
+// grid = (n_chunks, ceil(n_pad/32/4)); workgroup = 4 waves = 4 row tiles walking the same item chunk.
 //   ZT[32 items x 32 rows] = Wa_tile * H2_tile^T
 //   dH2_tile[32 rows x 64] += dZ[rows x items] * Wa_tile      (A = dZT registers AS THEY ARE, B = Wa[item(s,hi)][n])
+// The Wa tile (32 items x 64, 8 KB) is staged in LDS ONCE per workgroup and serves both products of all four waves
+// (A operand rows by ds_read_b128, B operand columns by ds_read_b32).  Double-buffered: the global loads of tile
+// t+1 are issued before the MFMAs of tile t and written to the other buffer afterwards (one barrier per tile).
+// Row stride 68 floats: ds_read_b128 of 16 lanes x different rows then hits 64 distinct banks.
 __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int n_pad, const float* __restrict__ wa,
                                                               const float* __restrict__ ba, MbView v) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
+    __shared__ float sB[2][kTileN];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * 4 + wv) * kTileM;
-    if (row0 >= n_pad) return;
+    const bool wave_ok = row0 < n_pad;   // all waves take part in the staging + barriers
     const int chunk = blockIdx.x;
-    const int jr = row0 + lo;
+    const int jr = wave_ok ? row0 + lo : 0;
     float hrow[32];
     {
         const float4* src = reinterpret_cast<const float4*>(v.h2 + (size_t)jr * kH + hi * 32);
@@ -418,64 +459,86 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
     }
     const float lse = v.lse[jr], c_logp = v.c_logp[jr], c_ent = v.c_ent[jr], h_ent = v.h_ent[jr];
     const int act = v.act[jr];
-    const bool row_ok = jr < mb;
+    const bool row_ok = wave_ok && jr < mb;
     f32x16 dh0, dh1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dh0[r] = 0.f; dh1[r] = 0.f; }
     float ent = 0.f;  // clamp correction of the entropy (see below)
     const float eps = 1.1920928955078125e-7f;
     const float kLogEps = -15.942385152878742f, kLog1mEps = -1.1920929665620834e-7f;
-    for (int it = 0; it < kTilesPerChunk; ++it) {
-        const int tile0 = chunk * kChunkItems + it * kTileN;
-        if (tile0 >= I) break;
-        const int item_a = tile0 + lo;
-        float wrow[32];
-        if (item_a < I) {
-            const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item_a * kH + hi * 32);
+
+    // staging role of this thread: 2 float4 of the 32 x 64 tile (thread -> item tid/8, floats (tid%8)*8 .. +8)
+    const int st_item = tid >> 3, st_col = (tid & 7) * 8;
+    const int first_tile = chunk * kChunkItems;
+    int n_tiles = 0;
+    for (int it = 0; it < kTilesPerChunk; ++it) n_tiles += (first_tile + it * kTileN) < I;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    float gb = 0.f;
+#define CIRS_ISSUE(TILE0)                                                                                  \
+    do {                                                                                                   \
+        const int item_ = (TILE0) + st_item;                                                               \
+        if (item_ < I) {                                                                                   \
+            const float4* src_ = reinterpret_cast<const float4*>(wa + (size_t)item_ * kH + st_col);        \
+            g0 = src_[0]; g1 = src_[1];                                                                    \
+        } else {                                                                                           \
+            g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0;                                                 \
+        }                                                                                                  \
+        if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
+    } while (0)
+#define CIRS_COMMIT(BUF)                                                                                   \
+    do {                                                                                                   \
+        float4* dst_ = reinterpret_cast<float4*>(&sW[BUF][st_item * kLdsStride + st_col]);                 \
+        dst_[0] = g0; dst_[1] = g1;                                                                        \
+        if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
+    } while (0)
+    if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
+    __syncthreads();
+    for (int it = 0; it < n_tiles; ++it) {
+        const int buf = it & 1;
+        const int tile0 = first_tile + it * kTileN;
+        if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);  // global loads in flight during the MFMAs below
+        if (wave_ok) {
+            const float* tw = sW[buf];
+            float wrow[32];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float4 t4 = src[q];
+                const float4 t4 = *reinterpret_cast<const float4*>(&tw[lo * kLdsStride + hi * 32 + 4 * q]);
                 wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
             }
-        } else {
+            f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) wrow[q] = 0.f;
-        }
-        f32x16 acc;
+            for (int r = 0; r < 16; ++r) acc[r] = sB[buf][(r & 3) + 8 * (r >> 2) + 4 * hi];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int i0 = tile0 + 8 * g + 4 * hi;
+            for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[4 * g + q] = (i0 + q) < I ? ba[i0 + q] : 0.f;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int item = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float d = 0.f;
-            if (item < I && row_ok) {
-                float p;
-                d = dz_of(acc[r], lse, c_logp, c_ent, h_ent, item == act, p);
-                // Categorical.entropy uses log(clamp(p, eps, 1-eps)): the un-clamped entropy lse - E_p[z] comes from the
-                // forward statistics; only the (rare) clamped elements contribute a correction here
-                if (p < eps) ent -= p * (kLogEps - (acc[r] - lse));
-                else if (p > 1.0f - eps) ent -= p * (kLog1mEps - (acc[r] - lse));
+            for (int r = 0; r < 16; ++r) {
+                const int item = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float d = 0.f;
+                if (item < I && row_ok) {
+                    float p;
+                    d = dz_of(acc[r], lse, c_logp, c_ent, h_ent, item == act, p);
+                    // Categorical.entropy uses log(clamp(p, eps, 1-eps)): the un-clamped entropy lse - E_p[z] comes from
+                    // the forward statistics; only the (rare) clamped elements contribute a correction here
+                    if (p < eps) ent -= p * (kLogEps - (acc[r] - lse));
+                    else if (p > 1.0f - eps) ent -= p * (kLog1mEps - (acc[r] - lse));
+                }
+                acc[r] = d;
             }
-            acc[r] = d;
-        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int item = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            float b0 = 0.f, b1 = 0.f;
-            if (item < I) {
-                b0 = wa[(size_t)item * kH + lo];
-                b1 = wa[(size_t)item * kH + 32 + lo];
+            for (int r = 0; r < 16; ++r) {
+                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;  // item within the tile (rows beyond I hold zeros)
+                const float b0 = tw[il * kLdsStride + lo];
+                const float b1 = tw[il * kLdsStride + 32 + lo];
+                dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dh0, 0, 0, 0);
+                dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dh1, 0, 0, 0);
             }
-            dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dh0, 0, 0, 0);
-            dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dh1, 0, 0, 0);
         }
+        if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);  // the other buffer was last read in iteration it-1 (barrier below)
+        __syncthreads();
     }
+#undef CIRS_ISSUE
+#undef CIRS_COMMIT
+    if (!wave_ok) return;
     float* slab = v.dh2p + (size_t)chunk * n_pad * kH;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
