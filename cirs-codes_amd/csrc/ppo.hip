@@ -14,7 +14,7 @@
 // Roofline of one minibatch step (mb x I x 64): forward stats 2*mb*I*64 flop + two backward kernels of
 // 2 * 2*mb*I*64 flop each = 10*mb*I*64 flop = 7.0 GFLOP at mb = 1024, I = 10728 on the fp32 MFMA pipe (157 TF peak);
 // HBM traffic is Wa (2.7 MB) + dWa partials (8 x 2.7 MB) + dH2 partials (n_chunks x mb x 256 B = 22 MB): MFMA-bound.
-#include "dense_small.h"
+#include "small_gemm.h"
 #include "policy_kernels.h"
 
 namespace cirs {
@@ -140,7 +140,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)kRowSplits * ((size_t)I * kH + I);    // dwap
     f += 64 + 256;                                     // red + sum-of-squares partials
-    f += dw_partial_floats(n_pad, kH, kH) + 64;        // weight-gradient slab partials (largest: 64 x 65)
+    f += dwg_partial_floats(n_pad, kH, kH) + 64;       // weight-gradient slab partials (largest: 64 x 65)
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
     return f;
 }
@@ -160,7 +160,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dwap = take((size_t)kRowSplits * ((size_t)I * kH + I));
     v.red = take(64);
     v.normp = take(256);
-    v.dwp = take(dw_partial_floats(n_pad, kH, kH) + 64);
+    v.dwp = take(dwg_partial_floats(n_pad, kH, kH) + 64);
     v.head_ws = (void*)p;
     return v;
 }
@@ -588,19 +588,6 @@ __global__ __launch_bounds__(256) void finalize_dh2_kernel(int mb, int n_pad, in
     if (tid == 0) v.ent_row[r] = r < mb ? v.h_ent[r] + she[0] : 0.f;  // (lse - E_p[z]) + clamp correction
 }
 
-// dX[r,k] = sum_o dY[r,o] * W[o,k]  (optionally masked by relu'(act[r,k]))
-__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ dY, const float* __restrict__ W, int R,
-                                                            int O, int K, const float* __restrict__ relu_of,
-                                                            float* __restrict__ dX) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= (long)R * K) return;
-    const int r = (int)(i / K), k = (int)(i % K);
-    float acc = 0.f;
-    for (int o = 0; o < O; ++o) acc = __builtin_fmaf(dY[(size_t)r * O + o], W[(size_t)o * K + k], acc);
-    if (relu_of && !(relu_of[i] > 0.f)) acc = 0.f;
-    dX[i] = acc;
-}
-
 // d obs rows -> tracker gradient tensor [T+1, B, S] at (row_t, row_env)
 __global__ __launch_bounds__(256) void scatter_dobs_kernel(const float* __restrict__ dobs, const int32_t* __restrict__ idx,
                                                            cirs_ppo_batch b, int mb, int S, int n_env,
@@ -804,20 +791,19 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
     hipLaunchKernelGGL(finalize_dh2_kernel, dim3(n_pad), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
     CIRS_CHECK_LAUNCH("finalize_dh2_kernel");
     // 6. critic + trunk backward
-    launch_dw(v.dvalue, v.h2, mb, 1, kH, grads + L.wc, grads + L.bc, v.dwp, s);  // d wc = sum_r dvalue_r h2[r], d bc
+    launch_dw_gemm(v.dvalue, 1, v.h2, kH, mb, 1, kH, grads + L.wc, grads + L.bc, v.dwp, s);  // d wc = sum_r dvalue_r h2[r], d bc
     CIRS_CHECK_LAUNCH("dw(critic)");
-    launch_dw(v.da2, v.h1, mb, kH, kH, grads + L.w2, grads + L.b2, v.dwp, s);
+    launch_dw_gemm(v.da2, kH, v.h1, kH, mb, kH, kH, grads + L.w2, grads + L.b2, v.dwp, s);
     CIRS_CHECK_LAUNCH("dw(w2)");
-    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv((long)n_pad * kH, 256)), dim3(256), 0, s, v.da2, w.w2, n_pad, kH, kH,
-                       v.h1, v.da1);
-    CIRS_CHECK_LAUNCH("linear_bwd_dx_kernel(h1)");
-    launch_dw(v.da1, v.obs, mb, kH, S, grads + L.w1, grads + L.b1, v.dwp, s);
+    // d a1 = (d a2 * W2) masked by relu'(h1)
+    launch_rows_gemm(false, v.da2, kH, w.w2, kH, nullptr, n_pad, kH, kH, 0, v.h1, 0, v.da1, kH, s);
+    CIRS_CHECK_LAUNCH("dx(h1)");
+    launch_dw_gemm(v.da1, kH, v.obs, S, mb, kH, S, grads + L.w1, grads + L.b1, v.dwp, s);
     CIRS_CHECK_LAUNCH("dw(w1)");
     if (dobs_accum) {
         float* dobs = v.dh2p;  // reuse: partial slabs are consumed
-        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdiv((long)mb * S, 256)), dim3(256), 0, s, v.da1, w.w1, mb, kH, S,
-                           (const float*)nullptr, dobs);
-        CIRS_CHECK_LAUNCH("linear_bwd_dx_kernel(obs)");
+        launch_rows_gemm(false, v.da1, kH, w.w1, S, nullptr, mb, kH, S, 0, nullptr, 0, dobs, S, s);
+        CIRS_CHECK_LAUNCH("dx(obs)");
         hipLaunchKernelGGL(scatter_dobs_kernel, dim3(cdiv((long)mb * S, 256)), dim3(256), 0, s, dobs, idx, *batch, mb, S, n_env, dobs_accum);
         CIRS_CHECK_LAUNCH("scatter_dobs_kernel");
     }

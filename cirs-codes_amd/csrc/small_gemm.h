@@ -1,0 +1,126 @@
+// small_gemm.h -- the small dense layers of the learner / tracker backward on the fp32 matrix cores.
+//
+// All matrices here have <= 129 columns and thousands of rows; they are L1/L2 resident and latency-bound, so the
+// kernels use plain (cached) global loads straight into the v_mfma_f32_32x32x2_f32 operand layout, one wavefront per
+// 32 x 32 output tile:
+//   rows_gemm   Y[R,N] (+)= X[R,Kd] * B  (+ bias, relu, relu-mask)   with B[kd,n] = W[n*ldw+kd] ("NT": forward linear,
+//               Y = X W^T) or W[kd*ldw+n] ("NN": backward dX = dY W).  Fixed k order -> deterministic.
+//   dw_gemm     dW[O,K] = sum_r dY[r,O]^T X[r,K], db[O] = sum_r dY[r,O]; rows are split into <= 64 contiguous slabs
+//               (one wavefront each), slab partials are summed in slab order by dw_gemm_final: fixed order, no atomics.
+#pragma once
+#include "common.h"
+
+namespace cirs {
+
+typedef float sg_f32x16 __attribute__((ext_vector_type(16)));
+
+// grid = (ceil(R/32), ceil(N/32)), block = 64
+template <bool kNT>
+static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                              const float* __restrict__ bias, int R, int Kd, int N, int relu,
+                                                              const float* __restrict__ relu_of, int accumulate,
+                                                              float* __restrict__ Y, int ldy) {
+    const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
+    const int row0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int row = row0 + lo, n = n0 + lo;
+    const bool row_ok = row < R, n_ok = n < N;
+    sg_f32x16 acc;
+    const float b = (bias && n_ok) ? bias[n] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = b;
+    const float* xr = X + (size_t)(row_ok ? row : 0) * ldx;
+    for (int kk = 0; kk < Kd; kk += 2) {
+        const int kd = kk + hi;
+        const bool k_ok = kd < Kd;
+        const float a = (row_ok && k_ok) ? xr[kd] : 0.f;
+        float bv = 0.f;
+        if (n_ok && k_ok) bv = kNT ? W[(size_t)n * ldw + kd] : W[(size_t)kd * ldw + n];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+    if (!n_ok) return;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int r = row0 + (s & 3) + 8 * (s >> 2) + 4 * hi;
+        if (r >= R) continue;
+        const size_t o = (size_t)r * ldy + n;
+        float v = acc[s];
+        if (relu) v = fmaxf(v, 0.f);
+        if (relu_of && !(relu_of[o] > 0.f)) v = 0.f;
+        Y[o] = accumulate ? Y[o] + v : v;
+    }
+}
+
+static inline void launch_rows_gemm(bool nt, const float* X, int ldx, const float* W, int ldw, const float* bias, int R, int Kd, int N,
+                                    int relu, const float* relu_of, int accumulate, float* Y, int ldy, hipStream_t s) {
+    const dim3 grid(cdiv(R, 32), cdiv(N, 32));
+    if (nt) hipLaunchKernelGGL(rows_gemm_kernel<true>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy);
+    else hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy);
+}
+
+constexpr int kDwMaxSlabs = 64;
+__host__ inline int dwg_slabs(long R) {
+    const long want = (R + 127) / 128;  // >= 128 rows per slab
+    return (int)(want < 1 ? 1 : (want > kDwMaxSlabs ? kDwMaxSlabs : want));
+}
+__host__ inline size_t dwg_partial_floats(long R, int O, int K) { return (size_t)dwg_slabs(R) * O * (K + 1); }
+
+// grid = (ceil(O/32) * ceil(K/32), n_slabs), block = 64.  partial[slab][o*(K+1)+k], k == K: bias column
+static __global__ __launch_bounds__(64) void dw_gemm_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int R,
+                                                            int O, int K, int rows_per_slab, float* __restrict__ partial) {
+    const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
+    const int k_tiles = (K + 31) / 32;
+    const int o0 = (blockIdx.x / k_tiles) * 32, k0 = (blockIdx.x % k_tiles) * 32;
+    const int slab = blockIdx.y;
+    const int r_beg = slab * rows_per_slab, r_end = min(R, r_beg + rows_per_slab);
+    const int o = o0 + lo, k = k0 + lo;
+    const bool o_ok = o < O, k_ok = k < K;
+    sg_f32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+    float bsum = 0.f;
+    for (int r = r_beg; r < r_end; r += 2) {
+        const int rr = r + hi;
+        const bool r_ok = rr < r_end;
+        const float a = (r_ok && o_ok) ? dY[(size_t)rr * ldy + o] : 0.f;
+        const float b = (r_ok && k_ok) ? X[(size_t)rr * ldx + k] : 0.f;
+        bsum += a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    float* out = partial + (size_t)slab * O * (K + 1);
+    if (k_ok) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int oo = o0 + (s & 3) + 8 * (s >> 2) + 4 * hi;
+            if (oo < O) out[(size_t)oo * (K + 1) + k] = acc[s];
+        }
+    }
+    if (k0 == 0) {
+        bsum += __shfl_xor(bsum, 32, CIRS_WAVE);
+        if (hi == 0 && o_ok) out[(size_t)o * (K + 1) + K] = bsum;
+    }
+}
+
+static __global__ __launch_bounds__(256) void dw_gemm_final(const float* __restrict__ partial, int n_slabs, int O, int K,
+                                                            float* __restrict__ dW, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_out = O * (K + 1);
+    if (i >= n_out) return;
+    float acc = 0.f;
+    for (int c = 0; c < n_slabs; ++c) acc += partial[(size_t)c * n_out + i];
+    const int o = i / (K + 1), k = i % (K + 1);
+    if (k < K) dW[(size_t)o * K + k] = acc;
+    else if (db) db[o] = acc;
+}
+
+// dW [O,K] (row-major, ld = K) and db [O] from dY [R,O] (ld ldy) and X [R,K] (ld ldx); `partial` >= dwg_partial_floats
+static inline void launch_dw_gemm(const float* dY, int ldy, const float* X, int ldx, int R, int O, int K, float* dW, float* db,
+                                  float* partial, hipStream_t s) {
+    const int slabs = dwg_slabs(R);
+    int rows_per_slab = (R + slabs - 1) / slabs;
+    rows_per_slab += rows_per_slab & 1;  // even: MFMA steps consume row pairs
+    const int tiles = cdiv(O, 32) * cdiv(K, 32);
+    hipLaunchKernelGGL(dw_gemm_kernel, dim3(tiles, slabs), dim3(64), 0, s, dY, ldy, X, ldx, R, O, K, rows_per_slab, partial);
+    hipLaunchKernelGGL(dw_gemm_final, dim3(cdiv(O * (K + 1), 256)), dim3(256), 0, s, partial, slabs, O, K, dW, db);
+}
+
+}  // namespace cirs

@@ -8,38 +8,12 @@
 // matters is that everything stays on device and every reduction has a fixed order.
 //   weight gradients : chunk-partial sums over 256-row chunks, then an ordered sum over chunks (two launches)
 //   embedding tables : per-row contributions, then one wavefront per table row sums its rows in a fixed order
-#include "dense_small.h"
+#include "small_gemm.h"
 
 namespace cirs {
 
 constexpr int tD = 32, tH = 128;
 constexpr int kChunkRows = 256;
-
-// Y[r,o] = b[o] + sum_k X[r,k] W[o,k]   (optional relu)
-__global__ __launch_bounds__(256) void lin_fwd(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
-                                               int R, int O, int K, int relu, float* __restrict__ Y) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= (long)R * O) return;
-    const int r = (int)(i / O), o = (int)(i % O);
-    float acc = b ? b[o] : 0.f;
-    const float* x = X + (size_t)r * K;
-    const float* w = W + (size_t)o * K;
-    for (int k = 0; k < K; ++k) acc = __builtin_fmaf(x[k], w[k], acc);
-    Y[i] = relu ? fmaxf(acc, 0.f) : acc;
-}
-
-// dX[r,k] (+)= sum_o dY[r,o] W[o,k]   ; mask: zero where relu_of[r,k] <= 0
-__global__ __launch_bounds__(256) void lin_bwd_dx(const float* __restrict__ dY, const float* __restrict__ W, int R, int O, int K,
-                                                  const float* __restrict__ relu_of, int accumulate, float* __restrict__ dX) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= (long)R * K) return;
-    const int r = (int)(i / K), k = (int)(i % K);
-    float acc = 0.f;
-    const float* dy = dY + (size_t)r * O;
-    for (int o = 0; o < O; ++o) acc = __builtin_fmaf(dy[o], W[(size_t)o * K + k], acc);
-    if (relu_of && !(relu_of[i] > 0.f)) acc = 0.f;
-    dX[i] = accumulate ? dX[i] + acc : acc;
-}
 
 // slot gather + scale + positional encoding: X0[r] = x_hist[b,p], H0 = X0*sqrt(D) + pe[p]
 __global__ __launch_bounds__(256) void embed_rows(const float* __restrict__ x_hist, const float* __restrict__ pe,
@@ -387,7 +361,7 @@ static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     f += (size_t)(nl + 1) * R * tD;               // H
     f += (size_t)nl * R * (96 + NH * Lp + tD + tD + 1 + tD + tH + tD + 1);
     f += 3 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp;  // T0..2, dQKV, dFF1, dS
-    f += dw_partial_floats(R, tH, tD) + dw_partial_floats(R, 2, tD) + 4096;  // partial (largest: 128 x 33)
+    f += dwg_partial_floats(R, tH, tD) + dwg_partial_floats(R, 2, tD) + 4096;  // partial (largest: 128 x 33)
     f += (size_t)R * (tD + 1);                    // GIN
     return f + 64 * 32;
 }
@@ -406,7 +380,7 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
     }
     s.T0 = take((size_t)R * tD); s.T1 = take((size_t)R * tD); s.T2 = take((size_t)R * tD);
     s.dQKV = take((size_t)R * 96); s.dFF1 = take((size_t)R * tH); s.dS = take((size_t)R * NH * Lp);
-    s.partial = take(dw_partial_floats(R, tH, tD) + dw_partial_floats(R, 2, tD) + 4096);
+    s.partial = take(dwg_partial_floats(R, tH, tD) + dwg_partial_floats(R, 2, tD) + 4096);
     s.GIN = take((size_t)R * (tD + 1));
     return s;
 }
@@ -435,7 +409,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     const int n_chunks = cdiv(R, kChunkRows);
     auto g1 = [&](long n) { return dim3(cdiv(n, 256)); };
 
-#define DW(dY, X, O, K, dWp, dbp) launch_dw(dY, X, R, O, K, dWp, dbp, sc.partial, s)
+#define DW(dY, X, O, K, dWp, dbp) launch_dw_gemm(dY, O, X, K, R, O, K, dWp, dbp, sc.partial, s)
 #define ATT_DISPATCH_SH(KERNEL, SHMEM, ...)                                                               \
     do {                                                                                                  \
         switch (NH) {                                                                                     \
@@ -451,13 +425,13 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0]);
     for (int l = 0; l < nl; ++l) {
         const cirs_tracker_layer& y = w->layer[l];
-        hipLaunchKernelGGL(lin_fwd, g1((long)R * 96), dim3(256), 0, s, sc.H[l], y.in_proj_w, y.in_proj_b, R, 96, tD, 0, sc.QKV[l]);
+        launch_rows_gemm(true, sc.H[l], tD, y.in_proj_w, tD, y.in_proj_b, R, tD, 96, 0, nullptr, 0, sc.QKV[l], 96, s);
         ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l]);
-        hipLaunchKernelGGL(lin_fwd, g1((long)R * tD), dim3(256), 0, s, sc.ATT[l], y.out_proj_w, y.out_proj_b, R, tD, tD, 0, sc.T0);
+        launch_rows_gemm(true, sc.ATT[l], tD, y.out_proj_w, tD, y.out_proj_b, R, tD, tD, 0, nullptr, 0, sc.T0, tD, s);
         hipLaunchKernelGGL(add_rows, g1((long)R * tD), dim3(256), 0, s, sc.H[l], sc.T0, (long)R * tD, sc.T1);
         hipLaunchKernelGGL(ln_fwd, g1(R), dim3(256), 0, s, sc.T1, y.norm1_w, y.norm1_b, R, sc.XH1[l], sc.RS1[l], sc.H1N[l]);
-        hipLaunchKernelGGL(lin_fwd, g1((long)R * tH), dim3(256), 0, s, sc.H1N[l], y.lin1_w, y.lin1_b, R, tH, tD, 1, sc.FF1[l]);
-        hipLaunchKernelGGL(lin_fwd, g1((long)R * tD), dim3(256), 0, s, sc.FF1[l], y.lin2_w, y.lin2_b, R, tD, tH, 0, sc.T0);
+        launch_rows_gemm(true, sc.H1N[l], tD, y.lin1_w, tD, y.lin1_b, R, tD, tH, 1, nullptr, 0, sc.FF1[l], tH, s);
+        launch_rows_gemm(true, sc.FF1[l], tH, y.lin2_w, tH, y.lin2_b, R, tH, tD, 0, nullptr, 0, sc.T0, tD, s);
         hipLaunchKernelGGL(add_rows, g1((long)R * tD), dim3(256), 0, s, sc.H1N[l], sc.T0, (long)R * tD, sc.T1);
         hipLaunchKernelGGL(ln_fwd, g1(R), dim3(256), 0, s, sc.T1, y.norm2_w, y.norm2_b, R, sc.XH2[l], sc.RS2[l], sc.H[l + 1]);
     }
@@ -466,7 +440,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     hipLaunchKernelGGL(gather_dstate, g1((long)R * S), dim3(256), 0, s, dstate, row_env, row_t, R, S, B, sc.G);
     DW(sc.G, sc.H[nl], S, tD, grads->dec_w, grads->dec_b);
     float* dH = sc.T0;  // gradient w.r.t. the current layer output
-    hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tD), dim3(256), 0, s, sc.G, w->dec_w, R, S, tD, (const float*)nullptr, 0, dH);
+    launch_rows_gemm(false, sc.G, S, w->dec_w, tD, nullptr, R, S, tD, 0, nullptr, 0, dH, tD, s);
     for (int l = nl - 1; l >= 0; --l) {
         const cirs_tracker_layer& y = w->layer[l];
         const cirs_tracker_layer_grads& gy = grads->layer[l];
@@ -477,10 +451,10 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2);
         // FF
         DW(dY2, sc.FF1[l], tD, tH, gy.lin2_w, gy.lin2_b);
-        hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tH), dim3(256), 0, s, dY2, y.lin2_w, R, tD, tH, sc.FF1[l], 0, sc.dFF1);
+        launch_rows_gemm(false, dY2, tD, y.lin2_w, tH, nullptr, R, tD, tH, 0, sc.FF1[l], 0, sc.dFF1, tH, s);
         DW(sc.dFF1, sc.H1N[l], tH, tD, gy.lin1_w, gy.lin1_b);
         // d H1N = dY2 (residual) + dFF1 * W1
-        hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tD), dim3(256), 0, s, sc.dFF1, y.lin1_w, R, tH, tD, (const float*)nullptr, 1, dY2);
+        launch_rows_gemm(false, sc.dFF1, tH, y.lin1_w, tD, nullptr, R, tH, tD, 0, nullptr, 1, dY2, tD, s);
         // LN1
         hipLaunchKernelGGL(ln_dgb_partial, dim3(n_chunks), dim3(64), 0, s, dY2, sc.XH1[l], R, sc.partial);
         hipLaunchKernelGGL(ln_dgb_final, dim3(1), dim3(64), 0, s, sc.partial, n_chunks, gy.norm1_w, gy.norm1_b);
@@ -489,14 +463,14 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         // out_proj
         DW(dY1, sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b);
         float* dATT = sc.T1;
-        hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tD), dim3(256), 0, s, dY1, y.out_proj_w, R, tD, tD, (const float*)nullptr, 0, dATT);
+        launch_rows_gemm(false, dY1, tD, y.out_proj_w, tD, nullptr, R, tD, tD, 0, nullptr, 0, dATT, tD, s);
         // attention
         ATT_DISPATCH(attn_bwd_q, sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV);
         ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
         // in_proj
         DW(sc.dQKV, sc.H[l], 96, tD, gy.in_proj_w, gy.in_proj_b);
         // d H_l = dY1 (residual) + dQKV * W_in
-        hipLaunchKernelGGL(lin_bwd_dx, g1((long)R * tD), dim3(256), 0, s, sc.dQKV, y.in_proj_w, R, 96, tD, (const float*)nullptr, 1, dY1);
+        launch_rows_gemm(false, sc.dQKV, 96, y.in_proj_w, tD, nullptr, R, 96, tD, 0, nullptr, 1, dY1, tD, s);
         dH = dY1;
         if (l > 0) {  // keep dH in T0 for the next iteration (T2 is reused as dY1)
             CIRS_HIP(hipMemcpyAsync(sc.T0, dY1, sizeof(float) * (size_t)R * tD, hipMemcpyDeviceToDevice, s));
