@@ -29,13 +29,18 @@ static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __res
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = b;
     const float* xr = X + (size_t)(row_ok ? row : 0) * ldx;
-    for (int kk = 0; kk < Kd; kk += 2) {
-        const int kd = kk + hi;
-        const bool k_ok = kd < Kd;
-        const float a = (row_ok && k_ok) ? xr[kd] : 0.f;
-        float bv = 0.f;
-        if (n_ok && k_ok) bv = kNT ? W[(size_t)n * ldw + kd] : W[(size_t)kd * ldw + n];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    for (int kk = 0; kk < Kd; kk += 16) {  // 8 MFMA steps per batch: all 16 loads are issued before the first MFMA
+        float a[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kd = kk + 2 * j + hi;
+            const bool k_ok = kd < Kd;
+            a[j] = (row_ok && k_ok) ? xr[kd] : 0.f;
+            bv[j] = 0.f;
+            if (n_ok && k_ok) bv[j] = kNT ? W[(size_t)n * ldw + kd] : W[(size_t)kd * ldw + n];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc, 0, 0, 0);
     }
     if (!n_ok) return;
 #pragma unroll
@@ -59,7 +64,7 @@ static inline void launch_rows_gemm(bool nt, const float* X, int ldx, const floa
 
 constexpr int kDwMaxSlabs = 64;
 __host__ inline int dwg_slabs(long R) {
-    const long want = (R + 127) / 128;  // >= 128 rows per slab
+    const long want = (R + 31) / 32;  // >= 32 rows per slab
     return (int)(want < 1 ? 1 : (want > kDwMaxSlabs ? kDwMaxSlabs : want));
 }
 __host__ inline size_t dwg_partial_floats(long R, int O, int K) { return (size_t)dwg_slabs(R) * O * (K + 1); }
@@ -78,13 +83,20 @@ static __global__ __launch_bounds__(64) void dw_gemm_kernel(const float* __restr
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
     float bsum = 0.f;
-    for (int r = r_beg; r < r_end; r += 2) {
-        const int rr = r + hi;
-        const bool r_ok = rr < r_end;
-        const float a = (r_ok && o_ok) ? dY[(size_t)rr * ldy + o] : 0.f;
-        const float b = (r_ok && k_ok) ? X[(size_t)rr * ldx + k] : 0.f;
-        bsum += a;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int r = r_beg; r < r_end; r += 16) {  // 8 MFMA steps (16 rows) per batch, loads first
+        float a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rr = r + 2 * j + hi;
+            const bool r_ok = rr < r_end;
+            a[j] = (r_ok && o_ok) ? dY[(size_t)rr * ldy + o] : 0.f;
+            b[j] = (r_ok && k_ok) ? X[(size_t)rr * ldx + k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bsum += a[j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+        }
     }
     float* out = partial + (size_t)slab * O * (K + 1);
     if (k_ok) {
@@ -117,7 +129,7 @@ static inline void launch_dw_gemm(const float* dY, int ldy, const float* X, int 
                                   float* partial, hipStream_t s) {
     const int slabs = dwg_slabs(R);
     int rows_per_slab = (R + slabs - 1) / slabs;
-    rows_per_slab += rows_per_slab & 1;  // even: MFMA steps consume row pairs
+    rows_per_slab = (rows_per_slab + 15) & ~15;  // multiple of 16: one batch = 8 MFMA steps = 16 rows
     const int tiles = cdiv(O, 32) * cdiv(K, 32);
     hipLaunchKernelGGL(dw_gemm_kernel, dim3(tiles, slabs), dim3(64), 0, s, dY, ldy, X, ldx, R, O, K, rows_per_slab, partial);
     hipLaunchKernelGGL(dw_gemm_final, dim3(cdiv(O * (K + 1), 256)), dim3(256), 0, s, partial, slabs, O, K, dW, db);
