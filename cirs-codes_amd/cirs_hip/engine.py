@@ -67,13 +67,14 @@ class CirsEngine:
                  tau=100.0, gamma_exposure=10.0, version="v1", r_decay=1.0, dim_model=32, dim_state=20, nhead=4,
                  hidden=64, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
                  lr=1e-3, rew_norm=True, value_clip=True, norm_adv=True, seed=2023, tracker_params=None,
-                 policy_params=None, dist_group=None, world_size=1, rank=0):
+                 policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False):
         self.device = tables.device
         self.tables = tables
         self.n_env, self.max_turn, self.S, self.D = n_env, max_turn, dim_state, dim_model
         U, I = tables.n_users, tables.n_items
         self.n_items = I
         self.world, self.rank, self.group = world_size, rank, dist_group
+        self.force_gather = force_gather  # exercise the packed all-gather path even with one rank (tests)
         self.env = DeviceEnv(tables, n_env, num_leave_compute=num_leave_compute, leave_threshold=leave_threshold,
                              max_turn=max_turn, tau=tau, gamma_exposure=gamma_exposure, version=version, r_decay=r_decay)
         tp = tracker_params or init_tracker_params(U, I, max_turn, seed=seed, dim_model=dim_model, dim_state=dim_state, nhead=nhead)
@@ -125,7 +126,7 @@ class CirsEngine:
     def _gather(self):
         """All ranks' trajectories -> one global buffer (single all-gather); world == 1: zero-copy views."""
         tr = self.rollout.traj
-        if self.world == 1:
+        if self.world == 1 and not self.force_gather:
             return tr, self.tracker.x_hist, self.lengths, self.users
         fields = dict(obs=tr.obs, act=tr.act, rew=tr.rew, done=tr.done, logp=tr.logp, value=tr.value, ctr=tr.ctr,
                       x_hist=self.tracker.x_hist, lens=self.lengths.to(torch.int32), users=self.users)
@@ -151,6 +152,6 @@ class CirsEngine:
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
         self.tracker.backward(users, traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).to(self.device),
                               torch.as_tensor(lens).to(self.device), n, ln.dobs,
-                              x_hist=x_hist if self.world > 1 else None)
+                              x_hist=x_hist if (self.world > 1 or self.force_gather) else None)
         self.tracker.adam_update()
         return losses, n

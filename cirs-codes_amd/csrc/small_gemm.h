@@ -62,9 +62,9 @@ static inline void launch_rows_gemm(bool nt, const float* X, int ldx, const floa
     else hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy);
 }
 
-constexpr int kDwMaxSlabs = 64;
+constexpr int kDwMaxSlabs = 32;
 __host__ inline int dwg_slabs(long R) {
-    const long want = (R + 31) / 32;  // >= 32 rows per slab
+    const long want = (R + 63) / 64;  // >= 64 rows per slab
     return (int)(want < 1 ? 1 : (want > kDwMaxSlabs ? kDwMaxSlabs : want));
 }
 __host__ inline size_t dwg_partial_floats(long R, int O, int K) { return (size_t)dwg_slabs(R) * O * (K + 1); }
