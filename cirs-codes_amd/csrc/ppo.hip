@@ -62,8 +62,15 @@ __global__ __launch_bounds__(256) void gae_kernel(cirs_ppo_cfg cfg, cirs_traj tr
         out.act[row] = (int32_t)traj.act[ti];
         out.row_env[row] = b;
         out.row_t[row] = t;
-        for (int k = 0; k < S; ++k) out.obs[(size_t)row * S + k] = traj.obs[ti * S + k];
     }
+}
+
+// obs rows of the time-major trajectory -> buffer order, one thread per (row, feature)
+__global__ __launch_bounds__(256) void compact_obs_kernel(cirs_traj traj, cirs_ppo_batch out, int N, int B, int S) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)N * S) return;
+    const int row = (int)(i / S), k = (int)(i % S);
+    out.obs[i] = traj.obs[((size_t)out.row_t[row] * B + out.row_env[row]) * S + k];
 }
 
 // single workgroup, fixed-order float64 reductions
@@ -140,7 +147,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)kRowSplits * ((size_t)I * kH + I);    // dwap
     f += 64 + 256;                                     // red + sum-of-squares partials
-    f += dwg_partial_floats(n_pad, kH, kH) + 64;       // weight-gradient slab partials (largest: 64 x 65)
+    f += dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64;  // dW slabs
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
     return f;
 }
@@ -160,7 +167,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dwap = take((size_t)kRowSplits * ((size_t)I * kH + I));
     v.red = take(64);
     v.normp = take(256);
-    v.dwp = take(dwg_partial_floats(n_pad, kH, kH) + 64);
+    v.dwp = take(dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64);
     v.head_ws = (void*)p;
     return v;
 }
@@ -550,16 +557,6 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
     if (hi == 0) v.entp[(size_t)chunk * n_pad + jr] = ent;
 }
 
-// sum the dWa slabs in fixed order into the flat gradient buffer (wa | ba segments are contiguous)
-__global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict__ dwap, long seg, float* __restrict__ g_wa_ba) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= seg) return;
-    float acc = 0.f;
-#pragma unroll
-    for (int s = 0; s < kRowSplits; ++s) acc += dwap[(size_t)s * seg + i];
-    g_wa_ba[i] = acc;
-}
-
 // d a2 = (sum_chunks d h2 partial + dvalue * wc) * relu'(h2) ; entropy per row.
 // One workgroup per row: thread (g, k) sums the chunk slabs c = g, g+4, ... for feature k, the four group sums are
 // then added in group order (fixed order, independent of timing).
@@ -602,15 +599,26 @@ __global__ __launch_bounds__(256) void scatter_dobs_kernel(const float* __restri
 // clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1).
 // stage 1: kNormBlocks workgroups, each a contiguous slice, fixed-order tree -> partial sums of squares
 constexpr int kNormBlocks = 256;
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n_trunk, long n_total,
-                                                            float* __restrict__ partial) {
+// The wa|ba segment of the gradient is still in kRowSplits partial slabs: they are summed here (slab order) and the
+// sum is written to the flat gradient buffer on the way.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ g, long n_trunk, long n_total, long wa_beg, long wa_len,
+                                                            const float* __restrict__ dwap, float* __restrict__ partial) {
     __shared__ float sh[256];
     const int tid = threadIdx.x;
     const long per = (n_total + kNormBlocks - 1) / kNormBlocks;
     const long lo = blockIdx.x * per, hi = min(n_total, lo + per);
     float acc = 0.f;
     for (long i = lo + tid; i < hi; i += 256) {
-        const float x = g[i];
+        float x;
+        const long wi = i - wa_beg;
+        if (wi >= 0 && wi < wa_len) {
+            x = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < kRowSplits; ++sl) x += dwap[(size_t)sl * wa_len + wi];
+            g[i] = x;
+        } else {
+            x = g[i];
+        }
         acc += (i < n_trunk ? 2.0f : 1.0f) * x * x;  // trunk parameters appear twice in the reference's list
     }
     sh[tid] = acc;
@@ -655,6 +663,29 @@ __global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, c
 }
 
 // torch.optim.Adam (_single_tensor_adam): lerp_, mul_/addcmul_, bias corrections from the step count
+struct AdamSeg { int n_sub; int scale_pow; float step_size0, bc2s0, step_size1, bc2s1; };
+
+// one launch over the whole flat buffer: elements [0, n_first) use segment a (trunk), the rest segment b (heads)
+__global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, long n_first, AdamSeg sa, AdamSeg sb, float beta1,
+                                                    float beta2, float eps, const float* __restrict__ grad_scale) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AdamSeg sg = i < n_first ? sa : sb;
+    float gi = g[i];
+    const float c = grad_scale[0];
+    for (int q = 0; q < sg.scale_pow; ++q) gi *= c;
+    float pi = p[i], mi = m[i], vi = v[i];
+    for (int sub = 0; sub < sg.n_sub; ++sub) {
+        mi = mi + (1.0f - beta1) * (gi - mi);
+        vi = vi * beta2 + (1.0f - beta2) * gi * gi;
+        const float ss = sub == 0 ? sg.step_size0 : sg.step_size1;
+        const float b2 = sub == 0 ? sg.bc2s0 : sg.bc2s1;
+        pi = pi - ss * (mi / (sqrtf(vi) / b2 + eps));
+    }
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, int n_sub, float beta1, float beta2, float eps,
                                                    float step_size0, float bc2s0, float step_size1, float bc2s1,
@@ -727,6 +758,7 @@ extern "C" int cirs_ppo_prepare(const cirs_ppo_cfg* cfg, const cirs_traj* traj, 
     CIRS_HIP(hipMallocAsync((void**)&unnorm, sizeof(double) * (size_t)n_rows, s));
     hipLaunchKernelGGL(gae_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, *cfg, *traj, lens, offsets, n_env, cfg->dim_state,
                        rms_state, *out, unnorm);
+    hipLaunchKernelGGL(compact_obs_kernel, dim3(cdiv((long)n_rows * cfg->dim_state, 256)), dim3(256), 0, s, *traj, *out, n_rows, n_env, cfg->dim_state);
     CIRS_CHECK_LAUNCH("gae_kernel");
     hipLaunchKernelGGL(returns_kernel, dim3(1), dim3(1024), 0, s, *cfg, unnorm, n_rows, rms_state, out->ret);
     CIRS_CHECK_LAUNCH("returns_kernel");
@@ -786,20 +818,21 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
     hipLaunchKernelGGL(head_bwd_dh2_kernel, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v);
     CIRS_CHECK_LAUNCH("head_bwd_dh2_kernel");
     const long seg = (long)I * kH + I;
-    hipLaunchKernelGGL(reduce_dwa_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, s, v.dwap, seg, grads + L.wa);
-    CIRS_CHECK_LAUNCH("reduce_dwa_kernel");
     hipLaunchKernelGGL(finalize_dh2_kernel, dim3(n_pad), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
     CIRS_CHECK_LAUNCH("finalize_dh2_kernel");
     // 6. critic + trunk backward
-    launch_dw_gemm(v.dvalue, 1, v.h2, kH, mb, 1, kH, grads + L.wc, grads + L.bc, v.dwp, s);  // d wc = sum_r dvalue_r h2[r], d bc
-    CIRS_CHECK_LAUNCH("dw(critic)");
-    launch_dw_gemm(v.da2, kH, v.h1, kH, mb, kH, kH, grads + L.w2, grads + L.b2, v.dwp, s);
-    CIRS_CHECK_LAUNCH("dw(w2)");
     // d a1 = (d a2 * W2) masked by relu'(h1)
     launch_rows_gemm(false, v.da2, kH, w.w2, kH, nullptr, n_pad, kH, kH, 0, v.h1, 0, v.da1, kH, s);
     CIRS_CHECK_LAUNCH("dx(h1)");
-    launch_dw_gemm(v.da1, kH, v.obs, S, mb, kH, S, grads + L.w1, grads + L.b1, v.dwp, s);
-    CIRS_CHECK_LAUNCH("dw(w1)");
+    {   // d wc/d bc, d W2/d b2, d W1/d b1 in one launch pair (same rows, fixed-order slab sums)
+        DwJobs jobs;
+        jobs.n = 3;
+        jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
+        jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
+        jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
+        launch_dw_multi(jobs, mb, v.dwp, s);
+        CIRS_CHECK_LAUNCH("dw(critic, w2, w1)");
+    }
     if (dobs_accum) {
         float* dobs = v.dh2p;  // reuse: partial slabs are consumed
         launch_rows_gemm(false, v.da1, kH, w.w1, S, nullptr, mb, kH, S, 0, nullptr, 0, dobs, S, s);
@@ -808,12 +841,22 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
         CIRS_CHECK_LAUNCH("scatter_dobs_kernel");
     }
     // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps; heads: once)
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, v.normp);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg, v.dwap, v.normp);
     hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, s, *cfg, v.normp, mb, v, loss_out);
     CIRS_CHECK_LAUNCH("gradnorm");
-    if (int rc = launch_adam(params, grads, adam_m, adam_v, L.trunk, 2 * opt_step, 2, cfg->lr, cfg->beta1, cfg->beta2,
-                             cfg->adam_eps, v.red + 4, 2, s))
-        return rc;
-    return launch_adam(params + L.trunk, grads + L.trunk, adam_m + L.trunk, adam_v + L.trunk, L.total - L.trunk, opt_step, 1,
-                       cfg->lr, cfg->beta1, cfg->beta2, cfg->adam_eps, v.red + 4, 1, s);
+    auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
+        AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};
+        for (int q = 0; q < n_sub; ++q) {
+            const double t = (double)(step_before + 1 + q);
+            const float ss = (float)((double)cfg->lr / (1.0 - pow((double)cfg->beta1, t)));
+            const float bs = (float)sqrt(1.0 - pow((double)cfg->beta2, t));
+            if (q == 0) { sg.step_size0 = ss; sg.bc2s0 = bs; } else { sg.step_size1 = ss; sg.bc2s1 = bs; }
+        }
+        return sg;
+    };
+    // trunk: two sequential sub-steps (steps 2k+1, 2k+2), clip coefficient squared; heads: one step, coefficient once
+    hipLaunchKernelGGL(adam2_kernel, dim3(cdiv(L.total, 256)), dim3(256), 0, s, params, grads, adam_m, adam_v, L.total, L.trunk,
+                       seg_of(2 * opt_step, 2, 2), seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, v.red + 4);
+    CIRS_CHECK_LAUNCH("adam2_kernel");
+    return CIRS_OK;
 }

@@ -227,24 +227,12 @@ __global__ __launch_bounds__(256) void ln_bwd(const float* __restrict__ dOut, co
         dY[(size_t)r * tD + d] = rs * (dxh - m1 - xhat[(size_t)r * tD + d] * m2);
     }
 }
-// d gamma[d] = sum_r dOut*xhat, d beta[d] = sum_r dOut  -- chunk partials then ordered sum
-__global__ __launch_bounds__(64) void ln_dgb_partial(const float* __restrict__ dOut, const float* __restrict__ xhat, int R,
-                                                     float* __restrict__ partial) {
-    const int c = blockIdx.x, t = threadIdx.x;  // t < 64: 0..31 gamma, 32..63 beta
-    const int r0 = c * kChunkRows, r1 = min(R, r0 + kChunkRows);
-    const int d = t & 31;
-    float acc = 0.f;
-    if (t < 32) for (int r = r0; r < r1; ++r) acc = __builtin_fmaf(dOut[(size_t)r * tD + d], xhat[(size_t)r * tD + d], acc);
-    else for (int r = r0; r < r1; ++r) acc += dOut[(size_t)r * tD + d];
-    partial[(size_t)c * 64 + t] = acc;
+// d gamma[d] = sum_r dOut[r,d]*xhat[r,d] = diag(dOut^T xhat), d beta[d] = sum_r dOut[r,d]: both fall out of the
+// small dW GEMM (32 x 32 product + bias column); this kernel picks the diagonal.
+__global__ __launch_bounds__(64) void ln_diag_kernel(const float* __restrict__ full, float* __restrict__ dg) {
+    const int d = threadIdx.x;
+    if (d < tD) dg[d] = full[d * tD + d];
 }
-__global__ __launch_bounds__(64) void ln_dgb_final(const float* __restrict__ partial, int n_chunks, float* __restrict__ dg, float* __restrict__ db) {
-    const int t = threadIdx.x;
-    float acc = 0.f;
-    for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * 64 + t];
-    if (t < 32) dg[t] = acc; else db[t - 32] = acc;
-}
-
 // upstream gradient rows: G[r, s] = dstate[row_t, row_env, s]
 __global__ __launch_bounds__(256) void gather_dstate(const float* __restrict__ dstate, const int32_t* __restrict__ row_env,
                                                      const int32_t* __restrict__ row_t, int R, int S, int B, float* __restrict__ G) {
@@ -351,7 +339,7 @@ struct BwdScratch {
     float *QKV[CIRS_MAX_TRACKER_LAYERS], *P[CIRS_MAX_TRACKER_LAYERS], *ATT[CIRS_MAX_TRACKER_LAYERS];
     float *XH1[CIRS_MAX_TRACKER_LAYERS], *RS1[CIRS_MAX_TRACKER_LAYERS], *H1N[CIRS_MAX_TRACKER_LAYERS], *FF1[CIRS_MAX_TRACKER_LAYERS];
     float *XH2[CIRS_MAX_TRACKER_LAYERS], *RS2[CIRS_MAX_TRACKER_LAYERS];
-    float *T0, *T1, *T2, *dQKV, *dFF1, *dS, *partial, *GIN;
+    float *T0, *T1, *T2, *dQKV, *dFF1, *dS, *partial, *GIN, *lnfull;
 };
 
 static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
@@ -363,6 +351,7 @@ static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     f += 3 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp;  // T0..2, dQKV, dFF1, dS
     f += dwg_partial_floats(R, tH, tD) + dwg_partial_floats(R, 2, tD) + 4096;  // partial (largest: 128 x 33)
     f += (size_t)R * (tD + 1);                    // GIN
+    f += tD * tD + 64;                            // lnfull
     return f + 64 * 32;
 }
 
@@ -382,6 +371,7 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
     s.dQKV = take((size_t)R * 96); s.dFF1 = take((size_t)R * tH); s.dS = take((size_t)R * NH * Lp);
     s.partial = take(dwg_partial_floats(R, tH, tD) + dwg_partial_floats(R, 2, tD) + 4096);
     s.GIN = take((size_t)R * (tD + 1));
+    s.lnfull = take(tD * tD + 64);
     return s;
 }
 
@@ -406,7 +396,6 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     hipStream_t s = (hipStream_t)stream;
     const int R = n_rows, B = cfg->n_env, S = cfg->dim_state, L = cfg->max_len, NH = cfg->nhead, nl = cfg->nlayers;
     BwdScratch sc = carve_bwd(workspace, cfg, R);
-    const int n_chunks = cdiv(R, kChunkRows);
     auto g1 = [&](long n) { return dim3(cdiv(n, 256)); };
 
 #define DW(dY, X, O, K, dWp, dbp) launch_dw_gemm(dY, O, X, K, R, O, K, dWp, dbp, sc.partial, s)
@@ -445,8 +434,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         const cirs_tracker_layer& y = w->layer[l];
         const cirs_tracker_layer_grads& gy = grads->layer[l];
         // LN2
-        hipLaunchKernelGGL(ln_dgb_partial, dim3(n_chunks), dim3(64), 0, s, dH, sc.XH2[l], R, sc.partial);
-        hipLaunchKernelGGL(ln_dgb_final, dim3(1), dim3(64), 0, s, sc.partial, n_chunks, gy.norm2_w, gy.norm2_b);
+        launch_dw_gemm(dH, tD, sc.XH2[l], tD, R, tD, tD, sc.lnfull, gy.norm2_b, sc.partial, s);
+        hipLaunchKernelGGL(ln_diag_kernel, dim3(1), dim3(64), 0, s, sc.lnfull, gy.norm2_w);
         float* dY2 = sc.T1;
         hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2);
         // FF
@@ -456,8 +445,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         // d H1N = dY2 (residual) + dFF1 * W1
         launch_rows_gemm(false, sc.dFF1, tH, y.lin1_w, tD, nullptr, R, tH, tD, 0, nullptr, 1, dY2, tD, s);
         // LN1
-        hipLaunchKernelGGL(ln_dgb_partial, dim3(n_chunks), dim3(64), 0, s, dY2, sc.XH1[l], R, sc.partial);
-        hipLaunchKernelGGL(ln_dgb_final, dim3(1), dim3(64), 0, s, sc.partial, n_chunks, gy.norm1_w, gy.norm1_b);
+        launch_dw_gemm(dY2, tD, sc.XH1[l], tD, R, tD, tD, sc.lnfull, gy.norm1_b, sc.partial, s);
+        hipLaunchKernelGGL(ln_diag_kernel, dim3(1), dim3(64), 0, s, sc.lnfull, gy.norm1_w);
         float* dY1 = sc.T2;
         hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dY2, sc.XH1[l], sc.RS1[l], y.norm1_w, R, dY1);
         // out_proj
