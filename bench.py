@@ -76,7 +76,7 @@ def hip_event_kernel_time(eng, wl, reps=20):
     return start.elapsed_time(stop) / reps * 1e-3, mb  # seconds per minibatch step
 
 
-def cpu_baseline(wl, budget_envs=256, threads=None):
+def cpu_baseline(wl, budget_envs=1024, threads=None):
     """The oracle port of the same step on the host cores, bounded sample (fewer envs, same tables / episode rule).
     Threads are capped: the per-step tensors are tiny and oversubscribing a 256-core host makes the port slower."""
     threads = threads or min(16, os.cpu_count() or 1)
