@@ -67,7 +67,7 @@ class CirsEngine:
                  tau=100.0, gamma_exposure=10.0, version="v1", r_decay=1.0, dim_model=32, dim_state=20, nhead=4,
                  hidden=64, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
                  lr=1e-3, rew_norm=True, value_clip=True, norm_adv=True, seed=2023, tracker_params=None,
-                 policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False):
+                 policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False, learner_mode="dp"):
         self.device = tables.device
         self.tables = tables
         self.n_env, self.max_turn, self.S, self.D = n_env, max_turn, dim_state, dim_model
@@ -75,6 +75,10 @@ class CirsEngine:
         self.n_items = I
         self.world, self.rank, self.group = world_size, rank, dist_group
         self.force_gather = force_gather  # exercise the packed all-gather path even with one rank (tests)
+        # "dp": global minibatch = batch_size * world rows, sharded by rows, gradients all-reduced per minibatch;
+        # "replicated": every rank runs the identical learner on the gathered buffer (no further communication)
+        assert learner_mode in ("dp", "replicated")
+        self.learner_mode = learner_mode
         self.env = DeviceEnv(tables, n_env, num_leave_compute=num_leave_compute, leave_threshold=leave_threshold,
                              max_turn=max_turn, tau=tau, gamma_exposure=gamma_exposure, version=version, r_decay=r_decay)
         tp = tracker_params or init_tracker_params(U, I, max_turn, seed=seed, dim_model=dim_model, dim_state=dim_state, nhead=nhead)
@@ -148,10 +152,39 @@ class CirsEngine:
             # identical permutations on every rank: replicated learners stay bit-identical
             rs = np.random.RandomState((self.seed * 7919 + self.collect_count) & 0x7FFFFFFF)
             perms = [rs.permutation(n) for _ in range(repeat)]
-        losses = ln.learn(batch_size, repeat, perms=perms)
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        if self.world > 1 and self.learner_mode == "dp":
+            return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms)
+        losses = ln.learn(batch_size, repeat, perms=perms)
         self.tracker.backward(users, traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).to(self.device),
                               torch.as_tensor(lens).to(self.device), n, ln.dobs,
                               x_hist=x_hist if (self.world > 1 or self.force_gather) else None)
+        self.tracker.adam_update()
+        return losses, n
+
+    def _update_dp(self, traj, lens, offsets, n, batch_size, repeat, perms):
+        """Data-parallel learner: per global minibatch one all-reduce of the flat policy gradients; per update one
+        all-reduce of d loss/d obs and one of the tracker gradients.  Every rank applies identical updates."""
+        import torch.distributed as dist
+        ln = self.learner
+
+        def all_reduce(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+        losses = ln.learn_dp(batch_size, repeat, perms, self.rank, self.world, all_reduce)
+        all_reduce(ln.dobs)  # each (t, env) row was written by exactly one rank
+        # tracker backward over THIS rank's envs only (its own trajectory / slots), then sum the gradients
+        Bl = self.n_env
+        lo_env, hi_env = self.rank * Bl, (self.rank + 1) * Bl
+        r0 = int(offsets[lo_env])
+        r1 = int(offsets[hi_env - 1] + lens[hi_env - 1])
+        lens_l = lens[lo_env:hi_env]
+        off_l = (offsets[lo_env:hi_env] - r0).astype(np.int32)
+        row_env_l = (ln.b_env[r0:r1] - lo_env).contiguous()
+        row_t_l = ln.b_t[r0:r1].contiguous()
+        dstate_l = ln.dobs[:, lo_env:hi_env, :].contiguous()
+        self.tracker.backward(self.users, self.rollout.traj, row_env_l, row_t_l, torch.as_tensor(off_l).to(self.device),
+                              torch.as_tensor(lens_l.astype(np.int32)).to(self.device), r1 - r0, dstate_l)
+        all_reduce(self.tracker.flat_grad)
         self.tracker.adam_update()
         return losses, n

@@ -57,7 +57,7 @@ class DeviceLearner:
         self._lib = abi.lib()
         assert flat_params.numel() == self._lib.cirs_ppo_param_count(C.byref(self.cfg))
         self.params = flat_params
-        self.grads = torch.zeros_like(flat_params)
+        self.grads = torch.zeros(flat_params.numel() + 4, dtype=torch.float32, device=self.device)  # + loss partials tail
         self.adam_m = torch.zeros_like(flat_params)
         self.adam_v = torch.zeros_like(flat_params)
         self.opt_step = 0
@@ -105,6 +105,47 @@ class DeviceLearner:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    # ---- data-parallel building blocks (one global minibatch = the union of the ranks' row shards) -----------------
+    def mb_phase1(self, idx_local, idx_global, want_dobs, loss_slot):
+        """forward + backward of this rank's shard -> self.grads (incl. loss partials in the tail), ready to be summed."""
+        ws = self.workspace(max(int(idx_local.numel()), 2))
+        abi.check(self._lib.cirs_ppo_minibatch_dp(
+            C.byref(self.cfg), self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+            self.opt_step, C.byref(self.batch), idx_local.data_ptr(), int(idx_local.numel()), idx_global.data_ptr(),
+            int(idx_global.numel()), self.dobs.data_ptr() if want_dobs else None, self.n_env, loss_slot.data_ptr(),
+            ws.data_ptr(), ws.numel(), 1, self._stream()), "cirs_ppo_minibatch_dp(phase 1)")
+
+    def mb_phase2(self, mb_local, mb_global, loss_slot):
+        """clip_grad_norm_ + Adam from the (all-reduced) gradients in self.grads."""
+        ws = self.workspace(max(mb_local, 2))
+        abi.check(self._lib.cirs_ppo_minibatch_dp(
+            C.byref(self.cfg), self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+            self.opt_step, C.byref(self.batch), None, mb_local, None, mb_global, None, self.n_env, loss_slot.data_ptr(),
+            ws.data_ptr(), ws.numel(), 2, self._stream()), "cirs_ppo_minibatch_dp(phase 2)")
+        self.opt_step += 1
+
+    def learn_dp(self, batch_size, repeat, perms, rank, world, all_reduce, want_tracker_grad=True):
+        """Data-parallel learn(): global minibatches of batch_size*world rows, rows rank::world of each belong to this
+        rank; `all_reduce(tensor)` sums a flat tensor over the ranks in place (torch.distributed.all_reduce)."""
+        n = self.n_rows
+        slices = minibatch_slices(n, batch_size * world)
+        losses = torch.zeros((repeat * len(slices), 4), dtype=torch.float32, device=self.device)
+        k = 0
+        for rep in range(repeat):
+            perm_d = torch.as_tensor(np.asarray(perms[rep]).astype(np.int32)).to(self.device)
+            last = rep == repeat - 1
+            if last and want_tracker_grad:
+                self.dobs.zero_()
+            for s0, e0 in slices:
+                g_idx = perm_d[s0:e0]
+                l_idx = g_idx[rank::world].contiguous()
+                assert l_idx.numel() >= 1, "global minibatch smaller than the world size"
+                self.mb_phase1(l_idx, g_idx, last and want_tracker_grad, losses[k])
+                all_reduce(self.grads)
+                self.mb_phase2(int(l_idx.numel()), int(g_idx.numel()), losses[k])
+                k += 1
+        return losses
 
     def learn(self, batch_size, repeat, perms: Optional[List[np.ndarray]] = None, want_tracker_grad=True):
         """learn(): `repeat` passes of shuffled minibatches.  Returns loss arrays + leaves d loss / d obs of the LAST

@@ -188,27 +188,31 @@ __global__ __launch_bounds__(256) void gather_kernel(cirs_ppo_batch b, const int
     else v.act[r] = ok ? b.act[src] : 0;
 }
 
-// b.adv = (b.adv - mean) / std, torch.Tensor.std = unbiased (ppo.py:185-186).  One workgroup, fixed order.
-__global__ __launch_bounds__(1024) void adv_norm_kernel(float* __restrict__ adv, int mb, int enable,
-                                                        float* __restrict__ red) {
+// advantage statistics of the (global) minibatch: mean and unbiased std (torch.Tensor.std, ppo.py:185-186) of
+// adv_flat[idx[0..m)].  One workgroup, fixed order.  red[0] = mean, red[1] = std (1, 0 when normalisation is off).
+__global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict__ adv_flat, const int32_t* __restrict__ idx, int m,
+                                                         int enable, float* __restrict__ red) {
     __shared__ float sh[1024];
     __shared__ float s_mean;
     const int tid = threadIdx.x;
-    if (!enable) return;
+    if (!enable) {
+        if (tid == 0) { red[0] = 0.f; red[1] = 1.f; }
+        return;
+    }
     float acc = 0.f;
-    for (int i = tid; i < mb; i += 1024) acc += adv[i];
+    for (int i = tid; i < m; i += 1024) acc += adv_flat[idx[i]];
     sh[tid] = acc;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
         if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
-    if (tid == 0) s_mean = sh[0] / (float)mb;
+    if (tid == 0) s_mean = sh[0] / (float)m;
     __syncthreads();
     const float mean = s_mean;
     acc = 0.f;
-    for (int i = tid; i < mb; i += 1024) {
-        const float d = adv[i] - mean;
+    for (int i = tid; i < m; i += 1024) {
+        const float d = adv_flat[idx[i]] - mean;
         acc += d * d;
     }
     __syncthreads();
@@ -218,9 +222,7 @@ __global__ __launch_bounds__(1024) void adv_norm_kernel(float* __restrict__ adv,
         if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
-    const float stdv = sqrtf(sh[0] / (float)(mb - 1));
-    for (int i = tid; i < mb; i += 1024) adv[i] = (adv[i] - mean) / stdv;
-    if (tid == 0) { red[0] = mean; red[1] = stdv; }
+    if (tid == 0) { red[0] = mean; red[1] = sqrtf(sh[0] / (float)(m - 1)); }
 }
 
 // merge the head-stats partials: lse, E_p[z] (for the entropy), z of the taken action (same k-order as the MFMA)
@@ -264,10 +266,11 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(int mb, int n_pad
 }
 
 // per-row loss terms and backward coefficients (ppo.py:183-212); one workgroup, fixed-order loss sums
-__global__ __launch_bounds__(1024) void row_scalar_kernel(cirs_ppo_cfg cfg, int mb, int n_pad, MbView v) {
+__global__ __launch_bounds__(1024) void row_scalar_kernel(cirs_ppo_cfg cfg, int mb, int mb_norm, int n_pad, MbView v) {
     __shared__ float sh_clip[1024], sh_vf[1024];
     const int tid = threadIdx.x;
-    const float inv_mb = 1.0f / (float)mb;
+    const float inv_mb = 1.0f / (float)mb_norm;  // means are over the GLOBAL minibatch
+    const float adv_mean = v.red[0], adv_std = v.red[1];
     const float eps = 1.1920928955078125e-7f;
     float a_clip = 0.f, a_vf = 0.f;
     for (int r = tid; r < n_pad; r += 1024) {
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(1024) void row_scalar_kernel(cirs_ppo_cfg cfg, int 
         const bool clamped = praw < eps || praw > 1.0f - eps;  // probs_to_logits clamp blocks the gradient
         const float logp = __logf(fminf(fmaxf(praw, eps), 1.0f - eps));
         const float ratio = __expf(logp - v.logp_old[r]);
-        const float A = v.adv[r];
+        const float A = (v.adv[r] - adv_mean) / adv_std;  // per-minibatch advantage normalisation (ppo.py:184-186)
         const float s1 = ratio * A;
         const float s2 = fminf(fmaxf(ratio, 1.0f - cfg.eps_clip), 1.0f + cfg.eps_clip) * A;
         a_clip += -fminf(s1, s2);
@@ -599,6 +602,17 @@ __global__ __launch_bounds__(256) void scatter_dobs_kernel(const float* __restri
 // clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1).
 // stage 1: kNormBlocks workgroups, each a contiguous slice, fixed-order tree -> partial sums of squares
 constexpr int kNormBlocks = 256;
+// sum the dWa slabs in fixed order into the flat gradient buffer (data-parallel path: grads must be complete before
+// the all-reduce; the single-rank path folds this into sumsq_partial_kernel)
+__global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict__ dwap, long seg, float* __restrict__ g_wa_ba) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= seg) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < kRowSplits; ++s) acc += dwap[(size_t)s * seg + i];
+    g_wa_ba[i] = acc;
+}
+
 // The wa|ba segment of the gradient is still in kRowSplits partial slabs: they are summed here (slab order) and the
 // sum is written to the flat gradient buffer on the way.
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ g, long n_trunk, long n_total, long wa_beg, long wa_len,
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
     for (long i = lo + tid; i < hi; i += 256) {
         float x;
         const long wi = i - wa_beg;
-        if (wi >= 0 && wi < wa_len) {
+        if (dwap && wi >= 0 && wi < wa_len) {
             x = 0.f;
 #pragma unroll
             for (int sl = 0; sl < kRowSplits; ++sl) x += dwap[(size_t)sl * wa_len + wi];
@@ -630,8 +644,23 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
     if (tid == 0) partial[blockIdx.x] = sh[0];
 }
 // stage 2: one workgroup: norm, clip coefficient, entropy mean, total loss
-__global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, const float* __restrict__ partial, int mb, MbView v,
-                                                             float* __restrict__ loss_out) {
+// loss partials of this rank: {clip, vf, ent} already divided by the global minibatch size -> grads tail
+__global__ __launch_bounds__(256) void loss_partials_kernel(int mb, int mb_norm, MbView v, float* __restrict__ tail) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x;
+    float e = 0.f;
+    for (int r = tid; r < mb; r += 256) e += v.ent_row[r];
+    sh[tid] = e;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) { tail[0] = v.red[2]; tail[1] = v.red[3]; tail[2] = sh[0] / (float)mb_norm; tail[3] = 0.f; }
+}
+
+__global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, const float* __restrict__ partial, const float* __restrict__ tail,
+                                                             MbView v, float* __restrict__ loss_out) {
     __shared__ float sh[256];
     const int tid = threadIdx.x;
     sh[tid] = tid < kNormBlocks ? partial[tid] : 0.f;
@@ -641,22 +670,12 @@ __global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, c
         __syncthreads();
     }
     const float total_norm = sqrtf(sh[0]);
-    __syncthreads();
-    float e = 0.f;
-    for (int r = tid; r < mb; r += 256) e += v.ent_row[r];
-    sh[tid] = e;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] += sh[tid + s];
-        __syncthreads();
-    }
     if (tid == 0) {
         float coef = 1.0f;
         if (cfg.max_grad_norm > 0.f) coef = fminf(cfg.max_grad_norm / (total_norm + 1e-6f), 1.0f);
         v.red[4] = coef;
         v.red[5] = total_norm;
-        const float ent = sh[0] / (float)mb;
-        const float clip = v.red[2], vf = v.red[3];
+        const float clip = tail[0], vf = tail[1], ent = tail[2];
         loss_out[0] = clip + cfg.vf_coef * vf - cfg.ent_coef * ent;
         loss_out[1] = clip; loss_out[2] = vf; loss_out[3] = ent;
     }
@@ -774,14 +793,15 @@ extern "C" int cirs_adam_step(float* params, const float* grads, float* m, float
     return launch_adam(params, grads, m, v, n, step_before, n_sub, lr, beta1, beta2, eps, grad_scale, scale_pow, (hipStream_t)stream);
 }
 
-extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
-                                  int64_t opt_step, const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb,
-                                  float* dobs_accum, int32_t n_env, float* loss_out, void* workspace,
-                                  int64_t workspace_bytes, void* stream) {
+static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
+                              const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb, const int32_t* idx_global,
+                              int32_t mb_global, float* dobs_accum, int32_t n_env, float* loss_out, void* workspace,
+                              int64_t workspace_bytes, int phase, void* stream) {
     using namespace cirs;
     if (int rc = validate_ppo(cfg)) return rc;
-    CIRS_REQUIRE(params && grads && adam_m && adam_v && batch && idx && loss_out && workspace, "null argument");
-    CIRS_REQUIRE(mb >= 2, "minibatch needs >= 2 rows (unbiased std)");
+    CIRS_REQUIRE(params && grads && adam_m && adam_v && batch && loss_out && workspace, "null argument");
+    CIRS_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0, 1 or 2");
+    CIRS_REQUIRE(mb >= 1 && mb_global >= 2 && mb <= mb_global, "bad minibatch sizes (need mb_global >= 2 for the unbiased std)");
     CIRS_REQUIRE(workspace_bytes >= cirs_ppo_workspace_bytes(cfg, mb), "workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int I = cfg->n_items, S = cfg->dim_state;
@@ -791,58 +811,70 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
     cirs_policy_cfg pcfg{I, S, kH};
     cirs_policy_weights w{params + L.w1, params + L.b1, params + L.w2, params + L.b2,
                           params + L.wa, params + L.ba, params + L.wc, params + L.bc};
-    // 1. gather + advantage normalisation
-    hipLaunchKernelGGL(gather_kernel, dim3(cdiv((long)n_pad * (S + 5), 256)), dim3(256), 0, s, *batch, idx, mb, n_pad, S, v);
-    CIRS_CHECK_LAUNCH("gather_kernel");
-    hipLaunchKernelGGL(adv_norm_kernel, dim3(1), dim3(1024), 0, s, v.adv, mb, cfg->norm_adv, v.red);
-    CIRS_CHECK_LAUNCH("adv_norm_kernel");
-    // 2. trunk forward (same fma chains as the rollout -> ratio == 1 exactly while the weights are unchanged)
-    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, pcfg, w, v.obs, (long)S, n_pad, (const uint8_t*)nullptr,
-                       v.h2, v.value, v.h1);
-    CIRS_CHECK_LAUNCH("trunk_kernel");
-    // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores
-    ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
-    hipLaunchKernelGGL(actor_head_kernel<false>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, pcfg, w.wa, w.ba,
-                       v.h2, mb, (const float*)nullptr, (uint64_t)0, 0u, (const int32_t*)nullptr, (const uint32_t*)nullptr,
-                       (const uint8_t*)nullptr, pv, n_pad);
-    CIRS_CHECK_LAUNCH("actor_head_kernel<stats>");
-    hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(mb, 4)), dim3(256), 0, s, mb, n_pad, n_chunks, pv, w.wa, w.ba, v);
-    CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
-    // 4. row losses + backward coefficients
-    hipLaunchKernelGGL(row_scalar_kernel, dim3(1), dim3(1024), 0, s, *cfg, mb, n_pad, v);
-    CIRS_CHECK_LAUNCH("row_scalar_kernel");
-    // 5. head backward
-    const int n_item_tiles = cdiv(I, kTileN);
-    hipLaunchKernelGGL(head_bwd_dwa_kernel, dim3(cdiv(n_item_tiles, 4), kRowSplits), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v, v.dwap);
-    CIRS_CHECK_LAUNCH("head_bwd_dwa_kernel");
-    hipLaunchKernelGGL(head_bwd_dh2_kernel, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v);
-    CIRS_CHECK_LAUNCH("head_bwd_dh2_kernel");
     const long seg = (long)I * kH + I;
-    hipLaunchKernelGGL(finalize_dh2_kernel, dim3(n_pad), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
-    CIRS_CHECK_LAUNCH("finalize_dh2_kernel");
-    // 6. critic + trunk backward
-    // d a1 = (d a2 * W2) masked by relu'(h1)
-    launch_rows_gemm(false, v.da2, kH, w.w2, kH, nullptr, n_pad, kH, kH, 0, v.h1, 0, v.da1, kH, s);
-    CIRS_CHECK_LAUNCH("dx(h1)");
-    {   // d wc/d bc, d W2/d b2, d W1/d b1 in one launch pair (same rows, fixed-order slab sums)
-        DwJobs jobs;
-        jobs.n = 3;
-        jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
-        jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
-        jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
-        launch_dw_multi(jobs, mb, v.dwp, s);
-        CIRS_CHECK_LAUNCH("dw(critic, w2, w1)");
-    }
-    if (dobs_accum) {
-        float* dobs = v.dh2p;  // reuse: partial slabs are consumed
-        launch_rows_gemm(false, v.da1, kH, w.w1, S, nullptr, mb, kH, S, 0, nullptr, 0, dobs, S, s);
-        CIRS_CHECK_LAUNCH("dx(obs)");
-        hipLaunchKernelGGL(scatter_dobs_kernel, dim3(cdiv((long)mb * S, 256)), dim3(256), 0, s, dobs, idx, *batch, mb, S, n_env, dobs_accum);
-        CIRS_CHECK_LAUNCH("scatter_dobs_kernel");
+    float* tail = grads + L.total;  // {clip, vf, ent, 0} partials of this rank
+    if (phase == 0 || phase == 1) {
+        CIRS_REQUIRE(idx != nullptr, "idx is null");
+        const int32_t* sidx = idx_global ? idx_global : idx;
+        // 1. gather + advantage statistics of the (global) minibatch
+        hipLaunchKernelGGL(gather_kernel, dim3(cdiv((long)n_pad * (S + 5), 256)), dim3(256), 0, s, *batch, idx, mb, n_pad, S, v);
+        CIRS_CHECK_LAUNCH("gather_kernel");
+        hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, s, batch->adv, sidx, idx_global ? mb_global : mb, cfg->norm_adv, v.red);
+        CIRS_CHECK_LAUNCH("adv_stats_kernel");
+        // 2. trunk forward (same fma chains as the rollout -> ratio == 1 exactly while the weights are unchanged)
+        hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, pcfg, w, v.obs, (long)S, n_pad, (const uint8_t*)nullptr,
+                           v.h2, v.value, v.h1);
+        CIRS_CHECK_LAUNCH("trunk_kernel");
+        // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores
+        ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
+        hipLaunchKernelGGL(actor_head_kernel<false>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, pcfg, w.wa, w.ba,
+                           v.h2, mb, (const float*)nullptr, (uint64_t)0, 0u, (const int32_t*)nullptr, (const uint32_t*)nullptr,
+                           (const uint8_t*)nullptr, pv, n_pad);
+        CIRS_CHECK_LAUNCH("actor_head_kernel<stats>");
+        hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(mb, 4)), dim3(256), 0, s, mb, n_pad, n_chunks, pv, w.wa, w.ba, v);
+        CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
+        // 4. row losses + backward coefficients (means over the global minibatch)
+        hipLaunchKernelGGL(row_scalar_kernel, dim3(1), dim3(1024), 0, s, *cfg, mb, idx_global ? mb_global : mb, n_pad, v);
+        CIRS_CHECK_LAUNCH("row_scalar_kernel");
+        // 5. head backward
+        const int n_item_tiles = cdiv(I, kTileN);
+        hipLaunchKernelGGL(head_bwd_dwa_kernel, dim3(cdiv(n_item_tiles, 4), kRowSplits), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v, v.dwap);
+        CIRS_CHECK_LAUNCH("head_bwd_dwa_kernel");
+        hipLaunchKernelGGL(head_bwd_dh2_kernel, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v);
+        CIRS_CHECK_LAUNCH("head_bwd_dh2_kernel");
+        hipLaunchKernelGGL(finalize_dh2_kernel, dim3(n_pad), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
+        CIRS_CHECK_LAUNCH("finalize_dh2_kernel");
+        // 6. critic + trunk backward:  d a1 = (d a2 * W2) masked by relu'(h1)
+        launch_rows_gemm(false, v.da2, kH, w.w2, kH, nullptr, n_pad, kH, kH, 0, v.h1, 0, v.da1, kH, s);
+        CIRS_CHECK_LAUNCH("dx(h1)");
+        {   // d wc/d bc, d W2/d b2, d W1/d b1 in one launch pair (same rows, fixed-order slab sums)
+            DwJobs jobs;
+            jobs.n = 3;
+            jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
+            jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
+            jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
+            launch_dw_multi(jobs, mb, v.dwp, s);
+            CIRS_CHECK_LAUNCH("dw(critic, w2, w1)");
+        }
+        if (dobs_accum) {
+            float* dobs = v.dh2p;  // reuse: partial slabs are consumed
+            launch_rows_gemm(false, v.da1, kH, w.w1, S, nullptr, mb, kH, S, 0, nullptr, 0, dobs, S, s);
+            CIRS_CHECK_LAUNCH("dx(obs)");
+            hipLaunchKernelGGL(scatter_dobs_kernel, dim3(cdiv((long)mb * S, 256)), dim3(256), 0, s, dobs, idx, *batch, mb, S, n_env, dobs_accum);
+            CIRS_CHECK_LAUNCH("scatter_dobs_kernel");
+        }
+        hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, mb, idx_global ? mb_global : mb, v, tail);
+        CIRS_CHECK_LAUNCH("loss_partials_kernel");
+        if (phase == 1) {  // gradients must be complete in `grads` before the caller's all-reduce
+            hipLaunchKernelGGL(reduce_dwa_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, s, v.dwap, seg, grads + L.wa);
+            CIRS_CHECK_LAUNCH("reduce_dwa_kernel");
+            return CIRS_OK;
+        }
     }
     // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps; heads: once)
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg, v.dwap, v.normp);
-    hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, s, *cfg, v.normp, mb, v, loss_out);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg,
+                       phase == 0 ? v.dwap : (const float*)nullptr, v.normp);
+    hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, s, *cfg, v.normp, tail, v, loss_out);
     CIRS_CHECK_LAUNCH("gradnorm");
     auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
         AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};
@@ -859,4 +891,22 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
                        seg_of(2 * opt_step, 2, 2), seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, v.red + 4);
     CIRS_CHECK_LAUNCH("adam2_kernel");
     return CIRS_OK;
+}
+
+extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
+                                  int64_t opt_step, const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb,
+                                  float* dobs_accum, int32_t n_env, float* loss_out, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    if (mb < 2) return cirs::fail(CIRS_E_INVALID, "minibatch needs >= 2 rows (unbiased std)");
+    return ppo_minibatch_impl(cfg, params, grads, adam_m, adam_v, opt_step, batch, idx, mb, nullptr, mb, dobs_accum, n_env, loss_out,
+                              workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
+                                     int64_t opt_step, const cirs_ppo_batch* batch, const int32_t* idx_local, int32_t mb_local,
+                                     const int32_t* idx_global, int32_t mb_global, float* dobs_accum, int32_t n_env,
+                                     float* loss_out, void* workspace, int64_t workspace_bytes, int32_t phase, void* stream) {
+    if (phase != 2 && !idx_global) return cirs::fail(CIRS_E_INVALID, "idx_global is null");
+    return ppo_minibatch_impl(cfg, params, grads, adam_m, adam_v, opt_step, batch, idx_local, mb_local, idx_global, mb_global,
+                              dobs_accum, n_env, loss_out, workspace, workspace_bytes, phase, stream);
 }

@@ -273,6 +273,20 @@ int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float* grads, flo
                        float* dobs_accum, int32_t n_env, float* loss_out, void* workspace, int64_t workspace_bytes,
                        void* stream);
 
+/* Data-parallel form of cirs_ppo_minibatch for a learner sharded over ranks.  A GLOBAL minibatch of mb_global rows
+ * (idx_global) is split by rows; this rank owns idx_local[mb_local].  Advantage normalisation uses the statistics of
+ * the global minibatch (every rank holds the gathered buffer) and every mean is over mb_global rows, so the SUM over
+ * ranks of the gradients equals the single-device gradient of the global minibatch.
+ *   phase 1: forward + backward -> grads[0 .. P) and the loss partials {clip, vf, ent, 0} in grads[P .. P+4)
+ *            (P = cirs_ppo_param_count; the grads buffer must hold P+4 floats)
+ *   -- caller all-reduces (sum) grads[0 .. P+4) over the ranks (RCCL) --
+ *   phase 2: clip_grad_norm_ + Adam from the reduced gradients, loss_out[4] from the reduced partials
+ *   phase 0: both phases back to back (single rank). */
+int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
+                          int64_t opt_step, const cirs_ppo_batch* batch, const int32_t* idx_local, int32_t mb_local,
+                          const int32_t* idx_global, int32_t mb_global, float* dobs_accum, int32_t n_env,
+                          float* loss_out, void* workspace, int64_t workspace_bytes, int32_t phase, void* stream);
+
 /* torch.optim.Adam single-tensor update over a flat buffer, `n_sub` sequential sub-steps with the same gradient
  * starting at step `step_before`+1; grad is multiplied by (*grad_scale)^scale_pow when grad_scale != NULL. */
 int cirs_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t step_before,

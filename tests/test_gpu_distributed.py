@@ -46,3 +46,61 @@ def test_gathered_path_equals_direct_path():
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+def test_data_parallel_learner_equals_single_device_large_batch():
+    """Two virtual ranks on one GPU: row-sharded phase-1 gradients summed (= all-reduce) + phase 2 on both must track a
+    single learner that runs the same GLOBAL minibatches (batch_size * world) on one device."""
+    from cirs_hip.rollout import Trajectory
+    import nn_oracle
+    import policycase
+    import rolloutcase
+    from test_gpu_learn import make_learner, rollout_time_value_logp, upload_traj
+    I, B, T, W, bs = 900, 40, 12, 2, 64
+    rng = np.random.RandomState(11)
+    tp = rolloutcase.tracker_param_dict(100, I, T, seed=1)
+    arrs = policycase.random_weights(rng, I, head_scale=1.5)
+    pp = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)) for k, v in arrs.items()}
+    lens = rng.randint(5, T + 1, size=B)
+    users = rng.randint(0, 100, B); acts = rng.randint(0, I, (B, T)); rews = rng.uniform(0, 1, (B, T))
+    dones = np.zeros((B, T), bool); dones[np.arange(B), lens - 1] = True
+    with torch.no_grad():
+        obs_bts = nn_oracle.tracker_states(tp, users, acts, rews).numpy()
+    value, logp = rollout_time_value_logp(pp, obs_bts, acts, lens)
+    n = int(lens.sum())
+    perms = [rng.permutation(n) for _ in range(2)]
+    hyper = [0.95, 0.95, 0.2, 0.25, 0.01, 0.5, 1e-3, bs, 2]
+    traj = Trajectory(B, T, 20, "cuda")
+    upload_traj(traj, acts, rews, dones, lens, obs_bts, value, logp)
+    # single device, global batch
+    ref, ref_views = make_learner(pp, I, B, T, hyper)
+    ref.prepare(traj, lens)
+    ref_losses = ref.learn(bs * W, 2, perms=perms)
+    # two virtual ranks
+    ranks = [make_learner(pp, I, B, T, hyper)[0] for _ in range(W)]
+    for ln in ranks:
+        ln.prepare(traj, lens)
+    from cirs_hip.learner import minibatch_slices
+    slices = minibatch_slices(n, bs * W)
+    losses = torch.zeros((2 * len(slices), 4), device="cuda")
+    k = 0
+    for rep in range(2):
+        perm_d = torch.as_tensor(perms[rep].astype(np.int32)).cuda()
+        for ln in ranks:
+            if rep == 1:
+                ln.dobs.zero_()
+        for s0, e0 in slices:
+            g_idx = perm_d[s0:e0]
+            shards = [g_idx[r::W].contiguous() for r in range(W)]
+            for r, ln in enumerate(ranks):
+                ln.mb_phase1(shards[r], g_idx, rep == 1, losses[k])
+            total = sum(ln.grads for ln in ranks)   # the all-reduce
+            for r, ln in enumerate(ranks):
+                ln.grads.copy_(total)
+                ln.mb_phase2(int(shards[r].numel()), int(g_idx.numel()), losses[k])
+            k += 1
+    assert torch.equal(ranks[0].params, ranks[1].params)          # ranks stay bit-identical
+    np.testing.assert_allclose(losses.cpu().numpy(), ref_losses.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(ranks[0].params.cpu().numpy(), ref.params.cpu().numpy(), rtol=2e-4, atol=2e-6)
+    dobs = sum(ln.dobs for ln in ranks)
+    np.testing.assert_allclose(dobs.cpu().numpy(), ref.dobs.cpu().numpy(), rtol=2e-3, atol=1e-7)
