@@ -35,7 +35,9 @@ class Collector:
         self._collect_count = 0
         self.data = Batch()
         if hasattr(policy, "_tracker") and env.workers[0].simulated:
-            policy.__dict__["_tracker"] = self.tracker  # the gradient through the stored obs goes to this tracker (ppo.py:215)
+            # the gradient through the stored obs of the TRAINING buffer goes to this tracker (ppo.py:215)
+            policy.__dict__["_tracker"] = self.tracker
+            policy.__dict__["_train_n_env"] = self.env_num
         self.reset_stat()
 
     def reset_stat(self):
@@ -51,6 +53,12 @@ class Collector:
         self.reset_env()
         self.reset_buffer()
         self.reset_stat()
+
+    def _assign_buffer(self, buffer):
+        self.buffer = buffer
+
+    def _reset_state(self, id):
+        pass
 
     def _get_rollout(self) -> DeviceRollout:
         if self._rollout is None:
@@ -75,8 +83,7 @@ class Collector:
         lengths = ro.collect(users_t, seed=self.policy.seed, rng_base=(self._collect_count * T) & 0xFFFFFFFF).cpu().numpy()
         self._collect_count += 1
         self.buffer.fill_from_trajectory(ro.traj, lengths)
-        self.policy.__dict__["_rollout"] = ro
-        self.policy.__dict__["_users"] = users_t
+        self.buffer._rollout, self.buffer._users = ro, users_t  # policy.update() consumes them with the buffer
         tr = ro.traj
         ep_rew = (tr.rew * (tr.act >= 0)).sum(0).cpu().numpy()
         step_count, episode_count = int(lengths.sum()), self.env_num

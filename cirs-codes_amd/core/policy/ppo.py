@@ -59,8 +59,7 @@ class PPOPolicy(nn.Module):
         self._learner: Optional[DeviceLearner] = None
         # plain attributes (NOT sub-modules: the reference's policy does not own the tracker, CIRS-RL-kuaishou.py:267-285)
         self.__dict__["_tracker"] = None   # set by the Collector (preprocess_fn's owner)
-        self.__dict__["_rollout"] = None   # the collector's DeviceRollout (trajectory + lens of the last collect)
-        self.__dict__["_users"] = None
+        self.__dict__["_train_n_env"] = None
         self.seed = int(torch.initial_seed() & 0x7FFFFFFF)
 
     # ---- protocol pieces the Collector / trainer call ----------------------------------------------------------------
@@ -98,20 +97,22 @@ class PPOPolicy(nn.Module):
         if buffer is None:
             return {}
         assert sample_size == 0, "on-policy: the whole buffer is used (onpolicy.py:199-201)"
-        ro = self._rollout
-        assert ro is not None and buffer._traj is ro.traj, "update() consumes the buffer of the last Collector.collect()"
+        ro = getattr(buffer, "_rollout", None)
+        assert ro is not None and buffer._traj is ro.traj, "update() consumes a buffer filled by Collector.collect()"
         self.updating = True
         lens = np.asarray(buffer._lengths, dtype=np.int32)
         ln = self._get_learner(ro.env.n_env, ro.env.max_turn)
         n = ln.prepare(ro.traj, lens)
         losses = ln.learn(batch_size, repeat, perms=perms, want_tracker_grad=self._tracker is not None)
         if self._tracker is not None:
-            eng = self._tracker.engine()
+            eng = self._tracker.engine(ro.env.n_env)
             eng.lr = self._tracker_lr
+            eng.adam_steps = self._tracker.adam_steps
             offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
             dev = self.flat.device
-            eng.backward(self._users, ro.traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).to(dev), torch.as_tensor(lens).to(dev), n, ln.dobs)
+            eng.backward(buffer._users, ro.traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).to(dev), torch.as_tensor(lens).to(dev), n, ln.dobs)
             eng.adam_update()
+            self._tracker.adam_steps = eng.adam_steps
         self.updating = False
         lo = losses.cpu().numpy()
         return {"loss": lo[:, 0].tolist(), "loss/clip": lo[:, 1].tolist(), "loss/vf": lo[:, 2].tolist(), "loss/ent": lo[:, 3].tolist()}

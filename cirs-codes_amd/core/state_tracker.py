@@ -31,8 +31,10 @@ class StateTrackerTransformer(nn.Module):
         for name, v in views.items():  # register under the reference's names (dots -> nested attribute path)
             self._register(name, nn.Parameter(v, requires_grad=False))
         self.register_buffer("pe", init["pos_encoder.pe"].to(self.device))
-        self._engine = None
+        self._engines = {}   # n_env -> DeviceTracker (all share the flat parameter buffer)
         self._n_env = None
+        self._train_state = None  # (flat_grad, grad_views, adam_m, adam_v) shared by whichever engine runs the backward
+        self.adam_steps = 0
 
     def _register(self, dotted, param):
         mod = self
@@ -56,23 +58,30 @@ class StateTrackerTransformer(nn.Module):
                 v.copy_(torch.as_tensor(sd[k]).to(v.device, v.dtype).reshape(v.shape))
 
     def engine(self, n_env=None) -> DeviceTracker:
+        """Device engine for a vector env of n_env envs (train and test collectors may differ in size); the parameters
+        and the Adam state are shared, the K/V caches are per engine."""
         n_env = n_env or self._n_env
-        if self._engine is None or self._engine.cfg.n_env != n_env:
+        if n_env not in self._engines:
             params = dict(self._views)
             params["pos_encoder.pe"] = self.pe
-            self._engine = DeviceTracker(params, self.n_users, self.n_items, n_env, self.MAX_TURN - 1, dim_model=self.dim_model,
-                                         dim_state=self.dim_state, nhead=self.nhead, d_hid=self.d_hid, nlayers=self.nlayers,
-                                         device=self.device)
-            self._engine.enable_training(self.flat)
-            self._n_env = n_env
-        return self._engine
+            eng = DeviceTracker(params, self.n_users, self.n_items, n_env, self.MAX_TURN - 1, dim_model=self.dim_model,
+                                dim_state=self.dim_state, nhead=self.nhead, d_hid=self.d_hid, nlayers=self.nlayers,
+                                device=self.device)
+            eng.enable_training(self.flat)
+            if self._train_state is None:
+                self._train_state = (eng.flat_grad, eng.grad_views, eng.g, eng.adam_m, eng.adam_v)
+            else:
+                eng.flat_grad, eng.grad_views, eng.g, eng.adam_m, eng.adam_v = self._train_state
+            self._engines[n_env] = eng
+        self._n_env = n_env
+        return self._engines[n_env]
 
     def build_state(self, obs=None, env_id=None, obs_next=None, rew=None, done=None, info=None, policy=None, dim_batch=None,
                     reset=False):
         if reset and dim_batch:
             self.engine(dim_batch).reset()
             return
-        eng = self.engine()
+        eng = self.engine(self._n_env)
         ids = None if env_id is None else torch.as_tensor(np.asarray(env_id).astype(np.int32)).to(self.device)
         if obs is not None:
             users = torch.as_tensor(np.asarray(obs).reshape(-1))

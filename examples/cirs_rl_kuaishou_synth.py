@@ -21,6 +21,8 @@ gym = gymlite.install()
 from gym.envs.registration import register  # noqa: E402
 
 from core.collector import Collector  # noqa: E402
+from core.collector_set import CollectorSet  # noqa: E402
+from core.trainer.onpolicy import onpolicy_trainer  # noqa: E402
 from core.inputs import get_dataset_columns  # noqa: E402
 from core.policy.ppo import PPOPolicy  # noqa: E402
 from core.state_tracker import StateTrackerTransformer  # noqa: E402
@@ -59,6 +61,9 @@ def get_args(argv=None):
     p.add_argument("--eps-clip", type=float, default=0.2)
     p.add_argument("--max-grad-norm", type=float, default=0.5)
     p.add_argument("--gae-lambda", type=float, default=0.95)
+    p.add_argument("--test-num", type=int, default=100)
+    p.add_argument("--force_length", type=int, default=10)
+    p.add_argument("--step-per-epoch", type=int, default=2000)
     p.add_argument("--n-users", type=int, default=1411)
     p.add_argument("--n-items", type=int, default=3327)
     return p.parse_args(argv)
@@ -115,15 +120,24 @@ def build(args):
     return tab, train_envs, state_tracker, policy, train_collector
 
 
+def build_test_collectors(args, policy, state_tracker):
+    """The FB / NX_0 / NX_k test collectors on the real (non-simulated) env (reference :213-221, :297-299)."""
+    test_envs_dict = {"FB": DummyVectorEnv([lambda: gym.make(args.env) for _ in range(args.test_num)]),
+                      "NX_0": DummyVectorEnv([lambda: gym.make(args.env) for _ in range(args.test_num)]),
+                      f"NX_{args.force_length}": DummyVectorEnv([lambda: gym.make(args.env) for _ in range(args.test_num)])}
+    return CollectorSet(policy, test_envs_dict, args.buffer_size, args.test_num, preprocess_fn=state_tracker.build_state,
+                        force_length=args.force_length)
+
+
 def main(argv=None):
     args = get_args(argv)
     tab, train_envs, state_tracker, policy, train_collector = build(args)
-    for epoch in range(1, args.epoch + 1):  # inner loop of onpolicy_trainer (core/trainer/onpolicy.py:170-209)
-        result = train_collector.collect(n_episode=args.episode_per_collect)
-        losses = policy.update(0, train_collector.buffer, batch_size=args.batch_size, repeat=args.repeat_per_collect)
-        print(f"Epoch {epoch}: n/st {result['n/st']} len {result['len']:.2f} rew {result['rew']:.3f} "
-              f"loss {np.mean(losses['loss']):.4f} vf {np.mean(losses['loss/vf']):.4f} ent {np.mean(losses['loss/ent']):.3f}", flush=True)
-    return policy, state_tracker
+    test_collector_set = build_test_collectors(args, policy, state_tracker)
+    result = onpolicy_trainer(policy, train_collector, test_collector_set, state_tracker, args.epoch, args.step_per_epoch,
+                              args.repeat_per_collect, args.test_num, args.batch_size, episode_per_collect=args.episode_per_collect,
+                              save_model_fn=lambda epoch, policy: None)
+    print(result)
+    return policy, state_tracker, result
 
 
 if __name__ == "__main__":

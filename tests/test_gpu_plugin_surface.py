@@ -76,3 +76,39 @@ def test_vector_env_protocol_and_test_envs():
     o, r, d, info = test_envs.step(np.array([5, 6, 7, 8]), np.arange(4))
     np.testing.assert_array_equal(r, tab.mat[np.arange(4), [5, 6, 7, 8]])  # reward = mat[u, a] (kuaishouEnv.py:172)
     assert "cum_reward" in info[0]
+
+
+def test_trainer_loop_with_test_collector_set():
+    """onpolicy_trainer + CollectorSet(FB, NX_0, NX_k): masking and forced length run inside the fused rollout."""
+    ex = load_example()
+    args = ex.get_args(["--n-users", "150", "--n-items", "400", "--training-num", "16", "--episode-per-collect", "16", "--test-num", "8",
+                        "--batch-size", "64", "--max_turn", "20", "--tau", "10", "--epoch", "2", "--step-per-epoch", "200",
+                        "--force_length", "10", "--leave_threshold", "0", "--num_leave_compute", "1"])
+    tab, train_envs, st, policy, coll = ex.build(args)
+    cs = ex.build_test_collectors(args, policy, st)
+    events = []
+
+    class CB:
+        def on_train_begin(self): events.append("begin")
+        def on_epoch_begin(self, epoch): events.append(("epoch", epoch))
+        def on_epoch_end(self, epoch, results): events.append(("end", epoch, sorted(results)[:3]))
+        def on_train_end(self): events.append("done")
+
+    policy.callbacks = [CB()]
+    from core.trainer.onpolicy import onpolicy_trainer
+    before = policy.flat.clone(); tbefore = st.flat.clone()
+    info = onpolicy_trainer(policy, coll, cs, st, args.epoch, args.step_per_epoch, args.repeat_per_collect, args.test_num, args.batch_size,
+                            episode_per_collect=args.episode_per_collect, save_model_fn=lambda epoch, policy: None, verbose=False)
+    assert events[0] == "begin" and events[-1] == "done" and ("epoch", 2) in events
+    assert info["train_step"] >= 2 * args.step_per_epoch and info["test_episode"] == 2 * 8
+    assert float((policy.flat - before).abs().max()) > 0 and float((st.flat - tbefore).abs().max()) > 0
+    res = cs.collect(n_episode=8)
+    assert {"n/st", "rew", "NX_0_n/st", "NX_0_rew", "NX_10_lens"} <= set(res)
+    assert (res["NX_10_lens"] == 10).all()                      # force_length
+    nx = cs.collector_dict["NX_0"].buffer
+    acts = nx._traj.act.cpu().numpy()
+    for b in range(8):                                           # remove_recommended_ids: no item twice in an episode
+        a = acts[:res["NX_0_lens"][b], b]
+        assert len(set(a.tolist())) == len(a)
+    # the training tracker state (Adam step counter) survived the differently sized test engines
+    assert st.adam_steps >= 2
