@@ -179,7 +179,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (policy/tracker, fp32 MFMA) + f64 (env rewards, GAE)", "data": "synthetic",
             "config": {"workload": wl["name"], "envs_total": wl["B"] * world,
-                       "parallelism": f"env-sharded x{world}, one all-gather of trajectories per update, replicated learner"},
+                       "parallelism": (f"env-sharded x{world}; one all-gather of trajectory records per update; data-parallel learner: "
+                                       f"global minibatch = 1024 x {world} rows sharded by rows, one flat-gradient all-reduce per minibatch")
+                       if world > 1 else "single GPU"},
             "ppo_minibatch_steps_per_s": mb_steps / elapsed,
             "rollout_only_env_steps_per_s": n_ro / (tb - ta),
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
