@@ -39,11 +39,15 @@ __host__ __device__ inline ActorPartialView partial_view(void* ws, int n, int n_
 }
 
 // ---- trunk: one wave per row ---------------------------------------------------------------------------------
+// row_index (nullable): row j reads state row row_index[j] (rows j >= n_valid read nothing and produce zeros);
+// obs_copy (nullable, [n, S]): the gathered input rows are kept for the weight-gradient GEMM of the learner.
 static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, cirs_policy_weights w,
                                                            const float* __restrict__ state, long state_stride, int n,
                                                            const uint8_t* __restrict__ skip, float* __restrict__ h2_out,
                                                            float* __restrict__ value_out,
-                                                           float* __restrict__ h1_out) {
+                                                           float* __restrict__ h1_out,
+                                                           const int32_t* __restrict__ row_index = nullptr, int n_valid = 0,
+                                                           float* __restrict__ obs_copy = nullptr) {
     __shared__ float lds[4][2][kH];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wv;
@@ -57,7 +61,16 @@ static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, 
         if (lane == 0 && value_out) value_out[j] = 0.f;
         return;
     }
-    if (lane < S) xs[lane] = state[(size_t)j * state_stride + lane];
+    if (row_index) {
+        const bool ok = j < n_valid;
+        const float x = (ok && lane < S) ? state[(size_t)row_index[j] * state_stride + lane] : 0.f;
+        if (lane < S) {
+            xs[lane] = x;
+            if (obs_copy) obs_copy[(size_t)j * S + lane] = x;
+        }
+    } else if (lane < S) {
+        xs[lane] = state[(size_t)j * state_stride + lane];
+    }
     __builtin_amdgcn_wave_barrier();
     // layer 1: lane o, chain over k = 0..S-1 starting from the bias
     float acc = w.b1[lane];

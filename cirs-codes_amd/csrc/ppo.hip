@@ -125,6 +125,8 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     float *lse, *ez, *za;                     // head stats: log-sum-exp, E_p[z], logit of the taken action
     float *c_logp, *c_ent, *h_ent, *dvalue;   // row coefficients for the backward pass
     float *ent_row;                           // entropy per row (from the backward pass)
+    float *clip_row, *vf_row;                 // per-row surrogate / value-loss terms (summed in fixed order later)
+    long *dst_row;                            // row of the [T+1,B] tracker-gradient tensor each minibatch row scatters to
     float *da2, *da1;                         // [n_pad,64] pre-activation gradients
     float *dh2p;                              // [n_chunks, n_pad, 64] partial d h2
     float *entp;                              // [n_chunks, n_pad]
@@ -143,6 +145,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 2 * (size_t)n_pad * kH + n_pad;               // h1, h2, value
     f += 3 * (size_t)n_pad;                            // lse, ez, za
     f += 4 * (size_t)n_pad + n_pad;                    // c_logp, c_ent, h_ent, dvalue, ent_row
+    f += 2 * (size_t)n_pad + 2 * (size_t)n_pad + 8;    // clip_row, vf_row, dst_row (int64)
     f += 2 * (size_t)n_pad * kH;                       // da2, da1
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)kRowSplits * ((size_t)I * kH + I);    // dwap
@@ -162,6 +165,8 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.h1 = take((size_t)n_pad * kH); v.h2 = take((size_t)n_pad * kH); v.value = take(n_pad);
     v.lse = take(n_pad); v.ez = take(n_pad); v.za = take(n_pad);
     v.c_logp = take(n_pad); v.c_ent = take(n_pad); v.h_ent = take(n_pad); v.dvalue = take(n_pad); v.ent_row = take(n_pad);
+    v.clip_row = take(n_pad); v.vf_row = take(n_pad);
+    v.dst_row = (long*)take(2 * (size_t)n_pad + 4);
     v.da2 = take((size_t)n_pad * kH); v.da1 = take((size_t)n_pad * kH);
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
     v.dwap = take((size_t)kRowSplits * ((size_t)I * kH + I));
@@ -170,22 +175,6 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dwp = take(dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64);
     v.head_ws = (void*)p;
     return v;
-}
-
-__global__ __launch_bounds__(256) void gather_kernel(cirs_ppo_batch b, const int32_t* __restrict__ idx, int mb, int n_pad,
-                                                     int S, MbView v) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;  // one thread per (row, column); columns S.. are the scalars
-    const int W = S + 5;
-    if (i >= (long)n_pad * W) return;
-    const int r = (int)(i / W), k = (int)(i % W);
-    const bool ok = r < mb;
-    const int src = ok ? idx[r] : 0;
-    if (k < S) v.obs[(size_t)r * S + k] = ok ? b.obs[(size_t)src * S + k] : 0.f;
-    else if (k == S) v.adv[r] = ok ? b.adv[src] : 0.f;
-    else if (k == S + 1) v.ret[r] = ok ? b.ret[src] : 0.f;
-    else if (k == S + 2) v.v_s[r] = ok ? b.v_s[src] : 0.f;
-    else if (k == S + 3) v.logp_old[r] = ok ? b.logp_old[src] : 0.f;
-    else v.act[r] = ok ? b.act[src] : 0;
 }
 
 // advantage statistics of the (global) minibatch: mean and unbiased std (torch.Tensor.std, ppo.py:185-186) of
@@ -225,13 +214,23 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict
     if (tid == 0) { red[0] = mean; red[1] = sqrtf(sh[0] / (float)(m - 1)); }
 }
 
-// merge the head-stats partials: lse, E_p[z] (for the entropy), z of the taken action (same k-order as the MFMA)
-__global__ __launch_bounds__(256) void head_stats_merge_kernel(int mb, int n_pad, int n_chunks, ActorPartialView pv,
-                                                               const float* __restrict__ wa, const float* __restrict__ ba,
-                                                               MbView v) {
+// One wavefront per minibatch row: merge the head-stats partials (lse, E_p[z]), recompute the taken action's logit
+// with the MFMA k-order, then (lane 0) the row's loss terms and backward coefficients (ppo.py:183-212).  Rows are read
+// from the buffer-order batch through idx (no separate gather pass); padded rows get neutral coefficients.
+__global__ __launch_bounds__(256) void head_stats_merge_kernel(cirs_ppo_cfg cfg, cirs_ppo_batch b, const int32_t* __restrict__ idx,
+                                                               int mb, int mb_norm, int n_pad, int n_chunks, int n_env,
+                                                               ActorPartialView pv, const float* __restrict__ wa,
+                                                               const float* __restrict__ ba, MbView v) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= mb) return;
+    if (j >= n_pad) return;
+    if (j >= mb) {
+        if (lane == 0) {
+            v.c_logp[j] = 0.f; v.c_ent[j] = 0.f; v.h_ent[j] = 0.f; v.dvalue[j] = 0.f; v.lse[j] = 1e30f;  // p = exp(z - lse) = 0
+            v.clip_row[j] = 0.f; v.vf_row[j] = 0.f; v.act[j] = 0; v.dst_row[j] = 0;
+        }
+        return;
+    }
     float m = -INFINITY, s = 0.f, t = 0.f;
     for (int c = lane; c < n_chunks; c += CIRS_WAVE) {
         const size_t o = (size_t)c * n_pad + j;
@@ -252,7 +251,8 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(int mb, int n_pad
         }
     }
     if (lane != 0) return;
-    const int a = v.act[j];
+    const int src = idx[j];
+    const int a = b.act[src];
     const float* wr = wa + (size_t)a * kH;
     const float* hr = v.h2 + (size_t)j * kH;
     float z = ba[a];
@@ -260,60 +260,40 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(int mb, int n_pad
         z = __builtin_fmaf(hr[kk], wr[kk], z);
         z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
     }
-    v.lse[j] = m + __logf(s);
-    v.ez[j] = t / s;
-    v.za[j] = z;
-}
-
-// per-row loss terms and backward coefficients (ppo.py:183-212); one workgroup, fixed-order loss sums
-__global__ __launch_bounds__(1024) void row_scalar_kernel(cirs_ppo_cfg cfg, int mb, int mb_norm, int n_pad, MbView v) {
-    __shared__ float sh_clip[1024], sh_vf[1024];
-    const int tid = threadIdx.x;
-    const float inv_mb = 1.0f / (float)mb_norm;  // means are over the GLOBAL minibatch
-    const float adv_mean = v.red[0], adv_std = v.red[1];
+    const float lse = m + __logf(s);
+    v.lse[j] = lse;
+    v.act[j] = a;
+    v.dst_row[j] = (long)b.row_t[src] * n_env + b.row_env[src];
+    // ---- row losses + backward coefficients; every mean is over the (global) minibatch of mb_norm rows --------------
+    const float inv_mb = 1.0f / (float)mb_norm;
     const float eps = 1.1920928955078125e-7f;
-    float a_clip = 0.f, a_vf = 0.f;
-    for (int r = tid; r < n_pad; r += 1024) {
-        if (r >= mb) {
-            v.c_logp[r] = 0.f; v.c_ent[r] = 0.f; v.h_ent[r] = 0.f; v.dvalue[r] = 0.f; v.lse[r] = 1e30f;  // p = exp(z - lse) = 0
-            continue;
-        }
-        const float praw = __expf(v.za[r] - v.lse[r]);
-        const bool clamped = praw < eps || praw > 1.0f - eps;  // probs_to_logits clamp blocks the gradient
-        const float logp = __logf(fminf(fmaxf(praw, eps), 1.0f - eps));
-        const float ratio = __expf(logp - v.logp_old[r]);
-        const float A = (v.adv[r] - adv_mean) / adv_std;  // per-minibatch advantage normalisation (ppo.py:184-186)
-        const float s1 = ratio * A;
-        const float s2 = fminf(fmaxf(ratio, 1.0f - cfg.eps_clip), 1.0f + cfg.eps_clip) * A;
-        a_clip += -fminf(s1, s2);
-        // d(-min(s1,s2))/d logp: s1 path when s1 <= s2 (a tie passes the full gradient), else clamp blocks it
-        v.c_logp[r] = (s1 <= s2 && !clamped) ? -inv_mb * A * ratio : 0.f;
-        // value loss
-        const float val = v.value[r], vs = v.v_s[r], ret = v.ret[r];
-        const float d1 = ret - val;
-        float vf = d1 * d1, dv = -2.0f * d1;
-        if (cfg.value_clip) {
-            const float dlt = val - vs;
-            const float vclip = vs + fminf(fmaxf(dlt, -cfg.eps_clip), cfg.eps_clip);
-            const float d2 = ret - vclip;
-            const float vf2 = d2 * d2;
-            const float dv2 = (dlt >= -cfg.eps_clip && dlt <= cfg.eps_clip) ? -2.0f * d2 : 0.f;
-            if (vf2 > vf) { vf = vf2; dv = dv2; }
-            else if (vf2 == vf) dv = 0.5f * (dv + dv2);  // torch.max splits ties
-        }
-        a_vf += vf;
-        v.dvalue[r] = cfg.vf_coef * inv_mb * dv;
-        // entropy gradient coefficient: dL/dz_i += c_ent * p_i * (z_i - lse + H), H = lse - E_p[z]
-        v.c_ent[r] = cfg.ent_coef * inv_mb;
-        v.h_ent[r] = v.lse[r] - v.ez[r];
+    const float praw = __expf(z - lse);
+    const bool clamped = praw < eps || praw > 1.0f - eps;  // probs_to_logits clamp blocks the gradient
+    const float logp = __logf(fminf(fmaxf(praw, eps), 1.0f - eps));
+    const float ratio = __expf(logp - b.logp_old[src]);
+    const float A = (b.adv[src] - v.red[0]) / v.red[1];    // per-minibatch advantage normalisation (ppo.py:184-186)
+    const float s1 = ratio * A;
+    const float s2 = fminf(fmaxf(ratio, 1.0f - cfg.eps_clip), 1.0f + cfg.eps_clip) * A;
+    v.clip_row[j] = -fminf(s1, s2);
+    // d(-min(s1,s2))/d logp: s1 path when s1 <= s2 (a tie passes the full gradient), else clamp blocks it
+    v.c_logp[j] = (s1 <= s2 && !clamped) ? -inv_mb * A * ratio : 0.f;
+    const float val = v.value[j], vs = b.v_s[src], ret = b.ret[src];
+    const float d1 = ret - val;
+    float vf = d1 * d1, dv = -2.0f * d1;
+    if (cfg.value_clip) {
+        const float dlt = val - vs;
+        const float vclip = vs + fminf(fmaxf(dlt, -cfg.eps_clip), cfg.eps_clip);
+        const float d2 = ret - vclip;
+        const float vf2 = d2 * d2;
+        const float dv2 = (dlt >= -cfg.eps_clip && dlt <= cfg.eps_clip) ? -2.0f * d2 : 0.f;
+        if (vf2 > vf) { vf = vf2; dv = dv2; }
+        else if (vf2 == vf) dv = 0.5f * (dv + dv2);  // torch.max splits ties
     }
-    sh_clip[tid] = a_clip; sh_vf[tid] = a_vf;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) { sh_clip[tid] += sh_clip[tid + s]; sh_vf[tid] += sh_vf[tid + s]; }
-        __syncthreads();
-    }
-    if (tid == 0) { v.red[2] = sh_clip[0] * inv_mb; v.red[3] = sh_vf[0] * inv_mb; }
+    v.vf_row[j] = vf;
+    v.dvalue[j] = cfg.vf_coef * inv_mb * dv;
+    // entropy gradient coefficient: dL/dz_i += c_ent * p_i * (z_i - lse + H), H = lse - E_p[z]
+    v.c_ent[j] = cfg.ent_coef * inv_mb;
+    v.h_ent[j] = lse - t / s;
 }
 
 __device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c_ent, float h_ent, bool is_act, float& p_out) {
@@ -588,17 +568,6 @@ __global__ __launch_bounds__(256) void finalize_dh2_kernel(int mb, int n_pad, in
     if (tid == 0) v.ent_row[r] = r < mb ? v.h_ent[r] + she[0] : 0.f;  // (lse - E_p[z]) + clamp correction
 }
 
-// d obs rows -> tracker gradient tensor [T+1, B, S] at (row_t, row_env)
-__global__ __launch_bounds__(256) void scatter_dobs_kernel(const float* __restrict__ dobs, const int32_t* __restrict__ idx,
-                                                           cirs_ppo_batch b, int mb, int S, int n_env,
-                                                           float* __restrict__ accum) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= (long)mb * S) return;
-    const int r = (int)(i / S), k = (int)(i % S);
-    const int row = idx[r];
-    accum[((size_t)b.row_t[row] * n_env + b.row_env[row]) * S + k] = dobs[i];
-}
-
 // clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1).
 // stage 1: kNormBlocks workgroups, each a contiguous slice, fixed-order tree -> partial sums of squares
 constexpr int kNormBlocks = 256;
@@ -645,24 +614,34 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
 }
 // stage 2: one workgroup: norm, clip coefficient, entropy mean, total loss
 // loss partials of this rank: {clip, vf, ent} already divided by the global minibatch size -> grads tail
-__global__ __launch_bounds__(256) void loss_partials_kernel(int mb, int mb_norm, MbView v, float* __restrict__ tail) {
-    __shared__ float sh[256];
-    const int tid = threadIdx.x;
-    float e = 0.f;
-    for (int r = tid; r < mb; r += 256) e += v.ent_row[r];
-    sh[tid] = e;
+__device__ __forceinline__ void loss_partials_block(int mb, int mb_norm, const MbView& v, float* __restrict__ tail, float* sh3) {
+    const int tid = threadIdx.x;  // blockDim.x == 256, sh3 = float[3][256]
+    float e = 0.f, c = 0.f, f = 0.f;
+    for (int r = tid; r < mb; r += 256) { e += v.ent_row[r]; c += v.clip_row[r]; f += v.vf_row[r]; }
+    sh3[tid] = c; sh3[256 + tid] = f; sh3[512 + tid] = e;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] += sh[tid + s];
+        if (tid < s) { sh3[tid] += sh3[tid + s]; sh3[256 + tid] += sh3[256 + tid + s]; sh3[512 + tid] += sh3[512 + tid + s]; }
         __syncthreads();
     }
-    if (tid == 0) { tail[0] = v.red[2]; tail[1] = v.red[3]; tail[2] = sh[0] / (float)mb_norm; tail[3] = 0.f; }
+    if (tid == 0) {
+        const float inv = 1.0f / (float)mb_norm;
+        tail[0] = sh3[0] * inv; tail[1] = sh3[256] * inv; tail[2] = sh3[512] * inv; tail[3] = 0.f;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void loss_partials_kernel(int mb, int mb_norm, MbView v, float* __restrict__ tail) {
+    __shared__ float sh3[768];
+    loss_partials_block(mb, mb_norm, v, tail, sh3);
 }
 
-__global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, const float* __restrict__ partial, const float* __restrict__ tail,
-                                                             MbView v, float* __restrict__ loss_out) {
+// mb > 0: single-rank path, the loss partials are formed here (no separate launch); mb == 0: they already are in `tail`
+__global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, const float* __restrict__ partial, float* __restrict__ tail,
+                                                             MbView v, float* __restrict__ loss_out, int mb, int mb_norm) {
     __shared__ float sh[256];
+    __shared__ float sh3[768];
     const int tid = threadIdx.x;
+    if (mb > 0) loss_partials_block(mb, mb_norm, v, tail, sh3);
     sh[tid] = tid < kNormBlocks ? partial[tid] : 0.f;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -816,14 +795,13 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
     if (phase == 0 || phase == 1) {
         CIRS_REQUIRE(idx != nullptr, "idx is null");
         const int32_t* sidx = idx_global ? idx_global : idx;
-        // 1. gather + advantage statistics of the (global) minibatch
-        hipLaunchKernelGGL(gather_kernel, dim3(cdiv((long)n_pad * (S + 5), 256)), dim3(256), 0, s, *batch, idx, mb, n_pad, S, v);
-        CIRS_CHECK_LAUNCH("gather_kernel");
+        // 1. advantage statistics of the (global) minibatch
         hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, s, batch->adv, sidx, idx_global ? mb_global : mb, cfg->norm_adv, v.red);
         CIRS_CHECK_LAUNCH("adv_stats_kernel");
         // 2. trunk forward (same fma chains as the rollout -> ratio == 1 exactly while the weights are unchanged)
-        hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, pcfg, w, v.obs, (long)S, n_pad, (const uint8_t*)nullptr,
-                           v.h2, v.value, v.h1);
+        //    rows are gathered from the buffer-order batch through idx inside the kernel (v.obs keeps the copy for d W1)
+        hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
+                           (const uint8_t*)nullptr, v.h2, v.value, v.h1, idx, (int)mb, v.obs);
         CIRS_CHECK_LAUNCH("trunk_kernel");
         // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
@@ -831,11 +809,10 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
                            v.h2, mb, (const float*)nullptr, (uint64_t)0, 0u, (const int32_t*)nullptr, (const uint32_t*)nullptr,
                            (const uint8_t*)nullptr, pv, n_pad);
         CIRS_CHECK_LAUNCH("actor_head_kernel<stats>");
-        hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(mb, 4)), dim3(256), 0, s, mb, n_pad, n_chunks, pv, w.wa, w.ba, v);
+        // 4. merge + row losses + backward coefficients (means over the global minibatch)
+        hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
+                           (int)(idx_global ? mb_global : mb), n_pad, n_chunks, (int)n_env, pv, w.wa, w.ba, v);
         CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
-        // 4. row losses + backward coefficients (means over the global minibatch)
-        hipLaunchKernelGGL(row_scalar_kernel, dim3(1), dim3(1024), 0, s, *cfg, mb, idx_global ? mb_global : mb, n_pad, v);
-        CIRS_CHECK_LAUNCH("row_scalar_kernel");
         // 5. head backward
         const int n_item_tiles = cdiv(I, kTileN);
         hipLaunchKernelGGL(head_bwd_dwa_kernel, dim3(cdiv(n_item_tiles, 4), kRowSplits), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v, v.dwap);
@@ -856,16 +833,13 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
             launch_dw_multi(jobs, mb, v.dwp, s);
             CIRS_CHECK_LAUNCH("dw(critic, w2, w1)");
         }
-        if (dobs_accum) {
-            float* dobs = v.dh2p;  // reuse: partial slabs are consumed
-            launch_rows_gemm(false, v.da1, kH, w.w1, S, nullptr, mb, kH, S, 0, nullptr, 0, dobs, S, s);
+        if (dobs_accum) {  // d obs = d a1 * W1, written straight to the tracker-gradient tensor at (row_t, row_env)
+            launch_rows_gemm(false, v.da1, kH, w.w1, S, nullptr, mb, kH, S, 0, nullptr, 0, dobs_accum, S, s, v.dst_row);
             CIRS_CHECK_LAUNCH("dx(obs)");
-            hipLaunchKernelGGL(scatter_dobs_kernel, dim3(cdiv((long)mb * S, 256)), dim3(256), 0, s, dobs, idx, *batch, mb, S, n_env, dobs_accum);
-            CIRS_CHECK_LAUNCH("scatter_dobs_kernel");
         }
-        hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, mb, idx_global ? mb_global : mb, v, tail);
-        CIRS_CHECK_LAUNCH("loss_partials_kernel");
-        if (phase == 1) {  // gradients must be complete in `grads` before the caller's all-reduce
+        if (phase == 1) {  // gradients + loss partials must be complete in `grads` before the caller's all-reduce
+            hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, mb, mb_global, v, tail);
+            CIRS_CHECK_LAUNCH("loss_partials_kernel");
             hipLaunchKernelGGL(reduce_dwa_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, s, v.dwap, seg, grads + L.wa);
             CIRS_CHECK_LAUNCH("reduce_dwa_kernel");
             return CIRS_OK;
@@ -874,7 +848,8 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
     // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps; heads: once)
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg,
                        phase == 0 ? v.dwap : (const float*)nullptr, v.normp);
-    hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, s, *cfg, v.normp, tail, v, loss_out);
+    hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, s, *cfg, v.normp, tail, v, loss_out, phase == 0 ? (int)mb : 0,
+                       (int)(idx_global ? mb_global : mb));
     CIRS_CHECK_LAUNCH("gradnorm");
     auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
         AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};

@@ -19,7 +19,8 @@ template <bool kNT>
 static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
                                                               const float* __restrict__ bias, int R, int Kd, int N, int relu,
                                                               const float* __restrict__ relu_of, int accumulate,
-                                                              float* __restrict__ Y, int ldy) {
+                                                              float* __restrict__ Y, int ldy,
+                                                              const long* __restrict__ out_row = nullptr) {
     const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
     const int row0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int row = row0 + lo, n = n0 + lo;
@@ -47,7 +48,7 @@ static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __res
     for (int s = 0; s < 16; ++s) {
         const int r = row0 + (s & 3) + 8 * (s >> 2) + 4 * hi;
         if (r >= R) continue;
-        const size_t o = (size_t)r * ldy + n;
+        const size_t o = (size_t)(out_row ? out_row[r] : (long)r) * ldy + n;  // optional scatter of output rows
         float v = acc[s];
         if (relu) v = fmaxf(v, 0.f);
         if (relu_of && !(relu_of[o] > 0.f)) v = 0.f;
@@ -56,10 +57,11 @@ static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __res
 }
 
 static inline void launch_rows_gemm(bool nt, const float* X, int ldx, const float* W, int ldw, const float* bias, int R, int Kd, int N,
-                                    int relu, const float* relu_of, int accumulate, float* Y, int ldy, hipStream_t s) {
+                                    int relu, const float* relu_of, int accumulate, float* Y, int ldy, hipStream_t s,
+                                    const long* out_row = nullptr) {
     const dim3 grid(cdiv(R, 32), cdiv(N, 32));
-    if (nt) hipLaunchKernelGGL(rows_gemm_kernel<true>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy);
-    else hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy);
+    if (nt) hipLaunchKernelGGL(rows_gemm_kernel<true>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy, out_row);
+    else hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy, out_row);
 }
 
 constexpr int kDwMaxSlabs = 32;
