@@ -379,22 +379,25 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dwa_kernel(int I, int mb, int
             for (int r = 0; r < 16; ++r) acc[r] = bias;
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[kk], wrow[kk], acc, 0, 0, 0);
-            // dZ for row pair r, immediately consumed as the A operand of the dWa^T MFMAs: the VALU work of element
-            // r+1 issues while the matrix pipe executes the MFMAs of element r (rows beyond mb: c = 0, lse = 1e30 -> 0)
-            __builtin_amdgcn_s_setprio(1);
+            // dZ in place (rows beyond mb have c = 0 and lse = 1e30 -> dZ = 0)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const float4 rs = sR[buf][rl];
                 float p;
                 const float d = item_ok ? dz_of(acc[r], rs.x, rs.y, rs.z, rs.w, sA[buf][rl] == item, p) : 0.f;
+                acc[r] = d;
                 db += d;
+            }
+            // dWa^T += dZ^T * H2 : step r pairs rows row(r,0), row(r,1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const float b0 = th[rl * kLdsStride + lo];
                 const float b1 = th[rl * kLdsStride + 32 + lo];
-                dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d, b0, dw0, 0, 0, 0);
-                dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d, b1, dw1, 0, 0, 0);
+                dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dw0, 0, 0, 0);
+                dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dw1, 0, 0, 0);
             }
-            __builtin_amdgcn_s_setprio(0);
         }
         if (rt + 1 < rt_end) CIRS_COMMIT(buf ^ 1);
         __syncthreads();
@@ -497,11 +500,9 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
             for (int r = 0; r < 16; ++r) acc[r] = sB[buf][(r & 3) + 8 * (r >> 2) + 4 * hi];
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {  // dZ element r feeds its two MFMAs at once; element r+1's VALU overlaps them
-                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;  // item within the tile (rows beyond I hold zeros)
-                const int item = tile0 + il;
+            for (int r = 0; r < 16; ++r) {
+                const int item = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float d = 0.f;
                 if (item < I && row_ok) {
                     float p;
@@ -511,12 +512,16 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
                     if (p < eps) ent -= p * (kLogEps - (acc[r] - lse));
                     else if (p > 1.0f - eps) ent -= p * (kLog1mEps - (acc[r] - lse));
                 }
+                acc[r] = d;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;  // item within the tile (rows beyond I hold zeros)
                 const float b0 = tw[il * kLdsStride + lo];
                 const float b1 = tw[il * kLdsStride + 32 + lo];
-                dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d, b0, dh0, 0, 0, 0);
-                dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d, b1, dh1, 0, 0, 0);
+                dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dh0, 0, 0, 0);
+                dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dh1, 0, 0, 0);
             }
-            __builtin_amdgcn_s_setprio(0);
         }
         if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);  // the other buffer was last read in iteration it-1 (barrier below)
         __syncthreads();
