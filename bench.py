@@ -31,6 +31,9 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
+# measured on MI355X, see profiles/r01_pmc_head_kernels.md: (2*FETCH_SIZE + WRITE_SIZE) KB summed over
+# actor_head_kernel<stats>, head_bwd_dwa_kernel, head_bwd_dh2_kernel of one 1024-row minibatch at I = 10728
+PMC_TRAFFIC_BYTES_PER_MINIBATCH = int((2 * (3885.8 + 3914.0 + 3952.2) + (1030.2 + 21791.3 + 22321.3)) * 1024)
 
 
 def build_engine(wl, rank, world, device):
@@ -74,6 +77,37 @@ def hip_event_kernel_time(eng, wl, reps=20):
     for t, s in zip((ln.params, ln.adam_m, ln.adam_v), snap):
         t.copy_(s)
     return start.elapsed_time(stop) / reps * 1e-3, mb  # seconds per minibatch step
+
+
+def deepfm_sweep_probe(wl, device, E=16, reps=5):
+    """Secondary metric M3: the full-catalogue DeepFM sweep (compute_normed_reward) at the workload's
+    U x I, synthetic weights of the shipped model's shape.  Times cirs_deepfm_sweep with HIP events on the launch stream."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import deepfmcase
+    from cirs_hip.deepfm import DeviceDeepFM
+    U, I = wl["U"], wl["I"]
+    rng = np.random.RandomState(0)
+    m = DeviceDeepFM(deepfmcase.random_weights(rng, U, I + 1, E), device=device)
+    feats = rng.randint(0, 32, (I, 4)); dur = rng.uniform(2, 60, I).astype(np.float32)
+    users, items = np.arange(U), np.arange(I)
+    m.sweep(users, items, feats, dur, want_pred=True)  # warm-up
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        m.sweep(users, items, feats, dur, want_pred=True)
+    stop.record()
+    torch.cuda.synchronize()
+    t = start.elapsed_time(stop) / reps * 1e-3
+    pairs = float(U) * I
+    executed = 2.0 * (64 * 64 + 64 + E) * pairs          # factored algorithm actually run (DESIGN.md §4)
+    algorithmic = (2.0 * ((6 * E + 1) * 64 + 64 * 64 + 64) + 18 * E) * pairs   # SURVEY §8(d) F_sweep (unfactored reference algorithm)
+    return {"pairs_per_s": pairs / t, "seconds_per_sweep": t, "emb_dim": E, "users": U, "items": I,
+            "roofline": {"bound": "mfma", "achieved": algorithmic / t / 1e12, "achieved_executed": executed / t / 1e12,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": algorithmic / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "frac_executed": executed / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "note": "achieved uses SURVEY's algorithmic F_sweep (unfactored first layer); achieved_executed counts the flops the factored kernel runs"},
+            "cpu_reference_pairs_per_s": 1.78e6}
 
 
 def cpu_baseline(wl, budget_envs=1024, threads=None):
@@ -189,6 +223,11 @@ def main():
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": None, "seconds_per_launch": t_mb, "rows": mb},
         }
+        # HBM traffic of the three MFMA head kernels of one minibatch step from the committed PMC passes
+        # (profiles/r01_pmc_head_kernels.md: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as reported)
+        out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_PER_MINIBATCH if args.workload == "c3" else None
+        out["roofline"]["traffic_source"] = "profiles/r01_pmc_head_kernels.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
+        out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
