@@ -97,6 +97,10 @@ class CirsEngine:
         self.learner = DeviceLearner(self.policy_flat, I, self.B_total, max_turn, dim_state=dim_state, hidden=hidden, gamma=gamma,
                                      gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
                                      max_grad_norm=max_grad_norm, lr=lr, norm_adv=norm_adv, value_clip=value_clip, rew_norm=rew_norm)
+        # size every lazily grown buffer for the worst case now (B*T rows, merged last minibatch < 2*batch_size):
+        # no allocation (= implicit device sync) ever happens inside the collect/update loop
+        self.learner.reserve(self.B_total * max_turn, 2 * 1024)
+        self.tracker.reserve_backward((self.B_total if world_size == 1 or learner_mode == "replicated" else n_env) * max_turn)
         self.seed = seed
         self.collect_count = 0
         self.users = None

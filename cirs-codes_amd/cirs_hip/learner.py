@@ -86,6 +86,12 @@ class DeviceLearner:
                                   ret=self.b_ret.data_ptr(), v_s=self.b_vs.data_ptr(), logp_old=self.b_logp.data_ptr(),
                                   row_env=self.b_env.data_ptr(), row_t=self.b_t.data_ptr())
 
+    def reserve(self, max_rows, max_minibatch):
+        """Allocate the buffer-order batch and the minibatch workspace for their maximum sizes up front."""
+        self._alloc_batch(max_rows)
+        self.workspace(max_minibatch)
+        self._idx_dev = torch.empty(max_rows, dtype=torch.int32, device=self.device)
+
     def prepare(self, traj, lens_host: np.ndarray):
         """process_fn: GAE + return normalisation + compaction into buffer order.  lens_host: episode lengths [B]."""
         lens_host = np.asarray(lens_host, dtype=np.int32)

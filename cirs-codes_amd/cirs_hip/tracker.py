@@ -139,6 +139,11 @@ class DeviceTracker:
             dstate.data_ptr(), C.byref(self.g), self._bws.data_ptr(), self._bws.numel(), self._stream()),
             "cirs_tracker_backward")
 
+    def reserve_backward(self, max_rows):
+        need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(self.cfg), max_rows)
+        if self._bws is None or self._bws.numel() < need:
+            self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+
     def adam_update(self):
         """optim_state.step(): one torch.optim.Adam step over every tracker tensor (ppo.py:235)."""
         abi.check(self._lib.cirs_adam_step(self.flat.data_ptr(), self.flat_grad.data_ptr(), self.adam_m.data_ptr(),
