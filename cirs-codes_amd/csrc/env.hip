@@ -173,9 +173,9 @@ extern "C" int cirs_env_reset(const cirs_env_cfg* cfg, cirs_env_state* st, const
                               const int32_t* env_ids, int32_t n, int64_t* obs_out, void* stream) {
     using namespace cirs;
     if (int rc = validate_cfg(cfg)) return rc;
+    if (n <= 0) return CIRS_OK;
     CIRS_REQUIRE(st && st->user && st->turn && st->done && st->hist_action && st->cum_reward, "env state has null field");
     CIRS_REQUIRE(users != nullptr, "users is null");
-    if (n <= 0) return CIRS_OK;
     const long total = (long)n * cfg->max_turn;
     const int grid = cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048;
     hipLaunchKernelGGL(env_reset_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *cfg, *st, users, env_ids, n,
@@ -189,6 +189,7 @@ extern "C" int cirs_env_step(const cirs_env_cfg* cfg, const cirs_env_tables* tab
                              double* rew_out, uint8_t* done_out, double* ctr_out, double* expo_out, void* stream) {
     using namespace cirs;
     if (int rc = validate_cfg(cfg)) return rc;
+    if (n <= 0) return CIRS_OK;  // empty batch: nothing to do (pointers may legitimately be null)
     CIRS_REQUIRE(tab && tab->item_cats, "tables: item_cats is null");
     CIRS_REQUIRE(tab->mat || cfg->simulated, "tables: mat is null");
     CIRS_REQUIRE(!cfg->simulated || tab->normed_mat, "tables: normed_mat is null (simulated env)");

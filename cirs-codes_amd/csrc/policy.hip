@@ -110,6 +110,7 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
                                  void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace cirs;
     if (int rc = validate_policy(cfg, w)) return rc;
+    if (n <= 0) return CIRS_OK;
     CIRS_REQUIRE(state && act_out && workspace, "null state/act/workspace");
     CIRS_REQUIRE(state_stride >= cfg->dim_state, "state_stride < dim_state");
     if (n <= 0) return CIRS_OK;

@@ -255,6 +255,7 @@ extern "C" int cirs_tracker_init(const cirs_tracker_cfg* cfg, const cirs_tracker
                                  int64_t state_stride, void* stream) {
     using namespace cirs;
     if (int rc = validate_tracker(cfg, w, st)) return rc;
+    if (n <= 0) return CIRS_OK;
     CIRS_REQUIRE(users && state_out, "users/state_out null");
     CIRS_REQUIRE(state_stride >= cfg->dim_state, "state_stride < dim_state");
     if (n <= 0) return CIRS_OK;
@@ -266,6 +267,7 @@ extern "C" int cirs_tracker_step(const cirs_tracker_cfg* cfg, const cirs_tracker
                                  int32_t n, float* state_out, int64_t state_stride, void* stream) {
     using namespace cirs;
     if (int rc = validate_tracker(cfg, w, st)) return rc;
+    if (n <= 0) return CIRS_OK;
     CIRS_REQUIRE(items && rew && state_out, "items/rew/state_out null");
     CIRS_REQUIRE(state_stride >= cfg->dim_state, "state_stride < dim_state");
     if (n <= 0) return CIRS_OK;

@@ -1,4 +1,5 @@
 """CPU: libcirs_hip.so loads without a GPU and exports exactly the entry points include/cirs_hip.h declares."""
+import ctypes as C
 import os
 import re
 
@@ -30,6 +31,11 @@ def test_version_and_error_plumbing():
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.cirs_env_step(None, None, None, None, None, 0, None, None, None, None, None, None)
     assert rc == -1 and b"cfg" in lib.cirs_last_error()
+    cfg = abi.EnvCfg(n_users=3, n_items=4, max_turn=5, num_leave_compute=1, leave_threshold=0, version=3, dist_mode=0, simulated=1)
+    assert lib.cirs_env_step(C.byref(cfg), None, None, None, None, 1, None, None, None, None, None, None) == -1
+    assert b"version" in lib.cirs_last_error()
+    cfg.version = 1
+    assert lib.cirs_env_step(C.byref(cfg), None, None, None, None, 0, None, None, None, None, None, None) == 0  # empty batch
 
 
 def test_struct_sizes_match_header_layout():

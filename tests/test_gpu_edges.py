@@ -26,7 +26,9 @@ def test_empty_batches_are_noops():
     o, r, d, c, _ = env.step(torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int32))
     assert o.numel() == 0 and torch.equal(env.turn, turn0)
     lib = abi.lib()
-    assert lib.cirs_env_step(C.byref(env.cfg), C.byref(env._tab), C.byref(env._st), None, None, 0, None, None, None, None, None, None) in (0, -1)
+    assert lib.cirs_env_step(C.byref(env.cfg), C.byref(env._tab), C.byref(env._st), None, None, 0, None, None, None, None, None, None) == 0
+    # a real null pointer with n > 0 is rejected on the host before any launch
+    assert lib.cirs_env_step(C.byref(env.cfg), C.byref(env._tab), C.byref(env._st), None, None, 2, None, None, None, None, None, None) == -1
 
 
 def test_finished_env_is_inert_and_out_of_range_action_is_rejected():
