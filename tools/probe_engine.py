@@ -1,6 +1,6 @@
 """Scratch probe: full step (collect + update) timing split at C2/C3 shapes."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd"))
 import numpy as np, torch
 from cirs_hip.synthetic import make_tables

@@ -1,6 +1,6 @@
 """Scratch probe (not the contract bench): rollout-only timing at C2/C3 shapes."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
 import rolloutcase
