@@ -27,7 +27,8 @@ class EnvCfg(C.Structure):
 
 class EnvTables(C.Structure):
     _fields_ = [("mat", C.c_void_p), ("normed_mat", C.c_void_p), ("dist", C.c_void_p),
-                ("item_cats", C.c_void_p), ("alpha_env", C.c_void_p), ("beta_env", C.c_void_p)]
+                ("item_cats", C.c_void_p), ("alpha_env", C.c_void_p), ("beta_env", C.c_void_p),
+                ("pred_online", C.c_void_p), ("pred_minmax", C.c_void_p)]
 
 
 class EnvState(C.Structure):
@@ -91,6 +92,12 @@ class DeepFMWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in DEEPFM_FIELDS]
 
 
+class OnlineReward(C.Structure):
+    _fields_ = [("cfg", C.POINTER(DeepFMCfg)), ("w", C.POINTER(DeepFMWeights))] + [
+        (k, C.c_void_p) for k in ("raw_uid", "raw_pid", "item_feats", "item_dur", "pred_minmax", "uid_buf", "pid_buf",
+                                  "feat_buf", "dur_buf", "pred_buf")]
+
+
 class Traj(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "act", "rew", "done", "logp", "value", "ctr")]
 
@@ -115,6 +122,11 @@ SIGNATURES = {
                                      C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
                                      C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
                                      C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, _P, C.c_int32, _P, C.c_int64, _P]),
+    "cirs_rollout_steps_online": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState),
+                                            C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
+                                            C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, _P, C.c_int32,
+                                            C.POINTER(OnlineReward), _P, C.c_int64, _P]),
     "cirs_ppo_param_count": (C.c_int64, [C.POINTER(PpoCfg)]),
     "cirs_ppo_workspace_bytes": (C.c_int64, [C.POINTER(PpoCfg), C.c_int32]),
     "cirs_ppo_prepare": (C.c_int, [C.POINTER(PpoCfg), C.POINTER(Traj), _P, _P, C.c_int32, C.c_int32, C.c_int32, _P,

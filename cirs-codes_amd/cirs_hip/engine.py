@@ -67,7 +67,8 @@ class CirsEngine:
                  tau=100.0, gamma_exposure=10.0, version="v1", r_decay=1.0, dim_model=32, dim_state=20, nhead=4,
                  hidden=64, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
                  lr=1e-3, rew_norm=True, value_clip=True, norm_adv=True, seed=2023, tracker_params=None,
-                 policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False, learner_mode="dp"):
+                 policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False, learner_mode="dp",
+                 online_reward=None, batch_size_hint=1024):
         self.device = tables.device
         self.tables = tables
         self.n_env, self.max_turn, self.S, self.D = n_env, max_turn, dim_state, dim_model
@@ -92,14 +93,14 @@ class CirsEngine:
         self.policy_views = pviews
         self.tracker_views = tviews
         self.policy = DevicePolicy(pviews, I, dim_state=dim_state, hidden=hidden, device=self.device)
-        self.rollout = DeviceRollout(self.env, self.tracker, self.policy)
+        self.rollout = DeviceRollout(self.env, self.tracker, self.policy, online=online_reward)
         self.B_total = n_env * world_size
         self.learner = DeviceLearner(self.policy_flat, I, self.B_total, max_turn, dim_state=dim_state, hidden=hidden, gamma=gamma,
                                      gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
                                      max_grad_norm=max_grad_norm, lr=lr, norm_adv=norm_adv, value_clip=value_clip, rew_norm=rew_norm)
         # size every lazily grown buffer for the worst case now (B*T rows, merged last minibatch < 2*batch_size):
         # no allocation (= implicit device sync) ever happens inside the collect/update loop
-        self.learner.reserve(self.B_total * max_turn, 2 * 1024)
+        self.learner.reserve(self.B_total * max_turn, 2 * batch_size_hint)
         self.tracker.reserve_backward((self.B_total if world_size == 1 or learner_mode == "replicated" else n_env) * max_turn)
         self.seed = seed
         self.collect_count = 0

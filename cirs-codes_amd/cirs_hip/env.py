@@ -23,10 +23,17 @@ class DeviceEnvTables:
     """Read-only tables in HBM (layout: include/cirs_hip.h cirs_env_tables)."""
 
     def __init__(self, mat, normed_mat, item_cats, *, dist=None, alpha_env=None, beta_env=None, device="cuda",
-                 build_dist_on_device=False, stream=None):
+                 build_dist_on_device=False, stream=None, n_users=None, n_items=None):
+        """mat may be None for a simulated env whose catalogue is too large for a U x I table (then pass n_users /
+        n_items and leave normed_mat None: the rollout scores rewards online, cirs_online_reward)."""
         self.device = torch.device(device)
-        self.n_users, self.n_items = mat.shape
-        self.mat = _dev(mat, torch.float64, self.device)
+        if mat is None:
+            assert n_users is not None and n_items is not None
+            self.n_users, self.n_items = int(n_users), int(n_items)
+            self.mat = None
+        else:
+            self.n_users, self.n_items = mat.shape
+            self.mat = _dev(mat, torch.float64, self.device)
         self.normed_mat = None if normed_mat is None else _dev(normed_mat, torch.float64, self.device)
         packed = item_cats if np.asarray(item_cats).ndim == 1 else pack_item_cats(item_cats)
         self.item_cats = torch.as_tensor(np.ascontiguousarray(packed).view(np.int32)).to(self.device)
@@ -42,7 +49,7 @@ class DeviceEnvTables:
         self.beta_env = _dev(beta_env if self.has_ab else np.ones(self.n_items), torch.float64, self.device)
 
     def struct(self):
-        return abi.EnvTables(mat=self.mat.data_ptr(),
+        return abi.EnvTables(mat=None if self.mat is None else self.mat.data_ptr(),
                              normed_mat=None if self.normed_mat is None else self.normed_mat.data_ptr(),
                              dist=None if self.dist is None else self.dist.data_ptr(),
                              item_cats=self.item_cats.data_ptr(), alpha_env=self.alpha_env.data_ptr(),

@@ -35,15 +35,49 @@ class Trajectory:
         self.done.zero_()
 
 
+class OnlineReward:
+    """Scores the chosen (user, item) pairs with the DeepFM user model inside the rollout loop instead of reading a
+    precomputed U x I table (reference simulated_env.py:88-98 keeps this variant commented out; BASELINE configs[4]
+    needs it: a 10^6 x 10^6 float64 table does not exist).
+
+    user_model: cirs_hip.deepfm.DeviceDeepFM; raw_uid [U] / raw_pid [I] int64 (lbe_*.classes_); item_feats [I,4] int32
+    (ids shifted by +1, 0 = padding); item_dur [I] float32; minmax: (min, max) of the raw scores used by
+    compute_normed_reward (kuaishouEnv.py:139-143)."""
+
+    def __init__(self, user_model, raw_uid, raw_pid, item_feats, item_dur, minmax, n_env, device="cuda"):
+        dev = torch.device(device)
+        self.user_model = user_model
+        self.raw_uid = torch.as_tensor(raw_uid, dtype=torch.int64).to(dev).contiguous()
+        self.raw_pid = torch.as_tensor(raw_pid, dtype=torch.int64).to(dev).contiguous()
+        self.item_feats = torch.as_tensor(item_feats, dtype=torch.int32).to(dev).contiguous()
+        self.item_dur = torch.as_tensor(item_dur, dtype=torch.float32).to(dev).contiguous()
+        assert self.item_feats.shape == (self.raw_pid.numel(), 4)
+        self.minmax = torch.as_tensor(minmax, dtype=torch.float32).to(dev).contiguous()
+        B = int(n_env)
+        self.uid_buf = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.pid_buf = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.feat_buf = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+        self.dur_buf = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.pred_buf = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.struct = abi.OnlineReward(
+            cfg=C.pointer(user_model.cfg), w=C.pointer(user_model.w), raw_uid=self.raw_uid.data_ptr(),
+            raw_pid=self.raw_pid.data_ptr(), item_feats=self.item_feats.data_ptr(), item_dur=self.item_dur.data_ptr(),
+            pred_minmax=self.minmax.data_ptr(), uid_buf=self.uid_buf.data_ptr(), pid_buf=self.pid_buf.data_ptr(),
+            feat_buf=self.feat_buf.data_ptr(), dur_buf=self.dur_buf.data_ptr(), pred_buf=self.pred_buf.data_ptr())
+
+
 class DeviceRollout:
     def __init__(self, env: DeviceEnv, tracker: DeviceTracker, policy: DevicePolicy, *, remove_recommended_ids=False,
-                 force_length=0):
+                 force_length=0, online: Optional[OnlineReward] = None):
         assert env.n_env == tracker.cfg.n_env
         self.env, self.tracker, self.policy = env, tracker, policy
         self.device = env.device
         self.traj = Trajectory(env.n_env, env.max_turn, tracker.dim_state, self.device)
         self.remove_recommended_ids = remove_recommended_ids
         self.force_length = int(force_length)
+        self.online = online
+        if online is None and env.cfg.simulated:
+            assert env.tables.normed_mat is not None, "simulated env needs normed_mat or an OnlineReward scorer"
         words = (policy.n_items + 31) // 32
         self.visited = torch.zeros((env.n_env, words), dtype=torch.int32, device=self.device) if remove_recommended_ids else None
         self._lib = abi.lib()
@@ -63,6 +97,14 @@ class DeviceRollout:
 
     def run_steps(self, t_begin, t_end, seed, rng_base):
         ws = self.policy.workspace(self.env.n_env)
+        if self.online is not None:
+            abi.check(self._lib.cirs_rollout_steps_online(
+                C.byref(self.env.cfg), C.byref(self.env._tab), C.byref(self.env._st), C.byref(self.tracker.cfg),
+                C.byref(self.tracker.w), C.byref(self.tracker.st), C.byref(self.policy.cfg), C.byref(self.policy.w),
+                C.byref(self.traj.struct), self.env.n_env, t_begin, t_end, seed, rng_base, abi.ptr(self.visited),
+                self.force_length, C.byref(self.online.struct), ws.data_ptr(), ws.numel(), self._stream()),
+                "cirs_rollout_steps_online")
+            return
         abi.check(self._lib.cirs_rollout_steps(
             C.byref(self.env.cfg), C.byref(self.env._tab), C.byref(self.env._st), C.byref(self.tracker.cfg),
             C.byref(self.tracker.w), C.byref(self.tracker.st), C.byref(self.policy.cfg), C.byref(self.policy.w),

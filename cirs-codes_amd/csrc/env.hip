@@ -107,7 +107,13 @@ __global__ __launch_bounds__(256) void env_step_kernel(cirs_env_cfg cfg, cirs_en
             if (cfg.has_ab) e_new = exposure_effect * tab.alpha_env[u] * tab.beta_env[action];
             exposure_gamma = e_new * cfg.gamma_exposure;
         }
-        const double pred = tab.normed_mat[(size_t)u * I + action];
+        double pred;
+        if (tab.pred_online) {  // online DeepFM score of this row's (user, action), min-max normalised in float64
+            const double lo = (double)tab.pred_minmax[0], hi2 = (double)tab.pred_minmax[1];
+            pred = ((double)tab.pred_online[j] - lo) / (hi2 - lo);
+        } else {
+            pred = tab.normed_mat[(size_t)u * I + action];
+        }
         reward = cfg.version == 1 ? pred / (1.0 + exposure_gamma) : pred - exposure_gamma;
         // num_actions[action] - 1 == occurrences before this step (this step's own append is guarded by t < T)
         const int num_repeat = (t < T) ? repeat : repeat - 1;
@@ -192,7 +198,7 @@ extern "C" int cirs_env_step(const cirs_env_cfg* cfg, const cirs_env_tables* tab
     if (n <= 0) return CIRS_OK;  // empty batch: nothing to do (pointers may legitimately be null)
     CIRS_REQUIRE(tab && tab->item_cats, "tables: item_cats is null");
     CIRS_REQUIRE(tab->mat || cfg->simulated, "tables: mat is null");
-    CIRS_REQUIRE(!cfg->simulated || tab->normed_mat, "tables: normed_mat is null (simulated env)");
+    CIRS_REQUIRE(!cfg->simulated || tab->normed_mat || (tab->pred_online && tab->pred_minmax), "tables: neither normed_mat nor online scores given");
     CIRS_REQUIRE(cfg->dist_mode == 1 || tab->dist || !(cfg->simulated && cfg->use_exposure),
                  "tables: dist is null in table mode");
     CIRS_REQUIRE(!(cfg->simulated && cfg->has_ab) || (tab->alpha_env && tab->beta_env), "tables: alpha/beta null");

@@ -26,6 +26,19 @@ __global__ __launch_bounds__(256) void force_done_kernel(uint8_t* __restrict__ s
     done_row[j] = (uint8_t)force_done;
 }
 
+// rows -> (raw uid, raw pid, feats, duration) of the chosen pair; finished rows (act < 0) score item 0 and are ignored
+__global__ __launch_bounds__(256) void online_pairs_kernel(const int32_t* __restrict__ env_user, const int64_t* __restrict__ act, int n,
+                                                           cirs_online_reward o) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long a = act[j] < 0 ? 0 : act[j];
+    o.uid_buf[j] = o.raw_uid[env_user[j]];
+    o.pid_buf[j] = o.raw_pid[a];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o.feat_buf[(size_t)j * 4 + q] = o.item_feats[(size_t)a * 4 + q];
+    o.dur_buf[j] = o.item_dur[a];
+}
+
 }  // namespace cirs
 
 extern "C" int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
@@ -34,7 +47,28 @@ extern "C" int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_ta
                                   const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
                                   int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited,
                                   int32_t force_length, void* workspace, int64_t workspace_bytes, void* stream) {
+    return cirs_rollout_steps_online(env_cfg, env_tab, env_st, trk_cfg, trk_w, trk_st, pol_cfg, pol_w, traj, n_env, t_begin, t_end,
+                                     seed, rng_base, visited, force_length, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                                  const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w,
+                                  cirs_tracker_state* trk_st, const cirs_policy_cfg* pol_cfg,
+                                  const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
+                                  int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited,
+                                  int32_t force_length, const cirs_online_reward* online, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
     using namespace cirs;
+    cirs_env_tables tab_local;
+    if (online) {
+        CIRS_REQUIRE(env_tab && online->cfg && online->w && online->raw_uid && online->raw_pid && online->item_feats && online->item_dur &&
+                     online->pred_minmax && online->uid_buf && online->pid_buf && online->feat_buf && online->dur_buf && online->pred_buf,
+                     "online reward: null field");
+        tab_local = *env_tab;
+        tab_local.pred_online = online->pred_buf;
+        tab_local.pred_minmax = online->pred_minmax;
+        env_tab = &tab_local;
+    }
     CIRS_REQUIRE(env_cfg && env_tab && env_st && trk_cfg && trk_w && trk_st && pol_cfg && pol_w && traj, "null argument");
     CIRS_REQUIRE(traj->obs && traj->act && traj->rew && traj->done && traj->logp && traj->value && traj->ctr, "trajectory pointer null");
     CIRS_REQUIRE(n_env > 0 && t_begin >= 0 && t_end <= env_cfg->max_turn && t_begin <= t_end, "bad step range");
@@ -58,6 +92,13 @@ extern "C" int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_ta
             hipLaunchKernelGGL(mark_visited_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, act_t, n_env,
                                pol_cfg->n_items, visited);
             CIRS_CHECK_LAUNCH("mark_visited_kernel");
+        }
+        if (online) {  // score the chosen (user, item) pairs with the DeepFM user model
+            hipLaunchKernelGGL(online_pairs_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, env_st->user, act_t, n_env, *online);
+            CIRS_CHECK_LAUNCH("online_pairs_kernel");
+            if (int rc = cirs_deepfm_forward(online->cfg, online->w, online->uid_buf, online->pid_buf, online->feat_buf, online->dur_buf,
+                                             n_env, online->pred_buf, stream))
+                return rc;
         }
         // env.step: obs_next id == action, so the int64 obs row doubles as scratch we do not keep
         if (int rc = cirs_env_step(env_cfg, env_tab, env_st, act_t, nullptr, n_env, (int64_t*)workspace, rew_t, done_t,

@@ -64,6 +64,12 @@ typedef struct cirs_env_tables { /* read-only, shared by all envs */
     const uint32_t* item_cats; /* [I] four u8 category ids per item, CIRS_CAT_NONE padded (kuaishouEnv.py:49)*/
     const double* alpha_env;   /* [U] alpha_u[raw uid of env user] widened to f64 (simulated_env.py:158-160)  */
     const double* beta_env;    /* [I] beta_i[raw pid of env item]                                             */
+    /* online-reward mode (catalogues too large for a U x I table, BASELINE configs[4]): when pred_online != NULL the
+     * predicted reward of row j is (pred_online[j] - pred_minmax[0]) / (pred_minmax[1] - pred_minmax[0]) in float64
+     * instead of normed_mat[u,a] -- the reference's own online variant (simulated_env.py:88-98, commented out there)
+     * with the normalisation of compute_normed_reward (kuaishouEnv.py:139-143) applied per pair. */
+    const float* pred_online;  /* [n] raw DeepFM score of (user of row j, action of row j), or NULL              */
+    const float* pred_minmax;  /* [2] global {min, max} of the raw scores                                        */
 } cirs_env_tables;
 
 typedef struct cirs_env_state { /* mutable, SoA, one entry per env (B envs) */
@@ -214,12 +220,37 @@ typedef struct cirs_traj {
  *                 env (remove_recommended_ids, the NX_* test collectors) and the bitmap is updated each step
  *   force_length  > 0: done is overridden to (t+1 >= force_length) for every env (core/collector.py:253-258)
  *   workspace     >= cirs_policy_workspace_bytes(policy_cfg, n_env) */
+struct cirs_deepfm_cfg;
+struct cirs_deepfm_weights;
+/* Online scoring of the chosen (user, item) pairs with the DeepFM user model between the policy and the env step. */
+typedef struct cirs_online_reward {
+    const struct cirs_deepfm_cfg* cfg;
+    const struct cirs_deepfm_weights* w;
+    const int64_t* raw_uid;     /* [U] raw id of env user (lbe_user.classes_)        */
+    const int64_t* raw_pid;     /* [I] raw id of env item (lbe_photo.classes_)       */
+    const int32_t* item_feats;  /* [I,4] feat ids (0 = padding)                      */
+    const float* item_dur;      /* [I]                                               */
+    const float* pred_minmax;   /* [2]                                               */
+    int64_t* uid_buf;           /* [B] scratch                                       */
+    int64_t* pid_buf;           /* [B] scratch                                       */
+    int32_t* feat_buf;          /* [B,4] scratch                                     */
+    float* dur_buf;             /* [B] scratch                                       */
+    float* pred_buf;            /* [B] scratch: raw scores of this step              */
+} cirs_online_reward;
+
 int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
                        const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
                        const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj,
                        int32_t n_env, int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base,
                        uint32_t* visited, int32_t force_length, void* workspace, int64_t workspace_bytes,
                        void* stream);
+/* same, with the predicted reward scored online (env_tab->normed_mat may be NULL) */
+int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                              const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w,
+                              cirs_tracker_state* trk_st, const cirs_policy_cfg* pol_cfg,
+                              const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env, int32_t t_begin,
+                              int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited, int32_t force_length,
+                              const cirs_online_reward* online, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Learner: PPO update over the collected trajectories

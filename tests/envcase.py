@@ -31,14 +31,15 @@ class HostEnv:
         self.lib = oracle_lib.lib()
         self.cfg = cfg
         self.n_env = n_env
-        self.keep = dict(mat=np.ascontiguousarray(mat, dtype=np.float64),
-                         normed=np.ascontiguousarray(normed_mat, dtype=np.float64),
+        self.keep = dict(mat=None if mat is None else np.ascontiguousarray(mat, dtype=np.float64),
+                         normed=None if normed_mat is None else np.ascontiguousarray(normed_mat, dtype=np.float64),
                          dist=None if dist is None else np.ascontiguousarray(dist, dtype=np.float64),
                          cats=np.ascontiguousarray(pack_item_cats(item_cats)),
                          alpha=np.ascontiguousarray(alpha_env, dtype=np.float64),
                          beta=np.ascontiguousarray(beta_env, dtype=np.float64))
         k = self.keep
-        self.tab = abi.EnvTables(mat=k["mat"].ctypes.data, normed_mat=k["normed"].ctypes.data,
+        self.tab = abi.EnvTables(mat=None if k["mat"] is None else k["mat"].ctypes.data,
+                                 normed_mat=None if k["normed"] is None else k["normed"].ctypes.data,
                                  dist=None if k["dist"] is None else k["dist"].ctypes.data,
                                  item_cats=k["cats"].ctypes.data, alpha_env=k["alpha"].ctypes.data,
                                  beta_env=k["beta"].ctypes.data)
@@ -58,6 +59,13 @@ class HostEnv:
                                        None if ids is None else ids.ctypes.data, n, obs.ctypes.data)
         assert rc == 0
         return obs
+
+    def set_online(self, pred, minmax):
+        """online-reward mode: raw user-model scores of this step's rows + the global (min, max)"""
+        self.keep["pred"] = np.ascontiguousarray(pred, np.float32)
+        self.keep["mm"] = np.ascontiguousarray(minmax, np.float32)
+        self.tab.pred_online = self.keep["pred"].ctypes.data
+        self.tab.pred_minmax = self.keep["mm"].ctypes.data
 
     def step(self, actions, env_ids):
         actions = np.ascontiguousarray(actions, np.int64)
