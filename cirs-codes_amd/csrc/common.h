@@ -67,6 +67,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it stalls every wave until its
+// outstanding global stores/loads have completed (~1-2 us for a store).  Use where the data exchanged is in LDS and
+// the global accesses in flight are either write-only results or prefetches consumed behind a later register dependency.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // category bitmask of an item's packed 4 x u8 category ids (CIRS_CAT_NONE = empty slot)
 __device__ __forceinline__ unsigned long long cat_mask(uint32_t packed) {
     unsigned long long m = 0;

@@ -41,14 +41,12 @@ __host__ __device__ inline ActorPartialView partial_view(void* ws, int n, int n_
 // ---- trunk: one wave per row ---------------------------------------------------------------------------------
 // row_index (nullable): row j reads state row row_index[j] (rows j >= n_valid read nothing and produce zeros);
 // obs_copy (nullable, [n, S]): the gathered input rows are kept for the weight-gradient GEMM of the learner.
-static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, cirs_policy_weights w,
-                                                           const float* __restrict__ state, long state_stride, int n,
-                                                           const uint8_t* __restrict__ skip, float* __restrict__ h2_out,
-                                                           float* __restrict__ value_out,
-                                                           float* __restrict__ h1_out,
-                                                           const int32_t* __restrict__ row_index = nullptr, int n_valid = 0,
-                                                           float* __restrict__ obs_copy = nullptr) {
-    __shared__ float lds[4][2][kH];
+__device__ __forceinline__ void trunk_rows(const cirs_policy_cfg& cfg, const cirs_policy_weights& w,
+                                           const float* __restrict__ state, long state_stride, int n,
+                                           const uint8_t* __restrict__ skip, float* __restrict__ h2_out,
+                                           float* __restrict__ value_out, float* __restrict__ h1_out,
+                                           const int32_t* __restrict__ row_index, int n_valid, float* __restrict__ obs_copy,
+                                           float (*lds)[2][kH]) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wv;
     if (j >= n) return;
@@ -100,6 +98,17 @@ static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, 
         for (int k = 0; k < kH; ++k) v = __builtin_fmaf(w.wc[k], xs[k], v);
         value_out[j] = v;
     }
+}
+
+static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, cirs_policy_weights w,
+                                                           const float* __restrict__ state, long state_stride, int n,
+                                                           const uint8_t* __restrict__ skip, float* __restrict__ h2_out,
+                                                           float* __restrict__ value_out,
+                                                           float* __restrict__ h1_out,
+                                                           const int32_t* __restrict__ row_index = nullptr, int n_valid = 0,
+                                                           float* __restrict__ obs_copy = nullptr) {
+    __shared__ float lds[4][2][kH];
+    trunk_rows(cfg, w, state, state_stride, n, skip, h2_out, value_out, h1_out, row_index, n_valid, obs_copy, lds);
 }
 
 // ---- actor head ------------------------------------------------------------------------------------------------

@@ -5,21 +5,27 @@
 //           returns_kernel      single workgroup: mean / population variance of the un-normalised returns (float64, fixed
 //                               order), normalised returns, RunningMeanStd merge (statistics.py:80-95)
 // minibatch gather -> adv norm -> trunk fwd -> head stats (MFMA, transposed tile, no logits in HBM) -> row scalars
-//           -> head backward: dWa/dba (item-tile owners, Z layout) and dH2 + entropy (row-tile owners, Z^T layout); both
-//              recompute the logits tile on the matrix cores instead of reading a B x I probability matrix
+//           -> head backward (one fused kernel): the logits tile is recomputed on the matrix cores instead of reading a
+//              B x I probability matrix; dZ feeds the d h2 product from the accumulator registers (Z^T layout) and,
+//              after a 4 KB transpose through LDS, the dWa product (Z layout)
 //           -> trunk / critic backward (small dense kernels) -> d obs scatter (gradient into the state tracker)
 //           -> clip_grad_norm_ (trunk counted twice) -> Adam (trunk: coefficient squared, two sub-steps)
 // Every reduction has a fixed order: two runs (or two ranks of a replicated learner) produce identical bits.
 //
-// Roofline of one minibatch step (mb x I x 64): forward stats 2*mb*I*64 flop + two backward kernels of
-// 2 * 2*mb*I*64 flop each = 10*mb*I*64 flop = 7.0 GFLOP at mb = 1024, I = 10728 on the fp32 MFMA pipe (157 TF peak);
-// HBM traffic is Wa (2.7 MB) + dWa partials (8 x 2.7 MB) + dH2 partials (n_chunks x mb x 256 B = 22 MB): MFMA-bound.
+// Roofline of one minibatch step (mb x I x 64): algorithmic 3 * 2*mb*I*64 flop (forward + two backward products,
+// SURVEY 8(d)) = 4.2 GFLOP at mb = 1024, I = 10728; executed 8*mb*I*64 (forward statistics pass + one recompute of the
+// logits in the backward kernel) on the fp32 MFMA pipe (157 TF peak).  HBM traffic is Wa (2.7 MB) + dWa partials
+// (n_row_blocks x 2.7 MB) + dH2 partials (n_chunks x mb x 256 B = 22 MB): MFMA-bound.
 #include "small_gemm.h"
 #include "policy_kernels.h"
 
 namespace cirs {
 
-constexpr int kRowSplits = 8;  // dWa partial slabs (rows of the minibatch split 8 ways)
+
+constexpr int kBwdWaves = 4;  // row tiles per workgroup of the fused head backward kernel (= rows/32 per dWa slab)
+__host__ __device__ inline int n_row_blocks_of(int n_pad) { return (n_pad / kTileM + kBwdWaves - 1) / kBwdWaves; }
+// floats between consecutive dWa|dba partial slabs (16 B aligned for the float4 stores)
+__host__ __device__ inline size_t dwa_slab_stride(int I) { return (((size_t)I * 64 + I) + 3) & ~(size_t)3; }
 
 struct PpoLayout {  // offsets (floats) into the flat parameter buffer
     long w1, b1, w2, b2, wa, ba, wc, bc, total, trunk;
@@ -130,7 +136,7 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     float *da2, *da1;                         // [n_pad,64] pre-activation gradients
     float *dh2p;                              // [n_chunks, n_pad, 64] partial d h2
     float *entp;                              // [n_chunks, n_pad]
-    float *dwap;                              // [kRowSplits, I*64 + I] partial dWa | dba
+    float *dwap;                              // [n_row_blocks, I*64 + I] partial dWa | dba
     float *red;                               // [16] scalars: adv mean/std, loss sums, grad norm coef
     float *normp;                             // [256] sum-of-squares partials
     float *dwp;                               // weight-gradient slab partials
@@ -148,7 +154,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 2 * (size_t)n_pad + 2 * (size_t)n_pad + 8;    // clip_row, vf_row, dst_row (int64)
     f += 2 * (size_t)n_pad * kH;                       // da2, da1
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
-    f += (size_t)kRowSplits * ((size_t)I * kH + I);    // dwap
+    f += (size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I);    // dwap
     f += 64 + 256;                                     // red + sum-of-squares partials
     f += dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64;  // dW slabs
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
@@ -169,7 +175,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dst_row = (long*)take(2 * (size_t)n_pad + 4);
     v.da2 = take((size_t)n_pad * kH); v.da1 = take((size_t)n_pad * kH);
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
-    v.dwap = take((size_t)kRowSplits * ((size_t)I * kH + I));
+    v.dwap = take((size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I));
     v.red = take(64);
     v.normp = take(256);
     v.dwp = take(dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64);
@@ -178,10 +184,10 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
 }
 
 // advantage statistics of the (global) minibatch: mean and unbiased std (torch.Tensor.std, ppo.py:185-186) of
-// adv_flat[idx[0..m)].  One workgroup, fixed order.  red[0] = mean, red[1] = std (1, 0 when normalisation is off).
-__global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict__ adv_flat, const int32_t* __restrict__ idx, int m,
-                                                         int enable, float* __restrict__ red) {
-    __shared__ float sh[1024];
+// adv_flat[idx[0..m)].  One workgroup of 256 threads, fixed order.  red[0] = mean, red[1] = std (0, 1 when
+// normalisation is off).
+__device__ __forceinline__ void adv_stats_block(const float* __restrict__ adv_flat, const int32_t* __restrict__ idx, int m,
+                                                int enable, float* __restrict__ red, float* sh /* [256] */) {
     __shared__ float s_mean;
     const int tid = threadIdx.x;
     if (!enable) {
@@ -189,10 +195,10 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict
         return;
     }
     float acc = 0.f;
-    for (int i = tid; i < m; i += 1024) acc += adv_flat[idx[i]];
+    for (int i = tid; i < m; i += 256) acc += adv_flat[idx[i]];
     sh[tid] = acc;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
@@ -200,18 +206,34 @@ __global__ __launch_bounds__(1024) void adv_stats_kernel(const float* __restrict
     __syncthreads();
     const float mean = s_mean;
     acc = 0.f;
-    for (int i = tid; i < m; i += 1024) {
+    for (int i = tid; i < m; i += 256) {
         const float d = adv_flat[idx[i]] - mean;
         acc += d * d;
     }
     __syncthreads();
     sh[tid] = acc;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
     if (tid == 0) { red[0] = mean; red[1] = sqrtf(sh[0] / (float)(m - 1)); }
+}
+
+// trunk forward of the minibatch rows (same fma chains as the rollout) + the advantage statistics in the extra last
+// workgroup: one launch for the two independent first steps of a minibatch
+__global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cirs_policy_weights w, const float* __restrict__ obs_flat,
+                                                        long stride, int n_pad, float* __restrict__ h2_out,
+                                                        float* __restrict__ value_out, float* __restrict__ h1_out,
+                                                        const int32_t* __restrict__ idx, int mb, float* __restrict__ obs_copy,
+                                                        const float* __restrict__ adv_flat, const int32_t* __restrict__ sidx,
+                                                        int m_stats, int enable, float* __restrict__ red) {
+    __shared__ float lds[4][2][kH];
+    if (blockIdx.x == gridDim.x - 1) {
+        adv_stats_block(adv_flat, sidx, m_stats, enable, red, &lds[0][0][0]);
+        return;
+    }
+    trunk_rows(cfg, w, obs_flat, stride, n_pad, nullptr, h2_out, value_out, h1_out, idx, mb, obs_copy, lds);
 }
 
 // One wavefront per minibatch row: merge the head-stats partials (lse, E_p[z]), recompute the taken action's logit
@@ -302,142 +324,40 @@ __device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c
     return c_logp * ((is_act ? 1.0f : 0.0f) - p) + c_ent * p * (z - lse + h_ent);
 }
 
-// ---- head backward 1: dWa, dba.  Z layout (lane owns an ITEM column, registers are rows) -----------------------
-// grid = (ceil(n_item_tiles/4), kRowSplits); workgroup = 4 waves = 4 item tiles walking the row tiles of one split.
-//   Z[32 rows x 32 items]   = H2_tile * Wa_tile^T           (A = H2 rows, B = Wa rows)
-//   dWa_tile[32 items x 64] += dZ^T[items x rows] * H2_tile   (A = dZ registers AS THEY ARE, B = H2[row(s,hi)][n])
-// The H2 row tile (32 x 64) and the per-row coefficients are staged in LDS once per workgroup (double-buffered) and
-// serve both products of all four waves.
-__global__ __launch_bounds__(256, 2) void head_bwd_dwa_kernel(int I, int mb, int n_pad, const float* __restrict__ wa,
-                                                              const float* __restrict__ ba, MbView v,
-                                                              float* __restrict__ dwap) {
-    __shared__ __attribute__((aligned(16))) float sH[2][kTileM * kLdsStride];
-    __shared__ __attribute__((aligned(16))) float4 sR[2][kTileM];  // {lse, c_logp, c_ent, h_ent} per row
-    __shared__ int sA[2][kTileM];                                   // action id per row
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int hi = lane >> 5, lo = lane & 31;
-    const int tile0 = (blockIdx.x * 4 + wv) * kTileN;
-    const bool wave_ok = tile0 < I;
-    const int split = blockIdx.y;
-    const int item = tile0 + lo;
-    const bool item_ok = wave_ok && item < I;
-    float wrow[32];
-    if (item_ok) {
-        const float4* src = reinterpret_cast<const float4*>(wa + (size_t)item * kH + hi * 32);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 t4 = src[q];
-            wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 32; ++q) wrow[q] = 0.f;
-    }
-    const float bias = item_ok ? ba[item] : 0.f;
-    f32x16 dw0, dw1;  // dWa^T accumulators: items x k[0..31], items x k[32..63]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
-    float db = 0.f;
-    const int n_row_tiles = n_pad / kTileM;
-    const int per = (n_row_tiles + kRowSplits - 1) / kRowSplits;
-    const int rt_beg = split * per, rt_end = min(n_row_tiles, rt_beg + per);
-    const int st_row = tid >> 3, st_col = (tid & 7) * 8;
-    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, gr = g0;
-    int ga = 0;
-#define CIRS_ISSUE(RT)                                                                                       \
-    do {                                                                                                     \
-        const float4* src_ = reinterpret_cast<const float4*>(v.h2 + (size_t)((RT) * kTileM + st_row) * kH + st_col); \
-        g0 = src_[0]; g1 = src_[1];                                                                          \
-        if (tid < kTileM) {                                                                                  \
-            const int row_ = (RT) * kTileM + tid;                                                            \
-            gr = make_float4(v.lse[row_], v.c_logp[row_], v.c_ent[row_], v.h_ent[row_]);                     \
-            ga = v.act[row_];                                                                                \
-        }                                                                                                    \
-    } while (0)
-#define CIRS_COMMIT(BUF)                                                                                     \
-    do {                                                                                                     \
-        float4* dst_ = reinterpret_cast<float4*>(&sH[BUF][st_row * kLdsStride + st_col]);                    \
-        dst_[0] = g0; dst_[1] = g1;                                                                          \
-        if (tid < kTileM) { sR[BUF][tid] = gr; sA[BUF][tid] = ga; }                                          \
-    } while (0)
-    if (rt_beg < rt_end) { CIRS_ISSUE(rt_beg); CIRS_COMMIT(0); }
-    __syncthreads();
-    for (int rt = rt_beg; rt < rt_end; ++rt) {
-        const int buf = (rt - rt_beg) & 1;
-        if (rt + 1 < rt_end) CIRS_ISSUE(rt + 1);
-        if (wave_ok) {
-            const float* th = sH[buf];
-            float hrow[32];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 t4 = *reinterpret_cast<const float4*>(&th[lo * kLdsStride + hi * 32 + 4 * q]);
-                hrow[4 * q] = t4.x; hrow[4 * q + 1] = t4.y; hrow[4 * q + 2] = t4.z; hrow[4 * q + 3] = t4.w;
-            }
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bias;
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hrow[kk], wrow[kk], acc, 0, 0, 0);
-            // dZ in place (rows beyond mb have c = 0 and lse = 1e30 -> dZ = 0)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float4 rs = sR[buf][rl];
-                float p;
-                const float d = item_ok ? dz_of(acc[r], rs.x, rs.y, rs.z, rs.w, sA[buf][rl] == item, p) : 0.f;
-                acc[r] = d;
-                db += d;
-            }
-            // dWa^T += dZ^T * H2 : step r pairs rows row(r,0), row(r,1)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float b0 = th[rl * kLdsStride + lo];
-                const float b1 = th[rl * kLdsStride + 32 + lo];
-                dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dw0, 0, 0, 0);
-                dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dw1, 0, 0, 0);
-            }
-        }
-        if (rt + 1 < rt_end) CIRS_COMMIT(buf ^ 1);
-        __syncthreads();
-    }
-#undef CIRS_ISSUE
-#undef CIRS_COMMIT
-    if (!wave_ok) return;
-    // store partial slab: C layout col = k (lane lo), rows = items (r&3)+8*(r>>2)+4*hi
-    float* slab = dwap + (size_t)split * ((size_t)I * kH + I);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int it = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (it < I) {
-            slab[(size_t)it * kH + lo] = dw0[r];
-            slab[(size_t)it * kH + 32 + lo] = dw1[r];
-        }
-    }
-    db += __shfl_xor(db, 32, CIRS_WAVE);
-    if (hi == 0 && item_ok) slab[(size_t)I * kH + item] = db;
-}
+// ---- head backward (fused): dWa, dba, d h2, entropy correction ------------------------------------------------
+// grid = (n_chunks, ceil(n_pad/32/kBwdWaves)); workgroup = kBwdWaves waves = that many ROW tiles walking the item
+// tiles of one chunk.  Per (row tile, item tile) the logits are recomputed ONCE:
+//   ZT[32 items x 32 rows] = Wa_tile * H2_tile^T             (A = Wa rows from LDS, B = this lane's H2 row, registers)
+//   dZ in place (lane owns a ROW: its lse / coefficients / action are scalars)
+//   dH2_tile[32 rows x 64] += dZ[rows x items] * Wa_tile      (A = the dZT registers AS THEY ARE, B = Wa[item(s,hi)][n], LDS)
+//   dZ -> LDS -> registers in the transposed (Z) layout: lane owns an ITEM, registers are rows (4 KB per wave)
+//   dWa_tile[32 items x 64]  = dZ^T[items x rows] * H2_tile   (A = transposed dZ registers, B = H2[row(s,hi)][n], registers)
+// d h2 stays in the accumulators across the chunk (one partial slab per chunk, summed by finalize_dh2_kernel); the dWa
+// tile of each wave covers only its 32 rows, so the kBwdWaves partial tiles are summed through LDS in wave order and
+// written to the slab of this ROW BLOCK (n_row_blocks slabs, summed in slab order by sumsq_partial / reduce_dwa).
+// The Wa tile (32 items x 64, 8 KB) is staged in LDS once per workgroup, double-buffered with the next tile's global
+// loads in flight; row stride 68 floats keeps the ds_read_b128 of the A operand conflict-free.
+constexpr int kTStride = 36;                 // transpose buffer row stride (floats): 16 B aligned, conflict-free b128 reads
+constexpr int kRSize = kTileN * kH + kTileN; // per-wave dWa partial tile + dba partial
 
-// ---- head backward 2: d h2 + entropy.  Z^T layout (lane owns a ROW, registers are items) -----------------------
-// grid = (n_chunks, ceil(n_pad/32/4)); workgroup = 4 waves = 4 row tiles walking the same item chunk.
-//   ZT[32 items x 32 rows] = Wa_tile * H2_tile^T
-//   dH2_tile[32 rows x 64] += dZ[rows x items] * Wa_tile      (A = dZT registers AS THEY ARE, B = Wa[item(s,hi)][n])
-// The Wa tile (32 items x 64, 8 KB) is staged in LDS ONCE per workgroup and serves both products of all four waves
-// (A operand rows by ds_read_b128, B operand columns by ds_read_b32).  Double-buffered: the global loads of tile
-// t+1 are issued before the MFMAs of tile t and written to the other buffer afterwards (one barrier per tile).
-// Row stride 68 floats: ds_read_b128 of 16 lanes x different rows then hits 64 distinct banks.
-__global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int n_pad, const float* __restrict__ wa,
-                                                              const float* __restrict__ ba, MbView v) {
+__global__ __launch_bounds__(kBwdWaves * 64, 2) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
+                                                                         const float* __restrict__ wa,
+                                                                         const float* __restrict__ ba, MbView v,
+                                                                         float* __restrict__ dwap) {
+    constexpr int kThreads = kBwdWaves * 64;
+    constexpr int kF4 = (kTileN * kH / 4) / kThreads;  // float4 per thread when staging a tile
     __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
     __shared__ float sB[2][kTileN];
+    __shared__ __attribute__((aligned(16))) float sT[kBwdWaves][kTileN * kTStride];
+    __shared__ __attribute__((aligned(16))) float sR[kBwdWaves][kRSize];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
-    const int row0 = (blockIdx.y * 4 + wv) * kTileM;
-    const bool wave_ok = row0 < n_pad;   // all waves take part in the staging + barriers
+    const int row0 = (blockIdx.y * kBwdWaves + wv) * kTileM;
+    const bool wave_ok = row0 < n_pad;   // all waves take part in the staging, barriers and the slab reduction
     const int chunk = blockIdx.x;
     const int jr = wave_ok ? row0 + lo : 0;
+    // B operand of ZT: this lane's row of H2, k = hi*32 + kk
     float hrow[32];
     {
         const float4* src = reinterpret_cast<const float4*>(v.h2 + (size_t)jr * kH + hi * 32);
@@ -446,6 +366,14 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
             const float4 t4 = src[q];
             hrow[4 * q] = t4.x; hrow[4 * q + 1] = t4.y; hrow[4 * q + 2] = t4.z; hrow[4 * q + 3] = t4.w;
         }
+    }
+    // B operand of the dWa product: H2[row(s,hi)][lo] and [32 + lo]
+    float hb0[16], hb1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float* hp = v.h2 + (size_t)(wave_ok ? row0 + rl : 0) * kH;
+        hb0[r] = hp[lo]; hb1[r] = hp[32 + lo];
     }
     const float lse = v.lse[jr], c_logp = v.c_logp[jr], c_ent = v.c_ent[jr], h_ent = v.h_ent[jr];
     const int act = v.act[jr];
@@ -456,37 +384,42 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
     float ent = 0.f;  // clamp correction of the entropy (see below)
     const float eps = 1.1920928955078125e-7f;
     const float kLogEps = -15.942385152878742f, kLog1mEps = -1.1920929665620834e-7f;
+    if (!wave_ok) {
+        for (int q = lane; q < kRSize; q += 64) sR[wv][q] = 0.f;
+    }
 
-    // staging role of this thread: 2 float4 of the 32 x 64 tile (thread -> item tid/8, floats (tid%8)*8 .. +8)
-    const int st_item = tid >> 3, st_col = (tid & 7) * 8;
-    const int first_tile = chunk * kChunkItems;
-    int n_tiles = 0;
-    for (int it = 0; it < kTilesPerChunk; ++it) n_tiles += (first_tile + it * kTileN) < I;
-    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    const int st_f4 = tid * kF4;                       // first float4 of the tile this thread stages
+    const int st_item = st_f4 >> 4, st_col = (st_f4 & 15) * 4;
+    const int first_tile = chunk * tiles_per_chunk * kTileN;
+    const int n_tiles = max(0, min(tiles_per_chunk, (I - first_tile + kTileN - 1) / kTileN));
+    float4 gq[kF4];
     float gb = 0.f;
 #define CIRS_ISSUE(TILE0)                                                                                  \
     do {                                                                                                   \
         const int item_ = (TILE0) + st_item;                                                               \
         if (item_ < I) {                                                                                   \
             const float4* src_ = reinterpret_cast<const float4*>(wa + (size_t)item_ * kH + st_col);        \
-            g0 = src_[0]; g1 = src_[1];                                                                    \
+            _Pragma("unroll") for (int q_ = 0; q_ < kF4; ++q_) gq[q_] = src_[q_];                          \
         } else {                                                                                           \
-            g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0;                                                 \
+            _Pragma("unroll") for (int q_ = 0; q_ < kF4; ++q_) gq[q_] = make_float4(0.f, 0.f, 0.f, 0.f);   \
         }                                                                                                  \
         if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
         float4* dst_ = reinterpret_cast<float4*>(&sW[BUF][st_item * kLdsStride + st_col]);                 \
-        dst_[0] = g0; dst_[1] = g1;                                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < kF4; ++q_) dst_[q_] = gq[q_];                              \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
     if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
     __syncthreads();
+    float* slab = dwap + (size_t)blockIdx.y * dwa_slab_stride(I);
     for (int it = 0; it < n_tiles; ++it) {
         const int buf = it & 1;
         const int tile0 = first_tile + it * kTileN;
         if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);  // global loads in flight during the MFMAs below
+        f32x16 dw0, dw1;
+        float db = 0.f;
         if (wave_ok) {
             const float* tw = sW[buf];
             float wrow[32];
@@ -500,19 +433,23 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
             for (int r = 0; r < 16; ++r) acc[r] = sB[buf][(r & 3) + 8 * (r >> 2) + 4 * hi];
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
+            float* tt = sT[wv];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int item = tile0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float d = 0.f;
-                if (item < I && row_ok) {
-                    float p;
-                    d = dz_of(acc[r], lse, c_logp, c_ent, h_ent, item == act, p);
-                    // Categorical.entropy uses log(clamp(p, eps, 1-eps)): the un-clamped entropy lse - E_p[z] comes from
-                    // the forward statistics; only the (rare) clamped elements contribute a correction here
-                    if (p < eps) ent -= p * (kLogEps - (acc[r] - lse));
-                    else if (p > 1.0f - eps) ent -= p * (kLog1mEps - (acc[r] - lse));
-                }
+                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int item = tile0 + il;
+                // branch-free: items beyond I carry zero weights (z = 0, finite), padded rows lse = 1e30 -> p = 0
+                float p;
+                const float dd = dz_of(acc[r], lse, c_logp, c_ent, h_ent, item == act, p);
+                const bool ok = item < I && row_ok;
+                const float d = ok ? dd : 0.f;
+                // Categorical.entropy uses log(clamp(p, eps, 1-eps)): the un-clamped entropy lse - E_p[z] comes from
+                // the forward statistics; only the (rare) clamped elements contribute a correction here
+                const bool c_lo = p < eps, c_hi = p > 1.0f - eps;
+                const float corr = p * ((c_lo ? kLogEps : kLog1mEps) - (acc[r] - lse));
+                ent -= (ok && (c_lo || c_hi)) ? corr : 0.f;
                 acc[r] = d;
+                tt[il * kTStride + lo] = d;   // transposed exchange: T[item][row]
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -522,50 +459,181 @@ __global__ __launch_bounds__(256, 2) void head_bwd_dh2_kernel(int I, int mb, int
                 dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dh0, 0, 0, 0);
                 dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dh1, 0, 0, 0);
             }
+            // the wave's own LDS writes above are read back by other lanes of the same wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            f32x16 dzt;  // lane owns item lo; register r' = row (r'&3) + 8*(r'>>2) + 4*hi
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&tt[lo * kTStride + 8 * g + 4 * hi]);
+                dzt[4 * g] = t4.x; dzt[4 * g + 1] = t4.y; dzt[4 * g + 2] = t4.z; dzt[4 * g + 3] = t4.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                db += dzt[r];
+                dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dzt[r], hb0[r], dw0, 0, 0, 0);
+                dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dzt[r], hb1[r], dw1, 0, 0, 0);
+            }
         }
-        if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);  // the other buffer was last read in iteration it-1 (barrier below)
-        __syncthreads();
+        lds_barrier();  // the slab reduction of the previous tile has finished reading sR
+        if (wave_ok) {
+            float* rr = sR[wv];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                rr[il * kH + lo] = dw0[r];
+                rr[il * kH + 32 + lo] = dw1[r];
+            }
+            db += __shfl_xor(db, 32, CIRS_WAVE);
+            if (hi == 0) rr[kTileN * kH + lo] = db;
+        }
+        if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);  // the other buffer was last read in iteration it-1
+        lds_barrier();
+        // sum the kBwdWaves partial tiles in wave order -> slab of this row block (coalesced float4 stores)
+        {
+#pragma unroll
+            for (int q = 0; q < (kTileN * kH / 4) / kThreads; ++q) {
+                const int f = tid + kThreads * q;  // float4 index within the 32 x 64 tile
+                float4 t = reinterpret_cast<const float4*>(sR[0])[f];
+#pragma unroll
+                for (int w2 = 1; w2 < kBwdWaves; ++w2) {
+                    const float4 u = reinterpret_cast<const float4*>(sR[w2])[f];
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
+                if (tile0 + (f >> 4) < I) *reinterpret_cast<float4*>(slab + (size_t)tile0 * kH + 4 * f) = t;
+            }
+            if (tid < kTileN) {
+                float t = sR[0][kTileN * kH + tid];
+#pragma unroll
+                for (int w2 = 1; w2 < kBwdWaves; ++w2) t += sR[w2][kTileN * kH + tid];
+                if (tile0 + tid < I) slab[(size_t)I * kH + tile0 + tid] = t;
+            }
+        }
     }
 #undef CIRS_ISSUE
 #undef CIRS_COMMIT
     if (!wave_ok) return;
-    float* slab = v.dh2p + (size_t)chunk * n_pad * kH;
+    float* hslab = v.dh2p + (size_t)chunk * n_pad * kH;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        slab[(size_t)row * kH + lo] = dh0[r];
-        slab[(size_t)row * kH + 32 + lo] = dh1[r];
+        hslab[(size_t)row * kH + lo] = dh0[r];
+        hslab[(size_t)row * kH + 32 + lo] = dh1[r];
     }
     ent += __shfl_xor(ent, 32, CIRS_WAVE);
     if (hi == 0) v.entp[(size_t)chunk * n_pad + jr] = ent;
 }
 
-// d a2 = (sum_chunks d h2 partial + dvalue * wc) * relu'(h2) ; entropy per row.
-// One workgroup per row: thread (g, k) sums the chunk slabs c = g, g+4, ... for feature k, the four group sums are
-// then added in group order (fixed order, independent of timing).
-__global__ __launch_bounds__(256) void finalize_dh2_kernel(int mb, int n_pad, int n_chunks, const float* __restrict__ wc, MbView v) {
-    __shared__ float sh[4][kH];
-    __shared__ float she[256];
-    const int r = blockIdx.x, tid = threadIdx.x;
-    const int g = tid >> 6, k = tid & 63;
-    float acc = 0.f;
-    for (int c = g; c < n_chunks; c += 4) acc += v.dh2p[((size_t)c * n_pad + r) * kH + k];
-    sh[g][k] = acc;
-    float e = 0.f;
-    for (int c = tid; c < n_chunks; c += 256) e += v.entp[(size_t)c * n_pad + r];
-    she[tid] = e;
+// ---- trunk backward, one workgroup (8 waves) per 32 minibatch rows ------------------------------------------------
+//   d a2 = (sum_chunks d h2 partial + dvalue * wc) * relu'(h2)      512 threads, one float4 each, chunk order fixed
+//   entropy per row = (lse - E_p[z]) + sum_chunks clamp correction
+//   d a1 = (d a2 * W2) * relu'(h1)                                  waves 0,1: one 32 x 32 MFMA tile each, A from LDS
+//   d obs = d a1 * W1  -> scattered to the [T+1,B,S] tracker-gradient tensor at dst_row (wave 2, only when requested)
+// d a2 / d a1 are also written to global memory for the weight-gradient GEMMs.
+__global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n_chunks, int S, const float* __restrict__ w1,
+                                                        const float* __restrict__ w2, const float* __restrict__ wc, MbView v,
+                                                        float* __restrict__ dobs_accum) {
+    __shared__ __attribute__((aligned(16))) float sA[kTileM * kLdsStride];
+    __shared__ __attribute__((aligned(16))) float sD[kTileM * kLdsStride];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int row0 = blockIdx.x * kTileM;
+    // B operands of the two MFMA stages do not depend on stage 1: issue their loads first (waves 0,1: W2; wave 2: W1)
+    float bcol[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        float t = 0.f;
+        if (wv < 2) t = w2[(size_t)(hi * 32 + kk) * kH + wv * 32 + lo];
+        else if (wv == 2 && dobs_accum && lo < S) t = w1[(size_t)(hi * 32 + kk) * S + lo];
+        bcol[kk] = t;
+    }
+    {
+        const int f = tid;  // one float4 column group of the 32 x 64 tile per thread
+        const int rl = f >> 4, c4 = (f & 15) * 4;
+        const int r = row0 + rl;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = v.dh2p + (size_t)r * kH + c4;
+        const size_t cstride = (size_t)n_pad * kH;
+        for (int c0 = 0; c0 < n_chunks; c0 += 16) {  // 16 loads in flight, added in chunk order
+            float4 t16[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                t16[u] = (c0 + u < n_chunks) ? *reinterpret_cast<const float4*>(src + (size_t)(c0 + u) * cstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { acc.x += t16[u].x; acc.y += t16[u].y; acc.z += t16[u].z; acc.w += t16[u].w; }
+        }
+        const float dv = v.dvalue[r];
+        const float4 wc4 = *reinterpret_cast<const float4*>(wc + c4);
+        const float4 h4 = *reinterpret_cast<const float4*>(v.h2 + (size_t)r * kH + c4);
+        const bool ok = r < mb;
+        float4 t;
+        t.x = (ok && h4.x > 0.f) ? __builtin_fmaf(dv, wc4.x, acc.x) : 0.f;
+        t.y = (ok && h4.y > 0.f) ? __builtin_fmaf(dv, wc4.y, acc.y) : 0.f;
+        t.z = (ok && h4.z > 0.f) ? __builtin_fmaf(dv, wc4.z, acc.z) : 0.f;
+        t.w = (ok && h4.w > 0.f) ? __builtin_fmaf(dv, wc4.w, acc.w) : 0.f;
+        *reinterpret_cast<float4*>(v.da2 + (size_t)r * kH + c4) = t;
+        *reinterpret_cast<float4*>(&sA[rl * kLdsStride + c4]) = t;
+    }
+    if (wv == 7 && lane < kTileM) {
+        const int r = row0 + lane;
+        float e = 0.f;
+        for (int c0 = 0; c0 < n_chunks; c0 += 16) {
+            float t16[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t16[u] = (c0 + u < n_chunks) ? v.entp[(size_t)(c0 + u) * n_pad + r] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) e += t16[u];
+        }
+        v.ent_row[r] = r < mb ? v.h_ent[r] + e : 0.f;  // (lse - E_p[z]) + clamp correction
+    }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) she[tid] += she[tid + s];
-        __syncthreads();
+    if (wv < 2) {  // d a1 tile: columns wv*32 .. +32
+        const int n = wv * 32 + lo;
+        float arow[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&sA[lo * kLdsStride + hi * 32 + 4 * q]);
+            arow[4 * q] = t4.x; arow[4 * q + 1] = t4.y; arow[4 * q + 2] = t4.z; arow[4 * q + 3] = t4.w;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[kk], bcol[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const size_t o = (size_t)(row0 + rl) * kH + n;
+            const float d = v.h1[o] > 0.f ? acc[r] : 0.f;
+            v.da1[o] = d;
+            sD[rl * kLdsStride + n] = d;
+        }
     }
-    if (tid < kH) {
-        float t = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
-        t = __builtin_fmaf(v.dvalue[r], wc[k], t);
-        const size_t i = (size_t)r * kH + k;
-        v.da2[i] = (r < mb && v.h2[i] > 0.f) ? t : 0.f;
+    if (!dobs_accum) return;
+    __syncthreads();
+    if (wv == 2) {
+        float arow[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&sD[lo * kLdsStride + hi * 32 + 4 * q]);
+            arow[4 * q] = t4.x; arow[4 * q + 1] = t4.y; arow[4 * q + 2] = t4.z; arow[4 * q + 3] = t4.w;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[kk], bcol[kk], acc, 0, 0, 0);
+        if (lo < S) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < mb) dobs_accum[(size_t)v.dst_row[row] * S + lo] = acc[r];
+            }
+        }
     }
-    if (tid == 0) v.ent_row[r] = r < mb ? v.h_ent[r] + she[0] : 0.f;  // (lse - E_p[z]) + clamp correction
 }
 
 // clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1).
@@ -573,19 +641,26 @@ __global__ __launch_bounds__(256) void finalize_dh2_kernel(int mb, int n_pad, in
 constexpr int kNormBlocks = 256;
 // sum the dWa slabs in fixed order into the flat gradient buffer (data-parallel path: grads must be complete before
 // the all-reduce; the single-rank path folds this into sumsq_partial_kernel)
-__global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict__ dwap, long seg, float* __restrict__ g_wa_ba) {
+__global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict__ dwap, long seg, long stride, int n_slabs, float* __restrict__ g_wa_ba) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= seg) return;
     float acc = 0.f;
+    for (int s0 = 0; s0 < n_slabs; s0 += 8) {
+        float t8[8];
 #pragma unroll
-    for (int s = 0; s < kRowSplits; ++s) acc += dwap[(size_t)s * seg + i];
+        for (int q = 0; q < 8; ++q) t8[q] = (s0 + q < n_slabs) ? dwap[(size_t)(s0 + q) * stride + i] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += t8[q];
+    }
     g_wa_ba[i] = acc;
 }
 
-// The wa|ba segment of the gradient is still in kRowSplits partial slabs: they are summed here (slab order) and the
+// The wa|ba segment of the gradient is still in n_slabs partial slabs: they are summed here (slab order) and the
 // sum is written to the flat gradient buffer on the way.
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ g, long n_trunk, long n_total, long wa_beg, long wa_len,
-                                                            const float* __restrict__ dwap, float* __restrict__ partial) {
+                                                            const float* __restrict__ dwap, long slab_stride, int n_slabs,
+                                                            DwJobs jobs, int n_dw_slabs, const float* __restrict__ dw_partial, int S,
+                                                            float* __restrict__ partial) {
     __shared__ float sh[256];
     const int tid = threadIdx.x;
     const long per = (n_total + kNormBlocks - 1) / kNormBlocks;
@@ -596,13 +671,38 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
         const long wi = i - wa_beg;
         if (dwap && wi >= 0 && wi < wa_len) {
             x = 0.f;
+            for (int s0 = 0; s0 < n_slabs; s0 += 8) {  // 8 independent loads in flight, added in slab order
+                float t8[8];
 #pragma unroll
-            for (int sl = 0; sl < kRowSplits; ++sl) x += dwap[(size_t)sl * wa_len + wi];
+                for (int q = 0; q < 8; ++q) t8[q] = (s0 + q < n_slabs) ? dwap[(size_t)(s0 + q) * slab_stride + wi] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x += t8[q];
+            }
             g[i] = x;
+        } else if (dw_partial) {
+            continue;  // trunk / critic elements: handled below, one element per thread across the first workgroups
         } else {
             x = g[i];
         }
         acc += (i < n_trunk ? 2.0f : 1.0f) * x * x;  // trunk parameters appear twice in the reference's list
+    }
+    if (dw_partial) {
+        // trunk / critic gradients still live in row-slab partials (dw_multi_kernel): job 2 = W1|b1, 1 = W2|b2, 0 = wc|bc.
+        // Element e of [trunk | wc | bc] belongs to thread e of the grid (fixed assignment -> fixed summation order).
+        const long e = blockIdx.x * 256L + tid;
+        const long n_dw = n_trunk + kH + 1;
+        if (e < n_dw) {
+            const long i = e < n_trunk ? e : wa_beg + wa_len + (e - n_trunk);
+            int ji, q;
+            if (e < (long)kH * S) { ji = 2; q = (int)(e / S) * (S + 1) + (int)(e % S); }
+            else if (e < (long)kH * S + kH) { ji = 2; q = (int)(e - (long)kH * S) * (S + 1) + S; }
+            else if (e < (long)kH * S + kH + (long)kH * kH) { const int r = (int)(e - ((long)kH * S + kH)); ji = 1; q = (r / kH) * (kH + 1) + (r % kH); }
+            else if (e < n_trunk) { ji = 1; q = (int)(e - ((long)kH * S + kH + (long)kH * kH)) * (kH + 1) + kH; }
+            else { ji = 0; q = (int)(e - n_trunk); }  // wc[0..63] then bc: row 0 of a [1, 64 + 1] problem
+            const float x = dw_multi_fetch(jobs.j[ji], n_dw_slabs, dw_partial, q);
+            g[i] = x;
+            acc += (e < n_trunk ? 2.0f : 1.0f) * x * x;
+        }
     }
     sh[tid] = acc;
     __syncthreads();
@@ -635,13 +735,21 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(int mb, int mb_norm,
     loss_partials_block(mb, mb_norm, v, tail, sh3);
 }
 
-// mb > 0: single-rank path, the loss partials are formed here (no separate launch); mb == 0: they already are in `tail`
-__global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, const float* __restrict__ partial, float* __restrict__ tail,
-                                                             MbView v, float* __restrict__ loss_out, int mb, int mb_norm) {
+// torch.optim.Adam (_single_tensor_adam): lerp_, mul_/addcmul_, bias corrections from the step count
+struct AdamSeg { int n_sub; int scale_pow; float step_size0, bc2s0, step_size1, bc2s1; };
+
+// one launch over the whole flat buffer: elements [0, n_first) use segment a (trunk), the rest segment b (heads).
+// clip_grad_norm_ stage 2 rides along: EVERY workgroup sums the kNormBlocks partial sums of squares in the same fixed
+// tree order (identical coefficient everywhere); workgroup 0 also forms the loss terms (mb > 0: single-rank path, the
+// loss partials are reduced here; mb == 0: they already are in `tail`) and publishes norm / coefficient.
+__global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, long n_first, AdamSeg sa, AdamSeg sb, float beta1,
+                                                    float beta2, float eps, cirs_ppo_cfg cfg, const float* __restrict__ partial,
+                                                    float* __restrict__ tail, MbView mv, float* __restrict__ loss_out, int mb, int mb_norm) {
     __shared__ float sh[256];
     __shared__ float sh3[768];
     const int tid = threadIdx.x;
-    if (mb > 0) loss_partials_block(mb, mb_norm, v, tail, sh3);
+    if (blockIdx.x == 0 && mb > 0) loss_partials_block(mb, mb_norm, mv, tail, sh3);
     sh[tid] = tid < kNormBlocks ? partial[tid] : 0.f;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -649,29 +757,19 @@ __global__ __launch_bounds__(256) void gradnorm_final_kernel(cirs_ppo_cfg cfg, c
         __syncthreads();
     }
     const float total_norm = sqrtf(sh[0]);
-    if (tid == 0) {
-        float coef = 1.0f;
-        if (cfg.max_grad_norm > 0.f) coef = fminf(cfg.max_grad_norm / (total_norm + 1e-6f), 1.0f);
-        v.red[4] = coef;
-        v.red[5] = total_norm;
+    float c = 1.0f;
+    if (cfg.max_grad_norm > 0.f) c = fminf(cfg.max_grad_norm / (total_norm + 1e-6f), 1.0f);
+    if (blockIdx.x == 0 && tid == 0) {
+        mv.red[4] = c;
+        mv.red[5] = total_norm;
         const float clip = tail[0], vf = tail[1], ent = tail[2];
         loss_out[0] = clip + cfg.vf_coef * vf - cfg.ent_coef * ent;
         loss_out[1] = clip; loss_out[2] = vf; loss_out[3] = ent;
     }
-}
-
-// torch.optim.Adam (_single_tensor_adam): lerp_, mul_/addcmul_, bias corrections from the step count
-struct AdamSeg { int n_sub; int scale_pow; float step_size0, bc2s0, step_size1, bc2s1; };
-
-// one launch over the whole flat buffer: elements [0, n_first) use segment a (trunk), the rest segment b (heads)
-__global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, long n, long n_first, AdamSeg sa, AdamSeg sb, float beta1,
-                                                    float beta2, float eps, const float* __restrict__ grad_scale) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= n) return;
     const AdamSeg sg = i < n_first ? sa : sb;
     float gi = g[i];
-    const float c = grad_scale[0];
     for (int q = 0; q < sg.scale_pow; ++q) gi *= c;
     float pi = p[i], mi = m[i], vi = v[i];
     for (int sub = 0; sub < sg.n_sub; ++sub) {
@@ -720,6 +818,16 @@ static int launch_adam(float* p, const float* g, float* m, float* v, long n, lon
                        (float)bs[0], (float)ss[1], (float)bs[1], grad_scale, scale_pow);
     CIRS_CHECK_LAUNCH("adam_kernel");
     return CIRS_OK;
+}
+
+static int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
 }
 
 static int validate_ppo(const cirs_ppo_cfg* cfg) {
@@ -791,18 +899,20 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
     cirs_policy_weights w{params + L.w1, params + L.b1, params + L.w2, params + L.b2,
                           params + L.wa, params + L.ba, params + L.wc, params + L.bc};
     const long seg = (long)I * kH + I;
+    const int n_slabs = n_row_blocks_of(n_pad);
+    DwJobs dw_jobs{};
+    int n_dw_slabs = 0;
     float* tail = grads + L.total;  // {clip, vf, ent, 0} partials of this rank
     if (phase == 0 || phase == 1) {
         CIRS_REQUIRE(idx != nullptr, "idx is null");
         const int32_t* sidx = idx_global ? idx_global : idx;
-        // 1. advantage statistics of the (global) minibatch
-        hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(1024), 0, s, batch->adv, sidx, idx_global ? mb_global : mb, cfg->norm_adv, v.red);
-        CIRS_CHECK_LAUNCH("adv_stats_kernel");
-        // 2. trunk forward (same fma chains as the rollout -> ratio == 1 exactly while the weights are unchanged)
-        //    rows are gathered from the buffer-order batch through idx inside the kernel (v.obs keeps the copy for d W1)
-        hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
-                           (const uint8_t*)nullptr, v.h2, v.value, v.h1, idx, (int)mb, v.obs);
-        CIRS_CHECK_LAUNCH("trunk_kernel");
+        // 1+2. advantage statistics of the (global) minibatch (last workgroup) and the trunk forward (same fma chains as
+        //    the rollout -> ratio == 1 exactly while the weights are unchanged); rows are gathered from the buffer-order
+        //    batch through idx inside the kernel (v.obs keeps the copy for d W1)
+        hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
+                           v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, sidx, (int)(idx_global ? mb_global : mb),
+                           (int)cfg->norm_adv, v.red);
+        CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         hipLaunchKernelGGL(actor_head_kernel<false>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, pcfg, w.wa, w.ba,
@@ -814,43 +924,41 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
                            (int)(idx_global ? mb_global : mb), n_pad, n_chunks, (int)n_env, pv, w.wa, w.ba, v);
         CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
         // 5. head backward
+        // chunking of the backward kernel: all workgroups co-resident (2 per CU) with equal tile counts -> no tail round
         const int n_item_tiles = cdiv(I, kTileN);
-        hipLaunchKernelGGL(head_bwd_dwa_kernel, dim3(cdiv(n_item_tiles, 4), kRowSplits), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v, v.dwap);
-        CIRS_CHECK_LAUNCH("head_bwd_dwa_kernel");
-        hipLaunchKernelGGL(head_bwd_dh2_kernel, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, I, mb, n_pad, w.wa, w.ba, v);
-        CIRS_CHECK_LAUNCH("head_bwd_dh2_kernel");
-        hipLaunchKernelGGL(finalize_dh2_kernel, dim3(n_pad), dim3(256), 0, s, mb, n_pad, n_chunks, w.wc, v);
-        CIRS_CHECK_LAUNCH("finalize_dh2_kernel");
-        // 6. critic + trunk backward:  d a1 = (d a2 * W2) masked by relu'(h1)
-        launch_rows_gemm(false, v.da2, kH, w.w2, kH, nullptr, n_pad, kH, kH, 0, v.h1, 0, v.da1, kH, s);
-        CIRS_CHECK_LAUNCH("dx(h1)");
+        const int tpc = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)2 * device_cu_count()));
+        const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
+        hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(n_bchunks, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc, w.wa, w.ba, v, v.dwap);
+        CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
+        // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
+        static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");
+        CIRS_REQUIRE(S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
+        hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM), dim3(512), 0, s, (int)mb, n_pad, n_bchunks, S, w.w1, w.w2, w.wc, v, dobs_accum);
+        CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
         {   // d wc/d bc, d W2/d b2, d W1/d b1 in one launch pair (same rows, fixed-order slab sums)
             DwJobs jobs;
             jobs.n = 3;
             jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
             jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
             jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
-            launch_dw_multi(jobs, mb, v.dwp, s);
+            // single-rank path: only the slab partials; the slab sums are folded into sumsq_partial_kernel below
+            n_dw_slabs = launch_dw_multi(jobs, mb, v.dwp, s, phase == 1);
+            dw_jobs = jobs;
             CIRS_CHECK_LAUNCH("dw(critic, w2, w1)");
-        }
-        if (dobs_accum) {  // d obs = d a1 * W1, written straight to the tracker-gradient tensor at (row_t, row_env)
-            launch_rows_gemm(false, v.da1, kH, w.w1, S, nullptr, mb, kH, S, 0, nullptr, 0, dobs_accum, S, s, v.dst_row);
-            CIRS_CHECK_LAUNCH("dx(obs)");
         }
         if (phase == 1) {  // gradients + loss partials must be complete in `grads` before the caller's all-reduce
             hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, mb, mb_global, v, tail);
             CIRS_CHECK_LAUNCH("loss_partials_kernel");
-            hipLaunchKernelGGL(reduce_dwa_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, s, v.dwap, seg, grads + L.wa);
+            hipLaunchKernelGGL(reduce_dwa_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, s, v.dwap, seg, (long)dwa_slab_stride(I), n_slabs, grads + L.wa);
             CIRS_CHECK_LAUNCH("reduce_dwa_kernel");
             return CIRS_OK;
         }
     }
     // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps; heads: once)
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg,
-                       phase == 0 ? v.dwap : (const float*)nullptr, v.normp);
-    hipLaunchKernelGGL(gradnorm_final_kernel, dim3(1), dim3(256), 0, s, *cfg, v.normp, tail, v, loss_out, phase == 0 ? (int)mb : 0,
-                       (int)(idx_global ? mb_global : mb));
-    CIRS_CHECK_LAUNCH("gradnorm");
+                       phase == 0 ? v.dwap : (const float*)nullptr, (long)dwa_slab_stride(I), n_slabs, dw_jobs, n_dw_slabs,
+                       phase == 0 ? (const float*)v.dwp : (const float*)nullptr, S, v.normp);
+    CIRS_CHECK_LAUNCH("sumsq_partial_kernel");
     auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
         AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};
         for (int q = 0; q < n_sub; ++q) {
@@ -863,7 +971,8 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
     };
     // trunk: two sequential sub-steps (steps 2k+1, 2k+2), clip coefficient squared; heads: one step, coefficient once
     hipLaunchKernelGGL(adam2_kernel, dim3(cdiv(L.total, 256)), dim3(256), 0, s, params, grads, adam_m, adam_v, L.total, L.trunk,
-                       seg_of(2 * opt_step, 2, 2), seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, v.red + 4);
+                       seg_of(2 * opt_step, 2, 2), seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, *cfg, v.normp, tail, v,
+                       loss_out, phase == 0 ? (int)mb : 0, (int)(idx_global ? mb_global : mb));
     CIRS_CHECK_LAUNCH("adam2_kernel");
     return CIRS_OK;
 }

@@ -193,6 +193,20 @@ static __global__ __launch_bounds__(64) void dw_multi_kernel(DwJobs jobs, int R,
     }
 }
 
+// sum of the slab partials of flat output element i of job jb (fixed slab order); device-side twin of dw_multi_final
+__device__ __forceinline__ float dw_multi_fetch(const DwJob& jb, int n_slabs, const float* __restrict__ partial, int i) {
+    const int n_out = jb.O * (jb.K + 1);
+    float acc = 0.f;
+    for (int c0 = 0; c0 < n_slabs; c0 += 16) {  // all loads of a batch in flight, added in slab order
+        float t16[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t16[q] = (c0 + q < n_slabs) ? partial[jb.part_off + (size_t)(c0 + q) * n_out + i] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += t16[q];
+    }
+    return acc;
+}
+
 static __global__ __launch_bounds__(256) void dw_multi_final(DwJobs jobs, int n_slabs, const float* __restrict__ partial) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= jobs.total_out) return;
@@ -204,8 +218,7 @@ static __global__ __launch_bounds__(256) void dw_multi_final(DwJobs jobs, int n_
     }
     const DwJob jb = jobs.j[ji];
     const int n_out = jb.O * (jb.K + 1);
-    float acc = 0.f;
-    for (int c = 0; c < n_slabs; ++c) acc += partial[jb.part_off + (size_t)c * n_out + i];
+    const float acc = dw_multi_fetch(jb, n_slabs, partial, i);
     const int o = i / (jb.K + 1), k = i % (jb.K + 1);
     if (k < jb.K) jb.dW[(size_t)o * jb.K + k] = acc;
     else if (jb.db) jb.db[o] = acc;
@@ -217,7 +230,8 @@ __host__ inline size_t dwg_multi_partial_floats(long R, const int* O, const int*
     return f;
 }
 
-static inline void launch_dw_multi(DwJobs& jobs, int R, float* partial, hipStream_t s) {
+// with_final = false: only the slab partials are produced (the caller folds the slab sums into a later kernel)
+static inline int launch_dw_multi(DwJobs& jobs, int R, float* partial, hipStream_t s, bool with_final = true) {
     const int slabs = dwg_slabs(R);
     int rows_per_slab = (R + slabs - 1) / slabs;
     rows_per_slab = (rows_per_slab + 15) & ~15;
@@ -232,7 +246,8 @@ static inline void launch_dw_multi(DwJobs& jobs, int R, float* partial, hipStrea
     jobs.total_tiles = tiles;
     jobs.total_out = out;
     hipLaunchKernelGGL(dw_multi_kernel, dim3(tiles, slabs), dim3(64), 0, s, jobs, R, rows_per_slab, slabs, partial);
-    hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(out, 256)), dim3(256), 0, s, jobs, slabs, partial);
+    if (with_final) hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(out, 256)), dim3(256), 0, s, jobs, slabs, partial);
+    return slabs;
 }
 
 }  // namespace cirs
