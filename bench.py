@@ -31,9 +31,9 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
-# measured on MI355X, see profiles/r01_pmc_head_kernels.md: (2*FETCH_SIZE + WRITE_SIZE) KB summed over
-# actor_head_kernel<stats>, head_bwd_dwa_kernel, head_bwd_dh2_kernel of one 1024-row minibatch at I = 10728
-PMC_TRAFFIC_BYTES_PER_MINIBATCH = int((2 * (3885.8 + 3914.0 + 3952.2) + (1030.2 + 21791.3 + 22321.3)) * 1024)
+# measured on MI355X, see profiles/r01f_pmc_minibatch_step.md: (2*FETCH_SIZE + WRITE_SIZE) KB summed over the eight
+# kernels of one 1024-row PPO minibatch step at I = 10728 (separate rocprofv3 --pmc passes)
+PMC_TRAFFIC_BYTES_PER_MINIBATCH = int((2 * 38180 + 68266) * 1024)
 
 
 def build_engine(wl, rank, world, device):
@@ -203,9 +203,13 @@ def main():
     if rank == 0:
         t_mb, mb = hip_event_kernel_time(eng, wl)
         I = wl["I"]
-        # ALGORITHMIC flop of one PPO minibatch step on the actor head: forward statistics 2*mb*I*64,
-        # two backward kernels that each recompute the logits tile and contract it once more: 2 * (2*2*mb*I*64)
-        flop = 10.0 * mb * I * 64
+        # ALGORITHMIC flop of one PPO minibatch step, SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) (forward + the two
+        # backward products of every dense layer) = 4.25 GFLOP at mb = 1024, I = 10728.  EXECUTED on the matrix cores:
+        # 8*mb*I*64 on the actor head (forward statistics pass + ONE recompute of the logits in the fused backward
+        # kernel, instead of a B x I probability matrix in HBM) + the trunk layers.
+        S, H = 20, 64
+        flop = 6.0 * mb * (S * H + H * H + H * I)
+        executed = 8.0 * mb * I * H + 6.0 * mb * (S * H + H * H)
         achieved = flop / t_mb / 1e12
         out = {
             "metric": "simulator env-steps/s (collect + PPO update in the timed region), KuaishouEnv",
@@ -219,14 +223,16 @@ def main():
             "ppo_minibatch_steps_per_s": mb_steps / elapsed,
             "rollout_only_env_steps_per_s": n_ro / (tb - ta),
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
-            "roofline": {"bound": "mfma", "kernel": "PPO minibatch step: actor_head_kernel<stats> + head_bwd_dwa_kernel + head_bwd_dh2_kernel (+ small kernels)",
+            "roofline": {"bound": "mfma", "kernel": "PPO minibatch step (one cirs_ppo_minibatch call: actor_head_kernel<stats> + head_bwd_fused_kernel "
+                                                      "+ 6 small kernels), fp32 MFMA",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": None, "seconds_per_launch": t_mb, "rows": mb},
+                         "achieved_executed": executed / t_mb / 1e12, "frac_executed": executed / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "algorithmic_flop_per_launch": flop, "traffic": None, "seconds_per_launch": t_mb, "rows": mb},
         }
-        # HBM traffic of the three MFMA head kernels of one minibatch step from the committed PMC passes
-        # (profiles/r01_pmc_head_kernels.md: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as reported)
+        # HBM traffic of one minibatch step (all eight kernels) from the committed PMC passes
+        # (profiles/r01f_pmc_minibatch_step.md: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as reported)
         out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_PER_MINIBATCH if args.workload == "c3" else None
-        out["roofline"]["traffic_source"] = "profiles/r01_pmc_head_kernels.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
+        out["roofline"]["traffic_source"] = "profiles/r01f_pmc_minibatch_step.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
         out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)

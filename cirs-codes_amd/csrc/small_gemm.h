@@ -5,7 +5,7 @@
 // 32 x 32 output tile:
 //   rows_gemm   Y[R,N] (+)= X[R,Kd] * B  (+ bias, relu, relu-mask)   with B[kd,n] = W[n*ldw+kd] ("NT": forward linear,
 //               Y = X W^T) or W[kd*ldw+n] ("NN": backward dX = dY W).  Fixed k order -> deterministic.
-//   dw_gemm     dW[O,K] = sum_r dY[r,O]^T X[r,K], db[O] = sum_r dY[r,O]; rows are split into <= 64 contiguous slabs
+//   dw_gemm     dW[O,K] = sum_r dY[r,O]^T X[r,K], db[O] = sum_r dY[r,O]; rows are split into <= 128 contiguous slabs
 //               (one wavefront each), slab partials are summed in slab order by dw_gemm_final: fixed order, no atomics.
 #pragma once
 #include "common.h"
@@ -64,7 +64,7 @@ static inline void launch_rows_gemm(bool nt, const float* X, int ldx, const floa
     else hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy, out_row);
 }
 
-constexpr int kDwMaxSlabs = 32;
+constexpr int kDwMaxSlabs = 128;  // 30 k buffer rows -> ~230 rows (15 load batches) per wavefront instead of ~920
 __host__ inline int dwg_slabs(long R) {
     const long want = (R + 63) / 64;  // >= 64 rows per slab
     return (int)(want < 1 ? 1 : (want > kDwMaxSlabs ? kDwMaxSlabs : want));
@@ -120,7 +120,13 @@ static __global__ __launch_bounds__(256) void dw_gemm_final(const float* __restr
     const int n_out = O * (K + 1);
     if (i >= n_out) return;
     float acc = 0.f;
-    for (int c = 0; c < n_slabs; ++c) acc += partial[(size_t)c * n_out + i];
+    for (int c0 = 0; c0 < n_slabs; c0 += 16) {  // 16 loads in flight, added in slab order
+        float t16[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t16[q] = (c0 + q < n_slabs) ? partial[(size_t)(c0 + q) * n_out + i] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += t16[q];
+    }
     const int o = i / (K + 1), k = i % (K + 1);
     if (k < K) dW[(size_t)o * K + k] = acc;
     else if (db) db[o] = acc;

@@ -8,6 +8,7 @@
 // matters is that everything stays on device and every reduction has a fixed order.
 //   weight gradients : chunk-partial sums over 256-row chunks, then an ordered sum over chunks (two launches)
 //   embedding tables : per-row contributions, then one wavefront per table row sums its rows in a fixed order
+#include <hipcub/hipcub.hpp>
 #include "small_gemm.h"
 
 namespace cirs {
@@ -297,41 +298,69 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
     }
 }
 
-// Deterministic embedding-gradient scatter: one wavefront per table row scans the row keys; lane l accumulates the
-// matching rows r = l, l+64, ... in ascending order and the 64 lane sums are combined by a fixed butterfly, so the
-// result does not depend on scheduling (no float atomics).  O(rows x table) key reads, all from L2.
-__global__ __launch_bounds__(256) void emb_scatter_kernel(const int32_t* __restrict__ keys, const float* __restrict__ contrib, int R,
-                                                          int n_table, float* __restrict__ g_emb) {
-    const int lane = threadIdx.x & 63;
-    const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (id >= n_table) return;
-    float acc[tD];
+// Deterministic embedding-gradient scatter without float atomics and without an O(rows x table) scan: the (key, row)
+// pairs are sorted by key with a stable radix sort (rows stay ascending inside a key), then one 32-lane group per
+// segment head adds the contribution rows of its key in row order.  Cost O(rows), independent of the table size
+// (a 10^6-row catalogue costs the same as 10^4), result independent of scheduling.
+__global__ __launch_bounds__(256) void scatter_keys_kernel(const int32_t* __restrict__ keys, int R, int n_table,
+                                                           uint32_t* __restrict__ keys_u, int32_t* __restrict__ rows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int32_t k = keys[r];
+    keys_u[r] = (k < 0 || k >= n_table) ? (uint32_t)n_table : (uint32_t)k;  // rows without a contribution sort last
+    rows[r] = r;
+}
+
+__global__ __launch_bounds__(256) void emb_segment_sum_kernel(const uint32_t* __restrict__ ks, const int32_t* __restrict__ rs,
+                                                              const float* __restrict__ contrib, int R, int n_table,
+                                                              float* __restrict__ g_emb) {
+    const int d = threadIdx.x & 31;
+    const int p = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (p >= R) return;
+    const uint32_t key = ks[p];
+    if (key >= (uint32_t)n_table || (p > 0 && ks[p - 1] == key)) return;  // not a segment head
+    float acc = 0.f;
+    int q = p;
+    while (q < R) {  // batches of 8 rows: loads in flight together, added in row order
+        float t8[8];
+        int n_ok = 0;
 #pragma unroll
-    for (int d = 0; d < tD; ++d) acc[d] = 0.f;
-    bool any = false;
-    for (int r = lane; r < R; r += CIRS_WAVE) {
-        if (keys[r] == id) {
-            any = true;
-            const float4* c4 = reinterpret_cast<const float4*>(contrib + (size_t)r * tD);
-#pragma unroll
-            for (int q = 0; q < tD / 4; ++q) {
-                const float4 t4 = c4[q];
-                acc[4 * q] += t4.x; acc[4 * q + 1] += t4.y; acc[4 * q + 2] += t4.z; acc[4 * q + 3] += t4.w;
-            }
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = (n_ok == u) && (q + u < R) && ks[q + u] == key;
+            t8[u] = ok ? contrib[(size_t)rs[q + u] * tD + d] : 0.f;
+            n_ok += ok;
         }
-    }
-    if (__ballot(any) == 0ull) {
-        if (lane < tD) g_emb[(size_t)id * tD + lane] = 0.f;
-        return;
-    }
 #pragma unroll
-    for (int d = 0; d < tD; ++d) acc[d] = wave_sum_f32(acc[d]);
-    if (lane < tD) {
-        float val = 0.f;
-#pragma unroll
-        for (int d = 0; d < tD; ++d) val = lane == d ? acc[d] : val;
-        g_emb[(size_t)id * tD + lane] = val;
+        for (int u = 0; u < 8; ++u) acc += (u < n_ok) ? t8[u] : 0.f;
+        if (n_ok < 8) break;
+        q += 8;
     }
+    g_emb[(size_t)key * tD + d] = acc;
+}
+
+static size_t emb_sort_bytes(long R) { return (size_t)R * 64 + (1u << 20); }
+
+// keys [R] (< 0: no contribution), contrib [R, 32] -> g_emb [n_table, 32] (fully overwritten)
+static int emb_scatter_sorted(const int32_t* keys, const float* contrib, int R, int n_table, float* g_emb, void* scratch,
+                              size_t scratch_bytes, hipStream_t s) {
+    static_assert(tD == 32, "emb_segment_sum_kernel maps one lane per embedding dimension");
+    uint32_t* k_in = (uint32_t*)scratch;
+    uint32_t* k_out = k_in + R;
+    int32_t* r_in = (int32_t*)(k_out + R);
+    int32_t* r_out = r_in + R;
+    char* temp = (char*)(((uintptr_t)(r_out + R) + 255) & ~(uintptr_t)255);
+    const size_t avail = scratch_bytes - (size_t)(temp - (char*)scratch);
+    int end_bit = 1;
+    while ((1u << end_bit) <= (uint32_t)n_table && end_bit < 32) ++end_bit;
+    size_t need = 0;
+    CIRS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, r_in, r_out, R, 0, end_bit, s));
+    CIRS_REQUIRE(need <= avail, "embedding scatter: sort scratch too small");
+    CIRS_HIP(hipMemsetAsync(g_emb, 0, (size_t)n_table * tD * sizeof(float), s));
+    hipLaunchKernelGGL(scatter_keys_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, keys, R, n_table, k_in, r_in);
+    CIRS_HIP(hipcub::DeviceRadixSort::SortPairs(temp, need, k_in, k_out, r_in, r_out, R, 0, end_bit, s));
+    hipLaunchKernelGGL(emb_segment_sum_kernel, dim3(cdiv(R, 8)), dim3(256), 0, s, k_out, r_out, contrib, R, n_table, g_emb);
+    CIRS_CHECK_LAUNCH("emb_segment_sum_kernel");
+    return CIRS_OK;
 }
 
 struct BwdScratch {
@@ -340,6 +369,7 @@ struct BwdScratch {
     float *XH1[CIRS_MAX_TRACKER_LAYERS], *RS1[CIRS_MAX_TRACKER_LAYERS], *H1N[CIRS_MAX_TRACKER_LAYERS], *FF1[CIRS_MAX_TRACKER_LAYERS];
     float *XH2[CIRS_MAX_TRACKER_LAYERS], *RS2[CIRS_MAX_TRACKER_LAYERS];
     float *T0, *T1, *T2, *dQKV, *dFF1, *dS, *partial, *GIN, *lnfull;
+    void* sort;  // emb_sort_bytes(R)
 };
 
 static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
@@ -352,6 +382,7 @@ static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     f += dwg_partial_floats(R, tH, tD) + dwg_partial_floats(R, 2, tD) + 4096;  // partial (largest: 128 x 33)
     f += (size_t)R * (tD + 1);                    // GIN
     f += tD * tD + 64;                            // lnfull
+    f += emb_sort_bytes(R) / 4 + 64;              // (key, row) sort of the embedding scatter
     return f + 64 * 32;
 }
 
@@ -372,6 +403,7 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
     s.partial = take(dwg_partial_floats(R, tH, tD) + dwg_partial_floats(R, 2, tD) + 4096);
     s.GIN = take((size_t)R * (tD + 1));
     s.lnfull = take(tD * tD + 64);
+    s.sort = (void*)take(emb_sort_bytes(R) / 4 + 64);
     return s;
 }
 
@@ -477,8 +509,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     int32_t* key_item = (int32_t*)sc.RS2[0];
     hipLaunchKernelGGL(slot_bwd, dim3(cdiv(R, 4)), dim3(256), 0, s, *w, dH, users, act, rew, row_env, row_t, R, B, DU, EU, DPRE,
                        sc.GIN, CU, CI, key_user, key_item);
-    hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(cfg->n_users, 4)), dim3(256), 0, s, key_user, CU, R, cfg->n_users, grads->emb_user);
-    hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(cfg->n_items, 4)), dim3(256), 0, s, key_item, CI, R, cfg->n_items, grads->emb_item);
+    if (int rc = emb_scatter_sorted(key_user, CU, R, cfg->n_users, grads->emb_user, sc.sort, emb_sort_bytes(R), s)) return rc;
+    if (int rc = emb_scatter_sorted(key_item, CI, R, cfg->n_items, grads->emb_item, sc.sort, emb_sort_bytes(R), s)) return rc;
     DW(DU, EU, tD, tD, grads->ffn_user_w, grads->ffn_user_b);
     DW(DPRE, sc.GIN, tD, tD + 1, grads->gate_w, grads->gate_b);
     CIRS_CHECK_LAUNCH("tracker backward slots");
