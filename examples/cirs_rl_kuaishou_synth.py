@@ -64,6 +64,7 @@ def get_args(argv=None):
     p.add_argument("--test-num", type=int, default=100)
     p.add_argument("--force_length", type=int, default=10)
     p.add_argument("--step-per-epoch", type=int, default=2000)
+    p.add_argument("--top_rate", type=float, default=0.8)
     p.add_argument("--n-users", type=int, default=1411)
     p.add_argument("--n-items", type=int, default=3327)
     return p.parse_args(argv)
@@ -129,10 +130,34 @@ def build_test_collectors(args, policy, state_tracker):
                         force_length=args.force_length)
 
 
+def build_callbacks(args, tab, test_collector_set):
+    """Coverage / feature-domination / log callbacks (reference :303-316); the 'training log' is synthetic."""
+    import pandas as pd
+    from environments.KuaishouRec.env.data_handler import get_sorted_domination_features
+    from evaluation import Callback_Coverage_Count
+    from util.utils import LoggerCallback_Policy
+    n_raw = int(tab.raw_pid.max()) + 1
+    feats = np.zeros((n_raw, 4), np.int64)  # category ids shifted by one, 0 = none (data_handler.py:29-33)
+    for rp in range(n_raw):
+        f = tab.list_feat[rp]
+        feats[rp, :len(f)] = np.asarray(f) + 1
+    df_item = pd.DataFrame(feats, columns=["feat0", "feat1", "feat2", "feat3"])
+    rng = np.random.RandomState(args.seed)
+    df_data = pd.DataFrame({"photo_id": rng.randint(0, n_raw, 20000), "watch_ratio": rng.gamma(2.0, 0.5, 20000)})
+    df_data = df_data.join(df_item, on=["photo_id"], how="left")
+    item_feat_domination = get_sorted_domination_features(df_data, df_item, is_multi_hot=True, yname="watch_ratio",
+                                                          threshold=np.percentile(df_data["watch_ratio"], 80))
+    lbe_photo = types.SimpleNamespace(classes_=tab.raw_pid)
+    return [Callback_Coverage_Count(test_collector_set, df_item, need_transform=True, item_feat_domination=item_feat_domination,
+                                    lbe_photo=lbe_photo, top_rate=args.top_rate),
+            LoggerCallback_Policy("cirs_rl_kuaishou_synth.log", args.force_length)]
+
+
 def main(argv=None):
     args = get_args(argv)
     tab, train_envs, state_tracker, policy, train_collector = build(args)
     test_collector_set = build_test_collectors(args, policy, state_tracker)
+    policy.callbacks = build_callbacks(args, tab, test_collector_set)
     result = onpolicy_trainer(policy, train_collector, test_collector_set, state_tracker, args.epoch, args.step_per_epoch,
                               args.repeat_per_collect, args.test_num, args.batch_size, episode_per_collect=args.episode_per_collect,
                               save_model_fn=lambda epoch, policy: None)

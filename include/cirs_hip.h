@@ -400,6 +400,17 @@ int cirs_deepfm_sweep(const cirs_deepfm_cfg* cfg, const cirs_deepfm_weights* w, 
 /* normed = (pred - min) / (max - min) in float64 (kuaishouEnv.py:139-143) */
 int cirs_normed_reward(const float* pred, int64_t n, const float* minmax, double* normed_out, void* stream);
 
+/* ---- evaluation metrics on device trajectories ---------------------------------------------------
+ * Replaces the buffer walks of Callback_Coverage_Count.on_epoch_end (reference evaluation.py:303-352) and the
+ * row test of get_feat_dominate_dict (evaluation.py:36-44):
+ *   act       [n] int64: the time-major act tensor of a rollout ([T,B], -1 where an env had finished)
+ *   item_flag [n_items] u8 or NULL: 1 if the item has one of the dominating feature values
+ *   bitmap    [ceil(n_items/32)] scratch
+ *   out3      {hit_item, n_acts, n_flagged}: CV = hit_item / n_items, CV_turn = hit_item / n_acts,
+ *             ifeat_feat = n_flagged / n_acts */
+int cirs_eval_coverage(const int64_t* act, int64_t n, int32_t n_items, const uint8_t* item_flag, uint32_t* bitmap,
+                       int64_t* out3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
-sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd"))
+# NOTE: cirs-codes_amd/ must NOT be on sys.path here: its mirror packages (`environments`, `core`, ...) carry the
+# reference's module names and `environments` (a namespace package in the reference) would shadow the reference's.
 
 import ref_harness  # noqa: E402
 
@@ -32,7 +33,13 @@ import pandas as pd  # noqa: E402
 import torch  # noqa: E402
 from sklearn.preprocessing import LabelEncoder  # noqa: E402
 
-from cirs_hip.synthetic import make_tables  # noqa: E402
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("cirs_synthetic", os.path.join(ROOT, "cirs-codes_amd", "cirs_hip", "synthetic.py"))
+_syn = importlib.util.module_from_spec(_spec)
+sys.modules["cirs_synthetic"] = _syn
+_spec.loader.exec_module(_syn)
+make_tables = _syn.make_tables
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLDEN, exist_ok=True)
@@ -404,7 +411,85 @@ def gen_deepfm():
           "feat row0 norm", float(np.abs(out["emb_feat"][0]).max()), "keys", [k for k in sd.keys()][:30])
 
 
-FAMILIES = {"deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+def gen_evalmetrics():
+    """Callback_Coverage_Count.on_epoch_end + get_feat_dominate_dict + get_sorted_domination_features + LoggerCallback_Policy
+    (reference evaluation.py:10-77,286-371, environments/KuaishouRec/env/data_handler.py:98-122, util/utils.py:83-137) on
+    replay buffers filled exactly like Collector.collect does (one fresh VectorReplayBuffer per collector)."""
+    from types import SimpleNamespace
+    from evaluation import Callback_Coverage_Count, get_feat_dominate_dict
+    from environments.KuaishouRec.env.data_handler import get_sorted_domination_features
+    from tianshou.data import Batch, VectorReplayBuffer
+    rng = np.random.RandomState(11)
+    tab = make_tables(40, 150, seed=3, build_dist=False)
+    I = tab.n_items
+    raw_pid = tab.raw_pid
+    n_raw = int(raw_pid.max()) + 1
+    # df_item (indexed by RAW photo id, feat ids shifted by one, 0 = none; data_handler.py:29-33)
+    feats_raw = np.zeros((n_raw, 4), np.int64)
+    for rp in range(n_raw):
+        f = tab.list_feat[rp]
+        feats_raw[rp, :len(f)] = np.asarray(f) + 1
+    df_item = pd.DataFrame(feats_raw, columns=["feat0", "feat1", "feat2", "feat3"])
+    df_item.index.name = "photo_id"
+    # training log -> domination list (multi-hot branch)
+    n_log = 4000
+    log_pid = rng.randint(0, n_raw, n_log)
+    df_data = pd.DataFrame({"photo_id": log_pid, "watch_ratio": rng.gamma(2.0, 0.5, n_log)})
+    df_data = df_data.join(df_item, on=["photo_id"], how="left")
+    thr = np.percentile(df_data["watch_ratio"], 80)
+    dom = get_sorted_domination_features(df_data, df_item, is_multi_hot=True, yname="watch_ratio", threshold=thr)
+    lbe_photo = LabelEncoder().fit(raw_pid)
+    out = dict(raw_pid=raw_pid, feats_raw=feats_raw, log_pid=log_pid, log_ratio=df_data["watch_ratio"].to_numpy(), log_thr=thr,
+               dom_values=np.array([p[0] for p in dom["feat"]], np.int64), dom_shares=np.array([p[1] for p in dom["feat"]], np.float64),
+               n_items=I)
+    cases = []
+    B, T = 12, 9
+    for ci, (top_rate, peaked) in enumerate([(0.8, False), (0.6, True), (0.05, False), (0.95, True)]):
+        names = ["FB", "NX_0", "NX_4"]
+        coll = {}
+        results = {"n/ep": B}
+        rec = {}
+        for name in names:
+            buf = VectorReplayBuffer(B * (T + 2), B)
+            lens = rng.randint(1, T + 1, B)
+            if name == "NX_4":
+                lens[:] = 4
+            p = np.ones(I) / I
+            if peaked:
+                p = rng.dirichlet(np.full(I, 0.05))
+            acts = np.full((B, T), -1, np.int64)
+            idxs = np.zeros(B, np.int64)
+            ready = np.arange(B)
+            for t in range(T):
+                live = ready[lens[ready] > t]
+                if len(live) == 0:
+                    break
+                a = rng.choice(I, size=len(live), p=p)
+                acts[live, t] = a
+                done = lens[live] == t + 1
+                batch = Batch(obs=np.zeros((len(live), 1)), act=a, rew=rng.uniform(size=len(live)), done=done,
+                              obs_next=np.zeros((len(live), 1)), info=Batch(), policy=Batch())
+                ptr, ep_rew, ep_len, ep_idx = buf.add(batch, buffer_ids=live)
+                idxs[live[done]] = ep_idx[done]
+            coll[name] = SimpleNamespace(buffer=buf)
+            results[("" if name == "FB" else name + "_") + "idxs"] = idxs
+            rec[name] = (acts, lens)
+        tcs = SimpleNamespace(collector_dict=coll, env=SimpleNamespace(mat=[np.zeros((tab.n_users, I))]))
+        cb = Callback_Coverage_Count(tcs, df_item, True, dom, lbe_photo, top_rate)
+        res = cb.on_epoch_end(0, results=dict(results))
+        for name in names:
+            pre = "" if name == "FB" else name + "_"
+            acts, lens = rec[name]
+            out[f"c{ci}_{name}_acts"] = acts; out[f"c{ci}_{name}_lens"] = lens
+            out[f"c{ci}_{name}_out"] = np.array([res[pre + "CV"], res[pre + "CV_turn"], res[pre + "ifeat_feat"]], np.float64)
+        out[f"c{ci}_top_rate"] = top_rate
+        cases.append(ci)
+    out["n_cases"] = len(cases)
+    np.savez_compressed(os.path.join(GOLDEN, "evalmetrics.npz"), **out)
+    print("evalmetrics.npz:", {k: out[k] for k in out if k.endswith("_out")}, "dom", out["dom_values"][:6], out["dom_shares"][:6])
+
+
+FAMILIES = {"evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

@@ -112,3 +112,27 @@ def test_trainer_loop_with_test_collector_set():
         assert len(set(a.tolist())) == len(a)
     # the training tracker state (Adam step counter) survived the differently sized test engines
     assert st.adam_steps >= 2
+
+
+def test_trainer_with_coverage_and_logger_callbacks():
+    """The evaluation callbacks of CIRS-RL-kuaishou.py:303-316 on the device trajectories of the three test collectors."""
+    ex = load_example()
+    args = ex.get_args(["--n-users", "150", "--n-items", "400", "--training-num", "16", "--episode-per-collect", "16", "--test-num", "8",
+                        "--batch-size", "64", "--max_turn", "20", "--tau", "10", "--epoch", "1", "--step-per-epoch", "100",
+                        "--force_length", "10", "--leave_threshold", "0", "--num_leave_compute", "1"])
+    tab, train_envs, st, policy, coll = ex.build(args)
+    cs = ex.build_test_collectors(args, policy, st)
+    policy.callbacks = cbs = ex.build_callbacks(args, tab, cs)
+    from core.trainer.onpolicy import onpolicy_trainer
+    onpolicy_trainer(policy, coll, cs, st, args.epoch, args.step_per_epoch, args.repeat_per_collect, args.test_num, args.batch_size,
+                     episode_per_collect=args.episode_per_collect, save_model_fn=lambda epoch, policy: None, verbose=False)
+    line = cbs[1].last_results
+    assert {"CV", "CV_turn", "ctr", "len_tra", "R_tra", "ifeat_feat", "NX_0_CV", "NX_10_CV_turn", "NX_10_ifeat_feat"} <= set(line)
+    assert line["NX_10_len_tra"] == 10.0 and 0.0 < float(line["NX_0_CV_turn"]) <= 1.0
+    # cross-check the FB numbers against a host recount of the collector's trajectory
+    import evalcase
+    acts = cs.collector_dict["FB"].buffer._rollout.traj.act.cpu().numpy()
+    flags = cbs[0]._flags["ifeat_feat"].cpu().numpy()
+    hit, n, fl = evalcase.oracle_counts(acts, tab.n_items, flags)
+    assert line["CV"] == f"{hit / tab.n_items:.5f}" and line["CV_turn"] == f"{hit / n:.5f}" and line["ifeat_feat"] == fl / n
+    assert line["len_tra"] == n / 8
