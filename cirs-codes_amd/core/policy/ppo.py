@@ -61,6 +61,49 @@ class PPOPolicy(nn.Module):
         self.__dict__["_tracker"] = None   # set by the Collector (preprocess_fn's owner)
         self.__dict__["_train_n_env"] = None
         self.seed = int(torch.initial_seed() & 0x7FFFFFFF)
+        # checkpoints: optim[i].state_dict() / load_state_dict() carry the device Adam state (CIRS-RL-kuaishou.py:340-358)
+        from cirs_hip import optim_bridge
+        self._restored_RL = None  # Adam state loaded before the learner exists
+        optim_bridge.bind(optim_RL, self._adam_state_RL)
+        if isinstance(optim, (list, tuple)) and len(optim) > 1:
+            optim_bridge.bind(optim[1], self._adam_state_tracker)
+
+    def _adam_state_RL(self, create=False):
+        ln = self._learner
+        if ln is None:
+            if not create:
+                return None
+            # resume before the first update: keep the moments until the learner is built
+            m, v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+            self._restored_RL = dict(m=m, v=v, opt_step=0)
+            holder = self._restored_RL
+            trunk_end = self.views["actor.last.model.0.weight"].data_ptr() - self.flat.data_ptr()
+
+            def set_steps(steps):
+                heads = [s for off, s in steps if off * 4 >= trunk_end]
+                holder["opt_step"] = heads[0] if heads else 0
+            return dict(flat=self.flat, m=m, v=v, steps=lambda off: 0, set_steps=set_steps)
+        trunk_floats = (self.views["actor.last.model.0.weight"].data_ptr() - self.flat.data_ptr()) // 4
+
+        def set_steps(steps):
+            heads = [s for off, s in steps if off >= trunk_floats]
+            if heads:
+                ln.opt_step = heads[0]
+        # the shared trunk appears twice in the reference's parameter list: two Adam sub-steps per optimiser step
+        return dict(flat=self.flat, m=ln.adam_m, v=ln.adam_v, steps=lambda off: (2 if off < trunk_floats else 1) * ln.opt_step,
+                    set_steps=set_steps)
+
+    def _adam_state_tracker(self, create=False):
+        trk = self._tracker
+        if trk is None:
+            return None
+        eng = trk.engine(trk._n_env or self._train_n_env or 1)
+
+        def set_steps(steps):
+            if steps:
+                trk.adam_steps = steps[0][1]
+                eng.adam_steps = trk.adam_steps
+        return dict(flat=trk.flat, m=eng.adam_m, v=eng.adam_v, steps=lambda off: trk.adam_steps, set_steps=set_steps)
 
     # ---- protocol pieces the Collector / trainer call ----------------------------------------------------------------
     def device_policy(self) -> DevicePolicy:
@@ -90,6 +133,10 @@ class PPOPolicy(nn.Module):
                                           value_clip=h["value_clip"], rew_norm=h["rew_norm"], betas=h["betas"], adam_eps=h["adam_eps"])
             if rms is not None:
                 self._learner.rms_state.copy_(rms)
+            if self._restored_RL is not None:  # optimiser state restored from a checkpoint before the first update
+                self._learner.adam_m.copy_(self._restored_RL["m"]); self._learner.adam_v.copy_(self._restored_RL["v"])
+                self._learner.opt_step = self._restored_RL["opt_step"]
+                self._restored_RL = None
         return self._learner
 
     def update(self, sample_size: int, buffer, batch_size: int = 1024, repeat: int = 2, perms=None, **kwargs) -> Dict[str, List[float]]:

@@ -407,6 +407,11 @@ def gen_deepfm():
                last=sd["last.weight"].numpy().reshape(-1), out_bias=sd["out.bias"].numpy().reshape(-1),
                alpha_u=sd["ab_embedding_dict.alpha_u.weight"].numpy()[raw_u, 0], beta_i=sd["ab_embedding_dict.beta_i.weight"].numpy()[raw_i, 0])
     np.savez_compressed(os.path.join(GOLDEN, "deepfm.npz"), **out)
+    # the shipped checkpoint pair itself is DATA (trained weights + constructor kwargs): kept as a fixture so the
+    # checkpoint interchange of SURVEY 8(f3) is tested on the real files
+    import shutil
+    for fn in ("DeepFM_Pair11.pt", "DeepFM_params_Pair11.pickle"):
+        shutil.copy(os.path.join(ref_harness.REF_ROOT, "reproduce_results_of_our_paper", "results_alpha_beta", fn), os.path.join(GOLDEN, fn))
     print("deepfm.npz: y range", float(y.min()), float(y.max()), "pred", pred.shape, "normed range", float(normed.min()), float(normed.max()),
           "feat row0 norm", float(np.abs(out["emb_feat"][0]).max()), "keys", [k for k in sd.keys()][:30])
 
@@ -489,7 +494,52 @@ def gen_evalmetrics():
     print("evalmetrics.npz:", {k: out[k] for k in out if k.endswith("_out")}, "dom", out["dom_values"][:6], out["dom_shares"][:6])
 
 
-FAMILIES = {"evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+def write_kuairec_files(root, log_user, log_photo, log_ratio, list_feat, durations):
+    """Tiny files in the KuaiRec layout the reference reads (kuaishouEnv.py:61-111)."""
+    import json
+    os.makedirs(root, exist_ok=True)
+    pd.DataFrame({"user_id": log_user, "photo_id": log_photo, "play_duration": 1, "watch_ratio": log_ratio}).to_csv(
+        os.path.join(root, "small_matrix.csv"), index=False)
+    with open(os.path.join(root, "item_categories.json"), "w") as fh:
+        json.dump({str(i): {"feature_index": [int(c) for c in f]} for i, f in enumerate(list_feat)}, fh)
+    with open(os.path.join(root, "photo_mean_duration.json"), "w") as fh:
+        json.dump({str(i): float(d) for i, d in enumerate(durations)}, fh)
+
+
+def gen_loaders():
+    """KuaishouEnv.load_mat + get_distance_mat (reference kuaishouEnv.py:61-111, core/util.py:225-273) on tiny files."""
+    import tempfile
+    import environments.KuaishouRec.env.kuaishouEnv as ke
+    import core.util as cu
+    rng = np.random.RandomState(5)
+    n_raw_item, n_raw_user = 60, 40
+    list_feat = [sorted(rng.choice(31, size=rng.randint(1, 5), replace=False).tolist()) for _ in range(n_raw_item)]
+    durations = rng.uniform(2, 60, n_raw_item)
+    users = rng.choice(n_raw_user, 25, replace=False); photos = rng.choice(n_raw_item, 33, replace=False)
+    uu, pp = np.meshgrid(users, photos, indexing="ij")
+    order = rng.permutation(uu.size)
+    log_user, log_photo = uu.ravel()[order], pp.ravel()[order]
+    log_ratio = rng.gamma(1.5, 1.2, uu.size)     # some > 5 (clipped)
+    with tempfile.TemporaryDirectory() as root:
+        write_kuairec_files(root, log_user, log_photo, log_ratio, list_feat, durations)
+        old = ke.DATAPATH
+        ke.DATAPATH = root
+        try:
+            mat, lbe_user, lbe_photo, lf, df_photo_env, df_dist_small = ke.KuaishouEnv.load_mat()
+        finally:
+            ke.DATAPATH = old
+        cached = pd.read_csv(os.path.join(root, "distance_mat_photo_small.csv"), index_col=0)
+    out = dict(log_user=log_user, log_photo=log_photo, log_ratio=log_ratio, durations=durations,
+               list_feat=np.array([f + [-1] * (4 - len(f)) for f in list_feat], np.int64),
+               mat=mat, user_classes=lbe_user.classes_, photo_classes=lbe_photo.classes_,
+               photo_env_index=df_photo_env.index.to_numpy(), photo_env_values=df_photo_env.to_numpy(dtype=np.float64),
+               dist=df_dist_small.to_numpy(dtype=np.float64), dist_index=df_dist_small.index.to_numpy(),
+               dist_columns=df_dist_small.columns.to_numpy().astype(np.int64), dist_csv=cached.to_numpy(dtype=np.float64))
+    np.savez_compressed(os.path.join(GOLDEN, "loaders.npz"), **out)
+    print("loaders.npz: mat", mat.shape, "max", mat.max(), "dist inf share", float(np.isinf(out["dist"]).mean()), "cols", list(df_photo_env.columns))
+
+
+FAMILIES = {"loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

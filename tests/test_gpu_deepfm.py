@@ -58,3 +58,20 @@ def test_sweep_full_baseline_shape_properties():
     for u in rows:
         ref = m.forward(np.full(ni, u), np.arange(ni), feats, dur)
         torch.testing.assert_close(pred[u], ref, rtol=1e-4, atol=2e-5)
+
+
+def test_shipped_checkpoint_forward_through_plugin_surface(golden_dir):
+    """The reference's files -> UserModel_Pairwise(**params).load_state_dict(...).forward(X) on the device."""
+    import pickle
+    from core.user_model_pairwise import UserModel_Pairwise
+    with open(os.path.join(golden_dir, "DeepFM_params_Pair11.pickle"), "rb") as fh:
+        params = pickle.load(fh)
+    params["device"] = "cpu"
+    model = UserModel_Pairwise(**params)
+    model.load_state_dict(torch.load(os.path.join(golden_dir, "DeepFM_Pair11.pt"), map_location="cpu", weights_only=False))
+    z = np.load(os.path.join(golden_dir, "deepfm.npz"))
+    pu, pi = z["pu"], z["pi"]
+    X = np.concatenate([z["raw_u"][pu][:, None], z["raw_i"][pi][:, None], z["feats"][pi], z["dur"][pi][:, None]], axis=1).astype(np.float32)
+    y = model.forward(torch.as_tensor(X)).cpu().numpy()
+    assert y.shape == (len(pu), 1)
+    np.testing.assert_allclose(y[:, 0], z["y"], rtol=1e-5, atol=2e-6)

@@ -21,3 +21,28 @@ def test_deepfm_oracle_matches_reference(golden_dir):
     normed = (p64 - p64.min()) / (p64.max() - p64.min())
     np.testing.assert_allclose(normed, z["normed"], atol=2e-6)
     assert np.abs(z["emb_feat"][0]).max() == 0.0  # padding row semantics: a zero vector in the trained table
+
+
+def test_shipped_checkpoint_unpickles_into_the_mirror(golden_dir):
+    """`UserModel_Pairwise(**pickle_params)` + `load_state_dict(torch.load(pt))` exactly as
+    CIRS-RL-kuaishou.py:141-161 does, with the reference's own files (host side only: no device call)."""
+    import os
+    import pickle
+    import torch
+    from core.user_model_pairwise import UserModel_Pairwise
+    with open(os.path.join(golden_dir, "DeepFM_params_Pair11.pickle"), "rb") as fh:
+        params = pickle.load(fh)
+    params["device"] = "cpu"
+    model = UserModel_Pairwise(**params)
+    sd = torch.load(os.path.join(golden_dir, "DeepFM_Pair11.pt"), map_location="cpu", weights_only=False)
+    model.load_state_dict(sd)
+    mine = model.state_dict()
+    assert set(mine) == set(sd), (set(mine) ^ set(sd))
+    for k in sd:
+        assert mine[k].shape == sd[k].shape and torch.equal(mine[k].cpu(), sd[k].cpu()), k
+    alpha_u = model.ab_embedding_dict["alpha_u"].weight.detach().cpu().numpy()
+    beta_i = model.ab_embedding_dict["beta_i"].weight.detach().cpu().numpy()
+    assert alpha_u.shape == (7176, 1) and beta_i.shape == (10729, 1)
+    z = np.load(os.path.join(golden_dir, "deepfm.npz"))
+    np.testing.assert_array_equal(alpha_u[z["raw_u"], 0], z["alpha_u"])
+    np.testing.assert_array_equal(beta_i[z["raw_i"], 0], z["beta_i"])
