@@ -110,6 +110,49 @@ def deepfm_sweep_probe(wl, device, E=16, reps=5):
             "cpu_reference_pairs_per_s": 1.78e6}
 
 
+def sweep_mode_probe(wl, eng, device, E=16, reps=5):
+    """The north-star's catalogue-sweep formulation: per vector step every env's user is scored
+    against the FULL catalogue by the DeepFM user model, one item is drawn per env from those scores (softmax sampling,
+    cirs_select_items) and the env steps.  Timed with HIP events on the launch stream, B = the workload's env count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import deepfmcase
+    from cirs_hip.deepfm import DeviceDeepFM
+    from cirs_hip.static_policy import select_items
+    U, I, B = wl["U"], wl["I"], wl["B"]
+    rng = np.random.RandomState(1)
+    m = DeviceDeepFM(deepfmcase.random_weights(rng, U, I + 1, E), device=device)
+    feats = torch.as_tensor(rng.randint(0, 32, (I, 4)).astype(np.int32)).to(device); dur = torch.as_tensor(rng.uniform(2, 60, I).astype(np.float32)).to(device)
+    users = torch.as_tensor(rng.randint(0, U, B)); items = torch.arange(I, device=device)
+    env = eng.env
+    env.reset(users)
+    users_d = users.to(device)
+
+    def step(k):
+        scores, _ = m.sweep(users_d, items, feats, dur, want_pred=True)
+        act, _ = select_items(scores, softmax=True, seed=7, rng_step=k, skip=env.done)
+        env.step(act)
+
+    step(0)
+    env.reset(users)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for k in range(reps):
+        step(k + 1)
+    stop.record()
+    torch.cuda.synchronize()
+    t = start.elapsed_time(stop) / reps * 1e-3
+    a_sweep = I * (4 * E + 24) + (4 * E + 4)                       # SURVEY 8(d): item-side DeepFM rows streamed once per env-step
+    f_sweep = I * (2.0 * ((6 * E + 1) * 64 + 64 * 64 + 64) + 18 * E)
+    steps_per_s = B / t
+    return {"env_steps_per_s": steps_per_s, "seconds_per_vector_step": t, "envs": B, "emb_dim": E,
+            "logical_hbm": {"bytes_per_env_step": a_sweep, "achieved": steps_per_s * a_sweep / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": steps_per_s * a_sweep / 1e9 / HBM_PEAK_GBS,
+                            "note": "logical rate: item rows staged once per workgroup serve every env of the tile, so it is not the physical HBM rate"},
+            "mfma": {"flop_per_env_step": f_sweep, "achieved": steps_per_s * f_sweep / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": steps_per_s * f_sweep / 1e12 / PEAK_FP32_MFMA_TFLOPS}}
+
+
 def cpu_baseline(wl, budget_envs=1024, threads=None):
     """The oracle port of the same step on the host cores, bounded sample (fewer envs, same tables / episode rule).
     Threads are capped: the per-step tensors are tiny and oversubscribing a 256-core host makes the port slower."""
@@ -234,6 +277,7 @@ def main():
         out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_PER_MINIBATCH if args.workload == "c3" else None
         out["roofline"]["traffic_source"] = "profiles/r01f_pmc_minibatch_step.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
         out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
+        out["sweep_mode"] = sweep_mode_probe(wl, eng, device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)

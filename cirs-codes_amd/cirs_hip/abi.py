@@ -143,6 +143,10 @@ SIGNATURES = {
     "cirs_normed_reward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "cirs_ppo_minibatch_dp": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, _P,
                                         C.c_int32, _P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P]),
+    "cirs_select_items": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_float, _P, C.c_uint64, C.c_uint32,
+                                    _P, _P, _P]),
+    "cirs_rollout_static": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState), _P, C.c_int64, _P, C.POINTER(Traj),
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_uint32, _P, C.c_int32, _P, _P]),
     "cirs_eval_coverage": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "cirs_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float,
                                  C.c_float, _P, C.c_int32, _P]),

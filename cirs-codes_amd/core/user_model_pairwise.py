@@ -56,6 +56,47 @@ class UserModel_Pairwise(nn.Module):
         self._dev = None
         return super().load_state_dict(state_dict, strict=False)
 
+    # ---- static-baseline recommendation (reference core/user_model.py:250-348) ------------------------------------------
+    def compile_UCB(self, n_arm):
+        self.n_rec = n_arm
+        self.n_each = np.ones(n_arm)
+
+    def recommend_k_item(self, user, dataset_val, k=1, is_softmax=True, epsilon=0, is_ucb=False, recommended_ids=[], gumbel=None,
+                         seed=None):
+        """One catalogue sweep for `user` (original id) over dataset_val.df_photo_env, then the choice of ONE item on the
+        device (cirs_select_items).  Returns (recommended_id_transform, recommended_id_raw, value_rec) like the reference:
+        position in df_photo_env, original id, u_value of the pick.  k > 1 is not built (the scripts use k = 1)."""
+        assert k == 1, "only k = 1 is built (interactive_evaluation / test_kuaishou call with k=1)"
+        from cirs_hip.static_policy import select_items
+        df_item_val = dataset_val.df_photo_env
+        item_index = df_item_val.index.to_numpy()
+        I = len(item_index)
+        dm = self.device_model()
+        feats = df_item_val[["feat0", "feat1", "feat2", "feat3"]].to_numpy()
+        dur = df_item_val["photo_duration"].to_numpy()
+        pred, _ = dm.sweep(np.asarray([user]), item_index, feats, dur)          # [1, I] on the device
+        visited = None
+        if len(recommended_ids):
+            words = np.zeros((I + 31) // 32, dtype=np.uint32)
+            ids = np.asarray(recommended_ids, dtype=np.int64)
+            np.bitwise_or.at(words, ids >> 5, (np.uint32(1) << (ids & 31).astype(np.uint32)))
+            visited = torch.as_tensor(words.view(np.int32)).reshape(1, -1)
+        bonus = None
+        if is_ucb and len(recommended_ids) == 0:
+            if not hasattr(self, "n_rec"):
+                self.compile_UCB(I)
+            bonus = torch.as_tensor(((2 * np.log(self.n_rec) / self.n_each) ** 0.5).astype(np.float32))
+        self._rec_calls = getattr(self, "_rec_calls", 0) + 1
+        act, val = select_items(pred, softmax=is_softmax, bonus=bonus, visited=visited, epsilon=float(epsilon), gumbel=gumbel,
+                                seed=self.seed_rec if seed is None else seed, rng_step=self._rec_calls)
+        recommended_id_transform = act.cpu().numpy()
+        if is_ucb:
+            self.n_rec += k
+            self.n_each[recommended_id_transform] += 1
+        return recommended_id_transform, item_index[recommended_id_transform], val.cpu().numpy()
+
+    seed_rec = 2022
+
     def forward(self, x):
         """x: float tensor (n, 7) = [user_id, photo_id, feat0..3, photo_duration] carrying raw ids."""
         x = torch.as_tensor(x)

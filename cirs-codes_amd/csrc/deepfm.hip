@@ -12,7 +12,7 @@
 //   sweep_kernel             per wave: a tile of 32 items held in registers, loop over a chunk of users staged in LDS;
 //                            per (user, 32 items): h1 = relu(A_u + A_i) formed directly in the MFMA B-operand layout,
 //                            H2^T[64 x 32 pairs] = W2[64 x 64] * h1^T on the fp32 matrix cores (64 v_mfma_f32_32x32x2),
-//                            a lane owns one pair so relu/last-dot/FM/bias are lane-local; min/max by ordered-int atomics.
+//                            a lane owns one pair so relu/last-dot/FM/bias are lane-local; min/max per wavefront slot + one reduce launch.
 // Roofline: 2*(64*64+64+E) = 8.4 kFLOP executed per pair (E = 16) vs 20.7 kFLOP of the unfactored algorithm
 // (SURVEY §8(d) F_sweep); MFMA-bound: 64 MFMA x 64 cycles per 32 pairs -> 19.2 G pairs/s at the fp32 MFMA peak.
 // HBM traffic per launch ~ item/user rows once + 4 B per pair of output: far below the MFMA time.
@@ -151,7 +151,7 @@ template <int E>
 __global__ __launch_bounds__(256, 1) void sweep_kernel(const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ last,
                                                        const float* __restrict__ AI, const float* __restrict__ SI, const float* __restrict__ CI,
                                                        const float* __restrict__ AU, const float* __restrict__ VU, const float* __restrict__ LU,
-                                                       int nu, int ni, float* __restrict__ pred, unsigned int* __restrict__ mmkeys) {
+                                                       int nu, int ni, float* __restrict__ pred, float* __restrict__ mmpart) {
     __shared__ float sAU[kUserChunk][fH];
     __shared__ float sVU[kUserChunk][E];
     __shared__ float sLU[kUserChunk];
@@ -166,7 +166,13 @@ __global__ __launch_bounds__(256, 1) void sweep_kernel(const float* __restrict__
     if (threadIdx.x < fH) { sB2[threadIdx.x] = b2[threadIdx.x]; sLast[threadIdx.x] = last[threadIdx.x]; }
     __syncthreads();
     const int tile0 = (blockIdx.x * 4 + wv) * 32;
-    if (tile0 >= ni) return;
+    if (tile0 >= ni) {
+        if (lane == 0) {
+            const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv;
+            mmpart[2 * slot] = INFINITY; mmpart[2 * slot + 1] = -INFINITY;
+        }
+        return;
+    }
     const int item = tile0 + lo;
     const bool ok = item < ni;
     // A operand (persistent): W2 rows; lane (out row = lo [+32], hi): w2[out][hi*32 + kk]
@@ -223,19 +229,31 @@ __global__ __launch_bounds__(256, 1) void sweep_kernel(const float* __restrict__
         vmin = fminf(vmin, __shfl_xor(vmin, off, CIRS_WAVE));
         vmax = fmaxf(vmax, __shfl_xor(vmax, off, CIRS_WAVE));
     }
-    if (lane == 0 && vmin <= vmax) {
-        atomicMin(&mmkeys[0], f32_key(vmin));
-        atomicMax(&mmkeys[1], f32_key(vmax));
+    // one (min, max) slot per wavefront, reduced by minmax_end_kernel: no atomics (tens of thousands of device-scope
+    // atomics on one address serialise at ~60 ns each and used to dominate the launch)
+    if (lane == 0) {
+        const size_t slot = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv;
+        mmpart[2 * slot] = vmin;
+        mmpart[2 * slot + 1] = vmax;
     }
 }
 
-__global__ void minmax_begin_kernel(const float* mm, unsigned int* keys, int init) {
-    keys[0] = init ? 0xFFFFFFFFu : f32_key(mm[0]);
-    keys[1] = init ? 0u : f32_key(mm[1]);
-}
-__global__ void minmax_end_kernel(const unsigned int* keys, float* mm) {
-    mm[0] = key_f32(keys[0]);
-    mm[1] = key_f32(keys[1]);
+// (min, max) over the per-wavefront slots, optionally merged with the running pair in mm (init == 0)
+__global__ __launch_bounds__(1024) void minmax_end_kernel(const float* __restrict__ part, long n_slots, float* __restrict__ mm, int init) {
+    __shared__ float s_lo[1024], s_hi[1024];
+    const int tid = threadIdx.x;
+    float lo = INFINITY, hi = -INFINITY;
+    for (long i = tid; i < n_slots; i += 1024) { lo = fminf(lo, part[2 * i]); hi = fmaxf(hi, part[2 * i + 1]); }
+    s_lo[tid] = lo; s_hi[tid] = hi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) { s_lo[tid] = fminf(s_lo[tid], s_lo[tid + s]); s_hi[tid] = fmaxf(s_hi[tid], s_hi[tid + s]); }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        mm[0] = init ? s_lo[0] : fminf(mm[0], s_lo[0]);
+        mm[1] = init ? s_hi[0] : fmaxf(mm[1], s_hi[0]);
+    }
 }
 
 __global__ __launch_bounds__(256) void normed_kernel(const float* __restrict__ pred, long n, const float* __restrict__ mm, double* __restrict__ out) {
@@ -269,7 +287,8 @@ extern "C" int cirs_deepfm_forward(const cirs_deepfm_cfg* cfg, const cirs_deepfm
 extern "C" int64_t cirs_deepfm_sweep_workspace_bytes(const cirs_deepfm_cfg* cfg, int32_t n_users, int32_t n_items) {
     if (!cfg) return 0;
     const int64_t E = cfg->emb_dim;
-    return 4 * ((int64_t)n_items * (cirs::fH + E + 1) + (int64_t)n_users * (cirs::fH + E + 1) + 64);
+    const int64_t n_wg = (int64_t)cirs::cdiv(cirs::cdiv(n_items, 32), 4) * cirs::cdiv(n_users, cirs::kUserChunk);
+    return 4 * ((int64_t)n_items * (cirs::fH + E + 1) + (int64_t)n_users * (cirs::fH + E + 1) + 8 * n_wg + 64);
 }
 
 extern "C" int cirs_deepfm_sweep(const cirs_deepfm_cfg* cfg, const cirs_deepfm_weights* w, const int64_t* user_ids, int32_t nu,
@@ -289,14 +308,13 @@ extern "C" int cirs_deepfm_sweep(const cirs_deepfm_cfg* cfg, const cirs_deepfm_w
     float* AU = CI + ni;
     float* VU = AU + (size_t)nu * fH;
     float* LU = VU + (size_t)nu * E;
-    unsigned int* keys = (unsigned int*)(LU + nu);
-    hipLaunchKernelGGL(minmax_begin_kernel, dim3(1), dim3(1), 0, s, minmax, keys, init_minmax);
+    float* mmpart = LU + nu + 2;
     hipLaunchKernelGGL(prep_items_kernel, dim3(cdiv(ni, 4)), dim3(256), 4 * sizeof(float) * (5 * E + 4), s, *cfg, *w, item_ids, item_feats,
                        item_dur, ni, AI, SI, CI);
     hipLaunchKernelGGL(prep_users_kernel, dim3(cdiv(nu, 4)), dim3(256), 0, s, *cfg, *w, user_ids, nu, AU, VU, LU);
     CIRS_CHECK_LAUNCH("deepfm prep");
     const dim3 grid(cdiv(cdiv(ni, 32), 4), cdiv(nu, kUserChunk));
-#define SWEEP(EE) hipLaunchKernelGGL(sweep_kernel<EE>, grid, dim3(256), 0, s, w->w2, w->b2, w->last, AI, SI, CI, AU, VU, LU, nu, ni, pred_out, keys)
+#define SWEEP(EE) hipLaunchKernelGGL(sweep_kernel<EE>, grid, dim3(256), 0, s, w->w2, w->b2, w->last, AI, SI, CI, AU, VU, LU, nu, ni, pred_out, mmpart)
     switch (E) {
         case 8: SWEEP(8); break;
         case 16: SWEEP(16); break;
@@ -304,7 +322,7 @@ extern "C" int cirs_deepfm_sweep(const cirs_deepfm_cfg* cfg, const cirs_deepfm_w
         default: SWEEP(64); break;
     }
 #undef SWEEP
-    hipLaunchKernelGGL(minmax_end_kernel, dim3(1), dim3(1), 0, s, keys, minmax);
+    hipLaunchKernelGGL(minmax_end_kernel, dim3(1), dim3(1024), 0, s, mmpart, (long)grid.x * grid.y * 4, minmax, init_minmax);
     CIRS_CHECK_LAUNCH("sweep_kernel");
     return CIRS_OK;
 }

@@ -35,6 +35,70 @@ def get_feat_dominate_dict(df_item_val, all_acts_origin, item_feat_domination, t
     return out
 
 
+def interactive_evaluation(model, env, dataset_val, is_softmax, epsilon, is_ucb, k, need_transform, num_trajectory, item_feat_domination,
+                           remove_recommended, force_length=0, top_rate=0.6, users=None, seed=0):
+    """reference evaluation.py:79-151 with the num_trajectory trajectories run in LOCK-STEP on the device: one catalogue
+    sweep per trajectory user (the model is static), then per step cirs_select_items -> env step (cirs_rollout_static).
+    Same result dict.  Differences that follow from batching: with is_ucb the arm counts are updated once per vector step
+    (the reference updates them after every single recommendation); users can be supplied (the reference draws them with
+    the unseeded `random`)."""
+    from cirs_hip.evalmetrics import CoverageCounter
+    from cirs_hip.static_policy import StaticRollout
+    assert k == 1 and need_transform, "built for KuaishouEnv (need_transform=True, k=1)"
+    B = int(num_trajectory)
+    df_item_val = dataset_val.df_photo_env
+    item_index = df_item_val.index.to_numpy()
+    assert np.array_equal(item_index, np.asarray(env.lbe_photo.classes_)), "df_photo_env must be in env item order (lbe_photo.classes_)"
+    I = len(item_index)
+    dev_env = env.build_device_env(B)
+    if users is None:
+        users = np.random.randint(0, env.mat.shape[0], B)
+    users = np.asarray(users)
+    raw_users = np.asarray(env.lbe_user.classes_)[users]
+    feats = df_item_val[["feat0", "feat1", "feat2", "feat3"]].to_numpy()
+    dur = df_item_val["photo_duration"].to_numpy()
+    scores, _ = model.device_model().sweep(raw_users, item_index, feats, dur)   # [B, I] u_value of every trajectory user
+    ro = StaticRollout(dev_env)
+    T = dev_env.max_turn if force_length <= 0 else min(force_length, dev_env.max_turn)
+    if is_ucb:
+        raise NotImplementedError("UCB exploration is sequential over recommendations (arm counts); call recommend_k_item per step")
+    ro.run(torch.as_tensor(users), scores, softmax=is_softmax, epsilon=epsilon, seed=seed, remove_recommended=remove_recommended,
+           force_length=force_length, n_steps=T)
+    valid = ro.act >= 0
+    total_turns = int(valid.sum())
+    cumulative_reward = float((ro.rew * valid).sum())
+    total_click_loss = float(((ro.value.double() - ro.rew).abs() * valid).sum())
+    ctr = cumulative_reward / total_turns
+    click_loss = total_click_loss / total_turns
+    cc = CoverageCounter(I, device=ro.act.device)
+    flags = None
+    if item_feat_domination is not None and "feat" in item_feat_domination:
+        flags = torch.as_tensor(item_flags(feats, dominated_values(item_feat_domination["feat"], top_rate)))
+    hit_item, n_acts, n_fl = cc.count(ro.act, flags)
+    eval_result_RL = {"click_loss": click_loss, "CV": f"{hit_item / I:.5f}", "CV_turn": f"{hit_item / n_acts:.5f}", "ctr": ctr,
+                      "len_tra": total_turns / B, "R_tra": cumulative_reward / B}
+    if flags is not None:
+        eval_result_RL["ifeat_feat"] = n_fl / n_acts
+    if remove_recommended:
+        eval_result_RL = {f"NX_{force_length}_" + key: v for key, v in eval_result_RL.items()}
+    interactive_evaluation.last_rollout = ro
+    return eval_result_RL
+
+
+def test_static_model_in_RL_env(model, env, dataset_val, is_softmax=True, epsilon=0, is_ucb=False, k=1, need_transform=False,
+                                num_trajectory=100, item_feat_domination=None, force_length=10, top_rate=0.6, users=None, seed=0):
+    """reference evaluation.py:153-176: free browsing, no-overlap, no-overlap with forced length."""
+    out = {}
+    for remove, fl in ((False, 0), (True, 0), (True, force_length)):
+        out.update(interactive_evaluation(model, env, dataset_val, is_softmax, epsilon, is_ucb, k, need_transform, num_trajectory,
+                                          item_feat_domination, remove_recommended=remove, force_length=fl, top_rate=top_rate, users=users,
+                                          seed=seed))
+    return out
+
+
+test_static_model_in_RL_env.__test__ = False  # not a pytest test
+
+
 class Callback_Coverage_Count:
     def __init__(self, test_collector_set, df_item_val, need_transform, item_feat_domination, lbe_photo, top_rate):
         self.collector_dict = test_collector_set.collector_dict

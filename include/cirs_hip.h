@@ -400,6 +400,25 @@ int cirs_deepfm_sweep(const cirs_deepfm_cfg* cfg, const cirs_deepfm_weights* w, 
 /* normed = (pred - min) / (max - min) in float64 (kuaishouEnv.py:139-143) */
 int cirs_normed_reward(const float* pred, int64_t n, const float* minmax, double* normed_out, void* stream);
 
+/* ---- the user model as a static recommendation policy ---------------------------------------------
+ * cirs_select_items replaces the tail of UserModel.recommend_k_item (reference core/user_model.py:296-346, k = 1) for n
+ * users at once, given their catalogue scores (cirs_deepfm_sweep):
+ *   scores [n, row_stride >= n_items] f32;  bonus [n_items] or NULL (UCB bound, :303-314);
+ *   visited [n, ceil(n_items/32)] or NULL (recommended_ids, :263-266);  skip [n] or NULL (row inactive -> act -1);
+ *   softmax != 0: multinomial(softmax(u_value)) as arg-max of u_value + Gumbel noise (gumbel [n, n_items] supplied, or
+ *   the counter-based generator keyed (seed, rng_step, row, item));  softmax == 0: arg-max, lowest id on ties (:331);
+ *   epsilon: probability of a uniform random non-removed item instead (:333-335).
+ *   act_out [n] int64 (-1: no item), value_out [n] or NULL: u_value of the chosen item (value_rec, :346).
+ * cirs_rollout_static replaces the loop of interactive_evaluation (reference evaluation.py:87-120) for n_env
+ * trajectories in lock-step: select -> mark visited -> env step -> forced length; traj->value holds reward_pred. */
+int cirs_select_items(const float* scores, int64_t row_stride, int32_t n, int32_t n_items, int32_t softmax,
+                      const float* bonus, const uint32_t* visited, const uint8_t* skip, float epsilon, const float* gumbel,
+                      uint64_t seed, uint32_t rng_step, int64_t* act_out, float* value_out, void* stream);
+int cirs_rollout_static(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                        const float* scores, int64_t row_stride, const float* bonus, const cirs_traj* traj, int32_t n_env,
+                        int32_t t_begin, int32_t t_end, int32_t softmax, float epsilon, uint64_t seed, uint32_t rng_base,
+                        uint32_t* visited, int32_t force_length, int64_t* obs_scratch, void* stream);
+
 /* ---- evaluation metrics on device trajectories ---------------------------------------------------
  * Replaces the buffer walks of Callback_Coverage_Count.on_epoch_end (reference evaluation.py:303-352) and the
  * row test of get_feat_dominate_dict (evaluation.py:36-44):

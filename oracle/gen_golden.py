@@ -539,7 +539,95 @@ def gen_loaders():
     print("loaders.npz: mat", mat.shape, "max", mat.max(), "dist inf share", float(np.isinf(out["dist"]).mean()), "cols", list(df_photo_env.columns))
 
 
-FAMILIES = {"loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+def load_shipped_user_model():
+    import pickle
+    from core.user_model_pairwise import UserModel_Pairwise
+    base = os.path.join(ref_harness.REF_ROOT, "reproduce_results_of_our_paper", "results_alpha_beta")
+    with open(os.path.join(base, "DeepFM_params_Pair11.pickle"), "rb") as fh:
+        params = pickle.load(fh)
+    params["device"] = "cpu"
+    model = UserModel_Pairwise(**params)
+    model.load_state_dict(torch.load(os.path.join(base, "DeepFM_Pair11.pt"), map_location="cpu"))
+    model.eval()
+    return model
+
+
+def gen_staticpolicy():
+    """UserModel.recommend_k_item (reference core/user_model.py:254-348) and interactive_evaluation (evaluation.py:79-151)
+    with the shipped DeepFM weights on a small synthetic KuaishouEnv.  Sampling modes use the shared-noise protocol:
+    torch.multinomial(probs, 1) is replaced by argmax(log probs + g) with recorded Gumbel noise g."""
+    import random as pyrandom
+    from types import SimpleNamespace
+    import evaluation as ev
+    from environments.KuaishouRec.env.kuaishouEnv import KuaishouEnv
+    model = load_shipped_user_model()
+    tab = make_tables(24, 96, seed=9, raw_user_space=7176, raw_item_space=10729)
+    kw = build_reference_env_kwargs(tab, num_leave_compute=3, leave_threshold=1, max_turn=12)
+    dataset_val = SimpleNamespace(df_photo_env=kw["df_photo_env"], x_columns=list(range(7)))
+    I = tab.n_items
+    rng = np.random.RandomState(3)
+    out = dict(raw_uid=tab.raw_uid, raw_pid=tab.raw_pid, mat=tab.mat, item_cats=tab.item_cats, duration=tab.duration, dist=tab.dist)
+    # ---- recommend_k_item -------------------------------------------------------------------------------------------
+    rec = []
+    noise = {}
+    real_multinomial = torch.multinomial
+
+    def fake_multinomial(probs, k, replacement=False):
+        g = noise["g"][:probs.numel()]
+        return torch.argmax(torch.log(probs) + torch.as_tensor(g, dtype=probs.dtype)).reshape(1)
+
+    cases = [dict(softmax=False, removed=[]), dict(softmax=False, removed=[3, 17, 40, 41, 95]), dict(softmax=True, removed=[]),
+             dict(softmax=True, removed=[0, 1, 2, 64]), dict(softmax=False, removed=[], ucb=True), dict(softmax=False, removed=[], ucb=True)]
+    users = rng.choice(tab.raw_uid, len(cases))
+    torch.multinomial = fake_multinomial
+    try:
+        for ci, (c, u) in enumerate(zip(cases, users)):
+            g = rng.gumbel(size=I).astype(np.float32)        # noise per ITEM id; the reference samples over the preserved items
+            keep = np.ones(I, bool); keep[c["removed"]] = False
+            noise["g"] = g[keep]
+            if c.get("ucb") and ci == len(cases) - 1:   # second UCB call sees the counts of the first + some extra pulls
+                model.n_each[rng.randint(0, I, 200)] += 3
+                model.n_rec += 600
+            ucb_state = (getattr(model, "n_rec", I), getattr(model, "n_each", np.ones(I)).copy()) if c.get("ucb") else (0, np.zeros(I))
+            t_id, raw_id, val = model.recommend_k_item(int(u), dataset_val, k=1, is_softmax=c["softmax"], epsilon=0, is_ucb=bool(c.get("ucb")),
+                                                      recommended_ids=list(c["removed"]))
+            out[f"r{ci}_user"] = u; out[f"r{ci}_softmax"] = int(c["softmax"]); out[f"r{ci}_removed"] = np.array(c["removed"], np.int64)
+            out[f"r{ci}_gumbel"] = g; out[f"r{ci}_ucb"] = int(bool(c.get("ucb"))); out[f"r{ci}_n_rec"] = ucb_state[0]; out[f"r{ci}_n_each"] = ucb_state[1]
+            out[f"r{ci}_out"] = np.array([int(np.asarray(t_id).reshape(-1)[0]), int(np.asarray(raw_id).reshape(-1)[0])], np.int64)
+            out[f"r{ci}_val"] = np.float32(np.asarray(val).reshape(-1)[0])
+            rec.append(ci)
+    finally:
+        torch.multinomial = real_multinomial
+    out["n_rec_cases"] = len(rec)
+    # ---- interactive_evaluation (greedy: deterministic given the users) ----------------------------------------------
+    dom = {"feat": [(1, 0.4), (2, 0.3), (5, 0.2), (7, 0.1)]}
+    n_traj = 10
+    for ei, (remove, fl) in enumerate([(False, 0), (True, 0), (True, 5)]):
+        env = KuaishouEnv(**kw)
+        pyrandom.seed(100 + ei)
+        drawn = []
+        orig_reset = env.reset
+
+        def rec_reset(_orig=orig_reset, _drawn=drawn):
+            o = _orig()
+            _drawn.append(int(np.asarray(o).reshape(-1)[0]))
+            return o
+        env.reset = rec_reset
+        res = ev.interactive_evaluation(model, env, dataset_val, is_softmax=False, epsilon=0, is_ucb=False, k=1, need_transform=True,
+                                        num_trajectory=n_traj, item_feat_domination=dom, remove_recommended=remove, force_length=fl,
+                                        top_rate=0.6)
+        pre = f"NX_{fl}_" if remove else ""
+        out[f"e{ei}_users"] = np.array(drawn, np.int64)
+        out[f"e{ei}_cfg"] = np.array([int(remove), fl], np.int64)
+        out[f"e{ei}_res"] = np.array([float(res[pre + "click_loss"]), float(res[pre + "CV"]), float(res[pre + "CV_turn"]), float(res[pre + "ctr"]),
+                                      float(res[pre + "len_tra"]), float(res[pre + "R_tra"]), float(res[pre + "ifeat_feat"])], np.float64)
+    out["n_eval_cases"] = 3
+    out["dom_values"] = np.array([p[0] for p in dom["feat"]], np.int64); out["dom_shares"] = np.array([p[1] for p in dom["feat"]])
+    np.savez_compressed(os.path.join(GOLDEN, "staticpolicy.npz"), **out)
+    print("staticpolicy.npz:", {k: out[k] for k in out if k.endswith("_out") or k.endswith("_res")})
+
+
+FAMILIES = {"staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)
