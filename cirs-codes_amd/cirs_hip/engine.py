@@ -152,7 +152,7 @@ class CirsEngine:
         traj, x_hist, lens_d, users = self._gather()
         lens = lens_d.cpu().numpy().astype(np.int32)   # host needs N to schedule minibatches (the only sync)
         ln = self.learner
-        n = ln.prepare(traj, lens)
+        n = ln.prepare(traj, lens, lens_dev=lens_d)
         if perms is None and self.world > 1:
             # identical permutations on every rank: replicated learners stay bit-identical
             rs = np.random.RandomState((self.seed * 7919 + self.collect_count) & 0x7FFFFFFF)
@@ -161,8 +161,7 @@ class CirsEngine:
         if self.world > 1 and self.learner_mode == "dp":
             return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms)
         losses = ln.learn(batch_size, repeat, perms=perms)
-        self.tracker.backward(users, traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).to(self.device),
-                              torch.as_tensor(lens).to(self.device), n, ln.dobs,
+        self.tracker.backward(users, traj, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs,
                               x_hist=x_hist if (self.world > 1 or self.force_gather) else None)
         self.tracker.adam_update()
         return losses, n

@@ -152,7 +152,7 @@ def test_engine_collect_update_million_item_catalogue():
     ident = np.arange(I, dtype=np.int64)
 
     def run():
-        np.random.seed(123)   # minibatch permutations come from the global numpy stream (Batch.split), like the reference
+        np.random.seed(123)   # (the learner draws its minibatch permutations from a seeded device generator)
         dt = DeviceEnvTables(None, None, cats, n_users=U, n_items=I)
         eng = CirsEngine(dt, B, max_turn=T, num_leave_compute=3, leave_threshold=1, tau=10.0, gamma_exposure=10.0, seed=1,
                          online_reward=OnlineReward(um, ident, ident, feats, dur, (-30.0, 30.0), B), batch_size_hint=128)
