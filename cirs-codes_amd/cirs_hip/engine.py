@@ -107,6 +107,7 @@ class CirsEngine:
         self.users = None
         self.lengths = None
         self._gtraj = None
+        self._users_pinned = None
         # user draws: the reference uses Python's (unseeded) random.randint per env reset (kuaishouEnv.py:155-159);
         # here a seeded generator per rank
         self._user_rng = np.random.RandomState(seed * 1000003 + rank)
@@ -114,8 +115,17 @@ class CirsEngine:
     # ---- rollout ------------------------------------------------------------------------------------------------
     def collect(self, users: Optional[torch.Tensor] = None, sync_every: Optional[int] = None):
         if users is None:
-            users = torch.as_tensor(self._user_rng.randint(0, self.tables.n_users, self.n_env))
-        self.users = users.to(self.device, torch.int32)
+            # pinned double buffer + asynchronous upload: the host does not block on the stream (it is usually one whole
+            # update ahead of the GPU here), so the rollout launches queue behind the update without a bubble
+            if self._users_pinned is None:
+                self._users_pinned = [torch.empty(self.n_env, dtype=torch.int32).pin_memory() for _ in range(2)]
+                self._users_dev = [torch.empty(self.n_env, dtype=torch.int32, device=self.device) for _ in range(2)]
+            k = self.collect_count & 1
+            self._users_pinned[k].numpy()[:] = self._user_rng.randint(0, self.tables.n_users, self.n_env)
+            self._users_dev[k].copy_(self._users_pinned[k], non_blocking=True)
+            self.users = self._users_dev[k]
+        else:
+            self.users = users.to(self.device, torch.int32)
         rng_base = (self.collect_count * self.max_turn) & 0xFFFFFFFF
         # RNG key = (seed, rank) so ranks draw independent noise; counter = (item, local env id, step)
         self.lengths = self.rollout.collect(self.users, seed=(self.seed << 8) + self.rank, rng_base=rng_base, sync_every=sync_every)
