@@ -11,11 +11,9 @@
 // HBM traffic per env-step (table mode): 4*t B history + 8*t B dist gathers (one 32 B sector each, physically)
 // + 4*(N+1) B category words + 16 B (mat, normed_mat) + 16 B (alpha, beta) + ~40 B state/outputs.  The path is
 // latency-bound, not bandwidth-bound: the design goal is one launch for all envs and no host sync.
-#include "common.h"
+#include "env_kernels.h"
 
 namespace cirs {
-
-constexpr int kEnvsPerBlock = 4;
 
 __global__ __launch_bounds__(256) void env_step_kernel(cirs_env_cfg cfg, cirs_env_tables tab, cirs_env_state st,
                                                        const int64_t* __restrict__ actions,
@@ -27,111 +25,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(cirs_env_cfg cfg, cirs_en
     const int j = blockIdx.x * kEnvsPerBlock + (threadIdx.x >> 6);
     if (j >= n) return;  // wave-uniform
     const int e = env_ids ? env_ids[j] : j;
-    const int64_t action = actions[j];
-    const int T = cfg.max_turn;
-    const long I = cfg.n_items;
-    int32_t* hist = st.hist_action + (size_t)e * T;
-
-    if (st.done[e] || action < 0 || action >= I) {  // finished envs are never stepped by the collector: no-op
-        if (lane == 0) {
-            obs_out[j] = action;
-            rew_out[j] = 0.0;
-            done_out[j] = 1;
-            ctr_out[j] = 0.0;
-            if (expo_out) expo_out[j] = 0.0;
-        }
-        return;
-    }
-    const int u = st.user[e];
-    const int t = st.turn[e];
-    const uint32_t cats_a = tab.item_cats[action];
-
-    // ---- (a) exit rule + (c) repeat count: integer scans over the history ---------------------------------
-    // window = sequence_action[t-N : t] with Python negative-start wrap
-    long start = (long)t - cfg.num_leave_compute;
-    if (start < 0) {
-        start += t;
-        if (start < 0) start = 0;
-    }
-    if (start > t) start = t;
-    // counts of each of the action's (<=4) categories inside the window, 16 bits each, packed in a u64
-    unsigned long long packed_counts = 0;
-    int repeat = 0;
-    const bool want_exposure = cfg.simulated && cfg.use_exposure && t > 0 && cfg.tau > 0;
-    double expo_part = 0.0;
-    for (int k = lane; k < t; k += CIRS_WAVE) {
-        const int32_t hk = hist[k];
-        repeat += (hk == (int32_t)action);
-        uint32_t cats_h = 0;
-        const bool in_window = k >= start;
-        if (in_window || (want_exposure && cfg.dist_mode == 1)) cats_h = tab.item_cats[hk];
-        if (in_window) {
-#pragma unroll
-            for (int ia = 0; ia < CIRS_MAX_CATS_PER_ITEM; ++ia) {
-                const uint32_t ca = (cats_a >> (8 * ia)) & 0xFFu;
-                if (ca == CIRS_CAT_NONE) continue;
-                int c = 0;
-#pragma unroll
-                for (int ih = 0; ih < CIRS_MAX_CATS_PER_ITEM; ++ih) c += (((cats_h >> (8 * ih)) & 0xFFu) == ca);
-                packed_counts += (unsigned long long)c << (16 * ia);
-            }
-        }
-        // ---- (b) exposure effect term, float64 -----------------------------------------------------------
-        if (want_exposure) {
-            const double d = cfg.dist_mode == 0 ? tab.dist[(size_t)action * I + hk] : jaccard_dist(cats_a, cats_h);
-            const double t_diff = (double)(t - k);
-            expo_part += exp(-t_diff * d / cfg.tau);
-        }
-    }
-    packed_counts = wave_sum_u64(packed_counts);
-    repeat = wave_sum_i32(repeat);
-    const double exposure_effect = want_exposure ? wave_sum_f64(expo_part) : 0.0;
-
-    if (lane != 0) return;
-
-    int done = 0;
-    if (t > 0) {
-#pragma unroll
-        for (int ia = 0; ia < CIRS_MAX_CATS_PER_ITEM; ++ia) {
-            const uint32_t ca = (cats_a >> (8 * ia)) & 0xFFu;
-            const int cnt = (int)((packed_counts >> (16 * ia)) & 0xFFFFull);
-            if (ca != CIRS_CAT_NONE && cnt > cfg.leave_threshold) done = 1;
-        }
-    }
-    if (t >= T - 1) done = 1;
-
-    double reward, exposure_gamma = 0.0;
-    if (cfg.simulated) {
-        if (cfg.use_exposure && t > 0) {
-            double e_new = exposure_effect;
-            if (cfg.has_ab) e_new = exposure_effect * tab.alpha_env[u] * tab.beta_env[action];
-            exposure_gamma = e_new * cfg.gamma_exposure;
-        }
-        double pred;
-        if (tab.pred_online) {  // online DeepFM score of this row's (user, action), min-max normalised in float64
-            const double lo = (double)tab.pred_minmax[0], hi2 = (double)tab.pred_minmax[1];
-            pred = ((double)tab.pred_online[j] - lo) / (hi2 - lo);
-        } else {
-            pred = tab.normed_mat[(size_t)u * I + action];
-        }
-        reward = cfg.version == 1 ? pred / (1.0 + exposure_gamma) : pred - exposure_gamma;
-        // num_actions[action] - 1 == occurrences before this step (this step's own append is guarded by t < T)
-        const int num_repeat = (t < T) ? repeat : repeat - 1;
-        reward = reward * pow(cfg.r_decay, (double)num_repeat);
-    } else {
-        reward = tab.mat[(size_t)u * I + action];
-    }
-    if (t < T) hist[t] = (int32_t)action;
-    const double cum = st.cum_reward[e] + reward;
-    st.cum_reward[e] = cum;
-    st.turn[e] = t + 1;
-    st.done[e] = (uint8_t)done;
-
-    obs_out[j] = action;
-    rew_out[j] = reward;
-    done_out[j] = (uint8_t)done;
-    ctr_out[j] = cfg.simulated ? cum / (double)(t + 1) / 10.0 : cum;
-    if (expo_out) expo_out[j] = exposure_gamma;
+    env_step_wave(cfg, tab, st, e, j, actions[j], lane, obs_out, rew_out, done_out, ctr_out, expo_out);
 }
 
 __global__ __launch_bounds__(256) void env_reset_kernel(cirs_env_cfg cfg, cirs_env_state st,

@@ -20,9 +20,7 @@
 
 namespace cirs {
 
-// merge partials across chunks (one wavefront per env row, lanes stride over chunks); recompute the chosen item's
-// logit with the SAME k-order as the MFMA chain (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with
-// the sampled distribution.
+// merge partials across chunks: action id (ties -> lowest id), logp with Categorical's clamp (actor_merge_wave)
 __global__ __launch_bounds__(256) void actor_merge_kernel(int n, int n_pad, int n_chunks, ActorPartialView pv,
                                                           const float* __restrict__ wa, const float* __restrict__ ba,
                                                           const float* __restrict__ h2,
@@ -38,52 +36,7 @@ __global__ __launch_bounds__(256) void actor_merge_kernel(int n, int n_pad, int 
         }
         return;
     }
-    float bs = -INFINITY, m = -INFINITY, s = 0.f;
-    int bi = 0x7FFFFFFF;
-    for (int c = lane; c < n_chunks; c += CIRS_WAVE) {  // within a lane chunks ascend: strict > keeps the lowest id
-        const size_t o = (size_t)c * n_pad + j;
-        const float os = pv.score[o];
-        const int oi = pv.idx[o];
-        if (os > bs) { bs = os; bi = oi; }
-        const float om = pv.m[o], osum = pv.s[o];
-        const float mn = fmaxf(m, om);
-        if (mn > -INFINITY) {
-            s = s * __expf(m - mn) + osum * __expf(om - mn);
-            m = mn;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float os = __shfl_xor(bs, off, CIRS_WAVE);
-        const int oi = __shfl_xor(bi, off, CIRS_WAVE);
-        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
-        const float om = __shfl_xor(m, off, CIRS_WAVE), osum = __shfl_xor(s, off, CIRS_WAVE);
-        const float mn = fmaxf(m, om);
-        if (mn > -INFINITY) {
-            s = s * __expf(m - mn) + osum * __expf(om - mn);
-            m = mn;
-        }
-    }
-    if (lane != 0) return;
-    act_out[j] = bi == 0x7FFFFFFF ? -1 : (int64_t)bi;
-    if (logp_out) {
-        float lp = 0.f;
-        if (bi != 0x7FFFFFFF) {
-            const float* wr = wa + (size_t)bi * kH;
-            const float* hr = h2 + (size_t)j * kH;
-            float z = ba[bi];
-            for (int kk = 0; kk < 32; ++kk) {
-                z = __builtin_fmaf(hr[kk], wr[kk], z);
-                z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
-            }
-            const float lse = m + __logf(s);
-            float p = __expf(z - lse);  // softmax prob of the chosen item (over unmasked items)
-            const float eps = 1.1920928955078125e-7f;
-            p = fminf(fmaxf(p, eps), 1.0f - eps);  // torch probs_to_logits clamp
-            lp = __logf(p);
-        }
-        logp_out[j] = lp;
-    }
+    actor_merge_wave(j, lane, n_pad, n_chunks, pv, wa, ba, h2, act_out, logp_out);
 }
 
 static int validate_policy(const cirs_policy_cfg* cfg, const cirs_policy_weights* w) {

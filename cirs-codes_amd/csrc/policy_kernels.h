@@ -39,6 +39,43 @@ __host__ __device__ inline ActorPartialView partial_view(void* ws, int n, int n_
 }
 
 // ---- trunk: one wave per row ---------------------------------------------------------------------------------
+// trunk on one row whose input already sits in LDS (xs[0..S)): h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2),
+// value = wc . h2 + bc.  Sequential-k fmaf chains (the order the oracle restates); lane o owns output feature o.
+__device__ __forceinline__ void trunk_compute(const cirs_policy_cfg& cfg, const cirs_policy_weights& w, float* xs, float* hs, int lane,
+                                              int j, float* __restrict__ h2_out, float* __restrict__ value_out,
+                                              float* __restrict__ h1_out) {
+    const int S = cfg.dim_state;
+    __builtin_amdgcn_wave_barrier();
+    // layer 1: lane o, chain over k = 0..S-1 starting from the bias
+    float acc = w.b1[lane];
+    const float* w1r = w.w1 + (size_t)lane * S;
+    for (int k = 0; k < S; ++k) acc = __builtin_fmaf(w1r[k], xs[k], acc);
+    hs[lane] = fmaxf(acc, 0.f);
+    if (h1_out) h1_out[(size_t)j * kH + lane] = hs[lane];
+    __builtin_amdgcn_wave_barrier();
+    // layer 2
+    acc = w.b2[lane];
+    const float4* w2r = reinterpret_cast<const float4*>(w.w2 + (size_t)lane * kH);
+#pragma unroll
+    for (int k4 = 0; k4 < kH / 4; ++k4) {
+        const float4 wv4 = w2r[k4];
+        acc = __builtin_fmaf(wv4.x, hs[4 * k4 + 0], acc);
+        acc = __builtin_fmaf(wv4.y, hs[4 * k4 + 1], acc);
+        acc = __builtin_fmaf(wv4.z, hs[4 * k4 + 2], acc);
+        acc = __builtin_fmaf(wv4.w, hs[4 * k4 + 3], acc);
+    }
+    const float h2 = fmaxf(acc, 0.f);
+    h2_out[(size_t)j * kH + lane] = h2;
+    __builtin_amdgcn_wave_barrier();
+    xs[lane] = h2;  // S <= 64
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && value_out) {  // critic: sequential chain (bit-reproducible), 64 fma
+        float v = w.bc[0];
+        for (int k = 0; k < kH; ++k) v = __builtin_fmaf(w.wc[k], xs[k], v);
+        value_out[j] = v;
+    }
+}
+
 // row_index (nullable): row j reads state row row_index[j] (rows j >= n_valid read nothing and produce zeros);
 // obs_copy (nullable, [n, S]): the gathered input rows are kept for the weight-gradient GEMM of the learner.
 __device__ __forceinline__ void trunk_rows(const cirs_policy_cfg& cfg, const cirs_policy_weights& w,
@@ -69,35 +106,7 @@ __device__ __forceinline__ void trunk_rows(const cirs_policy_cfg& cfg, const cir
     } else if (lane < S) {
         xs[lane] = state[(size_t)j * state_stride + lane];
     }
-    __builtin_amdgcn_wave_barrier();
-    // layer 1: lane o, chain over k = 0..S-1 starting from the bias
-    float acc = w.b1[lane];
-    const float* w1r = w.w1 + (size_t)lane * S;
-    for (int k = 0; k < S; ++k) acc = __builtin_fmaf(w1r[k], xs[k], acc);
-    hs[lane] = fmaxf(acc, 0.f);
-    if (h1_out) h1_out[(size_t)j * kH + lane] = hs[lane];
-    __builtin_amdgcn_wave_barrier();
-    // layer 2
-    acc = w.b2[lane];
-    const float4* w2r = reinterpret_cast<const float4*>(w.w2 + (size_t)lane * kH);
-#pragma unroll
-    for (int k4 = 0; k4 < kH / 4; ++k4) {
-        const float4 wv4 = w2r[k4];
-        acc = __builtin_fmaf(wv4.x, hs[4 * k4 + 0], acc);
-        acc = __builtin_fmaf(wv4.y, hs[4 * k4 + 1], acc);
-        acc = __builtin_fmaf(wv4.z, hs[4 * k4 + 2], acc);
-        acc = __builtin_fmaf(wv4.w, hs[4 * k4 + 3], acc);
-    }
-    const float h2 = fmaxf(acc, 0.f);
-    h2_out[(size_t)j * kH + lane] = h2;
-    __builtin_amdgcn_wave_barrier();
-    xs[lane] = h2;  // S <= 64
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0 && value_out) {  // critic: sequential chain (bit-reproducible), 64 fma
-        float v = w.bc[0];
-        for (int k = 0; k < kH; ++k) v = __builtin_fmaf(w.wc[k], xs[k], v);
-        value_out[j] = v;
-    }
+    trunk_compute(cfg, w, xs, hs, lane, j, h2_out, value_out, h1_out);
 }
 
 static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, cirs_policy_weights w,
@@ -282,6 +291,63 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
         else { pv.score[po] = run_t; }
         pv.m[po] = run_m; pv.s[po] = run_s;
     }
+}
+
+// merge the per-chunk partials of env row j (one wavefront, lanes stride over chunks); recompute the chosen item's
+// logit with the SAME k-order as the MFMA chain (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with the
+// sampled distribution.  Lane 0 writes act / logp; the action id is returned in every lane.
+__device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv,
+                                                    const float* __restrict__ wa, const float* __restrict__ ba,
+                                                    const float* __restrict__ h2, int64_t* __restrict__ act_out,
+                                                    float* __restrict__ logp_out) {
+    float bs = -INFINITY, m = -INFINITY, s = 0.f;
+    int bi = 0x7FFFFFFF;
+    for (int c = lane; c < n_chunks; c += CIRS_WAVE) {  // within a lane chunks ascend: strict > keeps the lowest id
+        const size_t o = (size_t)c * n_pad + j;
+        const float os = pv.score[o];
+        const int oi = pv.idx[o];
+        if (os > bs) { bs = os; bi = oi; }
+        const float om = pv.m[o], osum = pv.s[o];
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            s = s * __expf(m - mn) + osum * __expf(om - mn);
+            m = mn;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float os = __shfl_xor(bs, off, CIRS_WAVE);
+        const int oi = __shfl_xor(bi, off, CIRS_WAVE);
+        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+        const float om = __shfl_xor(m, off, CIRS_WAVE), osum = __shfl_xor(s, off, CIRS_WAVE);
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            s = s * __expf(m - mn) + osum * __expf(om - mn);
+            m = mn;
+        }
+    }
+    const int64_t act = bi == 0x7FFFFFFF ? -1 : (int64_t)bi;  // identical in every lane after the butterfly
+    if (lane != 0) return act;
+    act_out[j] = act;
+    if (logp_out) {
+        float lp = 0.f;
+        if (bi != 0x7FFFFFFF) {
+            const float* wr = wa + (size_t)bi * kH;
+            const float* hr = h2 + (size_t)j * kH;
+            float z = ba[bi];
+            for (int kk = 0; kk < 32; ++kk) {
+                z = __builtin_fmaf(hr[kk], wr[kk], z);
+                z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
+            }
+            const float lse = m + __logf(s);
+            float p = __expf(z - lse);  // softmax prob of the chosen item (over unmasked items)
+            const float eps = 1.1920928955078125e-7f;
+            p = fminf(fmaxf(p, eps), 1.0f - eps);  // torch probs_to_logits clamp
+            lp = __logf(p);
+        }
+        logp_out[j] = lp;
+    }
+    return act;
 }
 
 }  // namespace cirs

@@ -2,7 +2,9 @@
 // core/collector.py:219-317).  Per vector step: policy trunk + MFMA actor head + merge (policy.hip), env step
 // (env.hip), tracker decode step (tracker.hip); finished envs propagate as act = -1 so no compaction is needed and
 // every env keeps its row (RNG keyed by env id -> results independent of which other envs are still alive).
-#include "common.h"
+#include "env_kernels.h"
+#include "internal.h"
+#include "policy_kernels.h"
 
 namespace cirs {
 
@@ -37,6 +39,36 @@ __global__ __launch_bounds__(256) void online_pairs_kernel(const int32_t* __rest
 #pragma unroll
     for (int q = 0; q < 4; ++q) o.feat_buf[(size_t)j * 4 + q] = o.item_feats[(size_t)a * 4 + q];
     o.dur_buf[j] = o.item_dur[a];
+}
+
+// The tail of one vector step for env row j (one wavefront): merge the actor-head partials into the action / logp
+// (actor_merge_kernel), mark the visited bit, step the env (env_step_kernel), apply the forced episode length
+// (force_done_kernel) -- four dependent launches of the unfused path in one.
+__global__ __launch_bounds__(256) void step_tail_kernel(cirs_env_cfg cfg, cirs_env_tables tab, cirs_env_state st, int n, int n_pad,
+                                                        int n_chunks, ActorPartialView pv, const float* __restrict__ wa,
+                                                        const float* __restrict__ ba, const float* __restrict__ h2,
+                                                        uint32_t* __restrict__ visited, int force_length, int force_done,
+                                                        int64_t* __restrict__ act_out, float* __restrict__ logp_out,
+                                                        int64_t* __restrict__ obs_out, double* __restrict__ rew_out,
+                                                        uint8_t* __restrict__ done_out, double* __restrict__ ctr_out) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * kEnvsPerBlock + (threadIdx.x >> 6);
+    if (j >= n) return;
+    int64_t act = -1;
+    if (st.done[j]) {  // finished env: the policy skipped it
+        if (lane == 0) { act_out[j] = -1; logp_out[j] = 0.f; }
+    } else {
+        act = actor_merge_wave(j, lane, n_pad, n_chunks, pv, wa, ba, h2, act_out, logp_out);
+        if (visited && act >= 0 && lane == 0) {
+            const int words = (cfg.n_items + 31) / 32;
+            visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
+        }
+    }
+    env_step_wave(cfg, tab, st, j, j, act, lane, obs_out, rew_out, done_out, ctr_out, nullptr);
+    if (force_length > 0 && act >= 0 && lane == 0) {  // collector.py:253-258
+        st.done[j] = (uint8_t)force_done;
+        done_out[j] = (uint8_t)force_done;
+    }
 }
 
 }  // namespace cirs
@@ -77,40 +109,80 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
     CIRS_REQUIRE(trk_cfg->max_len >= env_cfg->max_turn + 1, "tracker max_len < max_turn + 1");
     const long B = n_env, S = trk_cfg->dim_state;
     hipStream_t s = (hipStream_t)stream;
-    for (int t = t_begin; t < t_end; ++t) {
-        float* obs_t = traj->obs + (size_t)t * B * S;
-        float* obs_n = traj->obs + (size_t)(t + 1) * B * S;
-        int64_t* act_t = traj->act + (size_t)t * B;
-        double* rew_t = traj->rew + (size_t)t * B;
-        uint8_t* done_t = traj->done + (size_t)t * B;
-        // policy(obs_t): finished envs (env_st->done) are skipped and get act = -1
-        if (int rc = cirs_actor_sample(pol_cfg, pol_w, obs_t, S, n_env, nullptr, seed, rng_base + (uint32_t)t, nullptr,
-                                       visited, env_st->done, act_t, traj->logp + (size_t)t * B,
-                                       traj->value + (size_t)t * B, workspace, workspace_bytes, stream))
-            return rc;
-        if (visited) {
-            hipLaunchKernelGGL(mark_visited_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, act_t, n_env,
-                               pol_cfg->n_items, visited);
-            CIRS_CHECK_LAUNCH("mark_visited_kernel");
-        }
-        if (online) {  // score the chosen (user, item) pairs with the DeepFM user model
+    if (online) {  // per-step user-model scoring sits between the policy and the env step: unfused launch sequence
+        for (int t = t_begin; t < t_end; ++t) {
+            float* obs_t = traj->obs + (size_t)t * B * S;
+            float* obs_n = traj->obs + (size_t)(t + 1) * B * S;
+            int64_t* act_t = traj->act + (size_t)t * B;
+            double* rew_t = traj->rew + (size_t)t * B;
+            uint8_t* done_t = traj->done + (size_t)t * B;
+            // policy(obs_t): finished envs (env_st->done) are skipped and get act = -1
+            if (int rc = cirs_actor_sample(pol_cfg, pol_w, obs_t, S, n_env, nullptr, seed, rng_base + (uint32_t)t, nullptr,
+                                           visited, env_st->done, act_t, traj->logp + (size_t)t * B,
+                                           traj->value + (size_t)t * B, workspace, workspace_bytes, stream))
+                return rc;
+            if (visited) {
+                hipLaunchKernelGGL(mark_visited_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, act_t, n_env,
+                                   pol_cfg->n_items, visited);
+                CIRS_CHECK_LAUNCH("mark_visited_kernel");
+            }
+            // score the chosen (user, item) pairs with the DeepFM user model
             hipLaunchKernelGGL(online_pairs_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, env_st->user, act_t, n_env, *online);
             CIRS_CHECK_LAUNCH("online_pairs_kernel");
             if (int rc = cirs_deepfm_forward(online->cfg, online->w, online->uid_buf, online->pid_buf, online->feat_buf, online->dur_buf,
                                              n_env, online->pred_buf, stream))
                 return rc;
+            // env.step: obs_next id == action, so the int64 obs row doubles as scratch we do not keep
+            if (int rc = cirs_env_step(env_cfg, env_tab, env_st, act_t, nullptr, n_env, (int64_t*)workspace, rew_t, done_t,
+                                       traj->ctr + (size_t)t * B, nullptr, stream))
+                return rc;
+            if (force_length > 0) {
+                hipLaunchKernelGGL(force_done_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, env_st->done, done_t, act_t,
+                                   n_env, (t + 1 >= force_length) ? 1 : 0);
+                CIRS_CHECK_LAUNCH("force_done_kernel");
+            }
+            // preprocess_fn(obs_next, rew): tracker appends one position for every env that acted this step
+            if (int rc = cirs_tracker_step(trk_cfg, trk_w, trk_st, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, stream))
+                return rc;
         }
-        // env.step: obs_next id == action, so the int64 obs row doubles as scratch we do not keep
-        if (int rc = cirs_env_step(env_cfg, env_tab, env_st, act_t, nullptr, n_env, (int64_t*)workspace, rew_t, done_t,
-                                   traj->ctr + (size_t)t * B, nullptr, stream))
-            return rc;
-        if (force_length > 0) {
-            hipLaunchKernelGGL(force_done_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, env_st->done, done_t, act_t,
-                               n_env, (t + 1 >= force_length) ? 1 : 0);
-            CIRS_CHECK_LAUNCH("force_done_kernel");
+        return CIRS_OK;
+    }
+    // ---- fused sequence: 3 launches per vector step ------------------------------------------------------------
+    //   actor_head_kernel<sample>   MFMA head + Gumbel-max partials            (trunk of obs_t already in the workspace)
+    //   step_tail_kernel            merge -> act/logp, visited bit, env step, forced length
+    //   tracker_step_kernel + trunk tracker decode step, then the policy trunk of obs_{t+1}
+    CIRS_REQUIRE(pol_cfg->hidden == kH && pol_cfg->dim_state == S && pol_cfg->n_items == env_cfg->n_items, "policy/env/tracker shape mismatch");
+    CIRS_REQUIRE(pol_w->w1 && pol_w->b1 && pol_w->w2 && pol_w->b2 && pol_w->wa && pol_w->ba && pol_w->wc && pol_w->bc, "policy weight pointer null");
+    CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(pol_cfg, n_env), "workspace too small");
+    CIRS_REQUIRE(env_tab->item_cats && (env_tab->normed_mat || !env_cfg->simulated) && (env_tab->mat || env_cfg->simulated), "env tables incomplete");
+    if (t_begin >= t_end) return CIRS_OK;
+    float* h2 = (float*)workspace;
+    const int n_pad = n_pad_of(n_env), n_chunks = n_chunks_of(pol_cfg->n_items);
+    ActorPartialView pv = partial_view(workspace, n_env, pol_cfg->n_items);
+    int64_t* obs_scratch = nullptr;  // the env's obs_next id == the action: not materialised
+    // trunk of the first step of this call (later ones ride on the tracker step)
+    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_env, 4)), dim3(256), 0, s, *pol_cfg, *pol_w, traj->obs + (size_t)t_begin * B * S, (long)S,
+                       n_env, (const uint8_t*)env_st->done, h2, traj->value + (size_t)t_begin * B, (float*)nullptr);
+    CIRS_CHECK_LAUNCH("trunk_kernel");
+    for (int t = t_begin; t < t_end; ++t) {
+        float* obs_n = traj->obs + (size_t)(t + 1) * B * S;
+        int64_t* act_t = traj->act + (size_t)t * B;
+        double* rew_t = traj->rew + (size_t)t * B;
+        uint8_t* done_t = traj->done + (size_t)t * B;
+        hipLaunchKernelGGL(actor_head_kernel<true>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, *pol_cfg, pol_w->wa, pol_w->ba,
+                           (const float*)h2, n_env, (const float*)nullptr, seed, rng_base + (uint32_t)t, (const int32_t*)nullptr,
+                           (const uint32_t*)visited, (const uint8_t*)env_st->done, pv, n_pad);
+        CIRS_CHECK_LAUNCH("actor_head_kernel");
+        hipLaunchKernelGGL(step_tail_kernel, dim3(cdiv(n_env, kEnvsPerBlock)), dim3(256), 0, s, *env_cfg, *env_tab, *env_st, n_env, n_pad,
+                           n_chunks, pv, pol_w->wa, pol_w->ba, (const float*)h2, visited, force_length, (t + 1 >= force_length) ? 1 : 0,
+                           act_t, traj->logp + (size_t)t * B, obs_scratch, rew_t, done_t, traj->ctr + (size_t)t * B);
+        CIRS_CHECK_LAUNCH("step_tail_kernel");
+        TrunkFuse tf{};
+        if (t + 1 < t_end) {
+            tf.on = 1; tf.cfg = *pol_cfg; tf.w = *pol_w; tf.skip = env_st->done; tf.h2 = h2; tf.value = traj->value + (size_t)(t + 1) * B;
         }
-        // preprocess_fn(obs_next, rew): tracker appends one position for every env that acted this step
-        if (int rc = cirs_tracker_step(trk_cfg, trk_w, trk_st, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, stream))
+        // preprocess_fn(obs_next, rew): the tracker appends one position for every env that acted this step
+        if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, &tf, s))
             return rc;
     }
     return CIRS_OK;

@@ -14,7 +14,8 @@
 //
 // Bytes per env-step: 128 B embedding row + 2 layers x (pos x 256 B K/V reads + 256 B K/V writes) + 128 B x_hist
 // + 80 B state; weights (~118 KB) are shared by all envs and stay in L2.  ~60 kFLOP per env-step: latency-bound.
-#include "common.h"
+#include "internal.h"
+#include "policy_kernels.h"
 
 namespace cirs {
 
@@ -54,13 +55,21 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
                                                            const int32_t* __restrict__ env_ids,
                                                            const uint8_t* __restrict__ skip, int n,
                                                            float* __restrict__ state_out, long state_stride,
-                                                           int lpad) {
+                                                           int lpad, TrunkFuse tf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = kD / NHEAD;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wv;
     if (j >= n) return;
-    if (skip && skip[j]) return;
+// rows that do not step still owe the fused trunk its "skipped row" outputs
+#define CIRS_TRUNK_ZERO()                                                  \
+    do {                                                                   \
+        if (tf.on) {                                                       \
+            tf.h2[(size_t)j * kH + lane] = 0.f;                            \
+            if (lane == 0 && tf.value) tf.value[j] = 0.f;                  \
+        }                                                                  \
+    } while (0)
+    if (skip && skip[j]) { CIRS_TRUNK_ZERO(); return; }
     const int e = env_ids ? env_ids[j] : j;
     const int B = cfg.n_env, L = cfg.max_len;
     // per-wave scratch
@@ -76,9 +85,9 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     const int o32 = lane & (kD - 1);
 
     const bool is_init = users != nullptr;
-    if (!is_init && items[j] < 0) return;  // act = -1: env finished earlier in this rollout
+    if (!is_init && items[j] < 0) { CIRS_TRUNK_ZERO(); return; }  // act = -1: env finished earlier in this rollout
     const int pos = is_init ? 0 : st.len[e];
-    if (pos >= L) return;  // history full: the caller never steps past max_turn (collector drops finished envs)
+    if (pos >= L) { CIRS_TRUNK_ZERO(); return; }  // history full: the caller never steps past max_turn
 
     // ---- 1. new input slot --------------------------------------------------------------------------------
     float x;
@@ -205,9 +214,21 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     // ---- 4. decoder ------------------------------------------------------------------------------------------
     if (lane < kD) xs[lane] = h;
     __builtin_amdgcn_wave_barrier();
-    if (lane < cfg.dim_state)
-        state_out[(size_t)j * state_stride + lane] = dot_row<kD>(w.dec_w + (size_t)lane * kD, xs, w.dec_b[lane]);
+    float sval = 0.f;
+    if (lane < cfg.dim_state) {
+        sval = dot_row<kD>(w.dec_w + (size_t)lane * kD, xs, w.dec_b[lane]);
+        state_out[(size_t)j * state_stride + lane] = sval;
+    }
     if (lane == 0) st.len[e] = pos + 1;
+    if (tf.on) {  // policy trunk of the next vector step on this state
+        if (tf.skip && tf.skip[j]) { CIRS_TRUNK_ZERO(); return; }
+        float* txs = ffs;        // [64] input, then h2 (critic)
+        float* ths = ffs + 64;   // [64] h1
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cfg.dim_state) txs[lane] = sval;
+        trunk_compute(tf.cfg, tf.w, txs, ths, lane, j, tf.h2, tf.value, nullptr);
+    }
+#undef CIRS_TRUNK_ZERO
 }
 
 static int validate_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st) {
@@ -229,14 +250,20 @@ static int validate_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weig
 
 static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
                           const int32_t* users, const int64_t* items, const double* rew, const int32_t* env_ids,
-                          const uint8_t* skip, int n, float* state_out, long state_stride, hipStream_t s) {
+                          const uint8_t* skip, int n, float* state_out, long state_stride, hipStream_t s,
+                          const TrunkFuse* fuse = nullptr) {
+    TrunkFuse tf{};
+    if (fuse) {
+        tf = *fuse;
+        if (tf.on && (tf.cfg.hidden != kH || tf.cfg.dim_state != cfg->dim_state || !tf.h2)) return fail(CIRS_E_INVALID, "fused trunk: bad policy configuration");
+    }
     const int lpad = (cfg->max_len + 3) & ~3;
     const size_t shmem = 4 * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad);
     if (shmem > 160 * 1024) return fail(CIRS_E_UNSUPPORTED, "max_len too large for the LDS score buffer");
     const dim3 grid(cdiv(n, 4)), block(256);
 #define CIRS_TRK(NH)                                                                                              \
     hipLaunchKernelGGL(tracker_step_kernel<NH>, grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
-                       n, state_out, state_stride, lpad)
+                       n, state_out, state_stride, lpad, tf)
     switch (cfg->nhead) {
         case 1: CIRS_TRK(1); break;
         case 2: CIRS_TRK(2); break;
@@ -246,6 +273,12 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
 #undef CIRS_TRK
     CIRS_CHECK_LAUNCH("tracker_step_kernel");
     return CIRS_OK;
+}
+
+int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
+                          const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
+                          long state_stride, const TrunkFuse* tf, hipStream_t s) {
+    return launch_tracker(cfg, w, st, users, items, rew, env_ids, skip, n, state_out, state_stride, s, tf);
 }
 
 }  // namespace cirs
