@@ -155,7 +155,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 2 * (size_t)n_pad * kH;                       // da2, da1
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I);    // dwap
-    f += 64 + 256;                                     // red + sum-of-squares partials
+    f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
     f += dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64;  // dW slabs
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
     return f;
@@ -177,7 +177,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
     v.dwap = take((size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I));
     v.red = take(64);
-    v.normp = take(256);
+    v.normp = take(1024);
     v.dwp = take(dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64);
     v.head_ws = (void*)p;
     return v;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
 
 // clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1).
 // stage 1: kNormBlocks workgroups, each a contiguous slice, fixed-order tree -> partial sums of squares
-constexpr int kNormBlocks = 256;
+constexpr int kNormBlocks = 1024;  // 4 per CU: enough loads in flight to stream the gradient slabs
 // sum the dWa slabs in fixed order into the flat gradient buffer (data-parallel path: grads must be complete before
 // the all-reduce; the single-rank path folds this into sumsq_partial_kernel)
 __global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict__ dwap, long seg, long stride, int n_slabs, float* __restrict__ g_wa_ba) {
@@ -750,7 +750,13 @@ __global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const
     __shared__ float sh3[768];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && mb > 0) loss_partials_block(mb, mb_norm, mv, tail, sh3);
-    sh[tid] = tid < kNormBlocks ? partial[tid] : 0.f;
+    static_assert(kNormBlocks % 256 == 0, "each thread folds kNormBlocks/256 partials");
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < kNormBlocks / 256; ++q) t += partial[tid + 256 * q];
+        sh[tid] = t;
+    }
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) sh[tid] += sh[tid + s];
