@@ -53,8 +53,9 @@ def build_engine(wl, rank, world, device):
 
 
 def hip_event_kernel_time(eng, wl, reps=20):
-    """Average duration (HIP events on the launch stream) of the dominant kernel pair of a PPO minibatch step:
-    the two MFMA head-backward kernels, launched exactly as inside the timed region."""
+    """Average duration (HIP events on the launch stream) of one whole PPO minibatch step (cirs_ppo_minibatch: the MFMA
+    actor-head forward + fused backward kernels and the six small kernels around them), launched exactly as inside the
+    timed region."""
     from cirs_hip import abi
     import ctypes as C
     ln = eng.learner
@@ -276,10 +277,11 @@ def main():
         # (profiles/r01f_pmc_minibatch_step.md: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as reported)
         out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_PER_MINIBATCH if args.workload == "c3" else None
         out["roofline"]["traffic_source"] = "profiles/r01f_pmc_minibatch_step.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
-        out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
-        out["sweep_mode"] = sweep_mode_probe(wl, eng, device)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
+        if world == 1:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
+            out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
+            out["sweep_mode"] = sweep_mode_probe(wl, eng, device)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
