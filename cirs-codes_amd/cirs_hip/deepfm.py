@@ -72,3 +72,12 @@ class DeviceDeepFM:
         abi.check(self._lib.cirs_normed_reward(pred.data_ptr(), pred.numel(), mm.data_ptr(), out.data_ptr(), self._stream()),
                   "cirs_normed_reward")
         return out
+
+
+def hash_ids(ids, n_buckets: int, device="cuda") -> torch.Tensor:
+    """splitmix64(id) mod n_buckets on the device (cirs_hash_ids): maps open-vocabulary ids into a fixed-size table."""
+    ids = torch.as_tensor(ids).to(device, torch.int64).contiguous()
+    out = torch.empty_like(ids)
+    abi.check(abi.lib().cirs_hash_ids(ids.data_ptr(), ids.numel(), int(n_buckets), out.data_ptr(), torch.cuda.current_stream(ids.device).cuda_stream),
+              "cirs_hash_ids")
+    return out

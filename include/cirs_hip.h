@@ -419,6 +419,11 @@ int cirs_rollout_static(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                         int32_t t_begin, int32_t t_end, int32_t softmax, float epsilon, uint64_t seed, uint32_t rng_base,
                         uint32_t* visited, int32_t force_length, int64_t* obs_scratch, void* stream);
 
+/* ---- feature hashing (BASELINE configs[4]: open-vocabulary ids hashed into fixed-size tables) -----------------------
+ * out[i] = splitmix64(ids[i]) mod n_buckets.  No reference counterpart (DeepCTR-Torch inputs.py:31-33 only prints a notice
+ * for use_hash): the mapping is this build's own and is restated bit for bit by the oracle. */
+int cirs_hash_ids(const int64_t* ids, int64_t n, int64_t n_buckets, int64_t* out, void* stream);
+
 /* ---- evaluation metrics on device trajectories ---------------------------------------------------
  * Replaces the buffer walks of Callback_Coverage_Count.on_epoch_end (reference evaluation.py:303-352) and the
  * row test of get_feat_dominate_dict (evaluation.py:36-44):

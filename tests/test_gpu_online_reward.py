@@ -170,3 +170,53 @@ def test_engine_collect_update_million_item_catalogue():
     assert float(dtk.abs().max()) > 0
     eng2, lengths2, losses2, n2, _, _ = run()
     assert torch.equal(eng.policy_flat, eng2.policy_flat) and torch.equal(eng.tracker_flat, eng2.tracker_flat)
+
+
+def test_c5_shape_hashed_ids_emb64():
+    """configs[4] shape on one GPU: ids from an open vocabulary hashed into 2^20-row tables (splitmix64, bit-exact vs the
+    oracle), DeepFM emb_dim = 64, online reward inside the rollout."""
+    import ctypes as C
+    import oracle_lib
+    from cirs_hip.deepfm import DeviceDeepFM, hash_ids
+    from cirs_hip.env import DeviceEnv, DeviceEnvTables
+    from cirs_hip.policy import DevicePolicy
+    from cirs_hip.rollout import DeviceRollout, OnlineReward
+    from cirs_hip.tracker import DeviceTracker
+    import policycase
+    NB = 1 << 20
+    rng = np.random.RandomState(21)
+    raw = rng.randint(0, 1 << 62, 50000, dtype=np.int64)
+    got = hash_ids(raw, NB).cpu().numpy()
+    want = np.zeros_like(raw)
+    assert oracle_lib.lib().oracle_hash_ids(raw.ctypes.data, raw.size, NB, want.ctypes.data) == 0
+    np.testing.assert_array_equal(got, want)
+    assert got.min() >= 0 and got.max() < NB and len(np.unique(got)) > 48000          # well spread
+    # env over the hashed id space: user u / item i of the env ARE bucket ids
+    U = I = NB
+    B, T = 128, 4
+    cats = np.where(np.arange(4)[None, :] < rng.randint(1, 5, I)[:, None], rng.randint(0, 31, (I, 4)), -1).astype(np.int32)
+    feats = np.where(cats >= 0, cats + 1, 0).astype(np.int32)
+    dur = rng.uniform(2, 60, I).astype(np.float32)
+    um = DeviceDeepFM(deepfmcase.random_weights(rng, U, I, 64))
+    dt = DeviceEnvTables(None, None, cats, n_users=U, n_items=I)
+    env = DeviceEnv(dt, B, num_leave_compute=3, leave_threshold=1, max_turn=T, tau=10.0, gamma_exposure=10.0, dist_mode=1)
+    tp = rolloutcase.tracker_param_dict(U, I, T, 4)
+    trk = DeviceTracker({k: v.float().cuda().contiguous() for k, v in tp.items()}, U, I, B, T)
+    arrs = policycase.random_weights(rng, I)
+    pol = DevicePolicy({rolloutcase.POLICY_NAMES[k]: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in arrs.items()}, I)
+    ident = np.arange(I, dtype=np.int64)
+    ro = DeviceRollout(env, trk, pol, online=OnlineReward(um, ident, ident, feats, dur, (-60.0, 60.0), B))
+    users = hash_ids(raw[:B], NB).to(torch.int32)
+    ro.collect(users, seed=9)
+    act = ro.traj.act.cpu().numpy().T; rew = ro.traj.rew.cpu().numpy().T
+    a0 = act[:, 0]
+    raw_s = um.forward(users.cpu().numpy().astype(np.int64), a0, feats[a0], dur[a0]).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(rew[:, 0], (raw_s + 60.0) / 120.0, rtol=1e-12)
+    # the pair scorer at E = 64 against the C oracle on the chosen pairs
+    want_s = deepfmcase.oracle_forward(um_weights(um), users.cpu().numpy().astype(np.int64), a0, feats[a0], dur[a0])
+    np.testing.assert_allclose(raw_s, want_s, rtol=2e-5, atol=5e-6)
+
+
+def um_weights(um):
+    from cirs_hip import abi
+    return {f: um.t[f].cpu().numpy() for f in abi.DEEPFM_FIELDS}
