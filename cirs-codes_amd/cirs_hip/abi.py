@@ -143,6 +143,11 @@ SIGNATURES = {
     "cirs_normed_reward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "cirs_ppo_minibatch_dp": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, _P,
                                         C.c_int32, _P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P]),
+    "cirs_deepfm_train_param_count": (C.c_int64, [C.POINTER(DeepFMCfg)]),
+    "cirs_deepfm_train_workspace_bytes": (C.c_int64, [C.POINTER(DeepFMCfg), C.c_int32]),
+    "cirs_deepfm_train_step": (C.c_int, [C.POINTER(DeepFMCfg), _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32,
+                                         C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         _P, _P, C.c_int64, _P]),
     "cirs_select_items": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_float, _P, C.c_uint64, C.c_uint32,
                                     _P, _P, _P]),
     "cirs_rollout_static": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState), _P, C.c_int64, _P, C.POINTER(Traj),

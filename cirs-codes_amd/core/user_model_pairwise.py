@@ -10,10 +10,26 @@ from core.inputs import SparseFeatP, compute_input_dim
 from deepctr_torch.inputs import DenseFeat, build_input_features
 
 
+def make_loss_kuaishou_pairwise(lambda_ab: float):
+    """loss_kuaishou_pairwise of CIRS-UserModel-kuaishou.py:262-278 with its `args.lambda_ab` bound.  The returned callable
+    is the torch formula (documentation / host use); fit_data recognises it by its `lambda_ab` attribute and runs the same
+    loss inside cirs_deepfm_train_step."""
+    def loss_kuaishou_pairwise(y, y_deepfm_pos, y_deepfm_neg, exposure, alpha_u=None, beta_i=None):
+        if alpha_u is not None:
+            exposure_new = exposure * alpha_u * beta_i
+            loss_ab = ((alpha_u - 1) ** 2).mean() + ((beta_i - 1) ** 2).mean()
+        else:
+            exposure_new, loss_ab = exposure, 0
+        y_exposure = 1 / (1 + exposure_new) * y_deepfm_pos
+        return ((y_exposure - y) ** 2).mean() - torch.sigmoid(y_deepfm_pos - y_deepfm_neg).log().mean() + lambda_ab * loss_ab
+    loss_kuaishou_pairwise.lambda_ab = float(lambda_ab)
+    return loss_kuaishou_pairwise
+
+
 class UserModel_Pairwise(nn.Module):
     def __init__(self, feature_columns, y_columns, task, task_logit_dim, dnn_hidden_units=(128, 128), l2_reg_embedding=1e-5,
                  l2_reg_dnn=1e-1, init_std=0.0001, task_dnn_units=None, seed=2022, dnn_dropout=0, dnn_activation="relu",
-                 dnn_use_bn=False, device="cpu", padding_idx=None, ab_columns=None):
+                 dnn_use_bn=False, device="cpu", padding_idx=None, ab_columns=None, l2_reg_linear=1e-5):
         super().__init__()
         assert task == "regression" and task_logit_dim == 1 and tuple(dnn_hidden_units) == (64, 64) and not dnn_use_bn
         self.feature_columns, self.y_columns = feature_columns, y_columns
@@ -41,6 +57,59 @@ class UserModel_Pairwise(nn.Module):
         if ab_columns is not None:
             self.ab_embedding_dict = nn.ModuleDict({c.embedding_name: nn.Embedding(int(c.vocabulary_size), 1) for c in ab_columns})
         self._dev = None
+        self._l2 = (float(l2_reg_embedding), float(l2_reg_linear), float(l2_reg_dnn))
+        self._trainer = None
+        self.optim = None
+
+    # ---- training (reference core/user_model.py:74-170) ---------------------------------------------------------------
+    def compile(self, optimizer, loss_dict=None, metrics=None, metric_fun=None, loss_func=None):
+        assert optimizer == "adam" or isinstance(optimizer, torch.optim.Adam), "the device step implements torch.optim.Adam"
+        assert loss_func is not None and hasattr(loss_func, "lambda_ab"), \
+            "pass core.user_model_pairwise.make_loss_kuaishou_pairwise(lambda_ab): the loss runs inside cirs_deepfm_train_step"
+        self.metrics_names = ["loss"]
+        self.loss_func, self.metric_fun, self.metrics = loss_func, metric_fun, metrics
+        self.optim = "adam"
+        self._lr = optimizer.param_groups[0]["lr"] if isinstance(optimizer, torch.optim.Adam) else 1e-3
+
+    def fit_data(self, dataset_train, dataset_val=None, batch_size=256, epochs=1, verbose=1, initial_epoch=0, callbacks=None, shuffle=True):
+        """One pass per epoch over (x, y, score) minibatches; every step is cirs_deepfm_train_step on the device."""
+        from cirs_hip.deepfm_train import DeepFMTrainer
+        assert self.optim is not None, "call compile() first"
+        if self._trainer is None:
+            self._trainer = DeepFMTrainer(self.state_dict(), use_ab=self.ab_columns is not None, lambda_ab=self.loss_func.lambda_ab,
+                                          l2_embedding=self._l2[0], l2_linear=self._l2[1], l2_all=self._l2[2], lr=self._lr)
+        tr = self._trainer
+        x = torch.as_tensor(dataset_train.x_numpy).to(tr.device, torch.float32)
+        y = torch.as_tensor(dataset_train.y_numpy).to(tr.device, torch.float32)
+        score = torch.as_tensor(dataset_train.score).to(tr.device, torch.float32)
+        n_all = x.shape[0]
+        callbacks = callbacks or []
+        for cb in callbacks:
+            cb.on_train_begin()
+        history = []
+        for epoch in range(initial_epoch, epochs):
+            for cb in callbacks:
+                cb.on_epoch_begin(epoch)
+            order = torch.randperm(n_all, device=tr.device) if shuffle else torch.arange(n_all, device=tr.device)
+            loss_sum = torch.zeros((), device=tr.device)
+            for s0 in range(0, n_all, batch_size):
+                idx = order[s0:s0 + batch_size]
+                lo = tr.step(x[idx], y[idx], score[idx])
+                loss_sum += lo[0] + lo[4]
+            logs = {"loss": float(loss_sum) / n_all}       # total_loss_epoch / sample_num (core/user_model.py:205)
+            history.append(logs)
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+        for cb in callbacks:
+            cb.on_train_end()
+        # publish the trained parameters under the module's state_dict names
+        with torch.no_grad():
+            mine = dict(self.named_parameters())
+            for k, v in tr.state_dict().items():
+                if k in mine:
+                    mine[k].copy_(v.reshape(mine[k].shape).to(mine[k].device))
+        self._dev = None
+        return history
 
     def device_model(self):
         """DeviceDeepFM over the current weights (rebuilt after load_state_dict)."""

@@ -400,6 +400,29 @@ int cirs_deepfm_sweep(const cirs_deepfm_cfg* cfg, const cirs_deepfm_weights* w, 
 /* normed = (pred - min) / (max - min) in float64 (kuaishouEnv.py:139-143) */
 int cirs_normed_reward(const float* pred, int64_t n, const float* minmax, double* normed_out, void* stream);
 
+/* ---- user-model training ---------------------------------------------------------------------------
+ * One optimiser step of fit_data's inner loop (reference core/user_model.py:150-170) for UserModel_Pairwise:
+ *   loss = loss_kuaishou_pairwise(y, y_pos, y_neg, exposure, alpha_u[uid], beta_i[pid])   (CIRS-UserModel-kuaishou.py:262-278,
+ *                                                                                         core/user_model_pairwise.py:134-151)
+ *        + get_regularization_loss()                                                      (core/user_model.py:401-417)
+ *   total_loss.backward(); Adam step (lr, betas, eps of torch.optim.Adam).
+ * Parameters, gradients and the two Adam moments are flat fp32 buffers of cirs_deepfm_train_param_count(cfg) floats in
+ * the order  emb_user [U,E] | emb_item [I,E] | emb_feat [F,E] | lin_user [U] | lin_item [I] | lin_feat [F] | lin_dense [1]
+ *          | w1 [64,6E+1] | b1 [64] | w2 [64,64] | b2 [64] | last [64] | out_bias [1] | alpha_u [U] | beta_i [I]
+ *          | linear_model.{user,item,feat} [U],[I],[F] | linear_model.weight [1]      (the unused duplicate of SURVEY Q12,
+ *                                                                                       which the regulariser still decays).
+ * Batch columns: positive pair (uid, pid, feats[n,4], dur), negative pair (same layout), y [n], exposure [n].
+ * l2_embedding / l2_linear / l2_all: the three regularisation lists of the reference (embedding_dict, linear_model, all).
+ * loss_out[5] = {loss, loss_y, bpr, loss_ab, reg_loss}. */
+int64_t cirs_deepfm_train_param_count(const cirs_deepfm_cfg* cfg);
+int64_t cirs_deepfm_train_workspace_bytes(const cirs_deepfm_cfg* cfg, int32_t n);
+int cirs_deepfm_train_step(const cirs_deepfm_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
+                           int64_t step_before, const int64_t* uid_pos, const int64_t* pid_pos, const int32_t* feats_pos,
+                           const float* dur_pos, const int64_t* uid_neg, const int64_t* pid_neg, const int32_t* feats_neg,
+                           const float* dur_neg, const float* y, const float* exposure, int32_t n, int32_t use_ab,
+                           float lambda_ab, float l2_embedding, float l2_linear, float l2_all, float lr, float beta1,
+                           float beta2, float eps, float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- the user model as a static recommendation policy ---------------------------------------------
  * cirs_select_items replaces the tail of UserModel.recommend_k_item (reference core/user_model.py:296-346, k = 1) for n
  * users at once, given their catalogue scores (cirs_deepfm_sweep):

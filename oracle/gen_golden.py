@@ -627,7 +627,92 @@ def gen_staticpolicy():
     print("staticpolicy.npz:", {k: out[k] for k in out if k.endswith("_out") or k.endswith("_res")})
 
 
-FAMILIES = {"staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+def gen_usertrain():
+    """UserModel_Pairwise training (reference core/user_model.py:87-170 fit_data, core/user_model_pairwise.py:134-151 get_loss,
+    CIRS-UserModel-kuaishou.py:262-278 loss_kuaishou_pairwise): three optimiser steps on fixed batches, run BOTH through the
+    reference's fit_data (shuffle off) and through its inner-loop statements one by one (per-step losses)."""
+    import copy
+    import importlib.util
+    from types import SimpleNamespace
+    from core.user_model_pairwise import UserModel_Pairwise
+    from core.inputs import SparseFeatP
+    from core.static_dataset import StaticDataset
+    from deepctr_torch.inputs import DenseFeat
+    spec = importlib.util.spec_from_file_location("cirs_usermodel_script", os.path.join(ref_harness.REF_ROOT, "CIRS-UserModel-kuaishou.py"))
+    script = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(script)               # defines loss_kuaishou_pairwise (reads the module-level `args.lambda_ab`)
+    out = {}
+    for ci, (U, I, E, n, use_ab, lam) in enumerate([(50, 80, 8, 32, True, 10.0), (40, 60, 16, 48, True, 1.0), (30, 50, 8, 16, False, 0.0)]):
+        script.args = SimpleNamespace(lambda_ab=lam)
+        F = 32
+        x_columns = [SparseFeatP("user_id", U, embedding_dim=E), SparseFeatP("photo_id", I, embedding_dim=E)] + \
+                    [SparseFeatP(f"feat{i}", F, embedding_dim=E, embedding_name="feat", padding_idx=0) for i in range(4)] + [DenseFeat("photo_duration", 1)]
+        ab_columns = [SparseFeatP("alpha_u", U, embedding_dim=1), SparseFeatP("beta_i", I, embedding_dim=1)] if use_ab else None
+        y_columns = [DenseFeat("y", 1)]
+        torch.manual_seed(7 + ci)
+        model = UserModel_Pairwise(x_columns, y_columns, "regression", 1, dnn_hidden_units=(64, 64), seed=2022, l2_reg_dnn=0.1, device="cpu",
+                                   ab_columns=ab_columns)
+        rng = np.random.RandomState(ci)
+        with torch.no_grad():     # the reference initialises embeddings with std 1e-4: scale up so every term of the loss matters
+            for name, prm in model.named_parameters():
+                if "embedding_dict" in name and "ab_" not in name:
+                    prm.copy_(torch.as_tensor(rng.normal(0, 0.3, prm.shape).astype(np.float32)))
+                    if name == "embedding_dict.feat.weight":
+                        prm[0] = 0
+                if name.startswith("ab_embedding_dict"):
+                    prm.copy_(torch.as_tensor(rng.normal(1, 0.2, prm.shape).astype(np.float32)))
+        init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+        steps = 3
+
+        def col(v):
+            return np.asarray(v, np.float64)[:, None]
+        N = steps * n
+        feats = lambda: np.where(np.arange(4)[None, :] < rng.randint(1, 5, N)[:, None], rng.randint(1, F, (N, 4)), 0)
+        u = rng.randint(0, U, N)
+        x = np.concatenate([col(u), col(rng.randint(0, I, N)), feats(), col(rng.uniform(2, 60, N)),
+                            col(u), col(rng.randint(0, I, N)), feats(), col(rng.uniform(2, 60, N))], axis=1)
+        y = rng.uniform(0, 5, (N, 1)); score = rng.gamma(1.0, 0.5, (N, 1))
+        model.compile(optimizer="adam", loss_func=script.loss_kuaishou_pairwise, metric_fun={}, metrics=None)
+        model_b = copy.deepcopy(model)
+        model_b.compile(optimizer="adam", loss_func=script.loss_kuaishou_pairwise, metric_fun={}, metrics=None)
+        # (a) the reference's own loop
+        ds = StaticDataset(x_columns, y_columns, num_workers=0)
+        ds.compile_dataset(pd.DataFrame(x), pd.DataFrame(y), score)
+        model.RL_eval_fun = None
+        model.fit_data(ds, dataset_val=None, batch_size=n, epochs=1, shuffle=False, callbacks=[])
+        final_a = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+        # (b) the same statements step by step, for the per-step numbers
+        losses = []
+        for st in range(steps):
+            xb = torch.as_tensor(x[st * n:(st + 1) * n]).float(); yb = torch.as_tensor(y[st * n:(st + 1) * n]).float()
+            sb = torch.as_tensor(score[st * n:(st + 1) * n]).float()
+            loss = model_b.get_loss(xb, yb, sb).squeeze()
+            model_b.optim.zero_grad()
+            reg = model_b.get_regularization_loss()
+            total = loss + reg + model_b.aux_loss
+            total.backward()
+            model_b.optim.step()
+            losses.append([float(loss), float(reg)])
+            if st == 0:
+                first = {k: v.detach().clone().numpy() for k, v in model_b.state_dict().items()}
+        final_b = {k: v.detach().clone().numpy() for k, v in model_b.state_dict().items()}
+        for k in final_a:
+            assert np.array_equal(final_a[k], final_b[k]), k          # the step-by-step replay IS fit_data
+        pre = f"c{ci}_"
+        out[pre + "cfg"] = np.array([U, I, F, E, n, int(use_ab), steps], np.int64); out[pre + "lambda_ab"] = lam
+        out[pre + "x"] = x; out[pre + "y"] = y; out[pre + "score"] = score; out[pre + "losses"] = np.array(losses)
+        for k, v in init.items():
+            out[pre + "init_" + k] = v
+        for k, v in first.items():
+            out[pre + "first_" + k] = v
+        for k, v in final_a.items():
+            out[pre + "final_" + k] = v
+    out["n_cases"] = 3
+    np.savez_compressed(os.path.join(GOLDEN, "usertrain.npz"), **out)
+    print("usertrain.npz:", {k: out[k] for k in out if k.endswith("losses")})
+
+
+FAMILIES = {"usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

@@ -259,3 +259,65 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
                trk_grads={k: g.clone() for k, g in trk_grads.items()}, obs=obs.detach().numpy(),
                dobs_rows=dobs_rows.numpy(), logits_old=None)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# User-model training: plain-PyTorch restatement of one epoch of fit_data's inner loop for UserModel_Pairwise
+#   forward        core/user_model_pairwise.py:98-132 (_deepfm: linear + FM + DNN), deepctr_torch layers
+#   loss           CIRS-UserModel-kuaishou.py:262-278 (loss_kuaishou_pairwise), core/user_model_pairwise.py:134-151 (get_loss)
+#   regulariser    core/user_model.py:401-417 with the three weight lists of :60-63 and user_model_pairwise.py:93
+#   optimiser      torch.optim.Adam(lr=1e-3) over every parameter (core/user_model.py:_get_optim)
+# ---------------------------------------------------------------------------------------------------------------------
+def deepfm_pair_forward(sd, X):
+    """X [n,7] float = [user, photo, feat0..3, duration] -> y [n]"""
+    ids = X[:, :6].long()
+    dur = X[:, 6:7]
+    vs = [sd["embedding_dict.user_id.weight"][ids[:, 0]], sd["embedding_dict.photo_id.weight"][ids[:, 1]]] + \
+         [sd["embedding_dict.feat.weight"][ids[:, 2 + q]] for q in range(4)]
+    lin = sd["linear.embedding_dict.user_id.weight"][ids[:, 0], 0] + sd["linear.embedding_dict.photo_id.weight"][ids[:, 1], 0]
+    for q in range(4):
+        lin = lin + sd["linear.embedding_dict.feat.weight"][ids[:, 2 + q], 0]
+    lin = lin + dur[:, 0] * sd["linear.weight"].reshape(())
+    S = sum(vs)
+    fm = 0.5 * ((S * S) - sum(v * v for v in vs)).sum(1)
+    x = torch.cat(vs + [dur], dim=1)
+    h1 = torch.relu(x @ sd["dnn.linears.0.weight"].T + sd["dnn.linears.0.bias"])
+    h2 = torch.relu(h1 @ sd["dnn.linears.1.weight"].T + sd["dnn.linears.1.bias"])
+    dnn = (h2 @ sd["last.weight"].T)[:, 0] + sd["out.bias"].reshape(())
+    return lin + fm + dnn
+
+
+def deepfm_train(init, x, y, score, n, steps, use_ab, lambda_ab, l2_embedding=1e-5, l2_linear=1e-5, l2_all=0.1, lr=1e-3):
+    """-> (losses [steps,2] = (loss, reg_loss), state_dict after the first step, state_dict after the last step)"""
+    sd = {k: torch.tensor(np.asarray(v), dtype=torch.float32, requires_grad=True) for k, v in init.items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=lr)
+    x = torch.as_tensor(x, dtype=torch.float32); y = torch.as_tensor(y, dtype=torch.float32).reshape(-1)
+    score = torch.as_tensor(score, dtype=torch.float32).reshape(-1)
+    losses, first = [], None
+    for st in range(steps):
+        xb, yb, sb = x[st * n:(st + 1) * n], y[st * n:(st + 1) * n], score[st * n:(st + 1) * n]
+        yp, yn = deepfm_pair_forward(sd, xb[:, :7]), deepfm_pair_forward(sd, xb[:, 7:])
+        if use_ab:
+            a = sd["ab_embedding_dict.alpha_u.weight"][xb[:, 0].long(), 0]; b = sd["ab_embedding_dict.beta_i.weight"][xb[:, 1].long(), 0]
+            ex_new = sb * a * b
+            loss_ab = ((a - 1) ** 2).mean() + ((b - 1) ** 2).mean()
+        else:
+            ex_new, loss_ab = sb, 0.0
+        loss = ((yp / (1 + ex_new) - yb) ** 2).mean() - torch.log(torch.sigmoid(yp - yn)).mean() + lambda_ab * loss_ab
+        reg = 0.0
+        for k, p in sd.items():
+            c = l2_all
+            if k.startswith("embedding_dict."):
+                c += l2_embedding
+            if k.startswith("linear_model."):
+                c += l2_linear
+            reg = reg + c * (p * p).sum()
+        opt.zero_grad()
+        (loss + reg).backward()
+        sd["embedding_dict.feat.weight"].grad[0] = 0       # nn.Embedding(padding_idx=0): the padding row never receives a gradient...
+        sd["embedding_dict.feat.weight"].grad[0] += 2 * (l2_all + l2_embedding) * sd["embedding_dict.feat.weight"].detach()[0]  # ...but it is regularised
+        opt.step()
+        losses.append([float(loss), float(reg)])
+        if st == 0:
+            first = {k: v.detach().clone().numpy() for k, v in sd.items()}
+    return np.array(losses), first, {k: v.detach().clone().numpy() for k, v in sd.items()}
