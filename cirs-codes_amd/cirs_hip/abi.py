@@ -148,6 +148,8 @@ SIGNATURES = {
     "cirs_deepfm_train_step": (C.c_int, [C.POINTER(DeepFMCfg), _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32,
                                          C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                          _P, _P, C.c_int64, _P]),
+    "cirs_exposure_history": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, C.c_int32, C.c_double, _P, _P]),
+    "cirs_find_negative": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, C.c_int64, _P, _P]),
     "cirs_select_items": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_float, _P, C.c_uint64, C.c_uint32,
                                     _P, _P, _P]),
     "cirs_rollout_static": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState), _P, C.c_int64, _P, C.POINTER(Traj),

@@ -423,6 +423,21 @@ int cirs_deepfm_train_step(const cirs_deepfm_cfg* cfg, float* params, float* gra
                            float lambda_ab, float l2_embedding, float l2_linear, float l2_all, float lr, float beta1,
                            float beta2, float eps, float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- user-model dataset preparation ---------------------------------------------------------------
+ * cirs_exposure_history replaces compute_exposure_each_user / the per-user loop of compute_exposure_effect_kuaishouRec
+ * (reference core/util.py:56-76,135-169): rows are the logged interactions in file order, a user's rows contiguous;
+ *   user_start[r] = index of the first row of row r's user, photo[r] item id, timestamp[r] (float64 seconds);
+ *   dist [n_items, n_items] float64 (1 / similarity) or NULL -> 1 / Jaccard from item_cats [n_items] packed category words;
+ *   exposure_out[r] = sum_{j in [user_start[r], r)} exp(-(max(ts_r - ts_j, ...)) * dist[photo_j, photo_r] / tau), dt == 0 -> 1.
+ * cirs_find_negative replaces find_negative (core/util.py:173-196): seen_small / seen_big are bitmaps
+ *   [n_users, ceil(n_items/32)] of the (user, item) pairs present in the small / big matrix; absent_id = 1225 for KuaiRec;
+ *   neg_out[i] = the sampled negative item (or -1 if none exists). */
+int cirs_exposure_history(const int64_t* user_start, const int32_t* photo, const double* timestamp, int64_t n_rows,
+                          const double* dist, const uint32_t* item_cats, int32_t n_items, double tau, double* exposure_out,
+                          void* stream);
+int cirs_find_negative(const int64_t* user_ids, const int64_t* photo_ids, int64_t n, const uint32_t* seen_small,
+                       const uint32_t* seen_big, int32_t n_items, int64_t absent_id, int64_t* neg_out, void* stream);
+
 /* ---- the user model as a static recommendation policy ---------------------------------------------
  * cirs_select_items replaces the tail of UserModel.recommend_k_item (reference core/user_model.py:296-346, k = 1) for n
  * users at once, given their catalogue scores (cirs_deepfm_sweep):

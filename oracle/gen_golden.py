@@ -712,7 +712,47 @@ def gen_usertrain():
     print("usertrain.npz:", {k: out[k] for k in out if k.endswith("losses")})
 
 
-FAMILIES = {"usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+def gen_dataprep():
+    """compute_exposure_effect_kuaishouRec / compute_exposure_each_user and find_negative (reference core/util.py:56-76,
+    135-196; numba's njit is the identity in this harness) on a small synthetic interaction log."""
+    import tempfile
+    import core.util as cu
+    rng = np.random.RandomState(17)
+    n_users, n_items = 12, 70
+    list_feat = [sorted(rng.choice(31, size=rng.randint(1, 5), replace=False).tolist()) for _ in range(n_items)]
+    rows = []
+    t0 = 1.6e9
+    for u in range(n_users):
+        L = rng.randint(1, 40)
+        ts = np.sort(t0 + rng.randint(0, 5000, L).astype(np.float64))   # repeated timestamps occur (t_diff == 0 -> 1)
+        for k in range(L):
+            rows.append((u, int(rng.randint(0, n_items)), ts[k]))
+    df = pd.DataFrame(rows, columns=["user_id", "photo_id", "timestamp"])
+    out = dict(user_id=df["user_id"].to_numpy(), photo_id=df["photo_id"].to_numpy(), timestamp=df["timestamp"].to_numpy(),
+               list_feat=np.array([f + [-1] * (4 - len(f)) for f in list_feat], np.int64))
+    for tau in (1000.0, 50.0):
+        with tempfile.TemporaryDirectory() as root:
+            os.makedirs(os.path.join(root, "m", "x"))
+            ex = cu.compute_exposure_effect_kuaishouRec(df[["user_id", "photo_id"]], df["timestamp"], list_feat, tau,
+                                                        os.path.join(root, "m", "x"), root)
+        out[f"exposure_tau{int(tau)}"] = np.asarray(ex, np.float64).reshape(-1)
+    # negative sampling
+    n_items2 = 1300   # includes the absent id 1225
+    mat_small = rng.uniform(size=(n_users, n_items2)) < 0.3
+    mat_big = rng.uniform(size=(n_users, n_items2)) < 0.3
+    mat_small[3, 600:] = True; mat_big[3, :10] = True      # forces the downward search
+    mat_small[4, 1220:1230] = True                          # neighbourhood of the absent id
+    uids = rng.randint(0, n_users, 400); pids = rng.randint(0, n_items2, 400)
+    uids[:6] = [3, 3, 4, 4, 4, 5]; pids[:6] = [700, 1299, 1223, 1224, 1226, 1299]
+    df_negative = np.zeros((len(uids), 2))
+    cu.find_negative(uids, pids, mat_small, mat_big, df_negative, n_items2 - 1)
+    out.update(neg_users=uids, neg_items=pids, mat_small=np.packbits(mat_small, axis=1, bitorder="little"),
+               mat_big=np.packbits(mat_big, axis=1, bitorder="little"), n_items2=n_items2, negatives=df_negative)
+    np.savez_compressed(os.path.join(GOLDEN, "dataprep.npz"), **out)
+    print("dataprep.npz: rows", len(df), "exposure max", out["exposure_tau1000"].max(), out["exposure_tau50"].max(), "neg sample", df_negative[:8, 1])
+
+
+FAMILIES = {"dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)
