@@ -332,7 +332,7 @@ __device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c
 //   dH2_tile[32 rows x 64] += dZ[rows x items] * Wa_tile      (A = the dZT registers AS THEY ARE, B = Wa[item(s,hi)][n], LDS)
 //   dZ -> LDS -> registers in the transposed (Z) layout: lane owns an ITEM, registers are rows (4 KB per wave)
 //   dWa_tile[32 items x 64]  = dZ^T[items x rows] * H2_tile   (A = transposed dZ registers, B = H2[row(s,hi)][n], registers)
-// d h2 stays in the accumulators across the chunk (one partial slab per chunk, summed by finalize_dh2_kernel); the dWa
+// d h2 stays in the accumulators across the chunk (one partial slab per chunk, summed by trunk_bwd_kernel); the dWa
 // tile of each wave covers only its 32 rows, so the kBwdWaves partial tiles are summed through LDS in wave order and
 // written to the slab of this ROW BLOCK (n_row_blocks slabs, summed in slab order by sumsq_partial / reduce_dwa).
 // The Wa tile (32 items x 64, 8 KB) is staged in LDS once per workgroup, double-buffered with the next tile's global
