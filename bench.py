@@ -34,6 +34,7 @@ HBM_PEAK_GBS = 8000.0
 # measured on MI355X, see profiles/r01f_pmc_minibatch_step.md: (2*FETCH_SIZE + WRITE_SIZE) KB summed over the eight
 # kernels of one 1024-row PPO minibatch step at I = 10728 (separate rocprofv3 --pmc passes)
 PMC_TRAFFIC_BYTES_PER_MINIBATCH = int((2 * 38180 + 68266) * 1024)
+PMC_TRAFFIC_BYTES_BWD_KERNEL = int((2 * 2737 + 37076) * 1024)   # head_bwd_fused_kernel: Wa / h2 in, 8 dWa + 56 dH2 partial slabs out
 
 
 def build_engine(wl, rank, world, device):
@@ -53,9 +54,10 @@ def build_engine(wl, rank, world, device):
 
 
 def hip_event_kernel_time(eng, wl, reps=20):
-    """Average duration (HIP events on the launch stream) of one whole PPO minibatch step (cirs_ppo_minibatch: the MFMA
-    actor-head forward + fused backward kernels and the six small kernels around them), launched exactly as inside the
-    timed region."""
+    """HIP-event timing on the launch stream, PPO minibatch step of mb rows launched exactly as inside the timed region:
+    -> (seconds per whole cirs_ppo_minibatch call, mb, {kernel name: average seconds per launch}) where the per-kernel numbers
+    come from event pairs the library records around each launch of that kernel (cirs_prof_start / cirs_prof_stop): the same
+    quantity as the kernel's average duration in the rocprofv3 --kernel-trace --stats summary under profiles/."""
     from cirs_hip import abi
     import ctypes as C
     ln = eng.learner
@@ -66,18 +68,32 @@ def hip_event_kernel_time(eng, wl, reps=20):
     losses = torch.zeros(4, dtype=torch.float32, device=eng.device)
     # snapshot optimiser state so the probe does not advance training
     snap = [t.clone() for t in (ln.params, ln.adam_m, ln.adam_v)]
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    start.record()
-    for _ in range(reps):
-        abi.check(ln._lib.cirs_ppo_minibatch(C.byref(ln.cfg), ln.params.data_ptr(), ln.grads.data_ptr(), ln.adam_m.data_ptr(),
+    lib = ln._lib
+
+    def run(k):
+        for _ in range(k):
+            abi.check(lib.cirs_ppo_minibatch(C.byref(ln.cfg), ln.params.data_ptr(), ln.grads.data_ptr(), ln.adam_m.data_ptr(),
                                              ln.adam_v.data_ptr(), ln.opt_step, C.byref(ln.batch), idx.data_ptr(), mb, None,
                                              ln.n_env, losses.data_ptr(), ws.data_ptr(), ws.numel(), ln._stream()), "probe")
+
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    run(3)
+    torch.cuda.synchronize()
+    start.record()
+    run(reps)
     stop.record()
     torch.cuda.synchronize()
+    t_step = start.elapsed_time(stop) / reps * 1e-3
+    per_kernel = {}
+    for kid, name in ((1, "head_bwd_fused_kernel"), (2, "actor_head_kernel<stats>")):
+        abi.check(lib.cirs_prof_start(kid, reps), "cirs_prof_start")
+        run(reps)
+        tot, cnt = C.c_double(0.0), C.c_int32(0)
+        abi.check(lib.cirs_prof_stop(C.byref(tot), C.byref(cnt)), "cirs_prof_stop")
+        per_kernel[name] = tot.value / max(cnt.value, 1)
     for t, s in zip((ln.params, ln.adam_m, ln.adam_v), snap):
         t.copy_(s)
-    return start.elapsed_time(stop) / reps * 1e-3, mb  # seconds per minibatch step
+    return t_step, mb, per_kernel
 
 
 def deepfm_sweep_probe(wl, device, E=16, reps=5):
@@ -245,16 +261,19 @@ def main():
     l2, n2 = eng.update(1024, 2); torch.cuda.synchronize(); tc = time.perf_counter()
 
     if rank == 0:
-        t_mb, mb = hip_event_kernel_time(eng, wl)
+        t_mb, mb, t_k = hip_event_kernel_time(eng, wl)
         I = wl["I"]
-        # ALGORITHMIC flop of one PPO minibatch step, SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) (forward + the two
-        # backward products of every dense layer) = 4.25 GFLOP at mb = 1024, I = 10728.  EXECUTED on the matrix cores:
-        # 8*mb*I*64 on the actor head (forward statistics pass + ONE recompute of the logits in the fused backward
-        # kernel, instead of a B x I probability matrix in HBM) + the trunk layers.
         S, H = 20, 64
-        flop = 6.0 * mb * (S * H + H * H + H * I)
-        executed = 8.0 * mb * I * H + 6.0 * mb * (S * H + H * H)
-        achieved = flop / t_mb / 1e12
+        # Dominant kernel of the timed step (profiles/*_kernel_stats.csv): head_bwd_fused_kernel, the fused actor-head backward
+        # of a PPO minibatch step.  ALGORITHMIC flop per launch: the two backward products of the head layer,
+        # dWa = dZ^T H2 and dH2 = dZ Wa: 2 x 2*mb*I*64 ("fwd + 2 x bwd" of 2*mb*64*I each).  EXECUTED: + one
+        # recompute of the logits tile (2*mb*I*64) instead of reading a B x I probability matrix from HBM.
+        t_bwd = t_k["head_bwd_fused_kernel"]
+        flop_bwd = 4.0 * mb * I * H
+        exec_bwd = 6.0 * mb * I * H
+        # whole minibatch step (8 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
+        flop_step = 6.0 * mb * (S * H + H * H + H * I)
+        exec_step = 8.0 * mb * I * H + 6.0 * mb * (S * H + H * H)
         out = {
             "metric": "simulator env-steps/s (collect + PPO update in the timed region), KuaishouEnv",
             "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -267,15 +286,22 @@ def main():
             "ppo_minibatch_steps_per_s": mb_steps / elapsed,
             "rollout_only_env_steps_per_s": n_ro / (tb - ta),
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
-            "roofline": {"bound": "mfma", "kernel": "PPO minibatch step (one cirs_ppo_minibatch call: actor_head_kernel<stats> + head_bwd_fused_kernel "
-                                                      "+ 6 small kernels), fp32 MFMA",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "achieved_executed": executed / t_mb / 1e12, "frac_executed": executed / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "algorithmic_flop_per_launch": flop, "traffic": None, "seconds_per_launch": t_mb, "rows": mb},
+            "roofline": {"bound": "mfma", "kernel": "head_bwd_fused_kernel (PPO minibatch step: fused actor-head backward, fp32 MFMA)",
+                         "achieved": flop_bwd / t_bwd / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop_bwd / t_bwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "achieved_executed": exec_bwd / t_bwd / 1e12, "frac_executed": exec_bwd / t_bwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "algorithmic_flop_per_launch": flop_bwd, "traffic": None, "seconds_per_launch": t_bwd, "rows": mb,
+                         "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (cirs_prof_start/stop)"},
+            "minibatch_step": {"seconds": t_mb, "launches": 8, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
+                               "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "traffic": None,
+                               "actor_head_stats_kernel_seconds": t_k["actor_head_kernel<stats>"],
+                               "note": "one whole cirs_ppo_minibatch call: actor_head_kernel<stats> + head_bwd_fused_kernel + 6 small kernels"},
         }
-        # HBM traffic of one minibatch step (all eight kernels) from the committed PMC passes
-        # (profiles/r01f_pmc_minibatch_step.md: FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as reported)
-        out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_PER_MINIBATCH if args.workload == "c3" else None
+        # HBM traffic from the committed PMC passes (profiles/r01f_pmc_minibatch_step.md: FETCH_SIZE doubled per the gfx950
+        # note, WRITE_SIZE as reported): the fused backward kernel alone, and the whole minibatch step (all eight kernels)
+        out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_BWD_KERNEL if args.workload == "c3" else None
+        out["minibatch_step"]["traffic"] = PMC_TRAFFIC_BYTES_PER_MINIBATCH if args.workload == "c3" else None
         out["roofline"]["traffic_source"] = "profiles/r01f_pmc_minibatch_step.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
         if world == 1:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
             out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)

@@ -1,33 +1,60 @@
-"""In-tree build of libcirs_hip.so: hipcc --offload-arch=gfx950 over csrc/*.hip (cross-compiles without a GPU)."""
+"""In-tree build of libcirs_hip.so: hipcc --offload-arch=gfx950 over csrc/*.hip (cross-compiles without a GPU).
+
+Every translation unit is compiled to an object file in parallel (csrc/_obj/, git-ignored) and only when it or a header it
+can include changed; one link step produces the shared library."""
 import glob
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(_HERE, "libcirs_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "cirs_hip.h")]
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+
+
 def stale():
     if not os.path.exists(OUT):
         return True
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [
-        os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "cirs_hip.h")]
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(os.path.getmtime(d) > t for d in sources() + _headers() if os.path.exists(d))
 
 
 def build(force=False, verbose=True):
     if not force and not stale():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + sources() + ["-o", OUT]
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers() if os.path.exists(h))
+    todo = [s for s in sources() if force or not os.path.exists(_obj(s)) or os.path.getmtime(_obj(s)) < max(os.path.getmtime(s), hdr_t)]
+
+    def compile_one(src):
+        cmd = [hipcc] + CFLAGS + ["-c", src, "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as pool:
+        list(pool.map(compile_one, todo))
+    live = {_obj(s) for s in sources()}
+    for o in glob.glob(os.path.join(OBJ, "*.o")):   # a removed source must not linger in the library
+        if o not in live:
+            os.remove(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + sorted(live) + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

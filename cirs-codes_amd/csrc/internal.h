@@ -15,6 +15,16 @@ struct TrunkFuse {
     float* value;         // [n] or null
 };
 
+// per-kernel timing hook (api.hip): ids 1 = head_bwd_fused_kernel, 2 = actor_head_kernel<stats>, 3 = actor_head_kernel<sample>
+bool prof_before(int kernel_id, hipStream_t s);
+void prof_after(hipStream_t s);
+#define CIRS_PROF_LAUNCH(ID, STREAM, ...)                       \
+    do {                                                        \
+        const bool prof_ = ::cirs::prof_before(ID, STREAM);     \
+        __VA_ARGS__;                                            \
+        if (prof_) ::cirs::prof_after(STREAM);                  \
+    } while (0)
+
 int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
                           long state_stride, const TrunkFuse* tf, hipStream_t s);

@@ -16,6 +16,7 @@
 // SURVEY 8(d)) = 4.2 GFLOP at mb = 1024, I = 10728; executed 8*mb*I*64 (forward statistics pass + one recompute of the
 // logits in the backward kernel) on the fp32 MFMA pipe (157 TF peak).  HBM traffic is Wa (2.7 MB) + dWa partials
 // (n_row_blocks x 2.7 MB) + dH2 partials (n_chunks x mb x 256 B = 22 MB): MFMA-bound.
+#include "internal.h"
 #include "small_gemm.h"
 #include "policy_kernels.h"
 
@@ -921,9 +922,9 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
-        hipLaunchKernelGGL(actor_head_kernel<false>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, pcfg, w.wa, w.ba,
-                           v.h2, mb, (const float*)nullptr, (uint64_t)0, 0u, (const int32_t*)nullptr, (const uint32_t*)nullptr,
-                           (const uint8_t*)nullptr, pv, n_pad);
+        CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(actor_head_kernel<false>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, pcfg, w.wa, w.ba,
+                                                  v.h2, mb, (const float*)nullptr, (uint64_t)0, 0u, (const int32_t*)nullptr,
+                                                  (const uint32_t*)nullptr, (const uint8_t*)nullptr, pv, n_pad));
         CIRS_CHECK_LAUNCH("actor_head_kernel<stats>");
         // 4. merge + row losses + backward coefficients (means over the global minibatch)
         hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
@@ -934,7 +935,8 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         const int n_item_tiles = cdiv(I, kTileN);
         const int tpc = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)2 * device_cu_count()));
         const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
-        hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(n_bchunks, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc, w.wa, w.ba, v, v.dwap);
+        CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(n_bchunks, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
+                                                  w.wa, w.ba, v, v.dwap));
         CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
         // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
         static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");

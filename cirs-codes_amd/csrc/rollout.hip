@@ -169,9 +169,10 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
         int64_t* act_t = traj->act + (size_t)t * B;
         double* rew_t = traj->rew + (size_t)t * B;
         uint8_t* done_t = traj->done + (size_t)t * B;
-        hipLaunchKernelGGL(actor_head_kernel<true>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, *pol_cfg, pol_w->wa, pol_w->ba,
-                           (const float*)h2, n_env, (const float*)nullptr, seed, rng_base + (uint32_t)t, (const int32_t*)nullptr,
-                           (const uint32_t*)visited, (const uint8_t*)env_st->done, pv, n_pad);
+        CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel<true>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, *pol_cfg,
+                                                  pol_w->wa, pol_w->ba, (const float*)h2, n_env, (const float*)nullptr, seed,
+                                                  rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
+                                                  (const uint8_t*)env_st->done, pv, n_pad));
         CIRS_CHECK_LAUNCH("actor_head_kernel");
         hipLaunchKernelGGL(step_tail_kernel, dim3(cdiv(n_env, kEnvsPerBlock)), dim3(256), 0, s, *env_cfg, *env_tab, *env_st, n_env, n_pad,
                            n_chunks, pv, pol_w->wa, pol_w->ba, (const float*)h2, visited, force_length, (t + 1 >= force_length) ? 1 : 0,
