@@ -36,6 +36,31 @@ __device__ __forceinline__ float dot_row(const float* __restrict__ wrow, const f
     return acc;
 }
 
+// A weight row held in registers: issued as loads BEFORE the stage that consumes it, so the L2 latency of the next
+// mat-vec overlaps the current one (one wavefront per SIMD here: nothing else hides it).  dot_pre uses the same fma order
+// as dot_row.
+template <int K>
+struct RowRegs { float4 q[K / 4]; };
+template <int K>
+__device__ __forceinline__ RowRegs<K> load_row(const float* __restrict__ wrow) {
+    RowRegs<K> r;
+    const float4* w4 = reinterpret_cast<const float4*>(wrow);
+#pragma unroll
+    for (int k4 = 0; k4 < K / 4; ++k4) r.q[k4] = w4[k4];
+    return r;
+}
+template <int K>
+__device__ __forceinline__ float dot_pre(const RowRegs<K>& r, const float* xs, float acc) {
+#pragma unroll
+    for (int k4 = 0; k4 < K / 4; ++k4) {
+        acc = __builtin_fmaf(r.q[k4].x, xs[4 * k4 + 0], acc);
+        acc = __builtin_fmaf(r.q[k4].y, xs[4 * k4 + 1], acc);
+        acc = __builtin_fmaf(r.q[k4].z, xs[4 * k4 + 2], acc);
+        acc = __builtin_fmaf(r.q[k4].w, xs[4 * k4 + 3], acc);
+    }
+    return acc;
+}
+
 // LayerNorm over the 32 values held by lanes 0..31 (lanes >= 32 pass 0 and get garbage they never use)
 __device__ __forceinline__ float layer_norm32(float v, int lane, const float* __restrict__ w, const float* __restrict__ b) {
     const float vv = lane < kD ? v : 0.f;
@@ -118,17 +143,23 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     float h = x * 5.656854249492381f + w.pe[(size_t)pos * kD + o32];  // sqrt(32)
 
     // ---- 3. encoder layers ----------------------------------------------------------------------------------
+    RowRegs<kD> pq = load_row<kD>(w.layer[0].in_proj_w + (size_t)lane * kD);                    // rows 0..63 (q, k)
+    RowRegs<kD> pv = load_row<kD>(w.layer[0].in_proj_w + (size_t)(2 * kD + o32) * kD);           // rows 64..95 (v)
+    float bq = w.layer[0].in_proj_b[lane], bv = w.layer[0].in_proj_b[2 * kD + o32];
     for (int l = 0; l < cfg.nlayers; ++l) {
         const cirs_tracker_layer& ly = w.layer[l];
         if (lane < kD) xs[lane] = h;
         __builtin_amdgcn_wave_barrier();
         // in_proj: 96 outputs; lanes 0..63 -> rows 0..63 (q,k), lanes 0..31 -> rows 64..95 (v)
         {
-            const float r0 = dot_row<kD>(ly.in_proj_w + (size_t)lane * kD, xs, ly.in_proj_b[lane]);
+            const float r0 = dot_pre<kD>(pq, xs, bq);
             if (lane < kD) qs[lane] = r0 * (1.0f / sqrtf((float)HD));  // torch scales q before QK^T
             else kcur[lane - kD] = r0;
-            if (lane < kD) vcur[lane] = dot_row<kD>(ly.in_proj_w + (size_t)(2 * kD + lane) * kD, xs, ly.in_proj_b[2 * kD + lane]);
+            if (lane < kD) vcur[lane] = dot_pre<kD>(pv, xs, bv);
         }
+        // next stage's weights: out_proj row + biases, LayerNorm-1 parameters (consumed after the attention below)
+        const RowRegs<kD> po = load_row<kD>(ly.out_proj_w + (size_t)o32 * kD);
+        const float bo = ly.out_proj_b[o32];
         __builtin_amdgcn_wave_barrier();
         float* kc = st.kcache + (((size_t)l * B + e) * L) * kD;
         float* vc = st.vcache + (((size_t)l * B + e) * L) * kD;
@@ -191,21 +222,34 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             for (int q = 1; q < NHEAD; ++q) norm = hh == q ? sm[q] : norm;
             if (lane < kD) att[d] = acc * norm;
         }
+        // prefetch the feed-forward's first layer (two rows per lane) while out_proj + LayerNorm run
+        const RowRegs<kD> pf0 = load_row<kD>(ly.lin1_w + (size_t)lane * kD);
+        const RowRegs<kD> pf1 = load_row<kD>(ly.lin1_w + (size_t)(64 + lane) * kD);
+        const float bf0 = ly.lin1_b[lane], bf1 = ly.lin1_b[64 + lane];
         __builtin_amdgcn_wave_barrier();
         // out_proj + residual + LN1
-        const float sa = dot_row<kD>(ly.out_proj_w + (size_t)o32 * kD, att, ly.out_proj_b[o32]);
+        const float sa = dot_pre<kD>(po, att, bo);
         const float h1 = layer_norm32(h + sa, lane, ly.norm1_w, ly.norm1_b);
         __builtin_amdgcn_wave_barrier();
         if (lane < kD) tmp[lane] = h1;
+        // prefetch lin2's half row (64 inputs per half-wave)
+        const int half2 = lane >> 5;
+        const RowRegs<64> pl2 = load_row<64>(ly.lin2_w + (size_t)o32 * kHid + half2 * 64);
+        const float bl2 = half2 == 0 ? ly.lin2_b[o32] : 0.f;
         __builtin_amdgcn_wave_barrier();
         // FF: 128 hidden = 2 rows per lane
-        ffs[lane] = fmaxf(dot_row<kD>(ly.lin1_w + (size_t)lane * kD, tmp, ly.lin1_b[lane]), 0.f);
-        ffs[64 + lane] = fmaxf(dot_row<kD>(ly.lin1_w + (size_t)(64 + lane) * kD, tmp, ly.lin1_b[64 + lane]), 0.f);
+        ffs[lane] = fmaxf(dot_pre<kD>(pf0, tmp, bf0), 0.f);
+        ffs[64 + lane] = fmaxf(dot_pre<kD>(pf1, tmp, bf1), 0.f);
+        // prefetch the next layer's in_proj rows (or nothing after the last layer)
+        if (l + 1 < cfg.nlayers) {
+            pq = load_row<kD>(w.layer[l + 1].in_proj_w + (size_t)lane * kD);
+            pv = load_row<kD>(w.layer[l + 1].in_proj_w + (size_t)(2 * kD + o32) * kD);
+            bq = w.layer[l + 1].in_proj_b[lane]; bv = w.layer[l + 1].in_proj_b[2 * kD + o32];
+        }
         __builtin_amdgcn_wave_barrier();
         // lin2: 32 outputs x 128 inputs, split k in two halves across the half-waves
         {
-            const int half = lane >> 5;
-            float acc = dot_row<64>(ly.lin2_w + (size_t)o32 * kHid + half * 64, ffs + half * 64, half == 0 ? ly.lin2_b[o32] : 0.f);
+            float acc = dot_pre<64>(pl2, ffs + half2 * 64, bl2);
             acc += __shfl_xor(acc, 32, CIRS_WAVE);
             h = layer_norm32(h1 + acc, lane, ly.norm2_w, ly.norm2_b);
         }
