@@ -1,8 +1,11 @@
-"""Log callbacks of the training scripts (reference util/utils.py:83-137 LoggerCallback_Policy): formats the per-epoch
-result dict into the paper's log line (ctr = R_tra / len_tra, CV, CV_turn, ifeat_*) for the FB / NX_0 / NX_k collectors.
-logzero is not a dependency here; a standard `logging` logger named "cirs" receives the same message text."""
+"""Epoch log line of the RL training scripts (behaviour of reference util/utils.py:83-137, LoggerCallback_Policy).
+
+After every epoch the trainer hands the merged result dict of the three test collectors (free browsing "", "NX_0_" and
+"NX_<k>_") to `on_epoch_end`; the callback derives, per collector, trajectory length, trajectory reward and their ratio
+(the "ctr" of the paper's tables), formats coverage with five decimals, carries the ifeat_* feature-domination entries over
+and logs one line "Epoch: [e], Info: [{...}]".  logzero is not a dependency here: the line goes to the standard `logging`
+logger named "cirs" and the dict is also returned / kept in `last_results`."""
 import logging
-import re
 
 logger = logging.getLogger("cirs")
 
@@ -13,38 +16,34 @@ class LoggerCallback_Policy:
         self.force_length = force_length
         self.last_results = None
 
-    def on_epoch_begin(self, epoch, **kwargs):
-        pass
-
+    # the trainer's callback protocol (core/trainer/onpolicy.py)
     def on_train_begin(self, **kwargs):
         pass
 
     def on_train_end(self, **kwargs):
         pass
 
+    def on_epoch_begin(self, epoch, **kwargs):
+        pass
+
+    def _collector_summary(self, results, prefix):
+        episodes = results["n/ep"]
+        length = results[prefix + "n/st"] / episodes
+        reward = results[prefix + "rew"]
+        summary = {"num_test": episodes,
+                   prefix + "CV": "%.5f" % results[prefix + "CV"],
+                   prefix + "CV_turn": "%.5f" % results[prefix + "CV_turn"],
+                   prefix + "ctr": "%.5f" % (reward / length),
+                   prefix + "len_tra": length,
+                   prefix + "R_tra": reward}
+        marker = prefix + "ifeat_"
+        summary.update({k: v for k, v in results.items() if k.startswith(marker)})
+        return summary
+
     def on_epoch_end(self, epoch, results=None, **kwargs):
-        def find_item_domination_results(prefix):
-            pattern = re.compile(prefix + "ifeat_")
-            return {k: v for k, v in results.items() if re.match(pattern, k)}
-
-        def get_one_result(prefix):
-            num_test = results["n/ep"]
-            len_tra = results[prefix + "n/st"] / num_test
-            R_tra = results[prefix + "rew"]
-            ctr = R_tra / len_tra
-            res = dict()
-            res['num_test'] = num_test
-            res[prefix + 'CV'] = f"{results[prefix + 'CV']:.5f}"
-            res[prefix + 'CV_turn'] = f"{results[prefix + 'CV_turn']:.5f}"
-            res[prefix + 'ctr'] = f"{ctr:.5f}"
-            res[prefix + 'len_tra'] = len_tra
-            res[prefix + 'R_tra'] = R_tra
-            return res
-
-        results_all = {}
-        for prefix in ["", "NX_0_", f"NX_{self.force_length}_"]:
-            results_all.update(get_one_result(prefix))
-            results_all.update(find_item_domination_results(prefix))
-        self.last_results = results_all
-        logger.info("Epoch: [{}], Info: [{}]".format(epoch, results_all))
-        return results_all
+        line = {}
+        for prefix in ("", "NX_0_", "NX_%s_" % self.force_length):
+            line.update(self._collector_summary(results, prefix))
+        self.last_results = line
+        logger.info("Epoch: [{}], Info: [{}]".format(epoch, line))
+        return line
