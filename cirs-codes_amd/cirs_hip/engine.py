@@ -164,9 +164,8 @@ class CirsEngine:
         ln = self.learner
         n = ln.prepare(traj, lens, lens_dev=lens_d)
         if perms is None and self.world > 1:
-            # identical permutations on every rank: replicated learners stay bit-identical
-            rs = np.random.RandomState((self.seed * 7919 + self.collect_count) & 0x7FFFFFFF)
-            perms = [rs.permutation(n) for _ in range(repeat)]
+            # identical permutations on every rank (same generator seed, same device type): learners stay bit-identical
+            ln._perm_gen.manual_seed((self.seed * 7919 + self.collect_count) & 0x7FFFFFFF)
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
         if self.world > 1 and self.learner_mode == "dp":
             return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms)

@@ -139,15 +139,26 @@ class DeviceLearner:
             ws.data_ptr(), ws.numel(), 2, self._stream()), "cirs_ppo_minibatch_dp(phase 2)")
         self.opt_step += 1
 
+    def _perms_on_device(self, n, repeat, perms):
+        """[repeat, n] int32 on the device: the recorded permutations (parity tests) or draws of the seeded device generator.
+        Batch.split(shuffle=True) draws np.random.permutation(n) on the host (tianshou/data/batch.py); drawing on the device
+        keeps the distribution and removes ~0.4 ms of host work + upload per update from the critical path (the host has
+        just synchronised on the episode lengths and has nothing queued).  Ranks of a data-parallel learner seed the
+        generator identically (CirsEngine.update), so they draw the same permutations."""
+        if perms is not None:
+            return torch.as_tensor(np.stack([np.asarray(perms[rep]).astype(np.int32) for rep in range(repeat)])).to(self.device)
+        return torch.stack([torch.randperm(n, device=self.device, generator=self._perm_gen) for _ in range(repeat)]).to(torch.int32)
+
     def learn_dp(self, batch_size, repeat, perms, rank, world, all_reduce, want_tracker_grad=True):
         """Data-parallel learn(): global minibatches of batch_size*world rows, rows rank::world of each belong to this
         rank; `all_reduce(tensor)` sums a flat tensor over the ranks in place (torch.distributed.all_reduce)."""
         n = self.n_rows
         slices = minibatch_slices(n, batch_size * world)
         losses = torch.zeros((repeat * len(slices), 4), dtype=torch.float32, device=self.device)
+        perm_all_d = self._perms_on_device(n, repeat, perms)
         k = 0
         for rep in range(repeat):
-            perm_d = torch.as_tensor(np.asarray(perms[rep]).astype(np.int32)).to(self.device)
+            perm_d = perm_all_d[rep]
             last = rep == repeat - 1
             if last and want_tracker_grad:
                 self.dobs.zero_()
@@ -164,22 +175,16 @@ class DeviceLearner:
     def learn(self, batch_size, repeat, perms: Optional[List[np.ndarray]] = None, want_tracker_grad=True):
         """learn(): `repeat` passes of shuffled minibatches.  Returns loss arrays + leaves d loss / d obs of the LAST
         repeat in self.dobs ([T+1, B, S]) for the tracker backward.  perms: recorded permutations (parity tests);
-        default np.random.permutation like Batch.split."""
+        default: draws of the seeded device generator (_perms_on_device)."""
         n = self.n_rows
         slices = minibatch_slices(n, batch_size)
         max_mb = max(e - s for s, e in slices)
         ws = self.workspace(max_mb)
         n_steps = repeat * len(slices)
         losses = torch.zeros((n_steps, 4), dtype=torch.float32, device=self.device)
-        # all permutations of this update in ONE upload, issued before the first minibatch: the minibatch launches of the
-        # following repeats then queue back to back (a per-repeat host permutation + upload left the GPU idle for ~0.2 ms)
-        if perms is not None:
-            perm_all_d = torch.as_tensor(np.stack([np.asarray(perms[rep]).astype(np.int32) for rep in range(repeat)])).to(self.device)
-        else:
-            # Batch.split(shuffle=True) draws np.random.permutation(n) on the host (tianshou/data/batch.py); drawing the
-            # permutation on the device keeps the distribution and removes ~0.4 ms of host work + upload per update from
-            # the critical path (the host has just synchronised on the episode lengths and has nothing queued)
-            perm_all_d = torch.stack([torch.randperm(n, device=self.device, generator=self._perm_gen) for _ in range(repeat)]).to(torch.int32)
+        # all permutations of this update at once, before the first minibatch: the launches of the following repeats then
+        # queue back to back
+        perm_all_d = self._perms_on_device(n, repeat, perms)
         k = 0
         for rep in range(repeat):
             perm_d = perm_all_d[rep]
