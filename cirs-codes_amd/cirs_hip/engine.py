@@ -191,13 +191,13 @@ class CirsEngine:
         lo_env, hi_env = self.rank * Bl, (self.rank + 1) * Bl
         r0 = int(offsets[lo_env])
         r1 = int(offsets[hi_env - 1] + lens[hi_env - 1])
-        lens_l = lens[lo_env:hi_env]
-        off_l = (offsets[lo_env:hi_env] - r0).astype(np.int32)
+        # this rank's slice of the episode offsets / lengths, taken from the device copies (no upload, no host sync)
+        off_l = (ln.offsets_dev[lo_env:hi_env] - r0).contiguous()
+        lens_l = ln.lens_dev[lo_env:hi_env].contiguous()
         row_env_l = (ln.b_env[r0:r1] - lo_env).contiguous()
         row_t_l = ln.b_t[r0:r1].contiguous()
         dstate_l = ln.dobs[:, lo_env:hi_env, :].contiguous()
-        self.tracker.backward(self.users, self.rollout.traj, row_env_l, row_t_l, torch.as_tensor(off_l).to(self.device),
-                              torch.as_tensor(lens_l.astype(np.int32)).to(self.device), r1 - r0, dstate_l)
+        self.tracker.backward(self.users, self.rollout.traj, row_env_l, row_t_l, off_l, lens_l, r1 - r0, dstate_l)
         all_reduce(self.tracker.flat_grad)
         self.tracker.adam_update()
         return losses, n
