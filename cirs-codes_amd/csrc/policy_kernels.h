@@ -226,6 +226,10 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
 
                 if (active) {
                     const uint32_t vis = (kSample && visited) ? visited[(size_t)e * vis_words + (tile0 >> 5)] : 0u;
+                    // log-sum-exp per tile: the lane's maximum first, then ONE rescale of the running sums and one exp per
+                    // element (masked / padded elements carry -inf and add exp(-inf) = 0)
+                    float zt[16];
+                    float tmax = -INFINITY;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int i0 = tile0 + 8 * g + 4 * hi;
@@ -239,28 +243,32 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int item = i0 + q;
-                            if (item >= I) continue;
-                            if (kSample && ((vis >> (item & 31)) & 1u)) continue;
+                            const bool valid = item < I && !(kSample && ((vis >> (item & 31)) & 1u));
                             const float z = acc[4 * g + q];
-                            if (kSample) {
+                            zt[4 * g + q] = valid ? z : -INFINITY;
+                            tmax = fmaxf(tmax, zt[4 * g + q]);
+                            if (kSample && valid) {
                                 const float gn = gumbel ? gumbel[(size_t)jr * I + item] : g4[q];
                                 const float sc = z + gn;
                                 if (sc > best_score) {  // items ascend within a lane: strict > keeps the lowest id on ties
                                     best_score = sc; best_idx = item;
                                 }
                             }
-                            // online log-sum-exp with ONE exp per element: ex = exp(-|z - m|)
-                            const float dlt = z - run_m;
-                            const float ex = __expf(-fabsf(dlt));
-                            if (dlt > 0.f) {
-                                run_s = __builtin_fmaf(run_s, ex, 1.0f);
-                                if (!kSample) run_t = __builtin_fmaf(run_t, ex, z);
-                                run_m = z;
-                            } else {
-                                run_s += ex;
-                                if (!kSample) run_t = __builtin_fmaf(ex, z, run_t);
-                            }
                         }
+                    }
+                    if (tmax > -INFINITY) {
+                        const float mn = fmaxf(run_m, tmax);
+                        const float keep = __expf(run_m - mn);      // run_m = -inf on the first tile: keep = 0
+                        float ss = 0.f, tt = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float ex = __expf(zt[r] - mn);
+                            ss += ex;
+                            if (!kSample) tt = __builtin_fmaf(ex, acc[r], tt);   // acc is finite where ex is 0
+                        }
+                        run_s = __builtin_fmaf(run_s, keep, ss);
+                        if (!kSample) run_t = __builtin_fmaf(run_t, keep, tt);
+                        run_m = mn;
                     }
                 }
             }

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const d
 // ------------------------------------------------------------------------------------------------------------
 // minibatch: gather + advantage normalisation
 // ------------------------------------------------------------------------------------------------------------
+constexpr int kPlaneTileU4 = 1536;  // uint4 per item tile of the bf16 planes of Wa (wa_planes_kernel)
 struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad rows)
     float *obs, *adv, *ret, *v_s, *logp_old;  // gathered
     int32_t* act;
@@ -141,6 +142,7 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     float *red;                               // [16] scalars: adv mean/std, loss sums, grad norm coef
     float *normp;                             // [256] sum-of-squares partials
     float *dwp;                               // weight-gradient slab partials
+    uint4 *wa_planes;                         // bf16 planes of Wa per item tile (wa_planes_kernel)
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
 };
 
@@ -158,6 +160,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += (size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I);    // dwap
     f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
     f += dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64;  // dW slabs
+    f += (size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4;   // wa_planes
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
     return f;
 }
@@ -180,6 +183,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.red = take(64);
     v.normp = take(1024);
     v.dwp = take(dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64);
+    v.wa_planes = (uint4*)take((size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4);
     v.head_ws = (void*)p;
     return v;
 }
@@ -325,29 +329,131 @@ __device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c
     return c_logp * ((is_act ? 1.0f : 0.0f) - p) + c_ent * p * (z - lse + h_ent);
 }
 
+// ---- fp32 products on the bf16 matrix pipe ("bf16x6") -------------------------------------------------------------
+// On gfx950 v_mfma_f32_32x32x2_f32 retires 2 k per 64 cycles and v_mfma_f32_32x32x16_bf16 16 k per 32 cycles, and neither
+// overlaps with VALU work of any wave of the SIMD (tools/probes/overlap_probe.hip): every cycle spent in an MFMA is a cycle
+// of the kernel.  An fp32 value is the exact sum of three bf16 pieces h + m + l (8 significand bits each), so
+//   a * b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + O(2^-24 |a b|)
+// is six bf16 MFMAs per 16 k (192 cycles) instead of eight fp32 MFMAs (512 cycles), accumulated in fp32 by the matrix
+// core, with the error of an fp32 product chain (tools/probes/bf16x6_probe.hip: 1.2e-7 vs 1.0e-7 of sum|a b|).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t pk4 __attribute__((ext_vector_type(4)));
+struct Planes { bf16x8 h, m, l; };
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo_val, float hi_val) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_val), "v"(hi_val));
+    return r;
+}
+// two fp32 values -> packed (h, m, l) pieces; the first value sits in the low half
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(sa, sb);
+}
+__device__ __forceinline__ Planes split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+    uint32_t hh[4], mm[4], ll[4];
+    split_pair(x0, x1, hh[0], mm[0], ll[0]); split_pair(x2, x3, hh[1], mm[1], ll[1]);
+    split_pair(x4, x5, hh[2], mm[2], ll[2]); split_pair(x6, x7, hh[3], mm[3], ll[3]);
+    const pk4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    Planes o;
+    o.h = __builtin_bit_cast(bf16x8, h); o.m = __builtin_bit_cast(bf16x8, m); o.l = __builtin_bit_cast(bf16x8, l);
+    return o;
+}
+__device__ __forceinline__ Planes split8(const f32x16& v, int base) {
+    return split8(v[base], v[base + 1], v[base + 2], v[base + 3], v[base + 4], v[base + 5], v[base + 6], v[base + 7]);
+}
+// c += a * b over 16 k; small terms first
+__device__ __forceinline__ f32x16 mfma_bf16x6(const Planes& a, const Planes& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+// two independent accumulators sharing the A operand, issued alternately: a dependent bf16 MFMA waits ~40 cycles for its
+// predecessor, an independent one issues after 32
+__device__ __forceinline__ void mfma_bf16x6_pair(const Planes& a, const Planes& b0, const Planes& b1, f32x16& c0, f32x16& c1) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b1.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0.l, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1.l, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0.m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1.m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0.m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1.m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1.h, c1, 0, 0, 0);
+}
+// accumulator register r of a 32 x 32 tile, lane half hi -> row (C/D layout of the 32x32 MFMAs)
+__device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// Wa as bf16 planes, per item tile of 32 (items beyond I are zero rows), 24576 B per tile:
+//   [0, 12288)      row-major  R[p][item 32][col 64]    : A operand of Z^T = Wa H2^T (lane = item, 8 consecutive cols)
+//   [12288, 24576)  col-major  C[p][col 64][slot 32]    : B operand of dH2 = dZ Wa  (lane = col, 8 consecutive slots);
+//                   slot 16 t + 8 hi + j holds item acc_row(8 t + j, hi): the order in which the logit accumulators
+//                   of a lane enumerate the items, so the dZ registers are the A operand as they are.
+__global__ __launch_bounds__(256) void wa_planes_kernel(int I, const float* __restrict__ wa, uint4* __restrict__ planes) {
+    __shared__ float sw[kTileN * 65];
+    const int tid = threadIdx.x, tile0 = blockIdx.x * kTileN;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int f = tid + 256 * q, item = f >> 4, col = (f & 15) * 4;
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile0 + item < I) t4 = *reinterpret_cast<const float4*>(wa + (size_t)(tile0 + item) * kH + col);
+        float* d = &sw[item * 65 + col];
+        d[0] = t4.x; d[1] = t4.y; d[2] = t4.z; d[3] = t4.w;
+    }
+    __syncthreads();
+    uint4* out = planes + (size_t)blockIdx.x * kPlaneTileU4;
+    {
+        const float* r = &sw[(tid >> 3) * 65 + 8 * (tid & 7)];
+        const Planes pl = split8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        out[tid] = __builtin_bit_cast(uint4, pl.h); out[256 + tid] = __builtin_bit_cast(uint4, pl.m); out[512 + tid] = __builtin_bit_cast(uint4, pl.l);
+    }
+    {
+        const int n = tid >> 2, t = (tid >> 1) & 1, hi = tid & 1;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = sw[acc_row(8 * t + j, hi) * 65 + n];
+        const Planes pl = split8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
+        out[768 + tid] = __builtin_bit_cast(uint4, pl.h); out[1024 + tid] = __builtin_bit_cast(uint4, pl.m); out[1280 + tid] = __builtin_bit_cast(uint4, pl.l);
+    }
+}
+
 // ---- head backward (fused): dWa, dba, d h2, entropy correction ------------------------------------------------
-// grid = (n_chunks, ceil(n_pad/32/kBwdWaves)); workgroup = kBwdWaves waves = that many ROW tiles walking the item
-// tiles of one chunk.  Per (row tile, item tile) the logits are recomputed ONCE:
-//   ZT[32 items x 32 rows] = Wa_tile * H2_tile^T             (A = Wa rows from LDS, B = this lane's H2 row, registers)
+// grid = (n_chunks, ceil(n_pad/32/kBwdWaves)), ONE workgroup per CU; workgroup = kBwdWaves waves = that many ROW tiles
+// walking the item tiles of one chunk.  Per (row tile, item tile) the logits are recomputed ONCE; all three products run
+// as bf16x6 (above):
+//   ZT[32 items x 32 rows] = Wa_tile * H2_tile^T             (A = Wa planes R from LDS, B = this lane's H2 row, registers)
 //   dZ in place (lane owns a ROW: its lse / coefficients / action are scalars)
-//   dH2_tile[32 rows x 64] += dZ[rows x items] * Wa_tile      (A = the dZT registers AS THEY ARE, B = Wa[item(s,hi)][n], LDS)
+//   dH2_tile[32 rows x 64] += dZ[rows x items] * Wa_tile      (A = the dZT registers split in place, B = Wa planes C, LDS)
 //   dZ -> LDS -> registers in the transposed (Z) layout: lane owns an ITEM, registers are rows (4 KB per wave)
-//   dWa_tile[32 items x 64]  = dZ^T[items x rows] * H2_tile   (A = transposed dZ registers, B = H2[row(s,hi)][n], registers)
+//   dWa_tile[32 items x 64]  = dZ^T[items x rows] * H2_tile   (A = transposed dZ registers split, B = H2 planes, registers)
 // d h2 stays in the accumulators across the chunk (one partial slab per chunk, summed by trunk_bwd_kernel); the dWa
 // tile of each wave covers only its 32 rows, so the kBwdWaves partial tiles are summed through LDS in wave order and
 // written to the slab of this ROW BLOCK (n_row_blocks slabs, summed in slab order by sumsq_partial / reduce_dwa).
-// The Wa tile (32 items x 64, 8 KB) is staged in LDS once per workgroup, double-buffered with the next tile's global
-// loads in flight; row stride 68 floats keeps the ds_read_b128 of the A operand conflict-free.
+// The Wa planes of a tile (24 KB, written by wa_planes_kernel) are staged in LDS once per workgroup, double-buffered with
+// the next tile's global loads in flight; row strides 144 B / 80 B keep the ds_read_b128 of the operands conflict-free.
 constexpr int kTStride = 36;                 // transpose buffer row stride (floats): 16 B aligned, conflict-free b128 reads
 constexpr int kRSize = kTileN * kH + kTileN; // per-wave dWa partial tile + dba partial
+constexpr int kRowB = 144, kColB = 80;       // LDS row strides (bytes) of the R and C planes
+constexpr int kRPlaneB = kTileN * kRowB, kCPlaneB = kH * kColB;
+constexpr int kWBufB = 3 * kRPlaneB + 3 * kCPlaneB;
 
-__global__ __launch_bounds__(kBwdWaves * 64, 2) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
-                                                                         const float* __restrict__ wa,
+__global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
+                                                                         const uint4* __restrict__ planes,
                                                                          const float* __restrict__ ba, MbView v,
                                                                          float* __restrict__ dwap) {
     constexpr int kThreads = kBwdWaves * 64;
-    constexpr int kF4 = (kTileN * kH / 4) / kThreads;  // float4 per thread when staging a tile
-    __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
+    static_assert(kThreads == 256, "the plane staging maps one 16-byte unit per thread and plane");
+    __shared__ __attribute__((aligned(16))) unsigned char sW[2][kWBufB];
     __shared__ float sB[2][kTileN];
     __shared__ __attribute__((aligned(16))) float sT[kBwdWaves][kTileN * kTStride];
     __shared__ __attribute__((aligned(16))) float sR[kBwdWaves][kRSize];
@@ -358,23 +464,28 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void head_bwd_fused_kernel(int I
     const bool wave_ok = row0 < n_pad;   // all waves take part in the staging, barriers and the slab reduction
     const int chunk = blockIdx.x;
     const int jr = wave_ok ? row0 + lo : 0;
-    // B operand of ZT: this lane's row of H2, k = hi*32 + kk
-    float hrow[32];
+    // B operand of ZT: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
+    Planes hz[4];
     {
-        const float4* src = reinterpret_cast<const float4*>(v.h2 + (size_t)jr * kH + hi * 32);
+        const float4* src = reinterpret_cast<const float4*>(v.h2 + (size_t)jr * kH + 8 * hi);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 t4 = src[q];
-            hrow[4 * q] = t4.x; hrow[4 * q + 1] = t4.y; hrow[4 * q + 2] = t4.z; hrow[4 * q + 3] = t4.w;
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 p = src[4 * s4], q = src[4 * s4 + 1];
+            hz[s4] = split8(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
         }
     }
-    // B operand of the dWa product: H2[row(s,hi)][lo] and [32 + lo]
-    float hb0[16], hb1[16];
+    // B operand of the dWa product: element j of k-step t = H2[row acc_row(8 t + j, hi)][32 c + lo]
+    Planes hb[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float* hp = v.h2 + (size_t)(wave_ok ? row0 + rl : 0) * kH;
-        hb0[r] = hp[lo]; hb1[r] = hp[32 + lo];
+    for (int t = 0; t < 2; ++t) {
+        float x0[8], x1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* hp = v.h2 + (size_t)(wave_ok ? row0 + acc_row(8 * t + j, hi) : 0) * kH;
+            x0[j] = hp[lo]; x1[j] = hp[32 + lo];
+        }
+        hb[0][t] = split8(x0[0], x0[1], x0[2], x0[3], x0[4], x0[5], x0[6], x0[7]);
+        hb[1][t] = split8(x1[0], x1[1], x1[2], x1[3], x1[4], x1[5], x1[6], x1[7]);
     }
     const float lse = v.lse[jr], c_logp = v.c_logp[jr], c_ent = v.c_ent[jr], h_ent = v.h_ent[jr];
     const int act = v.act[jr];
@@ -389,27 +500,28 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void head_bwd_fused_kernel(int I
         for (int q = lane; q < kRSize; q += 64) sR[wv][q] = 0.f;
     }
 
-    const int st_f4 = tid * kF4;                       // first float4 of the tile this thread stages
-    const int st_item = st_f4 >> 4, st_col = (st_f4 & 15) * 4;
     const int first_tile = chunk * tiles_per_chunk * kTileN;
     const int n_tiles = max(0, min(tiles_per_chunk, (I - first_tile + kTileN - 1) / kTileN));
-    float4 gq[kF4];
+    // staging: unit `tid` of each of the six planes; destination offsets inside a buffer
+    const int dst_r = (tid >> 3) * kRowB + (tid & 7) * 16;
+    const int dst_c = 3 * kRPlaneB + (tid >> 2) * kColB + (tid & 3) * 16;
+    uint4 gr0, gr1, gr2, gc0, gc1, gc2;
     float gb = 0.f;
 #define CIRS_ISSUE(TILE0)                                                                                  \
     do {                                                                                                   \
-        const int item_ = (TILE0) + st_item;                                                               \
-        if (item_ < I) {                                                                                   \
-            const float4* src_ = reinterpret_cast<const float4*>(wa + (size_t)item_ * kH + st_col);        \
-            _Pragma("unroll") for (int q_ = 0; q_ < kF4; ++q_) gq[q_] = src_[q_];                          \
-        } else {                                                                                           \
-            _Pragma("unroll") for (int q_ = 0; q_ < kF4; ++q_) gq[q_] = make_float4(0.f, 0.f, 0.f, 0.f);   \
-        }                                                                                                  \
+        const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kPlaneTileU4 + tid;                      \
+        gr0 = src_[0]; gr1 = src_[256]; gr2 = src_[512]; gc0 = src_[768]; gc1 = src_[1024]; gc2 = src_[1280]; \
         if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
-        float4* dst_ = reinterpret_cast<float4*>(&sW[BUF][st_item * kLdsStride + st_col]);                 \
-        _Pragma("unroll") for (int q_ = 0; q_ < kF4; ++q_) dst_[q_] = gq[q_];                              \
+        unsigned char* base_ = sW[BUF];                                                                    \
+        *reinterpret_cast<uint4*>(base_ + dst_r) = gr0;                                                    \
+        *reinterpret_cast<uint4*>(base_ + kRPlaneB + dst_r) = gr1;                                         \
+        *reinterpret_cast<uint4*>(base_ + 2 * kRPlaneB + dst_r) = gr2;                                     \
+        *reinterpret_cast<uint4*>(base_ + dst_c) = gc0;                                                    \
+        *reinterpret_cast<uint4*>(base_ + kCPlaneB + dst_c) = gc1;                                         \
+        *reinterpret_cast<uint4*>(base_ + 2 * kCPlaneB + dst_c) = gc2;                                     \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
     if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
@@ -422,61 +534,85 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void head_bwd_fused_kernel(int I
         f32x16 dw0, dw1;
         float db = 0.f;
         if (wave_ok) {
-            const float* tw = sW[buf];
-            float wrow[32];
+            const unsigned char* tw = sW[buf];
+            // every LDS operand of this tile up front: one latency exposure instead of one per k-step
+            Planes za[4], cb[2][2];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 t4 = *reinterpret_cast<const float4*>(&tw[lo * kLdsStride + hi * 32 + 4 * q]);
-                wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const unsigned char* ap = tw + lo * kRowB + (16 * s4 + 8 * hi) * 2;
+                za[s4].h = *reinterpret_cast<const bf16x8*>(ap);
+                za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);
+                za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);
             }
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = sB[buf][(r & 3) + 8 * (r >> 2) + 4 * hi];
+            for (int r = 0; r < 16; ++r) acc[r] = sB[buf][acc_row(r, hi)];
 #pragma unroll
-            for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const unsigned char* bp = tw + 3 * kRPlaneB + (32 * c + lo) * kColB + (16 * t + 8 * hi) * 2;
+                    cb[c][t].h = *reinterpret_cast<const bf16x8*>(bp);
+                    cb[c][t].m = *reinterpret_cast<const bf16x8*>(bp + kCPlaneB);
+                    cb[c][t].l = *reinterpret_cast<const bf16x8*>(bp + 2 * kCPlaneB);
+                }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = mfma_bf16x6(za[s4], hz[s4], acc);
             float* tt = sT[wv];
+            // dZ in place.  Padded rows carry zero coefficients and lse = 1e30 (p = 0, d = 0); items beyond I exist only in
+            // the last tile (zero weights -> finite z) and are masked there.  Categorical.entropy uses
+            // log(clamp(p, eps, 1-eps)): the un-clamped entropy lse - E_p[z] comes from the forward statistics and only
+            // clamped elements (p < eps or p > 1 - eps) contribute a correction, applied below when the wave has any.
+            f32x16 zkeep, pkeep;
+            bool any_clamped = false;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int item = tile0 + il;
-                // branch-free: items beyond I carry zero weights (z = 0, finite), padded rows lse = 1e30 -> p = 0
+                const int il = acc_row(r, hi);
                 float p;
-                const float dd = dz_of(acc[r], lse, c_logp, c_ent, h_ent, item == act, p);
-                const bool ok = item < I && row_ok;
-                const float d = ok ? dd : 0.f;
-                // Categorical.entropy uses log(clamp(p, eps, 1-eps)): the un-clamped entropy lse - E_p[z] comes from
-                // the forward statistics; only the (rare) clamped elements contribute a correction here
-                const bool c_lo = p < eps, c_hi = p > 1.0f - eps;
-                const float corr = p * ((c_lo ? kLogEps : kLog1mEps) - (acc[r] - lse));
-                ent -= (ok && (c_lo || c_hi)) ? corr : 0.f;
+                zkeep[r] = acc[r] - lse;
+                const float d = dz_of(acc[r], lse, c_logp, c_ent, h_ent, tile0 + il == act, p);
+                pkeep[r] = p;
+                any_clamped |= fabsf(p - 0.5f) > 0.5f - 2.0f * eps;   // superset of the clamp condition
                 acc[r] = d;
-                tt[il * kTStride + lo] = d;   // transposed exchange: T[item][row]
+            }
+            if (tile0 + kTileN > I) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = tile0 + acc_row(r, hi) < I ? acc[r] : 0.f;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;  // item within the tile (rows beyond I hold zeros)
-                const float b0 = tw[il * kLdsStride + lo];
-                const float b1 = tw[il * kLdsStride + 32 + lo];
-                dh0 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b0, dh0, 0, 0, 0);
-                dh1 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], b1, dh1, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) tt[acc_row(r, hi) * kTStride + lo] = acc[r];   // transposed exchange: T[item][row]
+            if (__any(any_clamped)) {
+                const bool last = tile0 + kTileN > I;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = pkeep[r];
+                    const bool c_lo = p < eps, c_hi = p > 1.0f - eps;
+                    const bool ok = row_ok && (!last || tile0 + acc_row(r, hi) < I);
+                    const float corr = p * ((c_lo ? kLogEps : kLog1mEps) - zkeep[r]);
+                    ent -= (ok && (c_lo || c_hi)) ? corr : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const Planes a = split8(acc, 8 * t);  // element j: dZ[row lo][item acc_row(8 t + j, hi)]
+                mfma_bf16x6_pair(a, cb[0][t], cb[1][t], dh0, dh1);
             }
             // the wave's own LDS writes above are read back by other lanes of the same wave
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            f32x16 dzt;  // lane owns item lo; register r' = row (r'&3) + 8*(r'>>2) + 4*hi
+            f32x16 dzt;  // lane owns item lo; register r' = row acc_row(r', hi)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t4 = *reinterpret_cast<const float4*>(&tt[lo * kTStride + 8 * g + 4 * hi]);
                 dzt[4 * g] = t4.x; dzt[4 * g + 1] = t4.y; dzt[4 * g + 2] = t4.z; dzt[4 * g + 3] = t4.w;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; db += dzt[r]; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                db += dzt[r];
-                dw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dzt[r], hb0[r], dw0, 0, 0, 0);
-                dw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dzt[r], hb1[r], dw1, 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                const Planes a = split8(dzt, 8 * t);  // element j: dZ[row acc_row(8 t + j, hi)][item lo]
+                mfma_bf16x6_pair(a, hb[0][t], hb[1][t], dw0, dw1);
             }
         }
         lds_barrier();  // the slab reduction of the previous tile has finished reading sR
@@ -484,7 +620,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void head_bwd_fused_kernel(int I
             float* rr = sR[wv];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int il = acc_row(r, hi);
                 rr[il * kH + lo] = dw0[r];
                 rr[il * kH + 32 + lo] = dw1[r];
             }
@@ -520,7 +656,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void head_bwd_fused_kernel(int I
     float* hslab = v.dh2p + (size_t)chunk * n_pad * kH;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int row = row0 + acc_row(r, hi);
         hslab[(size_t)row * kH + lo] = dh0[r];
         hslab[(size_t)row * kH + 32 + lo] = dh1[r];
     }
@@ -931,12 +1067,14 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
                            (int)(idx_global ? mb_global : mb), n_pad, n_chunks, (int)n_env, pv, w.wa, w.ba, v);
         CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
         // 5. head backward
-        // chunking of the backward kernel: all workgroups co-resident (2 per CU) with equal tile counts -> no tail round
+        hipLaunchKernelGGL(wa_planes_kernel, dim3(cdiv(I, kTileN)), dim3(256), 0, s, I, w.wa, v.wa_planes);
+        CIRS_CHECK_LAUNCH("wa_planes_kernel");
+        // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
         const int n_item_tiles = cdiv(I, kTileN);
-        const int tpc = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)2 * device_cu_count()));
+        const int tpc = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)device_cu_count()));
         const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
         CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(n_bchunks, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
-                                                  w.wa, w.ba, v, v.dwap));
+                                                  (const uint4*)v.wa_planes, w.ba, v, v.dwap));
         CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
         // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
         static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");

@@ -1,0 +1,20 @@
+"""Time the PPO minibatch kernels (bench.hip_event_kernel_time) with an alternative build of the library:
+    python tools/probe_kernel_lib.py path/to/lib.so [...]
+Used for ablation builds of one kernel; one collect + prepare with the FIRST library's engine per process."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd"))
+import torch
+from cirs_hip import abi
+if len(sys.argv) > 1:
+    abi.LIB_PATH = os.path.abspath(sys.argv[1])
+import bench
+
+wl = bench.WORKLOADS["c3"]
+dev = torch.device("cuda:0")
+eng, _ = bench.build_engine(wl, 0, 1, dev)
+eng.collect()
+eng.learner.prepare(eng.traj, eng.lengths_host() if hasattr(eng, "lengths_host") else None, eng.lengths) if False else None
+eng.update(1024, 1)
+t, mb, k = bench.hip_event_kernel_time(eng, wl)
+print(os.path.basename(abi.LIB_PATH), "minibatch %.1f us" % (t * 1e6), {n: round(v * 1e6, 2) for n, v in k.items()}, flush=True)
