@@ -225,22 +225,6 @@ __device__ __forceinline__ void adv_stats_block(const float* __restrict__ adv_fl
     if (tid == 0) { red[0] = mean; red[1] = sqrtf(sh[0] / (float)(m - 1)); }
 }
 
-// trunk forward of the minibatch rows (same fma chains as the rollout) + the advantage statistics in the extra last
-// workgroup: one launch for the two independent first steps of a minibatch
-__global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cirs_policy_weights w, const float* __restrict__ obs_flat,
-                                                        long stride, int n_pad, float* __restrict__ h2_out,
-                                                        float* __restrict__ value_out, float* __restrict__ h1_out,
-                                                        const int32_t* __restrict__ idx, int mb, float* __restrict__ obs_copy,
-                                                        const float* __restrict__ adv_flat, const int32_t* __restrict__ sidx,
-                                                        int m_stats, int enable, float* __restrict__ red) {
-    __shared__ float lds[4][2][kH];
-    if (blockIdx.x == gridDim.x - 1) {
-        adv_stats_block(adv_flat, sidx, m_stats, enable, red, &lds[0][0][0]);
-        return;
-    }
-    trunk_rows(cfg, w, obs_flat, stride, n_pad, nullptr, h2_out, value_out, h1_out, idx, mb, obs_copy, lds);
-}
-
 // One wavefront per minibatch row: merge the head-stats partials (lse, E_p[z]), recompute the taken action's logit
 // with the MFMA k-order, then (lane 0) the row's loss terms and backward coefficients (ppo.py:183-212).  Rows are read
 // from the buffer-order batch through idx (no separate gather pass); padded rows get neutral coefficients.
@@ -399,9 +383,8 @@ __device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3)
 //   [12288, 24576)  col-major  C[p][col 64][slot 32]    : B operand of dH2 = dZ Wa  (lane = col, 8 consecutive slots);
 //                   slot 16 t + 8 hi + j holds item acc_row(8 t + j, hi): the order in which the logit accumulators
 //                   of a lane enumerate the items, so the dZ registers are the A operand as they are.
-__global__ __launch_bounds__(256) void wa_planes_kernel(int I, const float* __restrict__ wa, uint4* __restrict__ planes) {
-    __shared__ float sw[kTileN * 65];
-    const int tid = threadIdx.x, tile0 = blockIdx.x * kTileN;
+__device__ __forceinline__ void wa_planes_block(int tile, int I, const float* __restrict__ wa, uint4* __restrict__ planes, float* sw) {
+    const int tid = threadIdx.x, tile0 = tile * kTileN;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int f = tid + 256 * q, item = f >> 4, col = (f & 15) * 4;
@@ -411,7 +394,7 @@ __global__ __launch_bounds__(256) void wa_planes_kernel(int I, const float* __re
         d[0] = t4.x; d[1] = t4.y; d[2] = t4.z; d[3] = t4.w;
     }
     __syncthreads();
-    uint4* out = planes + (size_t)blockIdx.x * kPlaneTileU4;
+    uint4* out = planes + (size_t)tile * kPlaneTileU4;
     {
         const float* r = &sw[(tid >> 3) * 65 + 8 * (tid & 7)];
         const Planes pl = split8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
@@ -424,6 +407,153 @@ __global__ __launch_bounds__(256) void wa_planes_kernel(int I, const float* __re
         for (int j = 0; j < 8; ++j) x[j] = sw[acc_row(8 * t + j, hi) * 65 + n];
         const Planes pl = split8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
         out[768 + tid] = __builtin_bit_cast(uint4, pl.h); out[1024 + tid] = __builtin_bit_cast(uint4, pl.m); out[1280 + tid] = __builtin_bit_cast(uint4, pl.l);
+    }
+}
+
+// First launch of a minibatch step, three independent jobs by workgroup index:
+//   [0, n_row_wgs)                trunk forward of the minibatch rows (same fma chains as the rollout)
+//   n_row_wgs                     advantage statistics of the (global) minibatch
+//   (n_row_wgs, n_row_wgs + tiles] bf16 planes of one Wa item tile (operands of the two head kernels)
+__global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cirs_policy_weights w, const float* __restrict__ obs_flat,
+                                                        long stride, int n_pad, float* __restrict__ h2_out,
+                                                        float* __restrict__ value_out, float* __restrict__ h1_out,
+                                                        const int32_t* __restrict__ idx, int mb, float* __restrict__ obs_copy,
+                                                        const float* __restrict__ adv_flat, const int32_t* __restrict__ sidx,
+                                                        int m_stats, int enable, float* __restrict__ red, int n_row_wgs,
+                                                        uint4* __restrict__ planes) {
+    __shared__ float lds_raw[kTileN * 65];
+    static_assert(kTileN * 65 >= 4 * 2 * kH, "the trunk rows use 4 x 2 x 64 floats of the same buffer");
+    if ((int)blockIdx.x > n_row_wgs) {
+        wa_planes_block((int)blockIdx.x - n_row_wgs - 1, cfg.n_items, w.wa, planes, lds_raw);
+        return;
+    }
+    if ((int)blockIdx.x == n_row_wgs) {
+        adv_stats_block(adv_flat, sidx, m_stats, enable, red, lds_raw);
+        return;
+    }
+    trunk_rows(cfg, w, obs_flat, stride, n_pad, nullptr, h2_out, value_out, h1_out, idx, mb, obs_copy,
+               reinterpret_cast<float (*)[2][kH]>(lds_raw));
+}
+
+constexpr int kTStride = 36;                 // transpose buffer row stride (floats): 16 B aligned, conflict-free b128 reads
+constexpr int kRSize = kTileN * kH + kTileN; // per-wave dWa partial tile + dba partial
+constexpr int kRowB = 144, kColB = 80;       // LDS row strides (bytes) of the R and C planes
+constexpr int kRPlaneB = kTileN * kRowB, kCPlaneB = kH * kColB;
+constexpr int kWBufB = 3 * kRPlaneB + 3 * kCPlaneB;
+
+// ---- head statistics (forward): log-sum-exp and sum exp(z - m) z per row, bf16x6 logits ---------------------------
+// grid = (n_chunks, ceil(n_pad/32/4)); workgroup = 4 waves = 4 row tiles walking the item tiles of one chunk; the R planes
+// of a Wa tile (12 KB) are staged once per workgroup, double-buffered.  Output: the per-chunk partials (m, s, t) of each
+// row in the ActorPartialView arrays (score = t), merged by head_stats_merge_kernel.
+__global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
+                                                            const uint4* __restrict__ planes, const float* __restrict__ ba,
+                                                            const float* __restrict__ h2, ActorPartialView pv) {
+    __shared__ __attribute__((aligned(16))) unsigned char sW[2][3 * kRPlaneB];
+    __shared__ float sB[2][kTileN];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int row0 = (blockIdx.y * 4 + wv) * kTileM;
+    const int chunk = blockIdx.x;
+    const int jr = row0 + lo;
+    const bool wave_ok = row0 < n_pad && row0 < mb;   // some row of this tile belongs to the minibatch
+    const bool active = jr < mb;
+    Planes hz[4];  // B operand: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
+    {
+        const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)(active ? jr : 0) * kH + 8 * hi);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 p = src[4 * s4], q = src[4 * s4 + 1];
+            hz[s4] = split8(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
+        }
+    }
+    float run_m = -INFINITY, run_s = 0.f, run_t = 0.f;
+    const int first_tile = chunk * tiles_per_chunk * kTileN;
+    const int n_tiles = max(0, min(tiles_per_chunk, (I - first_tile + kTileN - 1) / kTileN));
+    const int dst_r = (tid >> 3) * kRowB + (tid & 7) * 16;
+    uint4 g0, g1, g2;
+    float gb = 0.f;
+#define CIRS_ISSUE(TILE0)                                                                                  \
+    do {                                                                                                   \
+        const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kPlaneTileU4 + tid;                      \
+        g0 = src_[0]; g1 = src_[256]; g2 = src_[512];                                                      \
+        if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
+    } while (0)
+#define CIRS_COMMIT(BUF)                                                                                   \
+    do {                                                                                                   \
+        unsigned char* base_ = sW[BUF];                                                                    \
+        *reinterpret_cast<uint4*>(base_ + dst_r) = g0;                                                     \
+        *reinterpret_cast<uint4*>(base_ + kRPlaneB + dst_r) = g1;                                          \
+        *reinterpret_cast<uint4*>(base_ + 2 * kRPlaneB + dst_r) = g2;                                      \
+        if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
+    } while (0)
+    if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
+    __syncthreads();
+    for (int it = 0; it < n_tiles; ++it) {
+        const int buf = it & 1;
+        const int tile0 = first_tile + it * kTileN;
+        if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);
+        if (wave_ok) {
+            const unsigned char* tw = sW[buf];
+            Planes za[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const unsigned char* ap = tw + lo * kRowB + (16 * s4 + 8 * hi) * 2;
+                za[s4].h = *reinterpret_cast<const bf16x8*>(ap);
+                za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);
+                za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = sB[buf][acc_row(r, hi)];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = mfma_bf16x6(za[s4], hz[s4], acc);
+            // log-sum-exp per tile: the lane's maximum first, then ONE rescale of the running sums and one exp per element;
+            // items beyond I (last tile only) carry -inf and add exp(-inf) = 0
+            f32x16 zt = acc;
+            if (tile0 + kTileN > I) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zt[r] = tile0 + acc_row(r, hi) < I ? acc[r] : -INFINITY;
+            }
+            float tmax = zt[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, zt[r]);
+            if (tmax > -INFINITY) {
+                const float mn = fmaxf(run_m, tmax);
+                const float keep = __expf(run_m - mn);      // run_m = -inf on the first tile: keep = 0
+                float ss = 0.f, tt = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ex = __expf(zt[r] - mn);
+                    ss += ex;
+                    tt = __builtin_fmaf(ex, acc[r], tt);   // acc is finite where ex is 0
+                }
+                run_s = __builtin_fmaf(run_s, keep, ss);
+                run_t = __builtin_fmaf(run_t, keep, tt);
+                run_m = mn;
+            }
+        }
+        if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);
+        __syncthreads();
+    }
+#undef CIRS_ISSUE
+#undef CIRS_COMMIT
+    if (row0 >= n_pad) return;
+    if (!active) { run_m = -INFINITY; run_s = 0.f; run_t = 0.f; }
+    {   // combine the two half-waves (same row, disjoint items)
+        const float om = __shfl_xor(run_m, 32, CIRS_WAVE), osum = __shfl_xor(run_s, 32, CIRS_WAVE);
+        const float ot = __shfl_xor(run_t, 32, CIRS_WAVE);
+        const float mn = fmaxf(run_m, om);
+        if (mn > -INFINITY) {
+            const float fa = __expf(run_m - mn), fb = __expf(om - mn);
+            run_s = run_s * fa + osum * fb;
+            run_t = run_t * fa + ot * fb;
+            run_m = mn;
+        }
+    }
+    if (hi == 0) {
+        const size_t po = (size_t)chunk * n_pad + jr;
+        pv.score[po] = run_t; pv.m[po] = run_m; pv.s[po] = run_s;
     }
 }
 
@@ -441,11 +571,6 @@ __global__ __launch_bounds__(256) void wa_planes_kernel(int I, const float* __re
 // written to the slab of this ROW BLOCK (n_row_blocks slabs, summed in slab order by sumsq_partial / reduce_dwa).
 // The Wa planes of a tile (24 KB, written by wa_planes_kernel) are staged in LDS once per workgroup, double-buffered with
 // the next tile's global loads in flight; row strides 144 B / 80 B keep the ds_read_b128 of the operands conflict-free.
-constexpr int kTStride = 36;                 // transpose buffer row stride (floats): 16 B aligned, conflict-free b128 reads
-constexpr int kRSize = kTileN * kH + kTileN; // per-wave dWa partial tile + dba partial
-constexpr int kRowB = 144, kColB = 80;       // LDS row strides (bytes) of the R and C planes
-constexpr int kRPlaneB = kTileN * kRowB, kCPlaneB = kH * kColB;
-constexpr int kWBufB = 3 * kRPlaneB + 3 * kCPlaneB;
 
 __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                                          const uint4* __restrict__ planes,
@@ -803,24 +928,37 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
     const long per = (n_total + kNormBlocks - 1) / kNormBlocks;
     const long lo = blockIdx.x * per, hi = min(n_total, lo + per);
     float acc = 0.f;
-    for (long i = lo + tid; i < hi; i += 256) {
-        float x;
-        const long wi = i - wa_beg;
-        if (dwap && wi >= 0 && wi < wa_len) {
-            x = 0.f;
-            for (int s0 = 0; s0 < n_slabs; s0 += 8) {  // 8 independent loads in flight, added in slab order
-                float t8[8];
+    if (dwap) {
+        // wa|ba segment: one float4 per thread and slab (16-byte aligned: wa_beg and slab_stride are multiples of 4),
+        // 8 independent loads in flight, added in slab order
+        const long n4 = wa_len >> 2;
+        for (long q4 = blockIdx.x * 256L + tid; q4 < n4; q4 += (long)kNormBlocks * 256) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s0 = 0; s0 < n_slabs; s0 += 8) {
+                float4 t8[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) t8[q] = (s0 + q < n_slabs) ? dwap[(size_t)(s0 + q) * slab_stride + wi] : 0.f;
+                for (int q = 0; q < 8; ++q)
+                    t8[q] = (s0 + q < n_slabs) ? *reinterpret_cast<const float4*>(dwap + (size_t)(s0 + q) * slab_stride + 4 * q4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) x += t8[q];
+                for (int q = 0; q < 8; ++q) { x.x += t8[q].x; x.y += t8[q].y; x.z += t8[q].z; x.w += t8[q].w; }
             }
-            g[i] = x;
-        } else if (dw_partial) {
-            continue;  // trunk / critic elements: handled below, one element per thread across the first workgroups
-        } else {
-            x = g[i];
+            *reinterpret_cast<float4*>(g + wa_beg + 4 * q4) = x;
+            acc += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
         }
+        const long wi = (n4 << 2) + blockIdx.x * 256L + tid;   // the (< 4) elements after the last whole float4
+        if (wi < wa_len) {
+            float x = 0.f;
+            for (int s0 = 0; s0 < n_slabs; ++s0) x += dwap[(size_t)s0 * slab_stride + wi];
+            g[wa_beg + wi] = x;
+            acc += x * x;
+        }
+    }
+    // everything else: already summed in g unless dw_partial holds it (handled below)
+    for (long i = lo + tid; i < hi && !dw_partial; i += 256) {
+        const long wi = i - wa_beg;
+        if (dwap && wi >= 0 && wi < wa_len) continue;   // summed above
+        const float x = g[i];
         acc += (i < n_trunk ? 2.0f : 1.0f) * x * x;  // trunk parameters appear twice in the reference's list
     }
     if (dw_partial) {
@@ -1052,25 +1190,25 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         // 1+2. advantage statistics of the (global) minibatch (last workgroup) and the trunk forward (same fma chains as
         //    the rollout -> ratio == 1 exactly while the weights are unchanged); rows are gathered from the buffer-order
         //    batch through idx inside the kernel (v.obs keeps the copy for d W1)
-        hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
+        hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
                            v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, sidx, (int)(idx_global ? mb_global : mb),
-                           (int)cfg->norm_adv, v.red);
+                           (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes);
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
-        // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores
+        // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores from the bf16 planes of Wa written by launch 1;
+        //    all workgroups co-resident (2 per CU) with equal tile counts
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
-        CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(actor_head_kernel<false>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, pcfg, w.wa, w.ba,
-                                                  v.h2, mb, (const float*)nullptr, (uint64_t)0, 0u, (const int32_t*)nullptr,
-                                                  (const uint32_t*)nullptr, (const uint8_t*)nullptr, pv, n_pad));
-        CIRS_CHECK_LAUNCH("actor_head_kernel<stats>");
+        const int n_item_tiles = cdiv(I, kTileN);
+        const int tpc_s = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)2 * device_cu_count()));
+        const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
+        CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s,
+                                                  (const uint4*)v.wa_planes, w.ba, (const float*)v.h2, pv));
+        CIRS_CHECK_LAUNCH("head_stats_kernel");
         // 4. merge + row losses + backward coefficients (means over the global minibatch)
         hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
-                           (int)(idx_global ? mb_global : mb), n_pad, n_chunks, (int)n_env, pv, w.wa, w.ba, v);
+                           (int)(idx_global ? mb_global : mb), n_pad, n_schunks, (int)n_env, pv, w.wa, w.ba, v);
         CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
         // 5. head backward
-        hipLaunchKernelGGL(wa_planes_kernel, dim3(cdiv(I, kTileN)), dim3(256), 0, s, I, w.wa, v.wa_planes);
-        CIRS_CHECK_LAUNCH("wa_planes_kernel");
         // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
-        const int n_item_tiles = cdiv(I, kTileN);
         const int tpc = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)device_cu_count()));
         const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
         CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(n_bchunks, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
