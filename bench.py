@@ -85,7 +85,7 @@ def hip_event_kernel_time(eng, wl, reps=20):
     torch.cuda.synchronize()
     t_step = start.elapsed_time(stop) / reps * 1e-3
     per_kernel = {}
-    for kid, name in ((1, "head_bwd_fused_kernel"), (2, "actor_head_kernel<stats>")):
+    for kid, name in ((1, "head_bwd_fused_kernel"), (2, "head_stats_kernel")):
         abi.check(lib.cirs_prof_start(kid, reps), "cirs_prof_start")
         run(reps)
         tot, cnt = C.c_double(0.0), C.c_int32(0)
@@ -280,7 +280,7 @@ def main():
             "metric": "simulator env-steps/s (collect + PPO update in the timed region), KuaishouEnv",
             "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (policy/tracker, fp32 MFMA) + f64 (env rewards, GAE)", "data": "synthetic",
+            "dtype": "f32 (policy/tracker; rollout on the fp32 MFMA, PPO head products fp32-accurate from 3 bf16 pieces per operand on the bf16 MFMA, fp32 accumulate) + f64 (env rewards, GAE)", "data": "synthetic",
             "config": {"workload": wl["name"], "envs_total": wl["B"] * world,
                        "parallelism": (f"env-sharded x{world}; one all-gather of trajectory records per update; data-parallel learner: "
                                        f"global minibatch = 1024 x {world} rows sharded by rows, one flat-gradient all-reduce per minibatch")
@@ -288,17 +288,19 @@ def main():
             "ppo_minibatch_steps_per_s": mb_steps / elapsed,
             "rollout_only_env_steps_per_s": n_ro / (tb - ta),
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
-            "roofline": {"bound": "mfma", "kernel": "head_bwd_fused_kernel (PPO minibatch step: fused actor-head backward, fp32 MFMA)",
+            "roofline": {"bound": "mfma", "kernel": "head_bwd_fused_kernel (PPO minibatch step: fused actor-head backward; fp32 products as 3 bf16 pieces per operand on v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
                          "achieved": flop_bwd / t_bwd / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": flop_bwd / t_bwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          "achieved_executed": exec_bwd / t_bwd / 1e12, "frac_executed": exec_bwd / t_bwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          "algorithmic_flop_per_launch": flop_bwd, "traffic": None, "seconds_per_launch": t_bwd, "rows": mb,
-                         "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (cirs_prof_start/stop)"},
+                         "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (cirs_prof_start/stop)",
+                         "peak_note": "fp32 MFMA dense peak: the kernel's results are fp32-accurate (DESIGN.md section 4); its 6x expanded bf16 flops are exec_bf16_flop_per_launch",
+                         "exec_bf16_flop_per_launch": 6.0 * exec_bwd},
             "minibatch_step": {"seconds": t_mb, "launches": 8, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
                                "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "traffic": None,
-                               "actor_head_stats_kernel_seconds": t_k["actor_head_kernel<stats>"],
-                               "note": "one whole cirs_ppo_minibatch call: actor_head_kernel<stats> + head_bwd_fused_kernel + 6 small kernels"},
+                               "head_stats_kernel_seconds": t_k["head_stats_kernel"],
+                               "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel + 6 small kernels"},
         }
         # HBM traffic from the committed PMC passes (profiles/r01f_pmc_minibatch_step.md: FETCH_SIZE doubled per the gfx950
         # note, WRITE_SIZE as reported): the fused backward kernel alone, and the whole minibatch step (all eight kernels)

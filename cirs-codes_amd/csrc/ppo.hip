@@ -159,7 +159,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I);    // dwap
     f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
-    f += dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64;  // dW slabs
+    f += (size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64;  // dW row slabs (one per 32 rows)
     f += (size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4;   // wa_planes
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
     return f;
@@ -182,7 +182,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dwap = take((size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I));
     v.red = take(64);
     v.normp = take(1024);
-    v.dwp = take(dwg_partial_floats(n_pad, kH, kH) + dwg_partial_floats(n_pad, kH, S) + dwg_partial_floats(n_pad, 1, kH) + 64);
+    v.dwp = take((size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64);
     v.wa_planes = (uint4*)take((size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4);
     v.head_ws = (void*)p;
     return v;
@@ -789,6 +789,81 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     if (hi == 0) v.entp[(size_t)chunk * n_pad + jr] = ent;
 }
 
+// ---- slab sums of the wa|ba gradient (one of kWaSumBlocks workgroups of 512 threads) ------------------------------------
+// The n_slabs row-block partials written by head_bwd_fused_kernel are summed in slab order into the flat gradient, one
+// float4 per thread and slab (16-byte aligned: wa_beg and slab_stride are multiples of 4), 8 independent loads in flight;
+// the workgroup's sum of squares goes to partial_out (clip_grad_norm_ stage 1).  Runs as extra workgroups of the
+// trunk-backward launch: it only depends on the head backward kernel.
+constexpr int kNormBlocks = 256;   // workgroups of sumsq_partial_kernel = its slots of the norm partials
+constexpr int kWaSumBlocks = 128;  // slots [kNormBlocks, kNormBlocks + kWaSumBlocks) of the norm partials
+__device__ __forceinline__ void wa_slab_sum_block(float* __restrict__ g, long wa_beg, long wa_len, const float* __restrict__ dwap,
+                                                  long slab_stride, int n_slabs, int b, float* __restrict__ partial_out, float* sh) {
+    const int tid = threadIdx.x;  // blockDim.x == 512
+    float acc = 0.f;
+    const long n4 = wa_len >> 2;
+    for (long q4 = b * 512L + tid; q4 < n4; q4 += (long)kWaSumBlocks * 512) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < n_slabs; s0 += 8) {
+            float4 t8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                t8[q] = (s0 + q < n_slabs) ? *reinterpret_cast<const float4*>(dwap + (size_t)(s0 + q) * slab_stride + 4 * q4)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { x.x += t8[q].x; x.y += t8[q].y; x.z += t8[q].z; x.w += t8[q].w; }
+        }
+        *reinterpret_cast<float4*>(g + wa_beg + 4 * q4) = x;
+        acc += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    }
+    const long wi = (n4 << 2) + b * 512L + tid;   // the (< 4) elements after the last whole float4
+    if (wi < wa_len) {
+        float x = 0.f;
+        for (int s0 = 0; s0 < n_slabs; ++s0) x += dwap[(size_t)s0 * slab_stride + wi];
+        g[wa_beg + wi] = x;
+        acc += x * x;
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int st = 256; st > 0; st >>= 1) {
+        if (tid < st) sh[tid] += sh[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) *partial_out = sh[0];
+}
+
+// one 32 x 32 tile of dW = dY^T X (+ the bias column sum of dY when k0 == 0) over the 32 rows of a trunk-backward workgroup:
+// A = dY from its LDS copy (sY[row][o]), B = X rows from global memory; written as this workgroup's row slab of the job
+// (same partial layout as dw_multi_kernel: out[o * (K + 1) + k], k == K the bias column)
+__device__ __forceinline__ void dw_tile_32rows(const float* sY, const float* __restrict__ X, int ldx, int K, int row0, int n_rows, int o0,
+                                               int k0, float* __restrict__ out, int lane) {
+    const int hi = lane >> 5, lo = lane & 31;
+    const int o = o0 + lo, k = k0 + lo;
+    const bool k_ok = k < K;
+    float a[16], b[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        a[j] = sY[(2 * j + hi) * kLdsStride + o];
+        b[j] = (k_ok && row0 + 2 * j + hi < n_rows) ? X[(size_t)(row0 + 2 * j + hi) * ldx + k] : 0.f;  // rows beyond the minibatch: dY = 0
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        bsum += a[j];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+    }
+    if (k_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(size_t)(o0 + acc_row(r, hi)) * (K + 1) + k] = acc[r];
+    }
+    if (k0 == 0) {
+        bsum += __shfl_xor(bsum, 32, CIRS_WAVE);
+        if (hi == 0) out[(size_t)o * (K + 1) + K] = bsum;
+    }
+}
+
 // ---- trunk backward, one workgroup (8 waves) per 32 minibatch rows ------------------------------------------------
 //   d a2 = (sum_chunks d h2 partial + dvalue * wc) * relu'(h2)      512 threads, one float4 each, chunk order fixed
 //   entropy per row = (lse - E_p[z]) + sum_chunks clamp correction
@@ -797,9 +872,15 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
 // d a2 / d a1 are also written to global memory for the weight-gradient GEMMs.
 __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n_chunks, int S, const float* __restrict__ w1,
                                                         const float* __restrict__ w2, const float* __restrict__ wc, MbView v,
-                                                        float* __restrict__ dobs_accum) {
+                                                        float* __restrict__ dobs_accum, float* __restrict__ g, long wa_beg, long wa_len,
+                                                        long slab_stride, int n_slabs, DwJobs jobs, float* __restrict__ dwp) {
     __shared__ __attribute__((aligned(16))) float sA[kTileM * kLdsStride];
     __shared__ __attribute__((aligned(16))) float sD[kTileM * kLdsStride];
+    if ((int)blockIdx.x >= n_pad / kTileM) {   // extra workgroups (single-rank path): slab sums of the wa|ba gradient
+        const int b = (int)blockIdx.x - n_pad / kTileM;
+        wa_slab_sum_block(g, wa_beg, wa_len, v.dwap, slab_stride, n_slabs, b, v.normp + kNormBlocks + b, sA);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = blockIdx.x * kTileM;
@@ -873,9 +954,24 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
             v.da1[o] = d;
             sD[rl * kLdsStride + n] = d;
         }
+    } else if (dwp && wv < 6) {  // d W2 | d b2 row slab of this workgroup: four 32 x 32 tiles, waves 2..5
+        const int t = wv - 2;
+        dw_tile_32rows(sA, v.h1, kH, kH, row0, mb, (t >> 1) * 32, (t & 1) * 32, dwp + jobs.j[1].part_off + (size_t)blockIdx.x * (kH * (kH + 1)), lane);
+    } else if (dwp && wv == 6) {  // d wc | d bc row slab: lane = column of h2
+        float acc = 0.f, bs = 0.f;
+        for (int r = 0; r < kTileM && row0 + r < mb; ++r) {
+            const float dv = v.dvalue[row0 + r];
+            acc = __builtin_fmaf(dv, v.h2[(size_t)(row0 + r) * kH + lane], acc);
+            bs += dv;
+        }
+        float* out = dwp + jobs.j[0].part_off + (size_t)blockIdx.x * (kH + 1);
+        out[lane] = acc;
+        if (lane == 0) out[kH] = bs;
     }
-    if (!dobs_accum) return;
     __syncthreads();
+    if (dwp && wv < 2)   // d W1 | d b1 row slab: two 32 x 32 tiles (S <= 32 columns), waves 0, 1
+        dw_tile_32rows(sD, v.obs, S, S, row0, mb, wv * 32, 0, dwp + jobs.j[2].part_off + (size_t)blockIdx.x * (kH * (S + 1)), lane);
+    if (!dobs_accum) return;
     if (wv == 2) {
         float arow[32];
 #pragma unroll
@@ -900,7 +996,6 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
 
 // clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1).
 // stage 1: kNormBlocks workgroups, each a contiguous slice, fixed-order tree -> partial sums of squares
-constexpr int kNormBlocks = 256;  // one per CU (1024 measured slower: 18.6 vs 14.2 us)
 // sum the dWa slabs in fixed order into the flat gradient buffer (data-parallel path: grads must be complete before
 // the all-reduce; the single-rank path folds this into sumsq_partial_kernel)
 __global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict__ dwap, long seg, long stride, int n_slabs, float* __restrict__ g_wa_ba) {
@@ -920,7 +1015,7 @@ __global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict
 // The wa|ba segment of the gradient is still in n_slabs partial slabs: they are summed here (slab order) and the
 // sum is written to the flat gradient buffer on the way.
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ g, long n_trunk, long n_total, long wa_beg, long wa_len,
-                                                            const float* __restrict__ dwap, long slab_stride, int n_slabs,
+                                                            int wa_fused,
                                                             DwJobs jobs, int n_dw_slabs, const float* __restrict__ dw_partial, int S,
                                                             float* __restrict__ partial) {
     __shared__ float sh[256];
@@ -928,36 +1023,10 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
     const long per = (n_total + kNormBlocks - 1) / kNormBlocks;
     const long lo = blockIdx.x * per, hi = min(n_total, lo + per);
     float acc = 0.f;
-    if (dwap) {
-        // wa|ba segment: one float4 per thread and slab (16-byte aligned: wa_beg and slab_stride are multiples of 4),
-        // 8 independent loads in flight, added in slab order
-        const long n4 = wa_len >> 2;
-        for (long q4 = blockIdx.x * 256L + tid; q4 < n4; q4 += (long)kNormBlocks * 256) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s0 = 0; s0 < n_slabs; s0 += 8) {
-                float4 t8[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    t8[q] = (s0 + q < n_slabs) ? *reinterpret_cast<const float4*>(dwap + (size_t)(s0 + q) * slab_stride + 4 * q4)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { x.x += t8[q].x; x.y += t8[q].y; x.z += t8[q].z; x.w += t8[q].w; }
-            }
-            *reinterpret_cast<float4*>(g + wa_beg + 4 * q4) = x;
-            acc += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
-        }
-        const long wi = (n4 << 2) + blockIdx.x * 256L + tid;   // the (< 4) elements after the last whole float4
-        if (wi < wa_len) {
-            float x = 0.f;
-            for (int s0 = 0; s0 < n_slabs; ++s0) x += dwap[(size_t)s0 * slab_stride + wi];
-            g[wa_beg + wi] = x;
-            acc += x * x;
-        }
-    }
+    // slots of the wa|ba slab-sum workgroups (trunk-backward launch): theirs when wa_fused, zero otherwise
+    if (!wa_fused && blockIdx.x < kWaSumBlocks) { if (tid == 0) partial[kNormBlocks + blockIdx.x] = 0.f; }
     // everything else: already summed in g unless dw_partial holds it (handled below)
     for (long i = lo + tid; i < hi && !dw_partial; i += 256) {
-        const long wi = i - wa_beg;
-        if (dwap && wi >= 0 && wi < wa_len) continue;   // summed above
         const float x = g[i];
         acc += (i < n_trunk ? 2.0f : 1.0f) * x * x;  // trunk parameters appear twice in the reference's list
     }
@@ -1025,13 +1094,8 @@ __global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const
     __shared__ float sh3[768];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && mb > 0) loss_partials_block(mb, mb_norm, mv, tail, sh3);
-    static_assert(kNormBlocks % 256 == 0, "each thread folds kNormBlocks/256 partials");
-    {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < kNormBlocks / 256; ++q) t += partial[tid + 256 * q];
-        sh[tid] = t;
-    }
+    static_assert(kNormBlocks == 256 && kWaSumBlocks <= 256, "each thread folds one slot of each kind");
+    sh[tid] = partial[tid] + (tid < kWaSumBlocks ? partial[kNormBlocks + tid] : 0.f);
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) sh[tid] += sh[tid + s];
@@ -1217,17 +1281,26 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
         static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");
         CIRS_REQUIRE(S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
-        hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM), dim3(512), 0, s, (int)mb, n_pad, n_bchunks, S, w.w1, w.w2, w.wc, v, dobs_accum);
-        CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
-        {   // d wc/d bc, d W2/d b2, d W1/d b1 in one launch pair (same rows, fixed-order slab sums)
-            DwJobs jobs;
-            jobs.n = 3;
-            jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
-            jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
-            jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
-            // single-rank path: only the slab partials; the slab sums are folded into sumsq_partial_kernel below
-            n_dw_slabs = launch_dw_multi(jobs, mb, v.dwp, s, phase == 1);
+        // (single-rank path: + the slab sums of the wa|ba gradient as extra workgroups of the same launch)
+        // d wc/d bc, d W2/d b2, d W1/d b1: single-rank path = one row slab per trunk-backward workgroup (32 rows), summed in slab
+        // order by sumsq_partial_kernel; data-parallel phase 1 = dw_multi launch pair with the final sums
+        DwJobs jobs;
+        jobs.n = 3;
+        jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
+        jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
+        jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
+        if (phase == 0) {
+            n_dw_slabs = n_pad / kTileM;
+            int off = 0;
+            for (int q = 0; q < 3; ++q) { jobs.j[q].part_off = off; off += n_dw_slabs * jobs.j[q].O * (jobs.j[q].K + 1); }
             dw_jobs = jobs;
+        }
+        hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM + (phase == 0 ? kWaSumBlocks : 0)), dim3(512), 0, s, (int)mb, n_pad, n_bchunks, S,
+                           w.w1, w.w2, w.wc, v, dobs_accum, grads, (long)L.wa, seg, (long)dwa_slab_stride(I), n_slabs, jobs,
+                           phase == 0 ? v.dwp : (float*)nullptr);
+        CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
+        if (phase == 1) {
+            launch_dw_multi(jobs, mb, v.dwp, s, true);
             CIRS_CHECK_LAUNCH("dw(critic, w2, w1)");
         }
         if (phase == 1) {  // gradients + loss partials must be complete in `grads` before the caller's all-reduce
@@ -1240,7 +1313,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
     }
     // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps; heads: once)
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg,
-                       phase == 0 ? v.dwap : (const float*)nullptr, (long)dwa_slab_stride(I), n_slabs, dw_jobs, n_dw_slabs,
+                       (int)(phase == 0), dw_jobs, n_dw_slabs,
                        phase == 0 ? (const float*)v.dwp : (const float*)nullptr, S, v.normp);
     CIRS_CHECK_LAUNCH("sumsq_partial_kernel");
     auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
