@@ -1,0 +1,91 @@
+// bf16x6.h -- fp32 products on the bf16 matrix pipe of gfx950 (shared by the PPO head kernels and the DeepFM sweep).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cirs {
+
+typedef float f32x16_b __attribute__((ext_vector_type(16)));
+
+// ---- fp32 products on the bf16 matrix pipe ("bf16x6") -------------------------------------------------------------
+// On gfx950 v_mfma_f32_32x32x2_f32 retires 2 k per 64 cycles and v_mfma_f32_32x32x16_bf16 16 k per 32 cycles, and neither
+// overlaps with VALU work of any wave of the SIMD (tools/probes/overlap_probe.hip): every cycle spent in an MFMA is a cycle
+// of the kernel.  An fp32 value is the exact sum of three bf16 pieces h + m + l (8 significand bits each), so
+//   a * b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + O(2^-24 |a b|)
+// is six bf16 MFMAs per 16 k (192 cycles) instead of eight fp32 MFMAs (512 cycles), accumulated in fp32 by the matrix
+// core, with the error of an fp32 product chain (tools/probes/bf16x6_probe.hip: 1.2e-7 vs 1.0e-7 of sum|a b|).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t pk4 __attribute__((ext_vector_type(4)));
+struct Planes { bf16x8 h, m, l; };
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo_val, float hi_val) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_val), "v"(hi_val));
+    return r;
+}
+// two fp32 values -> packed (h, m, l) pieces; the first value sits in the low half
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(sa, sb);
+}
+__device__ __forceinline__ Planes split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+    uint32_t hh[4], mm[4], ll[4];
+    split_pair(x0, x1, hh[0], mm[0], ll[0]); split_pair(x2, x3, hh[1], mm[1], ll[1]);
+    split_pair(x4, x5, hh[2], mm[2], ll[2]); split_pair(x6, x7, hh[3], mm[3], ll[3]);
+    const pk4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    Planes o;
+    o.h = __builtin_bit_cast(bf16x8, h); o.m = __builtin_bit_cast(bf16x8, m); o.l = __builtin_bit_cast(bf16x8, l);
+    return o;
+}
+__device__ __forceinline__ Planes split8(const f32x16_b& v, int base) {
+    return split8(v[base], v[base + 1], v[base + 2], v[base + 3], v[base + 4], v[base + 5], v[base + 6], v[base + 7]);
+}
+// c += a * b over 16 k; small terms first
+__device__ __forceinline__ f32x16_b mfma_bf16x6(const Planes& a, const Planes& b, f32x16_b c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+// two independent accumulators sharing the A operand, issued alternately: a dependent bf16 MFMA waits ~40 cycles for its
+// predecessor, an independent one issues after 32
+__device__ __forceinline__ void mfma_bf16x6_pair(const Planes& a, const Planes& b0, const Planes& b1, f32x16_b& c0, f32x16_b& c1) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b1.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0.l, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1.l, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0.m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1.m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0.m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1.m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1.h, c1, 0, 0, 0);
+}
+// two independent accumulators sharing the B operand
+__device__ __forceinline__ void mfma_bf16x6_pair_b(const Planes& a0, const Planes& a1, const Planes& b, f32x16_b& c0, f32x16_b& c1) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.l, b.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b.l, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b.l, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b.m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b.m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b.m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b.m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b.h, c1, 0, 0, 0);
+}
+// accumulator register r of a 32 x 32 tile, lane half hi -> row (C/D layout of the 32x32 MFMAs)
+__device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+
+}  // namespace cirs

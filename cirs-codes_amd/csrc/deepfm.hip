@@ -17,6 +17,7 @@
 // (SURVEY §8(d) F_sweep); MFMA-bound: 64 MFMA x 64 cycles per 32 pairs -> 19.2 G pairs/s at the fp32 MFMA peak.
 // HBM traffic per launch ~ item/user rows once + 4 B per pair of output: far below the MFMA time.
 #include "common.h"
+#include "bf16x6.h"
 
 namespace cirs {
 
@@ -175,19 +176,21 @@ __global__ __launch_bounds__(256, 1) void sweep_kernel(const float* __restrict__
     }
     const int item = tile0 + lo;
     const bool ok = item < ni;
-    // A operand (persistent): W2 rows; lane (out row = lo [+32], hi): w2[out][hi*32 + kk]
-    float wa0[32], wa1[32];
+    // A operand (persistent): W2 rows as bf16 planes (bf16x6.h: fp32 products on the bf16 matrix pipe); lane (out row = lo
+    // [+32], hi), k-step s4: w2[out][16 s4 + 8 hi + j]
+    Planes wa0[4], wa1[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float4 a = reinterpret_cast<const float4*>(w2 + (size_t)lo * fH + hi * 32)[q];
-        const float4 b = reinterpret_cast<const float4*>(w2 + (size_t)(32 + lo) * fH + hi * 32)[q];
-        wa0[4 * q] = a.x; wa0[4 * q + 1] = a.y; wa0[4 * q + 2] = a.z; wa0[4 * q + 3] = a.w;
-        wa1[4 * q] = b.x; wa1[4 * q + 1] = b.y; wa1[4 * q + 2] = b.z; wa1[4 * q + 3] = b.w;
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const float4* a = reinterpret_cast<const float4*>(w2 + (size_t)lo * fH + 16 * s4 + 8 * hi);
+        const float4* b = reinterpret_cast<const float4*>(w2 + (size_t)(32 + lo) * fH + 16 * s4 + 8 * hi);
+        const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        wa0[s4] = split8(a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w);
+        wa1[s4] = split8(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w);
     }
-    // item side of this lane's pair column
+    // item side of this lane's pair column: ai[8 s4 + j] = feature 16 s4 + 8 hi + j
     float ai[32], si[E / 2];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) ai[q] = ok ? AI[(size_t)item * fH + hi * 32 + q] : 0.f;
+    for (int q = 0; q < 32; ++q) ai[q] = ok ? AI[(size_t)item * fH + 16 * (q >> 3) + 8 * hi + (q & 7)] : 0.f;
 #pragma unroll
     for (int q = 0; q < E / 2; ++q) si[q] = ok ? SI[(size_t)item * E + hi * (E / 2) + q] : 0.f;
     const float ci = ok ? CI[item] : 0.f;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void sweep_kernel(const float* __restrict__
     for (int uu = 0; uu < nuc; ++uu) {
         float h1[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) h1[q] = fmaxf(ai[q] + sAU[uu][hi * 32 + q], 0.f);
+        for (int q = 0; q < 32; ++q) h1[q] = fmaxf(ai[q] + sAU[uu][16 * (q >> 3) + 8 * hi + (q & 7)], 0.f);
         f32x16 acc0, acc1;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -204,9 +207,10 @@ __global__ __launch_bounds__(256, 1) void sweep_kernel(const float* __restrict__
             acc1[s] = sB2[32 + o];
         }
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0[kk], h1[kk], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1[kk], h1[kk], acc1, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const Planes hb = split8(h1[8 * s4], h1[8 * s4 + 1], h1[8 * s4 + 2], h1[8 * s4 + 3], h1[8 * s4 + 4], h1[8 * s4 + 5],
+                                     h1[8 * s4 + 6], h1[8 * s4 + 7]);
+            mfma_bf16x6_pair_b(wa0[s4], wa1[s4], hb, acc0, acc1);
         }
         float part = 0.f;
 #pragma unroll
