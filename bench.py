@@ -31,10 +31,10 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
-# measured on MI355X, see profiles/r01f_pmc_minibatch_step.md: (2*FETCH_SIZE + WRITE_SIZE) KB summed over the eight
+# measured on MI355X, see profiles/r01p_pmc_minibatch_step.md: (2*FETCH_SIZE + WRITE_SIZE) KB summed over the seven
 # kernels of one 1024-row PPO minibatch step at I = 10728 (separate rocprofv3 --pmc passes)
-PMC_TRAFFIC_BYTES_PER_MINIBATCH = int((2 * 38180 + 68266) * 1024)
-PMC_TRAFFIC_BYTES_BWD_KERNEL = int((2 * 2737 + 37076) * 1024)   # head_bwd_fused_kernel: Wa / h2 in, 8 dWa + 56 dH2 partial slabs out
+PMC_TRAFFIC_BYTES_PER_MINIBATCH = int((2 * 35202 + 69076) * 1024)
+PMC_TRAFFIC_BYTES_BWD_KERNEL = int((2 * 5284 + 30007) * 1024)   # head_bwd_fused_kernel: Wa planes / h2 in, 8 dWa + 31 dH2 partial slabs out
 
 
 def build_engine(wl, rank, world, device):
@@ -273,7 +273,7 @@ def main():
         t_bwd = t_k["head_bwd_fused_kernel"]
         flop_bwd = 4.0 * mb * I * H
         exec_bwd = 6.0 * mb * I * H
-        # whole minibatch step (8 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
+        # whole minibatch step (7 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
         flop_step = 6.0 * mb * (S * H + H * H + H * I)
         exec_step = 8.0 * mb * I * H + 6.0 * mb * (S * H + H * H)
         out = {
@@ -296,17 +296,17 @@ def main():
                          "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (cirs_prof_start/stop)",
                          "peak_note": "fp32 MFMA dense peak: the kernel's results are fp32-accurate (DESIGN.md section 4); its 6x expanded bf16 flops are exec_bf16_flop_per_launch",
                          "exec_bf16_flop_per_launch": 6.0 * exec_bwd},
-            "minibatch_step": {"seconds": t_mb, "launches": 8, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
+            "minibatch_step": {"seconds": t_mb, "launches": 7, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
                                "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "traffic": None,
                                "head_stats_kernel_seconds": t_k["head_stats_kernel"],
-                               "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel + 6 small kernels"},
+                               "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel + 5 small kernels"},
         }
-        # HBM traffic from the committed PMC passes (profiles/r01f_pmc_minibatch_step.md: FETCH_SIZE doubled per the gfx950
+        # HBM traffic from the committed PMC passes (profiles/r01p_pmc_minibatch_step.md: FETCH_SIZE doubled per the gfx950
         # note, WRITE_SIZE as reported): the fused backward kernel alone, and the whole minibatch step (all eight kernels)
         out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_BWD_KERNEL if args.workload == "c3" else None
         out["minibatch_step"]["traffic"] = PMC_TRAFFIC_BYTES_PER_MINIBATCH if args.workload == "c3" else None
-        out["roofline"]["traffic_source"] = "profiles/r01f_pmc_minibatch_step.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
+        out["roofline"]["traffic_source"] = "profiles/r01p_pmc_minibatch_step.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
         if world == 1:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
             out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
             out["sweep_mode"] = sweep_mode_probe(wl, eng, device)

@@ -524,6 +524,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     const int row0 = (blockIdx.y * kBwdWaves + wv) * kTileM;
     const bool wave_ok = row0 < n_pad;   // all waves take part in the staging, barriers and the slab reduction
     const int chunk = blockIdx.x;
+    // gridDim.x is padded to a multiple of 8: workgroups are dealt round-robin to the 8 XCDs, so linear id % 8 = chunk % 8
+    // and the row blocks that walk the same chunk share one L2 (the Wa planes of a tile leave HBM / MALL once, not 8 times)
+    if (chunk * tiles_per_chunk * kTileN >= I) return;
     const int jr = wave_ok ? row0 + lo : 0;
     // B operand of ZT: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
     Planes hz[4];
@@ -1211,7 +1214,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
         const int tpc = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)device_cu_count()));
         const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
-        CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(n_bchunks, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
+        CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
                                                   (const uint4*)v.wa_planes, w.ba, v, v.dwap));
         CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
         // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
