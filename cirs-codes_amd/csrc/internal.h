@@ -1,6 +1,7 @@
 // internal.h -- entry points shared between translation units of libcirs_hip.so (not part of the C ABI).
 #pragma once
 #include "common.h"
+#include "policy_kernels.h"
 
 namespace cirs {
 
@@ -14,6 +15,36 @@ struct TrunkFuse {
     float* h2;            // [n, 64]
     float* value;         // [n] or null
 };
+
+// CUs of the current device (cached)
+inline int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
+// Item tiles per workgroup of a head kernel so that ALL its workgroups are co-resident (`wgs_per_cu` per CU) with equal tile
+// counts: one round, no tail.  Never fewer than the 4 tiles the partial arrays are sized for (more tiles = fewer chunks).
+inline int head_tiles_per_chunk(int n_item_tiles, int n_row_blocks, int wgs_per_cu) {
+    const long slots = (long)wgs_per_cu * device_cu_count();
+    const int tpc = (int)(((long)n_item_tiles * n_row_blocks + slots - 1) / slots);
+    return tpc < 4 ? 4 : tpc;
+}
+
+inline HeadGrid sampler_grid(int n_items, int n_pad) {
+    HeadGrid g;
+    const int tiles = (n_items + kTileN - 1) / kTileN;
+    g.n_row_blocks = (n_pad / kTileM + 3) / 4;
+    g.tiles_per_chunk = head_tiles_per_chunk(tiles, g.n_row_blocks, kSamplerWgsPerCu);
+    g.n_chunks = (tiles + g.tiles_per_chunk - 1) / g.tiles_per_chunk;
+    g.grid_x = (g.n_chunks + 7) & ~7;
+    if (g.grid_x > n_chunks_of(n_items)) g.grid_x = g.n_chunks;   // the partial arrays hold n_chunks_of(n_items) chunks
+    return g;
+}
 
 // per-kernel timing hook (api.hip): ids 1 = head_bwd_fused_kernel, 2 = actor_head_kernel<stats>, 3 = actor_head_kernel<sample>
 bool prof_before(int kernel_id, hipStream_t s);

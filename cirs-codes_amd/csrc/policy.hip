@@ -17,6 +17,7 @@
 // Roofline: 2*64*I flop per env row (1.37 MFLOP at I = 10728) against 4*64*I bytes of Wa re-read per 32-env tile
 // from L2/MALL (2.7 MB, cache resident) -> MFMA-bound at fp32 (157 TF peak), HBM traffic ~ Wa once per launch.
 #include "policy_kernels.h"
+#include "internal.h"
 
 namespace cirs {
 
@@ -70,14 +71,16 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
     CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(cfg, n), "workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float* h2 = (float*)workspace;
-    const int n_pad = n_pad_of(n), n_chunks = n_chunks_of(cfg->n_items);
+    const int n_pad = n_pad_of(n);
+    const HeadGrid hg = sampler_grid(cfg->n_items, n_pad);
+    const int n_chunks = hg.n_chunks;
     ActorPartialView pv = partial_view(workspace, n, cfg->n_items);
     hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, *cfg, *w, state, (long)state_stride, n, skip, h2,
                        value_out, nullptr);
     CIRS_CHECK_LAUNCH("trunk_kernel");
-    const dim3 grid(n_chunks, cdiv(n_pad / kTileM, 4));
+    const dim3 grid(hg.grid_x, hg.n_row_blocks);
     hipLaunchKernelGGL(actor_head_kernel<true>, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
-                       rng_step, env_ids, visited, skip, pv, n_pad);
+                       rng_step, env_ids, visited, skip, pv, n_pad, hg.tiles_per_chunk);
     CIRS_CHECK_LAUNCH("actor_head_kernel");
     hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, n_chunks, pv, w->wa, w->ba,
                        h2, skip, act_out, logp_out);

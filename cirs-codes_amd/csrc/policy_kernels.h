@@ -129,6 +129,12 @@ static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, 
 // block and one float4 bias load serve them.
 // grid = (n_chunks, ceil(n_pad/32/4)); block = 4 waves = 4 env tiles walking the same item chunk (shared Wa lines).
 // kSample: true  -> Gumbel-max sampling + LSE (rollout);  false -> LSE (+ sum exp(z-m) z for the entropy) only.
+// Launch geometry of the sampler.  Unlike the MFMA-heavy PPO head kernels this one is VALU-bound (Philox: 20 quarter-rate
+// v_mad_u64_u32 per 4 items, two fixed-order logs per item) and wants MANY small co-resident workgroups (60 VGPRs, 17 KB LDS:
+// up to 3 per CU here): measured at C3 per launch, 4 tiles per chunk (672 workgroups) 42.9 us, 6 tiles (448) 46.4 us,
+// 11 tiles (248, one per CU) 54.7 us.  kSamplerWgsPerCu = 3 resolves to the 4-tile floor at this size.
+constexpr int kSamplerWgsPerCu = 3;
+struct HeadGrid { int tiles_per_chunk, n_chunks, grid_x, n_row_blocks; };
 constexpr int kLdsStride = 68;  // row stride (floats) of a staged 32 x 64 tile: ds_read_b128 of 16 lanes x 16 rows -> 64 banks
 
 template <bool kSample>
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
                                                             uint32_t rng_step, const int32_t* __restrict__ env_ids,
                                                             const uint32_t* __restrict__ visited,
                                                             const uint8_t* __restrict__ skip, ActorPartialView pv,
-                                                            int n_pad) {
+                                                            int n_pad, int tiles_per_chunk) {
     // The Wa tile (32 items x 64) is staged in LDS once per workgroup and shared by its four env tiles; double
     // buffered: global loads of tile t+1 are issued before the MFMAs of tile t (one barrier per tile).
     __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
@@ -174,9 +180,8 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
     int best_idx = 0x7FFFFFFF;
 
     const int st_item = tid >> 3, st_col = (tid & 7) * 8;  // staging role: 2 float4 of the tile
-    const int first_tile = chunk * kChunkItems;
-    int n_tiles = 0;
-    for (int it = 0; it < kTilesPerChunk; ++it) n_tiles += (first_tile + it * kTileN) < I;
+    const int first_tile = chunk * tiles_per_chunk * kTileN;
+    const int n_tiles = max(0, min(tiles_per_chunk, (I - first_tile + kTileN - 1) / kTileN));
     // a workgroup whose four env tiles are all finished only publishes neutral partials
     __shared__ int s_any;
     if (tid == 0) s_any = 0;

@@ -1104,16 +1104,6 @@ static int launch_adam(float* p, const float* g, float* m, float* v, long n, lon
     return CIRS_OK;
 }
 
-static int device_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
-    return cus;
-}
-
 static int validate_ppo(const cirs_ppo_cfg* cfg) {
     CIRS_REQUIRE(cfg, "ppo cfg null");
     if (cfg->hidden != kH) return fail(CIRS_E_UNSUPPORTED, "this build supports hidden == 64 only");
@@ -1201,7 +1191,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         //    all workgroups co-resident (2 per CU) with equal tile counts
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         const int n_item_tiles = cdiv(I, kTileN);
-        const int tpc_s = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)2 * device_cu_count()));
+        const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);
         const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
         CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s,
                                                   (const uint4*)v.wa_planes, w.ba, (const float*)v.h2, pv));
@@ -1212,7 +1202,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
         // 5. head backward
         // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
-        const int tpc = std::max(kTilesPerChunk, (int)cdiv((long)n_item_tiles * n_slabs, (long)device_cu_count()));
+        const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
         const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
         CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
                                                   (const uint4*)v.wa_planes, w.ba, v, v.dwap));

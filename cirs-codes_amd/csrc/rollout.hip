@@ -157,7 +157,9 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
     CIRS_REQUIRE(env_tab->item_cats && (env_tab->normed_mat || !env_cfg->simulated) && (env_tab->mat || env_cfg->simulated), "env tables incomplete");
     if (t_begin >= t_end) return CIRS_OK;
     float* h2 = (float*)workspace;
-    const int n_pad = n_pad_of(n_env), n_chunks = n_chunks_of(pol_cfg->n_items);
+    const int n_pad = n_pad_of(n_env);
+    const HeadGrid hg = sampler_grid(pol_cfg->n_items, n_pad);
+    const int n_chunks = hg.n_chunks;
     ActorPartialView pv = partial_view(workspace, n_env, pol_cfg->n_items);
     int64_t* obs_scratch = nullptr;  // the env's obs_next id == the action: not materialised
     // trunk of the first step of this call (later ones ride on the tracker step)
@@ -169,10 +171,10 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
         int64_t* act_t = traj->act + (size_t)t * B;
         double* rew_t = traj->rew + (size_t)t * B;
         uint8_t* done_t = traj->done + (size_t)t * B;
-        CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel<true>, dim3(n_chunks, cdiv(n_pad / kTileM, 4)), dim3(256), 0, s, *pol_cfg,
+        CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel<true>, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *pol_cfg,
                                                   pol_w->wa, pol_w->ba, (const float*)h2, n_env, (const float*)nullptr, seed,
                                                   rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
-                                                  (const uint8_t*)env_st->done, pv, n_pad));
+                                                  (const uint8_t*)env_st->done, pv, n_pad, hg.tiles_per_chunk));
         CIRS_CHECK_LAUNCH("actor_head_kernel");
         hipLaunchKernelGGL(step_tail_kernel, dim3(cdiv(n_env, kEnvsPerBlock)), dim3(256), 0, s, *env_cfg, *env_tab, *env_st, n_env, n_pad,
                            n_chunks, pv, pol_w->wa, pol_w->ba, (const float*)h2, visited, force_length, (t + 1 >= force_length) ? 1 : 0,
