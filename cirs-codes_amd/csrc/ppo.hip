@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 //   dWa_tile[32 items x 64]  = dZ^T[items x rows] * H2_tile   (A = transposed dZ registers split, B = H2 planes, registers)
 // d h2 stays in the accumulators across the chunk (one partial slab per chunk, summed by trunk_bwd_kernel); the dWa
 // tile of each wave covers only its 32 rows, so the kBwdWaves partial tiles are summed through LDS in wave order and
-// written to the slab of this ROW BLOCK (n_row_blocks slabs, summed in slab order by sumsq_partial / reduce_dwa).
+// written to the slab of this ROW BLOCK (n_row_blocks slabs, summed in slab order by the extra workgroups of the trunk-backward launch).
 // The Wa planes of a tile (24 KB, written by wa_planes_kernel) are staged in LDS once per workgroup, double-buffered with
 // the next tile's global loads in flight; row strides 144 B / 80 B keep the ds_read_b128 of the operands conflict-free.
 
@@ -772,7 +772,7 @@ __device__ __forceinline__ void wa_slab_sum_block(float* __restrict__ g, long wa
 
 // one 32 x 32 tile of dW = dY^T X (+ the bias column sum of dY when k0 == 0) over the 32 rows of a trunk-backward workgroup:
 // A = dY from its LDS copy (sY[row][o]), B = X rows from global memory; written as this workgroup's row slab of the job
-// (same partial layout as dw_multi_kernel: out[o * (K + 1) + k], k == K the bias column)
+// (partial layout of dw_multi_final / dw_multi_fetch: out[o * (K + 1) + k], k == K the bias column)
 __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float* __restrict__ X, int ldx, int K, int row0, int n_rows, int o0,
                                                int k0, float* __restrict__ out, int lane) {
     const int hi = lane >> 5, lo = lane & 31;
@@ -934,25 +934,10 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
 }
 
 // clip_grad_norm_: total norm over [trunk, wa, ba, trunk, wc, bc] -> coef = min(max_norm/(norm+1e-6), 1).
-// stage 1: kNormBlocks workgroups, each a contiguous slice, fixed-order tree -> partial sums of squares
-// sum the dWa slabs in fixed order into the flat gradient buffer (data-parallel path: grads must be complete before
-// the all-reduce; the single-rank path folds this into sumsq_partial_kernel)
-__global__ __launch_bounds__(256) void reduce_dwa_kernel(const float* __restrict__ dwap, long seg, long stride, int n_slabs, float* __restrict__ g_wa_ba) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= seg) return;
-    float acc = 0.f;
-    for (int s0 = 0; s0 < n_slabs; s0 += 8) {
-        float t8[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t8[q] = (s0 + q < n_slabs) ? dwap[(size_t)(s0 + q) * stride + i] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc += t8[q];
-    }
-    g_wa_ba[i] = acc;
-}
-
-// The wa|ba segment of the gradient is still in n_slabs partial slabs: they are summed here (slab order) and the
-// sum is written to the flat gradient buffer on the way.
+// stage 1: kNormBlocks workgroups, fixed-order tree -> partial sums of squares.  Single-rank path (dw_partial set): the wa|ba
+// squares come from the slab-sum workgroups of the trunk-backward launch (slots kNormBlocks..), here the trunk / critic
+// gradients are summed from their row slabs into the flat gradient on the way; data-parallel phase 2 (dw_partial null):
+// every element of the all-reduced gradient is read from the flat buffer.
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ g, long n_trunk, long n_total, long wa_beg, long wa_len,
                                                             int wa_fused,
                                                             DwJobs jobs, int n_dw_slabs, const float* __restrict__ dw_partial, int S,
@@ -970,7 +955,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
         acc += (i < n_trunk ? 2.0f : 1.0f) * x * x;  // trunk parameters appear twice in the reference's list
     }
     if (dw_partial) {
-        // trunk / critic gradients still live in row-slab partials (dw_multi_kernel): job 2 = W1|b1, 1 = W2|b2, 0 = wc|bc.
+        // trunk / critic gradients still live in row-slab partials (trunk_bwd_kernel): job 2 = W1|b1, 1 = W2|b2, 0 = wc|bc.
         // Element e of [trunk | wc | bc] belongs to thread e of the grid (fixed assignment -> fixed summation order).
         const long e = blockIdx.x * 256L + tid;
         const long n_dw = n_trunk + kH + 1;
@@ -1210,7 +1195,6 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
         static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");
         CIRS_REQUIRE(S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
-        // (single-rank path: + the slab sums of the wa|ba gradient as extra workgroups of the same launch)
         // d wc/d bc, d W2/d b2, d W1/d b1: single-rank path = one row slab per trunk-backward workgroup (32 rows), summed in slab
         // order by sumsq_partial_kernel; data-parallel phase 1 = dw_multi launch pair with the final sums
         DwJobs jobs;
@@ -1218,25 +1202,27 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
         jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
         jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
-        if (phase == 0) {
-            n_dw_slabs = n_pad / kTileM;
-            int off = 0;
-            for (int q = 0; q < 3; ++q) { jobs.j[q].part_off = off; off += n_dw_slabs * jobs.j[q].O * (jobs.j[q].K + 1); }
-            dw_jobs = jobs;
+        n_dw_slabs = n_pad / kTileM;
+        {
+            int off = 0, out = 0;
+            for (int q = 0; q < 3; ++q) {
+                jobs.j[q].part_off = off;
+                off += n_dw_slabs * jobs.j[q].O * (jobs.j[q].K + 1);
+                out += jobs.j[q].O * (jobs.j[q].K + 1);
+            }
+            jobs.total_out = out;
         }
-        hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM + (phase == 0 ? kWaSumBlocks : 0)), dim3(512), 0, s, (int)mb, n_pad, n_bchunks, S,
-                           w.w1, w.w2, w.wc, v, dobs_accum, grads, (long)L.wa, seg, (long)dwa_slab_stride(I), n_slabs, jobs,
-                           phase == 0 ? v.dwp : (float*)nullptr);
+        dw_jobs = jobs;
+        // (+ the slab sums of the wa|ba gradient as extra workgroups of the same launch: the flat gradient's wa|ba segment is
+        // complete after this launch)
+        hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM + kWaSumBlocks), dim3(512), 0, s, (int)mb, n_pad, n_bchunks, S,
+                           w.w1, w.w2, w.wc, v, dobs_accum, grads, (long)L.wa, seg, (long)dwa_slab_stride(I), n_slabs, jobs, v.dwp);
         CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
-        if (phase == 1) {
-            launch_dw_multi(jobs, mb, v.dwp, s, true);
-            CIRS_CHECK_LAUNCH("dw(critic, w2, w1)");
-        }
         if (phase == 1) {  // gradients + loss partials must be complete in `grads` before the caller's all-reduce
+            hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(jobs.total_out, 256)), dim3(256), 0, s, jobs, n_dw_slabs, (const float*)v.dwp);
+            CIRS_CHECK_LAUNCH("dw_multi_final");
             hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, mb, mb_global, v, tail);
             CIRS_CHECK_LAUNCH("loss_partials_kernel");
-            hipLaunchKernelGGL(reduce_dwa_kernel, dim3(cdiv(seg, 256)), dim3(256), 0, s, v.dwap, seg, (long)dwa_slab_stride(I), n_slabs, grads + L.wa);
-            CIRS_CHECK_LAUNCH("reduce_dwa_kernel");
             return CIRS_OK;
         }
     }

@@ -144,60 +144,14 @@ static inline void launch_dw_gemm(const float* dY, int ldy, const float* X, int 
 }
 
 
-// ---- several dW problems over the SAME rows in one launch pair (the PPO trunk/critic trio) ---------------------
+// ---- several dW problems over the SAME rows (the PPO trunk/critic trio): row-slab partials written by
+// trunk_bwd_kernel (ppo.hip), summed in slab order here ---------------------------------------------------------
 struct DwJob {
     const float* dY; int ldy; const float* X; int ldx; int O; int K;
     float* dW; float* db; int tile_begin; int part_off;  // first tile id / float offset of this job's partial slabs
 };
 constexpr int kMaxDwJobs = 4;
 struct DwJobs { DwJob j[kMaxDwJobs]; int n; int total_tiles; int total_out; };
-
-static __global__ __launch_bounds__(64) void dw_multi_kernel(DwJobs jobs, int R, int rows_per_slab, int n_slabs, float* __restrict__ partial) {
-    int ji = 0;
-#pragma unroll
-    for (int q = 1; q < kMaxDwJobs; ++q) if (q < jobs.n && (int)blockIdx.x >= jobs.j[q].tile_begin) ji = q;
-    const DwJob jb = jobs.j[ji];
-    const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
-    const int t = blockIdx.x - jb.tile_begin;
-    const int k_tiles = (jb.K + 31) / 32;
-    const int o0 = (t / k_tiles) * 32, k0 = (t % k_tiles) * 32;
-    const int slab = blockIdx.y;
-    const int r_beg = slab * rows_per_slab, r_end = min(R, r_beg + rows_per_slab);
-    const int o = o0 + lo, k = k0 + lo;
-    const bool o_ok = o < jb.O, k_ok = k < jb.K;
-    sg_f32x16 acc;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
-    float bsum = 0.f;
-    for (int r = r_beg; r < r_end; r += 16) {
-        float a[8], b[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int rr = r + 2 * j + hi;
-            const bool r_ok = rr < r_end;
-            a[j] = (r_ok && o_ok) ? jb.dY[(size_t)rr * jb.ldy + o] : 0.f;
-            b[j] = (r_ok && k_ok) ? jb.X[(size_t)rr * jb.ldx + k] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bsum += a[j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-        }
-    }
-    const int n_out = jb.O * (jb.K + 1);
-    float* out = partial + jb.part_off + (size_t)slab * n_out;
-    if (k_ok) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int oo = o0 + (s & 3) + 8 * (s >> 2) + 4 * hi;
-            if (oo < jb.O) out[(size_t)oo * (jb.K + 1) + k] = acc[s];
-        }
-    }
-    if (k0 == 0) {
-        bsum += __shfl_xor(bsum, 32, CIRS_WAVE);
-        if (hi == 0 && o_ok) out[(size_t)o * (jb.K + 1) + jb.K] = bsum;
-    }
-}
 
 // sum of the slab partials of flat output element i of job jb (fixed slab order); device-side twin of dw_multi_final
 __device__ __forceinline__ float dw_multi_fetch(const DwJob& jb, int n_slabs, const float* __restrict__ partial, int i) {
@@ -228,32 +182,6 @@ static __global__ __launch_bounds__(256) void dw_multi_final(DwJobs jobs, int n_
     const int o = i / (jb.K + 1), k = i % (jb.K + 1);
     if (k < jb.K) jb.dW[(size_t)o * jb.K + k] = acc;
     else if (jb.db) jb.db[o] = acc;
-}
-
-__host__ inline size_t dwg_multi_partial_floats(long R, const int* O, const int* K, int n) {
-    size_t f = 0;
-    for (int q = 0; q < n; ++q) f += dwg_partial_floats(R, O[q], K[q]);
-    return f;
-}
-
-// with_final = false: only the slab partials are produced (the caller folds the slab sums into a later kernel)
-static inline int launch_dw_multi(DwJobs& jobs, int R, float* partial, hipStream_t s, bool with_final = true) {
-    const int slabs = dwg_slabs(R);
-    int rows_per_slab = (R + slabs - 1) / slabs;
-    rows_per_slab = (rows_per_slab + 15) & ~15;
-    int tiles = 0, out = 0, off = 0;
-    for (int q = 0; q < jobs.n; ++q) {
-        jobs.j[q].tile_begin = tiles;
-        jobs.j[q].part_off = off;
-        tiles += cdiv(jobs.j[q].O, 32) * cdiv(jobs.j[q].K, 32);
-        out += jobs.j[q].O * (jobs.j[q].K + 1);
-        off += slabs * jobs.j[q].O * (jobs.j[q].K + 1);
-    }
-    jobs.total_tiles = tiles;
-    jobs.total_out = out;
-    hipLaunchKernelGGL(dw_multi_kernel, dim3(tiles, slabs), dim3(64), 0, s, jobs, R, rows_per_slab, slabs, partial);
-    if (with_final) hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(out, 256)), dim3(256), 0, s, jobs, slabs, partial);
-    return slabs;
 }
 
 }  // namespace cirs
