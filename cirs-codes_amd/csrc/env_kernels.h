@@ -9,10 +9,12 @@ constexpr int kEnvsPerBlock = 4;
 
 // One wavefront steps env e (row j of the call) with `action`; lane 0 writes the outputs (obs_out / expo_out may be null:
 // the next observation of this env is the action id itself).
+struct EnvStepResult { double reward; int done; };   // what lane 0 wrote for this env (reward 0 / done 1 for a no-op)
 __device__ __forceinline__ void env_step_wave(const cirs_env_cfg& cfg, const cirs_env_tables& tab, const cirs_env_state& st, int e, int j,
                                               int64_t action, int lane, int64_t* __restrict__ obs_out, double* __restrict__ rew_out,
                                               uint8_t* __restrict__ done_out, double* __restrict__ ctr_out,
-                                              double* __restrict__ expo_out) {
+                                              double* __restrict__ expo_out, EnvStepResult* res = nullptr) {
+    if (res) { res->reward = 0.0; res->done = 1; }
     const int T = cfg.max_turn;
     const long I = cfg.n_items;
     int32_t* hist = st.hist_action + (size_t)e * T;
@@ -115,6 +117,7 @@ __device__ __forceinline__ void env_step_wave(const cirs_env_cfg& cfg, const cir
     if (obs_out) obs_out[j] = action;
     rew_out[j] = reward;
     done_out[j] = (uint8_t)done;
+    if (res) { res->reward = reward; res->done = done; }
     ctr_out[j] = cfg.simulated ? cum / (double)(t + 1) / 10.0 : cum;
     if (expo_out) expo_out[j] = exposure_gamma;
 }

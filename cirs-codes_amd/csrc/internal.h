@@ -46,6 +46,26 @@ inline HeadGrid sampler_grid(int n_items, int n_pad) {
     return g;
 }
 
+// Optional head of the tracker step (fused rollout): the tail of the vector step for the same env row -- merge of the
+// actor-head partials into action / log-prob, visited bit, env step, forced episode length -- runs in the wavefront that
+// then appends the new position to the tracker: one launch per vector step less.
+struct TailFuse {
+    int on;
+    cirs_env_cfg cfg;
+    cirs_env_tables tab;
+    cirs_env_state st;
+    int n_pad, n_chunks;
+    ActorPartialView pv;
+    const float *wa, *ba, *h2;
+    uint32_t* visited;
+    int force_length, force_done;
+    int64_t* act_out;
+    float* logp_out;
+    double* rew_out;
+    uint8_t* done_out;
+    double* ctr_out;
+};
+
 // per-kernel timing hook (api.hip): ids 1 = head_bwd_fused_kernel, 2 = actor_head_kernel<stats>, 3 = actor_head_kernel<sample>
 bool prof_before(int kernel_id, hipStream_t s);
 void prof_after(hipStream_t s);
@@ -58,6 +78,6 @@ void prof_after(hipStream_t s);
 
 int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
-                          long state_stride, const TrunkFuse* tf, hipStream_t s);
+                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail = nullptr);
 
 }  // namespace cirs

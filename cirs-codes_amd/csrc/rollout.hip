@@ -41,36 +41,6 @@ __global__ __launch_bounds__(256) void online_pairs_kernel(const int32_t* __rest
     o.dur_buf[j] = o.item_dur[a];
 }
 
-// The tail of one vector step for env row j (one wavefront): merge the actor-head partials into the action / logp
-// (actor_merge_kernel), mark the visited bit, step the env (env_step_kernel), apply the forced episode length
-// (force_done_kernel) -- four dependent launches of the unfused path in one.
-__global__ __launch_bounds__(256) void step_tail_kernel(cirs_env_cfg cfg, cirs_env_tables tab, cirs_env_state st, int n, int n_pad,
-                                                        int n_chunks, ActorPartialView pv, const float* __restrict__ wa,
-                                                        const float* __restrict__ ba, const float* __restrict__ h2,
-                                                        uint32_t* __restrict__ visited, int force_length, int force_done,
-                                                        int64_t* __restrict__ act_out, float* __restrict__ logp_out,
-                                                        int64_t* __restrict__ obs_out, double* __restrict__ rew_out,
-                                                        uint8_t* __restrict__ done_out, double* __restrict__ ctr_out) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * kEnvsPerBlock + (threadIdx.x >> 6);
-    if (j >= n) return;
-    int64_t act = -1;
-    if (st.done[j]) {  // finished env: the policy skipped it
-        if (lane == 0) { act_out[j] = -1; logp_out[j] = 0.f; }
-    } else {
-        act = actor_merge_wave(j, lane, n_pad, n_chunks, pv, wa, ba, h2, act_out, logp_out);
-        if (visited && act >= 0 && lane == 0) {
-            const int words = (cfg.n_items + 31) / 32;
-            visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
-        }
-    }
-    env_step_wave(cfg, tab, st, j, j, act, lane, obs_out, rew_out, done_out, ctr_out, nullptr);
-    if (force_length > 0 && act >= 0 && lane == 0) {  // collector.py:253-258
-        st.done[j] = (uint8_t)force_done;
-        done_out[j] = (uint8_t)force_done;
-    }
-}
-
 }  // namespace cirs
 
 extern "C" int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
@@ -147,10 +117,10 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
         }
         return CIRS_OK;
     }
-    // ---- fused sequence: 3 launches per vector step ------------------------------------------------------------
+    // ---- fused sequence: 2 launches per vector step ------------------------------------------------------------
     //   actor_head_kernel<sample>   MFMA head + Gumbel-max partials            (trunk of obs_t already in the workspace)
-    //   step_tail_kernel            merge -> act/logp, visited bit, env step, forced length
-    //   tracker_step_kernel + trunk tracker decode step, then the policy trunk of obs_{t+1}
+    //   tracker_step_kernel         one wavefront per env: merge -> act/logp, visited bit, env step, forced length (TailFuse);
+    //                               tracker decode step; the policy trunk of obs_{t+1} (TrunkFuse)
     CIRS_REQUIRE(pol_cfg->hidden == kH && pol_cfg->dim_state == S && pol_cfg->n_items == env_cfg->n_items, "policy/env/tracker shape mismatch");
     CIRS_REQUIRE(pol_w->w1 && pol_w->b1 && pol_w->w2 && pol_w->b2 && pol_w->wa && pol_w->ba && pol_w->wc && pol_w->bc, "policy weight pointer null");
     CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(pol_cfg, n_env), "workspace too small");
@@ -176,16 +146,18 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
                                                   rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
                                                   (const uint8_t*)env_st->done, pv, n_pad, hg.tiles_per_chunk));
         CIRS_CHECK_LAUNCH("actor_head_kernel");
-        hipLaunchKernelGGL(step_tail_kernel, dim3(cdiv(n_env, kEnvsPerBlock)), dim3(256), 0, s, *env_cfg, *env_tab, *env_st, n_env, n_pad,
-                           n_chunks, pv, pol_w->wa, pol_w->ba, (const float*)h2, visited, force_length, (t + 1 >= force_length) ? 1 : 0,
-                           act_t, traj->logp + (size_t)t * B, obs_scratch, rew_t, done_t, traj->ctr + (size_t)t * B);
-        CIRS_CHECK_LAUNCH("step_tail_kernel");
         TrunkFuse tf{};
         if (t + 1 < t_end) {
             tf.on = 1; tf.cfg = *pol_cfg; tf.w = *pol_w; tf.skip = env_st->done; tf.h2 = h2; tf.value = traj->value + (size_t)(t + 1) * B;
         }
         // preprocess_fn(obs_next, rew): the tracker appends one position for every env that acted this step
-        if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, &tf, s))
+        // ... in the same launch as the tail of this step: merge -> act / logp, visited bit, env step, forced length
+        TailFuse tl{};
+        tl.on = 1; tl.cfg = *env_cfg; tl.tab = *env_tab; tl.st = *env_st; tl.n_pad = n_pad; tl.n_chunks = n_chunks; tl.pv = pv;
+        tl.wa = pol_w->wa; tl.ba = pol_w->ba; tl.h2 = h2; tl.visited = visited; tl.force_length = force_length;
+        tl.force_done = (t + 1 >= force_length) ? 1 : 0;
+        tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B; tl.rew_out = rew_t; tl.done_out = done_t; tl.ctr_out = traj->ctr + (size_t)t * B;
+        if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, &tf, s, &tl))
             return rc;
     }
     return CIRS_OK;

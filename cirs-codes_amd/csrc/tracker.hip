@@ -16,6 +16,7 @@
 // + 80 B state; weights (~118 KB) are shared by all envs and stay in L2.  ~60 kFLOP per env-step: latency-bound.
 #include "internal.h"
 #include "policy_kernels.h"
+#include "env_kernels.h"
 
 namespace cirs {
 
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
                                                            const int32_t* __restrict__ env_ids,
                                                            const uint8_t* __restrict__ skip, int n,
                                                            float* __restrict__ state_out, long state_stride,
-                                                           int lpad, TrunkFuse tf) {
+                                                           int lpad, TrunkFuse tf, TailFuse tl) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = kD / NHEAD;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -94,6 +95,34 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             if (lane == 0 && tf.value) tf.value[j] = 0.f;                  \
         }                                                                  \
     } while (0)
+    // fused rollout: the tail of the vector step for this env row first (action, env step); its results stay in registers
+    long it_f = -1;
+    float r_f = 0.f;
+    int fin_f = 0;
+    if (tl.on) {
+        int64_t act = -1;
+        if (tl.st.done[j]) {  // finished env: the policy skipped it
+            if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
+        } else {
+            act = actor_merge_wave(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.wa, tl.ba, tl.h2, tl.act_out, tl.logp_out);
+            if (tl.visited && act >= 0 && lane == 0) {
+                const int words = (tl.cfg.n_items + 31) / 32;
+                tl.visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
+            }
+        }
+        EnvStepResult er;
+        env_step_wave(tl.cfg, tl.tab, tl.st, j, j, act, lane, nullptr, tl.rew_out, tl.done_out, tl.ctr_out, nullptr, &er);
+        const unsigned long long rb = __builtin_bit_cast(unsigned long long, er.reward);
+        const unsigned rlo = __shfl((unsigned)rb, 0, CIRS_WAVE), rhi = __shfl((unsigned)(rb >> 32), 0, CIRS_WAVE);
+        const double reward = __builtin_bit_cast(double, ((unsigned long long)rhi << 32) | rlo);
+        fin_f = __shfl(er.done, 0, CIRS_WAVE);
+        if (tl.force_length > 0 && act >= 0) {  // collector.py:253-258
+            fin_f = tl.force_done;
+            if (lane == 0) { tl.st.done[j] = (uint8_t)tl.force_done; tl.done_out[j] = (uint8_t)tl.force_done; }
+        }
+        it_f = act;
+        r_f = (float)reward;
+    }
     if (skip && skip[j]) { CIRS_TRUNK_ZERO(); return; }
     const int e = env_ids ? env_ids[j] : j;
     const int B = cfg.n_env, L = cfg.max_len;
@@ -110,7 +139,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     const int o32 = lane & (kD - 1);
 
     const bool is_init = users != nullptr;
-    if (!is_init && items[j] < 0) { CIRS_TRUNK_ZERO(); return; }  // act = -1: env finished earlier in this rollout
+    if (!is_init && (tl.on ? it_f : items[j]) < 0) { CIRS_TRUNK_ZERO(); return; }  // act = -1: env finished earlier in this rollout
     const int pos = is_init ? 0 : st.len[e];
     if (pos >= L) { CIRS_TRUNK_ZERO(); return; }  // history full: the caller never steps past max_turn
 
@@ -122,8 +151,8 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         __builtin_amdgcn_wave_barrier();
         x = dot_row<kD>(w.ffn_user_w + (size_t)o32 * kD, xs, w.ffn_user_b[o32]);
     } else {
-        const long it = items[j];
-        const float r = (float)rew[j];
+        const long it = tl.on ? it_f : items[j];
+        const float r = tl.on ? r_f : (float)rew[j];
         float a = 0.f;
         if (lane < kD) {
             a = w.emb_item[(size_t)it * kD + lane];
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     }
     if (lane == 0) st.len[e] = pos + 1;
     if (tf.on) {  // policy trunk of the next vector step on this state
-        if (tf.skip && tf.skip[j]) { CIRS_TRUNK_ZERO(); return; }
+        if (tl.on ? fin_f != 0 : (tf.skip && tf.skip[j])) { CIRS_TRUNK_ZERO(); return; }
         float* txs = ffs;        // [64] input, then h2 (critic)
         float* ths = ffs + 64;   // [64] h1
         __builtin_amdgcn_wave_barrier();
@@ -295,7 +324,9 @@ static int validate_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weig
 static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
                           const int32_t* users, const int64_t* items, const double* rew, const int32_t* env_ids,
                           const uint8_t* skip, int n, float* state_out, long state_stride, hipStream_t s,
-                          const TrunkFuse* fuse = nullptr) {
+                          const TrunkFuse* fuse = nullptr, const TailFuse* tail = nullptr) {
+    TailFuse tl{};
+    if (tail) tl = *tail;
     TrunkFuse tf{};
     if (fuse) {
         tf = *fuse;
@@ -307,7 +338,7 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
     const dim3 grid(cdiv(n, 4)), block(256);
 #define CIRS_TRK(NH)                                                                                              \
     hipLaunchKernelGGL(tracker_step_kernel<NH>, grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
-                       n, state_out, state_stride, lpad, tf)
+                       n, state_out, state_stride, lpad, tf, tl)
     switch (cfg->nhead) {
         case 1: CIRS_TRK(1); break;
         case 2: CIRS_TRK(2); break;
@@ -321,8 +352,8 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
 
 int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
-                          long state_stride, const TrunkFuse* tf, hipStream_t s) {
-    return launch_tracker(cfg, w, st, users, items, rew, env_ids, skip, n, state_out, state_stride, s, tf);
+                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail) {
+    return launch_tracker(cfg, w, st, users, items, rew, env_ids, skip, n, state_out, state_stride, s, tf, tail);
 }
 
 }  // namespace cirs
