@@ -24,9 +24,4 @@ eng.collect(); torch.cuda.synchronize()
 tot, cnt = C.c_double(0.0), C.c_int32(0)
 abi.check(lib.cirs_prof_stop(C.byref(tot), C.byref(cnt)), "cirs_prof_stop")
 k["actor_head_kernel<sample>"] = tot.value / max(cnt.value, 1)
-import time
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(5):
-    eng.collect()
-torch.cuda.synchronize(); k["collect_ms"] = (time.perf_counter() - t0) / 5 * 1e3 * 1e-6
 print(os.path.basename(abi.LIB_PATH), "minibatch %.1f us" % (t * 1e6), {n: round(v * 1e6, 2) for n, v in k.items()}, flush=True)
