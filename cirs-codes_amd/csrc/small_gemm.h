@@ -184,4 +184,60 @@ static __global__ __launch_bounds__(256) void dw_multi_final(DwJobs jobs, int n_
     else if (jb.db) jb.db[o] = acc;
 }
 
+// ---- a whole backward pass worth of dW problems: slab partials per problem, ONE final launch -----------------------
+// launch_dw_partial() runs dw_gemm_kernel into the problem's own region of `partial` and records the job; dw_list_final sums
+// the slabs of every recorded problem in slab order (diag: only the diagonal of a square problem is kept -- LayerNorm weight
+// gradients are the diagonal of dY^T Xhat).
+constexpr int kMaxDwList = 3 + 6 * CIRS_MAX_TRACKER_LAYERS;   // the tracker backward pass: decoder, user ffn, gate + 6 per layer
+struct DwListJob { int O, K, part_off, diag; float* dW; float* db; };
+struct DwList { DwListJob j[kMaxDwList]; int n, total_out, part_floats; };
+
+static inline void launch_dw_partial(DwList& list, const float* dY, int ldy, const float* X, int ldx, int R, int O, int K, float* dW,
+                                     float* db, int diag, float* partial, hipStream_t s) {
+    const int slabs = dwg_slabs(R);
+    int rows_per_slab = (R + slabs - 1) / slabs;
+    rows_per_slab = (rows_per_slab + 15) & ~15;
+    DwListJob& jb = list.j[list.n++];
+    jb.O = O; jb.K = K; jb.part_off = list.part_floats; jb.diag = diag; jb.dW = dW; jb.db = db;
+    list.part_floats += slabs * O * (K + 1);
+    list.total_out += O * (K + 1);
+    const int tiles = cdiv(O, 32) * cdiv(K, 32);
+    hipLaunchKernelGGL(dw_gemm_kernel, dim3(tiles, slabs), dim3(64), 0, s, dY, ldy, X, ldx, R, O, K, rows_per_slab, partial + jb.part_off);
+}
+
+static __global__ __launch_bounds__(256) void dw_list_final(DwList list, int n_slabs, const float* __restrict__ partial) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= list.total_out) return;
+    int ji = 0;
+    for (; ji < list.n; ++ji) {
+        const int n_out = list.j[ji].O * (list.j[ji].K + 1);
+        if (i < n_out) break;
+        i -= n_out;
+    }
+    const DwListJob jb = list.j[ji];
+    const int n_out = jb.O * (jb.K + 1);
+    float acc = 0.f;
+    for (int c0 = 0; c0 < n_slabs; c0 += 16) {  // 16 loads in flight, added in slab order
+        float t16[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t16[q] = (c0 + q < n_slabs) ? partial[jb.part_off + (size_t)(c0 + q) * n_out + i] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += t16[q];
+    }
+    const int o = i / (jb.K + 1), k = i % (jb.K + 1);
+    if (k < jb.K) {
+        if (!jb.diag) jb.dW[(size_t)o * jb.K + k] = acc;
+        else if (o == k) jb.dW[o] = acc;
+    } else if (jb.db) {
+        jb.db[o] = acc;
+    }
+}
+
+static inline void launch_dw_list_final(const DwList& list, int R, const float* partial, hipStream_t s) {
+    hipLaunchKernelGGL(dw_list_final, dim3(cdiv(list.total_out, 256)), dim3(256), 0, s, list, dwg_slabs(R), partial);
+}
+
+// slab-partial floats of one problem (for workspace sizing)
+__host__ inline size_t dw_list_floats(long R, int O, int K) { return (size_t)dwg_slabs(R) * O * (K + 1); }
+
 }  // namespace cirs

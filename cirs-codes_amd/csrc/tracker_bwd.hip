@@ -228,12 +228,9 @@ __global__ __launch_bounds__(256) void ln_bwd(const float* __restrict__ dOut, co
         dY[(size_t)r * tD + d] = rs * (dxh - m1 - xhat[(size_t)r * tD + d] * m2);
     }
 }
-// d gamma[d] = sum_r dOut[r,d]*xhat[r,d] = diag(dOut^T xhat), d beta[d] = sum_r dOut[r,d]: both fall out of the
-// small dW GEMM (32 x 32 product + bias column); this kernel picks the diagonal.
-__global__ __launch_bounds__(64) void ln_diag_kernel(const float* __restrict__ full, float* __restrict__ dg) {
-    const int d = threadIdx.x;
-    if (d < tD) dg[d] = full[d * tD + d];
-}
+// (the LayerNorm weight gradient d gamma = diag(dOut^T xhat) and d beta = column sums of dOut fall out of a 32 x 32 dW
+// problem with the diag flag: dw_list_final keeps the diagonal)
+
 // upstream gradient rows: G[r, s] = dstate[row_t, row_env, s]
 __global__ __launch_bounds__(256) void gather_dstate(const float* __restrict__ dstate, const int32_t* __restrict__ row_env,
                                                      const int32_t* __restrict__ row_t, int R, int S, int B, float* __restrict__ G) {
@@ -368,9 +365,16 @@ struct BwdScratch {
     float *QKV[CIRS_MAX_TRACKER_LAYERS], *P[CIRS_MAX_TRACKER_LAYERS], *ATT[CIRS_MAX_TRACKER_LAYERS];
     float *XH1[CIRS_MAX_TRACKER_LAYERS], *RS1[CIRS_MAX_TRACKER_LAYERS], *H1N[CIRS_MAX_TRACKER_LAYERS], *FF1[CIRS_MAX_TRACKER_LAYERS];
     float *XH2[CIRS_MAX_TRACKER_LAYERS], *RS2[CIRS_MAX_TRACKER_LAYERS];
-    float *T0, *T1, *T2, *dQKV, *dFF1, *dS, *partial, *GIN, *lnfull;
+    float *T0, *T1, *T2, *dQKV, *dFF1, *dS, *partial, *GIN;
     void* sort;  // emb_sort_bytes(R)
 };
+
+static size_t bwd_partial_floats(const cirs_tracker_cfg* cfg, long R) {
+    size_t f = dw_list_floats(R, 32, tD) + dw_list_floats(R, tD, tD) + dw_list_floats(R, tD, tD + 1);   // decoder (S <= 32), ffn_user, gate
+    f += (size_t)cfg->nlayers * (2 * dw_list_floats(R, tD, tD) + dw_list_floats(R, tD, tH) + dw_list_floats(R, tH, tD) +
+                                 dw_list_floats(R, tD, tD) + dw_list_floats(R, 96, tD));              // LN2, LN1, lin2, lin1, out_proj, in_proj
+    return f;
+}
 
 static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     const long nl = cfg->nlayers, Lp = cfg->max_len, NH = cfg->nhead;
@@ -379,9 +383,8 @@ static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     f += (size_t)(nl + 1) * R * tD;               // H
     f += (size_t)nl * R * (96 + NH * Lp + tD + tD + 1 + tD + tH + tD + 1);
     f += 3 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp;  // T0..2, dQKV, dFF1, dS
-    f += dwg_partial_floats(R, tH, tD) + dwg_partial_floats(R, 2, tD) + 4096;  // partial (largest: 128 x 33)
+    f += bwd_partial_floats(cfg, R) + 4096;       // slab partials of every dW problem of the pass (one final launch)
     f += (size_t)R * (tD + 1);                    // GIN
-    f += tD * tD + 64;                            // lnfull
     f += emb_sort_bytes(R) / 4 + 64;              // (key, row) sort of the embedding scatter
     return f + 64 * 32;
 }
@@ -400,9 +403,8 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
     }
     s.T0 = take((size_t)R * tD); s.T1 = take((size_t)R * tD); s.T2 = take((size_t)R * tD);
     s.dQKV = take((size_t)R * 96); s.dFF1 = take((size_t)R * tH); s.dS = take((size_t)R * NH * Lp);
-    s.partial = take(dwg_partial_floats(R, tH, tD) + dwg_partial_floats(R, 2, tD) + 4096);
+    s.partial = take(bwd_partial_floats(cfg, R) + 4096);
     s.GIN = take((size_t)R * (tD + 1));
-    s.lnfull = take(tD * tD + 64);
     s.sort = (void*)take(emb_sort_bytes(R) / 4 + 64);
     return s;
 }
@@ -430,7 +432,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     BwdScratch sc = carve_bwd(workspace, cfg, R);
     auto g1 = [&](long n) { return dim3(cdiv(n, 256)); };
 
-#define DW(dY, X, O, K, dWp, dbp) launch_dw_gemm(dY, O, X, K, R, O, K, dWp, dbp, sc.partial, s)
+    DwList dwl{};
+#define DW(dY, X, O, K, dWp, dbp) launch_dw_partial(dwl, dY, O, X, K, R, O, K, dWp, dbp, 0, sc.partial, s)
 #define ATT_DISPATCH_SH(KERNEL, SHMEM, ...)                                                               \
     do {                                                                                                  \
         switch (NH) {                                                                                     \
@@ -466,8 +469,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         const cirs_tracker_layer& y = w->layer[l];
         const cirs_tracker_layer_grads& gy = grads->layer[l];
         // LN2
-        launch_dw_gemm(dH, tD, sc.XH2[l], tD, R, tD, tD, sc.lnfull, gy.norm2_b, sc.partial, s);
-        hipLaunchKernelGGL(ln_diag_kernel, dim3(1), dim3(64), 0, s, sc.lnfull, gy.norm2_w);
+        launch_dw_partial(dwl, dH, tD, sc.XH2[l], tD, R, tD, tD, gy.norm2_w, gy.norm2_b, 1, sc.partial, s);   // diag(dH^T Xhat), column sums
         float* dY2 = sc.T1;
         hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2);
         // FF
@@ -477,8 +479,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         // d H1N = dY2 (residual) + dFF1 * W1
         launch_rows_gemm(false, sc.dFF1, tH, y.lin1_w, tD, nullptr, R, tH, tD, 0, nullptr, 1, dY2, tD, s);
         // LN1
-        launch_dw_gemm(dY2, tD, sc.XH1[l], tD, R, tD, tD, sc.lnfull, gy.norm1_b, sc.partial, s);
-        hipLaunchKernelGGL(ln_diag_kernel, dim3(1), dim3(64), 0, s, sc.lnfull, gy.norm1_w);
+        launch_dw_partial(dwl, dY2, tD, sc.XH1[l], tD, R, tD, tD, gy.norm1_w, gy.norm1_b, 1, sc.partial, s);
         float* dY1 = sc.T2;
         hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dY2, sc.XH1[l], sc.RS1[l], y.norm1_w, R, dY1);
         // out_proj
@@ -513,6 +514,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     if (int rc = emb_scatter_sorted(key_item, CI, R, cfg->n_items, grads->emb_item, sc.sort, emb_sort_bytes(R), s)) return rc;
     DW(DU, EU, tD, tD, grads->ffn_user_w, grads->ffn_user_b);
     DW(DPRE, sc.GIN, tD, tD + 1, grads->gate_w, grads->gate_b);
+    launch_dw_list_final(dwl, R, sc.partial, s);   // every weight / bias gradient of the pass: slab sums in one launch
     CIRS_CHECK_LAUNCH("tracker backward slots");
 #undef DW
 #undef ATT_DISPATCH
