@@ -120,27 +120,26 @@ __global__ __launch_bounds__(256) void attn_bwd_q(const float* __restrict__ QKV,
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) dot[h] = wave_sum_f32(dot[h]);
-    float dq[tD];
-#pragma unroll
-    for (int d = 0; d < tD; ++d) dq[d] = 0.f;
+    // softmax backward: dS = P * (dP - sum_j P dP), kept in global memory for the key-side kernel and in LDS for dQ
+    extern __shared__ float smem_q[];
+    float* sds = smem_q + (size_t)(threadIdx.x >> 6) * NH * Lp;
     for (int jp = lane; jp <= p; jp += CIRS_WAVE) {
-        const float* k = QKV + (size_t)(base + jp) * 96 + tD;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const float ds = Pr[h * Lp + jp] * (dSr[h * Lp + jp] - dot[h]);  // softmax backward
+            const float ds = Pr[h * Lp + jp] * (dSr[h * Lp + jp] - dot[h]);
             dSr[h * Lp + jp] = ds;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) dq[h * HD + d] = __builtin_fmaf(ds, k[h * HD + d], dq[h * HD + d]);
+            sds[h * Lp + jp] = ds;
         }
     }
-#pragma unroll
-    for (int d = 0; d < tD; ++d) dq[d] = wave_sum_f32(dq[d]);
-    if (lane < tD) {
-        float val = 0.f;
-#pragma unroll
-        for (int d = 0; d < tD; ++d) val = lane == d ? dq[d] : val;
-        dQKV[(size_t)r * 96 + lane] = val * scale;  // scores used q*scale
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // dQ[d] = scale * sum_j dS[h(d), j] * K[j, d]: lane = (half, d), the two halves take every second key (coalesced rows)
+    const int half = lane >> 5, d = lane & (tD - 1), hd = d / HD;
+    float acc = 0.f;
+    for (int jp = half; jp <= p; jp += 2) acc = __builtin_fmaf(sds[hd * Lp + jp], QKV[(size_t)(base + jp) * 96 + tD + d], acc);
+    acc += __shfl_xor(acc, 32, CIRS_WAVE);
+    if (lane < tD) dQKV[(size_t)r * 96 + d] = acc * scale;  // scores used q*scale
 }
 
 // key side: dK[p'] = sum_{p >= p'} dS[p,p'] * q[p]*scale ; dV[p'] = sum_{p >= p'} P[p,p'] * dATT[p]
@@ -155,33 +154,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(const float* __restrict__ QKV
     if (r >= R) return;
     const int b = row_env[r], pk = row_t[r], base = offsets[b], len = lens[b];
     const float scale = 1.0f / sqrtf((float)HD);
-    float dk[tD], dv[tD];
+    // lane = (which, d): lanes 0..31 own dK[d], lanes 32..63 own dV[d]; the later queries of the episode are walked in order
+    // (<= max_turn of them): coalesced 128-byte rows, no cross-lane reduction
+    const int d = lane & (tD - 1), which = lane >> 5, h = d / HD;
+    const float* coef = (which == 0 ? dS : P) + ((size_t)base * NH + h) * Lp + pk;    // [query row][head][key position]
+    const float* vec = which == 0 ? QKV + (size_t)base * 96 + d : dATT + (size_t)base * tD + d;
+    const size_t cstride = (size_t)NH * Lp, vstride = which == 0 ? 96 : tD;
+    const float cs = which == 0 ? scale : 1.0f;
+    float acc = 0.f;
+    int p = pk;
+    for (; p + 4 <= len; p += 4) {   // 8 independent loads in flight
+        float c4[4], v4[4];
 #pragma unroll
-    for (int d = 0; d < tD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-    for (int p = pk + lane; p < len; p += CIRS_WAVE) {
-        const size_t rq = (size_t)(base + p);
-        const float* q = QKV + rq * 96;
-        const float* da = dATT + rq * tD;
+        for (int u = 0; u < 4; ++u) { c4[u] = coef[(size_t)(p + u) * cstride]; v4[u] = vec[(size_t)(p + u) * vstride]; }
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const float ds = dS[(rq * NH + h) * Lp + pk] * scale;
-            const float pr = P[(rq * NH + h) * Lp + pk];
-#pragma unroll
-            for (int d = 0; d < HD; ++d) {
-                dk[h * HD + d] = __builtin_fmaf(ds, q[h * HD + d], dk[h * HD + d]);
-                dv[h * HD + d] = __builtin_fmaf(pr, da[h * HD + d], dv[h * HD + d]);
-            }
-        }
+        for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(c4[u] * cs, v4[u], acc);
     }
-#pragma unroll
-    for (int d = 0; d < tD; ++d) { dk[d] = wave_sum_f32(dk[d]); dv[d] = wave_sum_f32(dv[d]); }
-    if (lane < tD) {
-        float a = 0.f, c = 0.f;
-#pragma unroll
-        for (int d = 0; d < tD; ++d) { a = lane == d ? dk[d] : a; c = lane == d ? dv[d] : c; }
-        dQKV[(size_t)r * 96 + tD + lane] = a;
-        dQKV[(size_t)r * 96 + 2 * tD + lane] = c;
-    }
+    for (; p < len; ++p) acc = __builtin_fmaf(coef[(size_t)p * cstride] * cs, vec[(size_t)p * vstride], acc);
+    dQKV[(size_t)r * 96 + tD + lane] = acc;   // columns [32, 64) = dK, [64, 96) = dV
 }
 
 // Y = A + B (pre-LayerNorm residual sum), one thread per element
@@ -487,7 +477,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         float* dATT = sc.T1;
         launch_rows_gemm(false, dY1, tD, y.out_proj_w, tD, nullptr, R, tD, tD, 0, nullptr, 0, dATT, tD, s);
         // attention
-        ATT_DISPATCH(attn_bwd_q, sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV);
+        ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV);
         ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
         // in_proj
         DW(sc.dQKV, sc.H[l], 96, tD, gy.in_proj_w, gy.in_proj_b);
