@@ -174,49 +174,46 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(const float* __restrict__ QKV
     dQKV[(size_t)r * 96 + tD + lane] = acc;   // columns [32, 64) = dK, [64, 96) = dV
 }
 
-// Y = A + B (pre-LayerNorm residual sum), one thread per element
-__global__ __launch_bounds__(256) void add_rows(const float* __restrict__ A, const float* __restrict__ B, long n, float* __restrict__ Y) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i < n) Y[i] = A[i] + B[i];
+// sum over the 32 lanes of a half-wave (one LayerNorm row per half-wave), result in every lane of the half
+__device__ __forceinline__ float half_sum32(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, CIRS_WAVE);
+    return v;
 }
 
-// LayerNorm(32) forward, one thread per row: out = (y - mean) * rstd * g + b ; xhat kept for the backward
-__global__ __launch_bounds__(256) void ln_fwd(const float* __restrict__ Y, const float* __restrict__ g, const float* __restrict__ b, int R,
-                                              float* __restrict__ xhat, float* __restrict__ rstd, float* __restrict__ out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const float* y = Y + (size_t)r * tD;
-    float mean = 0.f;
-    for (int d = 0; d < tD; ++d) mean += y[d];
-    mean *= (1.0f / tD);
-    float var = 0.f;
-    for (int d = 0; d < tD; ++d) { const float t = y[d] - mean; var += t * t; }
-    var *= (1.0f / tD);
+// LayerNorm(32) forward, one lane per element (a row = one half-wave, coalesced 128-byte rows):
+// y = Y + Y2 (residual); out = (y - mean) * rstd * g + b ; xhat and rstd kept for the backward
+__global__ __launch_bounds__(256) void ln_fwd(const float* __restrict__ Y, const float* __restrict__ Y2, const float* __restrict__ g,
+                                              const float* __restrict__ b, int R, float* __restrict__ xhat, float* __restrict__ rstd,
+                                              float* __restrict__ out) {
+    static_assert(tD == 32, "one half-wave per row");
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long r = i >> 5;
+    const int d = (int)(i & 31);
+    const bool ok = r < R;
+    const float y = ok ? Y[i] + Y2[i] : 0.f;   // the pre-LayerNorm residual sum rides along
+    const float mean = half_sum32(y) * (1.0f / tD);
+    const float t = y - mean;
+    const float var = half_sum32(t * t) * (1.0f / tD);
     const float rs = 1.0f / sqrtf(var + 1e-5f);
-    rstd[r] = rs;
-    for (int d = 0; d < tD; ++d) {
-        const float xh = (y[d] - mean) * rs;
-        xhat[(size_t)r * tD + d] = xh;
-        out[(size_t)r * tD + d] = xh * g[d] + b[d];
-    }
+    if (!ok) return;
+    if (d == 0) rstd[r] = rs;
+    const float xh = t * rs;
+    xhat[i] = xh;
+    out[i] = xh * g[d] + b[d];
 }
-// LayerNorm backward per row: dY = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)), dxh = dOut * g
+// LayerNorm backward, same mapping: dY = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)), dxh = dOut * g
 __global__ __launch_bounds__(256) void ln_bwd(const float* __restrict__ dOut, const float* __restrict__ xhat, const float* __restrict__ rstd,
                                               const float* __restrict__ g, int R, float* __restrict__ dY) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    float m1 = 0.f, m2 = 0.f;
-    for (int d = 0; d < tD; ++d) {
-        const float dxh = dOut[(size_t)r * tD + d] * g[d];
-        m1 += dxh;
-        m2 += dxh * xhat[(size_t)r * tD + d];
-    }
-    m1 *= (1.0f / tD); m2 *= (1.0f / tD);
-    const float rs = rstd[r];
-    for (int d = 0; d < tD; ++d) {
-        const float dxh = dOut[(size_t)r * tD + d] * g[d];
-        dY[(size_t)r * tD + d] = rs * (dxh - m1 - xhat[(size_t)r * tD + d] * m2);
-    }
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long r = i >> 5;
+    const int d = (int)(i & 31);
+    const bool ok = r < R;
+    const float dxh = ok ? dOut[i] * g[d] : 0.f;
+    const float xh = ok ? xhat[i] : 0.f;
+    const float m1 = half_sum32(dxh) * (1.0f / tD);
+    const float m2 = half_sum32(dxh * xh) * (1.0f / tD);
+    if (ok) dY[i] = rstd[r] * (dxh - m1 - xh * m2);
 }
 // (the LayerNorm weight gradient d gamma = diag(dOut^T xhat) and d beta = column sums of dOut fall out of a 32 x 32 dW
 // problem with the diag flag: dw_list_final keeps the diagonal)
@@ -442,12 +439,10 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         launch_rows_gemm(true, sc.H[l], tD, y.in_proj_w, tD, y.in_proj_b, R, tD, 96, 0, nullptr, 0, sc.QKV[l], 96, s);
         ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l]);
         launch_rows_gemm(true, sc.ATT[l], tD, y.out_proj_w, tD, y.out_proj_b, R, tD, tD, 0, nullptr, 0, sc.T0, tD, s);
-        hipLaunchKernelGGL(add_rows, g1((long)R * tD), dim3(256), 0, s, sc.H[l], sc.T0, (long)R * tD, sc.T1);
-        hipLaunchKernelGGL(ln_fwd, g1(R), dim3(256), 0, s, sc.T1, y.norm1_w, y.norm1_b, R, sc.XH1[l], sc.RS1[l], sc.H1N[l]);
+        hipLaunchKernelGGL(ln_fwd, g1((long)R * tD), dim3(256), 0, s, sc.H[l], sc.T0, y.norm1_w, y.norm1_b, R, sc.XH1[l], sc.RS1[l], sc.H1N[l]);
         launch_rows_gemm(true, sc.H1N[l], tD, y.lin1_w, tD, y.lin1_b, R, tD, tH, 1, nullptr, 0, sc.FF1[l], tH, s);
         launch_rows_gemm(true, sc.FF1[l], tH, y.lin2_w, tH, y.lin2_b, R, tH, tD, 0, nullptr, 0, sc.T0, tD, s);
-        hipLaunchKernelGGL(add_rows, g1((long)R * tD), dim3(256), 0, s, sc.H1N[l], sc.T0, (long)R * tD, sc.T1);
-        hipLaunchKernelGGL(ln_fwd, g1(R), dim3(256), 0, s, sc.T1, y.norm2_w, y.norm2_b, R, sc.XH2[l], sc.RS2[l], sc.H[l + 1]);
+        hipLaunchKernelGGL(ln_fwd, g1((long)R * tD), dim3(256), 0, s, sc.H1N[l], sc.T0, y.norm2_w, y.norm2_b, R, sc.XH2[l], sc.RS2[l], sc.H[l + 1]);
     }
     CIRS_CHECK_LAUNCH("tracker forward recompute");
     // ---------------- backward ----------------
@@ -461,7 +456,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         // LN2
         launch_dw_partial(dwl, dH, tD, sc.XH2[l], tD, R, tD, tD, gy.norm2_w, gy.norm2_b, 1, sc.partial, s);   // diag(dH^T Xhat), column sums
         float* dY2 = sc.T1;
-        hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2);
+        hipLaunchKernelGGL(ln_bwd, g1((long)R * tD), dim3(256), 0, s, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2);
         // FF
         DW(dY2, sc.FF1[l], tD, tH, gy.lin2_w, gy.lin2_b);
         launch_rows_gemm(false, dY2, tD, y.lin2_w, tH, nullptr, R, tD, tH, 0, sc.FF1[l], 0, sc.dFF1, tH, s);
@@ -471,7 +466,7 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         // LN1
         launch_dw_partial(dwl, dY2, tD, sc.XH1[l], tD, R, tD, tD, gy.norm1_w, gy.norm1_b, 1, sc.partial, s);
         float* dY1 = sc.T2;
-        hipLaunchKernelGGL(ln_bwd, g1(R), dim3(256), 0, s, dY2, sc.XH1[l], sc.RS1[l], y.norm1_w, R, dY1);
+        hipLaunchKernelGGL(ln_bwd, g1((long)R * tD), dim3(256), 0, s, dY2, sc.XH1[l], sc.RS1[l], y.norm1_w, R, dY1);
         // out_proj
         DW(dY1, sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b);
         float* dATT = sc.T1;
