@@ -295,34 +295,65 @@ __global__ __launch_bounds__(256) void scatter_keys_kernel(const int32_t* __rest
     rows[r] = r;
 }
 
-__global__ __launch_bounds__(256) void emb_segment_sum_kernel(const uint32_t* __restrict__ ks, const int32_t* __restrict__ rs,
-                                                              const float* __restrict__ contrib, int R, int n_table,
-                                                              float* __restrict__ g_emb) {
+// Ordered segment sums over the (key, row) pairs sorted by key, in two levels so that a very popular key (thousands of rows
+// once the policy concentrates on few items) is not one sequential chain:
+//   sub-runs   a sub-run starts at every segment head and at every multiple of 64 in the sorted order and ends at the next
+//              such position: <= 64 rows, summed in row order by one half-wave (lane = embedding dimension) -> part[start]
+//   segments   the head of a segment adds its sub-run partials in position order (every 64th position) -> g_emb[key]
+// Fixed order, no atomics; rows of keys outside the table are skipped.
+constexpr int kSubRun = 64;
+__global__ __launch_bounds__(256) void emb_subrun_kernel(const uint32_t* __restrict__ ks, const int32_t* __restrict__ rs,
+                                                         const float* __restrict__ contrib, int R, int n_table, float* __restrict__ part) {
     const int d = threadIdx.x & 31;
     const int p = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (p >= R) return;
     const uint32_t key = ks[p];
-    if (key >= (uint32_t)n_table || (p > 0 && ks[p - 1] == key)) return;  // not a segment head
+    if (key >= (uint32_t)n_table) return;
+    if ((p % kSubRun) != 0 && ks[p - 1] == key) return;   // neither a block start nor a segment head
+    const int end = min(R, (p / kSubRun + 1) * kSubRun);
     float acc = 0.f;
-    int q = p;
-    while (q < R) {  // batches of 8 rows: loads in flight together, added in row order
+    for (int q = p; q < end; q += 8) {  // batches of 8 rows: loads in flight together, added in row order
         float t8[8];
         int n_ok = 0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const bool ok = (n_ok == u) && (q + u < R) && ks[q + u] == key;
+            const bool ok = (n_ok == u) && (q + u < end) && ks[q + u] == key;
             t8[u] = ok ? contrib[(size_t)rs[q + u] * tD + d] : 0.f;
             n_ok += ok;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += (u < n_ok) ? t8[u] : 0.f;
         if (n_ok < 8) break;
-        q += 8;
+    }
+    part[(size_t)p * tD + d] = acc;
+}
+
+__global__ __launch_bounds__(256) void emb_segment_sum_kernel(const uint32_t* __restrict__ ks, const float* __restrict__ part, int R,
+                                                              int n_table, float* __restrict__ g_emb) {
+    const int d = threadIdx.x & 31;
+    const int p = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (p >= R) return;
+    const uint32_t key = ks[p];
+    if (key >= (uint32_t)n_table || (p > 0 && ks[p - 1] == key)) return;  // not a segment head
+    float acc = part[(size_t)p * tD + d];
+    for (int q = (p / kSubRun + 1) * kSubRun; q < R; q += 8 * kSubRun) {   // the segment's later sub-runs, 8 loads in flight
+        float t8[8];
+        int n_ok = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int qq = q + u * kSubRun;
+            const bool ok = (n_ok == u) && qq < R && ks[qq] == key;
+            t8[u] = ok ? part[(size_t)qq * tD + d] : 0.f;
+            n_ok += ok;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (u < n_ok) ? t8[u] : 0.f;
+        if (n_ok < 8) break;
     }
     g_emb[(size_t)key * tD + d] = acc;
 }
 
-static size_t emb_sort_bytes(long R) { return (size_t)R * 64 + (1u << 20); }
+static size_t emb_sort_bytes(long R) { return (size_t)R * (64 + 4 * tD) + (1u << 20); }   // keys/rows in+out, sub-run partials, sort temp
 
 // keys [R] (< 0: no contribution), contrib [R, 32] -> g_emb [n_table, 32] (fully overwritten)
 static int emb_scatter_sorted(const int32_t* keys, const float* contrib, int R, int n_table, float* g_emb, void* scratch,
@@ -332,7 +363,8 @@ static int emb_scatter_sorted(const int32_t* keys, const float* contrib, int R, 
     uint32_t* k_out = k_in + R;
     int32_t* r_in = (int32_t*)(k_out + R);
     int32_t* r_out = r_in + R;
-    char* temp = (char*)(((uintptr_t)(r_out + R) + 255) & ~(uintptr_t)255);
+    float* part = (float*)(((uintptr_t)(r_out + R) + 255) & ~(uintptr_t)255);   // [R, 32] sub-run partials
+    char* temp = (char*)(((uintptr_t)(part + (size_t)R * tD) + 255) & ~(uintptr_t)255);
     const size_t avail = scratch_bytes - (size_t)(temp - (char*)scratch);
     int end_bit = 1;
     while ((1u << end_bit) <= (uint32_t)n_table && end_bit < 32) ++end_bit;
@@ -342,7 +374,8 @@ static int emb_scatter_sorted(const int32_t* keys, const float* contrib, int R, 
     CIRS_HIP(hipMemsetAsync(g_emb, 0, (size_t)n_table * tD * sizeof(float), s));
     hipLaunchKernelGGL(scatter_keys_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, keys, R, n_table, k_in, r_in);
     CIRS_HIP(hipcub::DeviceRadixSort::SortPairs(temp, need, k_in, k_out, r_in, r_out, R, 0, end_bit, s));
-    hipLaunchKernelGGL(emb_segment_sum_kernel, dim3(cdiv(R, 8)), dim3(256), 0, s, k_out, r_out, contrib, R, n_table, g_emb);
+    hipLaunchKernelGGL(emb_subrun_kernel, dim3(cdiv(R, 8)), dim3(256), 0, s, k_out, r_out, contrib, R, n_table, part);
+    hipLaunchKernelGGL(emb_segment_sum_kernel, dim3(cdiv(R, 8)), dim3(256), 0, s, k_out, (const float*)part, R, n_table, g_emb);
     CIRS_CHECK_LAUNCH("emb_segment_sum_kernel");
     return CIRS_OK;
 }
