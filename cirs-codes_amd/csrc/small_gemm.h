@@ -87,7 +87,7 @@ static inline void launch_rows_gemm(bool nt, const float* X, int ldx, const floa
     else hipLaunchKernelGGL(rows_gemm_kernel<false>, grid, dim3(64), 0, s, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy, out_row);
 }
 
-constexpr int kDwMaxSlabs = 128;  // 30 k buffer rows -> ~230 rows (15 load batches) per wavefront instead of ~920
+constexpr int kDwMaxSlabs = 256;  // 30 k buffer rows -> ~115 rows (4 load batches of 32) per wavefront
 __host__ inline int dwg_slabs(long R) {
     const long want = (R + 63) / 64;  // >= 64 rows per slab
     return (int)(want < 1 ? 1 : (want > kDwMaxSlabs ? kDwMaxSlabs : want));
