@@ -178,6 +178,9 @@ def lib():
         raise CirsHipError(
             f"{LIB_PATH} not found: the HIP extension is the only implementation of this path (no CPU fallback). "
             "Build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950).")
+    # torch first: its bundled HIP runtime must be the one this process uses.  Loading libcirs_hip.so before torch pulls in
+    # the system libamdhip64 instead, and launches on torch's device pointers then fail ("no ROCm-capable device").
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         try:
