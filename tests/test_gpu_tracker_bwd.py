@@ -45,14 +45,17 @@ def rows_of(lens):
     return offsets, row_env, row_t
 
 
-@pytest.mark.parametrize("U,I,B,T,nhead", [(50, 80, 9, 12, 4), (300, 500, 70, 30, 4), (40, 60, 5, 100, 8), (30, 40, 6, 7, 1)])
-def test_tracker_backward_matches_autograd(U, I, B, T, nhead):
+@pytest.mark.parametrize("U,I,B,T,nhead,hot", [(50, 80, 9, 12, 4, 0.0), (300, 500, 70, 30, 4, 0.0), (40, 60, 5, 100, 8, 0.0),
+                                                (30, 40, 6, 7, 1, 0.0), (8, 90, 48, 30, 4, 0.6)])
+def test_tracker_backward_matches_autograd(U, I, B, T, nhead, hot):
     from cirs_hip.rollout import Trajectory
     rng = np.random.RandomState(B * T)
     tp = rolloutcase.tracker_param_dict(U, I, T, seed=3)
     lens = rng.randint(2, T + 1, size=B)
     users = rng.randint(0, U, B); acts = rng.randint(0, I, (B, T)); rews = rng.uniform(0, 1, (B, T))
     acts[:, ::5] = acts[:, :1]  # repeated items: several rows hit the same embedding row
+    if hot > 0:  # a concentrated policy: one item (and few users) own hundreds of rows -> embedding-gradient segments that span
+        acts[rng.uniform(size=acts.shape) < hot] = 7   # many 64-row sub-runs of the sorted scatter
     G = rng.normal(size=(T + 1, B, 20)).astype(np.float32)
     # autograd reference
     tpo = {k: v.clone() for k, v in tp.items()}
