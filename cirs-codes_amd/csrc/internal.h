@@ -66,7 +66,7 @@ struct TailFuse {
     double* ctr_out;
 };
 
-// per-kernel timing hook (api.hip): ids 1 = head_bwd_fused_kernel, 2 = actor_head_kernel<stats>, 3 = actor_head_kernel<sample>
+// per-kernel timing hook (api.hip): ids 1 = head_bwd_fused_kernel, 2 = head_stats_kernel, 3 = actor_head_kernel (sampler)
 bool prof_before(int kernel_id, hipStream_t s);
 void prof_after(hipStream_t s);
 #define CIRS_PROF_LAUNCH(ID, STREAM, ...)                       \

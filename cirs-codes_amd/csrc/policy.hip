@@ -79,7 +79,7 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
                        value_out, nullptr);
     CIRS_CHECK_LAUNCH("trunk_kernel");
     const dim3 grid(hg.grid_x, hg.n_row_blocks);
-    hipLaunchKernelGGL(actor_head_kernel<true>, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
+    hipLaunchKernelGGL(actor_head_kernel, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
                        rng_step, env_ids, visited, skip, pv, n_pad, hg.tiles_per_chunk);
     CIRS_CHECK_LAUNCH("actor_head_kernel");
     hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, n_chunks, pv, w->wa, w->ba,

@@ -128,7 +128,7 @@ static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, 
 // two half-waves at the end of the chunk.  Per accumulator group (s>>2) the 4 items are consecutive -> one Philox
 // block and one float4 bias load serve them.
 // grid = (n_chunks, ceil(n_pad/32/4)); block = 4 waves = 4 env tiles walking the same item chunk (shared Wa lines).
-// kSample: true  -> Gumbel-max sampling + LSE (rollout);  false -> LSE (+ sum exp(z-m) z for the entropy) only.
+// (The PPO update's statistics-only variant of this kernel moved to ppo.hip: head_stats_kernel, on the bf16 matrix pipe.)
 // Launch geometry of the sampler.  Unlike the MFMA-heavy PPO head kernels this one is VALU-bound (Philox: 20 quarter-rate
 // v_mad_u64_u32 per 4 items, two fixed-order logs per item) and wants MANY small co-resident workgroups (60 VGPRs, 17 KB LDS:
 // up to 3 per CU here): measured at C3 per launch, 4 tiles per chunk (672 workgroups) 42.9 us, 6 tiles (448) 46.4 us,
@@ -137,8 +137,7 @@ constexpr int kSamplerWgsPerCu = 3;
 struct HeadGrid { int tiles_per_chunk, n_chunks, grid_x, n_row_blocks; };
 constexpr int kLdsStride = 68;  // row stride (floats) of a staged 32 x 64 tile: ds_read_b128 of 16 lanes x 16 rows -> 64 banks
 
-template <bool kSample>
-__global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa,
+static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa,
                                                             const float* __restrict__ ba,
                                                             const float* __restrict__ h2, int n,
                                                             const float* __restrict__ gumbel, uint64_t seed,
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
 #pragma unroll
         for (int q = 0; q < 32; ++q) hrow[q] = 0.f;
     }
-    float best_score = -INFINITY, run_m = -INFINITY, run_s = 0.f, run_t = 0.f;
+    float best_score = -INFINITY, run_m = -INFINITY, run_s = 0.f;
     int best_idx = 0x7FFFFFFF;
 
     const int st_item = tid >> 3, st_col = (tid & 7) * 8;  // staging role: 2 float4 of the tile
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
                 for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
 
                 if (active) {
-                    const uint32_t vis = (kSample && visited) ? visited[(size_t)e * vis_words + (tile0 >> 5)] : 0u;
+                    const uint32_t vis = visited ? visited[(size_t)e * vis_words + (tile0 >> 5)] : 0u;
                     // log-sum-exp per tile: the lane's maximum first, then ONE rescale of the running sums and one exp per
                     // element (masked / padded elements carry -inf and add exp(-inf) = 0)
                     float zt[16];
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
                     for (int g = 0; g < 4; ++g) {
                         const int i0 = tile0 + 8 * g + 4 * hi;
                         float g4[4];
-                        if (kSample && !gumbel) {
+                        if (!gumbel) {
                             const u32x4 rr = philox4x32_10((uint32_t)i0 >> 2, (uint32_t)e, rng_step, CIRS_RNG_STREAM_ACTOR,
                                                            (uint32_t)seed, (uint32_t)(seed >> 32));
                             g4[0] = gumbel_from_bits(rr.x); g4[1] = gumbel_from_bits(rr.y);
@@ -248,11 +247,11 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int item = i0 + q;
-                            const bool valid = item < I && !(kSample && ((vis >> (item & 31)) & 1u));
+                            const bool valid = item < I && !((vis >> (item & 31)) & 1u);
                             const float z = acc[4 * g + q];
                             zt[4 * g + q] = valid ? z : -INFINITY;
                             tmax = fmaxf(tmax, zt[4 * g + q]);
-                            if (kSample && valid) {
+                            if (valid) {
                                 const float gn = gumbel ? gumbel[(size_t)jr * I + item] : g4[q];
                                 const float sc = z + gn;
                                 if (sc > best_score) {  // items ascend within a lane: strict > keeps the lowest id on ties
@@ -264,15 +263,13 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
                     if (tmax > -INFINITY) {
                         const float mn = fmaxf(run_m, tmax);
                         const float keep = __expf(run_m - mn);      // run_m = -inf on the first tile: keep = 0
-                        float ss = 0.f, tt = 0.f;
+                        float ss = 0.f;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float ex = __expf(zt[r] - mn);
                             ss += ex;
-                            if (!kSample) tt = __builtin_fmaf(ex, acc[r], tt);   // acc is finite where ex is 0
                         }
                         run_s = __builtin_fmaf(run_s, keep, ss);
-                        if (!kSample) run_t = __builtin_fmaf(run_t, keep, tt);
                         run_m = mn;
                     }
                 }
@@ -290,18 +287,15 @@ __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_cfg cfg,
         const int oi = __shfl_xor(best_idx, 32, CIRS_WAVE);
         if (os > best_score || (os == best_score && oi < best_idx)) { best_score = os; best_idx = oi; }
         const float om = __shfl_xor(run_m, 32, CIRS_WAVE), osum = __shfl_xor(run_s, 32, CIRS_WAVE);
-        const float ot = __shfl_xor(run_t, 32, CIRS_WAVE);
         const float mn = fmaxf(run_m, om);
         if (mn > -INFINITY) {
             const float fa = __expf(run_m - mn), fb = __expf(om - mn);
             run_s = run_s * fa + osum * fb;
-            run_t = run_t * fa + ot * fb;
             run_m = mn;
         }
     }
     if (hi == 0) {
-        if (kSample) { pv.score[po] = best_score; pv.idx[po] = best_idx; }
-        else { pv.score[po] = run_t; }
+        pv.score[po] = best_score; pv.idx[po] = best_idx;
         pv.m[po] = run_m; pv.s[po] = run_s;
     }
 }

@@ -118,7 +118,7 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
         return CIRS_OK;
     }
     // ---- fused sequence: 2 launches per vector step ------------------------------------------------------------
-    //   actor_head_kernel<sample>   MFMA head + Gumbel-max partials            (trunk of obs_t already in the workspace)
+    //   actor_head_kernel           MFMA head + Gumbel-max partials            (trunk of obs_t already in the workspace)
     //   tracker_step_kernel         one wavefront per env: merge -> act/logp, visited bit, env step, forced length (TailFuse);
     //                               tracker decode step; the policy trunk of obs_{t+1} (TrunkFuse)
     CIRS_REQUIRE(pol_cfg->hidden == kH && pol_cfg->dim_state == S && pol_cfg->n_items == env_cfg->n_items, "policy/env/tracker shape mismatch");
@@ -141,7 +141,7 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
         int64_t* act_t = traj->act + (size_t)t * B;
         double* rew_t = traj->rew + (size_t)t * B;
         uint8_t* done_t = traj->done + (size_t)t * B;
-        CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel<true>, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *pol_cfg,
+        CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *pol_cfg,
                                                   pol_w->wa, pol_w->ba, (const float*)h2, n_env, (const float*)nullptr, seed,
                                                   rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
                                                   (const uint8_t*)env_st->done, pv, n_pad, hg.tiles_per_chunk));

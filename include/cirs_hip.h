@@ -465,8 +465,8 @@ int cirs_hash_ids(const int64_t* ids, int64_t n, int64_t n_buckets, int64_t* out
 /* ---- per-kernel timing hook (measurement only; no reference counterpart) ----------------------------------------------
  * cirs_prof_start arms HIP-event pairs around the next `max_samples` launches of one named kernel, recorded on the stream
  * the kernel is launched on; cirs_prof_stop waits for them and returns the summed duration and the sample count.
- * kernel_id: 1 = head_bwd_fused_kernel (PPO minibatch, fused actor-head backward), 2 = actor_head_kernel<stats> (PPO
- * minibatch, forward statistics), 3 = actor_head_kernel<sample> (rollout).  bench.py's `roofline` object uses it so that
+ * kernel_id: 1 = head_bwd_fused_kernel (PPO minibatch, fused actor-head backward), 2 = head_stats_kernel (PPO
+ * minibatch, forward statistics), 3 = actor_head_kernel (rollout sampler).  bench.py's `roofline` object uses it so that
  * `seconds_per_launch` is the same quantity as the kernel's average in the rocprofv3 --kernel-trace --stats summary. */
 int cirs_prof_start(int32_t kernel_id, int32_t max_samples);
 int cirs_prof_stop(double* total_seconds, int32_t* n_samples);

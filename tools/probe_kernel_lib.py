@@ -23,5 +23,5 @@ abi.check(lib.cirs_prof_start(3, 64), "cirs_prof_start")
 eng.collect(); torch.cuda.synchronize()
 tot, cnt = C.c_double(0.0), C.c_int32(0)
 abi.check(lib.cirs_prof_stop(C.byref(tot), C.byref(cnt)), "cirs_prof_stop")
-k["actor_head_kernel<sample>"] = tot.value / max(cnt.value, 1)
+k["actor_head_kernel"] = tot.value / max(cnt.value, 1)
 print(os.path.basename(abi.LIB_PATH), "minibatch %.1f us" % (t * 1e6), {n: round(v * 1e6, 2) for n, v in k.items()}, flush=True)
