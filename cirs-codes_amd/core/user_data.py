@@ -1,0 +1,61 @@
+"""Assembly of the user-model training set from the KuaiRec files (reference CIRS-UserModel-kuaishou.py:86-148,
+`load_dataset_kuaishou`): positives from big_matrix.csv joined with the item categories, one sampled negative per row, the
+exposure effect of every interaction; the two O(big) loops run on the device (core.util.negative_sampling,
+core.util.compute_exposure_effect_kuaishouRec)."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+from core.inputs import SparseFeatP
+from core.static_dataset import StaticDataset
+from core.util import compute_exposure_effect_kuaishouRec, negative_sampling
+from deepctr_torch.inputs import DenseFeat
+
+DATAPATH = "environments/KuaishouRec/data"
+USER_COLS = ["user_id"]
+ITEM_COLS = ["photo_id", "feat0", "feat1", "feat2", "feat3", "photo_duration"]
+
+
+def item_feature_table(datapath):
+    """(list_feat, df_feat): category lists per photo id and the 4-column table shifted by one (0 = padding)."""
+    with open(os.path.join(datapath, "item_categories.json")) as fh:
+        raw = json.load(fh)
+    list_feat = [raw[str(i)]["feature_index"] for i in range(len(raw))]
+    df_feat = pd.DataFrame(list_feat, columns=["feat0", "feat1", "feat2", "feat3"])
+    df_feat.index.name = "photo_id"
+    df_feat = (df_feat.fillna(-1) + 1).astype(int)
+    return list_feat, df_feat
+
+
+def load_dataset_kuaishou(tau, entity_dim, feature_dim, MODEL_SAVE_PATH, datapath=None):
+    """-> (StaticDataset, x_columns, y_columns, ab_columns) exactly as the reference assembles them."""
+    datapath = DATAPATH if datapath is None else datapath
+    big = pd.read_csv(os.path.join(datapath, "big_matrix.csv"), usecols=["user_id", "photo_id", "timestamp", "watch_ratio", "photo_duration"])
+    big["photo_duration"] /= 1000
+    list_feat, df_feat = item_feature_table(datapath)
+    big = big.join(df_feat, on=["photo_id"], how="left")
+    big.loc[big["watch_ratio"] > 5, "watch_ratio"] = 5
+
+    n_user, n_photo = big["user_id"].max() + 1, big["photo_id"].max() + 1
+    x_columns = [SparseFeatP("user_id", n_user, embedding_dim=entity_dim), SparseFeatP("photo_id", n_photo, embedding_dim=entity_dim)]
+    x_columns += [SparseFeatP(f"feat{i}", df_feat.max().max() + 1, embedding_dim=feature_dim, embedding_name="feat", padding_idx=0)
+                  for i in range(4)]
+    x_columns += [DenseFeat("photo_duration", 1)]
+    ab_columns = [SparseFeatP("alpha_u", n_user, embedding_dim=1), SparseFeatP("beta_i", n_photo, embedding_dim=1)]
+    y_columns = [DenseFeat("y", 1)]
+
+    pos_x, pos_y = big[USER_COLS + ITEM_COLS], big[["watch_ratio"]]
+    neg = negative_sampling(big, df_feat, datapath)
+    neg_x = neg[USER_COLS + ITEM_COLS].rename(columns=lambda c: c + "_neg")
+    x_all = pd.concat([pos_x, neg_x], axis=1)
+
+    if tau == 0:
+        exposure = np.zeros([len(x_all), 1])
+    else:
+        exposure = compute_exposure_effect_kuaishouRec(pos_x, big["timestamp"], list_feat, tau, MODEL_SAVE_PATH, datapath)
+
+    dataset = StaticDataset(x_columns, y_columns, num_workers=4)
+    dataset.compile_dataset(x_all, pos_y, exposure)
+    return dataset, x_columns, y_columns, ab_columns

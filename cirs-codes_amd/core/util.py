@@ -53,3 +53,44 @@ def get_similarity_mat(list_feat, DATAPATH="environments/KuaishouRec/data"):
     sim = 1.0 / _device_distance(list_feat)
     pd.DataFrame(sim).to_csv(path)
     return sim
+
+
+# ---- dataset assembly of the user-model training (reference core/util.py:135-169, 277-309) --------------------------------
+def compute_exposure_effect_kuaishouRec(df_x, timestamp, list_feat, tau, MODEL_SAVE_PATH, DATAPATH):
+    """Exposure effect of every logged interaction, [n, 1] float64: sum over the user's EARLIER interactions of
+    exp(-dt * dist(item, earlier item) / tau) (compute_exposure_each_user), cached as
+    <MODEL_SAVE_PATH>/../saved_exposure/exposure_pos_<tau>.csv like the reference.  One launch of cirs_exposure_history over the
+    whole log (a user's rows are contiguous, as in big_matrix.csv); distances come from the category lists."""
+    from cirs_hip.dataprep import exposure_history
+    cache = os.path.join(MODEL_SAVE_PATH, "..", "saved_exposure", "exposure_pos_{:.1f}.csv".format(tau))
+    if os.path.isfile(cache):
+        return pd.read_csv(cache).to_numpy()
+    expo = exposure_history(df_x["user_id"].to_numpy(), df_x["photo_id"].to_numpy(), np.asarray(timestamp, dtype=np.float64), float(tau),
+                            list_feat=list_feat).cpu().numpy().reshape(-1, 1)
+    os.makedirs(os.path.dirname(cache), exist_ok=True)
+    pd.DataFrame(expo).to_csv(cache, index=False)
+    return expo
+
+
+def negative_sampling(df_big, df_feat, DATAPATH):
+    """One negative item per logged (user, item) pair: the nearest higher (else lower) photo id the user has interacted with in
+    neither matrix (find_negative), with that item's features, mean duration and watch_ratio 0.  The two user x item
+    interaction matrices are bitmaps; the search is cirs_find_negative."""
+    import json
+    from cirs_hip.dataprep import bitmap_rows, find_negative
+    small = pd.read_csv(os.path.join(DATAPATH, "small_matrix.csv"), header=0, usecols=["user_id", "photo_id"])
+    n_user, n_item = int(df_big["user_id"].max()) + 1, int(df_big["photo_id"].max()) + 1
+    seen = []
+    for log in (small, df_big):
+        m = np.zeros((n_user, n_item), dtype=bool)
+        m[log["user_id"].to_numpy(), log["photo_id"].to_numpy()] = True
+        seen.append(bitmap_rows(m))
+    users = df_big["user_id"].to_numpy()
+    neg = find_negative(users, df_big["photo_id"].to_numpy(), seen[0], seen[1], n_item).cpu().numpy()
+    out = pd.DataFrame({"user_id": users.astype(int), "photo_id": neg.astype(int)})
+    out = out.merge(df_feat, on=["photo_id"], how="left")
+    with open(os.path.join(DATAPATH, "photo_mean_duration.json")) as fh:
+        mean_dur = {int(k): v for k, v in json.load(fh).items()}
+    out["photo_duration"] = out["photo_id"].map(mean_dur)
+    out["watch_ratio"] = 0.0
+    return out

@@ -752,7 +752,54 @@ def gen_dataprep():
     print("dataprep.npz: rows", len(df), "exposure max", out["exposure_tau1000"].max(), out["exposure_tau50"].max(), "neg sample", df_negative[:8, 1])
 
 
-FAMILIES = {"dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+def gen_userdata():
+    """load_dataset_kuaishou (reference CIRS-UserModel-kuaishou.py:86-148 with core/util.py negative_sampling and
+    compute_exposure_effect_kuaishouRec) on tiny files in the KuaiRec layout: the assembled training arrays (x incl. the negative
+    half, y, exposure score) and the column descriptors, for tau = 0 and tau > 0."""
+    import tempfile
+    spec = importlib.util.spec_from_file_location("cirs_usermodel_script2", os.path.join(ref_harness.REF_ROOT, "CIRS-UserModel-kuaishou.py"))
+    script = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(script)
+    rng = np.random.RandomState(23)
+    n_users, n_items = 15, 1300   # ids reach past 1225, the absent photo id of the negative search
+    list_feat = [sorted(rng.choice(31, size=rng.randint(1, 5), replace=False).tolist()) for _ in range(n_items)]
+    durations = rng.uniform(2, 60, n_items)
+    rows = []
+    t0 = 1.6e9
+    hot = np.r_[np.arange(1215, 1235), rng.choice(n_items, 80, replace=False)]
+    for u in range(n_users):
+        L = rng.randint(3, 45)
+        ts = np.sort(t0 + rng.randint(0, 6000, L).astype(np.float64))
+        items = rng.choice(hot, L)   # a user's log, rows contiguous and time-ordered (the layout of big_matrix.csv)
+        for k in range(L):
+            rows.append((u, int(items[k]), ts[k], float(rng.gamma(1.5, 1.3)), float(durations[items[k]] * 1000.0)))
+    big = pd.DataFrame(rows, columns=["user_id", "photo_id", "timestamp", "watch_ratio", "photo_duration"])
+    small_u = rng.randint(0, n_users, 300); small_p = rng.choice(hot, 300)
+    out = dict(big_user=big["user_id"].to_numpy(), big_photo=big["photo_id"].to_numpy(), big_ts=big["timestamp"].to_numpy(),
+               big_ratio=big["watch_ratio"].to_numpy(), big_dur=big["photo_duration"].to_numpy(), small_user=small_u, small_photo=small_p,
+               durations=durations, list_feat=np.array([f + [-1] * (4 - len(f)) for f in list_feat], np.int64))
+    for tau in (0.0, 800.0):
+        with tempfile.TemporaryDirectory() as root:
+            write_kuairec_files(root, small_u, small_p, np.ones(len(small_u)), list_feat, durations)
+            big.to_csv(os.path.join(root, "big_matrix.csv"), index=False)
+            save = os.path.join(root, "saved_models", "env", "model")
+            os.makedirs(save)
+            script.DATAPATH = root
+            dataset, x_columns, y_columns, ab_columns = script.load_dataset_kuaishou(tau, 8, 8, save)
+        tag = f"tau{int(tau)}"
+        out[f"x_{tag}"] = np.asarray(dataset.x_numpy, np.float64)
+        out[f"y_{tag}"] = np.asarray(dataset.y_numpy, np.float64)
+        out[f"score_{tag}"] = np.asarray(dataset.score, np.float64)
+        if tau == 0.0:
+            out["x_col_names"] = np.array([c.name for c in x_columns])
+            out["x_col_vocab"] = np.array([getattr(c, "vocabulary_size", 0) for c in x_columns], np.int64)
+            out["x_col_dim"] = np.array([getattr(c, "embedding_dim", getattr(c, "dimension", 0)) for c in x_columns], np.int64)
+            out["ab_col_vocab"] = np.array([c.vocabulary_size for c in ab_columns], np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, "userdata.npz"), **out)
+    print("userdata.npz: rows", len(big), "x", out["x_tau0"].shape, "score max", out["score_tau800"].max(), "names", list(out["x_col_names"]))
+
+
+FAMILIES = {"userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)
