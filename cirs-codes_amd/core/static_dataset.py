@@ -19,6 +19,14 @@ class StaticDataset:
         self.neg_items_info = None
         self.x_numpy = self.y_numpy = self.score = None
 
+    def set_env_items(self, df_small, df_feat, photo_mean_duration):
+        """Per-item table of the evaluation environment (reference static_dataset.py:19-26): the items that occur in the small
+        matrix, their 4 (shifted) category columns and mean duration, ordered by photo id."""
+        items = np.sort(df_small["photo_id"].unique())
+        table = df_feat.loc[items].copy()
+        table["photo_duration"] = [photo_mean_duration[int(i)] for i in items]
+        self.df_photo_env = table
+
     def compile_dataset(self, df_x, df_y, score=None):
         self.x_numpy, self.y_numpy = _as_array(df_x), _as_array(df_y)
         n = len(self.x_numpy)

@@ -29,6 +29,30 @@ def item_feature_table(datapath):
     return list_feat, df_feat
 
 
+def feature_columns(n_user, n_photo, n_feat, entity_dim, feature_dim):
+    """The 7 input columns of the DeepFM user model: user, photo, four category slots sharing one table (0 = padding), duration."""
+    cols = [SparseFeatP("user_id", n_user, embedding_dim=entity_dim), SparseFeatP("photo_id", n_photo, embedding_dim=entity_dim)]
+    cols += [SparseFeatP(f"feat{i}", n_feat, embedding_dim=feature_dim, embedding_name="feat", padding_idx=0) for i in range(4)]
+    return cols + [DenseFeat("photo_duration", 1)]
+
+
+def load_static_validate_data_kuaishou(entity_dim, feature_dim, datapath=None):
+    """Validation set = the fully observed small matrix (reference core/util.py:81-133) + the evaluation env's item table."""
+    datapath = DATAPATH if datapath is None else datapath
+    small = pd.read_csv(os.path.join(datapath, "small_matrix.csv"), usecols=["user_id", "photo_id", "watch_ratio", "photo_duration"])
+    small["photo_duration"] /= 1000
+    _, df_feat = item_feature_table(datapath)
+    small = small.join(df_feat, on=["photo_id"], how="left")
+    small.loc[small["watch_ratio"] > 5, "watch_ratio"] = 5
+    x_columns = feature_columns(small["user_id"].max() + 1, small["photo_id"].max() + 1, df_feat.max().max() + 1, entity_dim, feature_dim)
+    with open(os.path.join(datapath, "photo_mean_duration.json")) as fh:
+        mean_dur = {int(k): v for k, v in json.load(fh).items()}
+    dataset_val = StaticDataset(x_columns, [DenseFeat("y", 1)], num_workers=4)
+    dataset_val.compile_dataset(small[USER_COLS + ITEM_COLS], small[["watch_ratio"]])
+    dataset_val.set_env_items(small, df_feat, mean_dur)
+    return dataset_val
+
+
 def load_dataset_kuaishou(tau, entity_dim, feature_dim, MODEL_SAVE_PATH, datapath=None):
     """-> (StaticDataset, x_columns, y_columns, ab_columns) exactly as the reference assembles them."""
     datapath = DATAPATH if datapath is None else datapath
@@ -39,10 +63,7 @@ def load_dataset_kuaishou(tau, entity_dim, feature_dim, MODEL_SAVE_PATH, datapat
     big.loc[big["watch_ratio"] > 5, "watch_ratio"] = 5
 
     n_user, n_photo = big["user_id"].max() + 1, big["photo_id"].max() + 1
-    x_columns = [SparseFeatP("user_id", n_user, embedding_dim=entity_dim), SparseFeatP("photo_id", n_photo, embedding_dim=entity_dim)]
-    x_columns += [SparseFeatP(f"feat{i}", df_feat.max().max() + 1, embedding_dim=feature_dim, embedding_name="feat", padding_idx=0)
-                  for i in range(4)]
-    x_columns += [DenseFeat("photo_duration", 1)]
+    x_columns = feature_columns(n_user, n_photo, df_feat.max().max() + 1, entity_dim, feature_dim)
     ab_columns = [SparseFeatP("alpha_u", n_user, embedding_dim=1), SparseFeatP("beta_i", n_photo, embedding_dim=1)]
     y_columns = [DenseFeat("y", 1)]
 

@@ -799,7 +799,38 @@ def gen_userdata():
     print("userdata.npz: rows", len(big), "x", out["x_tau0"].shape, "score max", out["score_tau800"].max(), "names", list(out["x_col_names"]))
 
 
-FAMILIES = {"userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+def gen_userval():
+    """load_static_validate_data_kuaishou + StaticDataset.set_env_items (reference core/util.py:81-133, core/static_dataset.py:19-26)
+    on tiny files: the validation arrays and the per-item table of the evaluation environment."""
+    import tempfile
+    import core.util as cu
+    rng = np.random.RandomState(29)
+    n_users, n_items = 20, 90
+    list_feat = [sorted(rng.choice(31, size=rng.randint(1, 5), replace=False).tolist()) for _ in range(n_items)]
+    durations = rng.uniform(2, 60, n_items)
+    users = rng.choice(n_users, 12, replace=False); photos = rng.choice(n_items, 25, replace=False)
+    uu, pp = np.meshgrid(users, photos, indexing="ij")
+    order = rng.permutation(uu.size)
+    log_user, log_photo = uu.ravel()[order], pp.ravel()[order]
+    log_ratio = rng.gamma(1.5, 1.4, uu.size)
+    log_dur = durations[log_photo] * 1000.0 * rng.uniform(0.9, 1.1, uu.size)
+    with tempfile.TemporaryDirectory() as root:
+        write_kuairec_files(root, log_user, log_photo, log_ratio, list_feat, durations)
+        df = pd.read_csv(os.path.join(root, "small_matrix.csv"))
+        df["photo_duration"] = log_dur
+        df.to_csv(os.path.join(root, "small_matrix.csv"), index=False)
+        ds = cu.load_static_validate_data_kuaishou(8, 8, root)
+    out = dict(log_user=log_user, log_photo=log_photo, log_ratio=log_ratio, log_dur=log_dur, durations=durations,
+               list_feat=np.array([f + [-1] * (4 - len(f)) for f in list_feat], np.int64),
+               x=np.asarray(ds.x_numpy, np.float64), y=np.asarray(ds.y_numpy, np.float64),
+               env_index=ds.df_photo_env.index.to_numpy(), env_columns=np.array(list(ds.df_photo_env.columns)),
+               env_values=ds.df_photo_env.to_numpy(dtype=np.float64),
+               x_col_vocab=np.array([getattr(c, "vocabulary_size", 0) for c in ds.x_columns], np.int64))
+    np.savez_compressed(os.path.join(GOLDEN, "userval.npz"), **out)
+    print("userval.npz: x", out["x"].shape, "env table", out["env_values"].shape, list(out["env_columns"]))
+
+
+FAMILIES = {"userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

@@ -15,8 +15,8 @@ def write_files(root, z):
     os.makedirs(root, exist_ok=True)
     pd.DataFrame({"user_id": z["big_user"], "photo_id": z["big_photo"], "timestamp": z["big_ts"], "watch_ratio": z["big_ratio"],
                   "photo_duration": z["big_dur"]}).to_csv(os.path.join(root, "big_matrix.csv"), index=False)
-    pd.DataFrame({"user_id": z["small_user"], "photo_id": z["small_photo"], "play_duration": 1, "watch_ratio": 1.0}).to_csv(
-        os.path.join(root, "small_matrix.csv"), index=False)
+    pd.DataFrame({"user_id": z["small_user"], "photo_id": z["small_photo"], "play_duration": 1, "watch_ratio": 1.0,
+                  "photo_duration": z["durations"][z["small_photo"]] * 1000.0}).to_csv(os.path.join(root, "small_matrix.csv"), index=False)
     feats = [[int(c) for c in row if c >= 0] for row in z["list_feat"]]
     with open(os.path.join(root, "item_categories.json"), "w") as fh:
         json.dump({str(i): {"feature_index": f} for i, f in enumerate(feats)}, fh)
