@@ -7,6 +7,8 @@ CIRS-RL-kuaishou.py builds (reference :141-292) and of onpolicy_trainer's inner 
 import math
 from typing import Dict, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -76,6 +78,7 @@ class CirsEngine:
         self.n_items = I
         self.world, self.rank, self.group = world_size, rank, dist_group
         self.force_gather = force_gather  # exercise the packed all-gather path even with one rank (tests)
+        self.force_dp = force_gather and os.environ.get("CIRS_FORCE_DP", "0") == "1"   # + the data-parallel learner with one rank (tests)
         # "dp": global minibatch = batch_size * world rows, sharded by rows, gradients all-reduced per minibatch;
         # "replicated": every rank runs the identical learner on the gathered buffer (no further communication)
         assert learner_mode in ("dp", "replicated")
@@ -167,7 +170,7 @@ class CirsEngine:
             # identical permutations on every rank (same generator seed, same device type): learners stay bit-identical
             ln._perm_gen.manual_seed((self.seed * 7919 + self.collect_count) & 0x7FFFFFFF)
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
-        if self.world > 1 and self.learner_mode == "dp":
+        if (self.world > 1 or self.force_dp) and self.learner_mode == "dp":
             return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms)
         losses = ln.learn(batch_size, repeat, perms=perms)
         self.tracker.backward(users, traj, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs,

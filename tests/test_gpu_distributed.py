@@ -104,3 +104,34 @@ def test_data_parallel_learner_equals_single_device_large_batch():
     np.testing.assert_allclose(ranks[0].params.cpu().numpy(), ref.params.cpu().numpy(), rtol=2e-4, atol=2e-6)
     dobs = sum(ln.dobs for ln in ranks)
     np.testing.assert_allclose(dobs.cpu().numpy(), ref.dobs.cpu().numpy(), rtol=2e-3, atol=1e-7)
+
+
+def test_data_parallel_path_over_rccl_with_one_rank(monkeypatch):
+    """The data-parallel learner (phase 1 -> all-reduce of the flat gradients -> phase 2, all-reduce of d loss/d obs and of the
+    tracker gradients) driven through a real NCCL/RCCL group of size 1: must track the single-rank learner (the two paths sum
+    gradient slabs in different launches, so float tolerance, not bits)."""
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        a = build(False)
+        monkeypatch.setenv("CIRS_FORCE_DP", "1")
+        b = build(True)
+        assert b.force_dp
+        users = torch.as_tensor(np.random.RandomState(1).randint(0, 120, 40))
+        for eng in (a, b):
+            eng.collect(users)
+        n = int(a.lengths.sum())
+        for k in range(2):
+            perms = [np.random.RandomState(3 + 2 * k + q).permutation(n) for q in range(2)]
+            la, na = a.update(16, 2, perms=perms)
+            lb, nb = b.update(16, 2, perms=perms)
+            assert na == nb == n
+            np.testing.assert_allclose(lb.cpu().numpy(), la.cpu().numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(b.policy_flat.cpu().numpy(), a.policy_flat.cpu().numpy(), rtol=1e-3, atol=2e-5)
+        # Adam turns round-off in near-zero gradients into O(lr) parameter differences: a handful of elements move by ~1e-4
+        np.testing.assert_allclose(b.tracker_flat.cpu().numpy(), a.tracker_flat.cpu().numpy(), rtol=1e-3, atol=3e-4)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
