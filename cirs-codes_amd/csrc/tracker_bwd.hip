@@ -295,6 +295,20 @@ __global__ __launch_bounds__(256) void scatter_keys_kernel(const int32_t* __rest
     rows[r] = r;
 }
 
+// Only the first row of an episode (the user slot) contributes to Emb_user: one (key, contribution) pair per env instead of one
+// per buffer row -> the sort of the user-embedding scatter handles n_env pairs.  Slot = env id, so pairs of one user stay in env
+// (= row) order.
+__global__ __launch_bounds__(256) void compact_user_rows(const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t,
+                                                         const int32_t* __restrict__ users, const float* __restrict__ CU, int R,
+                                                         int32_t* __restrict__ keys_c, float* __restrict__ contrib_c) {
+    const int d = threadIdx.x & 31;
+    const int r = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (r >= R || row_t[r] != 0) return;
+    const int b = row_env[r];
+    contrib_c[(size_t)b * tD + d] = CU[(size_t)r * tD + d];
+    if (d == 0) keys_c[b] = users[b];
+}
+
 // Ordered segment sums over the (key, row) pairs sorted by key, in two levels so that a very popular key (thousands of rows
 // once the policy concentrates on few items) is not one sequential chain:
 //   sub-runs   a sub-run starts at every segment head and at every multiple of 64 in the sorted order and ends at the next
@@ -528,7 +542,13 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     int32_t* key_item = (int32_t*)sc.RS2[0];
     hipLaunchKernelGGL(slot_bwd, dim3(cdiv(R, 4)), dim3(256), 0, s, *w, dH, users, act, rew, row_env, row_t, R, B, DU, EU, DPRE,
                        sc.GIN, CU, CI, key_user, key_item);
-    if (int rc = emb_scatter_sorted(key_user, CU, R, cfg->n_users, grads->emb_user, sc.sort, emb_sort_bytes(R), s)) return rc;
+    {   // user embeddings: one pair per env (T0 and T2 = [R, 32] each, R >= B, are free after slot_bwd)
+        int32_t* keys_c = (int32_t*)sc.T0;
+        float* contrib_c = sc.T2;
+        CIRS_HIP(hipMemsetAsync(keys_c, 0xFF, sizeof(int32_t) * (size_t)B, s));   // -1: env without rows in this call
+        hipLaunchKernelGGL(compact_user_rows, dim3(cdiv(R, 8)), dim3(256), 0, s, row_env, row_t, users, (const float*)CU, R, keys_c, contrib_c);
+        if (int rc = emb_scatter_sorted(keys_c, contrib_c, B, cfg->n_users, grads->emb_user, sc.sort, emb_sort_bytes(R), s)) return rc;
+    }
     if (int rc = emb_scatter_sorted(key_item, CI, R, cfg->n_items, grads->emb_item, sc.sort, emb_sort_bytes(R), s)) return rc;
     DW(DU, EU, tD, tD, grads->ffn_user_w, grads->ffn_user_b);
     DW(DPRE, sc.GIN, tD, tD + 1, grads->gate_w, grads->gate_b);
