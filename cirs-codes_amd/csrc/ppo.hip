@@ -53,27 +53,37 @@ __global__ __launch_bounds__(256) void gae_kernel(cirs_ppo_cfg cfg, cirs_traj tr
     const double scale = cfg.rew_norm ? sqrt(rms_state[1] + 1e-8) : 1.0;  // a2c.py:95-97, pg.py:60 (_eps = 1e-8)
     const double gamma = (double)cfg.gamma, gl = (double)cfg.gamma * (double)cfg.gae_lambda;
     double gae = 0.0;
-    for (int t = L - 1; t >= 0; --t) {
+    // the recurrence runs backwards over the episode; the loads of step t-1 are issued before step t is computed (they do not depend
+    // on it), so one memory latency per step is not on the chain
+    struct StepIn { bool done; float value, logp; double rew; long act; };
+    auto load_step = [&](int t) {
         const size_t ti = (size_t)t * B + b;
-        const bool done = traj.done[ti] != 0;
-        const double v_s = (double)traj.value[ti] * scale;
+        return StepIn{traj.done[ti] != 0, traj.value[ti], traj.logp[ti], traj.rew[ti], (long)traj.act[ti]};
+    };
+    StepIn cur = L > 0 ? load_step(L - 1) : StepIn{};
+    float value_next = 0.f;   // V(s_{t+1}) as recorded at step t+1
+    for (int t = L - 1; t >= 0; --t) {
+        const StepIn nxt = t > 0 ? load_step(t - 1) : StepIn{};
+        const bool done = cur.done;
+        const double v_s = (double)cur.value * scale;
         // value_mask (base.py:264): V(s') is zeroed on done; otherwise V(s_{t+1}) recorded at the next step
-        const double v_ns = (done || t + 1 >= L) ? 0.0 : (double)traj.value[(size_t)(t + 1) * B + b] * scale;
+        const double v_ns = (done || t + 1 >= L) ? 0.0 : (double)value_next * scale;
         const double end_flag = (done || t == L - 1) ? 1.0 : 0.0;  // done OR unfinished_index (base.py:307-308)
-        const double delta = traj.rew[ti] + v_ns * gamma - v_s;
+        const double delta = cur.rew + v_ns * gamma - v_s;
         gae = delta + (1.0 - end_flag) * gl * gae;
         const int row = off + t;
         out.adv[row] = (float)gae;
         unnorm_ret[row] = gae + v_s;
-        out.v_s[row] = traj.value[ti];
-        out.logp_old[row] = traj.logp[ti];
-        out.act[row] = (int32_t)traj.act[ti];
+        out.v_s[row] = cur.value;
+        out.logp_old[row] = cur.logp;
+        out.act[row] = (int32_t)cur.act;
         out.row_env[row] = b;
         out.row_t[row] = t;
+        value_next = cur.value;
+        cur = nxt;
     }
 }
 
-// obs rows of the time-major trajectory -> buffer order, one thread per (row, feature)
 __global__ __launch_bounds__(256) void compact_obs_kernel(cirs_traj traj, cirs_ppo_batch out, int N, int B, int S) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= (long)N * S) return;
