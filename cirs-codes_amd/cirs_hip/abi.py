@@ -155,6 +155,7 @@ SIGNATURES = {
     "cirs_rollout_static": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState), _P, C.c_int64, _P, C.POINTER(Traj),
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_uint32, _P, C.c_int32, _P, _P]),
     "cirs_hash_ids": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "cirs_random_permutation": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),
     "cirs_prof_start": (C.c_int, [C.c_int32, C.c_int32]),
     "cirs_prof_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "cirs_eval_coverage": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P]),

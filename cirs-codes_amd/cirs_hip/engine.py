@@ -167,8 +167,8 @@ class CirsEngine:
         ln = self.learner
         n = ln.prepare(traj, lens, lens_dev=lens_d)
         if perms is None and self.world > 1:
-            # identical permutations on every rank (same generator seed, same device type): learners stay bit-identical
-            ln._perm_gen.manual_seed((self.seed * 7919 + self.collect_count) & 0x7FFFFFFF)
+            # identical permutations on every rank (same key): learners stay bit-identical
+            ln.perm_seed, ln.perm_tag = self.seed * 7919 + 1, self.collect_count * 64
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
         if (self.world > 1 or self.force_dp) and self.learner_mode == "dp":
             return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms)

@@ -61,8 +61,7 @@ class DeviceLearner:
         self.adam_m = torch.zeros_like(flat_params)
         self.adam_v = torch.zeros_like(flat_params)
         self.opt_step = 0
-        self._perm_gen = torch.Generator(device=self.device)
-        self._perm_gen.manual_seed(20230)
+        self.perm_seed, self.perm_tag = 20230, 0   # key of the minibatch shuffles (see _perms_on_device)
         self.n_env, self.max_turn, self.S = n_env, max_turn, dim_state
         self.rms_state = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64, device=self.device)  # RunningMeanStd()
         self._ws = None
@@ -140,14 +139,20 @@ class DeviceLearner:
         self.opt_step += 1
 
     def _perms_on_device(self, n, repeat, perms):
-        """[repeat, n] int32 on the device: the recorded permutations (parity tests) or draws of the seeded device generator.
-        Batch.split(shuffle=True) draws np.random.permutation(n) on the host (tianshou/data/batch.py); drawing on the device
-        keeps the distribution and removes ~0.4 ms of host work + upload per update from the critical path (the host has
-        just synchronised on the episode lengths and has nothing queued).  Ranks of a data-parallel learner seed the
-        generator identically (CirsEngine.update), so they draw the same permutations."""
+        """[repeat, n] int32 on the device: the recorded permutations (parity tests) or keyed pseudo-random permutations.
+        Batch.split(shuffle=True) draws np.random.permutation(n) on the host (tianshou/data/batch.py).  Here every repeat is ONE
+        launch of cirs_random_permutation (Feistel network, one thread per index, key = (perm_seed, running tag)): no host work,
+        no upload and none of the sort / duplicate-handling launches of torch.randperm, whose host-side gaps cost ~0.35 ms of GPU
+        idle per update.  Ranks of a data-parallel learner set the same (perm_seed, tag) (CirsEngine.update), so they shuffle
+        identically."""
         if perms is not None:
             return torch.as_tensor(np.stack([np.asarray(perms[rep]).astype(np.int32) for rep in range(repeat)])).to(self.device)
-        return torch.stack([torch.randperm(n, device=self.device, generator=self._perm_gen) for _ in range(repeat)]).to(torch.int32)
+        out = torch.empty((repeat, n), dtype=torch.int32, device=self.device)
+        for rep in range(repeat):
+            abi.check(self._lib.cirs_random_permutation(int(n), int(self.perm_seed), int(self.perm_tag), out[rep].data_ptr(), self._stream()),
+                      "cirs_random_permutation")
+            self.perm_tag += 1
+        return out
 
     def learn_dp(self, batch_size, repeat, perms, rank, world, all_reduce, want_tracker_grad=True):
         """Data-parallel learn(): global minibatches of batch_size*world rows, rows rank::world of each belong to this

@@ -17,7 +17,45 @@ __global__ __launch_bounds__(256) void hash_ids_kernel(const int64_t* __restrict
     if (i < n) out[i] = (int64_t)(splitmix64((uint64_t)ids[i]) % n_buckets);
 }
 
+// ---- pseudo-random permutation of [0, n) without a sort ------------------------------------------------------------
+// out[i] = P(i) where P is a keyed bijection: a 6-round balanced Feistel network on 2h bits (2^(2h) >= n, < 4n) with a
+// splitmix64 round function, restricted to [0, n) by cycle walking (re-encrypt while the value is >= n; <= 4 expected rounds).
+// One thread per element, no host round trip: replaces np.random.permutation / torch.randperm for the minibatch shuffle.
+__host__ __device__ __forceinline__ uint64_t feistel_encrypt(uint64_t x, int h, uint64_t key) {
+    const uint64_t mask = (1ull << h) - 1;
+    uint64_t l = x >> h, r = x & mask;
+#pragma unroll
+    for (int round = 0; round < 6; ++round) {
+        const uint64_t f = splitmix64(r ^ (key + 0x632BE59BD9B4E019ull * (uint64_t)(round + 1))) & mask;
+        const uint64_t nl = r;
+        r = l ^ f;
+        l = nl;
+    }
+    return (l << h) | r;
+}
+__host__ __device__ __forceinline__ int64_t permute_index(int64_t i, int64_t n, int h, uint64_t key) {
+    uint64_t x = (uint64_t)i;
+    do { x = feistel_encrypt(x, h, key); } while (x >= (uint64_t)n);
+    return (int64_t)x;
+}
+__global__ __launch_bounds__(256) void permutation_kernel(long n, int h, uint64_t key, int32_t* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)permute_index(i, n, h, key);
+}
+
 }  // namespace cirs
+
+extern "C" int cirs_random_permutation(int64_t n, uint64_t seed, uint64_t tag, int32_t* out, void* stream) {
+    using namespace cirs;
+    if (n <= 0) return CIRS_OK;
+    CIRS_REQUIRE(out && n <= 0x7FFFFFFF, "bad arguments");
+    int h = 1;
+    while ((1ull << (2 * h)) < (uint64_t)n) ++h;
+    const uint64_t key = splitmix64(seed ^ splitmix64(tag));
+    hipLaunchKernelGGL(permutation_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (long)n, h, key, out);
+    CIRS_CHECK_LAUNCH("permutation_kernel");
+    return CIRS_OK;
+}
 
 extern "C" int cirs_hash_ids(const int64_t* ids, int64_t n, int64_t n_buckets, int64_t* out, void* stream) {
     using namespace cirs;

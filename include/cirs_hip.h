@@ -462,6 +462,12 @@ int cirs_rollout_static(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
  * for use_hash): the mapping is this build's own and is restated bit for bit by the oracle. */
 int cirs_hash_ids(const int64_t* ids, int64_t n, int64_t n_buckets, int64_t* out, void* stream);
 
+/* ---- minibatch shuffle (Batch.split(shuffle=True): np.random.permutation(n), tianshou/data/batch.py:734-744) --------------
+ * out[i] = P(i), a keyed pseudo-random permutation of [0, n): 6-round Feistel network over splitmix64 with cycle walking, one
+ * thread per element, no sort and no host round trip.  Same (seed, tag) -> same permutation (ranks of a data-parallel learner
+ * pass the same pair).  The oracle restates it bit for bit. */
+int cirs_random_permutation(int64_t n, uint64_t seed, uint64_t tag, int32_t* out, void* stream);
+
 /* ---- per-kernel timing hook (measurement only; no reference counterpart) ----------------------------------------------
  * cirs_prof_start arms HIP-event pairs around the next `max_samples` launches of one named kernel, recorded on the stream
  * the kernel is launched on; cirs_prof_stop waits for them and returns the summed duration and the sample count.

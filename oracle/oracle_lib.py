@@ -53,6 +53,8 @@ def lib():
         h.oracle_exposure_history.argtypes = [_P, _P, _P, C.c_int64, _P, _P, C.c_int32, C.c_double, _P]
         h.oracle_find_negative.restype = C.c_int
         h.oracle_find_negative.argtypes = [_P, _P, C.c_int64, _P, _P, C.c_int32, C.c_int64, _P]
+        h.oracle_random_permutation.restype = C.c_int
+        h.oracle_random_permutation.argtypes = [C.c_int64, C.c_uint64, C.c_uint64, _P]
         h.oracle_hash_ids.restype = C.c_int
         h.oracle_hash_ids.argtypes = [_P, C.c_int64, C.c_int64, _P]
         h.oracle_eval_coverage.restype = C.c_int

@@ -98,3 +98,18 @@ def test_minibatch_schedule_matches_batch_split_merge_last():
     assert minibatch_slices(10, 16) == [(0, 10)]
     assert minibatch_slices(17, 16) == [(0, 17)]
     assert minibatch_slices(33, 16) == [(0, 16), (16, 33)]
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 1000, 28673, 300001])
+def test_device_permutation_is_bit_exact_vs_oracle(n):
+    """cirs_random_permutation (the minibatch shuffle) vs its C restatement, and it is a permutation."""
+    import ctypes as C
+    import oracle_lib
+    from cirs_hip import abi
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    abi.check(abi.lib().cirs_random_permutation(n, 20230, 11, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "perm")
+    got = out.cpu().numpy()
+    want = np.empty(n, np.int32)
+    assert oracle_lib.lib().oracle_random_permutation(n, 20230, 11, want.ctypes.data_as(C.c_void_p)) == 0
+    assert np.array_equal(got, want)
+    assert np.array_equal(np.sort(got), np.arange(n))
