@@ -242,8 +242,8 @@ def main():
     t_collect = 0.0
     for _ in range(args.steps):
         eng.collect()
-        steps_local += int(eng.lengths.sum())  # lengths are read back by update() anyway
         losses, n = eng.update(batch_size=1024, repeat=2)
+        steps_local += n   # rows of the update = env-steps of this collect over ALL ranks (update() reads the lengths back once)
         mb_steps += losses.shape[0]
     barrier()
     elapsed = time.perf_counter() - t0
@@ -251,11 +251,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-        c = torch.tensor([steps_local], dtype=torch.float64, device=device)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_steps = float(c)
-    else:
-        total_steps = float(steps_local)
+    total_steps = float(steps_local)
 
     # split (untimed extra pass, same state): rollout-only and update-only rates
     barrier()
