@@ -15,6 +15,28 @@ from cirs_hip.rollout import DeviceRollout
 from tianshou.data import Batch, VectorReplayBuffer
 
 
+def result_from_trajectory(traj, lengths: np.ndarray, offsets: np.ndarray) -> Dict[str, Any]:
+    """Collector.collect's result dict (reference core/collector.py:343-362) from a finished time-major trajectory.
+    `rews / lens / idxs` are in the reference's order — episodes as they complete: by final step, env id ascending inside a
+    step (:280-288) — and every episode reward is the running float64 sum in step order (base.py:171 `self._ep_rew += rew`),
+    so the dict is bit-identical to the reference's for the same transitions."""
+    lengths = np.asarray(lengths, dtype=int)
+    rew = traj.rew.cpu().numpy()
+    ep_rew = np.zeros(len(lengths), dtype=np.float64)
+    for t in range(int(lengths.max(initial=0))):
+        live = lengths > t
+        ep_rew[live] += rew[t, :len(lengths)][live]
+    order = np.argsort(lengths, kind="stable")
+    rews, lens, idxs = ep_rew[order], lengths[order], np.asarray(offsets)[order]
+    n_ep = len(lengths)
+    if n_ep > 0:
+        rew_mean, rew_std, len_mean, len_std = rews.mean(), rews.std(), lens.mean(), lens.std()
+    else:
+        rew_mean = rew_std = len_mean = len_std = 0
+    return {"n/ep": n_ep, "n/st": int(lengths.sum()), "rews": rews, "lens": lens, "idxs": idxs, "rew": rew_mean, "len": len_mean,
+            "rew_std": rew_std, "len_std": len_std}
+
+
 class Collector:
     def __init__(self, policy, env, buffer: Optional[VectorReplayBuffer] = None, preprocess_fn: Optional[Callable[..., Any]] = None,
                  exploration_noise: bool = False, remove_recommended_ids=False, force_length=0):
@@ -84,11 +106,8 @@ class Collector:
         self._collect_count += 1
         self.buffer.fill_from_trajectory(ro.traj, lengths)
         self.buffer._rollout, self.buffer._users = ro, users_t  # policy.update() consumes them with the buffer
-        tr = ro.traj
-        ep_rew = (tr.rew * (tr.act >= 0)).sum(0).cpu().numpy()
-        step_count, episode_count = int(lengths.sum()), self.env_num
-        self.collect_step += step_count
-        self.collect_episode += episode_count
+        res = result_from_trajectory(ro.traj, lengths, self.buffer._offset[:self.env_num])
+        self.collect_step += res["n/st"]
+        self.collect_episode += res["n/ep"]
         self.collect_time += max(time.time() - start, 1e-9)
-        return {"n/ep": episode_count, "n/st": step_count, "rews": ep_rew, "lens": lengths, "idxs": self.buffer._offset.copy(),
-                "rew": float(ep_rew.mean()), "len": float(lengths.mean()), "rew_std": float(ep_rew.std()), "len_std": float(lengths.std())}
+        return res

@@ -95,10 +95,46 @@ class Batch:
             yield self[indices[idx:idx + size]]
 
 
+def _stack_value(v, n):
+    """Zero storage with n slots for values shaped like one entry of `v` (Batch -> Batch of storages)."""
+    if isinstance(v, Batch):
+        return Batch({k: _stack_value(x, n) for k, x in v.items()})
+    if isinstance(v, torch.Tensor):
+        return torch.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+    v = np.asanyarray(v)
+    return np.zeros((n,) + v.shape[1:], dtype=v.dtype)
+
+
+def _store(dst: "Batch", ptrs, src: "Batch"):
+    for k, v in src.items():
+        if isinstance(v, Batch):
+            if not len(v.keys()):
+                dst.__dict__.setdefault(k, Batch())
+                continue
+            if k not in dst or not isinstance(dst[k], Batch) or not len(dst[k].keys()):
+                dst.__dict__[k] = Batch()
+            _store(dst[k], ptrs, v)
+            continue
+        if k not in dst:
+            dst.__dict__[k] = _stack_value(v, _store.maxsize)
+        if isinstance(dst[k], torch.Tensor):
+            dst[k][torch.as_tensor(ptrs, device=dst[k].device)] = torch.as_tensor(v).to(dst[k])
+        else:
+            dst[k][ptrs] = np.asanyarray(v)
+
+
 class VectorReplayBuffer:
-    """buffer_num ring buffers of equal size (vecbuf.py:26-30).  `fill_from_trajectory` replaces the per-step
-    ReplayBufferManager.add (manager.py:91-142) for a finished collect: env b's transitions land at
-    _offset[b] .. _offset[b]+len_b-1, exactly where the reference's sequence of adds would have put them."""
+    """buffer_num ring buffers of equal size behind one index space (reference vecbuf.py:26-30, manager.py:16-232,
+    base.py:116-183): sub-buffer b owns rows [b*size, (b+1)*size).  Two ways in:
+      * `add(batch, buffer_ids)` — the per-step protocol of Collector (manager.py:91-142): ring write per sub-buffer, episode
+        reward / length / start-index accounting, returns (ptr, ep_rew, ep_len, ep_idx);
+      * `fill_from_trajectory(traj, lens)` — one shot from the device trajectory of cirs_rollout_steps: env b's transitions
+        land at _offset[b] .. _offset[b]+len_b-1, exactly where that sequence of adds would have put them (host copies are
+        made lazily on attribute access).
+    prev / next / unfinished_index follow manager.py:194-232 and base.py:116-141 (ring arithmetic per sub-buffer, vectorised
+    over the query instead of a loop over sub-buffers)."""
+
+    _reserved_keys = ("obs", "act", "rew", "done", "obs_next", "info", "policy")
 
     def __init__(self, total_size: int, buffer_num: int, **kwargs):
         assert buffer_num > 0
@@ -106,20 +142,62 @@ class VectorReplayBuffer:
         self.size = int(np.ceil(total_size / buffer_num))
         self.maxsize = self.size * buffer_num
         self._offset = np.arange(buffer_num) * self.size
-        self._lengths = np.zeros(buffer_num, dtype=int)
+        self.reset()
+
+    def reset(self, keep_statistics: bool = False):
+        n = self.buffer_num
+        self._lengths = np.zeros(n, dtype=int)
+        self._write = np.zeros(n, dtype=int)          # next write position inside each sub-buffer (base.py: self._index)
         self.last_index = self._offset.copy()
+        if not keep_statistics:
+            self._ep_rew = np.zeros(n, dtype=float)
+            self._ep_len = np.zeros(n, dtype=int)
+            self._ep_idx = np.zeros(n, dtype=int)     # sub-buffer-local start of the running episode
         self._meta = Batch()
         self._traj = None
+
+    # ---- per-step protocol -------------------------------------------------------------------------------------
+    def add(self, batch: Batch, buffer_ids=None):
+        """ReplayBufferManager.add (manager.py:91-142) + ReplayBuffer._add_index (base.py:163-183)."""
+        assert self._traj is None, "this buffer was filled from a device trajectory; add() needs a fresh buffer"
+        b = Batch({k: batch[k] for k in self._reserved_keys if k in batch})
+        assert {"obs", "act", "rew", "done"}.issubset(b.keys())
+        ids = np.arange(self.buffer_num) if buffer_ids is None else np.asarray(buffer_ids, dtype=int)
+        rew = np.asarray(to_numpy(b.rew), dtype=float).reshape(-1)
+        done = np.asarray(to_numpy(b.done)).astype(bool).reshape(-1)
+        assert len(ids) == len(rew) == len(done)
+        ptrs = np.empty(len(ids), dtype=int); ep_rews = np.zeros(len(ids)); ep_lens = np.zeros(len(ids), dtype=int)
+        ep_idxs = np.empty(len(ids), dtype=int)
+        for k, bid in enumerate(ids):       # sequential on purpose: the same sub-buffer may appear twice in buffer_ids
+            ptr = self._write[bid]
+            ptrs[k] = ptr + self._offset[bid]
+            self.last_index[bid] = ptrs[k]
+            self._lengths[bid] = min(self._lengths[bid] + 1, self.size)
+            self._write[bid] = (ptr + 1) % self.size
+            self._ep_rew[bid] += rew[k]
+            self._ep_len[bid] += 1
+            ep_idxs[k] = self._ep_idx[bid] + self._offset[bid]
+            if done[k]:
+                ep_rews[k], ep_lens[k] = self._ep_rew[bid], self._ep_len[bid]
+                self._ep_rew[bid], self._ep_len[bid], self._ep_idx[bid] = 0.0, 0, self._write[bid]
+        b.rew, b.done = rew, done
+        _store.maxsize = self.maxsize
+        _store(self._meta, ptrs, b)
+        return ptrs, ep_rews, ep_lens, ep_idxs
 
     # ---- filled from the device ------------------------------------------------------------------------------
     def fill_from_trajectory(self, traj, lens: np.ndarray, device_rows=None):
         """traj: cirs_hip.rollout.Trajectory (time-major, device).  Host copies are made lazily on attribute access."""
         lens = np.asarray(lens, dtype=int)
         assert lens.max(initial=0) <= self.size, "episode longer than the per-env buffer"
-        self._traj, self._lengths = traj, lens
-        self.last_index = self._offset + np.maximum(lens - 1, 0)
-        self._meta = Batch()
-        self._rows_env = np.repeat(np.arange(self.buffer_num), lens)
+        self.reset()
+        self._traj = traj
+        self._lengths[:len(lens)] = lens
+        self._write = self._lengths % self.size
+        self._ep_idx = self._write.copy()
+        self.last_index = self._offset + np.maximum(self._lengths - 1, 0)
+        nb = len(lens)
+        self._rows_env = np.repeat(np.arange(nb), lens)
         self._rows_t = np.concatenate([np.arange(l) for l in lens]) if lens.sum() else np.zeros(0, int)
         self._index = self._offset[self._rows_env] + self._rows_t
 
@@ -160,32 +238,54 @@ class VectorReplayBuffer:
         return self._meta[index]
 
     def sample_index(self, batch_size):
-        assert batch_size == 0, "on-policy use: the whole buffer (sample(0))"
-        return self._index.copy() if self._traj is not None else np.array([], int)
+        """manager.py:144-172; on-policy use is sample(0) = every stored row, sub-buffer by sub-buffer, oldest first."""
+        if batch_size < 0:
+            return np.array([], int)
+        parts = []
+        for b in range(self.buffer_num):      # base.py:185-205 for batch_size == 0: arange(write, size) ++ arange(write)
+            L, w = self._lengths[b], self._write[b]
+            loc = np.concatenate([np.arange(w, L), np.arange(w)]) if L == self.size else np.arange(L)
+            parts.append(loc + self._offset[b])
+        allidx = np.concatenate(parts) if parts else np.array([], int)
+        if batch_size == 0:
+            return allidx
+        return np.random.choice(allidx, batch_size)
 
     def sample(self, batch_size):
         idx = self.sample_index(batch_size)
         return self[idx], idx
 
-    # ring-buffer neighbours (manager.py:194-232) for a buffer that has not wrapped
+    # ---- ring-buffer neighbours (manager.py:194-232) ----------------------------------------------------------------
+    def _locate(self, index):
+        scalar = not isinstance(index, (list, np.ndarray))
+        index = np.atleast_1d(np.asarray(index, dtype=int)) % self.maxsize
+        b = index // self.size
+        return scalar, index, self._offset[b], np.maximum(1, self._lengths[b]), self.last_index[b]
+
     def prev(self, index):
-        index = np.asarray(index)
-        b = np.minimum(index // self.size, self.buffer_num - 1)
-        start = self._offset[b]
-        p = np.where(index > start, index - 1, index)
+        scalar, index, start, cur_len, last = self._locate(index)
         self._materialise()
-        return np.where(self._meta.done[p] & (p != index), index, p)
+        done = self._meta.done if "done" in self._meta else np.zeros(self.maxsize, bool)
+        sub = (index - start - 1) % cur_len
+        end_flag = done[sub + start] | (sub + start == last)
+        out = (sub + end_flag) % cur_len + start
+        return out[0] if scalar else out
 
     def next(self, index):
-        index = np.asarray(index)
+        scalar, index, start, cur_len, last = self._locate(index)
         self._materialise()
-        end = np.isin(index, self.last_index) | self._meta.done[index]
-        return np.where(end, index, index + 1)
+        done = self._meta.done if "done" in self._meta else np.zeros(self.maxsize, bool)
+        end_flag = done[index] | (index == last)
+        out = (index - start + 1 - end_flag) % cur_len + start
+        return out[0] if scalar else out
 
     def unfinished_index(self):
+        """base.py:116-119 per sub-buffer: the newest row unless it closed an episode."""
         self._materialise()
-        li = self.last_index[self._lengths > 0]
-        return li[~self._meta.done[li]]
+        has = self._lengths > 0
+        last = (self._write - 1) % np.maximum(1, self._lengths) + self._offset
+        done = self._meta.done if "done" in self._meta else np.zeros(self.maxsize, bool)
+        return last[has & ~done[last]]
 
 
 ReplayBuffer = VectorReplayBuffer  # only the vector flavour is used by CIRS

@@ -313,45 +313,64 @@ def gen_learn():
     train_envs = DummyVectorEnv([lambda: gym.make("SimulatedEnv-v0") for _ in range(B)])
     collector = Collector(policy, train_envs, VectorReplayBuffer(B * T, B), preprocess_fn=st.build_state)
     policy.train()
-    random.seed(321)
-    res = collector.collect(n_episode=B)
-    buf = collector.buffer
-    users = np.array([int(w.env.cur_user[0]) for w in train_envs.workers])
-    lens = np.array([len(b_) for b_ in buf.buffers])
-    acts = np.full((B, T), -1, np.int64); rews = np.zeros((B, T)); dones = np.zeros((B, T), bool)
-    obs = np.zeros((B, T + 1, 20), np.float32)
-    for b in range(B):
-        sl = slice(buf._offset[b], buf._offset[b] + lens[b])
-        acts[b, :lens[b]] = buf.act[sl]; rews[b, :lens[b]] = buf.rew[sl]; dones[b, :lens[b]] = buf.done[sl]
-        obs[b, :lens[b]] = buf.obs[sl].detach().numpy()
-        obs[b, lens[b]] = buf.obs_next[sl][-1].detach().numpy()
-    pre = {"pol_" + k: v.detach().clone().numpy() for k, v in policy.state_dict().items()}
-    pre.update({"trk_" + k: v.detach().clone().numpy() for k, v in st.state_dict().items()})
-    # record permutations and the processed batch
-    perms = []
+    perms_all = []
     orig_perm = np.random.permutation
+
     def rec_perm(n):
-        r = orig_perm(n); perms.append(np.array(r)); return r
-    np.random.permutation = rec_perm
+        r = orig_perm(n); perms_all.append(np.array(r)); return r
+
     stash = {}
     orig_learn = policy.learn
+
     def learn_wrap(batch, **kw):
         stash.update(returns=batch.returns.detach().numpy().copy(), adv=batch.adv.detach().numpy().copy(),
                      v_s=batch.v_s.detach().numpy().copy(), logp_old=batch.logp_old.detach().numpy().copy(),
                      act=batch.act.detach().numpy().copy())
         return orig_learn(batch, **kw)
     policy.learn = learn_wrap
-    np.random.seed(77)
-    losses = policy.update(0, buf, batch_size=16, repeat=2)
-    np.random.permutation = orig_perm
-    post = {"post_pol_" + k: v.detach().numpy() for k, v in policy.state_dict().items()}
-    post.update({"post_trk_" + k: v.detach().numpy() for k, v in st.state_dict().items()})
-    out = dict(users=users, lens=lens, acts=acts, rews=rews, dones=dones, obs=obs,
-               n_perm=np.int64(len(perms)), ret_rms=np.array([policy.ret_rms.mean, policy.ret_rms.var, policy.ret_rms.count], dtype=np.float64),
-               loss=np.array(losses["loss"]), loss_clip=np.array(losses["loss/clip"]), loss_vf=np.array(losses["loss/vf"]),
-               loss_ent=np.array(losses["loss/ent"]),
-               hyper=np.array([0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, 16, 2]), dims=np.array([U, I, B, T]),
-               **{f"perm{i}": p_ for i, p_ in enumerate(perms)}, **{"b_" + k: v for k, v in stash.items()}, **pre, **post)
+
+    def one_round(user_seed, perm_seed):
+        """One Collector.collect(n_episode=B) + policy.update(...) of the reference -> recorded inputs / outputs."""
+        random.seed(user_seed)
+        res = collector.collect(n_episode=B)
+        buf = collector.buffer
+        users = np.array([int(w.env.cur_user[0]) for w in train_envs.workers])
+        lens = np.array([len(b_) for b_ in buf.buffers])
+        acts = np.full((B, T), -1, np.int64); rews = np.zeros((B, T)); dones = np.zeros((B, T), bool)
+        obs = np.zeros((B, T + 1, 20), np.float32)
+        for b in range(B):
+            sl = slice(buf._offset[b], buf._offset[b] + lens[b])
+            acts[b, :lens[b]] = buf.act[sl]; rews[b, :lens[b]] = buf.rew[sl]; dones[b, :lens[b]] = buf.done[sl]
+            obs[b, :lens[b]] = buf.obs[sl].detach().numpy()
+            obs[b, lens[b]] = buf.obs_next[sl][-1].detach().numpy()
+        pre = {"pol_" + k: v.detach().clone().numpy() for k, v in policy.state_dict().items()}
+        pre.update({"trk_" + k: v.detach().clone().numpy() for k, v in st.state_dict().items()})
+        perms_all.clear()
+        np.random.permutation = rec_perm
+        np.random.seed(perm_seed)
+        losses = policy.update(0, buf, batch_size=16, repeat=2)
+        np.random.permutation = orig_perm
+        perms = [p_.copy() for p_ in perms_all]
+        post = {"post_pol_" + k: v.detach().numpy().copy() for k, v in policy.state_dict().items()}
+        post.update({"post_trk_" + k: v.detach().numpy().copy() for k, v in st.state_dict().items()})
+        # Collector.collect's result dict (core/collector.py:343-362): arrays in episode-completion order
+        res_out = dict(res_rews=np.asarray(res["rews"], np.float64), res_lens=np.asarray(res["lens"], np.int64),
+                       res_idxs=np.asarray(res["idxs"], np.int64),
+                       res_scalars=np.array([res["n/ep"], res["n/st"], res["rew"], res["len"], res["rew_std"], res["len_std"]], np.float64))
+        out = dict(users=users, lens=lens, acts=acts, rews=rews, dones=dones, obs=obs,
+                   n_perm=np.int64(len(perms)), ret_rms=np.array([policy.ret_rms.mean, policy.ret_rms.var, policy.ret_rms.count], dtype=np.float64),
+                   loss=np.array(losses["loss"]), loss_clip=np.array(losses["loss/clip"]), loss_vf=np.array(losses["loss/vf"]),
+                   loss_ent=np.array(losses["loss/ent"]),
+                   **{f"perm{i}": p_ for i, p_ in enumerate(perms)}, **{"b_" + k: v.copy() for k, v in stash.items()}, **pre, **post, **res_out)
+        return out, lens, losses, perms
+
+    out, lens, losses, perms = one_round(321, 77)
+    out.update(hyper=np.array([0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, 16, 2]), dims=np.array([U, I, B, T]))
+    # SECOND consecutive collect + update on the same policy / optimisers / ret_rms: the tracker's second Adam step pins
+    # gradient MAGNITUDES (the first one is +-lr whatever the magnitude) and ret_rms / Adam-moment carry-over
+    out2, lens2, losses2, perms2 = one_round(654, 78)
+    out.update({"r2_" + k: v for k, v in out2.items() if not (k.startswith("pol_") or k.startswith("trk_"))})
+    print("learn.npz round 2: N =", int(lens2.sum()), "lens", lens2.tolist(), "minibatches", len(losses2["loss"]))
     np.savez_compressed(os.path.join(GOLDEN, "learn.npz"), **out)
     print("learn.npz: N =", int(lens.sum()), "lens", lens.tolist(), "minibatches", len(losses["loss"]), "losses", np.round(losses["loss"], 4),
           "perms", [len(p_) for p_ in perms])

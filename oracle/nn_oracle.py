@@ -166,9 +166,11 @@ def adam_substeps(p, g, state, lr, n_sub, b1=0.9, b2=0.999, eps=1e-8):
 
 
 def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam=0.95, eps_clip=0.2, vf_coef=0.25,
-               ent_coef=0.0, max_grad_norm=0.5, lr=1e-3, batch_size=16, repeat=2, ret_rms=None, nhead=4):
+               ent_coef=0.0, max_grad_norm=0.5, lr=1e-3, batch_size=16, repeat=2, ret_rms=None, nhead=4, opt_state=None):
     """Runs one policy.update on teacher-forced episodes.  tp/pp are dicts of torch fp32 tensors and are updated
-    IN PLACE.  Returns dict(losses..., returns, adv, v_s, logp_old, ret_rms)."""
+    IN PLACE.  Returns dict(losses..., returns, adv, v_s, logp_old, ret_rms, opt_state).  Pass the previous call's
+    `ret_rms` and `opt_state` (Adam moments + step counters of optim_RL / optim_state) to continue a run: the reference keeps
+    both optimisers and policy.ret_rms alive across policy.update calls (CIRS-RL-kuaishou.py:256-283)."""
     lens = np.asarray(lens)
     ret_rms = ret_rms or RunningMeanStd()
     tparams = {k: v for k, v in tp.items() if k != "pos_encoder.pe"}
@@ -198,8 +200,10 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
 
     names_trunk = ["w1", "b1", "w2", "b2"]
     names_head = ["wa", "ba", "wc", "bc"]
-    st_pol = {k: dict(step=0, m=torch.zeros_like(pp[k]), v=torch.zeros_like(pp[k])) for k in pp}
-    st_trk = {k: dict(step=0, m=torch.zeros_like(v), v=torch.zeros_like(v)) for k, v in tparams.items()}
+    if opt_state is None:
+        opt_state = dict(pol={k: dict(step=0, m=torch.zeros_like(pp[k]), v=torch.zeros_like(pp[k])) for k in pp},
+                         trk={k: dict(step=0, m=torch.zeros_like(v), v=torch.zeros_like(v)) for k, v in tparams.items()})
+    st_pol, st_trk = opt_state["pol"], opt_state["trk"]
     out = dict(loss=[], clip=[], vf=[], ent=[])
     pi = 0
     trk_grads = None
@@ -257,7 +261,7 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
             adam_substeps(v, trk_grads[k], st_trk[k], lr, 1)
     out.update(returns=returns.numpy(), adv=adv_t.numpy(), v_s=v_s_t.numpy(), logp_old=logp_old.numpy(), ret_rms=ret_rms,
                trk_grads={k: g.clone() for k, g in trk_grads.items()}, obs=obs.detach().numpy(),
-               dobs_rows=dobs_rows.numpy(), logits_old=None)
+               dobs_rows=dobs_rows.numpy(), logits_old=None, opt_state=opt_state)
     return out
 
 

@@ -84,9 +84,10 @@ def test_learner_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(dobs[tt, env], out["dobs_rows"], rtol=2e-3, atol=2e-6)
 
 
-@pytest.mark.parametrize("I,B,T,bs,ent_coef", [(3327, 64, 30, 1024, 0.0), (10728, 160, 30, 1024, 0.01)])
+@pytest.mark.parametrize("I,B,T,bs,ent_coef", [(3327, 64, 30, 1024, 0.0), (10728, 160, 30, 1024, 0.01), (10728, 1024, 30, 1024, 0.0)])
 def test_learner_vs_restatement_large(I, B, T, bs, ent_coef):
-    """BASELINE catalogue sizes (C2: 3327 items, C3: 10728 items), merged last minibatch > 1024 rows, non-zero entropy coef."""
+    """BASELINE catalogue sizes (C2: 3327 items, C3: 10728 items), merged last minibatch > 1024 rows, non-zero entropy coef;
+    last case = the benchmarked learner workload: 1024 envs, ~19-27 k rows, ~2 x 19+ minibatch steps, merged last minibatch."""
     import policycase
     from cirs_hip.rollout import Trajectory
     U = 300

@@ -38,7 +38,9 @@ def test_script_wiring_runs_and_matches_engine():
     assert len(buf) == res["n/st"]
     batch, idx = buf.sample(0)
     assert batch.obs.shape == (res["n/st"], 20) and batch.act.shape == (res["n/st"],)
-    assert bool(batch.done[np.cumsum(res["lens"]) - 1].all()) and int(batch.done.sum()) == 32
+    assert bool(batch.done[np.cumsum(buf._lengths) - 1].all()) and int(batch.done.sum()) == 32
+    assert np.array_equal(np.sort(res["lens"]), np.sort(buf._lengths)) and (np.diff(res["lens"]) >= 0).all()  # completion order
+    assert np.array_equal(buf._lengths[res["idxs"] // buf.size], res["lens"])
     n = res["n/st"]
     perms = [np.random.RandomState(9 + k).permutation(n) for k in range(2)]
     losses = policy.update(0, buf, batch_size=64, repeat=2, perms=perms)

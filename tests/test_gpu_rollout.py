@@ -65,6 +65,13 @@ def test_rollout_c2_shapes():
     check_rollout(1411, 3327, 64, 30, seed=7)
 
 
+def test_rollout_c3_shapes():
+    """The benchmarked workload (BASELINE configs[2]: 7176 x 10728, 1024 envs, T = 30): the fused 2-launch path
+    (TailFuse / TrunkFuse in tracker_step_kernel) against the oracle, stage by stage."""
+    lengths = check_rollout(7176, 10728, 1024, 30, seed=11)
+    assert lengths.min() < lengths.max()
+
+
 def test_rollout_early_stop_polling_is_equivalent():
     a = check_rollout(200, 400, 40, 30, seed=9, N=4, thr=2, sync_every=4)
     b = check_rollout(200, 400, 40, 30, seed=9, N=4, thr=2)

@@ -123,3 +123,42 @@ def test_full_update_matches_reference_tracker_params(golden_dir):
         assert np.abs(got - pre).max() <= 1e-3 * 1.01
         assert (full | still).mean() > 0.9, k
     assert moved >= 20
+
+
+def test_two_consecutive_updates_match_reference(golden_dir):
+    """TWO consecutive collect (teacher-forced) + update rounds on the same learner / tracker state (tests/golden/learn.npz
+    r2_*, recorded from the reference's own second Collector.collect + policy.update): pins ret_rms carry-over, the Adam
+    moments of both optimisers across updates and — through the tracker's second Adam step, whose size depends on g2/g1 —
+    the MAGNITUDES of the tracker gradients (the first step only pins their signs)."""
+    from cirs_hip.rollout import Trajectory
+    from test_oracle_learn import compare_tracker_second_step, load_round2
+    z, tp, pp, perms = load_learn(golden_dir)
+    U, I, B, T = [int(v) for v in z["dims"]]
+    bs, rep, lr = int(z["hyper"][7]), int(z["hyper"][8]), float(z["hyper"][6])
+    trk, views = device_tracker_trainable(tp, U, I, B, T, lr=lr)
+    ln, pviews = make_learner(pp, I, B, T, z["hyper"])
+    traj = Trajectory(B, T, 20, "cuda")
+    for pre, pr in (("", perms), ("r2_", load_round2(z))):
+        lens = z[pre + "lens"]
+        acts = np.maximum(z[pre + "acts"], 0)
+        replay_tracker(trk, z[pre + "users"], acts, z[pre + "rews"], lens)
+        pp_now = {k: pviews[name].detach().cpu().reshape(pp[k].shape).clone() for k, name in POL.items()}
+        value, logp = rollout_time_value_logp(pp_now, z[pre + "obs"], acts, lens)
+        traj.clear()
+        upload_traj(traj, z[pre + "acts"], z[pre + "rews"], z[pre + "dones"], lens, z[pre + "obs"], value, logp)
+        n = ln.prepare(traj, lens)
+        np.testing.assert_allclose(ln.b_vs[:n].cpu().numpy(), z[pre + "b_v_s"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(ln.b_ret[:n].cpu().numpy(), z[pre + "b_returns"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(ln.b_adv[:n].cpu().numpy(), z[pre + "b_adv"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(ln.rms_state.cpu().numpy(), z[pre + "ret_rms"], rtol=1e-5)
+        losses = ln.learn(bs, rep, perms=pr).cpu().numpy()
+        np.testing.assert_allclose(losses[:, 0], z[pre + "loss"], rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(losses[:, 2], z[pre + "loss_vf"], rtol=5e-4, atol=5e-5)
+        offsets, _, _ = rows_of(lens)
+        trk.backward(torch.as_tensor(z[pre + "users"]), traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).cuda(),
+                     torch.as_tensor(lens.astype(np.int32)).cuda(), n, ln.dobs)
+        trk.adam_update()
+        for k, name in POL.items():
+            post = z[pre + "post_pol_" + name]
+            np.testing.assert_allclose(pviews[name].cpu().numpy().reshape(post.shape), post, rtol=2e-4, atol=5e-6, err_msg=pre + name)
+    compare_tracker_second_step({k: v.cpu().numpy() for k, v in views.items()}, z, lr=lr)
