@@ -30,11 +30,35 @@ WORKLOADS = {
                name="KuaishouEnv small_matrix-shaped synthetic 1411x3327, 64 envs/GPU, tracker dim 32, recent-N=10, max_turn=30, PPO batch 1024 x repeat 2"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
-# measured on MI355X, see profiles/r01p_pmc_minibatch_step.md: (2*FETCH_SIZE + WRITE_SIZE) KB summed over the seven
-# kernels of one 1024-row PPO minibatch step at I = 10728 (separate rocprofv3 --pmc passes)
-PMC_TRAFFIC_BYTES_PER_MINIBATCH = int((2 * 35202 + 69076) * 1024)
-PMC_TRAFFIC_BYTES_BWD_KERNEL = int((2 * 5284 + 30007) * 1024)   # head_bwd_fused_kernel: Wa planes / h2 in, 8 dWa + 31 dH2 partial slabs out
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+MINIBATCH_KERNELS = ("trunk_adv_kernel", "head_stats_kernel", "head_stats_merge_kernel", "head_bwd_fused_kernel", "trunk_bwd_kernel",
+                     "sumsq_partial_kernel", "adam2_kernel")
+
+
+def kernel_source_hash():
+    """Fingerprint of every kernel source: PMC numbers recorded for other sources are stale and are NOT reported."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cirs-codes_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cirs-codes_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    runs, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md) -- only if they were taken on THIS kernel source and workload;
+    otherwise None (never a stale constant).  -> ({kernel: bytes per launch}, source string) or (None, reason)."""
+    if not os.path.exists(PMC_TRAFFIC_JSON):
+        return None, "profiles/pmc_traffic.json absent: run tools/pmc_traffic.py on the GPU box"
+    z = json.load(open(PMC_TRAFFIC_JSON))
+    if z.get("source_hash") != kernel_source_hash():
+        return None, f"profiles/pmc_traffic.json is stale (taken on kernel sources {z.get('source_hash')}, this build is {kernel_source_hash()})"
+    if z.get("workload") != workload:
+        return None, f"profiles/pmc_traffic.json was taken on workload {z.get('workload')}"
+    return {k: int(v["bytes_per_launch"]) for k, v in z["kernels"].items()}, f"profiles/pmc_traffic.json ({z.get('taken', '?')}; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
 def build_engine(wl, rank, world, device):
@@ -121,15 +145,21 @@ def deepfm_sweep_probe(wl, device, E=16, reps=5):
     pairs = float(U) * I
     executed = 2.0 * (64 * 64 + 64 + E) * pairs          # factored algorithm actually run
     algorithmic = (2.0 * ((6 * E + 1) * 64 + 64 * 64 + 64) + 18 * E) * pairs   # SURVEY §8(d) F_sweep (unfactored reference algorithm)
+    # the 64x64 layer runs as fp32 products from 3 bf16 pieces per operand = 6 bf16 MFMAs per fp32 product: the pipe the kernel
+    # occupies is the bf16 one, so ITS flops (6 x the 64x64 layer + the fp32 VALU rest) are priced against the bf16 peak
+    bf16_pipe = 6.0 * 2.0 * 64 * 64 * pairs
     return {"pairs_per_s": pairs / t, "seconds_per_sweep": t, "emb_dim": E, "users": U, "items": I,
-            "roofline": {"bound": "mfma", "achieved": algorithmic / t / 1e12, "achieved_executed": executed / t / 1e12,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": algorithmic / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "frac_executed": executed / t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "note": "achieved uses SURVEY's algorithmic F_sweep (unfactored first layer); achieved_executed counts the flops the factored kernel runs"},
+            "roofline": {"bound": "mfma", "achieved": bf16_pipe / t / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": bf16_pipe / t / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                         "note": "executed bf16-pipe flops (6 bf16 MFMAs per fp32 product of the 64x64 layer) vs the dense bf16 MFMA peak"},
+            "logical_fp32": {"executed_tflops": executed / t / 1e12, "survey_f_sweep_tflops": algorithmic / t / 1e12,
+                             "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
+                             "note": "fp32-equivalent rates, NOT roofline fractions: 'executed' = flops of the factored algorithm (first layer split per user / per item), "
+                                     "'survey_f_sweep' = SURVEY 8(d)'s unfactored F_sweep; both can exceed the fp32 MFMA peak because the work runs on the bf16 pipe"},
             "cpu_reference_pairs_per_s": 1.78e6}
 
 
-def sweep_mode_probe(wl, eng, device, E=16, reps=5):
+def sweep_mode_probe(wl, eng, device, E=32, reps=5):
     """The north-star's catalogue-sweep formulation: per vector step every env's user is scored
     against the FULL catalogue by the DeepFM user model, one item is drawn per env from those scores (softmax sampling,
     cirs_select_items) and the env steps.  Timed with HIP events on the launch stream, B = the workload's env count."""
@@ -168,35 +198,114 @@ def sweep_mode_probe(wl, eng, device, E=16, reps=5):
             "logical_hbm": {"bytes_per_env_step": a_sweep, "achieved": steps_per_s * a_sweep / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": steps_per_s * a_sweep / 1e9 / HBM_PEAK_GBS,
                             "note": "logical rate: item rows staged once per workgroup serve every env of the tile, so it is not the physical HBM rate"},
-            "mfma": {"flop_per_env_step": f_sweep, "achieved": steps_per_s * f_sweep / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": steps_per_s * f_sweep / 1e12 / PEAK_FP32_MFMA_TFLOPS}}
+            "mfma": {"bf16_pipe_flop_per_env_step": 6.0 * 2.0 * 64 * 64 * I, "achieved": steps_per_s * 6.0 * 2.0 * 64 * 64 * I / 1e12,
+                     "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": steps_per_s * 6.0 * 2.0 * 64 * 64 * I / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                     "survey_f_sweep_flop_per_env_step": f_sweep, "survey_f_sweep_tflops": steps_per_s * f_sweep / 1e12,
+                     "note": "frac prices the executed bf16-pipe flops against the dense bf16 peak; survey_f_sweep_tflops is the logical fp32 rate of SURVEY's unfactored count (not a roofline fraction)"}}
 
 
-def cpu_baseline(wl, budget_envs=1024, threads=None):
-    """The oracle port of the same step on the host cores, bounded sample (fewer envs, same tables / episode rule).
-    Threads are capped: the per-step tensors are tiny and oversubscribing a 256-core host makes the port slower."""
-    threads = threads or min(16, os.cpu_count() or 1)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
+def gather_fm_probe(device, reps=10):
+    """K1-K2 micro-benchmark (the stage the north-star's ">= 40 % of the HBM-read roofline" applies to): embedding
+    gather + linear + FM bi-interaction on random (user, item) pairs, no DNN (cirs_gather_fm).  ALGORITHMIC bytes per pair =
+    28 (X row) + 2 x (4E + 4) (user and item embedding rows + their linear weights) + 4 (out) = 8E + 40; the 32 x E feat table
+    is LDS-resident and not counted.  Timed with HIP events on the launch stream, inputs resident in HBM.  Cases: the
+    KuaishouEnv big_matrix shape (tables of 0.9 + 1.4 MB at E = 32: they live in the 4 MiB L2 of every XCD, so the physical
+    HBM traffic is the X / out streams only and `achieved` is a LOGICAL rate) and the C5 shape (2^20 x 2^20, E = 64: 268 MB per
+    table, past L2 and Infinity Cache, where algorithmic ~ physical).  Physical FETCH/WRITE numbers: profiles/pmc_traffic.json."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import deepfmcase
+    from cirs_hip.deepfm import DeviceDeepFM
+    out = []
+    traffic, src = pmc_traffic("c3")
+    for name, U, I, E, n in (("c3_E32", 7176, 10728, 32, 1 << 24), ("c3_E16", 7176, 10728, 16, 1 << 24), ("c5_E64", 1 << 20, 1 << 20, 64, 1 << 23)):
+        g = torch.Generator(device="cpu").manual_seed(E)
+        # weights on the device directly (the C5 tables are 2 x 268 MB)
+        w = {"emb_user": torch.randn(U, E, generator=g) * 0.3, "emb_item": torch.randn(I + 1, E, generator=g) * 0.3,
+             "emb_feat": torch.randn(32, E, generator=g) * 0.3, "lin_user": torch.randn(U, generator=g) * 0.1,
+             "lin_item": torch.randn(I + 1, generator=g) * 0.1, "lin_feat": torch.randn(32, generator=g) * 0.1, "lin_dense": torch.randn(1, generator=g) * 0.01,
+             "w1": torch.zeros(64, 6 * E + 1), "b1": torch.zeros(64), "w2": torch.zeros(64, 64), "b2": torch.zeros(64), "last": torch.zeros(64),
+             "out_bias": torch.zeros(1)}
+        m = DeviceDeepFM(w, device=device)
+        X = torch.empty((n, 7), dtype=torch.float32, device=device)
+        gd = torch.Generator(device=device).manual_seed(E + 1)
+        X[:, 0] = torch.randint(0, U, (n,), device=device, generator=gd).float()
+        X[:, 1] = torch.randint(0, I, (n,), device=device, generator=gd).float()
+        X[:, 2:6] = torch.randint(0, 32, (n, 4), device=device, generator=gd).float()
+        X[:, 6] = torch.rand(n, device=device, generator=gd) * 58 + 2
+        m.gather_fm(X)
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        start.record()
+        for _ in range(reps):
+            y = m.gather_fm(X)
+        stop.record()
+        torch.cuda.synchronize()
+        t = start.elapsed_time(stop) / reps * 1e-3
+        alg = (8 * E + 40) * n
+        rec = {"case": name, "users": U, "items": I, "emb_dim": E, "pairs": n, "seconds_per_launch": t, "pairs_per_s": n / t,
+               "algorithmic_bytes_per_pair": 8 * E + 40,
+               "roofline": {"bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
+                            "traffic": (traffic or {}).get(f"gather_fm_kernel<{E}, true>"),
+                            "compulsory_stream_bytes_per_pair": 32,
+                            "note": "tables L2-resident: achieved is a logical gather rate, physical HBM traffic ~ 32 B/pair" if U < 100000 else
+                                    "tables past L2 / Infinity Cache: algorithmic ~ physical"}}
+        out.append(rec)
+        del m, X, w, y
+        torch.cuda.empty_cache()
+    return out
+
+
+def _set_omp_threads(n):
+    import ctypes
+    torch.set_num_threads(n)
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))   # OMP_NUM_THREADS is only read when libgomp initialises
+    except OSError:
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(n)
+
+
+def cpu_baseline(wl, eng):
+    """The oracle port of the same step (oracle/cpu_path.py: C oracle env / actor, torch-fp32 tracker + PPO restatement) on the host
+    cores, with the SAME tables, policy and tracker weights as the GPU leg, on a BOUNDED sample: a single-thread leg, a 16-thread
+    leg and an all-core leg (the per-step tensors are small, so more threads are not always faster; the best multi-thread leg is
+    `value`).  The reference's own Python numbers (SURVEY section 6 / tools/bench_reference.py, measured in the dev container:
+    the reference cannot travel to the GPU box) are quoted next to it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_path
-    import policycase
     import rolloutcase
     from cirs_hip.synthetic import make_tables
     tab = make_tables(wl["U"], wl["I"], seed=0, build_dist=False)
-    tp = rolloutcase.tracker_param_dict(wl["U"], wl["I"], wl["T"], seed=2, emb_scale=0.01)
-    arrs = policycase.random_weights(np.random.RandomState(2), wl["I"])
-    B = min(budget_envs, wl["B"])
-    torch.set_num_threads(threads)
-    cpu_path.run_cpu_step(tab, tp, arrs, 4, wl["T"], N=wl["N"], thr=wl["thr"], do_update=False)  # warm-up
-    t0 = time.perf_counter()
-    r = cpu_path.run_cpu_step(tab, tp, arrs, B, wl["T"], N=wl["N"], thr=wl["thr"], tau=wl["tau"],
-                              gamma_exposure=wl["gamma_exposure"], batch_size=1024, repeat=2)
-    dt = time.perf_counter() - t0
-    return {"value": r["env_steps"] / dt, "unit": "env-steps/s", "cores": threads, "host_cores": os.cpu_count() or 1, "kind": "port",
-            "sample": f"1 step (collect + update) with {B} envs on the same {wl['U']}x{wl['I']} tables: {r['env_steps']} env-steps, "
-                      f"{r['minibatches']} PPO minibatch steps, collect {r['t_collect']:.2f}s + update {r['t_update']:.2f}s "
-                      "(C oracle env/actor via OpenMP, torch-fp32 tracker/PPO restatement)"}
+    tp = {k: v.detach().cpu().clone() for k, v in eng.tracker.params.items()}
+    arrs = {k: eng.policy_views[name].detach().cpu().numpy().copy() for k, name in rolloutcase.POLICY_NAMES.items()}
+    host = os.cpu_count() or 1
+    legs = []
+    for threads, B in ((1, min(32, wl["B"])), (min(16, host), wl["B"]), (host, wl["B"])):
+        if any(l["cores"] == threads for l in legs):
+            continue
+        _set_omp_threads(threads)
+        cpu_path.run_cpu_step(tab, tp, arrs, 4, wl["T"], N=wl["N"], thr=wl["thr"], do_update=False)  # warm-up
+        t0 = time.perf_counter()
+        r = cpu_path.run_cpu_step(tab, tp, arrs, B, wl["T"], N=wl["N"], thr=wl["thr"], tau=wl["tau"], gamma_exposure=wl["gamma_exposure"],
+                                  batch_size=1024, repeat=2)
+        dt = time.perf_counter() - t0
+        legs.append({"cores": threads, "envs": B, "env_steps": r["env_steps"], "mean_episode_len": r["env_steps"] / B, "seconds": dt,
+                     "env_steps_per_s": r["env_steps"] / dt, "rollout_env_steps_per_s": r["env_steps"] / max(r["t_collect"], 1e-9),
+                     "ppo_minibatch_steps_per_s": r["minibatches"] / max(r["t_update"], 1e-9), "minibatches": r["minibatches"]})
+    best = max(legs[1:] or legs, key=lambda l: l["env_steps_per_s"])
+    ref = None
+    ref_json = os.path.join(ROOT, "profiles", "reference_python_cpu.json")
+    if os.path.exists(ref_json):
+        ref = json.load(open(ref_json))
+    return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["cores"], "host_cores": host, "kind": "port",
+            "sample": f"1 step (collect + update, same tables / policy / tracker weights as the GPU leg) with {best['envs']} envs on the {wl['U']}x{wl['I']} tables: "
+                      f"{best['env_steps']} env-steps, {best['minibatches']} PPO minibatch steps in {best['seconds']:.1f}s "
+                      "(C oracle env/actor via OpenMP, torch-fp32 tracker/PPO restatement)",
+            "single_thread": legs[0], "legs": legs,
+            "reference_python": ref or {"note": "profiles/reference_python_cpu.json absent", "survey_section_6": {
+                "c2_rollout_env_steps_per_s": 940, "c3_rollout_env_steps_per_s": 520, "c2_ppo_minibatch_steps_per_s": 1.9,
+                "c3_ppo_minibatch_steps_per_s": 0.75, "deepfm_pairs_per_s": 1.78e6, "cores": 8}}}
 
 
 def main():
@@ -206,6 +315,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probes", action="store_true", help="skip the secondary probes (gather_fm / sweep / cpu baseline): contract line only")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
 
@@ -252,10 +362,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     total_steps = float(steps_local)
+    ranks_identical = None
+    if world > 1:
+        # every rank must hold bit-identical policy / tracker parameters after the timed updates (order-fixed reductions)
+        h = torch.stack([eng.policy_flat.view(torch.int32).sum(dtype=torch.int64), eng.tracker_flat.view(torch.int32).sum(dtype=torch.int64),
+                         (eng.policy_flat.view(torch.int32).to(torch.int64) * torch.arange(1, eng.policy_flat.numel() + 1, device=device) % 1000003).sum()])
+        allh = [torch.zeros_like(h) for _ in range(world)]
+        dist.all_gather(allh, h)
+        ranks_identical = all(bool(torch.equal(allh[0], x)) for x in allh)
 
     # split (untimed extra pass, same state): rollout-only and update-only rates
     barrier()
-    ta = time.perf_counter(); eng.collect(); n_ro = int(eng.lengths.sum()); torch.cuda.synchronize(); tb = time.perf_counter()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    n_ro, reps_ro = 0, 3
+    ev[0].record()
+    for _ in range(reps_ro):        # rollout only: HIP events on the launch stream, no host sync / reduction inside the window
+        eng.collect()
+    ev[1].record()
+    torch.cuda.synchronize()
+    t_ro = ev[0].elapsed_time(ev[1]) * 1e-3 / reps_ro
+    n_ro = int(eng.lengths.sum())    # env-steps of the LAST of the collects (same policy: the others differ by sampling noise only)
+    tb = time.perf_counter()
     l2, n2 = eng.update(1024, 2); torch.cuda.synchronize(); tc = time.perf_counter()
 
     if rank == 0:
@@ -281,8 +408,8 @@ def main():
                        "parallelism": (f"env-sharded x{world}; one all-gather of trajectory records per update; data-parallel learner: "
                                        f"global minibatch = 1024 x {world} rows sharded by rows, one flat-gradient all-reduce per minibatch")
                        if world > 1 else "single GPU"},
-            "ppo_minibatch_steps_per_s": mb_steps / elapsed,
-            "rollout_only_env_steps_per_s": n_ro / (tb - ta),
+            "ppo_minibatch_steps_per_s": mb_steps / elapsed, "rank_parameters_bit_identical": ranks_identical,
+            "rollout_only_env_steps_per_s": n_ro / t_ro, "rollout_only_ms_per_collect": 1e3 * t_ro,
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
             "roofline": {"bound": "mfma", "kernel": "head_bwd_fused_kernel (PPO minibatch step: fused actor-head backward; fp32 products as 3 bf16 pieces per operand on v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
                          "achieved": flop_bwd / t_bwd / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -298,16 +425,19 @@ def main():
                                "head_stats_kernel_seconds": t_k["head_stats_kernel"],
                                "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel + 5 small kernels"},
         }
-        # HBM traffic from the committed PMC passes (profiles/r01p_pmc_minibatch_step.md: FETCH_SIZE doubled per the gfx950
-        # note, WRITE_SIZE as reported): the fused backward kernel alone, and the whole minibatch step (all eight kernels)
-        out["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_BWD_KERNEL if args.workload == "c3" else None
-        out["minibatch_step"]["traffic"] = PMC_TRAFFIC_BYTES_PER_MINIBATCH if args.workload == "c3" else None
-        out["roofline"]["traffic_source"] = "profiles/r01p_pmc_minibatch_step.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, C3)"
-        if world == 1:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
+        # HBM traffic per launch from the committed PMC passes -- only when they were taken on exactly these kernel sources
+        traffic, src = pmc_traffic(args.workload)
+        out["roofline"]["traffic"] = (traffic or {}).get("head_bwd_fused_kernel")
+        out["roofline"]["traffic_source"] = src
+        out["minibatch_step"]["traffic"] = sum(traffic.get(k, 0) for k in MINIBATCH_KERNELS) if traffic and all(k in traffic for k in MINIBATCH_KERNELS) else None
+        if traffic:
+            out["hbm_traffic_per_launch"] = {k: v for k, v in traffic.items() if k.split("<")[0] in ("actor_head_kernel", "tracker_step_kernel", "sweep_kernel", "gather_fm_kernel")}
+        if world == 1 and not args.no_probes:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
+            out["gather_fm"] = gather_fm_probe(device)
             out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
             out["sweep_mode"] = sweep_mode_probe(wl, eng, device)
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(wl)
+                out["cpu_baseline"] = cpu_baseline(wl, eng)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

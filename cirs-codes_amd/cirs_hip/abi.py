@@ -137,6 +137,7 @@ SIGNATURES = {
     "cirs_tracker_backward": (C.c_int, [C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState), _P, _P,
                                         _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(TrackerWeights), _P, C.c_int64, _P]),
     "cirs_deepfm_forward": (C.c_int, [C.POINTER(DeepFMCfg), C.POINTER(DeepFMWeights), _P, _P, _P, _P, C.c_int32, _P, _P]),
+    "cirs_gather_fm": (C.c_int, [C.POINTER(DeepFMCfg), C.POINTER(DeepFMWeights), _P, C.c_int64, _P, _P]),
     "cirs_deepfm_sweep_workspace_bytes": (C.c_int64, [C.POINTER(DeepFMCfg), C.c_int32, C.c_int32]),
     "cirs_deepfm_sweep": (C.c_int, [C.POINTER(DeepFMCfg), C.POINTER(DeepFMWeights), _P, C.c_int32, _P, _P, _P, C.c_int32,
                                     _P, _P, C.c_int32, _P, C.c_int64, _P]),

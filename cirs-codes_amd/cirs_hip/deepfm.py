@@ -50,6 +50,16 @@ class DeviceDeepFM:
                                                 dur.data_ptr(), n, out.data_ptr(), self._stream()), "cirs_deepfm_forward")
         return out
 
+    def gather_fm(self, X):
+        """K1-K2 alone: X [n, 7] float32 rows [user_id, photo_id, feat0..3, duration] (the reference's forward input) ->
+        linear logit + FM term [n] (cirs_gather_fm; no DNN)."""
+        X = torch.as_tensor(X).to(self.device, torch.float32).contiguous()
+        assert X.dim() == 2 and X.shape[1] == 7
+        out = torch.empty(X.shape[0], dtype=torch.float32, device=self.device)
+        abi.check(self._lib.cirs_gather_fm(C.byref(self.cfg), C.byref(self.w), X.data_ptr(), X.shape[0], out.data_ptr(), self._stream()),
+                  "cirs_gather_fm")
+        return out
+
     def sweep(self, user_ids, item_ids, item_feats, item_dur, want_pred=True):
         """All (user, item) pairs -> (pred [nu, ni] fp32 or None, minmax [2])."""
         dev = self.device

@@ -123,9 +123,17 @@ class CirsEngine:
             if self._users_pinned is None:
                 self._users_pinned = [torch.empty(self.n_env, dtype=torch.int32).pin_memory() for _ in range(2)]
                 self._users_dev = [torch.empty(self.n_env, dtype=torch.int32, device=self.device) for _ in range(2)]
+                self._users_uploaded = [None, None]
             k = self.collect_count & 1
+            if self._users_uploaded[k] is not None:
+                # the upload issued from this pinned buffer two collects ago must have been consumed before the host overwrites
+                # it (collect() may be called back to back without an update(), whose read-back would order it)
+                self._users_uploaded[k].synchronize()
             self._users_pinned[k].numpy()[:] = self._user_rng.randint(0, self.tables.n_users, self.n_env)
             self._users_dev[k].copy_(self._users_pinned[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._users_uploaded[k] = ev
             self.users = self._users_dev[k]
         else:
             self.users = users.to(self.device, torch.int32)

@@ -55,6 +55,10 @@ class Collector:
         assert self.buffer.buffer_num >= self.env_num
         self._rollout: Optional[DeviceRollout] = None
         self._collect_count = 0
+        # sampler key of this collector: (policy seed, collector stream).  Train / FB / NX_0 / NX_k collectors draw independent
+        # noise (with one shared key they would all see the same Gumbel draw per (env, step, item) in every epoch)
+        self.stream_id = getattr(policy, "_n_collectors", 0)     # the policy's first collector (train) keeps the bare seed
+        policy.__dict__["_n_collectors"] = self.stream_id + 1
         self.data = Batch()
         if hasattr(policy, "_tracker") and env.workers[0].simulated:
             # the gradient through the stored obs of the TRAINING buffer goes to this tracker (ppo.py:215)
@@ -85,10 +89,13 @@ class Collector:
     def _get_rollout(self) -> DeviceRollout:
         if self._rollout is None:
             dev_env = self.env.device_env()
-            trk = self.tracker.engine(self.env_num)
+            trk = self.tracker.engine(self.env_num, owner=self)
             self._rollout = DeviceRollout(dev_env, trk, self.policy.device_policy(), remove_recommended_ids=self.remove_recommended_ids,
                                           force_length=self.force_length)
         return self._rollout
+
+    def sampler_seed(self):
+        return ((int(self.policy.seed) * 0x9E3779B1) ^ (self.stream_id * 0x85EBCA6B)) & 0x7FFFFFFF if self.stream_id else int(self.policy.seed)
 
     def collect(self, n_step: Optional[int] = None, n_episode: Optional[int] = None, random: bool = False, render=None,
                 no_grad: bool = True, users=None) -> Dict[str, Any]:
@@ -102,7 +109,7 @@ class Collector:
             users = self.env.draw_users(self.env_num)
         users_t = torch.as_tensor(np.asarray(users))
         T = ro.env.max_turn
-        lengths = ro.collect(users_t, seed=self.policy.seed, rng_base=(self._collect_count * T) & 0xFFFFFFFF).cpu().numpy()
+        lengths = ro.collect(users_t, seed=self.sampler_seed(), rng_base=(self._collect_count * T) & 0xFFFFFFFF).cpu().numpy()
         self._collect_count += 1
         self.buffer.fill_from_trajectory(ro.traj, lengths)
         self.buffer._rollout, self.buffer._users = ro, users_t  # policy.update() consumes them with the buffer

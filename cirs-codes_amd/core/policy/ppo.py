@@ -36,9 +36,7 @@ class PPOPolicy(nn.Module):
                            max_grad_norm=max_grad_norm, norm_adv=advantage_normalization, value_clip=value_clip,
                            rew_norm=reward_normalization)
         optim_RL = optim[0] if isinstance(optim, (list, tuple)) else optim
-        g = optim_RL.param_groups[0]
-        self._hyper.update(lr=g["lr"], betas=tuple(g.get("betas", (0.9, 0.999))), adam_eps=g.get("eps", 1e-8))
-        self._tracker_lr = optim[1].param_groups[0]["lr"] if isinstance(optim, (list, tuple)) and len(optim) > 1 else g["lr"]
+        self._read_optim_hyper()
         # bind the modules' parameters into one flat device buffer (layout of include/cirs_hip.h)
         net = actor.preprocess
         assert critic.preprocess is net, "CIRS shares the trunk between actor and critic (CIRS-RL-kuaishou.py:245-247)"
@@ -67,6 +65,20 @@ class PPOPolicy(nn.Module):
         optim_bridge.bind(optim_RL, self._adam_state_RL)
         if isinstance(optim, (list, tuple)) and len(optim) > 1:
             optim_bridge.bind(optim[1], self._adam_state_tracker)
+
+    def _read_optim_hyper(self):
+        """lr / betas / eps of both torch optimisers are read on EVERY update (a scheduler or the user may change
+        param_groups between updates); what the device Adam does not implement is refused, not ignored."""
+        optim = self.optim
+        opts = list(optim) if isinstance(optim, (list, tuple)) else [optim]
+        for o in opts:
+            for g in o.param_groups:
+                if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                    raise NotImplementedError("the device Adam implements torch.optim.Adam(lr, betas, eps) only: weight_decay / amsgrad / maximize are not built")
+        g = opts[0].param_groups[0]
+        self._hyper.update(lr=float(g["lr"]), betas=tuple(g.get("betas", (0.9, 0.999))), adam_eps=float(g.get("eps", 1e-8)))
+        gt = opts[1].param_groups[0] if len(opts) > 1 else g
+        self._tracker_lr, self._tracker_betas, self._tracker_eps = float(gt["lr"]), tuple(gt.get("betas", (0.9, 0.999))), float(gt.get("eps", 1e-8))
 
     def _adam_state_RL(self, create=False):
         ln = self._learner
@@ -148,18 +160,23 @@ class PPOPolicy(nn.Module):
         assert ro is not None and buffer._traj is ro.traj, "update() consumes a buffer filled by Collector.collect()"
         self.updating = True
         lens = np.asarray(buffer._lengths, dtype=np.int32)
+        self._read_optim_hyper()
         ln = self._get_learner(ro.env.n_env, ro.env.max_turn)
+        ln.cfg.lr, (ln.cfg.beta1, ln.cfg.beta2), ln.cfg.adam_eps = self._hyper["lr"], self._hyper["betas"], self._hyper["adam_eps"]
+        ln.perm_seed = (self.seed * 7919 + 20230) & 0x7FFFFFFF
         n = ln.prepare(ro.traj, lens)
         losses = ln.learn(batch_size, repeat, perms=perms, want_tracker_grad=self._tracker is not None)
         if self._tracker is not None:
-            eng = self._tracker.engine(ro.env.n_env)
-            eng.lr = self._tracker_lr
+            eng = ro.tracker      # the slots / caches of THIS buffer's rollout (each Collector owns its engine)
+            eng.lr, eng.betas, eng.adam_eps = self._tracker_lr, self._tracker_betas, self._tracker_eps
             eng.adam_steps = self._tracker.adam_steps
             offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
             dev = self.flat.device
             eng.backward(buffer._users, ro.traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).to(dev), torch.as_tensor(lens).to(dev), n, ln.dobs)
             eng.adam_update()
             self._tracker.adam_steps = eng.adam_steps
+        if self.lr_scheduler is not None:      # ppo.py:239-240: stepped once per learn(); its optimisers are re-read next update
+            self.lr_scheduler.step()
         self.updating = False
         lo = losses.cpu().numpy()
         return {"loss": lo[:, 0].tolist(), "loss/clip": lo[:, 1].tolist(), "loss/vf": lo[:, 2].tolist(), "loss/ent": lo[:, 3].tolist()}

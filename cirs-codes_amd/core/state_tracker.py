@@ -57,11 +57,18 @@ class StateTrackerTransformer(nn.Module):
             for k, v in self._views.items():
                 v.copy_(torch.as_tensor(sd[k]).to(v.device, v.dtype).reshape(v.shape))
 
-    def engine(self, n_env=None) -> DeviceTracker:
-        """Device engine for a vector env of n_env envs (train and test collectors may differ in size); the parameters
-        and the Adam state are shared, the K/V caches are per engine."""
+    def engine(self, n_env=None, owner=None) -> DeviceTracker:
+        """Device engine for a vector env of n_env envs; the parameters and the Adam state are shared, the history slots
+        (the reference's self.data) and K/V caches are per engine.  `owner`: every Collector passes itself, so that two
+        collectors with the same env count (training_num == test_num == 100 in CIRS-RL-kuaishou.py) never share slots — the
+        tracker backward of policy.update(train_buffer) re-reads the slots of the TRAIN rollout even if a test rollout ran
+        in between (onpolicy.py:65-72 with stop_fn + test_in_train).  owner=None: the per-step build_state protocol."""
         n_env = n_env or self._n_env
-        if n_env not in self._engines:
+        key = n_env if owner is None else (n_env, id(owner))
+        if owner is not None:
+            self._owners = getattr(self, "_owners", {})
+            self._owners[id(owner)] = owner      # pin the id
+        if key not in self._engines:
             params = dict(self._views)
             params["pos_encoder.pe"] = self.pe
             eng = DeviceTracker(params, self.n_users, self.n_items, n_env, self.MAX_TURN - 1, dim_model=self.dim_model,
@@ -72,9 +79,10 @@ class StateTrackerTransformer(nn.Module):
                 self._train_state = (eng.flat_grad, eng.grad_views, eng.g, eng.adam_m, eng.adam_v)
             else:
                 eng.flat_grad, eng.grad_views, eng.g, eng.adam_m, eng.adam_v = self._train_state
-            self._engines[n_env] = eng
-        self._n_env = n_env
-        return self._engines[n_env]
+            self._engines[key] = eng
+        if owner is None:
+            self._n_env = n_env
+        return self._engines[key]
 
     def build_state(self, obs=None, env_id=None, obs_next=None, rew=None, done=None, info=None, policy=None, dim_batch=None,
                     reset=False):

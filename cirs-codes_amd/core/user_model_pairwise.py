@@ -1,12 +1,13 @@
 """UserModel_Pairwise (reference core/user_model_pairwise.py:14-154): the DeepFM user model, forward on the device.
 
 Constructor keywords and state_dict names match the shipped `DeepFM_params_Pair11.pickle` / `DeepFM_Pair11.pt`
-(SURVEY Appendix C).  Training (`fit_data`, losses) is offline and out of scope."""
+(SURVEY Appendix C).  compile / fit_data / recommend_k_item live in the base class core.user_model.UserModel, like in the reference."""
 import numpy as np
 import torch
 from torch import nn
 
 from core.inputs import SparseFeatP, compute_input_dim
+from core.user_model import UserModel
 from deepctr_torch.inputs import DenseFeat, build_input_features
 
 
@@ -26,7 +27,7 @@ def make_loss_kuaishou_pairwise(lambda_ab: float):
     return loss_kuaishou_pairwise
 
 
-class UserModel_Pairwise(nn.Module):
+class UserModel_Pairwise(UserModel):
     def __init__(self, feature_columns, y_columns, task, task_logit_dim, dnn_hidden_units=(128, 128), l2_reg_embedding=1e-5,
                  l2_reg_dnn=1e-1, init_std=0.0001, task_dnn_units=None, seed=2022, dnn_dropout=0, dnn_activation="relu",
                  dnn_use_bn=False, device="cpu", padding_idx=None, ab_columns=None, l2_reg_linear=1e-5):
@@ -61,56 +62,6 @@ class UserModel_Pairwise(nn.Module):
         self._trainer = None
         self.optim = None
 
-    # ---- training (reference core/user_model.py:74-170) ---------------------------------------------------------------
-    def compile(self, optimizer, loss_dict=None, metrics=None, metric_fun=None, loss_func=None):
-        assert optimizer == "adam" or isinstance(optimizer, torch.optim.Adam), "the device step implements torch.optim.Adam"
-        assert loss_func is not None and hasattr(loss_func, "lambda_ab"), \
-            "pass core.user_model_pairwise.make_loss_kuaishou_pairwise(lambda_ab): the loss runs inside cirs_deepfm_train_step"
-        self.metrics_names = ["loss"]
-        self.loss_func, self.metric_fun, self.metrics = loss_func, metric_fun, metrics
-        self.optim = "adam"
-        self._lr = optimizer.param_groups[0]["lr"] if isinstance(optimizer, torch.optim.Adam) else 1e-3
-
-    def fit_data(self, dataset_train, dataset_val=None, batch_size=256, epochs=1, verbose=1, initial_epoch=0, callbacks=None, shuffle=True):
-        """One pass per epoch over (x, y, score) minibatches; every step is cirs_deepfm_train_step on the device."""
-        from cirs_hip.deepfm_train import DeepFMTrainer
-        assert self.optim is not None, "call compile() first"
-        if self._trainer is None:
-            self._trainer = DeepFMTrainer(self.state_dict(), use_ab=self.ab_columns is not None, lambda_ab=self.loss_func.lambda_ab,
-                                          l2_embedding=self._l2[0], l2_linear=self._l2[1], l2_all=self._l2[2], lr=self._lr)
-        tr = self._trainer
-        x = torch.as_tensor(dataset_train.x_numpy).to(tr.device, torch.float32)
-        y = torch.as_tensor(dataset_train.y_numpy).to(tr.device, torch.float32)
-        score = torch.as_tensor(dataset_train.score).to(tr.device, torch.float32)
-        n_all = x.shape[0]
-        callbacks = callbacks or []
-        for cb in callbacks:
-            cb.on_train_begin()
-        history = []
-        for epoch in range(initial_epoch, epochs):
-            for cb in callbacks:
-                cb.on_epoch_begin(epoch)
-            order = torch.randperm(n_all, device=tr.device) if shuffle else torch.arange(n_all, device=tr.device)
-            loss_sum = torch.zeros((), device=tr.device)
-            for s0 in range(0, n_all, batch_size):
-                idx = order[s0:s0 + batch_size]
-                lo = tr.step(x[idx], y[idx], score[idx])
-                loss_sum += lo[0] + lo[4]
-            logs = {"loss": float(loss_sum) / n_all}       # total_loss_epoch / sample_num (core/user_model.py:205)
-            history.append(logs)
-            for cb in callbacks:
-                cb.on_epoch_end(epoch, logs)
-        for cb in callbacks:
-            cb.on_train_end()
-        # publish the trained parameters under the module's state_dict names
-        with torch.no_grad():
-            mine = dict(self.named_parameters())
-            for k, v in tr.state_dict().items():
-                if k in mine:
-                    mine[k].copy_(v.reshape(mine[k].shape).to(mine[k].device))
-        self._dev = None
-        return history
-
     def device_model(self):
         """DeviceDeepFM over the current weights (rebuilt after load_state_dict)."""
         if self._dev is None:
@@ -124,47 +75,6 @@ class UserModel_Pairwise(nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         self._dev = None
         return super().load_state_dict(state_dict, strict=False)
-
-    # ---- static-baseline recommendation (reference core/user_model.py:250-348) ------------------------------------------
-    def compile_UCB(self, n_arm):
-        self.n_rec = n_arm
-        self.n_each = np.ones(n_arm)
-
-    def recommend_k_item(self, user, dataset_val, k=1, is_softmax=True, epsilon=0, is_ucb=False, recommended_ids=[], gumbel=None,
-                         seed=None):
-        """One catalogue sweep for `user` (original id) over dataset_val.df_photo_env, then the choice of ONE item on the
-        device (cirs_select_items).  Returns (recommended_id_transform, recommended_id_raw, value_rec) like the reference:
-        position in df_photo_env, original id, u_value of the pick.  k > 1 is not built (the scripts use k = 1)."""
-        assert k == 1, "only k = 1 is built (interactive_evaluation / test_kuaishou call with k=1)"
-        from cirs_hip.static_policy import select_items
-        df_item_val = dataset_val.df_photo_env
-        item_index = df_item_val.index.to_numpy()
-        I = len(item_index)
-        dm = self.device_model()
-        feats = df_item_val[["feat0", "feat1", "feat2", "feat3"]].to_numpy()
-        dur = df_item_val["photo_duration"].to_numpy()
-        pred, _ = dm.sweep(np.asarray([user]), item_index, feats, dur)          # [1, I] on the device
-        visited = None
-        if len(recommended_ids):
-            words = np.zeros((I + 31) // 32, dtype=np.uint32)
-            ids = np.asarray(recommended_ids, dtype=np.int64)
-            np.bitwise_or.at(words, ids >> 5, (np.uint32(1) << (ids & 31).astype(np.uint32)))
-            visited = torch.as_tensor(words.view(np.int32)).reshape(1, -1)
-        bonus = None
-        if is_ucb and len(recommended_ids) == 0:
-            if not hasattr(self, "n_rec"):
-                self.compile_UCB(I)
-            bonus = torch.as_tensor(((2 * np.log(self.n_rec) / self.n_each) ** 0.5).astype(np.float32))
-        self._rec_calls = getattr(self, "_rec_calls", 0) + 1
-        act, val = select_items(pred, softmax=is_softmax, bonus=bonus, visited=visited, epsilon=float(epsilon), gumbel=gumbel,
-                                seed=self.seed_rec if seed is None else seed, rng_step=self._rec_calls)
-        recommended_id_transform = act.cpu().numpy()
-        if is_ucb:
-            self.n_rec += k
-            self.n_each[recommended_id_transform] += 1
-        return recommended_id_transform, item_index[recommended_id_transform], val.cpu().numpy()
-
-    seed_rec = 2022
 
     def forward(self, x):
         """x: float tensor (n, 7) = [user_id, photo_id, feat0..3, photo_duration] carrying raw ids."""

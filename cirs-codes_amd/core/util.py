@@ -1,6 +1,8 @@
 """core/util.py pieces of the reference that sit next to the hot path.
 
-compute_action_distance / compute_exposure / clip0 (reference core/util.py:21-54) are fused into csrc/env.hip.  Here:
+compute_action_distance / compute_exposure / clip0 (reference core/util.py:21-54) are fused into csrc/env.hip for the rollout;
+the Python names below are the host-side helpers of the same formulas for callers outside the rollout (notebooks, analysis
+scripts) — nothing on the product path calls them.  Also here:
 the item-item distance table builder / loader (reference core/util.py:225-273), which the reference computes with an
 O(I^2) Python double loop and caches as CSV; this build computes it on the device (cirs_dist_jaccard) and reads / writes
 the same CSV layout (index and columns = original photo ids, values = 1 / Jaccard similarity, inf when disjoint)."""
@@ -12,6 +14,31 @@ import torch
 
 from cirs_hip import abi
 from cirs_hip.synthetic import pack_item_cats
+
+
+def compute_action_distance(action, actions_hist, env_name="VirtualTB-v0", realenv=None):
+    """reference core/util.py:21-38.  KuaishouEnv: positional lookup dist[action, hist] in the item-item table (env-encoded
+    ids); VirtualTB: Euclidean distance between the 27-d action and every earlier action."""
+    if env_name == "VirtualTB-v0":
+        diff = np.asarray(action) - np.asarray(actions_hist)
+        return np.sqrt((diff * diff).sum(axis=-1))
+    if env_name == "KuaishouEnv-v0":
+        df_dist_small = realenv.df_dist_small
+        table = df_dist_small.to_numpy() if hasattr(df_dist_small, "to_numpy") else np.asarray(df_dist_small)
+        return table[int(action), np.asarray(actions_hist, dtype=int)]
+    raise ValueError(env_name)
+
+
+def compute_exposure(t_diff, dist, tau):
+    """reference core/util.py:40-50: sum_k exp(-t_diff_k * dist_k / tau); tau <= 0 switches the exposure effect off."""
+    if tau <= 0:
+        return 0
+    return float(np.exp(-np.asarray(t_diff, dtype=np.float64) * np.asarray(dist, dtype=np.float64) / tau).sum())
+
+
+def clip0(x):
+    """reference core/util.py:53-54 — np.amax over axis 0, NOT max(x, 0): the identity on scalars."""
+    return np.amax(x, 0)
 
 
 def _device_distance(list_feat_sub) -> np.ndarray:

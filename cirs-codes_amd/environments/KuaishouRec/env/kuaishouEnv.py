@@ -67,9 +67,13 @@ class KuaishouEnv(gym.Env):
                 a_env = np.asarray(alpha_u)[_classes(self.lbe_user), 0].astype(np.float64)
                 b_env = np.asarray(beta_i)[_classes(self.lbe_photo), 0].astype(np.float64)
             dist = None if self.df_dist_small is None else _to_numpy(self.df_dist_small)
-            _TABLE_CACHE[key] = DeviceEnvTables(self.mat, normed_mat, self.item_cats(), dist=dist, alpha_env=a_env, beta_env=b_env,
-                                                device=device, build_dist_on_device=dist is None and False)
-        return _TABLE_CACHE[key]
+            # a missing distance table is NOT rebuilt silently: a bare KuaishouEnv (no exposure term) does not read it
+            tables = DeviceEnvTables(self.mat, normed_mat, self.item_cats(), dist=dist, alpha_env=a_env, beta_env=b_env,
+                                     device=device, build_dist_on_device=False)
+            # the key is made of id()s: keep the keyed host objects alive next to the entry, otherwise CPython may hand a
+            # collected object's id to a different matrix and a later env would silently hit this entry
+            _TABLE_CACHE[key] = (tables, (self.mat, self.df_dist_small, normed_mat, alpha_u))
+        return _TABLE_CACHE[key][0]
 
     def build_device_env(self, n_env, device="cuda"):
         from cirs_hip.env import DeviceEnv

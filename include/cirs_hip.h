@@ -386,6 +386,14 @@ typedef struct cirs_deepfm_weights {
 int cirs_deepfm_forward(const cirs_deepfm_cfg* cfg, const cirs_deepfm_weights* w, const int64_t* uid, const int64_t* pid,
                         const int32_t* feats, const float* dur, int32_t n, float* out, void* stream);
 
+/* K1-K2 alone: embedding gather + linear logit + FM bi-interaction, no DNN -- the cache/HBM-bound stage.
+ * replaces  core/user_model.py:419-447 (input_from_feature_columns), core/layers.py:59-70 (Linear.forward),
+ *           DeepCTR-Torch deepctr_torch/layers/interaction.py:26-34 (FM.forward)
+ * X[n,7] float32 rows = [user_id, photo_id, feat0..3, photo_duration] -- the reference's own input tensor of
+ * UserModel_Pairwise.forward (ids as float32, exact below 2^24).  out[n] = linear logit + FM term.
+ * cirs_deepfm_forward(x) == cirs_gather_fm(x) + (last . DNN(x) + out_bias) up to fp32 summation order. */
+int cirs_gather_fm(const cirs_deepfm_cfg* cfg, const cirs_deepfm_weights* w, const float* X, int64_t n, float* out, void* stream);
+
 int64_t cirs_deepfm_sweep_workspace_bytes(const cirs_deepfm_cfg* cfg, int32_t n_users, int32_t n_items);
 
 /* Scores every (user, item) pair of users x items: pred_out[nu, ni] fp32 (nullable) and the global {min, max}

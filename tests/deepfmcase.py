@@ -35,3 +35,33 @@ def oracle_forward(wts, uid, pid, feats, dur):
                                    len(uid), out.ctypes.data)
     assert rc == 0
     return out
+
+
+def oracle_gather_fm(wts, X):
+    """K1-K2 only (C oracle, summation order of csrc/gather_fm.hip): X [n,7] float32 -> linear logit + FM term."""
+    import oracle_lib
+    lib = oracle_lib.lib()
+    keep = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in wts.items()}
+    E = keep["emb_user"].shape[1]
+    cfg = abi.DeepFMCfg(n_user_vocab=keep["emb_user"].shape[0], n_item_vocab=keep["emb_item"].shape[0],
+                        n_feat_vocab=keep["emb_feat"].shape[0], emb_dim=E, hidden=64)
+    w = abi.DeepFMWeights(**{f: keep[f].ctypes.data for f in abi.DEEPFM_FIELDS})
+    X = np.ascontiguousarray(X, np.float32)
+    out = np.zeros(len(X), np.float32)
+    assert lib.oracle_gather_fm(C.byref(cfg), C.byref(w), X.ctypes.data, len(X), out.ctypes.data) == 0
+    return out
+
+
+def dnn_part(wts, X):
+    """last . relu(W2 relu(W1 [v_user, v_item, v_f0..3, dur] + b1) + b2) + out_bias in float64 (core.py:120-134,155-161)."""
+    X = np.asarray(X, np.float32)
+    u, p, f = X[:, 0].astype(int), X[:, 1].astype(int), X[:, 2:6].astype(int)
+    x = np.concatenate([wts["emb_user"][u], wts["emb_item"][p]] + [wts["emb_feat"][f[:, q]] for q in range(4)] + [X[:, 6:7]], axis=1).astype(np.float64)
+    h1 = np.maximum(x @ wts["w1"].astype(np.float64).T + wts["b1"], 0)
+    h2 = np.maximum(h1 @ wts["w2"].astype(np.float64).T + wts["b2"], 0)
+    return h2 @ wts["last"].astype(np.float64).reshape(-1) + float(np.asarray(wts["out_bias"]).reshape(-1)[0])
+
+
+def x_rows(uid, pid, feats, dur):
+    return np.concatenate([np.asarray(uid, np.float32)[:, None], np.asarray(pid, np.float32)[:, None], np.asarray(feats, np.float32),
+                           np.asarray(dur, np.float32)[:, None]], axis=1).astype(np.float32)

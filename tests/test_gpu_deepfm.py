@@ -75,3 +75,31 @@ def test_shipped_checkpoint_forward_through_plugin_surface(golden_dir):
     y = model.forward(torch.as_tensor(X)).cpu().numpy()
     assert y.shape == (len(pu), 1)
     np.testing.assert_allclose(y[:, 0], z["y"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("E,U,I,n", [(16, 7176, 10729, 100003), (32, 7176, 10729, 65536), (64, 3000, 5000, 4099), (8, 40, 50, 1), (32, 9, 11, 31)])
+def test_gather_fm_bit_exact_vs_oracle(E, U, I, n):
+    """K1-K2 kernel (cirs_gather_fm) == C oracle bit for bit (same summation order), ragged n incl. a single pair."""
+    from cirs_hip.deepfm import DeviceDeepFM
+    rng = np.random.RandomState(E + n)
+    w = deepfmcase.random_weights(rng, U, I, E)
+    X = deepfmcase.x_rows(rng.randint(0, U, n), rng.randint(0, I, n), rng.randint(0, 32, (n, 4)), rng.uniform(2, 60, n))
+    got = DeviceDeepFM(w).gather_fm(X).cpu().numpy()
+    want = deepfmcase.oracle_gather_fm(w, X)
+    assert np.array_equal(got, want), f"max diff {np.abs(got - want).max()}"
+
+
+def test_gather_fm_golden_and_large_feat_vocab(golden_dir):
+    from cirs_hip.deepfm import DeviceDeepFM
+    z = np.load(os.path.join(golden_dir, "deepfm.npz"))
+    w = deepfmcase.weights_from_golden(z)
+    X = deepfmcase.x_rows(z["pu"], z["pi"], z["feats"][z["pi"]], z["dur"][z["pi"]])
+    m = DeviceDeepFM(w)
+    y = m.gather_fm(X).cpu().numpy().astype(np.float64) + deepfmcase.dnn_part(w, X)
+    np.testing.assert_allclose(y, z["y"], rtol=1e-5, atol=2e-6)            # + DNN branch == the reference's forward
+    np.testing.assert_allclose(m.forward(z["pu"], z["pi"], z["feats"][z["pi"]], z["dur"][z["pi"]]).cpu().numpy(), y, rtol=1e-5, atol=2e-6)
+    # a feat vocabulary too large for the LDS copy takes the global-gather variant: same bits
+    rng = np.random.RandomState(3)
+    wb = deepfmcase.random_weights(rng, 100, 120, 32, n_feat=600)
+    Xb = deepfmcase.x_rows(rng.randint(0, 100, 5000), rng.randint(0, 120, 5000), rng.randint(0, 600, (5000, 4)), rng.uniform(2, 60, 5000))
+    assert np.array_equal(DeviceDeepFM(wb).gather_fm(Xb).cpu().numpy(), deepfmcase.oracle_gather_fm(wb, Xb))

@@ -135,3 +135,27 @@ def test_data_parallel_path_over_rccl_with_one_rank(monkeypatch):
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on the node (RCCL over xGMI with N > 1 ranks)")
+@pytest.mark.parametrize("nproc", [2])
+def test_two_process_rccl_bench_ranks_stay_bit_identical(nproc):
+    """The driver's SCALE run must not be the first time RCCL sees N > 1 ranks: launch bench.py exactly as the driver does
+    (torch.distributed.run, one process per GPU), 3 timed steps, and require (a) a valid JSON line, (b) n_gpus == nproc and
+    envs_total == 1024 * nproc (env-sharded, weak scaling), (c) bit-identical policy / tracker parameters on every rank after
+    the updates (the all-gather + per-minibatch all-reduce path is order-fixed)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + os.getpid() % 200
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    z = json.loads(line)
+    assert z["n_gpus"] == nproc and z["config"]["envs_total"] == 1024 * nproc and z["scaling"] == "weak"
+    assert z["rank_parameters_bit_identical"] is True
+    assert z["value"] > 0 and z["steps"] == 3

@@ -52,7 +52,7 @@ def test_script_wiring_runs_and_matches_engine():
     eng = CirsEngine(dt, 32, max_turn=15, num_leave_compute=args.num_leave_compute, leave_threshold=args.leave_threshold, tau=10.0,
                      gamma_exposure=args.gamma_exposure, seed=0, tracker_params=tp0, policy_params=pp0)
     eng.users = torch.as_tensor(users).to(eng.device, torch.int32)
-    eng.lengths = eng.rollout.collect(eng.users, seed=policy.seed, rng_base=0)
+    eng.lengths = eng.rollout.collect(eng.users, seed=coll.sampler_seed(), rng_base=0)
     assert torch.equal(eng.rollout.traj.act, coll._rollout.traj.act)
     assert torch.equal(eng.rollout.traj.rew, coll._rollout.traj.rew)
     assert torch.equal(eng.rollout.traj.obs, coll._rollout.traj.obs)

@@ -46,3 +46,23 @@ def test_shipped_checkpoint_unpickles_into_the_mirror(golden_dir):
     z = np.load(os.path.join(golden_dir, "deepfm.npz"))
     np.testing.assert_array_equal(alpha_u[z["raw_u"], 0], z["alpha_u"])
     np.testing.assert_array_equal(beta_i[z["raw_i"], 0], z["beta_i"])
+
+
+def test_gather_fm_oracle_plus_dnn_is_the_reference_forward(golden_dir):
+    """K1-K2 (embedding gather + Linear + FM, oracle_gather_fm) + the DNN branch == the reference's recorded
+    UserModel_Pairwise.forward on the shipped weights: pins the split the HBM micro-benchmark measures."""
+    z = np.load(os.path.join(golden_dir, "deepfm.npz"))
+    w = deepfmcase.weights_from_golden(z)
+    X = deepfmcase.x_rows(z["pu"], z["pi"], z["feats"][z["pi"]], z["dur"][z["pi"]])
+    y = deepfmcase.oracle_gather_fm(w, X).astype(np.float64) + deepfmcase.dnn_part(w, X)
+    np.testing.assert_allclose(y, z["y"], rtol=1e-5, atol=1e-6)
+    # and against the literal restatement, at other embedding widths
+    rng = np.random.RandomState(0)
+    for E in (8, 16, 32, 64):
+        wr = deepfmcase.random_weights(rng, 50, 70, E)
+        n = 300
+        uid, pid = rng.randint(0, 50, n), rng.randint(0, 70, n)
+        feats = rng.randint(0, 32, (n, 4)); dur = rng.uniform(2, 60, n).astype(np.float32)
+        Xr = deepfmcase.x_rows(uid, pid, feats, dur)
+        full = deepfmcase.oracle_forward(wr, uid, pid, feats, dur)
+        np.testing.assert_allclose(deepfmcase.oracle_gather_fm(wr, Xr) + deepfmcase.dnn_part(wr, Xr), full, rtol=2e-5, atol=2e-5)
