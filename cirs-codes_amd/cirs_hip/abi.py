@@ -122,6 +122,10 @@ SIGNATURES = {
                                      C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
                                      C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
                                      C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, _P, C.c_int32, _P, C.c_int64, _P]),
+    "cirs_rollout_steps_noise": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState),
+                                           C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
+                                           C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
+                                           C.c_int32, C.c_int32, _P, _P, C.c_int32, _P, C.c_int64, _P]),
     "cirs_rollout_steps_online": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState),
                                             C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
                                             C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
@@ -137,6 +141,10 @@ SIGNATURES = {
     "cirs_tracker_backward": (C.c_int, [C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState), _P, _P,
                                         _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(TrackerWeights), _P, C.c_int64, _P]),
     "cirs_deepfm_forward": (C.c_int, [C.POINTER(DeepFMCfg), C.POINTER(DeepFMWeights), _P, _P, _P, _P, C.c_int32, _P, _P]),
+    "cirs_actor_shard_partials": (C.c_int, [C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), _P, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32,
+                                            _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64, _P]),
+    "cirs_actor_merge_shards": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "cirs_gather_rows": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P, _P]),
     "cirs_gather_fm": (C.c_int, [C.POINTER(DeepFMCfg), C.POINTER(DeepFMWeights), _P, C.c_int64, _P, _P]),
     "cirs_deepfm_sweep_workspace_bytes": (C.c_int64, [C.POINTER(DeepFMCfg), C.c_int32, C.c_int32]),
     "cirs_deepfm_sweep": (C.c_int, [C.POINTER(DeepFMCfg), C.POINTER(DeepFMWeights), _P, C.c_int32, _P, _P, _P, C.c_int32,

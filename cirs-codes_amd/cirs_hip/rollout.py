@@ -95,8 +95,17 @@ class DeviceRollout:
         B, S = self.env.n_env, self.tracker.dim_state
         self.tracker.init(users, out=self.traj.obs[0], out_stride=S)
 
-    def run_steps(self, t_begin, t_end, seed, rng_base):
+    def run_steps(self, t_begin, t_end, seed, rng_base, gumbel=None):
         ws = self.policy.workspace(self.env.n_env)
+        if gumbel is not None:      # harness-supplied sampler noise (parity fixtures recorded from the reference)
+            assert self.online is None and gumbel.dtype == torch.float32 and gumbel.is_contiguous()
+            assert tuple(gumbel.shape) == (self.env.max_turn, self.env.n_env, self.policy.n_items)
+            abi.check(self._lib.cirs_rollout_steps_noise(
+                C.byref(self.env.cfg), C.byref(self.env._tab), C.byref(self.env._st), C.byref(self.tracker.cfg),
+                C.byref(self.tracker.w), C.byref(self.tracker.st), C.byref(self.policy.cfg), C.byref(self.policy.w),
+                C.byref(self.traj.struct), self.env.n_env, t_begin, t_end, gumbel.data_ptr(), abi.ptr(self.visited),
+                self.force_length, ws.data_ptr(), ws.numel(), self._stream()), "cirs_rollout_steps_noise")
+            return
         if self.online is not None:
             abi.check(self._lib.cirs_rollout_steps_online(
                 C.byref(self.env.cfg), C.byref(self.env._tab), C.byref(self.env._st), C.byref(self.tracker.cfg),
@@ -111,13 +120,17 @@ class DeviceRollout:
             C.byref(self.traj.struct), self.env.n_env, t_begin, t_end, seed, rng_base, abi.ptr(self.visited),
             self.force_length, ws.data_ptr(), ws.numel(), self._stream()), "cirs_rollout_steps")
 
-    def collect(self, users: torch.Tensor, *, seed=0, rng_base=0, sync_every: Optional[int] = None):
+    def collect(self, users: torch.Tensor, *, seed=0, rng_base=0, sync_every: Optional[int] = None, gumbel=None):
         """One `collect(n_episode = n_env)`: all envs run to the end of their episode.  Returns (n_steps, lengths).
         sync_every: poll the live-env count every that many steps to stop early (None: run all max_turn steps
         without any host sync; idle steps of finished envs are no-ops)."""
         self.reset(users)
         T = self.env.max_turn
-        if sync_every is None:
+        if gumbel is not None:
+            gumbel = torch.as_tensor(gumbel).to(self.device, torch.float32).contiguous()
+            self.run_steps(0, T, seed, rng_base, gumbel=gumbel)
+            self._gumbel_keep = gumbel
+        elif sync_every is None:
             self.run_steps(0, T, seed, rng_base)
         else:
             t = 0

@@ -98,7 +98,9 @@ class Collector:
         return ((int(self.policy.seed) * 0x9E3779B1) ^ (self.stream_id * 0x85EBCA6B)) & 0x7FFFFFFF if self.stream_id else int(self.policy.seed)
 
     def collect(self, n_step: Optional[int] = None, n_episode: Optional[int] = None, random: bool = False, render=None,
-                no_grad: bool = True, users=None) -> Dict[str, Any]:
+                no_grad: bool = True, users=None, gumbel=None) -> Dict[str, Any]:
+        """users / gumbel: teacher forcing for parity tests -- the users the envs are reset to and the sampler noise
+        [max_turn, env_num, n_items] (g = -log q of the reference's Categorical.sample race)."""
         assert n_step is None and n_episode is not None, "the CIRS scripts collect whole episodes (n_episode)"
         assert n_episode == self.env_num, "n_episode must equal the number of envs (finished envs are not reset, SURVEY Q4)"
         assert not random
@@ -109,7 +111,7 @@ class Collector:
             users = self.env.draw_users(self.env_num)
         users_t = torch.as_tensor(np.asarray(users))
         T = ro.env.max_turn
-        lengths = ro.collect(users_t, seed=self.sampler_seed(), rng_base=(self._collect_count * T) & 0xFFFFFFFF).cpu().numpy()
+        lengths = ro.collect(users_t, seed=self.sampler_seed(), rng_base=(self._collect_count * T) & 0xFFFFFFFF, gumbel=gumbel).cpu().numpy()
         self._collect_count += 1
         self.buffer.fill_from_trajectory(ro.traj, lengths)
         self.buffer._rollout, self.buffer._users = ro, users_t  # policy.update() consumes them with the buffer

@@ -41,10 +41,12 @@ class CollectorSet:
     def _reset_state(self, id):
         self._each("_reset_state", id)
 
-    def collect(self, n_step=None, n_episode=None, random=False, render=None, no_grad=True) -> Dict[str, Any]:
+    def collect(self, n_step=None, n_episode=None, random=False, render=None, no_grad=True, users=None, gumbel=None) -> Dict[str, Any]:
+        """users / gumbel: optional {collector name: array} teacher forcing (parity tests), see Collector.collect."""
         all_res = {}
         for name, collector in self.collector_dict.items():
-            res = collector.collect(n_step, n_episode, random, render, no_grad)
+            res = collector.collect(n_step, n_episode, random, render, no_grad, users=None if users is None else users[name],
+                                    gumbel=None if gumbel is None else gumbel[name])
             all_res.update(res if name == "FB" else {f"{name}_{k}": v for k, v in res.items()})
         fb = self.collector_dict["FB"]
         self.collect_step, self.collect_episode, self.collect_time = fb.collect_step, fb.collect_episode, fb.collect_time

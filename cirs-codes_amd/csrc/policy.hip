@@ -40,6 +40,76 @@ __global__ __launch_bounds__(256) void actor_merge_kernel(int n, int n_pad, int 
     actor_merge_wave(j, lane, n_pad, n_chunks, pv, wa, ba, h2, act_out, logp_out);
 }
 
+__global__ __launch_bounds__(256) void actor_shard_tuple_kernel(int n, int n_pad, int n_chunks, ActorPartialView pv,
+                                                               const float* __restrict__ wa, const float* __restrict__ ba,
+                                                               const float* __restrict__ h2, const uint8_t* __restrict__ skip,
+                                                               int item_base, float* __restrict__ out5) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    if (skip && skip[j]) {
+        if (lane == 0) {
+            out5[j] = -INFINITY; reinterpret_cast<int32_t*>(out5)[(size_t)n + j] = 0x7FFFFFFF;
+            out5[(size_t)2 * n + j] = 0.f; out5[(size_t)3 * n + j] = -INFINITY; out5[(size_t)4 * n + j] = 0.f;
+        }
+        return;
+    }
+    actor_shard_tuple_wave(j, lane, n_pad, n_chunks, pv, wa, ba, h2, item_base, n, out5);
+}
+
+// cross-rank merge of W shard tuples per env row, in RANK ORDER (fixed): candidate with the highest noisy score (ties -> lowest
+// global id), running (max, sum-exp) folded rank by rank; logp of the winner with Categorical's clamp (as actor_merge_wave)
+__global__ __launch_bounds__(256) void actor_merge_shards_kernel(const float* __restrict__ tuples, int n_shards, int n,
+                                                                 const uint8_t* __restrict__ skip, int64_t* __restrict__ act_out,
+                                                                 float* __restrict__ logp_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (skip && skip[j]) {
+        act_out[j] = -1;
+        if (logp_out) logp_out[j] = 0.f;
+        return;
+    }
+    float bs = -INFINITY, m = -INFINITY, s = 0.f, zb = 0.f;
+    int bi = 0x7FFFFFFF;
+    for (int r = 0; r < n_shards; ++r) {
+        const float* t = tuples + (size_t)r * 5 * n;
+        const float os = t[j];
+        const int oi = reinterpret_cast<const int32_t*>(t)[(size_t)n + j];
+        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; zb = t[(size_t)2 * n + j]; }
+        const float om = t[(size_t)3 * n + j], osum = t[(size_t)4 * n + j];
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            s = s * __expf(m - mn) + osum * __expf(om - mn);
+            m = mn;
+        }
+    }
+    act_out[j] = bi == 0x7FFFFFFF ? -1 : (int64_t)bi;
+    if (logp_out) {
+        float lp = 0.f;
+        if (bi != 0x7FFFFFFF) {
+            const float lse = m + __logf(s);
+            float p = __expf(zb - lse);
+            const float eps = 1.1920928955078125e-7f;
+            p = fminf(fmaxf(p, eps), 1.0f - eps);
+            lp = __logf(p);
+        }
+        logp_out[j] = lp;
+    }
+}
+
+// rows of a row-major fp32 table: out[k, :] = table[idx[k], :]   (16 B per lane; row_floats % 4 == 0) -- the local side of a
+// row-sharded embedding lookup
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int row_floats, const int64_t* __restrict__ idx,
+                                                          long n, float* __restrict__ out) {
+    const int q = row_floats >> 2;
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n * q) return;
+    const long r = k / q;
+    const int c = (int)(k - r * q);
+    const long id = idx[r];     // id < 0: an empty message slot of the sharded lookup -> zeros
+    reinterpret_cast<float4*>(out)[k] = id < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4*>(table + (size_t)id * row_floats)[c];
+}
+
 static int validate_policy(const cirs_policy_cfg* cfg, const cirs_policy_weights* w) {
     CIRS_REQUIRE(cfg && w, "policy cfg/weights null");
     CIRS_REQUIRE(cfg->n_items > 0, "n_items must be positive");
@@ -85,5 +155,57 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
     hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, n_chunks, pv, w->wa, w->ba,
                        h2, skip, act_out, logp_out);
     CIRS_CHECK_LAUNCH("actor_merge_kernel");
+    return CIRS_OK;
+}
+
+extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const cirs_policy_weights* w_shard, const float* state,
+                                         int64_t state_stride, int32_t n, uint64_t seed, uint32_t rng_step, const int32_t* env_ids,
+                                         const uint32_t* visited, const uint8_t* skip, int32_t item_base, int32_t n_items_total,
+                                         float* tuples_out, float* value_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_policy(cfg_shard, w_shard)) return rc;
+    if (n <= 0) return CIRS_OK;
+    CIRS_REQUIRE(state && tuples_out && workspace, "null state/tuples/workspace");
+    CIRS_REQUIRE(state_stride >= cfg_shard->dim_state, "state_stride < dim_state");
+    CIRS_REQUIRE(item_base >= 0 && (item_base & 31) == 0, "item_base must be a non-negative multiple of 32");
+    CIRS_REQUIRE(n_items_total >= item_base + cfg_shard->n_items, "n_items_total < item_base + shard size");
+    CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(cfg_shard, n), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* h2 = (float*)workspace;
+    const int n_pad = n_pad_of(n);
+    const HeadGrid hg = sampler_grid(cfg_shard->n_items, n_pad);
+    ActorPartialView pv = partial_view(workspace, n, cfg_shard->n_items);
+    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, *cfg_shard, *w_shard, state, (long)state_stride, n, skip, h2,
+                       value_out, nullptr);
+    CIRS_CHECK_LAUNCH("trunk_kernel");
+    hipLaunchKernelGGL(actor_head_kernel, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *cfg_shard, w_shard->wa, w_shard->ba,
+                       (const float*)h2, n, (const float*)nullptr, seed, rng_step, env_ids, visited, skip, pv, n_pad, hg.tiles_per_chunk,
+                       item_base, n_items_total);
+    CIRS_CHECK_LAUNCH("actor_head_kernel");
+    hipLaunchKernelGGL(actor_shard_tuple_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, hg.n_chunks, pv, w_shard->wa, w_shard->ba,
+                       (const float*)h2, skip, item_base, tuples_out);
+    CIRS_CHECK_LAUNCH("actor_shard_tuple_kernel");
+    return CIRS_OK;
+}
+
+extern "C" int cirs_actor_merge_shards(const float* tuples, int32_t n_shards, int32_t n, const uint8_t* skip, int64_t* act_out,
+                                       float* logp_out, void* stream) {
+    using namespace cirs;
+    if (n <= 0) return CIRS_OK;
+    CIRS_REQUIRE(tuples && act_out && n_shards > 0, "null tuples / act_out or n_shards <= 0");
+    hipLaunchKernelGGL(actor_merge_shards_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, tuples, n_shards, n, skip,
+                       act_out, logp_out);
+    CIRS_CHECK_LAUNCH("actor_merge_shards_kernel");
+    return CIRS_OK;
+}
+
+extern "C" int cirs_gather_rows(const float* table, int32_t row_floats, const int64_t* idx, int64_t n, float* out, void* stream) {
+    using namespace cirs;
+    if (n <= 0) return CIRS_OK;
+    CIRS_REQUIRE(table && idx && out, "null argument");
+    CIRS_REQUIRE(row_floats > 0 && (row_floats & 3) == 0, "row_floats must be a positive multiple of 4");
+    const long total = n * (row_floats >> 2);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, table, row_floats, idx, (long)n, out);
+    CIRS_CHECK_LAUNCH("gather_rows_kernel");
     return CIRS_OK;
 }

@@ -144,7 +144,12 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
                                                             uint32_t rng_step, const int32_t* __restrict__ env_ids,
                                                             const uint32_t* __restrict__ visited,
                                                             const uint8_t* __restrict__ skip, ActorPartialView pv,
-                                                            int n_pad, int tiles_per_chunk) {
+                                                            int n_pad, int tiles_per_chunk, int item_base = 0,
+                                                            int n_items_total = 0) {
+    // Column-sharded head (BASELINE configs[4]): wa / ba / cfg.n_items describe THIS rank's item shard, whose first item has the
+    // global id item_base (a multiple of 32); noise counters, the visited bitmap, harness noise and the returned candidate ids use
+    // GLOBAL item ids (n_items_total = size of the whole catalogue), so a shard computes exactly what the full kernel computes
+    // for its items.  item_base = 0, n_items_total = 0: the whole catalogue on one device.
     // The Wa tile (32 items x 64) is staged in LDS once per workgroup and shared by its four env tiles; double
     // buffered: global loads of tile t+1 are issued before the MFMAs of tile t (one barrier per tile).
     __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
@@ -155,7 +160,8 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
     const int row0 = (blockIdx.y * 4 + wv) * kTileM;
     const int I = cfg.n_items;
     const int chunk = blockIdx.x;
-    const int vis_words = (I + 31) / 32;
+    const int I_tot = n_items_total > 0 ? n_items_total : I;
+    const int vis_words = (I_tot + 31) / 32;
     const int jr = row0 + lo;  // this lane's env row
     const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
     const bool wave_live = __ballot(active) != 0ull;  // some row of this env tile still runs
@@ -229,7 +235,7 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
                 for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
 
                 if (active) {
-                    const uint32_t vis = visited ? visited[(size_t)e * vis_words + (tile0 >> 5)] : 0u;
+                    const uint32_t vis = visited ? visited[(size_t)e * vis_words + ((item_base + tile0) >> 5)] : 0u;
                     // log-sum-exp per tile: the lane's maximum first, then ONE rescale of the running sums and one exp per
                     // element (masked / padded elements carry -inf and add exp(-inf) = 0)
                     float zt[16];
@@ -239,7 +245,7 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
                         const int i0 = tile0 + 8 * g + 4 * hi;
                         float g4[4];
                         if (!gumbel) {
-                            const u32x4 rr = philox4x32_10((uint32_t)i0 >> 2, (uint32_t)e, rng_step, CIRS_RNG_STREAM_ACTOR,
+                            const u32x4 rr = philox4x32_10((uint32_t)(item_base + i0) >> 2, (uint32_t)e, rng_step, CIRS_RNG_STREAM_ACTOR,
                                                            (uint32_t)seed, (uint32_t)(seed >> 32));
                             g4[0] = gumbel_from_bits(rr.x); g4[1] = gumbel_from_bits(rr.y);
                             g4[2] = gumbel_from_bits(rr.z); g4[3] = gumbel_from_bits(rr.w);
@@ -252,10 +258,10 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
                             zt[4 * g + q] = valid ? z : -INFINITY;
                             tmax = fmaxf(tmax, zt[4 * g + q]);
                             if (valid) {
-                                const float gn = gumbel ? gumbel[(size_t)jr * I + item] : g4[q];
+                                const float gn = gumbel ? gumbel[(size_t)jr * I_tot + item_base + item] : g4[q];
                                 const float sc = z + gn;
                                 if (sc > best_score) {  // items ascend within a lane: strict > keeps the lowest id on ties
-                                    best_score = sc; best_idx = item;
+                                    best_score = sc; best_idx = item_base + item;
                                 }
                             }
                         }
@@ -355,6 +361,55 @@ __device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, 
         logp_out[j] = lp;
     }
     return act;
+}
+
+// Column-sharded head: merge this shard's chunk partials of env row j into ONE tuple (score, global id, logit of that candidate,
+// running max, running sum-exp) -- what a rank contributes to the cross-rank merge.  Same reduction order as actor_merge_wave.
+__device__ __forceinline__ void actor_shard_tuple_wave(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv,
+                                                       const float* __restrict__ wa, const float* __restrict__ ba,
+                                                       const float* __restrict__ h2, int item_base, int n, float* __restrict__ out5) {
+    float bs = -INFINITY, m = -INFINITY, s = 0.f;
+    int bi = 0x7FFFFFFF;
+    for (int c = lane; c < n_chunks; c += CIRS_WAVE) {
+        const size_t o = (size_t)c * n_pad + j;
+        const float os = pv.score[o];
+        const int oi = pv.idx[o];
+        if (os > bs) { bs = os; bi = oi; }
+        const float om = pv.m[o], osum = pv.s[o];
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            s = s * __expf(m - mn) + osum * __expf(om - mn);
+            m = mn;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float os = __shfl_xor(bs, off, CIRS_WAVE);
+        const int oi = __shfl_xor(bi, off, CIRS_WAVE);
+        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+        const float om = __shfl_xor(m, off, CIRS_WAVE), osum = __shfl_xor(s, off, CIRS_WAVE);
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            s = s * __expf(m - mn) + osum * __expf(om - mn);
+            m = mn;
+        }
+    }
+    if (lane != 0) return;
+    float z = 0.f;
+    if (bi != 0x7FFFFFFF) {     // the candidate's logit, same k-order as the MFMA chain (bias, then k = kk, 32 + kk)
+        const float* wr = wa + (size_t)(bi - item_base) * kH;
+        const float* hr = h2 + (size_t)j * kH;
+        z = ba[bi - item_base];
+        for (int kk = 0; kk < 32; ++kk) {
+            z = __builtin_fmaf(hr[kk], wr[kk], z);
+            z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
+        }
+    }
+    out5[j] = bs;
+    reinterpret_cast<int32_t*>(out5)[(size_t)n + j] = bi;
+    out5[(size_t)2 * n + j] = z;
+    out5[(size_t)3 * n + j] = m;
+    out5[(size_t)4 * n + j] = s;
 }
 
 }  // namespace cirs

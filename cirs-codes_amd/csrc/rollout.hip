@@ -43,6 +43,22 @@ __global__ __launch_bounds__(256) void online_pairs_kernel(const int32_t* __rest
 
 }  // namespace cirs
 
+static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                        const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                        const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
+                        int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited, int32_t force_length,
+                        const cirs_online_reward* online, const float* gumbel, void* workspace, int64_t workspace_bytes, void* stream);
+
+extern "C" int cirs_rollout_steps_noise(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                                        const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                                        const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj,
+                                        int32_t n_env, int32_t t_begin, int32_t t_end, const float* gumbel, uint32_t* visited,
+                                        int32_t force_length, void* workspace, int64_t workspace_bytes, void* stream) {
+    CIRS_REQUIRE(gumbel, "cirs_rollout_steps_noise: gumbel is null (use cirs_rollout_steps for the counter-based sampler)");
+    return rollout_impl(env_cfg, env_tab, env_st, trk_cfg, trk_w, trk_st, pol_cfg, pol_w, traj, n_env, t_begin, t_end, 0, 0, visited,
+                        force_length, nullptr, gumbel, workspace, workspace_bytes, stream);
+}
+
 extern "C" int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
                                   const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w,
                                   cirs_tracker_state* trk_st, const cirs_policy_cfg* pol_cfg,
@@ -60,6 +76,16 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
                                   int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited,
                                   int32_t force_length, const cirs_online_reward* online, void* workspace,
                                   int64_t workspace_bytes, void* stream) {
+    return rollout_impl(env_cfg, env_tab, env_st, trk_cfg, trk_w, trk_st, pol_cfg, pol_w, traj, n_env, t_begin, t_end, seed, rng_base,
+                        visited, force_length, online, nullptr, workspace, workspace_bytes, stream);
+}
+
+// gumbel (nullable): harness-supplied sampler noise [max_turn][n_env][n_items] (g = -log q), row t used at vector step t
+static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                        const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                        const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
+                        int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited, int32_t force_length,
+                        const cirs_online_reward* online, const float* gumbel, void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace cirs;
     cirs_env_tables tab_local;
     if (online) {
@@ -87,7 +113,7 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
             double* rew_t = traj->rew + (size_t)t * B;
             uint8_t* done_t = traj->done + (size_t)t * B;
             // policy(obs_t): finished envs (env_st->done) are skipped and get act = -1
-            if (int rc = cirs_actor_sample(pol_cfg, pol_w, obs_t, S, n_env, nullptr, seed, rng_base + (uint32_t)t, nullptr,
+            if (int rc = cirs_actor_sample(pol_cfg, pol_w, obs_t, S, n_env, gumbel ? gumbel + (size_t)t * B * pol_cfg->n_items : nullptr, seed, rng_base + (uint32_t)t, nullptr,
                                            visited, env_st->done, act_t, traj->logp + (size_t)t * B,
                                            traj->value + (size_t)t * B, workspace, workspace_bytes, stream))
                 return rc;
@@ -142,7 +168,8 @@ extern "C" int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs
         double* rew_t = traj->rew + (size_t)t * B;
         uint8_t* done_t = traj->done + (size_t)t * B;
         CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *pol_cfg,
-                                                  pol_w->wa, pol_w->ba, (const float*)h2, n_env, (const float*)nullptr, seed,
+                                                  pol_w->wa, pol_w->ba, (const float*)h2, n_env,
+                                                  gumbel ? gumbel + (size_t)t * B * pol_cfg->n_items : (const float*)nullptr, seed,
                                                   rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
                                                   (const uint8_t*)env_st->done, pv, n_pad, hg.tiles_per_chunk));
         CIRS_CHECK_LAUNCH("actor_head_kernel");

@@ -9,12 +9,12 @@ from typing import Any, Callable, Dict, Optional
 
 
 def test_episode(policy, collector, test_fn: Optional[Callable], epoch: int, n_episode: int, logger=None,
-                 global_step: Optional[int] = None, reward_metric=None) -> Dict[str, Any]:
+                 global_step: Optional[int] = None, reward_metric=None, **teacher) -> Dict[str, Any]:
     for prepare in (collector.reset_env, collector.reset_buffer, policy.eval):
         prepare()
     if test_fn is not None:
         test_fn(epoch, global_step)
-    outcome = collector.collect(n_episode=n_episode)
+    outcome = collector.collect(n_episode=n_episode, **teacher)   # teacher: users= / gumbel= of the parity tests
     if reward_metric is not None:
         outcome["rews"] = reward_metric(outcome["rews"])
     if logger is not None and global_step is not None:

@@ -70,9 +70,9 @@ def get_args(argv=None):
     return p.parse_args(argv)
 
 
-def build(args):
+def build(args, table_seed=0):
     from cirs_hip.synthetic import make_tables
-    tab = make_tables(args.n_users, args.n_items, seed=0)
+    tab = make_tables(args.n_users, args.n_items, seed=table_seed)
     lbe_user = types.SimpleNamespace(classes_=tab.raw_uid)
     lbe_photo = types.SimpleNamespace(classes_=tab.raw_pid)
     device = torch.device("cuda:0")

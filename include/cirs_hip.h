@@ -195,6 +195,27 @@ int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, 
                       const int32_t* env_ids, const uint32_t* visited, const uint8_t* skip, int64_t* act_out,
                       float* logp_out, float* value_out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- column-sharded actor head + row-sharded tables (BASELINE configs[4]: catalogue / embedding tables split over the ranks) ----
+ * The reference has no counterpart (deepctr_torch/inputs.py:31-33 only prints a notice for use_hash); the spec is SURVEY 8(e):
+ * "actor head column-sharded over items with a cross-rank (max, sum-exp, sampled-candidate) reduction", "tables row-sharded by
+ * id mod W, per step an all-to-all of requested ids and returned rows".  Semantics to match: cirs_actor_sample on one device.
+ *
+ * cirs_actor_shard_partials: THIS rank's item shard (cfg_shard->n_items items whose first global id is item_base, a multiple of
+ * 32; w_shard->wa / ba = the shard's rows, trunk / critic weights replicated) against n env rows (all envs of the job; env_ids =
+ * their global ids).  Noise counters, the visited bitmap and candidate ids use GLOBAL item ids, so a shard computes exactly what
+ * the full kernel computes for its items.  tuples_out [5, n] f32: {noisy score, candidate id (int32 bits), candidate logit,
+ * running max, running sum-exp}.  cirs_actor_merge_shards: tuples [n_shards, 5, n] folded in shard order -> act (argmax of the
+ * noisy score, ties -> lowest id: identical to the single-device action) and logp (Categorical clamp). */
+int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const cirs_policy_weights* w_shard, const float* state,
+                              int64_t state_stride, int32_t n, uint64_t seed, uint32_t rng_step, const int32_t* env_ids,
+                              const uint32_t* visited, const uint8_t* skip, int32_t item_base, int32_t n_items_total,
+                              float* tuples_out, float* value_out, void* workspace, int64_t workspace_bytes, void* stream);
+int cirs_actor_merge_shards(const float* tuples, int32_t n_shards, int32_t n, const uint8_t* skip, int64_t* act_out,
+                            float* logp_out, void* stream);
+/* out[k, :] = table[idx[k], :] (zeros where idx[k] < 0) for a row-major fp32 table with row_floats (multiple of 4) floats per row: the local side of a
+ * row-sharded nn.Embedding lookup (core/user_model.py:435-437, core/state_tracker.py:97-110 `embedding_dict[...](ids)`). */
+int cirs_gather_rows(const float* table, int32_t row_floats, const int64_t* idx, int64_t n, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Device-resident rollout: the Collector hot loop with no host round trip per step
  * replaces  core/collector.py:219-317 (policy forward -> env.step -> preprocess_fn -> buffer.add, per vector step)
@@ -244,6 +265,15 @@ int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_t
                        int32_t n_env, int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base,
                        uint32_t* visited, int32_t force_length, void* workspace, int64_t workspace_bytes,
                        void* stream);
+/* same loop with HARNESS-SUPPLIED sampler noise instead of the counter-based generator: gumbel [max_turn][n_env][n_items] f32,
+ * g = -log q with q ~ Exp(1) (torch.multinomial's race noise, core/policy/ppo.py:148-155 `dist.sample()`), row t is used at
+ * vector step t and indexed by ORIGINAL item id also when recommended ids are masked (core/policy/utils.py:30-58): the device
+ * rollout then reproduces a reference Collector.collect whose Categorical.sample was fed the same q (parity fixtures). */
+int cirs_rollout_steps_noise(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                             const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                             const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj,
+                             int32_t n_env, int32_t t_begin, int32_t t_end, const float* gumbel, uint32_t* visited,
+                             int32_t force_length, void* workspace, int64_t workspace_bytes, void* stream);
 /* same, with the predicted reward scored online (env_tab->normed_mat may be NULL) */
 int cirs_rollout_steps_online(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
                               const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w,

@@ -12,6 +12,8 @@ Families
   tracker  StateTrackerTransformer.build_state over whole episodes (eval mode)
   policy   Actor/Critic forward + shared-noise sampling (ppo.py:111-163)
   learn    one full PPOPolicy.update on a recorded rollout (ppo.py:96-246)
+  collectorset   test_episode + CollectorSet.collect (FB / NX_0 / NX_k test collectors) under teacher-forced sampler noise
+                 (tianshou/trainer/utils.py:10-31, core/collector_set.py:13-77, core/policy/utils.py:7-58)
 """
 import os
 import random
@@ -374,6 +376,113 @@ def gen_learn():
     np.savez_compressed(os.path.join(GOLDEN, "learn.npz"), **out)
     print("learn.npz: N =", int(lens.sum()), "lens", lens.tolist(), "minibatches", len(losses["loss"]), "losses", np.round(losses["loss"], 4),
           "perms", [len(p_) for p_ in perms])
+
+
+# --------------------------------------------------------------------------------------------------
+# collectorset family: the reference's test_episode over CollectorSet(FB, NX_0, NX_k) with the sampler noise
+# supplied by the harness, so that the device rollout can be fed the very same noise and must return the same result dict.
+# --------------------------------------------------------------------------------------------------
+def gen_collectorset():
+    import gym
+    import core.policy.ppo as ref_ppo
+    from core.collector_set import CollectorSet
+    from core.policy.ppo import PPOPolicy
+    from tianshou.env import DummyVectorEnv
+    from tianshou.trainer.utils import test_episode
+    import warnings
+    warnings.simplefilter("ignore")
+
+    U, I, B, T, K = 40, 120, 10, 12, 5
+    tab = make_tables(U, I, seed=3, with_ab=True, build_dist=True)
+    envp = dict(num_leave_compute=3, leave_threshold=1, max_turn=T, tau=10.0, gamma_exposure=10.0, version="v1", r_decay=1.0, with_ab=True)
+    register_envs(tab, **envp)
+    st = make_reference_tracker(U, I, T, seed=31)
+    st.eval()
+    net, actor, critic = make_reference_policy(I, seed=6)
+    g = torch.Generator().manual_seed(23)
+    with torch.no_grad():
+        for p_ in list(actor.parameters()) + list(critic.parameters()):
+            if p_.dim() == 1:
+                p_.copy_(0.2 * torch.randn(p_.shape, generator=g))
+        actor.last.model[0].weight.mul_(3.0)
+    optim_RL = torch.optim.Adam(list(actor.parameters()) + list(critic.parameters()), lr=1e-3)
+    optim_state = torch.optim.Adam(st.parameters(), lr=1e-3)
+    env0 = gym.make("KuaishouEnv-v0")
+    policy = PPOPolicy(actor, critic, [optim_RL, optim_state], torch.distributions.Categorical, discount_factor=0.95, max_grad_norm=0.5,
+                       eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, reward_normalization=1, advantage_normalization=1, recompute_advantage=0,
+                       value_clip=1, gae_lambda=0.95, action_space=env0.action_space, action_bound_method="", action_scaling=False)
+    names = ["FB", "NX_0", f"NX_{K}"]
+    envs = {n: DummyVectorEnv([lambda: gym.make("KuaishouEnv-v0") for _ in range(B)]) for n in names}     # CIRS-RL-kuaishou.py:213-221
+    cs = CollectorSet(policy, envs, B * T, B, preprocess_fn=st.build_state, force_length=K)                  # :297-299
+
+    # ---- teacher-forced noise: q[name][t, env, item] ~ Exp(1); Categorical.sample := argmax(probs / q) (= torch.multinomial's race)
+    gq = torch.Generator().manual_seed(99)
+    noise = {n: torch.empty(T, B, I).exponential_(1.0, generator=gq) for n in names}
+    ctx = dict(name=None, t=0, env_ids=None, idx=None)
+    coll_of_policy_call = {id(c): n for n, c in cs.collector_dict.items()}
+
+    orig_forward = policy.forward
+
+    def forward_wrap(batch, buffer=None, remove_recommended_ids=False, state=None, **kw):
+        n_rows = len(batch.obs)
+        if len(buffer) == 0:
+            env_ids = np.arange(n_rows)
+        else:   # rows of self.data = live envs in ascending order (core/policy/utils.py:11 uses the same selection)
+            env_ids = np.where(~buffer.done[buffer.last_index])[0]
+        assert len(env_ids) == n_rows
+        ctx["env_ids"], ctx["idx"] = env_ids, None
+        out = orig_forward(batch, buffer=buffer, remove_recommended_ids=remove_recommended_ids, state=state, **kw)
+        ctx["t"] += 1
+        return out
+    policy.forward = forward_wrap
+
+    orig_remove = ref_ppo.removed_recommended_id_from_embedding
+
+    def remove_wrap(logits, recommended_ids):
+        lm, im = orig_remove(logits, recommended_ids)
+        ctx["idx"] = im
+        return lm, im
+    ref_ppo.removed_recommended_id_from_embedding = remove_wrap
+
+    def sample_patch(self, sample_shape=torch.Size()):
+        q = noise[ctx["name"]][ctx["t"]][torch.as_tensor(ctx["env_ids"])]
+        if ctx["idx"] is not None:
+            q = q.gather(1, ctx["idx"])
+        return torch.argmax(self.probs / q, dim=-1)
+    orig_sample = torch.distributions.Categorical.sample
+    torch.distributions.Categorical.sample = sample_patch
+
+    for n, c in cs.collector_dict.items():     # tell the patch which collector is running
+        oc = c.collect
+
+        def wrapped(*a, _oc=oc, _n=n, **k):
+            ctx["name"], ctx["t"] = _n, 0
+            return _oc(*a, **k)
+        c.collect = wrapped
+    random.seed(2468)
+    res = test_episode(policy, cs, None, 1, B, None, None)
+    torch.distributions.Categorical.sample = orig_sample
+    ref_ppo.removed_recommended_id_from_embedding = orig_remove
+
+    out = dict(dims=np.array([U, I, B, T, K]), seed_tables=np.int64(3),
+               env_params=np.array([envp["num_leave_compute"], envp["leave_threshold"], T]))
+    for n, c in cs.collector_dict.items():
+        buf = c.buffer
+        lens = np.array([len(b_) for b_ in buf.buffers])
+        acts = np.full((B, T), -1, np.int64); rews = np.zeros((B, T)); dones = np.zeros((B, T), bool)
+        for b in range(B):
+            sl = slice(buf._offset[b], buf._offset[b] + lens[b])
+            acts[b, :lens[b]] = buf.act[sl]; rews[b, :lens[b]] = buf.rew[sl]; dones[b, :lens[b]] = buf.done[sl]
+        out[f"{n}_users"] = np.array([int(np.asarray(w.env.cur_user).reshape(-1)[0]) for w in envs[n].workers])
+        out[f"{n}_acts"], out[f"{n}_rews"], out[f"{n}_dones"], out[f"{n}_buf_lens"] = acts, rews, dones, lens
+        out[f"{n}_gumbel"] = (-torch.log(noise[n])).numpy().astype(np.float32)
+    for k, v in res.items():
+        out["res_" + k.replace("/", "__")] = np.asarray(v)
+    out.update({"pol_" + k: v.detach().numpy() for k, v in policy.state_dict().items()})
+    out.update({"trk_" + k: v.detach().numpy() for k, v in st.state_dict().items()})
+    np.savez_compressed(os.path.join(GOLDEN, "collectorset.npz"), **out)
+    print("collectorset.npz: result keys", sorted(res), "FB lens", res["lens"].tolist(), "NX_0 lens", res["NX_0_lens"].tolist(),
+          f"NX_{K} lens", res[f"NX_{K}_lens"].tolist())
 
 
 # --------------------------------------------------------------------------------------------------
@@ -849,7 +958,7 @@ def gen_userval():
     print("userval.npz: x", out["x"].shape, "env table", out["env_values"].shape, list(out["env_columns"]))
 
 
-FAMILIES = {"userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+FAMILIES = {"collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

@@ -1,0 +1,118 @@
+"""GPU (one device, W virtual ranks as threads): BASELINE configs[4] in its SPLIT form -- row-sharded embedding tables (DeepFM user /
+item rows, tracker user / item rows: id mod W) with the all-to-all id / row exchange, actor head column-sharded over items with the
+fixed-order cross-rank (candidate, max, sum-exp) merge, envs sharded over the ranks -- must reproduce the single-device 2^20 run
+(DeviceRollout + OnlineReward, tests/test_gpu_online_reward.py): action ids and rewards BIT-IDENTICAL, states / log-probs to fp32
+round-off of the sum-exp merge order."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import deepfmcase
+import policycase
+import rolloutcase
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gather_rows_and_thread_comm_lookup():
+    from cirs_hip.sharded import ShardedTable, ThreadComm, hip_gather_rows
+    full = torch.randn(5003, 36, generator=torch.Generator().manual_seed(0)).cuda()
+    idx = torch.as_tensor(np.r_[np.random.RandomState(0).randint(0, 5003, 777), -1, -1]).cuda()
+    got = hip_gather_rows(full, idx)
+    assert torch.equal(got[:-2], full[idx[:-2]]) and float(got[-2:].abs().max()) == 0.0
+    W = 4
+    comms = ThreadComm.make(W)
+    res = [None] * W
+
+    def run(r):
+        torch.cuda.set_device(0)
+        tab = ShardedTable(ShardedTable.shard_of(full, r, W), 5003, comms[r])
+        ids = torch.as_tensor(np.random.RandomState(10 + r).randint(0, 5003, 129)).cuda()
+        res[r] = bool(torch.equal(tab.lookup(ids), full[ids])) and bool(torch.equal(tab.lookup(ids // W * W), full[ids // W * W]))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join(120) for t in th]
+    assert res == [True] * W
+
+
+@pytest.mark.parametrize("W,E", [(4, 64), (8, 16)])
+def test_sharded_rollout_bit_identical_to_single_device(W, E):
+    from cirs_hip.deepfm import DeviceDeepFM
+    from cirs_hip.env import DeviceEnv, DeviceEnvTables
+    from cirs_hip.policy import DevicePolicy
+    from cirs_hip.rollout import DeviceRollout, OnlineReward, Trajectory
+    from cirs_hip.sharded import ShardedRollout, ShardedTable, ThreadComm
+    from cirs_hip.tracker import DeviceTracker
+    U = I = 1 << 20
+    Bl, T = 32, 5
+    B = Bl * W
+    rng = np.random.RandomState(31 + W)
+    cats = np.where(np.arange(4)[None, :] < rng.randint(1, 5, I)[:, None], rng.randint(0, 31, (I, 4)), -1).astype(np.int32)
+    feats = np.where(cats >= 0, cats + 1, 0).astype(np.int32)
+    dur = rng.uniform(2, 60, I).astype(np.float32)
+    wfm = deepfmcase.random_weights(rng, U, I, E)
+    um = DeviceDeepFM(wfm)
+    ident = np.arange(I, dtype=np.int64)
+    mm = (-60.0, 60.0)
+    tp = rolloutcase.tracker_param_dict(U, I, T, 4)
+    arrs = policycase.random_weights(rng, I)
+    env_kw = dict(num_leave_compute=3, leave_threshold=1, max_turn=T, tau=10.0, gamma_exposure=10.0, dist_mode=1)
+    users = torch.as_tensor(rng.randint(0, U, B).astype(np.int32)).cuda()
+    seed, rng_base = 77, 40
+
+    # ---- everything on one device ----
+    dt = DeviceEnvTables(None, None, cats, n_users=U, n_items=I)
+    env = DeviceEnv(dt, B, **env_kw)
+    trk = DeviceTracker({k: v.float().cuda().contiguous() for k, v in tp.items()}, U, I, B, T)
+    pol = DevicePolicy({rolloutcase.POLICY_NAMES[k]: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in arrs.items()}, I)
+    ro = DeviceRollout(env, trk, pol, online=OnlineReward(um, ident, ident, feats, dur, mm, B))
+    lengths = ro.collect(users, seed=seed, rng_base=rng_base).cpu().numpy()
+    ref = {k: getattr(ro.traj, k).clone() for k in ("act", "rew", "done", "ctr", "obs", "logp", "value")}
+    assert lengths.min() >= 1 and int((ref["act"] >= 0).sum()) == int(lengths.sum())
+
+    # ---- W virtual ranks: tables / head split, envs split ----
+    fm_user_full = torch.zeros((U, E + 4)); fm_user_full[:, :E] = torch.as_tensor(wfm["emb_user"]); fm_user_full[:, E] = torch.as_tensor(wfm["lin_user"])
+    fm_item_full = torch.zeros((I, E + 4)); fm_item_full[:, :E] = torch.as_tensor(wfm["emb_item"]); fm_item_full[:, E] = torch.as_tensor(wfm["lin_item"])
+    trk_user_full, trk_item_full = tp["embedding_dict.feat_user.weight"].float(), tp["embedding_dict.feat_item.weight"].float()
+    comms = ThreadComm.make(W)
+    out, err = [None] * W, [None] * W
+    Is = I // W
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = comms[r]
+            dtl = DeviceEnvTables(None, None, cats, n_users=U, n_items=I)
+            envl = DeviceEnv(dtl, Bl, **env_kw)
+            tpl = {k: (v if not k.startswith("embedding_dict") else torch.zeros(4, 32)).float().cuda().contiguous() for k, v in tp.items()}
+            trkl = DeviceTracker(tpl, Bl, Bl, Bl, T)       # embedding tables are placeholders: rows come from the sharded lookup
+            wl = {k: (v if k not in ("emb_user", "emb_item", "lin_user", "lin_item") else np.zeros((4,) + v.shape[1:], np.float32)) for k, v in wfm.items()}
+            fml = DeviceDeepFM(wl)
+            shard = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)) for k, v in arrs.items()}
+            shard["wa"], shard["ba"] = shard["wa"][r * Is:(r + 1) * Is], shard["ba"][r * Is:(r + 1) * Is]
+            mk = lambda full, n: ShardedTable(ShardedTable.shard_of(full, r, W).cuda(), n, comm)  # noqa: E731
+            sr = ShardedRollout(comm, envl, trkl, Trajectory(Bl, T, 20, "cuda"), shard, r * Is, I, fml, mk(fm_user_full, U), mk(fm_item_full, I),
+                                mk(trk_user_full, U), mk(trk_item_full, I), ident, ident, feats, dur, mm)
+            ln = sr.collect(users[r * Bl:(r + 1) * Bl], seed=seed, rng_base=rng_base)
+            torch.cuda.synchronize()
+            out[r] = (sr.traj, ln.cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+            comms[r].s.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join(600) for t in th]
+    assert all(e is None for e in err), err
+    for r in range(W):
+        tr, ln = out[r]
+        sl = slice(r * Bl, (r + 1) * Bl)
+        assert np.array_equal(ln, lengths[sl])
+        assert torch.equal(tr.act, ref["act"][:, sl]), f"rank {r}: action ids differ from the single-device run"
+        assert torch.equal(tr.rew, ref["rew"][:, sl]), f"rank {r}: rewards differ from the single-device run"
+        assert torch.equal(tr.done, ref["done"][:, sl]) and torch.equal(tr.ctr, ref["ctr"][:, sl])
+        assert torch.equal(tr.value, ref["value"][:, sl])
+        live = (ref["act"][:, sl] >= 0)
+        assert torch.equal(tr.obs[0], ref["obs"][0, sl])
+        assert torch.equal(tr.obs[1:][live], ref["obs"][1:, sl][live]), "tracker states: same rows, same arithmetic -> same bits"
+        torch.testing.assert_close(tr.logp[live], ref["logp"][:, sl][live], rtol=2e-5, atol=2e-5)   # sum-exp folded in a different order
+    assert int(ref["act"].max()) >= I - I // W, "the sampler must reach the last rank's item shard"
