@@ -42,7 +42,7 @@ MAX_TRACKER_LAYERS = 4
 class TrackerCfg(C.Structure):
     _fields_ = [("n_users", C.c_int32), ("n_items", C.c_int32), ("dim_model", C.c_int32), ("dim_state", C.c_int32),
                 ("nhead", C.c_int32), ("d_hid", C.c_int32), ("nlayers", C.c_int32), ("max_len", C.c_int32),
-                ("n_env", C.c_int32)]
+                ("n_env", C.c_int32), ("dropout_p", C.c_float), ("drop_env_base", C.c_int32), ("dropout_seed", C.c_uint64)]
 
 
 class TrackerLayer(C.Structure):

@@ -70,7 +70,9 @@ class CirsEngine:
                  hidden=64, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
                  lr=1e-3, rew_norm=True, value_clip=True, norm_adv=True, seed=2023, tracker_params=None,
                  policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False, learner_mode="dp",
-                 online_reward=None, batch_size_hint=1024):
+                 online_reward=None, batch_size_hint=1024, dropout=0.0):
+        """dropout: probability of the tracker's five dropout sites.  0.0 (default) is the mode of every parity fixture and of
+        the benchmark; 0.1 reproduces the reference's training procedure, whose tracker is never put in eval()."""
         self.device = tables.device
         self.tables = tables
         self.n_env, self.max_turn, self.S, self.D = n_env, max_turn, dim_state, dim_model
@@ -89,7 +91,8 @@ class CirsEngine:
         self.tracker_flat, tviews = flat_tracker_params(tracker_param_shapes(U, I, dim_model, dim_state), device=self.device, init=tp)
         tparams = dict(tviews)
         tparams["pos_encoder.pe"] = tp["pos_encoder.pe"].to(self.device).float().contiguous()
-        self.tracker = DeviceTracker(tparams, U, I, n_env, max_turn, dim_model=dim_model, dim_state=dim_state, nhead=nhead, device=self.device)
+        self.tracker = DeviceTracker(tparams, U, I, n_env, max_turn, dim_model=dim_model, dim_state=dim_state, nhead=nhead, device=self.device,
+                                     dropout_p=dropout)
         self.tracker.enable_training(self.tracker_flat, lr=lr)
         pp = policy_params or init_policy_params(I, seed=seed, dim_state=dim_state, hidden=hidden)
         self.policy_flat, pviews = flat_policy_params(I, dim_state, hidden, device=self.device, init=pp)
@@ -97,6 +100,8 @@ class CirsEngine:
         self.tracker_views = tviews
         self.policy = DevicePolicy(pviews, I, dim_state=dim_state, hidden=hidden, device=self.device)
         self.rollout = DeviceRollout(self.env, self.tracker, self.policy, online=online_reward)
+        self.rollout.dropout_env_base = rank * n_env
+        self.rollout.dropout_key_from_high_bits = True
         self.B_total = n_env * world_size
         self.learner = DeviceLearner(self.policy_flat, I, self.B_total, max_turn, dim_state=dim_state, hidden=hidden, gamma=gamma,
                                      gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,

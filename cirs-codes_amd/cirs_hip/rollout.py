@@ -81,6 +81,9 @@ class DeviceRollout:
         words = (policy.n_items + 31) // 32
         self.visited = torch.zeros((env.n_env, words), dtype=torch.int32, device=self.device) if remove_recommended_ids else None
         self._lib = abi.lib()
+        # dropout masks are defined per GLOBAL env of a multi-rank job: key shared by the ranks, env ids offset per rank
+        self.dropout_env_base = 0
+        self.dropout_key_from_high_bits = False   # CirsEngine packs (seed << 8) + rank into the sampler seed
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -124,6 +127,8 @@ class DeviceRollout:
         """One `collect(n_episode = n_env)`: all envs run to the end of their episode.  Returns (n_steps, lengths).
         sync_every: poll the live-env count every that many steps to stop early (None: run all max_turn steps
         without any host sync; idle steps of finished envs are no-ops)."""
+        if self.tracker.cfg.dropout_p > 0:   # fresh masks per collect (the reference draws fresh dropout noise at every call)
+            self.tracker.set_dropout_key(seed >> 8 if self.dropout_key_from_high_bits else seed, rng_base, self.dropout_env_base)
         self.reset(users)
         T = self.env.max_turn
         if gumbel is not None:

@@ -80,10 +80,11 @@ class DeviceTracker:
     """KV-cached tracker state for B envs.  `params` maps reference state_dict names to device tensors."""
 
     def __init__(self, params: Dict[str, torch.Tensor], n_users, n_items, n_env, max_turn, *, dim_model=32,
-                 dim_state=20, nhead=4, d_hid=128, nlayers=2, device="cuda"):
+                 dim_state=20, nhead=4, d_hid=128, nlayers=2, device="cuda", dropout_p=0.0):
         self.device = torch.device(device)
         self.cfg = abi.TrackerCfg(n_users=n_users, n_items=n_items, dim_model=dim_model, dim_state=dim_state,
-                                  nhead=nhead, d_hid=d_hid, nlayers=nlayers, max_len=max_turn + 1, n_env=n_env)
+                                  nhead=nhead, d_hid=d_hid, nlayers=nlayers, max_len=max_turn + 1, n_env=n_env,
+                                  dropout_p=float(dropout_p), drop_env_base=0, dropout_seed=0)
         self.params = params
         pe = params.get("pos_encoder.pe")
         if pe is None:
@@ -101,6 +102,20 @@ class DeviceTracker:
                                    vcache=self.vcache.data_ptr(), len=self.len.data_ptr())
         self._lib = abi.lib()
         self.dim_state = dim_state
+
+    def set_dropout(self, p: float):
+        """Dropout probability of the five sites (0 = off: the mode of every reference-recorded fixture)."""
+        assert 0.0 <= p < 1.0
+        self.cfg.dropout_p = float(p)
+
+    def set_dropout_key(self, seed: int, tag: int = 0, env_base: int = 0):
+        """Mask key of the rollout about to start: masks are a pure function of (key, env_base + env, position, layer, site,
+        element); the backward of THIS rollout's buffer regenerates them from the same key.  Every rank of a job uses the same
+        (seed, tag) and its own env_base = rank * n_env, so masks are defined per global env."""
+        mix = (int(seed) * 0x9E3779B97F4A7C15 + (int(tag) + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        mix ^= mix >> 29
+        self.cfg.dropout_seed = mix
+        self.cfg.drop_env_base = int(env_base)
 
     def refresh_weights(self):
         self.w = weights_struct(self.params, self.pe, self.nlayers)
@@ -128,6 +143,7 @@ class DeviceTracker:
         if x_hist is not None:
             cfg = abi.TrackerCfg.from_buffer_copy(self.cfg)
             cfg.n_env = x_hist.shape[0]
+            cfg.drop_env_base = 0      # rows of a gathered buffer carry GLOBAL env ids already
             st = abi.TrackerState(x_hist=x_hist.data_ptr(), kcache=self.kcache.data_ptr(), vcache=self.vcache.data_ptr(),
                                   len=self.len.data_ptr())
         need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(cfg), n_rows)

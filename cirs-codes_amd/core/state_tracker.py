@@ -22,7 +22,10 @@ class StateTrackerTransformer(nn.Module):
         self.dim_model, self.dim_state, self.nhead, self.d_hid, self.nlayers = dim_model, dim_state, nhead, d_hid, nlayers
         self.MAX_TURN = MAX_TURN + 1
         self.n_users, self.n_items = user_columns[0].vocabulary_size, action_columns[0].vocabulary_size
-        self.dropout_p = dropout  # the device path runs with dropout off
+        # nn.Dropout(p) of PositionalEncoding and of both encoder layers (core/state_tracker.py:155-156): live while the module is in
+        # training mode -- which in the reference's scripts is ALWAYS (the tracker is not a sub-module of the policy, so
+        # policy.eval() never reaches it).  state_tracker.eval() switches it off (the mode of the parity fixtures).
+        self.dropout_p = float(dropout)
         init = init_tracker_params(self.n_users, self.n_items, MAX_TURN, seed=seed, dim_model=dim_model, dim_state=dim_state,
                                    nhead=nhead, d_hid=d_hid, nlayers=nlayers, init_std=init_std)
         shapes = tracker_param_shapes(self.n_users, self.n_items, dim_model, dim_state, d_hid, nlayers)
@@ -74,6 +77,7 @@ class StateTrackerTransformer(nn.Module):
             eng = DeviceTracker(params, self.n_users, self.n_items, n_env, self.MAX_TURN - 1, dim_model=self.dim_model,
                                 dim_state=self.dim_state, nhead=self.nhead, d_hid=self.d_hid, nlayers=self.nlayers,
                                 device=self.device)
+            eng.set_dropout(self.dropout_p if self.training else 0.0)
             eng.enable_training(self.flat)
             if self._train_state is None:
                 self._train_state = (eng.flat_grad, eng.grad_views, eng.g, eng.adam_m, eng.adam_v)
@@ -83,6 +87,12 @@ class StateTrackerTransformer(nn.Module):
         if owner is None:
             self._n_env = n_env
         return self._engines[key]
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        for eng in getattr(self, "_engines", {}).values():
+            eng.set_dropout(self.dropout_p if mode else 0.0)
+        return self
 
     def build_state(self, obs=None, env_id=None, obs_next=None, rew=None, done=None, info=None, policy=None, dim_batch=None,
                     reset=False):

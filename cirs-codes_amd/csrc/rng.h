@@ -80,4 +80,28 @@ __host__ __device__ __forceinline__ float actor_gumbel(uint64_t seed, uint32_t r
     return gumbel_from_bits(x);
 }
 
+// ---- dropout masks of the state tracker (production mode) ---------------------------------------------------
+// The reference never puts the tracker in eval(): nn.Dropout(p = 0.1) is live at five kinds of sites (core/state_tracker.py:155-156,
+// 176; torch TransformerEncoderLayer): 0 = PositionalEncoding output, 1 = attention probabilities, 2 = attention-branch residual
+// (dropout1), 3 = feed-forward hidden (dropout), 4 = feed-forward residual (dropout2).  Here every keep / drop decision is a pure
+// function of (seed, env, position, layer, site, element): Philox counter (element >> 2, env, position | site << 12 | layer << 16,
+// 'DROP'), key = seed, word element & 3; keep iff word >= thr with thr = floor(p * 2^32).  A position keeps its masks for the
+// rest of the episode, which is what makes the K/V-cached decode step and the row-parallel backward recompute consistent.
+#define CIRS_RNG_STREAM_DROPOUT 0x44524F50u /* 'DROP' */
+enum { CIRS_DROP_POS = 0, CIRS_DROP_ATTN = 1, CIRS_DROP_RES1 = 2, CIRS_DROP_FF = 3, CIRS_DROP_RES2 = 4 };
+
+__host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)((double)p * 4294967296.0); }
+
+__host__ __device__ __forceinline__ u32x4 dropout_block(uint64_t seed, uint32_t env, uint32_t pos, uint32_t layer, uint32_t site,
+                                                        uint32_t elem_group) {
+    return philox4x32_10(elem_group, env, pos | (site << 12) | (layer << 16), CIRS_RNG_STREAM_DROPOUT, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__host__ __device__ __forceinline__ uint32_t block_word(const u32x4& r, uint32_t sel) {
+    return sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
+}
+__host__ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t env, uint32_t pos, uint32_t layer, uint32_t site,
+                                                      uint32_t elem, uint32_t thr) {
+    return block_word(dropout_block(seed, env, pos, layer, site, elem >> 2), elem & 3u) >= thr;
+}
+
 }  // namespace cirs

@@ -73,7 +73,7 @@ __device__ __forceinline__ float layer_norm32(float v, int lane, const float* __
     return dlt * inv * w[o] + b[o];
 }
 
-template <int NHEAD>
+template <int NHEAD, bool DROP>
 __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w,
                                                            cirs_tracker_state st, const int32_t* __restrict__ users,
                                                            const int64_t* __restrict__ items,
@@ -170,6 +170,13 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     if (lane < kD) st.x_hist[((size_t)e * L + pos) * kD + lane] = x;
     // ---- 2. scale + positional encoding ---------------------------------------------------------------------
     float h = x * 5.656854249492381f + w.pe[(size_t)pos * kD + o32];  // sqrt(32)
+    // dropout (DROP): counter-based masks keyed by (seed, global env, position, layer, site, element), csrc/rng.h
+    const uint32_t d_thr = DROP ? dropout_threshold(cfg.dropout_p) : 0u;
+    const float d_inv = DROP ? 1.0f / (1.0f - cfg.dropout_p) : 1.0f;
+    const uint32_t d_env = (uint32_t)(cfg.drop_env_base + e);
+#define CIRS_DROP(V, LAYER, SITE, ELEM) \
+    (dropout_keep(cfg.dropout_seed, d_env, (uint32_t)pos, (uint32_t)(LAYER), (uint32_t)(SITE), (uint32_t)(ELEM), d_thr) ? (V) * d_inv : 0.f)
+    if (DROP) h = CIRS_DROP(h, 0, CIRS_DROP_POS, o32);
 
     // ---- 3. encoder layers ----------------------------------------------------------------------------------
     RowRegs<kD> pq = load_row<kD>(w.layer[0].in_proj_w + (size_t)lane * kD);                    // rows 0..63 (q, k)
@@ -230,7 +237,8 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
 #pragma unroll
             for (int hh = 0; hh < NHEAD; ++hh) {
                 const float pexp = expf(ps[hh * lpad + jp] - mx[hh]);
-                ps[hh * lpad + jp] = pexp;
+                // attention-probability dropout acts AFTER the softmax: the normaliser sums the unmasked terms
+                ps[hh * lpad + jp] = DROP ? CIRS_DROP(pexp, l, CIRS_DROP_ATTN, jp * NHEAD + hh) : pexp;
                 sm[hh] += pexp;
             }
         }
@@ -257,7 +265,8 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         const float bf0 = ly.lin1_b[lane], bf1 = ly.lin1_b[64 + lane];
         __builtin_amdgcn_wave_barrier();
         // out_proj + residual + LN1
-        const float sa = dot_pre<kD>(po, att, bo);
+        float sa = dot_pre<kD>(po, att, bo);
+        if (DROP) sa = CIRS_DROP(sa, l, CIRS_DROP_RES1, o32);
         const float h1 = layer_norm32(h + sa, lane, ly.norm1_w, ly.norm1_b);
         __builtin_amdgcn_wave_barrier();
         if (lane < kD) tmp[lane] = h1;
@@ -267,8 +276,12 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         const float bl2 = half2 == 0 ? ly.lin2_b[o32] : 0.f;
         __builtin_amdgcn_wave_barrier();
         // FF: 128 hidden = 2 rows per lane
-        ffs[lane] = fmaxf(dot_pre<kD>(pf0, tmp, bf0), 0.f);
-        ffs[64 + lane] = fmaxf(dot_pre<kD>(pf1, tmp, bf1), 0.f);
+        {
+            float f0 = fmaxf(dot_pre<kD>(pf0, tmp, bf0), 0.f), f1 = fmaxf(dot_pre<kD>(pf1, tmp, bf1), 0.f);
+            if (DROP) { f0 = CIRS_DROP(f0, l, CIRS_DROP_FF, lane); f1 = CIRS_DROP(f1, l, CIRS_DROP_FF, 64 + lane); }
+            ffs[lane] = f0;
+            ffs[64 + lane] = f1;
+        }
         // prefetch the next layer's in_proj rows (or nothing after the last layer)
         if (l + 1 < cfg.nlayers) {
             pq = load_row<kD>(w.layer[l + 1].in_proj_w + (size_t)lane * kD);
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         {
             float acc = dot_pre<64>(pl2, ffs + half2 * 64, bl2);
             acc += __shfl_xor(acc, 32, CIRS_WAVE);
+            if (DROP) acc = CIRS_DROP(acc, l, CIRS_DROP_RES2, o32);
             h = layer_norm32(h1 + acc, lane, ly.norm2_w, ly.norm2_b);
         }
         __builtin_amdgcn_wave_barrier();
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         trunk_compute(tf.cfg, tf.w, txs, ths, lane, j, tf.h2, tf.value, nullptr);
     }
 #undef CIRS_TRUNK_ZERO
+#undef CIRS_DROP
 }
 
 static int validate_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st) {
@@ -336,9 +351,17 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
     const size_t shmem = 4 * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad);
     if (shmem > 160 * 1024) return fail(CIRS_E_UNSUPPORTED, "max_len too large for the LDS score buffer");
     const dim3 grid(cdiv(n, 4)), block(256);
-#define CIRS_TRK(NH)                                                                                              \
-    hipLaunchKernelGGL(tracker_step_kernel<NH>, grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
-                       n, state_out, state_stride, lpad, tf, tl)
+    const bool drop = cfg->dropout_p > 0.f;
+    if (drop && !(cfg->dropout_p < 1.f)) return fail(CIRS_E_INVALID, "dropout_p must be in [0, 1)");
+#define CIRS_TRK(NH)                                                                                                  \
+    do {                                                                                                              \
+        if (drop)                                                                                                     \
+            hipLaunchKernelGGL((tracker_step_kernel<NH, true>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
+                               n, state_out, state_stride, lpad, tf, tl);                                             \
+        else                                                                                                          \
+            hipLaunchKernelGGL((tracker_step_kernel<NH, false>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
+                               n, state_out, state_stride, lpad, tf, tl);                                             \
+    } while (0)
     switch (cfg->nhead) {
         case 1: CIRS_TRK(1); break;
         case 2: CIRS_TRK(2); break;

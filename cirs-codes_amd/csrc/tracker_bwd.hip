@@ -10,21 +10,44 @@
 //   embedding tables : per-row contributions, then one wavefront per table row sums its rows in a fixed order
 #include <hipcub/hipcub.hpp>
 #include "small_gemm.h"
+#include "rng.h"
 
 namespace cirs {
 
 constexpr int tD = 32, tH = 128;
 constexpr int kChunkRows = 256;
 
+// dropout of the recompute / backward (production mode): the masks the forward decode steps applied, regenerated from their
+// counters (csrc/rng.h); on == 0: every kernel below is the dropout-free code path, bit for bit
+struct DropCfg {
+    int on;
+    uint32_t thr;
+    float inv;
+    uint64_t seed;
+    int env_base;
+};
+__device__ __forceinline__ float drop_apply(const DropCfg& dc, float v, int env, int pos, int layer, int site, int elem) {
+    return dropout_keep(dc.seed, (uint32_t)(dc.env_base + env), (uint32_t)pos, (uint32_t)layer, (uint32_t)site, (uint32_t)elem, dc.thr) ? v * dc.inv : 0.f;
+}
+// elementwise: out[r, c] = mask(row r's (env, position), layer, site, c) * in[r, c]   (N columns per row; in == out allowed)
+__global__ __launch_bounds__(256) void drop_rows(DropCfg dc, const float* __restrict__ in, const int32_t* __restrict__ row_env,
+                                                 const int32_t* __restrict__ row_t, int R, int N, int layer, int site, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)R * N) return;
+    const int r = (int)(i / N), c = (int)(i % N);
+    out[i] = drop_apply(dc, in[i], row_env[r], row_t[r], layer, site, c);
+}
+
 // slot gather + scale + positional encoding: X0[r] = x_hist[b,p], H0 = X0*sqrt(D) + pe[p]
 __global__ __launch_bounds__(256) void embed_rows(const float* __restrict__ x_hist, const float* __restrict__ pe,
                                                   const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t, int R,
-                                                  int L, float* __restrict__ H0) {
+                                                  int L, float* __restrict__ H0, DropCfg dc) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= (long)R * tD) return;
     const int r = (int)(i / tD), d = (int)(i % tD);
     const int b = row_env[r], p = row_t[r];
-    H0[i] = x_hist[((size_t)b * L + p) * tD + d] * 5.656854249492381f + pe[(size_t)p * tD + d];
+    const float h = x_hist[((size_t)b * L + p) * tD + d] * 5.656854249492381f + pe[(size_t)p * tD + d];
+    H0[i] = dc.on ? drop_apply(dc, h, b, p, 0, CIRS_DROP_POS, d) : h;
 }
 
 // causal attention forward, one wavefront per row; Q/K/V live in QKV[R,96]; P[R,NH,Lp] keeps the probabilities for
@@ -32,7 +55,9 @@ __global__ __launch_bounds__(256) void embed_rows(const float* __restrict__ x_hi
 template <int NH>
 __global__ __launch_bounds__(256) void attn_fwd(const float* __restrict__ QKV, const int32_t* __restrict__ row_env,
                                                 const int32_t* __restrict__ row_t, const int32_t* __restrict__ offsets, int R,
-                                                int Lp, float* __restrict__ P, float* __restrict__ ATT) {
+                                                int Lp, float* __restrict__ P, float* __restrict__ ATT, DropCfg dc, int layer,
+                                                float* __restrict__ PM) {
+    // dc.on: PM [R, NH, Lp] receives the probabilities AFTER the attention dropout (what multiplies V); P stays the softmax
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = tD / NH;
     const int lane = threadIdx.x & 63;
@@ -75,8 +100,14 @@ __global__ __launch_bounds__(256) void attn_fwd(const float* __restrict__ QKV, c
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const float pr = ps[h * Lp + jp] * sm[h];
-            ps[h * Lp + jp] = pr;
             Pr[h * Lp + jp] = pr;
+            if (dc.on) {
+                const float pm = drop_apply(dc, pr, row_env[r], p, layer, CIRS_DROP_ATTN, jp * NH + h);
+                PM[(size_t)r * NH * Lp + h * Lp + jp] = pm;
+                ps[h * Lp + jp] = pm;
+            } else {
+                ps[h * Lp + jp] = pr;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -92,7 +123,8 @@ template <int NH>
 __global__ __launch_bounds__(256) void attn_bwd_q(const float* __restrict__ QKV, const float* __restrict__ P, const float* __restrict__ dATT,
                                                   const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t,
                                                   const int32_t* __restrict__ offsets, int R, int Lp, float* __restrict__ dS,
-                                                  float* __restrict__ dQKV) {
+                                                  float* __restrict__ dQKV, const float* __restrict__ PM, float drop_inv) {
+    // PM (nullable): probabilities after the attention dropout; dP = dPM * (kept ? 1/(1-p) : 0), kept <=> PM != 0 (or P == 0)
     constexpr int HD = tD / NH;
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -114,6 +146,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q(const float* __restrict__ QKV,
             float dp = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) dp = __builtin_fmaf(da[h * HD + d], v[h * HD + d], dp);
+            if (PM) dp = PM[(size_t)r * NH * Lp + h * Lp + jp] != 0.f ? dp * drop_inv : 0.f;
             dSr[h * Lp + jp] = dp;  // dP for now
             dot[h] = __builtin_fmaf(Pr[h * Lp + jp], dp, dot[h]);
         }
@@ -185,13 +218,16 @@ __device__ __forceinline__ float half_sum32(float v) {
 // y = Y + Y2 (residual); out = (y - mean) * rstd * g + b ; xhat and rstd kept for the backward
 __global__ __launch_bounds__(256) void ln_fwd(const float* __restrict__ Y, const float* __restrict__ Y2, const float* __restrict__ g,
                                               const float* __restrict__ b, int R, float* __restrict__ xhat, float* __restrict__ rstd,
-                                              float* __restrict__ out) {
+                                              float* __restrict__ out, DropCfg dc, const int32_t* __restrict__ row_env,
+                                              const int32_t* __restrict__ row_t, int layer, int site) {
     static_assert(tD == 32, "one half-wave per row");
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const long r = i >> 5;
     const int d = (int)(i & 31);
     const bool ok = r < R;
-    const float y = ok ? Y[i] + Y2[i] : 0.f;   // the pre-LayerNorm residual sum rides along
+    float y2 = ok ? Y2[i] : 0.f;
+    if (dc.on && ok) y2 = drop_apply(dc, y2, row_env[r], row_t[r], layer, site, d);   // dropout1 / dropout2 on the branch
+    const float y = ok ? Y[i] + y2 : 0.f;   // the pre-LayerNorm residual sum rides along
     const float mean = half_sum32(y) * (1.0f / tD);
     const float t = y - mean;
     const float var = half_sum32(t * t) * (1.0f / tD);
@@ -217,6 +253,11 @@ __global__ __launch_bounds__(256) void ln_bwd(const float* __restrict__ dOut, co
 }
 // (the LayerNorm weight gradient d gamma = diag(dOut^T xhat) and d beta = column sums of dOut fall out of a 32 x 32 dW
 // problem with the diag flag: dw_list_final keeps the diagonal)
+
+__global__ __launch_bounds__(256) void scale_rows(float* __restrict__ x, long n, float a) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= a;
+}
 
 // upstream gradient rows: G[r, s] = dstate[row_t, row_env, s]
 __global__ __launch_bounds__(256) void gather_dstate(const float* __restrict__ dstate, const int32_t* __restrict__ row_env,
@@ -399,7 +440,8 @@ struct BwdScratch {
     float *QKV[CIRS_MAX_TRACKER_LAYERS], *P[CIRS_MAX_TRACKER_LAYERS], *ATT[CIRS_MAX_TRACKER_LAYERS];
     float *XH1[CIRS_MAX_TRACKER_LAYERS], *RS1[CIRS_MAX_TRACKER_LAYERS], *H1N[CIRS_MAX_TRACKER_LAYERS], *FF1[CIRS_MAX_TRACKER_LAYERS];
     float *XH2[CIRS_MAX_TRACKER_LAYERS], *RS2[CIRS_MAX_TRACKER_LAYERS];
-    float *T0, *T1, *T2, *dQKV, *dFF1, *dS, *partial, *GIN;
+    float *T0, *T1, *T2, *T3, *dQKV, *dFF1, *dS, *partial, *GIN;
+    float* PM[CIRS_MAX_TRACKER_LAYERS];   // dropout: attention probabilities after the mask
     void* sort;  // emb_sort_bytes(R)
 };
 
@@ -416,7 +458,8 @@ static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     f += (size_t)R * 32;                          // G (S <= 32)
     f += (size_t)(nl + 1) * R * tD;               // H
     f += (size_t)nl * R * (96 + NH * Lp + tD + tD + 1 + tD + tH + tD + 1);
-    f += 3 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp;  // T0..2, dQKV, dFF1, dS
+    f += 4 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp;  // T0..3, dQKV, dFF1, dS
+    if (cfg->dropout_p > 0.f) f += (size_t)nl * R * NH * Lp + 64;                      // PM
     f += bwd_partial_floats(cfg, R) + 4096;       // slab partials of every dW problem of the pass (one final launch)
     f += (size_t)R * (tD + 1);                    // GIN
     f += emb_sort_bytes(R) / 4 + 64;              // (key, row) sort of the embedding scatter
@@ -435,7 +478,8 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
         s.XH1[l] = take((size_t)R * tD); s.RS1[l] = take(R); s.H1N[l] = take((size_t)R * tD); s.FF1[l] = take((size_t)R * tH);
         s.XH2[l] = take((size_t)R * tD); s.RS2[l] = take(R);
     }
-    s.T0 = take((size_t)R * tD); s.T1 = take((size_t)R * tD); s.T2 = take((size_t)R * tD);
+    s.T0 = take((size_t)R * tD); s.T1 = take((size_t)R * tD); s.T2 = take((size_t)R * tD); s.T3 = take((size_t)R * tD);
+    for (int l = 0; l < nl; ++l) s.PM[l] = cfg->dropout_p > 0.f ? take((size_t)R * NH * Lp) : nullptr;
     s.dQKV = take((size_t)R * 96); s.dFF1 = take((size_t)R * tH); s.dS = take((size_t)R * NH * Lp);
     s.partial = take(bwd_partial_floats(cfg, R) + 4096);
     s.GIN = take((size_t)R * (tD + 1));
@@ -479,17 +523,27 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     } while (0)
 #define ATT_DISPATCH(KERNEL, ...) ATT_DISPATCH_SH(KERNEL, 0, __VA_ARGS__)
 
+    DropCfg dc{};
+    if (cfg->dropout_p > 0.f) {
+        CIRS_REQUIRE(cfg->dropout_p < 1.f, "dropout_p must be in [0, 1)");
+        dc.on = 1; dc.thr = dropout_threshold(cfg->dropout_p); dc.inv = 1.0f / (1.0f - cfg->dropout_p);
+        dc.seed = cfg->dropout_seed; dc.env_base = cfg->drop_env_base;
+    }
     // ---------------- forward recompute ----------------
-    hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0]);
+    hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0], dc);
     for (int l = 0; l < nl; ++l) {
         const cirs_tracker_layer& y = w->layer[l];
         launch_rows_gemm(true, sc.H[l], tD, y.in_proj_w, tD, y.in_proj_b, R, tD, 96, 0, nullptr, 0, sc.QKV[l], 96, s);
-        ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l]);
+        ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l], dc, l, sc.PM[l]);
         launch_rows_gemm(true, sc.ATT[l], tD, y.out_proj_w, tD, y.out_proj_b, R, tD, tD, 0, nullptr, 0, sc.T0, tD, s);
-        hipLaunchKernelGGL(ln_fwd, g1((long)R * tD), dim3(256), 0, s, sc.H[l], sc.T0, y.norm1_w, y.norm1_b, R, sc.XH1[l], sc.RS1[l], sc.H1N[l]);
+        hipLaunchKernelGGL(ln_fwd, g1((long)R * tD), dim3(256), 0, s, sc.H[l], sc.T0, y.norm1_w, y.norm1_b, R, sc.XH1[l], sc.RS1[l], sc.H1N[l],
+                           dc, row_env, row_t, l, (int)CIRS_DROP_RES1);
         launch_rows_gemm(true, sc.H1N[l], tD, y.lin1_w, tD, y.lin1_b, R, tD, tH, 1, nullptr, 0, sc.FF1[l], tH, s);
+        if (dc.on)   // FF1 holds relu(.) * mask / (1 - p): the input of lin2, the relu-and-dropout gate of the backward
+            hipLaunchKernelGGL(drop_rows, g1((long)R * tH), dim3(256), 0, s, dc, (const float*)sc.FF1[l], row_env, row_t, R, tH, l, (int)CIRS_DROP_FF, sc.FF1[l]);
         launch_rows_gemm(true, sc.FF1[l], tH, y.lin2_w, tH, y.lin2_b, R, tH, tD, 0, nullptr, 0, sc.T0, tD, s);
-        hipLaunchKernelGGL(ln_fwd, g1((long)R * tD), dim3(256), 0, s, sc.H1N[l], sc.T0, y.norm2_w, y.norm2_b, R, sc.XH2[l], sc.RS2[l], sc.H[l + 1]);
+        hipLaunchKernelGGL(ln_fwd, g1((long)R * tD), dim3(256), 0, s, sc.H1N[l], sc.T0, y.norm2_w, y.norm2_b, R, sc.XH2[l], sc.RS2[l], sc.H[l + 1],
+                           dc, row_env, row_t, l, (int)CIRS_DROP_RES2);
     }
     CIRS_CHECK_LAUNCH("tracker forward recompute");
     // ---------------- backward ----------------
@@ -504,9 +558,16 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         launch_dw_partial(dwl, dH, tD, sc.XH2[l], tD, R, tD, tD, gy.norm2_w, gy.norm2_b, 1, sc.partial, s);   // diag(dH^T Xhat), column sums
         float* dY2 = sc.T1;
         hipLaunchKernelGGL(ln_bwd, g1((long)R * tD), dim3(256), 0, s, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2);
-        // FF
-        DW(dY2, sc.FF1[l], tD, tH, gy.lin2_w, gy.lin2_b);
-        launch_rows_gemm(false, dY2, tD, y.lin2_w, tH, nullptr, R, tD, tH, 0, sc.FF1[l], 0, sc.dFF1, tH, s);
+        // FF: with dropout the lin2 branch sees dY2 * mask2 / (1 - p) (the residual keeps dY2) and the gate of the hidden layer is
+        // relu' * mask_ff / (1 - p): FF1 > 0 already encodes "relu active and kept", the scale is applied to dFF1
+        const float* dB2 = dY2;
+        if (dc.on) {
+            hipLaunchKernelGGL(drop_rows, g1((long)R * tD), dim3(256), 0, s, dc, (const float*)dY2, row_env, row_t, R, tD, l, (int)CIRS_DROP_RES2, sc.T3);
+            dB2 = sc.T3;
+        }
+        DW(dB2, sc.FF1[l], tD, tH, gy.lin2_w, gy.lin2_b);
+        launch_rows_gemm(false, dB2, tD, y.lin2_w, tH, nullptr, R, tD, tH, 0, sc.FF1[l], 0, sc.dFF1, tH, s);
+        if (dc.on) hipLaunchKernelGGL(scale_rows, g1((long)R * tH), dim3(256), 0, s, sc.dFF1, (long)R * tH, dc.inv);
         DW(sc.dFF1, sc.H1N[l], tH, tD, gy.lin1_w, gy.lin1_b);
         // d H1N = dY2 (residual) + dFF1 * W1
         launch_rows_gemm(false, sc.dFF1, tH, y.lin1_w, tD, nullptr, R, tH, tD, 0, nullptr, 1, dY2, tD, s);
@@ -514,13 +575,19 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         launch_dw_partial(dwl, dY2, tD, sc.XH1[l], tD, R, tD, tD, gy.norm1_w, gy.norm1_b, 1, sc.partial, s);
         float* dY1 = sc.T2;
         hipLaunchKernelGGL(ln_bwd, g1((long)R * tD), dim3(256), 0, s, dY2, sc.XH1[l], sc.RS1[l], y.norm1_w, R, dY1);
-        // out_proj
-        DW(dY1, sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b);
+        // out_proj (its branch sees dY1 * mask1 / (1 - p); the residual keeps dY1)
+        const float* dB1 = dY1;
+        if (dc.on) {
+            hipLaunchKernelGGL(drop_rows, g1((long)R * tD), dim3(256), 0, s, dc, (const float*)dY1, row_env, row_t, R, tD, l, (int)CIRS_DROP_RES1, sc.T3);
+            dB1 = sc.T3;
+        }
+        DW(dB1, sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b);
         float* dATT = sc.T1;
-        launch_rows_gemm(false, dY1, tD, y.out_proj_w, tD, nullptr, R, tD, tD, 0, nullptr, 0, dATT, tD, s);
-        // attention
-        ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV);
-        ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
+        launch_rows_gemm(false, dB1, tD, y.out_proj_w, tD, nullptr, R, tD, tD, 0, nullptr, 0, dATT, tD, s);
+        // attention (dropout: V is weighted by the masked probabilities PM; the softmax backward runs on P)
+        ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV,
+                        (const float*)sc.PM[l], dc.inv);
+        ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], dc.on ? sc.PM[l] : sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
         // in_proj
         DW(sc.dQKV, sc.H[l], 96, tD, gy.in_proj_w, gy.in_proj_b);
         // d H_l = dY1 (residual) + dQKV * W_in
@@ -532,6 +599,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         }
     }
     CIRS_CHECK_LAUNCH("tracker backward layers");
+    if (dc.on)   // gradient through the PositionalEncoding dropout
+        hipLaunchKernelGGL(drop_rows, g1((long)R * tD), dim3(256), 0, s, dc, (const float*)dH, row_env, row_t, R, tD, 0, (int)CIRS_DROP_POS, dH);
     // input slots + embeddings (forward activations are no longer needed: reuse their scratch)
     float* DU = sc.T1;
     float* EU = sc.H[nl];

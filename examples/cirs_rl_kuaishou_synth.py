@@ -65,6 +65,7 @@ def get_args(argv=None):
     p.add_argument("--force_length", type=int, default=10)
     p.add_argument("--step-per-epoch", type=int, default=2000)
     p.add_argument("--top_rate", type=float, default=0.8)
+    p.add_argument("--dropout", type=float, default=0.1, help="state-tracker dropout (live during rollout and update, like the reference)")
     p.add_argument("--n-users", type=int, default=1411)
     p.add_argument("--n-items", type=int, default=3327)
     return p.parse_args(argv)
@@ -98,7 +99,7 @@ def build(args, table_seed=0):
                                             dim_state=args.dim_state, dim_max_batch=args.training_num, dataset=args.env,
                                             has_user_embedding=has_user_embedding, has_action_embedding=has_action_embedding,
                                             has_feedback_embedding=has_feedback_embedding, nhead=args.nhead, d_hid=128, nlayers=2,
-                                            dropout=0.1, device=device, seed=args.seed, MAX_TURN=args.max_turn).to(device)
+                                            dropout=args.dropout, device=device, seed=args.seed, MAX_TURN=args.max_turn).to(device)
     net = Net(args.dim_state, hidden_sizes=args.hidden_sizes, device=device)
     actor = Actor(net, env.mat.shape[1], device=device).to(device)
     critic = Critic(net, device=device).to(device)

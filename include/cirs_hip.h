@@ -118,6 +118,12 @@ typedef struct cirs_tracker_cfg {
     int32_t nlayers;   /* 2 */
     int32_t max_len;   /* MAX_TURN + 1 (state_tracker.py:144) */
     int32_t n_env;     /* B: leading dimension of the state arrays */
+    /* dropout (production mode; 0 = off, the mode every reference-recorded fixture uses).  The reference runs the tracker with
+     * nn.Dropout(0.1) live in rollout, test and backward (core/state_tracker.py:155-156,176; never eval(), CIRS-RL-kuaishou.py:235-243).
+     * Masks are counter-based: a pure function of (dropout_seed, drop_env_base + env, position, layer, site, element), see csrc/rng.h. */
+    float dropout_p;
+    int32_t drop_env_base; /* added to the local env index: global env id of the job (rank * n_env), same in forward and backward */
+    uint64_t dropout_seed; /* changes per collect (seed, collect counter) */
 } cirs_tracker_cfg;
 
 typedef struct cirs_tracker_layer { /* names: transformer_encoder.layers.<l>.*  */

@@ -43,14 +43,60 @@ def tracker_inputs(p, users, acts, rews):
     return torch.cat([x0.unsqueeze(1), g * a], dim=1)
 
 
-def tracker_forward_all(p, x_hist, nhead=4, nlayers=2):
+# ---- counter-based dropout masks (production mode): numpy restatement of csrc/rng.h -------------------------------
+DROP_POS, DROP_ATTN, DROP_RES1, DROP_FF, DROP_RES2 = 0, 1, 2, 3, 4
+_STREAM_DROPOUT = 0x44524F50
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11) on uint32 arrays of one shape -> 4 uint32 arrays."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) for c in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
+        c0, c1, c2, c3 = n0 & mask, p1 & mask, n2 & mask, p0 & mask
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c0.astype(np.uint32), c1.astype(np.uint32), c2.astype(np.uint32), c3.astype(np.uint32)
+
+
+def dropout_key(seed, tag=0):
+    """cirs_hip.tracker.DeviceTracker.set_dropout_key's mix of (seed, collect tag) -> 64-bit Philox key."""
+    mix = (int(seed) * 0x9E3779B97F4A7C15 + (int(tag) + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    return mix ^ (mix >> 29)
+
+
+def dropout_scale(key, p, envs, pos, layer, site, n_elem):
+    """Keep masks already scaled by 1/(1-p): float32 [len(envs), len(pos), n_elem] for (global env ids, positions); the element e
+    of (env, position, layer, site) is kept iff word (e & 3) of Philox(counter = (e >> 2, env, pos | site << 12 | layer << 16,
+    'DROP'), key) >= floor(p * 2^32)."""
+    thr = np.uint32(int(float(np.float32(p)) * 4294967296.0))
+    envs = np.asarray(envs, dtype=np.uint32)[:, None, None]
+    pos = np.asarray(pos, dtype=np.uint32)[None, :, None]
+    grp = (np.arange((n_elem + 3) // 4, dtype=np.uint32))[None, None, :]
+    words = philox4x32_10(grp, envs, pos | np.uint32((site << 12) | (layer << 16)), np.uint32(_STREAM_DROPOUT), key & 0xFFFFFFFF, key >> 32)
+    w = np.stack(np.broadcast_arrays(*words), axis=-1).reshape(envs.shape[0], pos.shape[1], -1)[:, :, :n_elem]
+    return torch.as_tensor(np.where(w >= thr, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32))
+
+
+def tracker_forward_all(p, x_hist, nhead=4, nlayers=2, dropout=None):
     """Causal transformer over the whole episode, decoder applied at EVERY position: states[B, L, S].
     Because the mask is causal and dropout is off, states[:, j] equals the reference's
-    forward(data[:j+1])[-1] (state_tracker.py:170-186,246) -- the equivalence the KV-cache design relies on."""
+    forward(data[:j+1])[-1] (state_tracker.py:170-186,246) -- the equivalence the KV-cache design relies on.
+    dropout = dict(p, key, envs [B] global env ids): the production mode -- inverted dropout at the reference's five kinds of sites
+    (PositionalEncoding output; per layer: attention probabilities, dropout1, FF hidden, dropout2) with the counter-based masks
+    of csrc/rng.h, every position keeping its masks for the whole episode."""
     B, L, D = x_hist.shape
     hd = D // nhead
     pe = p["pos_encoder.pe"][:L, 0, :]  # [L, D]
     h = x_hist * math.sqrt(D) + pe.unsqueeze(0)
+    if dropout is not None:
+        dk, dp, denv = dropout["key"], dropout["p"], dropout["envs"]
+        dmask = lambda layer, site, n: dropout_scale(dk, dp, denv, np.arange(L), layer, site, n)  # noqa: E731
+        h = h * dmask(0, DROP_POS, D)
     causal = torch.triu(torch.full((L, L), float("-inf")), diagonal=1)
     for l in range(nlayers):
         pre = f"transformer_encoder.layers.{l}."
@@ -60,18 +106,27 @@ def tracker_forward_all(p, x_hist, nhead=4, nlayers=2):
         k = k.view(B, L, nhead, hd).transpose(1, 2)
         v = v.view(B, L, nhead, hd).transpose(1, 2)
         sc = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + causal
-        att = torch.softmax(sc, dim=-1) @ v  # [B, H, L, hd]
+        prob = torch.softmax(sc, dim=-1)  # [B, H, Lq, Lk]
+        if dropout is not None:   # element of (env, query position): key * nhead + head
+            prob = prob * dmask(l, DROP_ATTN, L * nhead).view(B, L, L, nhead).permute(0, 3, 1, 2)
+        att = prob @ v  # [B, H, L, hd]
         att = att.transpose(1, 2).reshape(B, L, D)
         sa = att @ p[pre + "self_attn.out_proj.weight"].T + p[pre + "self_attn.out_proj.bias"]
+        if dropout is not None:
+            sa = sa * dmask(l, DROP_RES1, D)
         h = F.layer_norm(h + sa, (D,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-5)
         ff = torch.relu(h @ p[pre + "linear1.weight"].T + p[pre + "linear1.bias"])
+        if dropout is not None:
+            ff = ff * dmask(l, DROP_FF, ff.shape[-1])
         ff = ff @ p[pre + "linear2.weight"].T + p[pre + "linear2.bias"]
+        if dropout is not None:
+            ff = ff * dmask(l, DROP_RES2, D)
         h = F.layer_norm(h + ff, (D,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-5)
     return h @ p["decoder.weight"].T + p["decoder.bias"]
 
 
-def tracker_states(p, users, acts, rews, nhead=4, nlayers=2):
-    return tracker_forward_all(p, tracker_inputs(p, users, acts, rews), nhead, nlayers)
+def tracker_states(p, users, acts, rews, nhead=4, nlayers=2, dropout=None):
+    return tracker_forward_all(p, tracker_inputs(p, users, acts, rews), nhead, nlayers, dropout=dropout)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -46,6 +46,8 @@ def lib():
                                           C.c_int32, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P]
         h.oracle_deepfm_forward.restype = C.c_int
         h.oracle_deepfm_forward.argtypes = [C.POINTER(abi.DeepFMCfg), C.POINTER(abi.DeepFMWeights), _P, _P, _P, _P, C.c_int32, _P]
+        h.oracle_dropout_keep.restype = C.c_int
+        h.oracle_dropout_keep.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]
         h.oracle_gather_fm.restype = C.c_int
         h.oracle_gather_fm.argtypes = [C.POINTER(abi.DeepFMCfg), C.POINTER(abi.DeepFMWeights), _P, C.c_int64, _P]
         h.oracle_select_items.restype = C.c_int

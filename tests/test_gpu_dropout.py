@@ -1,0 +1,108 @@
+"""GPU: production-mode dropout of the state tracker (the reference trains, tests and back-propagates with
+nn.Dropout(0.1) live -- core/state_tracker.py:155-156,176; CIRS-RL-kuaishou.py:235-243 never calls eval()).  Counter-based masks
+keyed (key, global env, position, layer, site, element):
+  * the K/V-cached decode steps (tracker_step_kernel<NH, true>) == the torch restatement with the SAME masks injected;
+  * cirs_tracker_backward (masks regenerated from the counters) == autograd through that restatement;
+  * through the engine: key = (seed, collect tag), env ids offset per rank; collect + update are deterministic;
+  * p = 0 is the dropout-free kernel instantiation (every other GPU test)."""
+import numpy as np
+import pytest
+import torch
+
+import nn_oracle
+import rolloutcase
+from test_gpu_tracker_bwd import device_tracker_trainable, replay_tracker, rows_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("U,I,B,T,nhead,p", [(50, 80, 9, 12, 4, 0.1), (40, 60, 70, 30, 4, 0.1), (30, 40, 6, 7, 2, 0.3), (20, 30, 5, 40, 8, 0.1)])
+def test_forward_and_backward_with_masks_match_restatement(U, I, B, T, nhead, p):
+    from cirs_hip.rollout import Trajectory
+    rng = np.random.RandomState(B * T + nhead)
+    tp = rolloutcase.tracker_param_dict(U, I, T, seed=3)
+    lens = rng.randint(2, T + 1, size=B)
+    users = rng.randint(0, U, B); acts = rng.randint(0, I, (B, T)); rews = rng.uniform(0, 1, (B, T))
+    G = rng.randn(T + 1, B, 20).astype(np.float32)
+    env_base, seed, tag = 1000, 99, 17
+    d = dict(p=p, key=nn_oracle.dropout_key(seed, tag), envs=np.arange(B) + env_base)
+    # device: incremental decode with dropout on
+    trk, views = device_tracker_trainable(tp, U, I, B, T, nhead=nhead)
+    trk.set_dropout(p)
+    trk.set_dropout_key(seed, tag, env_base)
+    states_dev = np.zeros((B, T + 1, 20), np.float32)
+    trk.reset()
+    states_dev[:, 0] = trk.init(torch.as_tensor(users)).cpu().numpy()
+    for t in range(T):
+        live = np.where(lens > t)[0]
+        if len(live) == 0:
+            break
+        out = trk.step(torch.as_tensor(acts[live, t]), torch.as_tensor(rews[live, t]), env_ids=torch.as_tensor(live.astype(np.int32)).cuda())
+        states_dev[live, t + 1] = out.cpu().numpy()
+    # restatement with the same masks + autograd
+    tpo = {k: v.clone() for k, v in tp.items()}
+    for k, v in tpo.items():
+        if k != "pos_encoder.pe":
+            v.requires_grad_(True)
+    states = nn_oracle.tracker_forward_all(tpo, nn_oracle.tracker_inputs(tpo, users, acts, rews), nhead, dropout=d)  # [B, T+1, S]
+    sn = states.detach().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(states_dev[b, :lens[b] + 1], sn[b, :lens[b] + 1], atol=3e-5, rtol=1e-4)
+    plain = nn_oracle.tracker_forward_all(tp, nn_oracle.tracker_inputs(tp, users, acts, rews), nhead).detach().numpy()
+    assert np.abs(plain - sn).max() > 1e-3, "dropout must change the states"
+    up = torch.zeros_like(states)
+    for b in range(B):
+        up[b, :lens[b]] = torch.as_tensor(G[:lens[b], b])
+    (states * up).sum().backward()
+    traj = Trajectory(B, T, 20, "cuda")
+    a = np.where(np.arange(T)[None, :] < lens[:, None], acts, -1)
+    traj.act.copy_(torch.as_tensor(a.T.copy())); traj.rew.copy_(torch.as_tensor(rews.T.copy()))
+    offsets, row_env, row_t = rows_of(lens)
+    dd = lambda x: torch.as_tensor(x).cuda()  # noqa: E731
+    trk.backward(torch.as_tensor(users), traj, dd(row_env), dd(row_t), dd(offsets), dd(lens.astype(np.int32)), int(lens.sum()), dd(G))
+    for k, gv in trk.grad_views.items():
+        want = tpo[k].grad.numpy()
+        got = gv.cpu().numpy()
+        if k.endswith("self_attn.in_proj_bias"):   # key-bias gradient: analytically 0 (softmax shift invariance survives the mask)
+            want, got = np.delete(want, slice(32, 64)), np.delete(got, slice(32, 64))
+        scale = np.abs(want).max() + 1e-12
+        np.testing.assert_allclose(got / scale, want / scale, atol=3e-4, err_msg=k)
+
+
+def test_engine_dropout_mode_keys_and_determinism():
+    from cirs_hip.engine import CirsEngine
+    from cirs_hip.env import DeviceEnvTables
+    from cirs_hip.synthetic import make_tables
+    U, I, B, T = 90, 200, 48, 12
+    tab = make_tables(U, I, seed=0, build_dist=False)
+    a_env = tab.alpha_u[tab.raw_uid, 0].astype(np.float64); b_env = tab.beta_i[tab.raw_pid, 0].astype(np.float64)
+
+    def run(dropout):
+        dt = DeviceEnvTables(tab.mat, tab.normed_mat, tab.item_cats, alpha_env=a_env, beta_env=b_env)
+        eng = CirsEngine(dt, B, max_turn=T, num_leave_compute=3, leave_threshold=1, tau=10.0, gamma_exposure=10.0, seed=11, dropout=dropout)
+        users = torch.as_tensor(np.random.RandomState(1).randint(0, U, B))
+        eng.collect(users)                       # collect #0: rng_base 0
+        eng.update(batch_size=64, repeat=2)
+        eng.collect(users)                       # collect #1: rng_base T -> different masks
+        return eng, users
+
+    eng, users = run(0.1)
+    tr = eng.rollout.traj
+    lens = eng.lengths.cpu().numpy()
+    act = tr.act.cpu().numpy().T; rew = tr.rew.cpu().numpy().T
+    tp = {k: v.detach().cpu() for k, v in eng.tracker.params.items()}
+    d = dict(p=0.1, key=nn_oracle.dropout_key(11, 1 * T), envs=np.arange(B))
+    with torch.no_grad():
+        want = nn_oracle.tracker_states(tp, users.numpy(), np.maximum(act, 0), rew, dropout=d).numpy()
+        want_off = nn_oracle.tracker_states(tp, users.numpy(), np.maximum(act, 0), rew).numpy()
+    obs = tr.obs.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(obs[:lens[b] + 1, b], want[b, :lens[b] + 1], atol=5e-5, rtol=1e-4)
+    assert np.abs(want - want_off).max() > 1e-3
+    losses, n = eng.update(batch_size=64, repeat=2)
+    assert torch.isfinite(losses).all() and torch.isfinite(eng.tracker_flat).all()
+    eng2, _ = run(0.1)
+    eng2.update(batch_size=64, repeat=2)
+    assert torch.equal(eng.policy_flat, eng2.policy_flat) and torch.equal(eng.tracker_flat, eng2.tracker_flat)
+    eng0, _ = run(0.0)
+    assert not torch.equal(eng0.rollout.traj.obs, eng.rollout.traj.obs)

@@ -22,7 +22,7 @@ def load_example():
 def test_script_wiring_runs_and_matches_engine():
     ex = load_example()
     args = ex.get_args(["--n-users", "200", "--n-items", "500", "--training-num", "32", "--episode-per-collect", "32",
-                        "--batch-size", "64", "--max_turn", "15", "--tau", "10"])
+                        "--batch-size", "64", "--max_turn", "15", "--tau", "10", "--dropout", "0"])
     tab, train_envs, st, policy, coll = ex.build(args)
     # state_dict names of the reference
     assert "embedding_dict.feat_item.weight" in st.state_dict() and "transformer_encoder.layers.1.linear2.weight" in st.state_dict()
