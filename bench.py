@@ -281,7 +281,9 @@ def cpu_baseline(wl, eng):
     arrs = {k: eng.policy_views[name].detach().cpu().numpy().copy() for k, name in rolloutcase.POLICY_NAMES.items()}
     host = os.cpu_count() or 1
     legs = []
-    for threads, B in ((1, min(32, wl["B"])), (min(16, host), wl["B"]), (host, wl["B"])):
+    # bounded samples: every leg is sized to ~10-30 s (a 256-core host does NOT make the port faster: the per-step tensors are tiny,
+    # so the widest leg is capped at 64 threads)
+    for threads, B in ((1, min(16, wl["B"])), (min(16, host), min(512, wl["B"])), (min(64, host), min(512, wl["B"]))):
         if any(l["cores"] == threads for l in legs):
             continue
         _set_omp_threads(threads)
