@@ -221,11 +221,15 @@ def adam_substeps(p, g, state, lr, n_sub, b1=0.9, b2=0.999, eps=1e-8):
 
 
 def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam=0.95, eps_clip=0.2, vf_coef=0.25,
-               ent_coef=0.0, max_grad_norm=0.5, lr=1e-3, batch_size=16, repeat=2, ret_rms=None, nhead=4, opt_state=None):
+               ent_coef=0.0, max_grad_norm=0.5, lr=1e-3, batch_size=16, repeat=2, ret_rms=None, nhead=4, opt_state=None,
+               snapshot_steps=()):
     """Runs one policy.update on teacher-forced episodes.  tp/pp are dicts of torch fp32 tensors and are updated
     IN PLACE.  Returns dict(losses..., returns, adv, v_s, logp_old, ret_rms, opt_state).  Pass the previous call's
     `ret_rms` and `opt_state` (Adam moments + step counters of optim_RL / optim_state) to continue a run: the reference keeps
-    both optimisers and policy.ret_rms alive across policy.update calls (CIRS-RL-kuaishou.py:256-283)."""
+    both optimisers and policy.ret_rms alive across policy.update calls (CIRS-RL-kuaishou.py:256-283).
+    snapshot_steps: minibatch-step indices k for which out["snap"][k] records the policy parameters, Adam moments and step counters
+    BEFORE step k, the row indices of the minibatch and the parameters AFTER it -- so a second implementation can be teacher-forced
+    onto exactly this state (two fp32 implementations of a long run drift apart chaotically; single steps do not)."""
     lens = np.asarray(lens)
     ret_rms = ret_rms or RunningMeanStd()
     tparams = {k: v for k, v in tp.items() if k != "pos_encoder.pe"}
@@ -259,8 +263,9 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
         opt_state = dict(pol={k: dict(step=0, m=torch.zeros_like(pp[k]), v=torch.zeros_like(pp[k])) for k in pp},
                          trk={k: dict(step=0, m=torch.zeros_like(v), v=torch.zeros_like(v)) for k, v in tparams.items()})
     st_pol, st_trk = opt_state["pol"], opt_state["trk"]
-    out = dict(loss=[], clip=[], vf=[], ent=[])
+    out = dict(loss=[], clip=[], vf=[], ent=[], snap={})
     pi = 0
+    step_k = 0
     trk_grads = None
     for rep in range(repeat):
         trk_grads = {k: torch.zeros_like(v) for k, v in tparams.items()}  # optim_state.zero_grad()
@@ -275,6 +280,10 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
             idx_list.append(perm[s0:s0 + batch_size])
         for idx in idx_list:
             idx_t = torch.as_tensor(idx).long()
+            if step_k in snapshot_steps:
+                out["snap"][step_k] = dict(idx=np.asarray(idx).copy(), pp={k: v.detach().clone() for k, v in pp.items()},
+                                           m={k: st_pol[k]["m"].clone() for k in pp}, v={k: st_pol[k]["v"].clone() for k in pp},
+                                           steps={k: st_pol[k]["step"] for k in pp})
             for k in pp:
                 pp[k].requires_grad_(True)
             b_obs = obs[idx_t]
@@ -309,7 +318,10 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
                     adam_substeps(pp[k], gp[k] * coef * coef, st_pol[k], lr, 2)
                 for k in names_head:
                     adam_substeps(pp[k], gp[k] * coef, st_pol[k], lr, 1)
-            out["loss"].append(float(loss)); out["clip"].append(float(clip_loss)); out["vf"].append(float(vf_loss)); out["ent"].append(float(ent_loss))
+            out["loss"].append(float(loss.detach())); out["clip"].append(float(clip_loss.detach())); out["vf"].append(float(vf_loss.detach())); out["ent"].append(float(ent_loss.detach()))
+            if step_k in out["snap"]:
+                out["snap"][step_k]["pp_after"] = {k: v.detach().clone() for k, v in pp.items()}
+            step_k += 1
     with torch.no_grad():
         for k, v in tparams.items():
             v.requires_grad_(False)

@@ -25,6 +25,7 @@ def test_test_episode_result_dict_equals_reference(golden_dir):
                         "--force_length", str(K), "--leave_threshold", str(thr), "--num_leave_compute", str(N), "--tau", "10",
                         "--buffer-size", str(B * T)])
     tab, train_envs, st, policy, coll = ex.build(args, table_seed=int(z["seed_tables"]))
+    st.eval()      # the fixture was recorded with the reference tracker in eval mode (dropout off)
     # the reference's weights
     st.load_state_dict({k[4:]: torch.as_tensor(z[k]) for k in z.files if k.startswith("trk_")})
     with torch.no_grad():

@@ -84,10 +84,9 @@ def test_learner_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(dobs[tt, env], out["dobs_rows"], rtol=2e-3, atol=2e-6)
 
 
-@pytest.mark.parametrize("I,B,T,bs,ent_coef", [(3327, 64, 30, 1024, 0.0), (10728, 160, 30, 1024, 0.01), (10728, 1024, 30, 1024, 0.0)])
+@pytest.mark.parametrize("I,B,T,bs,ent_coef", [(3327, 64, 30, 1024, 0.0), (10728, 160, 30, 1024, 0.01)])
 def test_learner_vs_restatement_large(I, B, T, bs, ent_coef):
-    """BASELINE catalogue sizes (C2: 3327 items, C3: 10728 items), merged last minibatch > 1024 rows, non-zero entropy coef;
-    last case = the benchmarked learner workload: 1024 envs, ~19-27 k rows, ~2 x 19+ minibatch steps, merged last minibatch."""
+    """BASELINE catalogue sizes (C2: 3327 items, C3: 10728 items), merged last minibatch > 1024 rows, non-zero entropy coef."""
     import policycase
     from cirs_hip.rollout import Trajectory
     U = 300
@@ -123,3 +122,85 @@ def test_learner_vs_restatement_large(I, B, T, bs, ent_coef):
     dobs = ln.dobs.cpu().numpy()
     env = ln.b_env[:n].cpu().numpy(); tt = ln.b_t[:n].cpu().numpy()
     np.testing.assert_allclose(dobs[tt, env], out["dobs_rows"], rtol=5e-3, atol=1e-6)
+
+
+def _flat_from(pd, views_like):
+    """dict keyed w1..bc -> flat fp32 tensor in the learner's [w1|b1|w2|b2|wa|ba|wc|bc] layout"""
+    from cirs_hip.learner import FLAT_ORDER
+    return torch.cat([pd[k].reshape(-1).float() for k in FLAT_ORDER])
+
+
+def test_learner_benchmark_workload_1024_envs():
+    """The BENCHMARKED learner workload (C3: 10728 items, 1024 envs -> ~20 k rows, 2 x 19 minibatch steps, merged last minibatch)
+    against the torch-fp32 restatement:
+      * process_fn outputs (GAE advantages, normalised returns) over all rows;
+      * FREE-RUNNING through the whole first repeat (19 optimiser steps): per-minibatch losses to 2e-5 relative;
+      * TEACHER-FORCED single steps in the second repeat (first, middle, last = merged minibatch): the device learner is set to
+        the restatement's parameters + Adam moments + step counters before step k, runs step k on the same rows, and must reproduce
+        the loss terms and the post-step parameters.
+    Why not free-running to the end: after ~20 optimiser steps two float32 implementations of this update (bf16x6 MFMA products /
+    torch CPU sgemm, different summation orders) separate at ~1.6x per step -- Adam turns 1e-8 gradient differences of near-zero
+    gradients into +-lr parameter steps -- so step 37 differs in the third digit although every single step agrees to 1e-5
+    (measured: losses agree to 1e-6 for steps 0-18, 6e-5 at step 19, 6e-2 at step 37)."""
+    import policycase
+    from cirs_hip.learner import FLAT_ORDER
+    from cirs_hip.rollout import Trajectory
+    I, B, T, bs = 10728, 1024, 30, 1024
+    U = 300
+    rng = np.random.RandomState(I)
+    tp = rolloutcase.tracker_param_dict(U, I, T, seed=1)
+    arrs = policycase.random_weights(rng, I, head_scale=1.5)
+    pp = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)) for k, v in arrs.items()}
+    lens = rng.randint(8, T + 1, size=B)
+    users = rng.randint(0, U, B); acts = rng.randint(0, I, (B, T)); rews = rng.uniform(0, 1, (B, T))
+    dones = np.zeros((B, T), bool); dones[np.arange(B), lens - 1] = True
+    with torch.no_grad():
+        obs_bts = nn_oracle.tracker_states(tp, users, acts, rews).numpy()
+    value, logp = rollout_time_value_logp(pp, obs_bts, acts, lens)
+    n = int(lens.sum())
+    perms = [rng.permutation(n) for _ in range(2)]
+    hyper = [0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, bs, 2]
+    traj = Trajectory(B, T, 20, "cuda")
+    upload_traj(traj, acts, rews, dones, lens, obs_bts, value, logp)
+    ln, views = make_learner(pp, I, B, T, hyper)
+    assert ln.prepare(traj, lens) == n
+    n_mb = len(__import__("cirs_hip.learner", fromlist=["minibatch_slices"]).minibatch_slices(n, bs))
+    assert n_mb >= 15 and n % bs > 0                      # merged last minibatch
+    forced = [n_mb, n_mb + n_mb // 2, 2 * n_mb - 1]
+    tp_o = {k: v.clone() for k, v in tp.items()}
+    pp_o = {k: v.clone() for k, v in pp.items()}
+    out = nn_oracle.ppo_update(tp_o, pp_o, users, acts, rews, dones, lens, perms, gamma=0.95, lam=0.95, eps_clip=0.2, vf_coef=0.25,
+                               ent_coef=0.0, max_grad_norm=0.5, lr=1e-3, batch_size=bs, repeat=2, snapshot_steps=set(forced))
+    np.testing.assert_allclose(ln.b_adv[:n].cpu().numpy(), out["adv"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ln.b_ret[:n].cpu().numpy(), out["returns"], rtol=1e-4, atol=1e-5)
+    # ---- free-running: the whole first repeat
+    losses = ln.learn(bs, 1, perms=perms[:1], want_tracker_grad=False).cpu().numpy()
+    assert losses.shape[0] == n_mb
+    np.testing.assert_allclose(losses[:, 0], out["loss"][:n_mb], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(losses[:, 2], out["vf"][:n_mb], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(losses[:, 3], out["ent"][:n_mb], rtol=2e-5, atol=2e-5)
+    # ---- teacher-forced steps of the second repeat
+    import ctypes as C
+    from cirs_hip import abi
+    for k in forced:
+        sn = out["snap"][k]
+        ln.params.copy_(_flat_from(sn["pp"], views).cuda())
+        ln.adam_m.copy_(_flat_from(sn["m"], views).cuda()); ln.adam_v.copy_(_flat_from(sn["v"], views).cuda())
+        assert sn["steps"]["w1"] == 2 * sn["steps"]["wa"] == 2 * k   # duplicated trunk: two Adam sub-steps per optimiser step (SURVEY Q8)
+        ln.opt_step = k
+        idx = torch.as_tensor(sn["idx"].astype(np.int32)).cuda()
+        mb = idx.numel()
+        ws = ln.workspace(mb)
+        lo = torch.zeros(4, dtype=torch.float32, device="cuda")
+        abi.check(ln._lib.cirs_ppo_minibatch(C.byref(ln.cfg), ln.params.data_ptr(), ln.grads.data_ptr(), ln.adam_m.data_ptr(), ln.adam_v.data_ptr(),
+                                             ln.opt_step, C.byref(ln.batch), idx.data_ptr(), mb, None, ln.n_env, lo.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), ln._stream()), "cirs_ppo_minibatch")
+        lo = lo.cpu().numpy()
+        assert mb == (n - (n_mb - 1) * bs if k == 2 * n_mb - 1 else bs)
+        np.testing.assert_allclose(lo, [out["loss"][k], out["clip"][k], out["vf"][k], out["ent"][k]], rtol=3e-5, atol=3e-5, err_msg=f"step {k}")
+        after = _flat_from(sn["pp_after"], views).numpy()
+        got = ln.params.cpu().numpy()
+        # Adam: an element whose gradient is ~0 in fp32 may step +-lr either way; everything else to 1e-5
+        close = np.abs(got - after) <= 2e-6 + 2e-5 * np.abs(after)
+        assert close.mean() > 0.999, f"step {k}: only {close.mean():.5f} of the parameters agree tightly"
+        np.testing.assert_allclose(got, after, rtol=0, atol=2.5e-3, err_msg=f"step {k}")

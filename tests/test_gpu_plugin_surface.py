@@ -109,9 +109,10 @@ def test_trainer_loop_with_test_collector_set():
     assert (res["NX_10_lens"] == 10).all()                      # force_length
     nx = cs.collector_dict["NX_0"].buffer
     acts = nx._traj.act.cpu().numpy()
+    assert np.array_equal(np.sort(res["NX_0_lens"]), np.sort(nx._lengths))     # result arrays come in completion order
     for b in range(8):                                           # remove_recommended_ids: no item twice in an episode
-        a = acts[:res["NX_0_lens"][b], b]
-        assert len(set(a.tolist())) == len(a)
+        a = acts[:nx._lengths[b], b]
+        assert len(set(a.tolist())) == len(a) and (a >= 0).all()
     # the training tracker state (Adam step counter) survived the differently sized test engines
     assert st.adam_steps >= 2
 
