@@ -14,10 +14,12 @@ class SparseFeatP(SparseFeat):
         self.padding_idx = padding_idx
 
 
-def get_dataset_columns(dim_model, envname="KuaishouEnv-v0", env=None):
-    """KuaishouEnv branch of the reference (core/inputs.py:35-41); VirtualTB is CPU plumbing and not mirrored."""
+def get_dataset_columns(dim_model, envname="VirtualTB-v0", env=None):
+    """reference core/inputs.py:24-44: the (user, action, feedback) columns of the state tracker and whether each is embedded."""
+    if envname == "VirtualTB-v0":     # 88-d one-hot user, 27-d continuous action, scalar feedback: all dense
+        return [DenseFeat("feat_user", 88)], [DenseFeat("feat_item", 27)], [DenseFeat("feat_feedback", 1)], True, True, True
     if envname != "KuaishouEnv-v0":
-        raise NotImplementedError("only KuaishouEnv-v0 is on the MI355X hot path (SURVEY §8: C1 is CPU plumbing)")
+        raise ValueError(f"unknown env {envname}")
     user_columns = [SparseFeatP("feat_user", env.mat.shape[0], embedding_dim=dim_model)]
     action_columns = [SparseFeatP("feat_item", env.mat.shape[1], embedding_dim=dim_model)]
     feedback_columns = [DenseFeat("feat_feedback", 1)]

@@ -486,6 +486,89 @@ def gen_collectorset():
 
 
 # --------------------------------------------------------------------------------------------------
+# virtualtb family (BASELINE configs[0], CPU plumbing): the reference's VirtualTB env with its shipped simulator weights, and
+# SimulatedEnv(VirtualTB) around a seeded UserModel_MMOE, driven through torch's seeded CPU generator.
+# (environments/VirtualTaobao/virtualTB/envs/virtualTB.py:74-133, core/env/simulatedEnv/simulated_env.py:49-168,
+#  core/user_model_mmoe.py:144-262, CIRS-UserModel-taobao.py:100-148)
+# --------------------------------------------------------------------------------------------------
+def _pad_states(states, width=91):
+    """states of VirtualTB are 91-d after a reset (user one-hot) and 30-d after a step (action): pad + keep the lengths"""
+    out = np.full((len(states), width), np.nan)
+    for k, s_ in enumerate(states):
+        out[k, :len(s_)] = s_
+    return out, np.array([len(s_) for s_ in states])
+
+
+def gen_virtualtb():
+    import collections
+    import gym
+    from core.user_model_mmoe import UserModel_MMOE
+    from deepctr_torch.inputs import DenseFeat
+    N, thr, T = 4, 2.4, 9
+    gym.register(id="VirtualTB-v0", entry_point="virtualTB.envs.virtualTB:VirtualTB",
+                 kwargs=dict(num_leave_compute=N, leave_threshold=thr, max_turn=T))
+    rng = np.random.RandomState(5)
+    n_steps = 40
+    actions = rng.uniform(-1, 1, (n_steps, 27)).astype(np.float32)
+    for k in range(3, n_steps, 5):            # near-repeats so that the exit rule fires (distance <= threshold)
+        actions[k] = actions[k - 1] + rng.uniform(-0.2, 0.2, 27).astype(np.float32)
+    out = dict(actions=actions, env_params=np.array([N, thr, T]))
+
+    torch.manual_seed(11)
+    env = gym.make("VirtualTB-v0")
+    s = env.reset()
+    states, rews, dones, ctrs = [np.asarray(s, np.float64)], [], [], []
+    for a in actions:
+        s, r, d, info = env.step(a)
+        states.append(np.asarray(s, np.float64)); rews.append(r); dones.append(d); ctrs.append(info["CTR"])
+        if d:
+            s = env.reset()
+            states.append(np.asarray(s, np.float64))
+    es, el = _pad_states(states)
+    out.update(env_states=es, env_state_len=el, env_rews=np.array(rews, np.float64), env_dones=np.array(dones), env_ctr=np.array(ctrs))
+
+    x_columns = [DenseFeat("user_feat", 91), DenseFeat("feat_item", 27)]
+    y_columns = [DenseFeat("y", 1)]
+    tasks = collections.OrderedDict({f.name: "regression" for f in y_columns})
+    task_logit_dim = {f.name: f.dimension for f in y_columns}
+    model = UserModel_MMOE(x_columns, y_columns, len(tasks), tasks, task_logit_dim, dnn_hidden_units=(128, 128), seed=2022, device="cpu")
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():                    # the stock init (std 1e-4) makes the output almost constant: stress it
+        for name, p_ in model.named_parameters():
+            if name.startswith("dnn.") and name.endswith("weight"):
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.15)
+            elif name.endswith("weight") and "linear_model" in name:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.3)
+            elif name.endswith("bias"):
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+        model.tower_network[0].weight.mul_(0.05)
+    model.eval()
+    X = torch.randn(64, 118, generator=g)
+    with torch.no_grad():
+        out["mmoe_x"], out["mmoe_y"] = X.numpy(), model.forward(X).numpy()
+    out.update({"mmoe_" + k: v.detach().numpy() for k, v in model.state_dict().items()})
+    for ver, tau, gam in (("v1", 10.0, 3.0), ("v2", 1.0, 0.5)):
+        gym.register(id="SimulatedEnv-v0", entry_point="core.env.simulatedEnv.simulated_env:SimulatedEnv",
+                     kwargs=dict(user_model=model, task_name="VirtualTB-v0", version=ver, tau=tau, gamma_exposure=gam))
+        torch.manual_seed(23)
+        sim = gym.make("SimulatedEnv-v0")
+        s = sim.reset()
+        states, rews, dones, ctrs = [np.asarray(s, np.float64)], [], [], []
+        for a in actions[:24]:
+            s, r, d, info = sim.step(a)
+            states.append(np.asarray(s, np.float64)); rews.append(float(r)); dones.append(d); ctrs.append(float(info["CTR"]))
+            if d:
+                s = sim.reset()
+                states.append(np.asarray(s, np.float64))
+        es, el = _pad_states(states)
+        out.update({f"sim_{ver}_states": es, f"sim_{ver}_state_len": el, f"sim_{ver}_rews": np.array(rews), f"sim_{ver}_dones": np.array(dones),
+                    f"sim_{ver}_ctr": np.array(ctrs), f"sim_{ver}_cfg": np.array([tau, gam])})
+    np.savez_compressed(os.path.join(GOLDEN, "virtualtb.npz"), **out)
+    print("virtualtb.npz: env dones", int(np.sum(out["env_dones"])), "rewards", out["env_rews"][:12], "sim v1 rews", np.round(out["sim_v1_rews"][:6], 4),
+          "sim dones", int(out["sim_v1_dones"].sum()), int(out["sim_v2_dones"].sum()), "mmoe y", out["mmoe_y"][:4, 0])
+
+
+# --------------------------------------------------------------------------------------------------
 # deepfm family: UserModel_Pairwise.forward with the SHIPPED trained weights + compute_normed_reward
 # --------------------------------------------------------------------------------------------------
 def gen_deepfm():
@@ -958,7 +1041,7 @@ def gen_userval():
     print("userval.npz: x", out["x"].shape, "env table", out["env_values"].shape, list(out["env_columns"]))
 
 
-FAMILIES = {"collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+FAMILIES = {"virtualtb": gen_virtualtb, "collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)
