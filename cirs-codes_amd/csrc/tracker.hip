@@ -144,6 +144,14 @@ __device__ __forceinline__ float dot_lds(const float* wt, int ld, int o, const f
     return acc;
 }
 
+#ifdef CIRS_TRK_PROF
+// stage timestamps of workgroup 0 / wave 0 (probe builds only: tools/probes/trk_prof.py)
+__device__ unsigned long long g_trk_prof[32];
+#define CIRS_STAMP(K) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_trk_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CIRS_STAMP(K) do { } while (0)
+#endif
+
 template <int NHEAD, bool DROP, bool LDSW>
 __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w,
                                                            cirs_tracker_state st, const int32_t* __restrict__ users,
@@ -160,12 +168,14 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     // LDSW: the weight image sits behind the four per-wave scratch areas
     const ImgLayout IL = LDSW ? img_layout(cfg.nlayers, tf.on ? tf.cfg.dim_state : cfg.dim_state) : ImgLayout{};
     float* lw = smem + (size_t)4 * (6 * kD + kHid + NHEAD * lpad);
+    CIRS_STAMP(0);
     if (LDSW) {
         const float4* src = reinterpret_cast<const float4*>(img);
         float4* dst = reinterpret_cast<float4*>(lw);
         for (int q = threadIdx.x; q < IL.total / 4; q += 256) dst[q] = src[q];
         __syncthreads();
     }
+    CIRS_STAMP(1);
     if (j >= n) return;
 // rows that do not step still owe the fused trunk its "skipped row" outputs
 #define CIRS_TRUNK_ZERO()                                                  \
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
                 tl.visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
             }
         }
+        CIRS_STAMP(2);
         EnvStepResult er;
         env_step_wave(tl.cfg, tl.tab, tl.st, j, j, act, lane, nullptr, tl.rew_out, tl.done_out, tl.ctr_out, nullptr, &er);
         const unsigned long long rb = __builtin_bit_cast(unsigned long long, er.reward);
@@ -203,6 +214,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         it_f = act;
         r_f = (float)reward;
     }
+    CIRS_STAMP(3);
     if (skip && skip[j]) { CIRS_TRUNK_ZERO(); return; }
     const int e = env_ids ? env_ids[j] : j;
     const int B = cfg.n_env, L = cfg.max_len;
@@ -273,6 +285,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         pv = load_row<kD>(w.layer[0].in_proj_w + (size_t)(2 * kD + o32) * kD);           // rows 64..95 (v)
         bq = w.layer[0].in_proj_b[lane]; bv = w.layer[0].in_proj_b[2 * kD + o32];
     }
+    CIRS_STAMP(4);
     for (int l = 0; l < cfg.nlayers; ++l) {
         const cirs_tracker_layer& ly = w.layer[l];
         if (lane < kD) xs[lane] = h;
@@ -293,6 +306,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         float* vc = st.vcache + (((size_t)l * B + e) * L) * kD;
         if (lane < kD) kc[(size_t)pos * kD + lane] = kcur[lane];
         else vc[(size_t)pos * kD + (lane - kD)] = vcur[lane - kD];
+        CIRS_STAMP(5 + 6 * l);
         // scores: lanes stride over positions 0..pos
         float mx[NHEAD];
 #pragma unroll
@@ -337,6 +351,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
 #pragma unroll
         for (int hh = 0; hh < NHEAD; ++hh) sm[hh] = 1.0f / wave_sum_f32(sm[hh]);
         __builtin_amdgcn_wave_barrier();
+        CIRS_STAMP(6 + 6 * l);
         // weighted sum of V: lane (half, d): positions jp = half, half+2, ...
         {
             const int half = lane >> 5, d = o32, hh = d / HD;
@@ -351,6 +366,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             for (int q = 1; q < NHEAD; ++q) norm = hh == q ? sm[q] : norm;
             if (lane < kD) att[d] = acc * norm;
         }
+        CIRS_STAMP(7 + 6 * l);
         // prefetch the feed-forward's first layer (two rows per lane) while out_proj + LayerNorm run
         RowRegs<kD> pf0{}, pf1{};
         float bf0 = 0.f, bf1 = 0.f;
@@ -365,6 +381,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         if (DROP) sa = CIRS_DROP(sa, l, CIRS_DROP_RES1, o32);
         const float h1 = LDSW ? layer_norm32(h + sa, lane, lw + IL.n1w[l], lw + IL.n1b[l]) : layer_norm32(h + sa, lane, ly.norm1_w, ly.norm1_b);
         __builtin_amdgcn_wave_barrier();
+        CIRS_STAMP(8 + 6 * l);
         if (lane < kD) tmp[lane] = h1;
         // prefetch lin2's half row (64 inputs per half-wave)
         const int half2 = lane >> 5;
@@ -393,6 +410,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             bq = w.layer[l + 1].in_proj_b[lane]; bv = w.layer[l + 1].in_proj_b[2 * kD + o32];
         }
         __builtin_amdgcn_wave_barrier();
+        CIRS_STAMP(9 + 6 * l);
         // lin2: 32 outputs x 128 inputs, split k in two halves across the half-waves
         {
             float acc = LDSW ? dot_lds<64>(lw + IL.l2_t[l] + half2 * (64 * kD + kL2HalfPad), kD, o32, ffs + half2 * 64, bl2)
@@ -403,6 +421,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         }
         __builtin_amdgcn_wave_barrier();
     }
+    CIRS_STAMP(17);
     // ---- 4. decoder ------------------------------------------------------------------------------------------
     if (lane < kD) xs[lane] = h;
     __builtin_amdgcn_wave_barrier();
@@ -412,6 +431,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         state_out[(size_t)j * state_stride + lane] = sval;
     }
     if (lane == 0) st.len[e] = pos + 1;
+    CIRS_STAMP(18);
     if (tf.on) {  // policy trunk of the next vector step on this state
         if (tl.on ? fin_f != 0 : (tf.skip && tf.skip[j])) { CIRS_TRUNK_ZERO(); return; }
         float* txs = ffs;        // [64] input, then h2 (critic)
@@ -440,6 +460,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             trunk_compute(tf.cfg, tf.w, txs, ths, lane, j, tf.h2, tf.value, nullptr);
         }
     }
+    CIRS_STAMP(19);
 #undef CIRS_TRUNK_ZERO
 #undef CIRS_DROP
 }
@@ -534,6 +555,12 @@ int tracker_pack_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* 
 }
 
 }  // namespace cirs
+
+#ifdef CIRS_TRK_PROF
+extern "C" int cirs_debug_trk_prof(unsigned long long* out_host32) {
+    return hipMemcpyFromSymbol(out_host32, HIP_SYMBOL(cirs::g_trk_prof), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int cirs_tracker_init(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
                                  const int32_t* users, const int32_t* env_ids, int32_t n, float* state_out,

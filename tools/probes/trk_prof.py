@@ -1,0 +1,36 @@
+"""Stage timestamps of tracker_step_kernel inside the fused C3 rollout (probe build: tools/probes/build_prof_lib.sh).
+    python tools/probes/trk_prof.py [c3|c2]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd"))
+import numpy as np
+import torch
+from cirs_hip import abi
+
+abi.LIB_PATH = os.path.join(ROOT, "tools", "probes", "libcirs_prof.so")
+import bench
+
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
+eng, _ = bench.build_engine(wl, 0, 1, torch.device("cuda:0"))
+lib = C.CDLL(abi.LIB_PATH)
+names = {0: "start", 1: "lds image", 2: "merge (tail)", 3: "env step (tail)", 4: "slot+gate+pe", 5: "L0 in_proj+kv write", 6: "L0 scores+softmax", 7: "L0 V sum",
+         8: "L0 out_proj+LN1", 9: "L0 FF1", 11: "L1 in_proj (+L0 lin2+LN2)", 12: "L1 scores+softmax", 13: "L1 V sum", 14: "L1 out_proj+LN1", 15: "L1 FF1",
+         17: "L1 lin2+LN2", 18: "decoder", 19: "trunk"}
+acc = None
+for rep in range(6):
+    eng.collect()
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 32)()
+    assert lib.cirs_debug_trk_prof(buf) == 0
+    t = np.array(buf[:], dtype=np.float64)
+    if rep >= 1:
+        acc = t if acc is None else acc + t
+t = acc / 5
+prev = t[0]
+print("stage deltas of workgroup 0 / wave 0 at the LAST step of the rollout (s_memtime ticks, 100 MHz -> x10 ns):")
+for k in sorted(names):
+    print(f"  {names[k]:32s} {10 * (t[k] - prev):9.0f} ns   (cum {10 * (t[k] - t[0]):9.0f})")
+    prev = t[k]
