@@ -98,15 +98,8 @@ class DeviceRollout:
         B, S = self.env.n_env, self.tracker.dim_state
         self.tracker.init(users, out=self.traj.obs[0], out_stride=S)
 
-    def _workspace(self):
-        """Sampler scratch + room for the LDS weight image of the fused tracker step (cirs_rollout_workspace_bytes)."""
-        need = self._lib.cirs_rollout_workspace_bytes(C.byref(self.policy.cfg), C.byref(self.tracker.cfg), self.env.n_env)
-        if getattr(self, "_ws", None) is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
-
     def run_steps(self, t_begin, t_end, seed, rng_base, gumbel=None):
-        ws = self._workspace()
+        ws = self.policy.workspace(self.env.n_env)
         if gumbel is not None:      # harness-supplied sampler noise (parity fixtures recorded from the reference)
             assert self.online is None and gumbel.dtype == torch.float32 and gumbel.is_contiguous()
             assert tuple(gumbel.shape) == (self.env.max_turn, self.env.n_env, self.policy.n_items)

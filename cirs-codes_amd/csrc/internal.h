@@ -78,10 +78,6 @@ void prof_after(hipStream_t s);
 
 int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
-                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail = nullptr, const float* img = nullptr);
-// LDS weight image of the fused rollout (tracker.hip): transposed tracker + policy-trunk weights, built once per rollout call
-size_t tracker_image_bytes(const cirs_tracker_cfg* cfg, int dim_state_policy);
-int tracker_pack_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_policy_weights* pol, int dim_state_policy,
-                       float* img, hipStream_t s);
+                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail = nullptr);
 
 }  // namespace cirs

@@ -150,16 +150,6 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     CIRS_REQUIRE(pol_cfg->hidden == kH && pol_cfg->dim_state == S && pol_cfg->n_items == env_cfg->n_items, "policy/env/tracker shape mismatch");
     CIRS_REQUIRE(pol_w->w1 && pol_w->b1 && pol_w->w2 && pol_w->b2 && pol_w->wa && pol_w->ba && pol_w->wc && pol_w->bc, "policy weight pointer null");
     CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(pol_cfg, n_env), "workspace too small");
-    // LDS weight image of the tracker step (tracker.hip): lives behind the sampler workspace when the caller sized the workspace
-    // with cirs_rollout_workspace_bytes; built once per call (the weights do not change inside a rollout)
-    float* img = nullptr;
-    {
-        const int64_t base = (cirs_policy_workspace_bytes(pol_cfg, n_env) + 255) & ~(int64_t)255;
-        if (trk_cfg->nlayers <= 2 && workspace_bytes >= base + (int64_t)tracker_image_bytes(trk_cfg, pol_cfg->dim_state)) {
-            img = (float*)((char*)workspace + base);
-            if (int rc = tracker_pack_image(trk_cfg, trk_w, pol_w, pol_cfg->dim_state, img, s)) return rc;
-        }
-    }
     CIRS_REQUIRE(env_tab->item_cats && (env_tab->normed_mat || !env_cfg->simulated) && (env_tab->mat || env_cfg->simulated), "env tables incomplete");
     if (t_begin >= t_end) return CIRS_OK;
     float* h2 = (float*)workspace;
@@ -194,14 +184,8 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         tl.wa = pol_w->wa; tl.ba = pol_w->ba; tl.h2 = h2; tl.visited = visited; tl.force_length = force_length;
         tl.force_done = (t + 1 >= force_length) ? 1 : 0;
         tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B; tl.rew_out = rew_t; tl.done_out = done_t; tl.ctr_out = traj->ctr + (size_t)t * B;
-        if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, &tf, s, &tl, img))
+        if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, &tf, s, &tl))
             return rc;
     }
     return CIRS_OK;
-}
-
-extern "C" int64_t cirs_rollout_workspace_bytes(const cirs_policy_cfg* pol_cfg, const cirs_tracker_cfg* trk_cfg, int32_t n_env) {
-    if (!pol_cfg || !trk_cfg || n_env <= 0) return 0;
-    const int64_t base = (cirs_policy_workspace_bytes(pol_cfg, n_env) + 255) & ~(int64_t)255;
-    return base + (int64_t)cirs::tracker_image_bytes(trk_cfg, pol_cfg->dim_state) + 256;
 }

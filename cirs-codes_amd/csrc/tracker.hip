@@ -73,77 +73,6 @@ __device__ __forceinline__ float layer_norm32(float v, int lane, const float* __
     return dlt * inv * w[o] + b[o];
 }
 
-// ---- LDS-resident weights (fused rollout) ---------------------------------------------------------------------------
-// One wavefront per env means ONE wavefront per SIMD at 1024 envs: nothing hides the L2 latency of the ~24 dependent mat-vec
-// stages of a step, and prefetching a stage ahead does not cover it (a stage is shorter than an L2 round trip).  The weights
-// are shared by every env, so the fused rollout keeps them in LDS: a packed image (every matrix TRANSPOSED, k-major, so lane o
-// reads Wt[k][o]: consecutive lanes -> consecutive banks) is built once per cirs_rollout_steps call by pack_tracker_image_kernel
-// and copied global -> LDS with coalesced 16-byte loads at the start of every step kernel (~113 KB tracker + ~22 KB policy
-// trunk: one workgroup of 4 envs per CU, as before).  The fma order of every dot product is unchanged: same bits.
-struct ImgLayout {
-    int gate_t, gate_b, ffn_t, ffn_b;
-    int in_t[2], in_b[2], out_t[2], out_b[2], l1_t[2], l1_b[2], l2_t[2], l2_b[2], n1w[2], n1b[2], n2w[2], n2b[2];
-    int dec_t, dec_b, w1_t, b1, w2_t, b2, wc, bc, total;
-};
-constexpr int kL2HalfPad = 32;   // lin2: the two k-halves are read by the two half-waves -> shift the second by 32 banks
-__host__ __device__ inline ImgLayout img_layout(int nlayers, int S) {
-    ImgLayout L{};
-    int o = 0;
-    auto take = [&](int n) { const int r = o; o += (n + 3) & ~3; return r; };
-    L.gate_t = take((kD + 1) * kD); L.gate_b = take(kD);
-    L.ffn_t = take(kD * kD); L.ffn_b = take(kD);
-    for (int l = 0; l < nlayers && l < 2; ++l) {
-        L.in_t[l] = take(kD * 96); L.in_b[l] = take(96);
-        L.out_t[l] = take(kD * kD); L.out_b[l] = take(kD);
-        L.l1_t[l] = take(kD * kHid); L.l1_b[l] = take(kHid);
-        L.l2_t[l] = take(kHid * kD + kL2HalfPad); L.l2_b[l] = take(kD);
-        L.n1w[l] = take(kD); L.n1b[l] = take(kD); L.n2w[l] = take(kD); L.n2b[l] = take(kD);
-    }
-    L.dec_t = take(kD * 32); L.dec_b = take(32);
-    L.w1_t = take(S * kH); L.b1 = take(kH); L.w2_t = take(kH * kH); L.b2 = take(kH); L.wc = take(kH); L.bc = take(4);
-    L.total = o;
-    return L;
-}
-
-// img[...] <- transposed copies of the tracker weights and of the policy trunk (pol may carry null pointers: no trunk fusion)
-__global__ __launch_bounds__(256) void pack_tracker_image_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w, cirs_policy_weights pol, int S,
-                                                                 float* __restrict__ img) {
-    const ImgLayout L = img_layout(cfg.nlayers, S);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    auto tr = [&](int dst, const float* src, int O, int K, int ld_dst) {   // dst[k * ld_dst + o] = src[o * K + k]
-        for (int i = t; i < O * K; i += nt) { const int o = i / K, k = i % K; img[dst + k * ld_dst + o] = src[i]; }
-    };
-    auto cp = [&](int dst, const float* src, int n) { for (int i = t; i < n; i += nt) img[dst + i] = src[i]; };
-    tr(L.gate_t, w.gate_w, kD, kD + 1, kD); cp(L.gate_b, w.gate_b, kD);
-    tr(L.ffn_t, w.ffn_user_w, kD, kD, kD); cp(L.ffn_b, w.ffn_user_b, kD);
-    for (int l = 0; l < cfg.nlayers; ++l) {
-        const cirs_tracker_layer& y = w.layer[l];
-        tr(L.in_t[l], y.in_proj_w, 96, kD, 96); cp(L.in_b[l], y.in_proj_b, 96);
-        tr(L.out_t[l], y.out_proj_w, kD, kD, kD); cp(L.out_b[l], y.out_proj_b, kD);
-        tr(L.l1_t[l], y.lin1_w, kHid, kD, kHid); cp(L.l1_b[l], y.lin1_b, kHid);
-        for (int i = t; i < kD * kHid; i += nt) {   // lin2 [32 out][128 in] -> [k][o], second k-half shifted by the pad
-            const int o = i / kHid, k = i % kHid;
-            img[L.l2_t[l] + k * kD + o + (k >= 64 ? kL2HalfPad : 0)] = y.lin2_w[i];
-        }
-        cp(L.l2_b[l], y.lin2_b, kD);
-        cp(L.n1w[l], y.norm1_w, kD); cp(L.n1b[l], y.norm1_b, kD); cp(L.n2w[l], y.norm2_w, kD); cp(L.n2b[l], y.norm2_b, kD);
-    }
-    tr(L.dec_t, w.dec_w, cfg.dim_state, kD, 32); cp(L.dec_b, w.dec_b, cfg.dim_state);
-    if (pol.w1) {
-        tr(L.w1_t, pol.w1, kH, S, kH); cp(L.b1, pol.b1, kH);
-        tr(L.w2_t, pol.w2, kH, kH, kH); cp(L.b2, pol.b2, kH);
-        cp(L.wc, pol.wc, kH); cp(L.bc, pol.bc, 1);
-    }
-}
-
-// acc = bias + sum_k Wt[k][o] * xs[k], k ascending: the fma order of dot_row / dot_pre
-template <int K>
-__device__ __forceinline__ float dot_lds(const float* wt, int ld, int o, const float* xs, float acc) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc = __builtin_fmaf(wt[k * ld + o], xs[k], acc);
-    return acc;
-}
-
 #ifdef CIRS_TRK_PROF
 // stage timestamps of workgroup 0 / wave 0 (probe builds only: tools/probes/trk_prof.py)
 __device__ unsigned long long g_trk_prof[32];
@@ -152,7 +81,7 @@ __device__ unsigned long long g_trk_prof[32];
 #define CIRS_STAMP(K) do { } while (0)
 #endif
 
-template <int NHEAD, bool DROP, bool LDSW>
+template <int NHEAD, bool DROP>
 __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w,
                                                            cirs_tracker_state st, const int32_t* __restrict__ users,
                                                            const int64_t* __restrict__ items,
@@ -160,21 +89,12 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
                                                            const int32_t* __restrict__ env_ids,
                                                            const uint8_t* __restrict__ skip, int n,
                                                            float* __restrict__ state_out, long state_stride,
-                                                           int lpad, TrunkFuse tf, TailFuse tl, const float* __restrict__ img) {
+                                                           int lpad, TrunkFuse tf, TailFuse tl) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = kD / NHEAD;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wv;
-    // LDSW: the weight image sits behind the four per-wave scratch areas
-    const ImgLayout IL = LDSW ? img_layout(cfg.nlayers, tf.on ? tf.cfg.dim_state : cfg.dim_state) : ImgLayout{};
-    float* lw = smem + (size_t)4 * (6 * kD + kHid + NHEAD * lpad);
     CIRS_STAMP(0);
-    if (LDSW) {
-        const float4* src = reinterpret_cast<const float4*>(img);
-        float4* dst = reinterpret_cast<float4*>(lw);
-        for (int q = threadIdx.x; q < IL.total / 4; q += 256) dst[q] = src[q];
-        __syncthreads();
-    }
     CIRS_STAMP(1);
     if (j >= n) return;
 // rows that do not step still owe the fused trunk its "skipped row" outputs
@@ -251,17 +171,10 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             xs[lane] = a;
         }
         __builtin_amdgcn_wave_barrier();
-        float acc;
-        if (LDSW) {
-            const float* gt = lw + IL.gate_t;                    // [33][32]: row 0 = the reward column
-            acc = __builtin_fmaf(gt[o32], r, lw[IL.gate_b + o32]);
-            acc = dot_lds<kD>(gt + kD, kD, o32, xs, acc);
-        } else {
-            const float* gw = w.gate_w + (size_t)o32 * (kD + 1);  // input order [r, a_0..a_31]
-            acc = w.gate_b[o32];
-            acc = __builtin_fmaf(gw[0], r, acc);
-            for (int k = 0; k < kD; ++k) acc = __builtin_fmaf(gw[1 + k], xs[k], acc);
-        }
+        const float* gw = w.gate_w + (size_t)o32 * (kD + 1);  // input order [r, a_0..a_31]
+        float acc = w.gate_b[o32];
+        acc = __builtin_fmaf(gw[0], r, acc);
+        for (int k = 0; k < kD; ++k) acc = __builtin_fmaf(gw[1 + k], xs[k], acc);
         const float g = 1.0f / (1.0f + expf(-acc));
         x = g * a;
     }
@@ -278,13 +191,9 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     if (DROP) h = CIRS_DROP(h, 0, CIRS_DROP_POS, o32);
 
     // ---- 3. encoder layers ----------------------------------------------------------------------------------
-    RowRegs<kD> pq{}, pv{};
-    float bq = 0.f, bv = 0.f;
-    if (!LDSW) {
-        pq = load_row<kD>(w.layer[0].in_proj_w + (size_t)lane * kD);                    // rows 0..63 (q, k)
-        pv = load_row<kD>(w.layer[0].in_proj_w + (size_t)(2 * kD + o32) * kD);           // rows 64..95 (v)
-        bq = w.layer[0].in_proj_b[lane]; bv = w.layer[0].in_proj_b[2 * kD + o32];
-    }
+    RowRegs<kD> pq = load_row<kD>(w.layer[0].in_proj_w + (size_t)lane * kD);                    // rows 0..63 (q, k)
+    RowRegs<kD> pv = load_row<kD>(w.layer[0].in_proj_w + (size_t)(2 * kD + o32) * kD);           // rows 64..95 (v)
+    float bq = w.layer[0].in_proj_b[lane], bv = w.layer[0].in_proj_b[2 * kD + o32];
     CIRS_STAMP(4);
     for (int l = 0; l < cfg.nlayers; ++l) {
         const cirs_tracker_layer& ly = w.layer[l];
@@ -292,15 +201,14 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         __builtin_amdgcn_wave_barrier();
         // in_proj: 96 outputs; lanes 0..63 -> rows 0..63 (q,k), lanes 0..31 -> rows 64..95 (v)
         {
-            const float r0 = LDSW ? dot_lds<kD>(lw + IL.in_t[l], 96, lane, xs, lw[IL.in_b[l] + lane]) : dot_pre<kD>(pq, xs, bq);
+            const float r0 = dot_pre<kD>(pq, xs, bq);
             if (lane < kD) qs[lane] = r0 * (1.0f / sqrtf((float)HD));  // torch scales q before QK^T
             else kcur[lane - kD] = r0;
-            if (lane < kD) vcur[lane] = LDSW ? dot_lds<kD>(lw + IL.in_t[l], 96, 2 * kD + o32, xs, lw[IL.in_b[l] + 2 * kD + o32]) : dot_pre<kD>(pv, xs, bv);
+            if (lane < kD) vcur[lane] = dot_pre<kD>(pv, xs, bv);
         }
         // next stage's weights: out_proj row + biases, LayerNorm-1 parameters (consumed after the attention below)
-        RowRegs<kD> po{};
-        float bo = 0.f;
-        if (!LDSW) { po = load_row<kD>(ly.out_proj_w + (size_t)o32 * kD); bo = ly.out_proj_b[o32]; }
+        const RowRegs<kD> po = load_row<kD>(ly.out_proj_w + (size_t)o32 * kD);
+        const float bo = ly.out_proj_b[o32];
         __builtin_amdgcn_wave_barrier();
         float* kc = st.kcache + (((size_t)l * B + e) * L) * kD;
         float* vc = st.vcache + (((size_t)l * B + e) * L) * kD;
@@ -368,43 +276,31 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         }
         CIRS_STAMP(7 + 6 * l);
         // prefetch the feed-forward's first layer (two rows per lane) while out_proj + LayerNorm run
-        RowRegs<kD> pf0{}, pf1{};
-        float bf0 = 0.f, bf1 = 0.f;
-        if (!LDSW) {
-            pf0 = load_row<kD>(ly.lin1_w + (size_t)lane * kD);
-            pf1 = load_row<kD>(ly.lin1_w + (size_t)(64 + lane) * kD);
-            bf0 = ly.lin1_b[lane]; bf1 = ly.lin1_b[64 + lane];
-        }
+        const RowRegs<kD> pf0 = load_row<kD>(ly.lin1_w + (size_t)lane * kD);
+        const RowRegs<kD> pf1 = load_row<kD>(ly.lin1_w + (size_t)(64 + lane) * kD);
+        const float bf0 = ly.lin1_b[lane], bf1 = ly.lin1_b[64 + lane];
         __builtin_amdgcn_wave_barrier();
         // out_proj + residual + LN1
-        float sa = LDSW ? dot_lds<kD>(lw + IL.out_t[l], kD, o32, att, lw[IL.out_b[l] + o32]) : dot_pre<kD>(po, att, bo);
+        float sa = dot_pre<kD>(po, att, bo);
         if (DROP) sa = CIRS_DROP(sa, l, CIRS_DROP_RES1, o32);
-        const float h1 = LDSW ? layer_norm32(h + sa, lane, lw + IL.n1w[l], lw + IL.n1b[l]) : layer_norm32(h + sa, lane, ly.norm1_w, ly.norm1_b);
+        const float h1 = layer_norm32(h + sa, lane, ly.norm1_w, ly.norm1_b);
         __builtin_amdgcn_wave_barrier();
         CIRS_STAMP(8 + 6 * l);
         if (lane < kD) tmp[lane] = h1;
         // prefetch lin2's half row (64 inputs per half-wave)
         const int half2 = lane >> 5;
-        RowRegs<64> pl2{};
-        float bl2 = 0.f;
-        if (!LDSW) { pl2 = load_row<64>(ly.lin2_w + (size_t)o32 * kHid + half2 * 64); bl2 = half2 == 0 ? ly.lin2_b[o32] : 0.f; }
-        else bl2 = half2 == 0 ? lw[IL.l2_b[l] + o32] : 0.f;
+        const RowRegs<64> pl2 = load_row<64>(ly.lin2_w + (size_t)o32 * kHid + half2 * 64);
+        const float bl2 = half2 == 0 ? ly.lin2_b[o32] : 0.f;
         __builtin_amdgcn_wave_barrier();
         // FF: 128 hidden = 2 rows per lane
         {
-            float f0, f1;
-            if (LDSW) {
-                f0 = fmaxf(dot_lds<kD>(lw + IL.l1_t[l], kHid, lane, tmp, lw[IL.l1_b[l] + lane]), 0.f);
-                f1 = fmaxf(dot_lds<kD>(lw + IL.l1_t[l], kHid, 64 + lane, tmp, lw[IL.l1_b[l] + 64 + lane]), 0.f);
-            } else {
-                f0 = fmaxf(dot_pre<kD>(pf0, tmp, bf0), 0.f); f1 = fmaxf(dot_pre<kD>(pf1, tmp, bf1), 0.f);
-            }
+            float f0 = fmaxf(dot_pre<kD>(pf0, tmp, bf0), 0.f), f1 = fmaxf(dot_pre<kD>(pf1, tmp, bf1), 0.f);
             if (DROP) { f0 = CIRS_DROP(f0, l, CIRS_DROP_FF, lane); f1 = CIRS_DROP(f1, l, CIRS_DROP_FF, 64 + lane); }
             ffs[lane] = f0;
             ffs[64 + lane] = f1;
         }
         // prefetch the next layer's in_proj rows (or nothing after the last layer)
-        if (!LDSW && l + 1 < cfg.nlayers) {
+        if (l + 1 < cfg.nlayers) {
             pq = load_row<kD>(w.layer[l + 1].in_proj_w + (size_t)lane * kD);
             pv = load_row<kD>(w.layer[l + 1].in_proj_w + (size_t)(2 * kD + o32) * kD);
             bq = w.layer[l + 1].in_proj_b[lane]; bv = w.layer[l + 1].in_proj_b[2 * kD + o32];
@@ -413,11 +309,10 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         CIRS_STAMP(9 + 6 * l);
         // lin2: 32 outputs x 128 inputs, split k in two halves across the half-waves
         {
-            float acc = LDSW ? dot_lds<64>(lw + IL.l2_t[l] + half2 * (64 * kD + kL2HalfPad), kD, o32, ffs + half2 * 64, bl2)
-                             : dot_pre<64>(pl2, ffs + half2 * 64, bl2);
+            float acc = dot_pre<64>(pl2, ffs + half2 * 64, bl2);
             acc += __shfl_xor(acc, 32, CIRS_WAVE);
             if (DROP) acc = CIRS_DROP(acc, l, CIRS_DROP_RES2, o32);
-            h = LDSW ? layer_norm32(h1 + acc, lane, lw + IL.n2w[l], lw + IL.n2b[l]) : layer_norm32(h1 + acc, lane, ly.norm2_w, ly.norm2_b);
+            h = layer_norm32(h1 + acc, lane, ly.norm2_w, ly.norm2_b);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -427,7 +322,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     __builtin_amdgcn_wave_barrier();
     float sval = 0.f;
     if (lane < cfg.dim_state) {
-        sval = LDSW ? dot_lds<kD>(lw + IL.dec_t, 32, lane, xs, lw[IL.dec_b + lane]) : dot_row<kD>(w.dec_w + (size_t)lane * kD, xs, w.dec_b[lane]);
+        sval = dot_row<kD>(w.dec_w + (size_t)lane * kD, xs, w.dec_b[lane]);
         state_out[(size_t)j * state_stride + lane] = sval;
     }
     if (lane == 0) st.len[e] = pos + 1;
@@ -438,27 +333,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         float* ths = ffs + 64;   // [64] h1
         __builtin_amdgcn_wave_barrier();
         if (lane < cfg.dim_state) txs[lane] = sval;
-        if (LDSW) {   // trunk_compute with the weights read from the LDS image: same fma chains (bias first, k ascending)
-            const int S = tf.cfg.dim_state;
-            __builtin_amdgcn_wave_barrier();
-            float acc = lw[IL.b1 + lane];
-            for (int k = 0; k < S; ++k) acc = __builtin_fmaf(lw[IL.w1_t + k * kH + lane], txs[k], acc);
-            ths[lane] = fmaxf(acc, 0.f);
-            __builtin_amdgcn_wave_barrier();
-            acc = dot_lds<kH>(lw + IL.w2_t, kH, lane, ths, lw[IL.b2 + lane]);
-            const float h2v = fmaxf(acc, 0.f);
-            tf.h2[(size_t)j * kH + lane] = h2v;
-            __builtin_amdgcn_wave_barrier();
-            txs[lane] = h2v;
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0 && tf.value) {
-                float v = lw[IL.bc];
-                for (int k = 0; k < kH; ++k) v = __builtin_fmaf(lw[IL.wc + k], txs[k], v);
-                tf.value[j] = v;
-            }
-        } else {
-            trunk_compute(tf.cfg, tf.w, txs, ths, lane, j, tf.h2, tf.value, nullptr);
-        }
+        trunk_compute(tf.cfg, tf.w, txs, ths, lane, j, tf.h2, tf.value, nullptr);
     }
     CIRS_STAMP(19);
 #undef CIRS_TRUNK_ZERO
@@ -485,7 +360,7 @@ static int validate_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weig
 static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
                           const int32_t* users, const int64_t* items, const double* rew, const int32_t* env_ids,
                           const uint8_t* skip, int n, float* state_out, long state_stride, hipStream_t s,
-                          const TrunkFuse* fuse = nullptr, const TailFuse* tail = nullptr, const float* img = nullptr) {
+                          const TrunkFuse* fuse = nullptr, const TailFuse* tail = nullptr) {
     TailFuse tl{};
     if (tail) tl = *tail;
     TrunkFuse tf{};
@@ -494,34 +369,19 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
         if (tf.on && (tf.cfg.hidden != kH || tf.cfg.dim_state != cfg->dim_state || !tf.h2)) return fail(CIRS_E_INVALID, "fused trunk: bad policy configuration");
     }
     const int lpad = (cfg->max_len + 3) & ~3;
-    size_t shmem = 4 * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad);
+    const size_t shmem = 4 * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad);
     if (shmem > 160 * 1024) return fail(CIRS_E_UNSUPPORTED, "max_len too large for the LDS score buffer");
-    // LDS-resident weights: only when the image (2 layers at most) fits next to the scratch, and not for the init step
-    const size_t img_bytes = sizeof(float) * (size_t)img_layout(cfg->nlayers, tf.on ? tf.cfg.dim_state : cfg->dim_state).total;
-    const bool ldsw = img != nullptr && users == nullptr && cfg->nlayers <= 2 && shmem + img_bytes <= 160 * 1024;
-    if (ldsw) shmem += img_bytes;
     const dim3 grid(cdiv(n, 4)), block(256);
     const bool drop = cfg->dropout_p > 0.f;
     if (drop && !(cfg->dropout_p < 1.f)) return fail(CIRS_E_INVALID, "dropout_p must be in [0, 1)");
-#define CIRS_TRK_ONE(NH, DR, LW)                                                                                      \
-    do {                                                                                                              \
-        auto kern_ = tracker_step_kernel<NH, DR, LW>;                                                                 \
-        if (LW) {                                                                                                     \
-            static bool attr_set_ = false; /* > 64 KB of dynamic LDS needs the opt-in, once per instantiation */      \
-            if (!attr_set_) {                                                                                         \
-                CIRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                attr_set_ = true;                                                                                     \
-            }                                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL(kern_, grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, n, state_out, \
-                           state_stride, lpad, tf, tl, img);                                                          \
-    } while (0)
 #define CIRS_TRK(NH)                                                                                                  \
     do {                                                                                                              \
-        if (drop && ldsw) CIRS_TRK_ONE(NH, true, true);                                                               \
-        else if (drop) CIRS_TRK_ONE(NH, true, false);                                                                 \
-        else if (ldsw) CIRS_TRK_ONE(NH, false, true);                                                                 \
-        else CIRS_TRK_ONE(NH, false, false);                                                                          \
+        if (drop)                                                                                                     \
+            hipLaunchKernelGGL((tracker_step_kernel<NH, true>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
+                               n, state_out, state_stride, lpad, tf, tl);                                             \
+        else                                                                                                          \
+            hipLaunchKernelGGL((tracker_step_kernel<NH, false>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
+                               n, state_out, state_stride, lpad, tf, tl);                                             \
     } while (0)
     switch (cfg->nhead) {
         case 1: CIRS_TRK(1); break;
@@ -530,28 +390,14 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
         default: CIRS_TRK(8); break;
     }
 #undef CIRS_TRK
-#undef CIRS_TRK_ONE
     CIRS_CHECK_LAUNCH("tracker_step_kernel");
     return CIRS_OK;
 }
 
 int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
-                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail, const float* img) {
-    return launch_tracker(cfg, w, st, users, items, rew, env_ids, skip, n, state_out, state_stride, s, tf, tail, img);
-}
-
-size_t tracker_image_bytes(const cirs_tracker_cfg* cfg, int dim_state_policy) {
-    return sizeof(float) * (size_t)img_layout(cfg->nlayers, dim_state_policy).total;
-}
-
-int tracker_pack_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_policy_weights* pol, int dim_state_policy,
-                       float* img, hipStream_t s) {
-    cirs_policy_weights pw{};
-    if (pol) pw = *pol;
-    hipLaunchKernelGGL(pack_tracker_image_kernel, dim3(32), dim3(256), 0, s, *cfg, *w, pw, dim_state_policy, img);
-    CIRS_CHECK_LAUNCH("pack_tracker_image_kernel");
-    return CIRS_OK;
+                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail) {
+    return launch_tracker(cfg, w, st, users, items, rew, env_ids, skip, n, state_out, state_stride, s, tf, tail);
 }
 
 }  // namespace cirs

@@ -265,10 +265,6 @@ typedef struct cirs_online_reward {
     float* pred_buf;            /* [B] scratch: raw scores of this step              */
 } cirs_online_reward;
 
-/* workspace of cirs_rollout_steps*: the sampler scratch (cirs_policy_workspace_bytes) + the LDS weight image of the fused tracker
- * step (transposed tracker / policy-trunk weights, rebuilt at the start of every call).  A workspace of only
- * cirs_policy_workspace_bytes is accepted too: the tracker step then reads its weights from global memory (same results). */
-int64_t cirs_rollout_workspace_bytes(const cirs_policy_cfg* pol_cfg, const cirs_tracker_cfg* trk_cfg, int32_t n_env);
 int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
                        const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
                        const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj,
