@@ -14,6 +14,11 @@ constexpr int kChunkItems = kTileN * kTilesPerChunk;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// value of lane `k` (compile-time constant) in every lane: v_readlane_b32, no LDS round trip
+__device__ __forceinline__ float lane_bcast(float v, int k) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+
 struct ActorPartialView {  // SoA in the workspace, each array [n_chunks][n_pad]
     float* score;
     int32_t* idx;
@@ -340,18 +345,23 @@ __device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, 
         }
     }
     const int64_t act = bi == 0x7FFFFFFF ? -1 : (int64_t)bi;  // identical in every lane after the butterfly
+    // the chosen item's logit: its row of Wa and this row of H2 arrive as two coalesced 256-byte loads (lane k holds element k);
+    // the fma chain (bias, then k = kk, 32 + kk) reads them lane by lane through v_readlane: uniform values, same order, same bits
+    float z = 0.f;
+    if (logp_out && bi != 0x7FFFFFFF) {
+        const float wv = wa[(size_t)bi * kH + lane], hv = h2[(size_t)j * kH + lane];
+        z = ba[bi];
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            z = __builtin_fmaf(lane_bcast(hv, kk), lane_bcast(wv, kk), z);
+            z = __builtin_fmaf(lane_bcast(hv, 32 + kk), lane_bcast(wv, 32 + kk), z);
+        }
+    }
     if (lane != 0) return act;
     act_out[j] = act;
     if (logp_out) {
         float lp = 0.f;
         if (bi != 0x7FFFFFFF) {
-            const float* wr = wa + (size_t)bi * kH;
-            const float* hr = h2 + (size_t)j * kH;
-            float z = ba[bi];
-            for (int kk = 0; kk < 32; ++kk) {
-                z = __builtin_fmaf(hr[kk], wr[kk], z);
-                z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
-            }
             const float lse = m + __logf(s);
             float p = __expf(z - lse);  // softmax prob of the chosen item (over unmasked items)
             const float eps = 1.1920928955078125e-7f;

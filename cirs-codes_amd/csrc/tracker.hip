@@ -111,7 +111,10 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     int fin_f = 0;
     if (tl.on) {
         int64_t act = -1;
-        if (tl.st.done[j]) {  // finished env: the policy skipped it
+        // the env's own state (user, turn, history entry of this lane, running reward) does not depend on the action: its loads
+        // are issued BEFORE the merge of the sampler partials and complete underneath it
+        const EnvPrefetch epf = env_prefetch(tl.cfg, tl.st, j, lane);
+        if (epf.done) {  // finished env: the policy skipped it
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
         } else {
             act = actor_merge_wave(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.wa, tl.ba, tl.h2, tl.act_out, tl.logp_out);
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         }
         CIRS_STAMP(2);
         EnvStepResult er;
-        env_step_wave(tl.cfg, tl.tab, tl.st, j, j, act, lane, nullptr, tl.rew_out, tl.done_out, tl.ctr_out, nullptr, &er);
+        env_step_wave(tl.cfg, tl.tab, tl.st, j, j, act, lane, nullptr, tl.rew_out, tl.done_out, tl.ctr_out, nullptr, &er, &epf);
         const unsigned long long rb = __builtin_bit_cast(unsigned long long, er.reward);
         const unsigned rlo = __shfl((unsigned)rb, 0, CIRS_WAVE), rhi = __shfl((unsigned)(rb >> 32), 0, CIRS_WAVE);
         const double reward = __builtin_bit_cast(double, ((unsigned long long)rhi << 32) | rlo);
@@ -264,9 +267,20 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         {
             const int half = lane >> 5, d = o32, hh = d / HD;
             float acc = 0.f;
-            for (int jp = half; jp <= pos; jp += 2) {
-                const float vv = jp == pos ? vcur[d] : vc[(size_t)jp * kD + d];
-                acc = __builtin_fmaf(ps[hh * lpad + jp], vv, acc);
+            // 8 cached rows per batch: the loads of a batch are in flight together (one L2 round trip per 16 positions instead of
+            // one per position); the fma chain keeps its order (jp ascending per half-wave): same bits
+            for (int j0 = half; j0 <= pos; j0 += 16) {
+                float v8[8];
+#pragma unroll
+                for (int u8 = 0; u8 < 8; ++u8) {
+                    const int jp = j0 + 2 * u8;
+                    v8[u8] = jp < pos ? vc[(size_t)jp * kD + d] : 0.f;
+                }
+#pragma unroll
+                for (int u8 = 0; u8 < 8; ++u8) {
+                    const int jp = j0 + 2 * u8;
+                    if (jp <= pos) acc = __builtin_fmaf(ps[hh * lpad + jp], jp == pos ? vcur[d] : v8[u8], acc);
+                }
             }
             acc += __shfl_xor(acc, 32, CIRS_WAVE);
             float norm = sm[0];
