@@ -67,6 +67,32 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
+// ---- register-only wavefront reductions (DPP within a row of 16 lanes, v_readlane across the four rows): no LDS round trips.
+// Pairing order: xor 1, xor 2, then the two quads / the two halves of a row (mirror permutations: after the xor steps all lanes
+// of a quad / half hold the same value, so the mirror partner carries exactly the other group's sum), then (r0 + r1) + (r2 + r3).
+// A balanced tree like the __shfl_xor butterfly above, but with a different pairing: sums may differ in the last bit, max is exact.
+template <int kCtrl>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_pick(float v, int lane_id) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_id));
+}
+__device__ __forceinline__ float wave_sum_f32_dpp(float v) {
+    v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);   // row_half_mirror
+    v += dpp_f32<0x140>(v);   // row_mirror
+    return (row_pick(v, 0) + row_pick(v, 16)) + (row_pick(v, 32) + row_pick(v, 48));
+}
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return fmaxf(fmaxf(row_pick(v, 0), row_pick(v, 16)), fmaxf(row_pick(v, 32), row_pick(v, 48)));
+}
+
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it stalls every wave until its
 // outstanding global stores/loads have completed (~1-2 us for a store).  Use where the data exchanged is in LDS and
 // the global accesses in flight are either write-only results or prefetches consumed behind a later register dependency.

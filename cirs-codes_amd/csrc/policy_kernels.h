@@ -314,18 +314,36 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 // merge the per-chunk partials of env row j (one wavefront, lanes stride over chunks); recompute the chosen item's
 // logit with the SAME k-order as the MFMA chain (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with the
 // sampled distribution.  Lane 0 writes act / logp; the action id is returned in every lane.
+// The first two chunk partials of every lane (chunks lane and lane + 64: the whole catalogue up to 128 chunks) and this row's
+// element of H2 do not depend on anything computed in the merging kernel: a caller may request them early (fused rollout: together
+// with the env-state prefetch, before it knows whether the env still runs) and pass them in.
+struct MergePre { float sc[2], m[2], s[2], hv; int idx[2]; };
+__device__ __forceinline__ MergePre actor_merge_prefetch(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv,
+                                                         const float* __restrict__ h2) {
+    MergePre p;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + CIRS_WAVE * q;
+        const size_t o = (size_t)(c < n_chunks ? c : 0) * n_pad + j;
+        p.sc[q] = pv.score[o]; p.idx[q] = pv.idx[o]; p.m[q] = pv.m[o]; p.s[q] = pv.s[o];
+    }
+    p.hv = h2[(size_t)j * kH + lane];
+    return p;
+}
+
 __device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv,
                                                     const float* __restrict__ wa, const float* __restrict__ ba,
                                                     const float* __restrict__ h2, int64_t* __restrict__ act_out,
-                                                    float* __restrict__ logp_out) {
+                                                    float* __restrict__ logp_out, const MergePre* pre = nullptr) {
     float bs = -INFINITY, m = -INFINITY, s = 0.f;
     int bi = 0x7FFFFFFF;
-    for (int c = lane; c < n_chunks; c += CIRS_WAVE) {  // within a lane chunks ascend: strict > keeps the lowest id
+    for (int c = lane, q = 0; c < n_chunks; c += CIRS_WAVE, ++q) {  // within a lane chunks ascend: strict > keeps the lowest id
         const size_t o = (size_t)c * n_pad + j;
-        const float os = pv.score[o];
-        const int oi = pv.idx[o];
+        const bool early = pre && q < 2;
+        const float os = early ? (q == 0 ? pre->sc[0] : pre->sc[1]) : pv.score[o];
+        const int oi = early ? (q == 0 ? pre->idx[0] : pre->idx[1]) : pv.idx[o];
         if (os > bs) { bs = os; bi = oi; }
-        const float om = pv.m[o], osum = pv.s[o];
+        const float om = early ? (q == 0 ? pre->m[0] : pre->m[1]) : pv.m[o], osum = early ? (q == 0 ? pre->s[0] : pre->s[1]) : pv.s[o];
         const float mn = fmaxf(m, om);
         if (mn > -INFINITY) {
             s = s * __expf(m - mn) + osum * __expf(om - mn);
@@ -349,7 +367,7 @@ __device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, 
     // the fma chain (bias, then k = kk, 32 + kk) reads them lane by lane through v_readlane: uniform values, same order, same bits
     float z = 0.f;
     if (logp_out && bi != 0x7FFFFFFF) {
-        const float wv = wa[(size_t)bi * kH + lane], hv = h2[(size_t)j * kH + lane];
+        const float wv = wa[(size_t)bi * kH + lane], hv = pre ? pre->hv : h2[(size_t)j * kH + lane];
         z = ba[bi];
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk) {

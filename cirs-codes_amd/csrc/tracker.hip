@@ -65,9 +65,9 @@ __device__ __forceinline__ float dot_pre(const RowRegs<K>& r, const float* xs, f
 // LayerNorm over the 32 values held by lanes 0..31 (lanes >= 32 pass 0 and get garbage they never use)
 __device__ __forceinline__ float layer_norm32(float v, int lane, const float* __restrict__ w, const float* __restrict__ b) {
     const float vv = lane < kD ? v : 0.f;
-    const float mean = wave_sum_f32(vv) * (1.0f / kD);
+    const float mean = wave_sum_f32_dpp(vv) * (1.0f / kD);
     const float dlt = lane < kD ? v - mean : 0.f;
-    const float var = wave_sum_f32(dlt * dlt) * (1.0f / kD);
+    const float var = wave_sum_f32_dpp(dlt * dlt) * (1.0f / kD);
     const float inv = 1.0f / sqrtf(var + 1e-5f);
     const int o = lane & (kD - 1);
     return dlt * inv * w[o] + b[o];
@@ -114,10 +114,11 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         // the env's own state (user, turn, history entry of this lane, running reward) does not depend on the action: its loads
         // are issued BEFORE the merge of the sampler partials and complete underneath it
         const EnvPrefetch epf = env_prefetch(tl.cfg, tl.st, j, lane);
+        const MergePre mpre = actor_merge_prefetch(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.h2);   // same round trip as the env state
         if (epf.done) {  // finished env: the policy skipped it
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
         } else {
-            act = actor_merge_wave(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.wa, tl.ba, tl.h2, tl.act_out, tl.logp_out);
+            act = actor_merge_wave(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.wa, tl.ba, tl.h2, tl.act_out, tl.logp_out, &mpre);
             if (tl.visited && act >= 0 && lane == 0) {
                 const int words = (tl.cfg.n_items + 31) / 32;
                 tl.visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
@@ -158,6 +159,24 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     const int pos = is_init ? 0 : st.len[e];
     if (pos >= L) { CIRS_TRUNK_ZERO(); return; }  // history full: the caller never steps past max_turn
 
+    // ---- 0. K/V cache rows of the earlier positions depend on (env, pos) only: the first batch of a layer (positions < 64 for K,
+    //         < 16 per half-wave for V) is requested one layer AHEAD -- layer 0 here, layer l + 1 right after layer l's attention --
+    //         and arrives under the mat-vec stages in between (one register set, reused)
+    float4 kpre[kD / 4];
+    float vpre[8];
+#define CIRS_KV_PREFETCH(LAYER)                                                                                  \
+    do {                                                                                                         \
+        const float* kc0_ = st.kcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
+        const float* vc0_ = st.vcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
+        const float4* k4_ = reinterpret_cast<const float4*>(kc0_ + (size_t)lane * kD);                           \
+        _Pragma("unroll") for (int q4 = 0; q4 < kD / 4; ++q4)                                                    \
+            kpre[q4] = lane < pos ? k4_[q4] : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+        _Pragma("unroll") for (int u8 = 0; u8 < 8; ++u8) {                                                       \
+            const int jp_ = (lane >> 5) + 2 * u8;                                                                \
+            vpre[u8] = jp_ < pos ? vc0_[(size_t)jp_ * kD + o32] : 0.f;                                           \
+        }                                                                                                        \
+    } while (0)
+    CIRS_KV_PREFETCH(0);
     // ---- 1. new input slot --------------------------------------------------------------------------------
     float x;
     if (is_init) {
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
                 const float4* k4 = reinterpret_cast<const float4*>(kc + (size_t)jp * kD);
 #pragma unroll
                 for (int q4 = 0; q4 < kD / 4; ++q4) {
-                    const float4 t4 = k4[q4];
+                    const float4 t4 = jp == lane ? kpre[q4] : k4[q4];   // first batch (jp == lane): prefetched
                     kv[4 * q4] = t4.x; kv[4 * q4 + 1] = t4.y; kv[4 * q4 + 2] = t4.z; kv[4 * q4 + 3] = t4.w;
                 }
             }
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         float sm[NHEAD];
 #pragma unroll
         for (int hh = 0; hh < NHEAD; ++hh) {
-            mx[hh] = wave_max_f32(mx[hh]);
+            mx[hh] = wave_max_f32_dpp(mx[hh]);
             sm[hh] = 0.f;
         }
         for (int jp = lane; jp <= pos; jp += CIRS_WAVE) {
@@ -260,7 +279,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             }
         }
 #pragma unroll
-        for (int hh = 0; hh < NHEAD; ++hh) sm[hh] = 1.0f / wave_sum_f32(sm[hh]);
+        for (int hh = 0; hh < NHEAD; ++hh) sm[hh] = 1.0f / wave_sum_f32_dpp(sm[hh]);
         __builtin_amdgcn_wave_barrier();
         CIRS_STAMP(6 + 6 * l);
         // weighted sum of V: lane (half, d): positions jp = half, half+2, ...
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
 #pragma unroll
                 for (int u8 = 0; u8 < 8; ++u8) {
                     const int jp = j0 + 2 * u8;
-                    v8[u8] = jp < pos ? vc[(size_t)jp * kD + d] : 0.f;
+                    v8[u8] = j0 == half ? vpre[u8] : (jp < pos ? vc[(size_t)jp * kD + d] : 0.f);   // first batch: prefetched
                 }
 #pragma unroll
                 for (int u8 = 0; u8 < 8; ++u8) {
@@ -288,6 +307,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             for (int q = 1; q < NHEAD; ++q) norm = hh == q ? sm[q] : norm;
             if (lane < kD) att[d] = acc * norm;
         }
+        if (l + 1 < cfg.nlayers) CIRS_KV_PREFETCH(l + 1);
         CIRS_STAMP(7 + 6 * l);
         // prefetch the feed-forward's first layer (two rows per lane) while out_proj + LayerNorm run
         const RowRegs<kD> pf0 = load_row<kD>(ly.lin1_w + (size_t)lane * kD);
@@ -351,6 +371,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     }
     CIRS_STAMP(19);
 #undef CIRS_TRUNK_ZERO
+#undef CIRS_KV_PREFETCH
 #undef CIRS_DROP
 }
 
