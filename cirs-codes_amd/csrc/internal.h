@@ -56,7 +56,6 @@ struct TailFuse {
     cirs_env_state st;
     int n_pad, n_chunks;
     ActorPartialView pv;
-    const float *wa, *ba, *h2;
     uint32_t* visited;
     int force_length, force_done;
     int64_t* act_out;

@@ -23,8 +23,6 @@ namespace cirs {
 
 // merge partials across chunks: action id (ties -> lowest id), logp with Categorical's clamp (actor_merge_wave)
 __global__ __launch_bounds__(256) void actor_merge_kernel(int n, int n_pad, int n_chunks, ActorPartialView pv,
-                                                          const float* __restrict__ wa, const float* __restrict__ ba,
-                                                          const float* __restrict__ h2,
                                                           const uint8_t* __restrict__ skip,
                                                           int64_t* __restrict__ act_out, float* __restrict__ logp_out) {
     const int lane = threadIdx.x & 63;
@@ -37,13 +35,11 @@ __global__ __launch_bounds__(256) void actor_merge_kernel(int n, int n_pad, int 
         }
         return;
     }
-    actor_merge_wave(j, lane, n_pad, n_chunks, pv, wa, ba, h2, act_out, logp_out);
+    actor_merge_wave(j, lane, n_pad, n_chunks, pv, act_out, logp_out);
 }
 
 __global__ __launch_bounds__(256) void actor_shard_tuple_kernel(int n, int n_pad, int n_chunks, ActorPartialView pv,
-                                                               const float* __restrict__ wa, const float* __restrict__ ba,
-                                                               const float* __restrict__ h2, const uint8_t* __restrict__ skip,
-                                                               int item_base, float* __restrict__ out5) {
+                                                               const uint8_t* __restrict__ skip, float* __restrict__ out5) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n) return;
@@ -54,7 +50,7 @@ __global__ __launch_bounds__(256) void actor_shard_tuple_kernel(int n, int n_pad
         }
         return;
     }
-    actor_shard_tuple_wave(j, lane, n_pad, n_chunks, pv, wa, ba, h2, item_base, n, out5);
+    actor_shard_tuple_wave(j, lane, n_pad, n_chunks, pv, n, out5);
 }
 
 // cross-rank merge of W shard tuples per env row, in RANK ORDER (fixed): candidate with the highest noisy score (ties -> lowest
@@ -124,7 +120,7 @@ static int validate_policy(const cirs_policy_cfg* cfg, const cirs_policy_weights
 extern "C" int64_t cirs_policy_workspace_bytes(const cirs_policy_cfg* cfg, int32_t n) {
     using namespace cirs;
     if (!cfg || n <= 0) return 0;
-    return (int64_t)(ws_h2_floats(n) + 4 * ws_partial_elems(n, cfg->n_items)) * 4;
+    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items)) * 4;
 }
 
 extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state,
@@ -152,8 +148,7 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
     hipLaunchKernelGGL(actor_head_kernel, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
                        rng_step, env_ids, visited, skip, pv, n_pad, hg.tiles_per_chunk);
     CIRS_CHECK_LAUNCH("actor_head_kernel");
-    hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, n_chunks, pv, w->wa, w->ba,
-                       h2, skip, act_out, logp_out);
+    hipLaunchKernelGGL(actor_merge_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, n_chunks, pv, skip, act_out, logp_out);
     CIRS_CHECK_LAUNCH("actor_merge_kernel");
     return CIRS_OK;
 }
@@ -182,8 +177,7 @@ extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const
                        (const float*)h2, n, (const float*)nullptr, seed, rng_step, env_ids, visited, skip, pv, n_pad, hg.tiles_per_chunk,
                        item_base, n_items_total);
     CIRS_CHECK_LAUNCH("actor_head_kernel");
-    hipLaunchKernelGGL(actor_shard_tuple_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, hg.n_chunks, pv, w_shard->wa, w_shard->ba,
-                       (const float*)h2, skip, item_base, tuples_out);
+    hipLaunchKernelGGL(actor_shard_tuple_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, hg.n_chunks, pv, skip, tuples_out);
     CIRS_CHECK_LAUNCH("actor_shard_tuple_kernel");
     return CIRS_OK;
 }

@@ -14,16 +14,12 @@ constexpr int kChunkItems = kTileN * kTilesPerChunk;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// value of lane `k` (compile-time constant) in every lane: v_readlane_b32, no LDS round trip
-__device__ __forceinline__ float lane_bcast(float v, int k) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
-}
-
 struct ActorPartialView {  // SoA in the workspace, each array [n_chunks][n_pad]
     float* score;
     int32_t* idx;
     float* m;
     float* s;
+    float* z;   // sampler only: the candidate's own logit (the MFMA accumulator value), so the merge needs no second look at Wa
 };
 
 __host__ __device__ inline int n_chunks_of(int n_items) { return (n_items + kChunkItems - 1) / kChunkItems; }
@@ -40,6 +36,7 @@ __host__ __device__ inline ActorPartialView partial_view(void* ws, int n, int n_
     v.idx = (int32_t*)(base + e);
     v.m = base + 2 * e;
     v.s = base + 3 * e;
+    v.z = base + 4 * e;   // (the learner's statistics pass sizes its buffer for four arrays and never touches z)
     return v;
 }
 
@@ -186,7 +183,7 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 #pragma unroll
         for (int q = 0; q < 32; ++q) hrow[q] = 0.f;
     }
-    float best_score = -INFINITY, run_m = -INFINITY, run_s = 0.f;
+    float best_score = -INFINITY, best_z = 0.f, run_m = -INFINITY, run_s = 0.f;
     int best_idx = 0x7FFFFFFF;
 
     const int st_item = tid >> 3, st_col = (tid & 7) * 8;  // staging role: 2 float4 of the tile
@@ -266,7 +263,7 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
                                 const float gn = gumbel ? gumbel[(size_t)jr * I_tot + item_base + item] : g4[q];
                                 const float sc = z + gn;
                                 if (sc > best_score) {  // items ascend within a lane: strict > keeps the lowest id on ties
-                                    best_score = sc; best_idx = item_base + item;
+                                    best_score = sc; best_idx = item_base + item; best_z = z;
                                 }
                             }
                         }
@@ -294,9 +291,9 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
     if (row0 >= n_pad) return;
     // combine the two half-waves (same env row, disjoint items)
     {
-        const float os = __shfl_xor(best_score, 32, CIRS_WAVE);
+        const float os = __shfl_xor(best_score, 32, CIRS_WAVE), oz = __shfl_xor(best_z, 32, CIRS_WAVE);
         const int oi = __shfl_xor(best_idx, 32, CIRS_WAVE);
-        if (os > best_score || (os == best_score && oi < best_idx)) { best_score = os; best_idx = oi; }
+        if (os > best_score || (os == best_score && oi < best_idx)) { best_score = os; best_idx = oi; best_z = oz; }
         const float om = __shfl_xor(run_m, 32, CIRS_WAVE), osum = __shfl_xor(run_s, 32, CIRS_WAVE);
         const float mn = fmaxf(run_m, om);
         if (mn > -INFINITY) {
@@ -306,7 +303,7 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
         }
     }
     if (hi == 0) {
-        pv.score[po] = best_score; pv.idx[po] = best_idx;
+        pv.score[po] = best_score; pv.idx[po] = best_idx; pv.z[po] = best_z;
         pv.m[po] = run_m; pv.s[po] = run_s;
     }
 }
@@ -314,74 +311,81 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 // merge the per-chunk partials of env row j (one wavefront, lanes stride over chunks); recompute the chosen item's
 // logit with the SAME k-order as the MFMA chain (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with the
 // sampled distribution.  Lane 0 writes act / logp; the action id is returned in every lane.
-// The first two chunk partials of every lane (chunks lane and lane + 64: the whole catalogue up to 128 chunks) and this row's
-// element of H2 do not depend on anything computed in the merging kernel: a caller may request them early (fused rollout: together
-// with the env-state prefetch, before it knows whether the env still runs) and pass them in.
-struct MergePre { float sc[2], m[2], s[2], hv; int idx[2]; };
-__device__ __forceinline__ MergePre actor_merge_prefetch(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv,
-                                                         const float* __restrict__ h2) {
+// ---- merge of the per-chunk partials of one env row (one wavefront) --------------------------------------------------------
+// Candidate = (noisy score, item id, its logit); the winner is the highest score, ties -> lowest id (order independent);
+// (m, s) = running max / sum-exp of the logits, folded pairwise.  Lanes first fold the chunks they own (lane, lane + 64, ...),
+// then the wavefront reduces in registers: four DPP steps inside each row of 16 lanes (xor 1, xor 2, half-mirror, mirror: after
+// every step both partners hold the same merged value, so the mirror partner carries exactly the other group's result) and the
+// four row results are folded in row order through v_readlane.  No LDS round trips, no second look at Wa: the candidate's logit
+// travels with it (it is the MFMA accumulator value the oracle's fma chain reproduces bit for bit).
+struct Cand { float bs, bz, m, s; int bi; };
+__device__ __forceinline__ void cand_fold(Cand& a, float os, int oi, float oz, float om, float osum) {
+    if (os > a.bs || (os == a.bs && oi < a.bi)) { a.bs = os; a.bi = oi; a.bz = oz; }
+    const float mn = fmaxf(a.m, om);
+    if (mn > -INFINITY) {
+        a.s = a.s * __expf(a.m - mn) + osum * __expf(om - mn);
+        a.m = mn;
+    }
+}
+template <int kCtrl>
+__device__ __forceinline__ void cand_dpp_step(Cand& a) {
+    const float os = dpp_f32<kCtrl>(a.bs), oz = dpp_f32<kCtrl>(a.bz), om = dpp_f32<kCtrl>(a.m), osum = dpp_f32<kCtrl>(a.s);
+    const int oi = __builtin_amdgcn_update_dpp(0, a.bi, kCtrl, 0xF, 0xF, false);
+    cand_fold(a, os, oi, oz, om, osum);
+}
+__device__ __forceinline__ Cand cand_wave_reduce(Cand a) {
+    cand_dpp_step<0xB1>(a); cand_dpp_step<0x4E>(a); cand_dpp_step<0x141>(a); cand_dpp_step<0x140>(a);
+    Cand r{row_pick(a.bs, 0), row_pick(a.bz, 0), row_pick(a.m, 0), row_pick(a.s, 0), __builtin_amdgcn_readlane(a.bi, 0)};
+#pragma unroll
+    for (int row = 1; row < 4; ++row)
+        cand_fold(r, row_pick(a.bs, 16 * row), __builtin_amdgcn_readlane(a.bi, 16 * row), row_pick(a.bz, 16 * row), row_pick(a.m, 16 * row),
+                  row_pick(a.s, 16 * row));
+    return r;   // identical in every lane
+}
+
+// The first two chunk partials of every lane (chunks lane and lane + 64: the whole catalogue up to 128 chunks) do not depend on
+// anything computed in the merging kernel: a caller may request them early (fused rollout: together with the env-state prefetch,
+// before it knows whether the env still runs) and pass them in.
+struct MergePre { float sc[2], z[2], m[2], s[2]; int idx[2]; };
+__device__ __forceinline__ MergePre actor_merge_prefetch(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv) {
     MergePre p;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = lane + CIRS_WAVE * q;
         const size_t o = (size_t)(c < n_chunks ? c : 0) * n_pad + j;
-        p.sc[q] = pv.score[o]; p.idx[q] = pv.idx[o]; p.m[q] = pv.m[o]; p.s[q] = pv.s[o];
+        p.sc[q] = pv.score[o]; p.idx[q] = pv.idx[o]; p.z[q] = pv.z[o]; p.m[q] = pv.m[o]; p.s[q] = pv.s[o];
     }
-    p.hv = h2[(size_t)j * kH + lane];
     return p;
 }
 
-__device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv,
-                                                    const float* __restrict__ wa, const float* __restrict__ ba,
-                                                    const float* __restrict__ h2, int64_t* __restrict__ act_out,
-                                                    float* __restrict__ logp_out, const MergePre* pre = nullptr) {
-    float bs = -INFINITY, m = -INFINITY, s = 0.f;
-    int bi = 0x7FFFFFFF;
-    for (int c = lane, q = 0; c < n_chunks; c += CIRS_WAVE, ++q) {  // within a lane chunks ascend: strict > keeps the lowest id
+__device__ __forceinline__ Cand actor_merge_chunks(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv, const MergePre* pre) {
+    Cand a{-INFINITY, 0.f, -INFINITY, 0.f, 0x7FFFFFFF};
+    for (int c = lane, q = 0; c < n_chunks; c += CIRS_WAVE, ++q) {  // within a lane chunks ascend
         const size_t o = (size_t)c * n_pad + j;
-        const bool early = pre && q < 2;
-        const float os = early ? (q == 0 ? pre->sc[0] : pre->sc[1]) : pv.score[o];
-        const int oi = early ? (q == 0 ? pre->idx[0] : pre->idx[1]) : pv.idx[o];
-        if (os > bs) { bs = os; bi = oi; }
-        const float om = early ? (q == 0 ? pre->m[0] : pre->m[1]) : pv.m[o], osum = early ? (q == 0 ? pre->s[0] : pre->s[1]) : pv.s[o];
-        const float mn = fmaxf(m, om);
-        if (mn > -INFINITY) {
-            s = s * __expf(m - mn) + osum * __expf(om - mn);
-            m = mn;
+        if (pre && q < 2) {
+            const int k = q;   // q is 0 or 1 here: selects, no dynamic register index
+            cand_fold(a, k == 0 ? pre->sc[0] : pre->sc[1], k == 0 ? pre->idx[0] : pre->idx[1], k == 0 ? pre->z[0] : pre->z[1],
+                      k == 0 ? pre->m[0] : pre->m[1], k == 0 ? pre->s[0] : pre->s[1]);
+        } else {
+            cand_fold(a, pv.score[o], pv.idx[o], pv.z[o], pv.m[o], pv.s[o]);
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float os = __shfl_xor(bs, off, CIRS_WAVE);
-        const int oi = __shfl_xor(bi, off, CIRS_WAVE);
-        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
-        const float om = __shfl_xor(m, off, CIRS_WAVE), osum = __shfl_xor(s, off, CIRS_WAVE);
-        const float mn = fmaxf(m, om);
-        if (mn > -INFINITY) {
-            s = s * __expf(m - mn) + osum * __expf(om - mn);
-            m = mn;
-        }
-    }
-    const int64_t act = bi == 0x7FFFFFFF ? -1 : (int64_t)bi;  // identical in every lane after the butterfly
-    // the chosen item's logit: its row of Wa and this row of H2 arrive as two coalesced 256-byte loads (lane k holds element k);
-    // the fma chain (bias, then k = kk, 32 + kk) reads them lane by lane through v_readlane: uniform values, same order, same bits
-    float z = 0.f;
-    if (logp_out && bi != 0x7FFFFFFF) {
-        const float wv = wa[(size_t)bi * kH + lane], hv = pre ? pre->hv : h2[(size_t)j * kH + lane];
-        z = ba[bi];
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
-            z = __builtin_fmaf(lane_bcast(hv, kk), lane_bcast(wv, kk), z);
-            z = __builtin_fmaf(lane_bcast(hv, 32 + kk), lane_bcast(wv, 32 + kk), z);
-        }
-    }
+    return cand_wave_reduce(a);
+}
+
+// action id (ties -> lowest id) and log-prob with Categorical's clamp; lane 0 writes, the action id is returned in every lane
+__device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv,
+                                                    int64_t* __restrict__ act_out, float* __restrict__ logp_out,
+                                                    const MergePre* pre = nullptr) {
+    const Cand r = actor_merge_chunks(j, lane, n_pad, n_chunks, pv, pre);
+    const int64_t act = r.bi == 0x7FFFFFFF ? -1 : (int64_t)r.bi;
     if (lane != 0) return act;
     act_out[j] = act;
     if (logp_out) {
         float lp = 0.f;
-        if (bi != 0x7FFFFFFF) {
-            const float lse = m + __logf(s);
-            float p = __expf(z - lse);  // softmax prob of the chosen item (over unmasked items)
+        if (r.bi != 0x7FFFFFFF) {
+            const float lse = r.m + __logf(r.s);
+            float p = __expf(r.bz - lse);  // softmax prob of the chosen item (over unmasked items)
             const float eps = 1.1920928955078125e-7f;
             p = fminf(fmaxf(p, eps), 1.0f - eps);  // torch probs_to_logits clamp
             lp = __logf(p);
@@ -391,53 +395,17 @@ __device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, 
     return act;
 }
 
-// Column-sharded head: merge this shard's chunk partials of env row j into ONE tuple (score, global id, logit of that candidate,
-// running max, running sum-exp) -- what a rank contributes to the cross-rank merge.  Same reduction order as actor_merge_wave.
-__device__ __forceinline__ void actor_shard_tuple_wave(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv,
-                                                       const float* __restrict__ wa, const float* __restrict__ ba,
-                                                       const float* __restrict__ h2, int item_base, int n, float* __restrict__ out5) {
-    float bs = -INFINITY, m = -INFINITY, s = 0.f;
-    int bi = 0x7FFFFFFF;
-    for (int c = lane; c < n_chunks; c += CIRS_WAVE) {
-        const size_t o = (size_t)c * n_pad + j;
-        const float os = pv.score[o];
-        const int oi = pv.idx[o];
-        if (os > bs) { bs = os; bi = oi; }
-        const float om = pv.m[o], osum = pv.s[o];
-        const float mn = fmaxf(m, om);
-        if (mn > -INFINITY) {
-            s = s * __expf(m - mn) + osum * __expf(om - mn);
-            m = mn;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float os = __shfl_xor(bs, off, CIRS_WAVE);
-        const int oi = __shfl_xor(bi, off, CIRS_WAVE);
-        if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
-        const float om = __shfl_xor(m, off, CIRS_WAVE), osum = __shfl_xor(s, off, CIRS_WAVE);
-        const float mn = fmaxf(m, om);
-        if (mn > -INFINITY) {
-            s = s * __expf(m - mn) + osum * __expf(om - mn);
-            m = mn;
-        }
-    }
+// Column-sharded head: this shard's chunk partials of env row j as ONE tuple (score, global id, logit of that candidate, running
+// max, running sum-exp) -- what a rank contributes to the cross-rank merge.
+__device__ __forceinline__ void actor_shard_tuple_wave(int j, int lane, int n_pad, int n_chunks, const ActorPartialView& pv, int n,
+                                                       float* __restrict__ out5) {
+    const Cand r = actor_merge_chunks(j, lane, n_pad, n_chunks, pv, nullptr);
     if (lane != 0) return;
-    float z = 0.f;
-    if (bi != 0x7FFFFFFF) {     // the candidate's logit, same k-order as the MFMA chain (bias, then k = kk, 32 + kk)
-        const float* wr = wa + (size_t)(bi - item_base) * kH;
-        const float* hr = h2 + (size_t)j * kH;
-        z = ba[bi - item_base];
-        for (int kk = 0; kk < 32; ++kk) {
-            z = __builtin_fmaf(hr[kk], wr[kk], z);
-            z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
-        }
-    }
-    out5[j] = bs;
-    reinterpret_cast<int32_t*>(out5)[(size_t)n + j] = bi;
-    out5[(size_t)2 * n + j] = z;
-    out5[(size_t)3 * n + j] = m;
-    out5[(size_t)4 * n + j] = s;
+    out5[j] = r.bs;
+    reinterpret_cast<int32_t*>(out5)[(size_t)n + j] = r.bi;
+    out5[(size_t)2 * n + j] = r.bi != 0x7FFFFFFF ? r.bz : 0.f;
+    out5[(size_t)3 * n + j] = r.m;
+    out5[(size_t)4 * n + j] = r.s;
 }
 
 }  // namespace cirs

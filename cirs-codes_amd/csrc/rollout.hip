@@ -181,7 +181,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         // ... in the same launch as the tail of this step: merge -> act / logp, visited bit, env step, forced length
         TailFuse tl{};
         tl.on = 1; tl.cfg = *env_cfg; tl.tab = *env_tab; tl.st = *env_st; tl.n_pad = n_pad; tl.n_chunks = n_chunks; tl.pv = pv;
-        tl.wa = pol_w->wa; tl.ba = pol_w->ba; tl.h2 = h2; tl.visited = visited; tl.force_length = force_length;
+        tl.visited = visited; tl.force_length = force_length;
         tl.force_done = (t + 1 >= force_length) ? 1 : 0;
         tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B; tl.rew_out = rew_t; tl.done_out = done_t; tl.ctr_out = traj->ctr + (size_t)t * B;
         if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, &tf, s, &tl))

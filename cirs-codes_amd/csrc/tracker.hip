@@ -105,6 +105,17 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             if (lane == 0 && tf.value) tf.value[j] = 0.f;                  \
         }                                                                  \
     } while (0)
+    // the gate row of this lane's feature (33 floats, odd row stride: scalar loads) is needed right after the tail of the vector
+    // step: requested first, it arrives underneath the merge / env step
+    const bool is_init = users != nullptr;
+    float gpre[kD + 1];
+    float gbias = 0.f;
+    if (!is_init) {
+        const float* gw = w.gate_w + (size_t)(lane & (kD - 1)) * (kD + 1);
+#pragma unroll
+        for (int k = 0; k <= kD; ++k) gpre[k] = gw[k];
+        gbias = w.gate_b[lane & (kD - 1)];
+    }
     // fused rollout: the tail of the vector step for this env row first (action, env step); its results stay in registers
     long it_f = -1;
     float r_f = 0.f;
@@ -114,11 +125,11 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         // the env's own state (user, turn, history entry of this lane, running reward) does not depend on the action: its loads
         // are issued BEFORE the merge of the sampler partials and complete underneath it
         const EnvPrefetch epf = env_prefetch(tl.cfg, tl.st, j, lane);
-        const MergePre mpre = actor_merge_prefetch(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.h2);   // same round trip as the env state
+        const MergePre mpre = actor_merge_prefetch(j, lane, tl.n_pad, tl.n_chunks, tl.pv);   // same round trip as the env state
         if (epf.done) {  // finished env: the policy skipped it
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
         } else {
-            act = actor_merge_wave(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.wa, tl.ba, tl.h2, tl.act_out, tl.logp_out, &mpre);
+            act = actor_merge_wave(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.act_out, tl.logp_out, &mpre);
             if (tl.visited && act >= 0 && lane == 0) {
                 const int words = (tl.cfg.n_items + 31) / 32;
                 tl.visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
@@ -154,16 +165,15 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     float* ps = ffs + kHid;      // [NHEAD][lpad] attention probabilities
     const int o32 = lane & (kD - 1);
 
-    const bool is_init = users != nullptr;
     if (!is_init && (tl.on ? it_f : items[j]) < 0) { CIRS_TRUNK_ZERO(); return; }  // act = -1: env finished earlier in this rollout
     const int pos = is_init ? 0 : st.len[e];
     if (pos >= L) { CIRS_TRUNK_ZERO(); return; }  // history full: the caller never steps past max_turn
 
     // ---- 0. K/V cache rows of the earlier positions depend on (env, pos) only: the first batch of a layer (positions < 64 for K,
-    //         < 16 per half-wave for V) is requested one layer AHEAD -- layer 0 here, layer l + 1 right after layer l's attention --
+    //         < 32 for V) is requested one layer AHEAD -- layer 0 here, layer l + 1 right after layer l's attention --
     //         and arrives under the mat-vec stages in between (one register set, reused)
     float4 kpre[kD / 4];
-    float vpre[8];
+    float vpre[16];
 #define CIRS_KV_PREFETCH(LAYER)                                                                                  \
     do {                                                                                                         \
         const float* kc0_ = st.kcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         const float4* k4_ = reinterpret_cast<const float4*>(kc0_ + (size_t)lane * kD);                           \
         _Pragma("unroll") for (int q4 = 0; q4 < kD / 4; ++q4)                                                    \
             kpre[q4] = lane < pos ? k4_[q4] : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
-        _Pragma("unroll") for (int u8 = 0; u8 < 8; ++u8) {                                                       \
+        _Pragma("unroll") for (int u8 = 0; u8 < 16; ++u8) {                                                      \
             const int jp_ = (lane >> 5) + 2 * u8;                                                                \
             vpre[u8] = jp_ < pos ? vc0_[(size_t)jp_ * kD + o32] : 0.f;                                           \
         }                                                                                                        \
@@ -193,10 +203,10 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             xs[lane] = a;
         }
         __builtin_amdgcn_wave_barrier();
-        const float* gw = w.gate_w + (size_t)o32 * (kD + 1);  // input order [r, a_0..a_31]
-        float acc = w.gate_b[o32];
-        acc = __builtin_fmaf(gw[0], r, acc);
-        for (int k = 0; k < kD; ++k) acc = __builtin_fmaf(gw[1 + k], xs[k], acc);
+        float acc = gbias;                                   // input order [r, a_0..a_31]
+        acc = __builtin_fmaf(gpre[0], r, acc);
+#pragma unroll
+        for (int k = 0; k < kD; ++k) acc = __builtin_fmaf(gpre[1 + k], xs[k], acc);
         const float g = 1.0f / (1.0f + expf(-acc));
         x = g * a;
     }
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
 #pragma unroll
                 for (int u8 = 0; u8 < 8; ++u8) {
                     const int jp = j0 + 2 * u8;
-                    v8[u8] = j0 == half ? vpre[u8] : (jp < pos ? vc[(size_t)jp * kD + d] : 0.f);   // first batch: prefetched
+                    v8[u8] = j0 == half ? vpre[u8] : (j0 == half + 16 ? vpre[8 + u8] : (jp < pos ? vc[(size_t)jp * kD + d] : 0.f));   // first two batches: prefetched
                 }
 #pragma unroll
                 for (int u8 = 0; u8 < 8; ++u8) {
