@@ -53,6 +53,29 @@ __global__ __launch_bounds__(256) void actor_shard_tuple_kernel(int n, int n_pad
     actor_shard_tuple_wave(j, lane, n_pad, n_chunks, pv, n, out5);
 }
 
+// two-level sampler, stages 2 + 3 for n rows (one wavefront per row): final action / log-prob, or (tuple_out) the shard tuple
+__global__ __launch_bounds__(256) void actor_pick_kernel(PickArgs a, int n, const int32_t* __restrict__ env_ids,
+                                                         const uint8_t* __restrict__ skip, int64_t* __restrict__ act_out,
+                                                         float* __restrict__ logp_out, float* __restrict__ tuple_out) {
+    __shared__ float hs[4][kH];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wv;
+    if (j >= n) return;
+    Cand r{-INFINITY, 0.f, -INFINITY, 0.f, 0x7FFFFFFF};
+    if (!(skip && skip[j])) r = actor_pick_wave(a, j, env_ids ? env_ids[j] : j, lane, hs[wv], nullptr);
+    if (lane != 0) return;
+    if (tuple_out) {
+        tuple_out[j] = r.bs;
+        reinterpret_cast<int32_t*>(tuple_out)[(size_t)n + j] = r.bi;
+        tuple_out[(size_t)2 * n + j] = r.bi != 0x7FFFFFFF ? r.bz : 0.f;
+        tuple_out[(size_t)3 * n + j] = r.m;
+        tuple_out[(size_t)4 * n + j] = r.s;
+        return;
+    }
+    act_out[j] = r.bi == 0x7FFFFFFF ? -1 : (int64_t)r.bi;
+    if (logp_out) logp_out[j] = cand_logp(r);
+}
+
 // cross-rank merge of W shard tuples per env row, in RANK ORDER (fixed): candidate with the highest noisy score (ties -> lowest
 // global id), running (max, sum-exp) folded rank by rank; logp of the winner with Categorical's clamp (as actor_merge_wave)
 __global__ __launch_bounds__(256) void actor_merge_shards_kernel(const float* __restrict__ tuples, int n_shards, int n,
@@ -144,6 +167,17 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
     hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, *cfg, *w, state, (long)state_stride, n, skip, h2,
                        value_out, nullptr);
     CIRS_CHECK_LAUNCH("trunk_kernel");
+    if (!gumbel) {   // counter-based sampler: two-level Gumbel-max (chunk masses, then chunk + item draws)
+        const int cpw = (hg.tiles_per_chunk + kTilesPerChunk - 1) / kTilesPerChunk;
+        const int nch = n_chunks_of(cfg->n_items);
+        hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg, w->wa, w->ba, (const float*)h2, n,
+                           env_ids, visited, skip, pv.m, n_pad, cpw, 0, 0);
+        CIRS_CHECK_LAUNCH("actor_mass_kernel");
+        PickArgs pa{pv.m, n_pad, nch, w->wa, w->ba, h2, visited, cfg->n_items, 0, 0, seed, rng_step};
+        hipLaunchKernelGGL(actor_pick_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, pa, n, env_ids, skip, act_out, logp_out, (float*)nullptr);
+        CIRS_CHECK_LAUNCH("actor_pick_kernel");
+        return CIRS_OK;
+    }
     const dim3 grid(hg.grid_x, hg.n_row_blocks);
     hipLaunchKernelGGL(actor_head_kernel, grid, dim3(256), 0, s, *cfg, w->wa, w->ba, h2, n, gumbel, seed,
                        rng_step, env_ids, visited, skip, pv, n_pad, hg.tiles_per_chunk);
@@ -173,12 +207,15 @@ extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const
     hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, *cfg_shard, *w_shard, state, (long)state_stride, n, skip, h2,
                        value_out, nullptr);
     CIRS_CHECK_LAUNCH("trunk_kernel");
-    hipLaunchKernelGGL(actor_head_kernel, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *cfg_shard, w_shard->wa, w_shard->ba,
-                       (const float*)h2, n, (const float*)nullptr, seed, rng_step, env_ids, visited, skip, pv, n_pad, hg.tiles_per_chunk,
-                       item_base, n_items_total);
-    CIRS_CHECK_LAUNCH("actor_head_kernel");
-    hipLaunchKernelGGL(actor_shard_tuple_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, n, n_pad, hg.n_chunks, pv, skip, tuples_out);
-    CIRS_CHECK_LAUNCH("actor_shard_tuple_kernel");
+    CIRS_REQUIRE((item_base % CIRS_SAMPLER_CHUNK) == 0, "item_base must be a multiple of the sampler chunk (128 items)");
+    const int cpw = (hg.tiles_per_chunk + kTilesPerChunk - 1) / kTilesPerChunk;
+    const int nch = n_chunks_of(cfg_shard->n_items);
+    hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg_shard, w_shard->wa, w_shard->ba,
+                       (const float*)h2, n, env_ids, visited, skip, pv.m, n_pad, cpw, item_base, n_items_total);
+    CIRS_CHECK_LAUNCH("actor_mass_kernel");
+    PickArgs pa{pv.m, n_pad, nch, w_shard->wa, w_shard->ba, h2, visited, cfg_shard->n_items, item_base, n_items_total, seed, rng_step};
+    hipLaunchKernelGGL(actor_pick_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, pa, n, env_ids, skip, (int64_t*)nullptr, (float*)nullptr, tuples_out);
+    CIRS_CHECK_LAUNCH("actor_pick_kernel");
     return CIRS_OK;
 }
 

@@ -311,6 +311,136 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 // merge the per-chunk partials of env row j (one wavefront, lanes stride over chunks); recompute the chosen item's
 // logit with the SAME k-order as the MFMA chain (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with the
 // sampled distribution.  Lane 0 writes act / logp; the action id is returned in every lane.
+// ---- two-level sampler, stage 1: log-mass of every 128-item chunk ----------------------------------------------------------
+// Same tiling as actor_head_kernel (ZT[32 items x 32 rows] per MFMA tile, a lane owns ONE env row and 16 items of a tile; Wa tile
+// staged in LDS once per workgroup, double buffered), but no noise at all: the four tiles of a chunk stay in the accumulators,
+// M_c = max of the lane pair's valid logits, S_c = sum of det_expf_neg(z - M_c) in register order (tile, r) per half-wave,
+// S_c = S_hi0 + S_hi1, L_c = M_c + det_logf(S_c): bit-identical to oracle/cirs_oracle.c two_level_draw.  One float per (chunk,
+// env row) leaves the kernel: lmass[c][row] (-inf: no valid item).  grid = (ceil(n_chunks / chunks_per_wg), row blocks).
+static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa,
+                                                                   const float* __restrict__ ba, const float* __restrict__ h2, int n,
+                                                                   const int32_t* __restrict__ env_ids,
+                                                                   const uint32_t* __restrict__ visited,
+                                                                   const uint8_t* __restrict__ skip, float* __restrict__ lmass,
+                                                                   int n_pad, int chunks_per_wg, int item_base = 0,
+                                                                   int n_items_total = 0) {
+    __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
+    __shared__ float sB[2][kTileN];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int row0 = (blockIdx.y * 4 + wv) * kTileM;
+    const int I = cfg.n_items;
+    const int I_tot = n_items_total > 0 ? n_items_total : I;
+    const int vis_words = (I_tot + 31) / 32;
+    const int jr = row0 + lo;
+    const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
+    const bool wave_live = __ballot(active) != 0ull;
+    const int e = active ? (env_ids ? env_ids[jr] : jr) : 0;
+    float hrow[32];
+    if (wave_live && jr < n) {
+        const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)jr * kH + hi * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = src[q];
+            hrow[4 * q + 0] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) hrow[q] = 0.f;
+    }
+    const int n_chunks = n_chunks_of(I);
+    const int c_begin = blockIdx.x * chunks_per_wg;
+    const int c_end = min(n_chunks, c_begin + chunks_per_wg);
+    __shared__ int s_any;
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    if (wave_live && lane == 0) s_any = 1;
+    __syncthreads();
+    if (s_any == 0) {   // every env of this workgroup has finished: neutral masses, no arithmetic
+        if (row0 < n_pad && hi == 0)
+            for (int c = c_begin; c < c_end; ++c) lmass[(size_t)c * n_pad + jr] = -INFINITY;
+        return;
+    }
+    const int st_item = tid >> 3, st_col = (tid & 7) * 8;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    float gb = 0.f;
+#define CIRS_ISSUE(TILE0)                                                                                  \
+    do {                                                                                                   \
+        const int item_ = (TILE0) + st_item;                                                               \
+        if (item_ < I) {                                                                                   \
+            const float4* src_ = reinterpret_cast<const float4*>(wa + (size_t)item_ * kH + st_col);        \
+            g0 = src_[0]; g1 = src_[1];                                                                    \
+        } else {                                                                                           \
+            g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0;                                                 \
+        }                                                                                                  \
+        if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
+    } while (0)
+#define CIRS_COMMIT(BUF)                                                                                   \
+    do {                                                                                                   \
+        float4* dst_ = reinterpret_cast<float4*>(&sW[BUF][st_item * kLdsStride + st_col]);                 \
+        dst_[0] = g0; dst_[1] = g1;                                                                        \
+        if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
+    } while (0)
+    if (c_begin < c_end) { CIRS_ISSUE(c_begin * kChunkItems); CIRS_COMMIT(0); }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        f32x16 acc[4];
+        uint32_t vis[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {           // tile t of the chunk lives in buffer t & 1 (4 tiles per chunk: the parity carries over)
+            const int buf = t & 1;
+            const int tile0 = c * kChunkItems + t * kTileN;
+            const bool more = t < 3 || c + 1 < c_end;
+            if (more) CIRS_ISSUE(tile0 + kTileN);
+            if (wave_live) {
+                const float* tw = sW[buf];
+                float wrow[32];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(&tw[lo * kLdsStride + hi * 32 + 4 * q]);
+                    wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = sB[buf][(r & 3) + 8 * (r >> 2) + 4 * hi];
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc[t], 0, 0, 0);
+                vis[t] = (visited && active) ? visited[(size_t)e * vis_words + ((item_base + tile0) >> 5)] : 0u;
+            }
+            if (more) CIRS_COMMIT(buf ^ 1);
+            __syncthreads();
+        }
+        if (!wave_live) continue;
+        // mask, chunk maximum over the lane pair, fixed-order sum of exponentials
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int item = c * kChunkItems + t * kTileN + il;
+                const bool valid = item < I && !((vis[t] >> (il & 31)) & 1u);
+                acc[t][r] = valid ? acc[t][r] : -INFINITY;
+                mloc = fmaxf(mloc, acc[t][r]);
+            }
+        const float M = fmaxf(mloc, __shfl_xor(mloc, 32, CIRS_WAVE));
+        float L = -INFINITY;
+        if (M > -INFINITY) {        // uniform over the lane pair (M is shared), evaluated by every lane that has a partner
+            float sl = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sl += det_expf_neg(acc[t][r] - M);   // masked elements: e^(-inf) = 0
+            const float so = __shfl_xor(sl, 32, CIRS_WAVE);
+            const float S = hi == 0 ? sl + so : so + sl;                          // S_hi0 + S_hi1, in that order on both lanes
+            L = M + det_logf(S);
+        }
+        if (row0 < n_pad && hi == 0) lmass[(size_t)c * n_pad + jr] = active ? L : -INFINITY;
+    }
+#undef CIRS_ISSUE
+#undef CIRS_COMMIT
+}
+
 // ---- merge of the per-chunk partials of one env row (one wavefront) --------------------------------------------------------
 // Candidate = (noisy score, item id, its logit); the winner is the highest score, ties -> lowest id (order independent);
 // (m, s) = running max / sum-exp of the logits, folded pairwise.  Lanes first fold the chunks they own (lane, lane + 64, ...),
@@ -393,6 +523,82 @@ __device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, 
         logp_out[j] = lp;
     }
     return act;
+}
+
+// ---- two-level sampler, stage 2 + 3: one wavefront per env row -------------------------------------------------------------
+// chunk c* = argmax_c (L_c + G1_c) (lanes stride the chunks, register-only reduction, ties -> lowest chunk), then the 128 items
+// of c*: two per lane, logits as scalar fma chains in the MFMA's k-order (bias, then k = kk, 32 + kk: the very bits stage 1 saw),
+// item = argmax_i (z_i + G2_i), ties -> lowest id.  The row's log-sum-exp for logp is folded from the chunk masses (hardware exp:
+// tolerance-checked, it decides nothing).  hs: 64 floats of per-wave LDS scratch.  Result identical in every lane.
+struct PickPre { float L[2]; };
+__device__ __forceinline__ PickPre actor_pick_prefetch(int j, int lane, int n_pad, int n_chunks, const float* __restrict__ lmass) {
+    PickPre p;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + CIRS_WAVE * q;
+        p.L[q] = lmass[(size_t)(c < n_chunks ? c : 0) * n_pad + j];
+    }
+    return p;
+}
+struct PickArgs {
+    const float* lmass; int n_pad, n_chunks;      // stage-1 output of this shard
+    const float *wa, *ba, *h2;                   // head rows of this shard, hidden rows [n, 64]
+    const uint32_t* visited; int n_items, item_base, n_items_total;
+    uint64_t seed; uint32_t rng_step;
+};
+__device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e, int lane, float* hs, const PickPre* pre) {
+    const int chunk_base = a.item_base / CIRS_SAMPLER_CHUNK;
+    Cand c0{-INFINITY, 0.f, -INFINITY, 0.f, 0x7FFFFFFF};     // bi = chunk id here
+    for (int c = lane, q = 0; c < a.n_chunks; c += CIRS_WAVE, ++q) {
+        const float L = (pre && q < 2) ? (q == 0 ? pre->L[0] : pre->L[1]) : a.lmass[(size_t)c * a.n_pad + j];
+        if (L > -INFINITY) cand_fold(c0, L + chunk_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)(chunk_base + c)), c, 0.f, L, 1.0f);
+    }
+    const Cand cw = cand_wave_reduce(c0);
+    Cand out{cw.bs, 0.f, cw.m, cw.s, 0x7FFFFFFF};
+    if (cw.bi == 0x7FFFFFFF) return out;          // nothing left to recommend
+    hs[lane] = a.h2[(size_t)j * kH + lane];
+    __builtin_amdgcn_wave_barrier();
+    const int I_tot = a.n_items_total > 0 ? a.n_items_total : a.n_items;
+    const int vis_words = (I_tot + 31) / 32;
+    Cand it{-INFINITY, 0.f, -INFINITY, 0.f, 0x7FFFFFFF};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int il = cw.bi * CIRS_SAMPLER_CHUNK + lane + 64 * q;      // local item of this shard
+        if (il < a.n_items) {
+            const int ig = a.item_base + il;
+            const bool seen = a.visited && ((a.visited[(size_t)e * vis_words + (ig >> 5)] >> (ig & 31)) & 1u);
+            if (!seen) {
+                const float4* wr = reinterpret_cast<const float4*>(a.wa + (size_t)il * kH);
+                float4 w4[16];
+#pragma unroll
+                for (int k4 = 0; k4 < 16; ++k4) w4[k4] = wr[k4];
+                float z = a.ba[il];
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    const float4 lo4 = w4[kk >> 2], hi4 = w4[8 + (kk >> 2)];
+                    const int s4 = kk & 3;
+                    z = __builtin_fmaf(hs[kk], s4 == 0 ? lo4.x : s4 == 1 ? lo4.y : s4 == 2 ? lo4.z : lo4.w, z);
+                    z = __builtin_fmaf(hs[32 + kk], s4 == 0 ? hi4.x : s4 == 1 ? hi4.y : s4 == 2 ? hi4.z : hi4.w, z);
+                }
+                const float sc = z + actor_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)ig);
+                if (sc > it.bs || (sc == it.bs && ig < it.bi)) { it.bs = sc; it.bi = ig; it.bz = z; }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const Cand iw = cand_wave_reduce(it);
+    out.bi = iw.bi; out.bz = iw.bz;
+    return out;      // bs = the chunk-level noisy score (what shards are compared by), (m, s) = log-sum-exp of the shard's masses
+}
+
+// log-prob of the drawn item with Categorical's clamp (torch probs_to_logits), from its logit and the row's (max, sum-exp)
+__device__ __forceinline__ float cand_logp(const Cand& r) {
+    if (r.bi == 0x7FFFFFFF) return 0.f;
+    const float lse = r.m + __logf(r.s);
+    float p = __expf(r.bz - lse);
+    const float eps = 1.1920928955078125e-7f;
+    p = fminf(fmaxf(p, eps), 1.0f - eps);
+    return __logf(p);
 }
 
 // Column-sharded head: this shard's chunk partials of env row j as ONE tuple (score, global id, logit of that candidate, running

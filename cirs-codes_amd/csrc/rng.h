@@ -69,7 +69,27 @@ __host__ __device__ __forceinline__ float gumbel_from_bits(uint32_t x) {
     return -det_logf(-det_logf(u));
 }
 
+// e^x for x <= 0, bit-reproducible like det_logf: y = x * log2(e) (one rounding), n = floor(y), g = (y - n) - 1/2 in [-1/2, 1/2),
+// 2^(n + 1/2 + g) = 2^n * sqrt(2) * e^(g ln 2) with the degree-6 Taylor polynomial in g (coefficients sqrt(2) (ln 2)^k / k!, fmaf
+// Horner), scaled by an exact ldexp.  Relative error <= 3e-6 (dominated by the rounding of y for |x| ~ 30), x < -87 -> 0.
+__host__ __device__ __forceinline__ float det_expf_neg(float x) {
+    if (!(x >= -87.0f)) return 0.f;
+    const float y = x * 1.4426950408889634f;
+    const float n = floorf(y);
+    const float g = (y - n) - 0.5f;
+    float p = 0.00021783880947623402f;
+    p = __builtin_fmaf(p, g, 0.0018856498645618558f);
+    p = __builtin_fmaf(p, g, 0.013602088205516338f);
+    p = __builtin_fmaf(p, g, 0.07849466055631638f);
+    p = __builtin_fmaf(p, g, 0.3397315740585327f);
+    p = __builtin_fmaf(p, g, 0.9802581667900085f);
+    p = __builtin_fmaf(p, g, 1.4142135381698608f);
+    return ldexpf(p, (int)n);
+}
+
 #define CIRS_RNG_STREAM_ACTOR 0x43495253u /* 'CIRS' */
+#define CIRS_RNG_STREAM_CHUNK 0x43484E4Bu /* 'CHNK' */
+#define CIRS_SAMPLER_CHUNK 128             /* items per chunk of the two-level sampler (4 MFMA tiles of 32) */
 
 // noise for (env e, item i) at rng_step: Philox counter (i>>2, e, rng_step, stream), key = seed; output word i&3.
 // Four consecutive items of one env share a Philox block (the head kernel holds 4 consecutive items per lane).
@@ -102,6 +122,22 @@ __host__ __device__ __forceinline__ uint32_t block_word(const u32x4& r, uint32_t
 __host__ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t env, uint32_t pos, uint32_t layer, uint32_t site,
                                                       uint32_t elem, uint32_t thr) {
     return block_word(dropout_block(seed, env, pos, layer, site, elem >> 2), elem & 3u) >= thr;
+}
+
+// Two-level ("chunked") Gumbel-max sampler -- the counter-based sampler of the rollout.
+//   Categorical(softmax(z)).sample() is drawn in two exact stages: a chunk c of 128 consecutive items with probability
+//   mass_c / sum mass, mass_c = sum_{i in c} e^{z_i} -- realised as argmax_c (L_c + G1_c), L_c = log mass_c -- and then an item
+//   inside the chosen chunk, argmax_{i in c} (z_i + G2_i).  Both arg-maxes are Gumbel-max draws, so the pair is an exact sample of
+//   the categorical distribution, but only n_chunks + 128 noise values are needed per draw instead of one per catalogue item
+//   (10728 items: 84 + 128).  L_c must be identical on every implementation (it decides the chunk): L_c = M_c + det_logf(S_c),
+//   M_c = max of the chunk's valid logits, S_c = sum of det_expf_neg(z_i - M_c) in the order fixed below.
+//   Noise: G1_c from Philox counter (c >> 2, env, rng_step, 'CHNK'), word c & 3; G2_i = actor_gumbel (counter (i >> 2, env,
+//   rng_step, 'CIRS')).  Ties -> lowest chunk / lowest item.  Masked (already recommended) items are invalid in both stages.
+__host__ __device__ __forceinline__ float chunk_gumbel(uint64_t seed, uint32_t rng_step, uint32_t env, uint32_t chunk) {
+    const u32x4 r = philox4x32_10(chunk >> 2, env, rng_step, CIRS_RNG_STREAM_CHUNK, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t sel = chunk & 3u;
+    const uint32_t x = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
+    return gumbel_from_bits(x);
 }
 
 }  // namespace cirs
