@@ -55,7 +55,9 @@ struct TailFuse {
     cirs_env_tables tab;
     cirs_env_state st;
     int n_pad, n_chunks;
-    ActorPartialView pv;
+    ActorPartialView pv;       // harness-noise mode: partials of actor_head_kernel, merged here
+    int pick_on;               // counter-based mode: chunk masses of actor_mass_kernel, chunk + item drawn here (two-level sampler)
+    PickArgs pick;
     uint32_t* visited;
     int force_length, force_done;
     int64_t* act_out;

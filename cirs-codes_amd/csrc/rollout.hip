@@ -157,6 +157,8 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     const HeadGrid hg = sampler_grid(pol_cfg->n_items, n_pad);
     const int n_chunks = hg.n_chunks;
     ActorPartialView pv = partial_view(workspace, n_env, pol_cfg->n_items);
+    const int mass_cpw = (hg.tiles_per_chunk + kTilesPerChunk - 1) / kTilesPerChunk;
+    const int n_mass_chunks = n_chunks_of(pol_cfg->n_items);
     int64_t* obs_scratch = nullptr;  // the env's obs_next id == the action: not materialised
     // trunk of the first step of this call (later ones ride on the tracker step)
     hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_env, 4)), dim3(256), 0, s, *pol_cfg, *pol_w, traj->obs + (size_t)t_begin * B * S, (long)S,
@@ -167,11 +169,17 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         int64_t* act_t = traj->act + (size_t)t * B;
         double* rew_t = traj->rew + (size_t)t * B;
         uint8_t* done_t = traj->done + (size_t)t * B;
-        CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *pol_cfg,
-                                                  pol_w->wa, pol_w->ba, (const float*)h2, n_env,
-                                                  gumbel ? gumbel + (size_t)t * B * pol_cfg->n_items : (const float*)nullptr, seed,
-                                                  rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
-                                                  (const uint8_t*)env_st->done, pv, n_pad, hg.tiles_per_chunk));
+        const float* gum_t = gumbel ? gumbel + (size_t)t * B * pol_cfg->n_items : (const float*)nullptr;
+        if (gum_t) {   // harness-supplied noise: plain Gumbel-max over the catalogue (reference-recorded fixtures)
+            CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *pol_cfg,
+                                                      pol_w->wa, pol_w->ba, (const float*)h2, n_env, gum_t, seed,
+                                                      rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
+                                                      (const uint8_t*)env_st->done, pv, n_pad, hg.tiles_per_chunk));
+        } else {       // counter-based sampler: chunk log-masses now, chunk + item draws in the tail of the step kernel
+            CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(n_mass_chunks, mass_cpw), hg.n_row_blocks), dim3(256), 0, s,
+                                                      *pol_cfg, pol_w->wa, pol_w->ba, (const float*)h2, n_env, (const int32_t*)nullptr,
+                                                      (const uint32_t*)visited, (const uint8_t*)env_st->done, pv.m, n_pad, mass_cpw, 0, 0));
+        }
         CIRS_CHECK_LAUNCH("actor_head_kernel");
         TrunkFuse tf{};
         if (t + 1 < t_end) {
@@ -182,6 +190,10 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         TailFuse tl{};
         tl.on = 1; tl.cfg = *env_cfg; tl.tab = *env_tab; tl.st = *env_st; tl.n_pad = n_pad; tl.n_chunks = n_chunks; tl.pv = pv;
         tl.visited = visited; tl.force_length = force_length;
+        if (!gum_t) {
+            tl.pick_on = 1;
+            tl.pick = PickArgs{pv.m, n_pad, n_mass_chunks, pol_w->wa, pol_w->ba, h2, visited, pol_cfg->n_items, 0, 0, seed, rng_base + (uint32_t)t};
+        }
         tl.force_done = (t + 1 >= force_length) ? 1 : 0;
         tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B; tl.rew_out = rew_t; tl.done_out = done_t; tl.ctr_out = traj->ctr + (size_t)t * B;
         if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, &tf, s, &tl))

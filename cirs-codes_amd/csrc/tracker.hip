@@ -125,15 +125,24 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         // the env's own state (user, turn, history entry of this lane, running reward) does not depend on the action: its loads
         // are issued BEFORE the merge of the sampler partials and complete underneath it
         const EnvPrefetch epf = env_prefetch(tl.cfg, tl.st, j, lane);
-        const MergePre mpre = actor_merge_prefetch(j, lane, tl.n_pad, tl.n_chunks, tl.pv);   // same round trip as the env state
+        // sampler inputs of this row: same round trip as the env state
+        MergePre mpre{};
+        PickPre ppre{};
+        if (tl.pick_on) ppre = actor_pick_prefetch(j, lane, tl.pick.n_pad, tl.pick.n_chunks, tl.pick.lmass);
+        else mpre = actor_merge_prefetch(j, lane, tl.n_pad, tl.n_chunks, tl.pv);
         if (epf.done) {  // finished env: the policy skipped it
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
+        } else if (tl.pick_on) {   // two-level draw: chunk, then item (per-wave LDS scratch: the feed-forward buffer, free here)
+            float* hs_pick = smem + (size_t)wv * (6 * kD + kHid + NHEAD * lpad) + 6 * kD;
+            const Cand r = actor_pick_wave(tl.pick, j, j, lane, hs_pick, &ppre);
+            act = r.bi == 0x7FFFFFFF ? -1 : (int64_t)r.bi;
+            if (lane == 0) { tl.act_out[j] = act; tl.logp_out[j] = cand_logp(r); }
         } else {
             act = actor_merge_wave(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.act_out, tl.logp_out, &mpre);
-            if (tl.visited && act >= 0 && lane == 0) {
-                const int words = (tl.cfg.n_items + 31) / 32;
-                tl.visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
-            }
+        }
+        if (tl.visited && act >= 0 && lane == 0) {
+            const int words = (tl.cfg.n_items + 31) / 32;
+            tl.visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
         }
         CIRS_STAMP(2);
         EnvStepResult er;
