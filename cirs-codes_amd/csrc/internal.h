@@ -56,6 +56,7 @@ struct TailFuse {
     cirs_env_state st;
     int n_pad, n_chunks;
     ActorPartialView pv;       // harness-noise mode: partials of actor_head_kernel, merged here
+    int env_base;              // env id of row 0 of this launch (env groups on separate streams): state / noise / visited use env_base + j
     int pick_on;               // counter-based mode: chunk masses of actor_mass_kernel, chunk + item drawn here (two-level sampler)
     PickArgs pick;
     uint32_t* visited;

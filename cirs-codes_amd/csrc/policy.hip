@@ -143,7 +143,8 @@ static int validate_policy(const cirs_policy_cfg* cfg, const cirs_policy_weights
 extern "C" int64_t cirs_policy_workspace_bytes(const cirs_policy_cfg* cfg, int32_t n) {
     using namespace cirs;
     if (!cfg || n <= 0) return 0;
-    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items)) * 4;
+    // + slack: the fused rollout may carve one (256-byte aligned) workspace per env group out of this buffer
+    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items)) * 4 + 8192;
 }
 
 extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state,

@@ -323,7 +323,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
                                                                    const uint32_t* __restrict__ visited,
                                                                    const uint8_t* __restrict__ skip, float* __restrict__ lmass,
                                                                    int n_pad, int chunks_per_wg, int item_base = 0,
-                                                                   int n_items_total = 0) {
+                                                                   int n_items_total = 0, int env_base = 0) {
     __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
     __shared__ float sB[2][kTileN];
     const int tid = threadIdx.x;
@@ -336,7 +336,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
     const int jr = row0 + lo;
     const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
     const bool wave_live = __ballot(active) != 0ull;
-    const int e = active ? (env_ids ? env_ids[jr] : jr) : 0;
+    const int e = active ? (env_ids ? env_ids[jr] : env_base + jr) : 0;
     float hrow[32];
     if (wave_live && jr < n) {
         const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)jr * kH + hi * 32);
@@ -413,16 +413,23 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
         if (!wave_live) continue;
         // mask, chunk maximum over the lane pair, fixed-order sum of exponentials
         float mloc = -INFINITY;
+        if (!visited && (c + 1) * kChunkItems <= I) {     // whole chunk inside the catalogue, nothing masked: no per-element tests
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int item = c * kChunkItems + t * kTileN + il;
-                const bool valid = item < I && !((vis[t] >> (il & 31)) & 1u);
-                acc[t][r] = valid ? acc[t][r] : -INFINITY;
-                mloc = fmaxf(mloc, acc[t][r]);
-            }
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, acc[t][r]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int item = c * kChunkItems + t * kTileN + il;
+                    const bool valid = item < I && !((vis[t] >> (il & 31)) & 1u);
+                    acc[t][r] = valid ? acc[t][r] : -INFINITY;
+                    mloc = fmaxf(mloc, acc[t][r]);
+                }
+        }
         const float M = fmaxf(mloc, __shfl_xor(mloc, 32, CIRS_WAVE));
         float L = -INFINITY;
         if (M > -INFINITY) {        // uniform over the lane pair (M is shared), evaluated by every lane that has a partner

@@ -41,6 +41,8 @@ __global__ __launch_bounds__(256) void online_pairs_kernel(const int32_t* __rest
     o.dur_buf[j] = o.item_dur[a];
 }
 
+constexpr int kMaxGroups = 4;
+
 }  // namespace cirs
 
 static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
@@ -152,52 +154,107 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(pol_cfg, n_env), "workspace too small");
     CIRS_REQUIRE(env_tab->item_cats && (env_tab->normed_mat || !env_cfg->simulated) && (env_tab->mat || env_cfg->simulated), "env tables incomplete");
     if (t_begin >= t_end) return CIRS_OK;
-    float* h2 = (float*)workspace;
-    const int n_pad = n_pad_of(n_env);
-    const HeadGrid hg = sampler_grid(pol_cfg->n_items, n_pad);
-    const int n_chunks = hg.n_chunks;
-    ActorPartialView pv = partial_view(workspace, n_env, pol_cfg->n_items);
-    const int mass_cpw = (hg.tiles_per_chunk + kTilesPerChunk - 1) / kTilesPerChunk;
+    // ---- env groups on separate streams ---------------------------------------------------------------------------------------
+    // The step kernel (one wavefront per env) is latency-bound: a chain of ~25 dependent stages that leaves the matrix / vector pipes
+    // idle, while the chunk-mass kernel of the sampler is throughput-bound.  Envs are independent (noise, masks and dropout are
+    // keyed by the env id), so the envs are split into G groups whose launch sequences run on G streams: one group's step kernel
+    // overlaps another group's mass kernel.  Results are identical to G = 1 (tests/test_gpu_rollout.py).
+    int G = 1;
+    if (!gumbel) {
+        static int forced = -1;
+        if (forced < 0) { const char* ev = getenv("CIRS_ROLLOUT_GROUPS"); forced = ev ? atoi(ev) : 0; }
+        G = forced > 0 ? forced : (n_env >= 1024 ? 4 : (n_env >= 256 ? 2 : 1));
+        if (G > kMaxGroups) G = kMaxGroups;
+    }
+    int n_g = ((n_env + G - 1) / G + 127) / 128 * 128;       // rows per group: whole 128-row blocks of the mass kernel
+    if (G > 1) {   // room for one sampler workspace per group?
+        const int64_t per = (cirs_policy_workspace_bytes(pol_cfg, n_g) + 255) & ~(int64_t)255;
+        if (per * G > workspace_bytes) { G = 1; n_g = n_env; }
+    } else {
+        n_g = n_env;
+    }
+    static hipStream_t gs[kMaxGroups] = {};
+    static hipEvent_t gev[kMaxGroups + 1] = {};
+    if (G > 1) {
+        for (int g = 1; g < G; ++g)
+            if (!gs[g]) CIRS_HIP(hipStreamCreateWithFlags(&gs[g], hipStreamNonBlocking));
+        for (int g = 0; g <= G && g <= kMaxGroups; ++g)
+            if (!gev[g]) CIRS_HIP(hipEventCreateWithFlags(&gev[g], hipEventDisableTiming));
+        CIRS_HIP(hipEventRecord(gev[0], s));
+        for (int g = 1; g < G; ++g) CIRS_HIP(hipStreamWaitEvent(gs[g], gev[0], 0));
+    }
+    const int64_t ws_per = (cirs_policy_workspace_bytes(pol_cfg, n_g) + 255) & ~(int64_t)255;
     const int n_mass_chunks = n_chunks_of(pol_cfg->n_items);
-    int64_t* obs_scratch = nullptr;  // the env's obs_next id == the action: not materialised
+    struct Group { int base, n, n_pad; float* h2; ActorPartialView pv; HeadGrid hg; int cpw; hipStream_t st; };
+    Group grp[kMaxGroups];
+    int n_groups = 0;
+    for (int g = 0; g < G; ++g) {
+        const int base = g * n_g;
+        if (base >= n_env) break;
+        Group& q = grp[n_groups++];
+        q.base = base; q.n = min(n_g, n_env - base); q.n_pad = n_pad_of(q.n);
+        void* wsg = (char*)workspace + (size_t)g * ws_per;
+        q.h2 = (float*)wsg;
+        q.pv = partial_view(wsg, q.n, pol_cfg->n_items);
+        q.hg = sampler_grid(pol_cfg->n_items, q.n_pad);
+        q.cpw = (q.hg.tiles_per_chunk + kTilesPerChunk - 1) / kTilesPerChunk;
+        q.st = g == 0 ? s : gs[g];
+    }
+    const uint8_t* done_all = (const uint8_t*)env_st->done;
     // trunk of the first step of this call (later ones ride on the tracker step)
-    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_env, 4)), dim3(256), 0, s, *pol_cfg, *pol_w, traj->obs + (size_t)t_begin * B * S, (long)S,
-                       n_env, (const uint8_t*)env_st->done, h2, traj->value + (size_t)t_begin * B, (float*)nullptr);
+    for (int gi = 0; gi < n_groups; ++gi) {
+        const Group& q = grp[gi];
+        hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(q.n, 4)), dim3(256), 0, q.st, *pol_cfg, *pol_w,
+                           traj->obs + ((size_t)t_begin * B + q.base) * S, (long)S, q.n, done_all + q.base, q.h2,
+                           traj->value + (size_t)t_begin * B + q.base, (float*)nullptr);
+    }
     CIRS_CHECK_LAUNCH("trunk_kernel");
     for (int t = t_begin; t < t_end; ++t) {
-        float* obs_n = traj->obs + (size_t)(t + 1) * B * S;
-        int64_t* act_t = traj->act + (size_t)t * B;
-        double* rew_t = traj->rew + (size_t)t * B;
-        uint8_t* done_t = traj->done + (size_t)t * B;
         const float* gum_t = gumbel ? gumbel + (size_t)t * B * pol_cfg->n_items : (const float*)nullptr;
-        if (gum_t) {   // harness-supplied noise: plain Gumbel-max over the catalogue (reference-recorded fixtures)
-            CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_head_kernel, dim3(hg.grid_x, hg.n_row_blocks), dim3(256), 0, s, *pol_cfg,
-                                                      pol_w->wa, pol_w->ba, (const float*)h2, n_env, gum_t, seed,
-                                                      rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
-                                                      (const uint8_t*)env_st->done, pv, n_pad, hg.tiles_per_chunk));
-        } else {       // counter-based sampler: chunk log-masses now, chunk + item draws in the tail of the step kernel
-            CIRS_PROF_LAUNCH(3, s, hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(n_mass_chunks, mass_cpw), hg.n_row_blocks), dim3(256), 0, s,
-                                                      *pol_cfg, pol_w->wa, pol_w->ba, (const float*)h2, n_env, (const int32_t*)nullptr,
-                                                      (const uint32_t*)visited, (const uint8_t*)env_st->done, pv.m, n_pad, mass_cpw, 0, 0));
+        for (int gi = 0; gi < n_groups; ++gi) {
+            const Group& q = grp[gi];
+            float* obs_n = traj->obs + ((size_t)(t + 1) * B + q.base) * S;
+            int64_t* act_t = traj->act + (size_t)t * B + q.base;
+            double* rew_t = traj->rew + (size_t)t * B + q.base;
+            uint8_t* done_t = traj->done + (size_t)t * B + q.base;
+            if (gum_t) {   // harness-supplied noise: plain Gumbel-max over the catalogue (reference-recorded fixtures); one group
+                CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_head_kernel, dim3(q.hg.grid_x, q.hg.n_row_blocks), dim3(256), 0, q.st, *pol_cfg,
+                                                             pol_w->wa, pol_w->ba, (const float*)q.h2, q.n, gum_t, seed,
+                                                             rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
+                                                             done_all, q.pv, q.n_pad, q.hg.tiles_per_chunk));
+            } else {       // counter-based sampler: chunk log-masses now, chunk + item draws in the tail of the step kernel
+                CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(n_mass_chunks, q.cpw), q.hg.n_row_blocks), dim3(256), 0,
+                                                             q.st, *pol_cfg, pol_w->wa, pol_w->ba, (const float*)q.h2, q.n, (const int32_t*)nullptr,
+                                                             (const uint32_t*)visited, done_all + q.base, q.pv.m, q.n_pad, q.cpw, 0, 0, q.base));
+            }
+            CIRS_CHECK_LAUNCH("sampler kernel");
+            TrunkFuse tf{};
+            if (t + 1 < t_end) {
+                tf.on = 1; tf.cfg = *pol_cfg; tf.w = *pol_w; tf.skip = done_all + q.base; tf.h2 = q.h2;
+                tf.value = traj->value + (size_t)(t + 1) * B + q.base;
+            }
+            // preprocess_fn(obs_next, rew): the tracker appends one position for every env that acted this step
+            // ... in the same launch as the tail of this step: action / logp, visited bit, env step, forced length
+            TailFuse tl{};
+            tl.on = 1; tl.cfg = *env_cfg; tl.tab = *env_tab; tl.st = *env_st; tl.n_pad = q.n_pad; tl.n_chunks = q.hg.n_chunks; tl.pv = q.pv;
+            tl.env_base = q.base;
+            tl.visited = visited; tl.force_length = force_length;
+            if (!gum_t) {
+                tl.pick_on = 1;
+                tl.pick = PickArgs{q.pv.m, q.n_pad, n_mass_chunks, pol_w->wa, pol_w->ba, q.h2, visited, pol_cfg->n_items, 0, 0, seed, rng_base + (uint32_t)t};
+            }
+            tl.force_done = (t + 1 >= force_length) ? 1 : 0;
+            tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B + q.base; tl.rew_out = rew_t; tl.done_out = done_t;
+            tl.ctr_out = traj->ctr + (size_t)t * B + q.base;
+            if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, q.n, obs_n, S, &tf, q.st, &tl))
+                return rc;
         }
-        CIRS_CHECK_LAUNCH("actor_head_kernel");
-        TrunkFuse tf{};
-        if (t + 1 < t_end) {
-            tf.on = 1; tf.cfg = *pol_cfg; tf.w = *pol_w; tf.skip = env_st->done; tf.h2 = h2; tf.value = traj->value + (size_t)(t + 1) * B;
+    }
+    if (n_groups > 1) {
+        for (int gi = 1; gi < n_groups; ++gi) {
+            CIRS_HIP(hipEventRecord(gev[gi], grp[gi].st));
+            CIRS_HIP(hipStreamWaitEvent(s, gev[gi], 0));
         }
-        // preprocess_fn(obs_next, rew): the tracker appends one position for every env that acted this step
-        // ... in the same launch as the tail of this step: merge -> act / logp, visited bit, env step, forced length
-        TailFuse tl{};
-        tl.on = 1; tl.cfg = *env_cfg; tl.tab = *env_tab; tl.st = *env_st; tl.n_pad = n_pad; tl.n_chunks = n_chunks; tl.pv = pv;
-        tl.visited = visited; tl.force_length = force_length;
-        if (!gum_t) {
-            tl.pick_on = 1;
-            tl.pick = PickArgs{pv.m, n_pad, n_mass_chunks, pol_w->wa, pol_w->ba, h2, visited, pol_cfg->n_items, 0, 0, seed, rng_base + (uint32_t)t};
-        }
-        tl.force_done = (t + 1 >= force_length) ? 1 : 0;
-        tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B; tl.rew_out = rew_t; tl.done_out = done_t; tl.ctr_out = traj->ctr + (size_t)t * B;
-        if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, n_env, obs_n, S, &tf, s, &tl))
-            return rc;
     }
     return CIRS_OK;
 }

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         int64_t act = -1;
         // the env's own state (user, turn, history entry of this lane, running reward) does not depend on the action: its loads
         // are issued BEFORE the merge of the sampler partials and complete underneath it
-        const EnvPrefetch epf = env_prefetch(tl.cfg, tl.st, j, lane);
+        const int et = tl.env_base + j;    // this row's env (env groups: row 0 of the launch is env env_base)
+        const EnvPrefetch epf = env_prefetch(tl.cfg, tl.st, et, lane);
         // sampler inputs of this row: same round trip as the env state
         MergePre mpre{};
         PickPre ppre{};
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
         } else if (tl.pick_on) {   // two-level draw: chunk, then item (per-wave LDS scratch: the feed-forward buffer, free here)
             float* hs_pick = smem + (size_t)wv * (6 * kD + kHid + NHEAD * lpad) + 6 * kD;
-            const Cand r = actor_pick_wave(tl.pick, j, j, lane, hs_pick, &ppre);
+            const Cand r = actor_pick_wave(tl.pick, j, et, lane, hs_pick, &ppre);
             act = r.bi == 0x7FFFFFFF ? -1 : (int64_t)r.bi;
             if (lane == 0) { tl.act_out[j] = act; tl.logp_out[j] = cand_logp(r); }
         } else {
@@ -142,25 +143,25 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         }
         if (tl.visited && act >= 0 && lane == 0) {
             const int words = (tl.cfg.n_items + 31) / 32;
-            tl.visited[(size_t)j * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
+            tl.visited[(size_t)et * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
         }
         CIRS_STAMP(2);
         EnvStepResult er;
-        env_step_wave(tl.cfg, tl.tab, tl.st, j, j, act, lane, nullptr, tl.rew_out, tl.done_out, tl.ctr_out, nullptr, &er, &epf);
+        env_step_wave(tl.cfg, tl.tab, tl.st, et, j, act, lane, nullptr, tl.rew_out, tl.done_out, tl.ctr_out, nullptr, &er, &epf);
         const unsigned long long rb = __builtin_bit_cast(unsigned long long, er.reward);
         const unsigned rlo = __shfl((unsigned)rb, 0, CIRS_WAVE), rhi = __shfl((unsigned)(rb >> 32), 0, CIRS_WAVE);
         const double reward = __builtin_bit_cast(double, ((unsigned long long)rhi << 32) | rlo);
         fin_f = __shfl(er.done, 0, CIRS_WAVE);
         if (tl.force_length > 0 && act >= 0) {  // collector.py:253-258
             fin_f = tl.force_done;
-            if (lane == 0) { tl.st.done[j] = (uint8_t)tl.force_done; tl.done_out[j] = (uint8_t)tl.force_done; }
+            if (lane == 0) { tl.st.done[et] = (uint8_t)tl.force_done; tl.done_out[j] = (uint8_t)tl.force_done; }
         }
         it_f = act;
         r_f = (float)reward;
     }
     CIRS_STAMP(3);
     if (skip && skip[j]) { CIRS_TRUNK_ZERO(); return; }
-    const int e = env_ids ? env_ids[j] : j;
+    const int e = env_ids ? env_ids[j] : (tl.on ? tl.env_base + j : j);
     const int B = cfg.n_env, L = cfg.max_len;
     // per-wave scratch
     float* base = smem + (size_t)wv * (6 * kD + kHid + NHEAD * lpad);
