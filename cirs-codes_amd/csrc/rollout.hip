@@ -42,6 +42,10 @@ __global__ __launch_bounds__(256) void online_pairs_kernel(const int32_t* __rest
 }
 
 constexpr int kMaxGroups = 4;
+// sampler scratch of one env group (cirs_policy_workspace_bytes without its slack)
+static inline int64_t group_ws_bytes(const cirs_policy_cfg* cfg, int n) {
+    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items)) * 4;
+}
 
 }  // namespace cirs
 
@@ -168,7 +172,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     }
     int n_g = ((n_env + G - 1) / G + 127) / 128 * 128;       // rows per group: whole 128-row blocks of the mass kernel
     if (G > 1) {   // room for one sampler workspace per group?
-        const int64_t per = (cirs_policy_workspace_bytes(pol_cfg, n_g) + 255) & ~(int64_t)255;
+        const int64_t per = (group_ws_bytes(pol_cfg, n_g) + 255) & ~(int64_t)255;
         if (per * G > workspace_bytes) { G = 1; n_g = n_env; }
     } else {
         n_g = n_env;
@@ -183,7 +187,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         CIRS_HIP(hipEventRecord(gev[0], s));
         for (int g = 1; g < G; ++g) CIRS_HIP(hipStreamWaitEvent(gs[g], gev[0], 0));
     }
-    const int64_t ws_per = (cirs_policy_workspace_bytes(pol_cfg, n_g) + 255) & ~(int64_t)255;
+    const int64_t ws_per = (group_ws_bytes(pol_cfg, n_g) + 255) & ~(int64_t)255;
     const int n_mass_chunks = n_chunks_of(pol_cfg->n_items);
     struct Group { int base, n, n_pad; float* h2; ActorPartialView pv; HeadGrid hg; int cpw; hipStream_t st; };
     Group grp[kMaxGroups];
