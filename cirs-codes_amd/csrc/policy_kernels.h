@@ -537,14 +537,16 @@ __device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, 
 // of c*: two per lane, logits as scalar fma chains in the MFMA's k-order (bias, then k = kk, 32 + kk: the very bits stage 1 saw),
 // item = argmax_i (z_i + G2_i), ties -> lowest id.  The row's log-sum-exp for logp is folded from the chunk masses (hardware exp:
 // tolerance-checked, it decides nothing).  hs: 64 floats of per-wave LDS scratch.  Result identical in every lane.
-struct PickPre { float L[2]; };
-__device__ __forceinline__ PickPre actor_pick_prefetch(int j, int lane, int n_pad, int n_chunks, const float* __restrict__ lmass) {
+struct PickPre { float L[2], hv; };   // first two chunk masses of this lane + its element of the row's hidden vector
+__device__ __forceinline__ PickPre actor_pick_prefetch(int j, int lane, int n_pad, int n_chunks, const float* __restrict__ lmass,
+                                                       const float* __restrict__ h2) {
     PickPre p;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = lane + CIRS_WAVE * q;
         p.L[q] = lmass[(size_t)(c < n_chunks ? c : 0) * n_pad + j];
     }
+    p.hv = h2[(size_t)j * kH + lane];
     return p;
 }
 struct PickArgs {
@@ -563,7 +565,7 @@ __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e,
     const Cand cw = cand_wave_reduce(c0);
     Cand out{cw.bs, 0.f, cw.m, cw.s, 0x7FFFFFFF};
     if (cw.bi == 0x7FFFFFFF) return out;          // nothing left to recommend
-    hs[lane] = a.h2[(size_t)j * kH + lane];
+    hs[lane] = pre ? pre->hv : a.h2[(size_t)j * kH + lane];
     __builtin_amdgcn_wave_barrier();
     const int I_tot = a.n_items_total > 0 ? a.n_items_total : a.n_items;
     const int vis_words = (I_tot + 31) / 32;

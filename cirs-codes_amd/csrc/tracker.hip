@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     }
     // fused rollout: the tail of the vector step for this env row first (action, env step); its results stay in registers
     long it_f = -1;
-    float r_f = 0.f;
+    float r_f = 0.f, a_pre = 0.f;
     int fin_f = 0;
     if (tl.on) {
         int64_t act = -1;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         // sampler inputs of this row: same round trip as the env state
         MergePre mpre{};
         PickPre ppre{};
-        if (tl.pick_on) ppre = actor_pick_prefetch(j, lane, tl.pick.n_pad, tl.pick.n_chunks, tl.pick.lmass);
+        if (tl.pick_on) ppre = actor_pick_prefetch(j, lane, tl.pick.n_pad, tl.pick.n_chunks, tl.pick.lmass, tl.pick.h2);
         else mpre = actor_merge_prefetch(j, lane, tl.n_pad, tl.n_chunks, tl.pv);
         if (epf.done) {  // finished env: the policy skipped it
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
@@ -146,6 +146,8 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             tl.visited[(size_t)et * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
         }
         CIRS_STAMP(2);
+        // the tracker's input slot needs Emb_item[action]: requested now, it arrives underneath the env step
+        if (act >= 0 && lane < kD) a_pre = w.emb_item[(size_t)act * kD + lane];
         EnvStepResult er;
         env_step_wave(tl.cfg, tl.tab, tl.st, et, j, act, lane, nullptr, tl.rew_out, tl.done_out, tl.ctr_out, nullptr, &er, &epf);
         const unsigned long long rb = __builtin_bit_cast(unsigned long long, er.reward);
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         const float r = tl.on ? r_f : (float)rew[j];
         float a = 0.f;
         if (lane < kD) {
-            a = w.emb_item[(size_t)it * kD + lane];
+            a = tl.on ? a_pre : w.emb_item[(size_t)it * kD + lane];
             xs[lane] = a;
         }
         __builtin_amdgcn_wave_barrier();
