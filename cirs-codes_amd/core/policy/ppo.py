@@ -128,11 +128,34 @@ class PPOPolicy(nn.Module):
         return act
 
     def forward(self, batch, buffer=None, remove_recommended_ids=False, state=None, **kwargs):
-        if remove_recommended_ids:
-            raise NotImplementedError("id masking runs inside the fused rollout (Collector(remove_recommended_ids=True))")
+        """The per-step protocol (core/policy/ppo.py:111-163): one cirs_actor_sample launch over the rows of `batch`.
+        remove_recommended_ids: the ids every live env has already recommended in its running episode are read back from the
+        buffer exactly like core/policy/utils.py:7-27 does (walk `buffer.prev` from the last index of every unfinished sub-buffer)
+        and masked through the sampler's visited bitmap (the reference drops them from the probability vector and renormalises,
+        :30-58 -- the same distribution).  Rows are the live envs in ascending order, as in the reference."""
         obs = batch.obs
+        obs = obs if isinstance(obs, torch.Tensor) else torch.as_tensor(np.asarray(obs), dtype=torch.float32)
+        obs = obs.to(self.flat.device, torch.float32).contiguous()
+        n = obs.shape[0]
+        visited = env_ids = None
+        if remove_recommended_ids and buffer is not None and len(buffer) > 0:
+            live = buffer.last_index[~np.asarray(buffer.done)[buffer.last_index] & (buffer._lengths > 0)]
+            assert len(live) == n, "rows of the batch must be the unfinished envs of the buffer (core/policy/utils.py:11)"
+            words = (self.n_items + 31) // 32
+            bm = np.zeros((n, words), dtype=np.uint32)
+            idx = live.copy()
+            acts = np.asarray(buffer.act)
+            while True:
+                a = acts[idx].astype(np.int64)
+                np.bitwise_or.at(bm, (np.arange(n), a >> 5), (np.uint32(1) << (a & 31).astype(np.uint32)))
+                prv = buffer.prev(idx)
+                if np.all(prv == idx):
+                    break
+                idx = prv
+            visited = torch.as_tensor(bm.view(np.int32)).to(self.flat.device)
+            env_ids = torch.arange(n, dtype=torch.int32, device=self.flat.device)   # bitmap rows = batch rows
         self._step_counter = getattr(self, "_step_counter", 0) + 1
-        act, logp, value = self._dev_policy.sample(obs.contiguous(), seed=self.seed, rng_step=self._step_counter & 0xFFFFFFFF)
+        act, logp, value = self._dev_policy.sample(obs, seed=self.seed, rng_step=self._step_counter & 0xFFFFFFFF, env_ids=env_ids, visited=visited)
         return Batch(logits=None, act=act, state=None, dist=None, policy=Batch(logp=logp, value=value))
 
     def _get_learner(self, n_env, max_turn):

@@ -158,3 +158,31 @@ def test_policy_learns_longer_and_more_rewarding_trajectories():
     last = coll.collect(n_episode=128)
     assert last["len"] > 1.4 * first["len"], (first["len"], last["len"])
     assert last["rew"] > 1.5 * first["rew"], (first["rew"], last["rew"])
+
+
+def test_policy_forward_masks_recommended_ids_through_the_protocol():
+    """PPOPolicy.forward(batch, buffer, remove_recommended_ids=True) of the per-step protocol (core/policy/ppo.py:133-163 with
+    core/policy/utils.py:7-58): ids already in the running episodes of the buffer are never drawn again; finished envs drop out."""
+    from tianshou.data import Batch, VectorReplayBuffer
+    ex = load_example()
+    args = ex.get_args(["--n-users", "60", "--n-items", "70", "--training-num", "6", "--max_turn", "40", "--dropout", "0"])
+    tab, train_envs, st, policy, coll = ex.build(args)
+    B, I = 6, 70
+    buf = VectorReplayBuffer(B * 40, B)
+    rng = np.random.RandomState(0)
+    live = np.arange(B)
+    seen = {b: [] for b in range(B)}
+    obs = torch.randn(B, 20)
+    for t in range(30):
+        out = policy.forward(Batch(obs=obs[live]), buf, remove_recommended_ids=True)
+        act = out.act.cpu().numpy()
+        assert act.shape == (len(live),)
+        for b, a in zip(live, act):
+            assert a not in seen[b], f"env {b} was recommended item {a} twice"
+            seen[b].append(int(a))
+        done = (rng.uniform(size=len(live)) < 0.12)
+        buf.add(Batch(obs=obs[live].numpy(), act=act, rew=np.ones(len(live)), done=done), buffer_ids=live)
+        live = live[~done]
+        if len(live) == 0:
+            break
+    assert max(len(v) for v in seen.values()) >= 10
