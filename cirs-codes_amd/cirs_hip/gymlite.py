@@ -21,6 +21,8 @@ class Box(Space):
         self.high = np.full(shape, high, dtype=dtype)
 
     def sample(self):
+        if np.issubdtype(self.dtype, np.integer):      # gym: integer boxes are sampled uniformly from [low, high] inclusive
+            return np.random.randint(self.low.astype(np.int64), self.high.astype(np.int64) + 1).astype(self.dtype)
         return np.random.uniform(self.low, self.high).astype(self.dtype)
 
 

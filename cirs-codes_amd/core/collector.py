@@ -103,7 +103,8 @@ class Collector:
         [max_turn, env_num, n_items] (g = -log q of the reference's Categorical.sample race)."""
         assert n_step is None and n_episode is not None, "the CIRS scripts collect whole episodes (n_episode)"
         assert n_episode == self.env_num, "n_episode must equal the number of envs (finished envs are not reset, SURVEY Q4)"
-        assert not random
+        if random:
+            return self._collect_stepwise(n_episode, users)
         start = time.time()
         ro = self._get_rollout()
         self.reset_buffer()
@@ -120,3 +121,43 @@ class Collector:
         self.collect_episode += res["n/ep"]
         self.collect_time += max(time.time() - start, 1e-9)
         return res
+
+    def _collect_stepwise(self, n_episode, users=None) -> Dict[str, Any]:
+        """`collect(random=True)` (reference core/collector.py:225-227): actions are drawn from the envs' action spaces instead of
+        the policy, everything else is the reference's loop one vector step at a time through the per-step protocol -- env.step
+        (one cirs_env_step launch), preprocess_fn = StateTracker.build_state (one cirs_tracker_step launch), buffer.add -- with
+        finished envs dropped from the ready set and the result dict assembled from add()'s episode accounting (:272-362)."""
+        start = time.time()
+        self.reset_buffer()
+        n = self.env_num
+        self.preprocess_fn(dim_batch=n, reset=True)
+        obs = self.env.reset(users=users)
+        state = self.preprocess_fn(obs=obs, env_id=np.arange(n))["obs"]
+        ready = np.arange(n)
+        step_count, episode_count, cnt_loop = 0, 0, 0
+        ep_rews, ep_lens, ep_idxs = [], [], []
+        while True:
+            act = np.array([int(np.asarray(self._action_space[i].sample()).reshape(-1)[0]) for i in ready], dtype=np.int64)
+            obs_next, rew, done, info = self.env.step(self.policy.map_action(act), ready)
+            cnt_loop += 1
+            if self.force_length > 0:
+                done = np.full_like(done, cnt_loop >= self.force_length)
+            nxt = self.preprocess_fn(obs_next=obs_next, rew=rew, done=done, info=info, policy=None, env_id=ready)["obs_next"]
+            ptr, e_rew, e_len, e_idx = self.buffer.add(Batch(obs=state, act=act, rew=rew, done=done, obs_next=nxt,
+                                                             info=Batch(env_id=ready.copy())), buffer_ids=ready)
+            step_count += len(ready)
+            if np.any(done):
+                fin = np.where(done)[0]
+                episode_count += len(fin)
+                ep_lens.append(e_len[fin]); ep_rews.append(e_rew[fin]); ep_idxs.append(e_idx[fin])
+                keep = ~done
+                ready, nxt = ready[keep], nxt[torch.as_tensor(keep, device=nxt.device)]
+            state = nxt
+            if episode_count >= n_episode or len(ready) == 0:
+                break
+        rews, lens, idxs = np.concatenate(ep_rews), np.concatenate(ep_lens), np.concatenate(ep_idxs)
+        self.collect_step += step_count
+        self.collect_episode += episode_count
+        self.collect_time += max(time.time() - start, 1e-9)
+        return {"n/ep": episode_count, "n/st": step_count, "rews": rews, "lens": lens, "idxs": idxs, "rew": rews.mean(), "len": lens.mean(),
+                "rew_std": rews.std(), "len_std": lens.std()}

@@ -186,3 +186,43 @@ def test_policy_forward_masks_recommended_ids_through_the_protocol():
         if len(live) == 0:
             break
     assert max(len(v) for v in seen.values()) >= 10
+
+
+def test_collect_with_random_policy_through_the_step_protocol():
+    """Collector.collect(n_episode, random=True) (core/collector.py:225-227): actions from the action spaces, the loop one vector
+    step at a time through env.step / build_state / buffer.add; checked against the C oracle env teacher-forced with the buffer's
+    actions, the torch restatement of the tracker, and the result-dict arithmetic."""
+    import envcase
+    import nn_oracle
+    ex = load_example()
+    args = ex.get_args(["--n-users", "80", "--n-items", "120", "--training-num", "12", "--episode-per-collect", "12", "--max_turn", "9",
+                        "--tau", "10", "--leave_threshold", "1", "--num_leave_compute", "3", "--dropout", "0"])
+    tab, train_envs, st, policy, coll = ex.build(args)
+    np.random.seed(4)
+    users = np.random.RandomState(2).randint(0, 80, 12)
+    res = coll.collect(n_episode=12, random=True, users=users)
+    buf = coll.buffer
+    lens = buf._lengths
+    assert res["n/ep"] == 12 and res["n/st"] == lens.sum() == len(buf) and lens.min() >= 1 and lens.max() <= 9
+    assert np.array_equal(np.sort(res["lens"]), np.sort(lens)) and (np.diff(res["lens"]) >= 0).all()
+    acts = np.zeros((12, 9), np.int64); rews = np.zeros((12, 9))
+    for b in range(12):
+        sl = slice(buf._offset[b], buf._offset[b] + lens[b])
+        acts[b, :lens[b]] = buf.act[sl]; rews[b, :lens[b]] = buf.rew[sl]
+        assert buf.done[sl][-1] and not buf.done[sl][:-1].any()
+    assert acts.max() < 120 and len(np.unique(acts)) > 30
+    a_env, b_env = envcase.ab_env_tables(tab.raw_uid, tab.raw_pid, tab.alpha_u, tab.beta_i, 80, 120)
+    host = envcase.HostEnv(envcase.env_cfg(80, 120, num_leave_compute=3, leave_threshold=1, max_turn=9, tau=10.0, gamma_exposure=args.gamma_exposure,
+                                           version=1, r_decay=1.0, has_ab=True), tab.mat, tab.normed_mat, tab.dist, tab.item_cats, a_env, b_env, 12)
+    want = envcase.run_teacher_forced(host, users, acts, 9)
+    assert np.array_equal(want["length"], lens)
+    for b in range(12):
+        np.testing.assert_allclose(rews[b, :lens[b]], want["rew"][b, :lens[b]], rtol=1e-12)
+    order = np.argsort(lens, kind="stable")
+    np.testing.assert_allclose(res["rews"], np.array([rews[b, :lens[b]].sum() for b in order]), rtol=1e-12)
+    tp = {k: v.detach().cpu() for k, v in st.state_dict().items()}
+    states = nn_oracle.tracker_states(tp, users, acts, rews).detach().numpy()
+    for b in range(12):
+        sl = slice(buf._offset[b], buf._offset[b] + lens[b])
+        np.testing.assert_allclose(buf.obs[sl].cpu().numpy(), states[b, :lens[b]], atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(buf.obs_next[sl].cpu().numpy(), states[b, 1:lens[b] + 1], atol=1e-4, rtol=1e-4)
