@@ -518,6 +518,14 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 // The Wa planes of a tile (24 KB, written by wa_planes_kernel) are staged in LDS once per workgroup, double-buffered with
 // the next tile's global loads in flight; row strides 144 B / 80 B keep the ds_read_b128 of the operands conflict-free.
 
+#ifdef CIRS_HEAD_PROF
+// per-tile stage timestamps of workgroup (0, 0) / wave 0 at its third tile (probe builds only: tools/probes/head_prof.py)
+__device__ unsigned long long g_head_prof[32];
+#define CIRS_HSTAMP(K) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && it == 2) g_head_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CIRS_HSTAMP(K) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                                          const uint4* __restrict__ planes,
                                                                          const float* __restrict__ ba, MbView v,
@@ -604,6 +612,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     for (int it = 0; it < n_tiles; ++it) {
         const int buf = it & 1;
         const int tile0 = first_tile + it * kTileN;
+        CIRS_HSTAMP(0);
         if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);  // global loads in flight during the MFMAs below
         f32x16 dw0, dw1;
         float db = 0.f;
@@ -630,8 +639,10 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                     cb[c][t].m = *reinterpret_cast<const bf16x8*>(bp + kCPlaneB);
                     cb[c][t].l = *reinterpret_cast<const bf16x8*>(bp + 2 * kCPlaneB);
                 }
+            CIRS_HSTAMP(1);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc = mfma_bf16x6(za[s4], hz[s4], acc);
+            CIRS_HSTAMP(2);
             float* tt = sT[wv];
             // dZ in place.  Padded rows carry zero coefficients and lse = 1e30 (p = 0, d = 0); items beyond I exist only in
             // the last tile (zero weights -> finite z) and are masked there.  Categorical.entropy uses
@@ -653,6 +664,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = tile0 + acc_row(r, hi) < I ? acc[r] : 0.f;
             }
+            CIRS_HSTAMP(3);
 #pragma unroll
             for (int r = 0; r < 16; ++r) tt[acc_row(r, hi) * kTStride + lo] = acc[r];   // transposed exchange: T[item][row]
             if (__any(any_clamped)) {
@@ -666,11 +678,13 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                     ent -= (ok && (c_lo || c_hi)) ? corr : 0.f;
                 }
             }
+            CIRS_HSTAMP(4);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const Planes a = split8(acc, 8 * t);  // element j: dZ[row lo][item acc_row(8 t + j, hi)]
                 mfma_bf16x6_pair(a, cb[0][t], cb[1][t], dh0, dh1);
             }
+            CIRS_HSTAMP(5);
             // the wave's own LDS writes above are read back by other lanes of the same wave
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -681,6 +695,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 const float4 t4 = *reinterpret_cast<const float4*>(&tt[lo * kTStride + 8 * g + 4 * hi]);
                 dzt[4 * g] = t4.x; dzt[4 * g + 1] = t4.y; dzt[4 * g + 2] = t4.z; dzt[4 * g + 3] = t4.w;
             }
+            CIRS_HSTAMP(6);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; db += dzt[r]; }
 #pragma unroll
@@ -689,7 +704,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 mfma_bf16x6_pair(a, hb[0][t], hb[1][t], dw0, dw1);
             }
         }
+        CIRS_HSTAMP(7);
         lds_barrier();  // the slab reduction of the previous tile has finished reading sR
+        CIRS_HSTAMP(8);
         if (wave_ok) {
             float* rr = sR[wv];
 #pragma unroll
@@ -702,7 +719,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
             if (hi == 0) rr[kTileN * kH + lo] = db;
         }
         if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);  // the other buffer was last read in iteration it-1
+        CIRS_HSTAMP(9);
         lds_barrier();
+        CIRS_HSTAMP(10);
         // sum the kBwdWaves partial tiles in wave order -> slab of this row block (coalesced float4 stores)
         {
 #pragma unroll
@@ -723,6 +742,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 if (tile0 + tid < I) slab[(size_t)I * kH + tile0 + tid] = t;
             }
         }
+        CIRS_HSTAMP(11);
     }
 #undef CIRS_ISSUE
 #undef CIRS_COMMIT
@@ -1098,6 +1118,12 @@ static int launch_adam(float* p, const float* g, float* m, float* v, long n, lon
     CIRS_CHECK_LAUNCH("adam_kernel");
     return CIRS_OK;
 }
+
+#ifdef CIRS_HEAD_PROF
+extern "C" int cirs_debug_head_prof(unsigned long long* out_host32) {
+    return hipMemcpyFromSymbol(out_host32, HIP_SYMBOL(cirs::g_head_prof), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 static int validate_ppo(const cirs_ppo_cfg* cfg) {
     CIRS_REQUIRE(cfg, "ppo cfg null");

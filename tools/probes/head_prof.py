@@ -1,0 +1,37 @@
+"""Per-tile stage timestamps of head_bwd_fused_kernel (probe build: tools/probes/build_prof_lib.sh), C3 minibatch of 1024 rows.
+    python tools/probes/head_prof.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd"))
+import numpy as np
+import torch
+from cirs_hip import abi
+
+abi.LIB_PATH = os.path.join(ROOT, "tools", "probes", "libcirs_prof.so")
+import bench
+
+wl = bench.WORKLOADS["c3"]
+eng, _ = bench.build_engine(wl, 0, 1, torch.device("cuda:0"))
+eng.collect(); eng.update(1024, 1)
+lib = C.CDLL(abi.LIB_PATH)
+names = {0: "tile start", 1: "LDS operand reads (za, cb, bias)", 2: "logits MFMAs (24)", 3: "dZ (exp, coefficients, mask)", 4: "dZ^T -> LDS (+ clamp corr.)",
+         5: "split + dH2 MFMAs (24)", 6: "fence + dZ^T read back", 7: "split + dWa MFMAs (24)", 8: "barrier 1", 9: "sR writes + plane commit", 10: "barrier 2",
+         11: "4-wave dWa sum + slab stores"}
+acc = None
+for rep in range(8):
+    bench.hip_event_kernel_time(eng, wl, reps=2)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 32)()
+    assert lib.cirs_debug_head_prof(buf) == 0
+    t = np.array(buf[:], dtype=np.float64)
+    if rep >= 2:
+        acc = t if acc is None else acc + t
+t = acc / 6
+prev = t[0]
+print("head_bwd_fused_kernel, workgroup (0,0) wave 0, third tile (raw s_memtime ticks):")
+for k in sorted(names):
+    print(f"  {names[k]:36s} {t[k] - prev:9.0f}   (cum {t[k] - t[0]:9.0f})")
+    prev = t[k]
