@@ -155,7 +155,7 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
     // The Wa tile (32 items x 64) is staged in LDS once per workgroup and shared by its four env tiles; double
     // buffered: global loads of tile t+1 are issued before the MFMAs of tile t (one barrier per tile).
     __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
-    __shared__ float sB[2][kTileN];
+    __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
@@ -325,7 +325,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
                                                                    int n_pad, int chunks_per_wg, int item_base = 0,
                                                                    int n_items_total = 0, int env_base = 0) {
     __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
-    __shared__ float sB[2][kTileN];
+    __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;

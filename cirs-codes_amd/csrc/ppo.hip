@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
                                                             const uint4* __restrict__ planes, const float* __restrict__ ba,
                                                             const float* __restrict__ h2, ActorPartialView pv) {
     __shared__ __attribute__((aligned(16))) unsigned char sW[2][3 * kRPlaneB];
-    __shared__ float sB[2][kTileN];
+    __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     constexpr int kThreads = kBwdWaves * 64;
     static_assert(kThreads == 256, "the plane staging maps one 16-byte unit per thread and plane");
     __shared__ __attribute__((aligned(16))) unsigned char sW[2][kWBufB];
-    __shared__ float sB[2][kTileN];
+    __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     __shared__ __attribute__((aligned(16))) float sT[kBwdWaves][kTileN * kTStride];
     __shared__ __attribute__((aligned(16))) float sR[kBwdWaves][kRSize];
     const int tid = threadIdx.x;
