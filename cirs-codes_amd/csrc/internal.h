@@ -78,8 +78,46 @@ void prof_after(hipStream_t s);
         if (prof_) ::cirs::prof_after(STREAM);                  \
     } while (0)
 
+// ---- packed weight image of the fused rollout's step kernel ----------------------------------------------------------------
+// tracker_step_kernel runs one wavefront per env and lane o owns output feature o of every mat-vec: with the row-major torch
+// layout W[o][k] every load instruction touches 64 different cache lines (one 16-byte piece of 64 rows), which the texture
+// addresser serialises -- ~190 such instructions per step, four wavefronts per CU.  The image stores every matrix as
+// [k/4][O][4] (lane o reads the float4 (k..k+3) of its row: consecutive lanes -> consecutive 16 bytes, 1 KB per instruction) and
+// the small vectors contiguously.  Built once per cirs_rollout_steps call by pack_tracker_image (weights change between calls);
+// the fma order of every dot product is unchanged.  Offsets in floats, all multiples of 4.
+struct TrkImg {
+    int gate_r, gate_p, gate_b;
+    int in_p[CIRS_MAX_TRACKER_LAYERS], in_b[CIRS_MAX_TRACKER_LAYERS], out_p[CIRS_MAX_TRACKER_LAYERS], out_b[CIRS_MAX_TRACKER_LAYERS];
+    int l1_p[CIRS_MAX_TRACKER_LAYERS], l1_b[CIRS_MAX_TRACKER_LAYERS], l2_p[CIRS_MAX_TRACKER_LAYERS], l2_b[CIRS_MAX_TRACKER_LAYERS];
+    int ln[CIRS_MAX_TRACKER_LAYERS];   // norm1_w | norm1_b | norm2_w | norm2_b, 32 floats each
+    int dec_p, dec_b;
+    int w1_t, b1, w2_p, b2, wc, bc;    // policy trunk (w1 transposed [S][64]: one dword per lane and k)
+    int total;
+};
+constexpr int64_t kTrkImgBytes = 256 * 1024;   // reserved at the end of the policy workspace (cirs_policy_workspace_bytes)
+inline TrkImg trk_img_layout(int nlayers, int S) {
+    TrkImg L{};
+    int o = 0;
+    auto take = [&](int n) { const int r = o; o += (n + 3) & ~3; return r; };
+    L.gate_r = take(32); L.gate_p = take(32 * 32); L.gate_b = take(32);
+    for (int l = 0; l < nlayers && l < CIRS_MAX_TRACKER_LAYERS; ++l) {
+        L.in_p[l] = take(96 * 32); L.in_b[l] = take(96);
+        L.out_p[l] = take(32 * 32); L.out_b[l] = take(32);
+        L.l1_p[l] = take(128 * 32); L.l1_b[l] = take(128);
+        L.l2_p[l] = take(32 * 128); L.l2_b[l] = take(32);
+        L.ln[l] = take(4 * 32);
+    }
+    L.dec_p = take(32 * 32); L.dec_b = take(32);
+    L.w1_t = take(S * 64); L.b1 = take(64); L.w2_p = take(64 * 64); L.b2 = take(64); L.wc = take(64); L.bc = take(4);
+    L.total = o;
+    return L;
+}
+// img <- the image of (w, pol); pol may be null (no trunk fusion)
+int pack_tracker_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_policy_weights* pol, int S, float* img,
+                       hipStream_t s);
+
 int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
-                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail = nullptr);
+                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail = nullptr, const float* img = nullptr);
 
 }  // namespace cirs

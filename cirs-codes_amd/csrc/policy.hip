@@ -57,12 +57,13 @@ __global__ __launch_bounds__(256) void actor_shard_tuple_kernel(int n, int n_pad
 __global__ __launch_bounds__(256) void actor_pick_kernel(PickArgs a, int n, const int32_t* __restrict__ env_ids,
                                                          const uint8_t* __restrict__ skip, int64_t* __restrict__ act_out,
                                                          float* __restrict__ logp_out, float* __restrict__ tuple_out) {
+    __shared__ __attribute__((aligned(16))) float stage[4][kPickStage];
     __shared__ float hs[4][kH];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wv;
     if (j >= n) return;
     Cand r{-INFINITY, 0.f, -INFINITY, 0.f, 0x7FFFFFFF};
-    if (!(skip && skip[j])) r = actor_pick_wave(a, j, env_ids ? env_ids[j] : j, lane, hs[wv], nullptr);
+    if (!(skip && skip[j])) r = actor_pick_wave(a, j, env_ids ? env_ids[j] : j, lane, hs[wv], stage[wv], nullptr);
     if (lane != 0) return;
     if (tuple_out) {
         tuple_out[j] = r.bs;
@@ -144,7 +145,8 @@ extern "C" int64_t cirs_policy_workspace_bytes(const cirs_policy_cfg* cfg, int32
     using namespace cirs;
     if (!cfg || n <= 0) return 0;
     // + slack: the fused rollout may carve one (256-byte aligned) workspace per env group out of this buffer
-    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items)) * 4 + 8192;
+    // + the packed weight image of the fused rollout's step kernel (internal.h: TrkImg) at its end
+    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items)) * 4 + 8192 + kTrkImgBytes;
 }
 
 extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state,

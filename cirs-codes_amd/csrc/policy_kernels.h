@@ -480,6 +480,46 @@ __device__ __forceinline__ Cand cand_wave_reduce(Cand a) {
     return r;   // identical in every lane
 }
 
+// The two halves of a Cand reduced separately (two-level sampler: the arg-max sits on the critical path of the vector step, the
+// log-sum-exp only feeds logp).  Same pairing as cand_wave_reduce; the arg-max (ties -> lowest id) does not depend on the order.
+struct Best { float bs, bz; int bi; };
+struct Mass { float m, s; };
+__device__ __forceinline__ void best_fold(Best& a, float os, int oi, float oz) {
+    if (os > a.bs || (os == a.bs && oi < a.bi)) { a.bs = os; a.bi = oi; a.bz = oz; }
+}
+__device__ __forceinline__ void mass_fold(Mass& a, float om, float osum) {
+    const float mn = fmaxf(a.m, om);
+    if (mn > -INFINITY) {
+        a.s = a.s * __expf(a.m - mn) + osum * __expf(om - mn);
+        a.m = mn;
+    }
+}
+template <int kCtrl>
+__device__ __forceinline__ void best_dpp_step(Best& a) {
+    const float os = dpp_f32<kCtrl>(a.bs), oz = dpp_f32<kCtrl>(a.bz);
+    const int oi = __builtin_amdgcn_update_dpp(0, a.bi, kCtrl, 0xF, 0xF, false);
+    best_fold(a, os, oi, oz);
+}
+__device__ __forceinline__ Best best_wave_reduce(Best a) {
+    best_dpp_step<0xB1>(a); best_dpp_step<0x4E>(a); best_dpp_step<0x141>(a); best_dpp_step<0x140>(a);
+    Best r{row_pick(a.bs, 0), row_pick(a.bz, 0), __builtin_amdgcn_readlane(a.bi, 0)};
+#pragma unroll
+    for (int row = 1; row < 4; ++row) best_fold(r, row_pick(a.bs, 16 * row), __builtin_amdgcn_readlane(a.bi, 16 * row), row_pick(a.bz, 16 * row));
+    return r;   // identical in every lane
+}
+template <int kCtrl>
+__device__ __forceinline__ void mass_dpp_step(Mass& a) {
+    const float om = dpp_f32<kCtrl>(a.m), osum = dpp_f32<kCtrl>(a.s);
+    mass_fold(a, om, osum);
+}
+__device__ __forceinline__ Mass mass_wave_reduce(Mass a) {
+    mass_dpp_step<0xB1>(a); mass_dpp_step<0x4E>(a); mass_dpp_step<0x141>(a); mass_dpp_step<0x140>(a);
+    Mass r{row_pick(a.m, 0), row_pick(a.s, 0)};
+#pragma unroll
+    for (int row = 1; row < 4; ++row) mass_fold(r, row_pick(a.m, 16 * row), row_pick(a.s, 16 * row));
+    return r;
+}
+
 // The first two chunk partials of every lane (chunks lane and lane + 64: the whole catalogue up to 128 chunks) do not depend on
 // anything computed in the merging kernel: a caller may request them early (fused rollout: together with the env-state prefetch,
 // before it knows whether the env still runs) and pass them in.
@@ -536,7 +576,8 @@ __device__ __forceinline__ int64_t actor_merge_wave(int j, int lane, int n_pad, 
 // chunk c* = argmax_c (L_c + G1_c) (lanes stride the chunks, register-only reduction, ties -> lowest chunk), then the 128 items
 // of c*: two per lane, logits as scalar fma chains in the MFMA's k-order (bias, then k = kk, 32 + kk: the very bits stage 1 saw),
 // item = argmax_i (z_i + G2_i), ties -> lowest id.  The row's log-sum-exp for logp is folded from the chunk masses (hardware exp:
-// tolerance-checked, it decides nothing).  hs: 64 floats of per-wave LDS scratch.  Result identical in every lane.
+// tolerance-checked, it decides nothing).  hs: 64 floats of per-wave LDS scratch, stage: kPickStage more.  Result identical in
+// every lane.
 struct PickPre { float L[2], hv; };   // first two chunk masses of this lane + its element of the row's hidden vector
 __device__ __forceinline__ PickPre actor_pick_prefetch(int j, int lane, int n_pad, int n_chunks, const float* __restrict__ lmass,
                                                        const float* __restrict__ h2) {
@@ -555,49 +596,112 @@ struct PickArgs {
     const uint32_t* visited; int n_items, item_base, n_items_total;
     uint64_t seed; uint32_t rng_step;
 };
-__device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e, int lane, float* hs, const PickPre* pre) {
+// The 128 head rows of the drawn chunk are 32 KB of CONSECUTIVE memory: the wave reads them coalesced (32 x 1 KB, all requested at
+// once) and transposes them through `stage` (per-wave LDS, kPickStage floats: 64 rows of kH + 4 floats -- 16-byte rows whose b128
+// reads by 16 consecutive lanes cover all 64 banks) in two halves, so that lane i then owns row i / 64 + i.  (One 256-byte row per
+// lane straight from L2 costs 64 cache lines per load instruction: 20 k cycles at the head of the step kernel's critical path.)
+#ifndef CIRS_PICK_STAMP
+#define CIRS_PICK_STAMP(K) do { } while (0)
+#endif
+constexpr int kPickRow = kH + 4;
+constexpr int kPickStage = 64 * kPickRow;
+struct PickNoHook { __device__ __forceinline__ void operator()() const {} };
+// after_issue(): called once, right after the chunk's row loads are requested -- a caller's own prefetches queue up BEHIND them
+template <class AfterIssue = PickNoHook>
+__device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e, int lane, float* hs, float* stage, const PickPre* pre,
+                                                AfterIssue&& after_issue = AfterIssue()) {
     const int chunk_base = a.item_base / CIRS_SAMPLER_CHUNK;
-    Cand c0{-INFINITY, 0.f, -INFINITY, 0.f, 0x7FFFFFFF};     // bi = chunk id here
-    for (int c = lane, q = 0; c < a.n_chunks; c += CIRS_WAVE, ++q) {
-        const float L = (pre && q < 2) ? (q == 0 ? pre->L[0] : pre->L[1]) : a.lmass[(size_t)c * a.n_pad + j];
-        if (L > -INFINITY) cand_fold(c0, L + chunk_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)(chunk_base + c)), c, 0.f, L, 1.0f);
-    }
-    const Cand cw = cand_wave_reduce(c0);
-    Cand out{cw.bs, 0.f, cw.m, cw.s, 0x7FFFFFFF};
-    if (cw.bi == 0x7FFFFFFF) return out;          // nothing left to recommend
-    hs[lane] = pre ? pre->hv : a.h2[(size_t)j * kH + lane];
-    __builtin_amdgcn_wave_barrier();
-    const int I_tot = a.n_items_total > 0 ? a.n_items_total : a.n_items;
-    const int vis_words = (I_tot + 31) / 32;
-    Cand it{-INFINITY, 0.f, -INFINITY, 0.f, 0x7FFFFFFF};
+    // the noise of this lane's first two chunks depends on nothing loaded: computed while the masses are still on their way
+    float G[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int il = cw.bi * CIRS_SAMPLER_CHUNK + lane + 64 * q;      // local item of this shard
-        if (il < a.n_items) {
-            const int ig = a.item_base + il;
-            const bool seen = a.visited && ((a.visited[(size_t)e * vis_words + (ig >> 5)] >> (ig & 31)) & 1u);
-            if (!seen) {
-                const float4* wr = reinterpret_cast<const float4*>(a.wa + (size_t)il * kH);
-                float4 w4[16];
-#pragma unroll
-                for (int k4 = 0; k4 < 16; ++k4) w4[k4] = wr[k4];
-                float z = a.ba[il];
-#pragma unroll
-                for (int kk = 0; kk < 32; ++kk) {
-                    const float4 lo4 = w4[kk >> 2], hi4 = w4[8 + (kk >> 2)];
-                    const int s4 = kk & 3;
-                    z = __builtin_fmaf(hs[kk], s4 == 0 ? lo4.x : s4 == 1 ? lo4.y : s4 == 2 ? lo4.z : lo4.w, z);
-                    z = __builtin_fmaf(hs[32 + kk], s4 == 0 ? hi4.x : s4 == 1 ? hi4.y : s4 == 2 ? hi4.z : hi4.w, z);
-                }
-                const float sc = z + actor_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)ig);
-                if (sc > it.bs || (sc == it.bs && ig < it.bi)) { it.bs = sc; it.bi = ig; it.bz = z; }
-            }
-        }
+        const int c = lane + CIRS_WAVE * q;
+        G[q] = c < a.n_chunks ? chunk_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)(chunk_base + c)) : 0.f;
     }
-    __builtin_amdgcn_wave_barrier();
-    const Cand iw = cand_wave_reduce(it);
-    out.bi = iw.bi; out.bz = iw.bz;
-    return out;      // bs = the chunk-level noisy score (what shards are compared by), (m, s) = log-sum-exp of the shard's masses
+#ifdef CIRS_PICK_EXTRA_GUMBELS   // probe: what two more Gumbels cost at this point
+    float Gx = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) Gx += chunk_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)(chunk_base + 1000 + lane + CIRS_WAVE * q));
+    if (Gx == 12345.678f) G[0] = Gx;
+#endif
+    CIRS_PICK_STAMP(26);
+    Best c0{-INFINITY, 0.f, 0x7FFFFFFF};     // bi = chunk id here
+    Mass ms{-INFINITY, 0.f};
+    for (int c = lane, q = 0; c < a.n_chunks; c += CIRS_WAVE, ++q) {
+        const float L = (pre && q < 2) ? (q == 0 ? pre->L[0] : pre->L[1]) : a.lmass[(size_t)c * a.n_pad + j];
+        const float g = q == 0 ? G[0] : q == 1 ? G[1] : chunk_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)(chunk_base + c));
+        if (L > -INFINITY) { best_fold(c0, L + g, c, 0.f); mass_fold(ms, L, 1.0f); }
+    }
+    CIRS_PICK_STAMP(20);
+    const Best cw = best_wave_reduce(c0);
+    CIRS_PICK_STAMP(21);
+    if (cw.bi == 0x7FFFFFFF) return Cand{cw.bs, 0.f, -INFINITY, 0.f, 0x7FFFFFFF};          // nothing left to recommend
+    const int row0 = cw.bi * CIRS_SAMPLER_CHUNK;  // first local item of the drawn chunk
+    // bias / visited words of this lane's two items first, then all 32 KB of the chunk's rows in flight at once (rows past the
+    // shard's end re-read its last row: never used)
+    const int I_tot = a.n_items_total > 0 ? a.n_items_total : a.n_items;
+    const int vis_words = (I_tot + 31) / 32;
+    float bias[2];
+    uint32_t vword[2];
+    bool live[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int il = row0 + lane + 64 * q;      // local item of this shard
+        live[q] = il < a.n_items;
+        const int ilc = live[q] ? il : a.n_items - 1;
+        bias[q] = a.ba[ilc];
+        vword[q] = a.visited ? a.visited[(size_t)e * vis_words + ((a.item_base + ilc) >> 5)] : 0u;
+    }
+    // (native vector values: a float4 struct copy becomes a memcpy through a private array that is not promoted to registers)
+    typedef float pick_v4 __attribute__((ext_vector_type(4)));
+    const pick_v4* wa4 = reinterpret_cast<const pick_v4*>(a.wa);
+    pick_v4 g0[16], g1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        int r = row0 + 4 * t + (lane >> 4);
+        r = r < a.n_items ? r : a.n_items - 1;
+        g0[t] = wa4[(size_t)r * (kH / 4) + (lane & 15)];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        int r = row0 + 64 + 4 * t + (lane >> 4);
+        r = r < a.n_items ? r : a.n_items - 1;
+        g1[t] = wa4[(size_t)r * (kH / 4) + (lane & 15)];
+    }
+    after_issue();
+    // underneath the loads: the item-level noise of this lane's two items and the log-sum-exp of the chunk masses
+    float gi[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) gi[q] = actor_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)(a.item_base + row0 + lane + 64 * q));
+    const Mass mw = mass_wave_reduce(ms);
+    hs[lane] = pre ? pre->hv : a.h2[(size_t)j * kH + lane];
+    pick_v4* st4 = reinterpret_cast<pick_v4*>(stage);
+    Best it{-INFINITY, 0.f, 0x7FFFFFFF};
+    CIRS_PICK_STAMP(22);
+#define CIRS_PICK_HALF(G4, Q)                                                                                         \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t) st4[(4 * t + (lane >> 4)) * (kPickRow / 4) + (lane & 15)] = G4[t]; \
+        __builtin_amdgcn_wave_barrier();                                                                              \
+        float z = bias[Q];                                                                                            \
+        _Pragma("unroll") for (int k4 = 0; k4 < 8; ++k4) {                                                            \
+            const pick_v4 lo4 = st4[lane * (kPickRow / 4) + k4], hi4 = st4[lane * (kPickRow / 4) + 8 + k4];           \
+            z = __builtin_fmaf(hs[4 * k4 + 0], lo4.x, z); z = __builtin_fmaf(hs[32 + 4 * k4 + 0], hi4.x, z);          \
+            z = __builtin_fmaf(hs[4 * k4 + 1], lo4.y, z); z = __builtin_fmaf(hs[32 + 4 * k4 + 1], hi4.y, z);          \
+            z = __builtin_fmaf(hs[4 * k4 + 2], lo4.z, z); z = __builtin_fmaf(hs[32 + 4 * k4 + 2], hi4.z, z);          \
+            z = __builtin_fmaf(hs[4 * k4 + 3], lo4.w, z); z = __builtin_fmaf(hs[32 + 4 * k4 + 3], hi4.w, z);          \
+        }                                                                                                             \
+        const int ig = a.item_base + row0 + lane + 64 * Q;                                                            \
+        if (live[Q] && !((vword[Q] >> (ig & 31)) & 1u)) best_fold(it, z + gi[Q], ig, z);                              \
+        __builtin_amdgcn_wave_barrier();                                                                              \
+    } while (0)
+    CIRS_PICK_HALF(g0, 0);
+    CIRS_PICK_STAMP(23);
+    CIRS_PICK_HALF(g1, 1);
+    CIRS_PICK_STAMP(24);
+#undef CIRS_PICK_HALF
+    const Best iw = best_wave_reduce(it);
+    CIRS_PICK_STAMP(25);
+    return Cand{cw.bs, iw.bz, mw.m, mw.s, iw.bi};   // bs = the chunk-level noisy score (what shards are compared by), (m, s) = log-sum-exp of the shard's masses
 }
 
 // log-prob of the drawn item with Categorical's clamp (torch probs_to_logits), from its logit and the row's (max, sum-exp)

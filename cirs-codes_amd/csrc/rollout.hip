@@ -176,10 +176,14 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     int n_g = ((n_env + G - 1) / G + 127) / 128 * 128;       // rows per group: whole 128-row blocks of the mass kernel
     if (G > 1) {   // room for one sampler workspace per group?
         const int64_t per = (group_ws_bytes(pol_cfg, n_g) + 255) & ~(int64_t)255;
-        if (per * G > workspace_bytes) { G = 1; n_g = n_env; }
+        if (per * G > workspace_bytes - kTrkImgBytes) { G = 1; n_g = n_env; }
     } else {
         n_g = n_env;
     }
+    // packed weight image of the step kernel (tracker + policy trunk), rebuilt per call (the weights change between calls) on the
+    // caller's stream, before the group streams fork from it
+    float* img = (float*)((char*)workspace + ((workspace_bytes - kTrkImgBytes) & ~(int64_t)255));
+    if (int rc = pack_tracker_image(trk_cfg, trk_w, pol_w, S, img, s)) return rc;
     static hipStream_t gs[kMaxGroups] = {};
     static hipEvent_t gev[kMaxGroups + 1] = {};
     if (G > 1) {
@@ -253,7 +257,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
             tl.force_done = (t + 1 >= force_length) ? 1 : 0;
             tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B + q.base; tl.rew_out = rew_t; tl.done_out = done_t;
             tl.ctr_out = traj->ctr + (size_t)t * B + q.base;
-            if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, q.n, obs_n, S, &tf, q.st, &tl))
+            if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, q.n, obs_n, S, &tf, q.st, &tl, img))
                 return rc;
         }
     }

@@ -14,6 +14,12 @@
 //
 // Bytes per env-step: 128 B embedding row + 2 layers x (pos x 256 B K/V reads + 256 B K/V writes) + 128 B x_hist
 // + 80 B state; weights (~118 KB) are shared by all envs and stay in L2.  ~60 kFLOP per env-step: latency-bound.
+#include <hip/hip_runtime.h>
+#ifdef CIRS_TRK_PROF
+// probe builds: sub-stage stamps inside the sampler's pick (slots 20..), see CIRS_STAMP below
+namespace cirs { extern __device__ unsigned long long g_trk_prof[32]; }
+#define CIRS_PICK_STAMP(K) do { if (blockIdx.x == 0 && threadIdx.x == 0) cirs::g_trk_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #include "internal.h"
 #include "policy_kernels.h"
 #include "env_kernels.h"
@@ -62,15 +68,32 @@ __device__ __forceinline__ float dot_pre(const RowRegs<K>& r, const float* xs, f
     return acc;
 }
 
-// LayerNorm over the 32 values held by lanes 0..31 (lanes >= 32 pass 0 and get garbage they never use)
-__device__ __forceinline__ float layer_norm32(float v, int lane, const float* __restrict__ w, const float* __restrict__ b) {
+// LayerNorm over the 32 values held by lanes 0..31 (lanes >= 32 pass 0 and get garbage they never use); wo / bo = this lane's
+// weight and bias, loaded by the caller well before (a load here would wait behind every weight row requested in between)
+__device__ __forceinline__ float layer_norm32(float v, int lane, float wo, float bo) {
     const float vv = lane < kD ? v : 0.f;
     const float mean = wave_sum_f32_dpp(vv) * (1.0f / kD);
     const float dlt = lane < kD ? v - mean : 0.f;
     const float var = wave_sum_f32_dpp(dlt * dlt) * (1.0f / kD);
     const float inv = 1.0f / sqrtf(var + 1e-5f);
-    const int o = lane & (kD - 1);
-    return dlt * inv * w[o] + b[o];
+    return dlt * inv * wo + bo;
+}
+
+// K consecutive inputs (from k0) of output row o of a weight matrix, into registers.  IMG: from the packed image (internal.h:
+// [k/4][O][4] at float offset off: consecutive lanes -> consecutive 16 bytes); else from the row-major matrix rm (leading dim ld).
+template <int K, bool IMG>
+__device__ __forceinline__ RowRegs<K> wrow(const float* __restrict__ img, int off, int O, const float* __restrict__ rm, int ld, int o, int k0) {
+    RowRegs<K> r;
+    if (IMG) {
+        const float4* p = reinterpret_cast<const float4*>(img + off) + (size_t)(k0 >> 2) * O + o;
+#pragma unroll
+        for (int k4 = 0; k4 < K / 4; ++k4) r.q[k4] = p[(size_t)k4 * O];
+    } else {
+        const float4* w4 = reinterpret_cast<const float4*>(rm + (size_t)o * ld + k0);
+#pragma unroll
+        for (int k4 = 0; k4 < K / 4; ++k4) r.q[k4] = w4[k4];
+    }
+    return r;
 }
 
 #ifdef CIRS_TRK_PROF
@@ -81,7 +104,7 @@ __device__ unsigned long long g_trk_prof[32];
 #define CIRS_STAMP(K) do { } while (0)
 #endif
 
-template <int NHEAD, bool DROP>
+template <int NHEAD, bool DROP, bool IMG>
 __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w,
                                                            cirs_tracker_state st, const int32_t* __restrict__ users,
                                                            const int64_t* __restrict__ items,
@@ -89,12 +112,25 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
                                                            const int32_t* __restrict__ env_ids,
                                                            const uint8_t* __restrict__ skip, int n,
                                                            float* __restrict__ state_out, long state_stride,
-                                                           int lpad, TrunkFuse tf, TailFuse tl) {
+                                                           int lpad, TrunkFuse tf, TailFuse tl, const float* __restrict__ img,
+                                                           TrkImg IL) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = kD / NHEAD;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wv;
     CIRS_STAMP(0);
+    {   // the ~1.1 KB of by-value arguments are read through the scalar cache, cold at every launch: the compiler fetches them
+        // piecemeal at first use (five to eight dependent round trips before the first vector load goes out).  One dword of every
+        // 64-byte line of the kernarg segment, requested back to back, turns that into a single round trip.
+        typedef const uint32_t __attribute__((address_space(4))) * kernarg_words;
+        kernarg_words ka = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t warm = 0;
+#pragma unroll
+        for (int o = 0; o < (int)((sizeof(cirs_tracker_cfg) + sizeof(cirs_tracker_weights) + sizeof(cirs_tracker_state) + sizeof(TrunkFuse) +
+                                   sizeof(TailFuse) + sizeof(TrkImg) + 96) / 4); o += 16)
+            warm ^= ka[o];
+        asm volatile("" ::"s"(warm));
+    }
     CIRS_STAMP(1);
     if (j >= n) return;
 // rows that do not step still owe the fused trunk its "skipped row" outputs
@@ -105,16 +141,80 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             if (lane == 0 && tf.value) tf.value[j] = 0.f;                  \
         }                                                                  \
     } while (0)
-    // the gate row of this lane's feature (33 floats, odd row stride: scalar loads) is needed right after the tail of the vector
-    // step: requested first, it arrives underneath the merge / env step
     const bool is_init = users != nullptr;
-    float gpre[kD + 1];
-    float gbias = 0.f;
-    if (!is_init) {
-        const float* gw = w.gate_w + (size_t)(lane & (kD - 1)) * (kD + 1);
-#pragma unroll
-        for (int k = 0; k <= kD; ++k) gpre[k] = gw[k];
-        gbias = w.gate_b[lane & (kD - 1)];
+    const int o32 = lane & (kD - 1);
+    const int e = env_ids ? env_ids[j] : (tl.on ? tl.env_base + j : j);
+    // the gate row of this lane's feature is needed right after the tail of the vector step: requested at kernel entry, it arrives
+    // underneath the pick / env step -- but BEHIND the few loads the pick waits for first (memory returns in order).  Row-major
+    // (no image) it is 33 floats with an odd row stride: one dword per lane and load, 64 cache lines per instruction.
+    RowRegs<kD> gp;
+    float g_r = 0.f, gbias = 0.f;
+#define CIRS_GATE_PREFETCH()                                                                   \
+    do {                                                                                       \
+        if (!is_init) {                                                                        \
+            if (IMG) {                                                                         \
+                g_r = img[IL.gate_r + o32]; gbias = img[IL.gate_b + o32];                      \
+                gp = wrow<kD, true>(img, IL.gate_p, kD, nullptr, 0, o32, 0);                   \
+            } else {                                                                           \
+                const float* gw = w.gate_w + (size_t)o32 * (kD + 1);   /* input order [r, a_0..a_31] */ \
+                g_r = gw[0]; gbias = w.gate_b[o32];                                            \
+                _Pragma("unroll") for (int k4 = 0; k4 < kD / 4; ++k4)                          \
+                    gp.q[k4] = make_float4(gw[1 + 4 * k4], gw[2 + 4 * k4], gw[3 + 4 * k4], gw[4 + 4 * k4]); \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
+    const int B = cfg.n_env, L = cfg.max_len;
+    // per-wave scratch
+    float* base = smem + (size_t)wv * (6 * kD + kHid + NHEAD * lpad);
+    float* xs = base;            // [32] current vector (mat-vec input)
+    float* qs = base + kD;       // [32] scaled query
+    float* kcur = base + 2 * kD; // [32]
+    float* vcur = base + 3 * kD; // [32]
+    float* att = base + 4 * kD;  // [32]
+    float* tmp = base + 5 * kD;  // [32]
+    float* ffs = base + 6 * kD;  // [128]
+    float* ps = ffs + kHid;      // [NHEAD][lpad] attention probabilities
+    // ---- what depends on (env, position) only: requested as early as the position is known -------------------------------------
+    //  * K/V cache rows of the earlier positions: the first batch of a layer (positions < 64 for K, < 32 for V) is requested one
+    //    layer AHEAD -- layer 0 here, layer l + 1 right after layer l's attention -- and arrives under the stages in between
+    //    (one register set, reused)
+    //  * the positional-encoding element, layer 0's in_proj rows
+    float4 kpre[kD / 4];
+    float vpre[16];
+    float pe_pre = 0.f;
+    RowRegs<kD> pq, pv;
+    float bq = 0.f, bv = 0.f;
+    int pos = 0;
+#define CIRS_KV_PREFETCH(LAYER)                                                                                  \
+    do {                                                                                                         \
+        const float* kc0_ = st.kcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
+        const float* vc0_ = st.vcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
+        const float4* k4_ = reinterpret_cast<const float4*>(kc0_) + lane;   /* K cache: [d/4][L][4], see below */ \
+        _Pragma("unroll") for (int q4 = 0; q4 < kD / 4; ++q4)                                                    \
+            kpre[q4] = lane < pos ? k4_[(size_t)q4 * L] : make_float4(0.f, 0.f, 0.f, 0.f);                       \
+        _Pragma("unroll") for (int u8 = 0; u8 < 16; ++u8) {                                                      \
+            const int jp_ = (lane >> 5) + 2 * u8;                                                                \
+            vpre[u8] = jp_ < pos ? vc0_[(size_t)jp_ * kD + o32] : 0.f;                                           \
+        }                                                                                                        \
+    } while (0)
+#define CIRS_IN_PROJ_PREFETCH(LAYER)                                                                             \
+    do {                                                                                                         \
+        pq = wrow<kD, IMG>(img, IL.in_p[LAYER], 96, w.layer[LAYER].in_proj_w, kD, lane, 0);          /* rows 0..63 (q, k) */ \
+        pv = wrow<kD, IMG>(img, IL.in_p[LAYER], 96, w.layer[LAYER].in_proj_w, kD, 2 * kD + o32, 0);  /* rows 64..95 (v) */   \
+        bq = IMG ? img[IL.in_b[LAYER] + lane] : w.layer[LAYER].in_proj_b[lane];                                  \
+        bv = IMG ? img[IL.in_b[LAYER] + 2 * kD + o32] : w.layer[LAYER].in_proj_b[2 * kD + o32];                  \
+    } while (0)
+    auto step_prefetch = [&]() {
+        if (pos < L) {
+            CIRS_KV_PREFETCH(0);
+            pe_pre = w.pe[(size_t)pos * kD + o32];
+        }
+        CIRS_IN_PROJ_PREFETCH(0);
+    };
+    if (!tl.on) {
+        CIRS_GATE_PREFETCH();
+        if (!is_init) pos = st.len[e];
+        step_prefetch();
     }
     // fused rollout: the tail of the vector step for this env row first (action, env step); its results stay in registers
     long it_f = -1;
@@ -131,19 +231,24 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         PickPre ppre{};
         if (tl.pick_on) ppre = actor_pick_prefetch(j, lane, tl.pick.n_pad, tl.pick.n_chunks, tl.pick.lmass, tl.pick.h2);
         else mpre = actor_merge_prefetch(j, lane, tl.n_pad, tl.n_chunks, tl.pv);
+        pos = st.len[e];
+        CIRS_GATE_PREFETCH();
         if (epf.done) {  // finished env: the policy skipped it
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
         } else if (tl.pick_on) {   // two-level draw: chunk, then item (per-wave LDS scratch: the feed-forward buffer, free here)
-            float* hs_pick = smem + (size_t)wv * (6 * kD + kHid + NHEAD * lpad) + 6 * kD;
-            const Cand r = actor_pick_wave(tl.pick, j, et, lane, hs_pick, &ppre);
+            float* stage = smem + (size_t)4 * (6 * kD + kHid + NHEAD * lpad) + (size_t)wv * kPickStage;   // after the four waves' scratch
+            // the (env, position) prefetch goes out right behind the pick's own row loads: it returns after them, under the item draw
+            const Cand r = actor_pick_wave(tl.pick, j, et, lane, ffs, stage, &ppre, step_prefetch);
             act = r.bi == 0x7FFFFFFF ? -1 : (int64_t)r.bi;
             if (lane == 0) { tl.act_out[j] = act; tl.logp_out[j] = cand_logp(r); }
         } else {
             act = actor_merge_wave(j, lane, tl.n_pad, tl.n_chunks, tl.pv, tl.act_out, tl.logp_out, &mpre);
+            step_prefetch();
         }
         if (tl.visited && act >= 0 && lane == 0) {
             const int words = (tl.cfg.n_items + 31) / 32;
-            tl.visited[(size_t)et * words + (act >> 5)] |= 1u << (act & 31);  // this env's own row: no atomics needed
+            // this env's own row; a result-less atomic so that the wave does not wait for a load-modify-store round trip
+            atomicOr(&tl.visited[(size_t)et * words + (act >> 5)], 1u << (act & 31));
         }
         CIRS_STAMP(2);
         // the tracker's input slot needs Emb_item[action]: requested now, it arrives underneath the env step
@@ -163,42 +268,9 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     }
     CIRS_STAMP(3);
     if (skip && skip[j]) { CIRS_TRUNK_ZERO(); return; }
-    const int e = env_ids ? env_ids[j] : (tl.on ? tl.env_base + j : j);
-    const int B = cfg.n_env, L = cfg.max_len;
-    // per-wave scratch
-    float* base = smem + (size_t)wv * (6 * kD + kHid + NHEAD * lpad);
-    float* xs = base;            // [32] current vector (mat-vec input)
-    float* qs = base + kD;       // [32] scaled query
-    float* kcur = base + 2 * kD; // [32]
-    float* vcur = base + 3 * kD; // [32]
-    float* att = base + 4 * kD;  // [32]
-    float* tmp = base + 5 * kD;  // [32]
-    float* ffs = base + 6 * kD;  // [128]
-    float* ps = ffs + kHid;      // [NHEAD][lpad] attention probabilities
-    const int o32 = lane & (kD - 1);
-
     if (!is_init && (tl.on ? it_f : items[j]) < 0) { CIRS_TRUNK_ZERO(); return; }  // act = -1: env finished earlier in this rollout
-    const int pos = is_init ? 0 : st.len[e];
     if (pos >= L) { CIRS_TRUNK_ZERO(); return; }  // history full: the caller never steps past max_turn
 
-    // ---- 0. K/V cache rows of the earlier positions depend on (env, pos) only: the first batch of a layer (positions < 64 for K,
-    //         < 32 for V) is requested one layer AHEAD -- layer 0 here, layer l + 1 right after layer l's attention --
-    //         and arrives under the mat-vec stages in between (one register set, reused)
-    float4 kpre[kD / 4];
-    float vpre[16];
-#define CIRS_KV_PREFETCH(LAYER)                                                                                  \
-    do {                                                                                                         \
-        const float* kc0_ = st.kcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
-        const float* vc0_ = st.vcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
-        const float4* k4_ = reinterpret_cast<const float4*>(kc0_ + (size_t)lane * kD);                           \
-        _Pragma("unroll") for (int q4 = 0; q4 < kD / 4; ++q4)                                                    \
-            kpre[q4] = lane < pos ? k4_[q4] : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
-        _Pragma("unroll") for (int u8 = 0; u8 < 16; ++u8) {                                                      \
-            const int jp_ = (lane >> 5) + 2 * u8;                                                                \
-            vpre[u8] = jp_ < pos ? vc0_[(size_t)jp_ * kD + o32] : 0.f;                                           \
-        }                                                                                                        \
-    } while (0)
-    CIRS_KV_PREFETCH(0);
     // ---- 1. new input slot --------------------------------------------------------------------------------
     float x;
     if (is_init) {
@@ -215,17 +287,14 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             xs[lane] = a;
         }
         __builtin_amdgcn_wave_barrier();
-        float acc = gbias;                                   // input order [r, a_0..a_31]
-        acc = __builtin_fmaf(gpre[0], r, acc);
-#pragma unroll
-        for (int k = 0; k < kD; ++k) acc = __builtin_fmaf(gpre[1 + k], xs[k], acc);
+        const float acc = dot_pre<kD>(gp, xs, __builtin_fmaf(g_r, r, gbias));   // input order [r, a_0..a_31]
         const float g = 1.0f / (1.0f + expf(-acc));
         x = g * a;
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < kD) st.x_hist[((size_t)e * L + pos) * kD + lane] = x;
     // ---- 2. scale + positional encoding ---------------------------------------------------------------------
-    float h = x * 5.656854249492381f + w.pe[(size_t)pos * kD + o32];  // sqrt(32)
+    float h = x * 5.656854249492381f + pe_pre;  // sqrt(32); pe_pre = pe[pos][o32]
     // dropout (DROP): counter-based masks keyed by (seed, global env, position, layer, site, element), csrc/rng.h
     const uint32_t d_thr = DROP ? dropout_threshold(cfg.dropout_p) : 0u;
     const float d_inv = DROP ? 1.0f / (1.0f - cfg.dropout_p) : 1.0f;
@@ -235,12 +304,12 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     if (DROP) h = CIRS_DROP(h, 0, CIRS_DROP_POS, o32);
 
     // ---- 3. encoder layers ----------------------------------------------------------------------------------
-    RowRegs<kD> pq = load_row<kD>(w.layer[0].in_proj_w + (size_t)lane * kD);                    // rows 0..63 (q, k)
-    RowRegs<kD> pv = load_row<kD>(w.layer[0].in_proj_w + (size_t)(2 * kD + o32) * kD);           // rows 64..95 (v)
-    float bq = w.layer[0].in_proj_b[lane], bv = w.layer[0].in_proj_b[2 * kD + o32];
     CIRS_STAMP(4);
     for (int l = 0; l < cfg.nlayers; ++l) {
         const cirs_tracker_layer& ly = w.layer[l];
+        // this layer's LayerNorm parameters: requested before any of the weight rows below, so they are there when needed
+        const float n1w = IMG ? img[IL.ln[l] + o32] : ly.norm1_w[o32], n1b = IMG ? img[IL.ln[l] + kD + o32] : ly.norm1_b[o32];
+        const float n2w = IMG ? img[IL.ln[l] + 2 * kD + o32] : ly.norm2_w[o32], n2b = IMG ? img[IL.ln[l] + 3 * kD + o32] : ly.norm2_b[o32];
         if (lane < kD) xs[lane] = h;
         __builtin_amdgcn_wave_barrier();
         // in_proj: 96 outputs; lanes 0..63 -> rows 0..63 (q,k), lanes 0..31 -> rows 64..95 (v)
@@ -251,12 +320,14 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             if (lane < kD) vcur[lane] = dot_pre<kD>(pv, xs, bv);
         }
         // next stage's weights: out_proj row + biases, LayerNorm-1 parameters (consumed after the attention below)
-        const RowRegs<kD> po = load_row<kD>(ly.out_proj_w + (size_t)o32 * kD);
-        const float bo = ly.out_proj_b[o32];
+        const RowRegs<kD> po = wrow<kD, IMG>(img, IL.out_p[l], kD, ly.out_proj_w, kD, o32, 0);
+        const float bo = IMG ? img[IL.out_b[l] + o32] : ly.out_proj_b[o32];
         __builtin_amdgcn_wave_barrier();
         float* kc = st.kcache + (((size_t)l * B + e) * L) * kD;
         float* vc = st.vcache + (((size_t)l * B + e) * L) * kD;
-        if (lane < kD) kc[(size_t)pos * kD + lane] = kcur[lane];
+        // K cache of (layer, env): [d/4][L][4] -- the scores' lane jp reads the float4 (d..d+3) of ITS position: consecutive lanes ->
+        // consecutive 16 bytes (position-major [L][32] rows cost one cache line per lane and load)
+        if (lane < kD) kc[((size_t)(lane >> 2) * L + pos) * 4 + (lane & 3)] = kcur[lane];
         else vc[(size_t)pos * kD + (lane - kD)] = vcur[lane - kD];
         CIRS_STAMP(5 + 6 * l);
         // scores: lanes stride over positions 0..pos
@@ -269,10 +340,10 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
 #pragma unroll
                 for (int d = 0; d < kD; ++d) kv[d] = kcur[d];
             } else {
-                const float4* k4 = reinterpret_cast<const float4*>(kc + (size_t)jp * kD);
+                const float4* k4 = reinterpret_cast<const float4*>(kc) + jp;
 #pragma unroll
                 for (int q4 = 0; q4 < kD / 4; ++q4) {
-                    const float4 t4 = jp == lane ? kpre[q4] : k4[q4];   // first batch (jp == lane): prefetched
+                    const float4 t4 = jp == lane ? kpre[q4] : k4[(size_t)q4 * L];   // first batch (jp == lane): prefetched
                     kv[4 * q4] = t4.x; kv[4 * q4 + 1] = t4.y; kv[4 * q4 + 2] = t4.z; kv[4 * q4 + 3] = t4.w;
                 }
             }
@@ -332,53 +403,66 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         if (l + 1 < cfg.nlayers) CIRS_KV_PREFETCH(l + 1);
         CIRS_STAMP(7 + 6 * l);
         // prefetch the feed-forward's first layer (two rows per lane) while out_proj + LayerNorm run
-        const RowRegs<kD> pf0 = load_row<kD>(ly.lin1_w + (size_t)lane * kD);
-        const RowRegs<kD> pf1 = load_row<kD>(ly.lin1_w + (size_t)(64 + lane) * kD);
-        const float bf0 = ly.lin1_b[lane], bf1 = ly.lin1_b[64 + lane];
+        const RowRegs<kD> pf0 = wrow<kD, IMG>(img, IL.l1_p[l], kHid, ly.lin1_w, kD, lane, 0);
+        const RowRegs<kD> pf1 = wrow<kD, IMG>(img, IL.l1_p[l], kHid, ly.lin1_w, kD, 64 + lane, 0);
+        const float bf0 = IMG ? img[IL.l1_b[l] + lane] : ly.lin1_b[lane], bf1 = IMG ? img[IL.l1_b[l] + 64 + lane] : ly.lin1_b[64 + lane];
         __builtin_amdgcn_wave_barrier();
         // out_proj + residual + LN1
         float sa = dot_pre<kD>(po, att, bo);
         if (DROP) sa = CIRS_DROP(sa, l, CIRS_DROP_RES1, o32);
-        const float h1 = layer_norm32(h + sa, lane, ly.norm1_w, ly.norm1_b);
+        const float h1 = layer_norm32(h + sa, lane, n1w, n1b);
         __builtin_amdgcn_wave_barrier();
         CIRS_STAMP(8 + 6 * l);
         if (lane < kD) tmp[lane] = h1;
         // prefetch lin2's half row (64 inputs per half-wave)
         const int half2 = lane >> 5;
-        const RowRegs<64> pl2 = load_row<64>(ly.lin2_w + (size_t)o32 * kHid + half2 * 64);
-        const float bl2 = half2 == 0 ? ly.lin2_b[o32] : 0.f;
+        const RowRegs<64> pl2 = wrow<64, IMG>(img, IL.l2_p[l], kD, ly.lin2_w, kHid, o32, half2 * 64);
+        const float bl2 = half2 == 0 ? (IMG ? img[IL.l2_b[l] + o32] : ly.lin2_b[o32]) : 0.f;
         __builtin_amdgcn_wave_barrier();
+        if (l == 0) CIRS_STAMP(27);
         // FF: 128 hidden = 2 rows per lane
         {
             float f0 = fmaxf(dot_pre<kD>(pf0, tmp, bf0), 0.f), f1 = fmaxf(dot_pre<kD>(pf1, tmp, bf1), 0.f);
+            if (l == 0) CIRS_STAMP(28);
             if (DROP) { f0 = CIRS_DROP(f0, l, CIRS_DROP_FF, lane); f1 = CIRS_DROP(f1, l, CIRS_DROP_FF, 64 + lane); }
             ffs[lane] = f0;
             ffs[64 + lane] = f1;
         }
         // prefetch the next layer's in_proj rows (or nothing after the last layer)
-        if (l + 1 < cfg.nlayers) {
-            pq = load_row<kD>(w.layer[l + 1].in_proj_w + (size_t)lane * kD);
-            pv = load_row<kD>(w.layer[l + 1].in_proj_w + (size_t)(2 * kD + o32) * kD);
-            bq = w.layer[l + 1].in_proj_b[lane]; bv = w.layer[l + 1].in_proj_b[2 * kD + o32];
-        }
+        if (l + 1 < cfg.nlayers) CIRS_IN_PROJ_PREFETCH(l + 1);
         __builtin_amdgcn_wave_barrier();
         CIRS_STAMP(9 + 6 * l);
         // lin2: 32 outputs x 128 inputs, split k in two halves across the half-waves
         {
             float acc = dot_pre<64>(pl2, ffs + half2 * 64, bl2);
+            if (l == 0) CIRS_STAMP(29);
             acc += __shfl_xor(acc, 32, CIRS_WAVE);
             if (DROP) acc = CIRS_DROP(acc, l, CIRS_DROP_RES2, o32);
-            h = layer_norm32(h1 + acc, lane, ly.norm2_w, ly.norm2_b);
+            h = layer_norm32(h1 + acc, lane, n2w, n2b);
+            if (l == 0) CIRS_STAMP(30);
         }
         __builtin_amdgcn_wave_barrier();
     }
     CIRS_STAMP(17);
     // ---- 4. decoder ------------------------------------------------------------------------------------------
+    // the decoder's row and (image path) the fused trunk's weights in one batch (requesting them inside the layer loop would carry
+    // ~130 registers around it)
+    const int od = lane < cfg.dim_state ? lane : cfg.dim_state - 1;
+    const RowRegs<kD> pdec = wrow<kD, IMG>(img, IL.dec_p, kD, w.dec_w, kD, IMG ? o32 : od, 0);
+    const float bdec = IMG ? img[IL.dec_b + o32] : w.dec_b[od];
+    RowRegs<kH> tw2;                  // trunk layer-2 row, layer-1 column, biases, critic weight of this lane
+    float tw1[kD], tb1 = 0.f, tb2 = 0.f, twc = 0.f, tbc = 0.f;
+    if (IMG && tf.on) {
+        tb1 = img[IL.b1 + lane]; tb2 = img[IL.b2 + lane]; twc = img[IL.wc + lane]; tbc = img[IL.bc];
+#pragma unroll
+        for (int k = 0; k < kD; ++k) tw1[k] = k < tf.cfg.dim_state ? img[IL.w1_t + k * kH + lane] : 0.f;
+        tw2 = wrow<kH, true>(img, IL.w2_p, kH, nullptr, 0, lane, 0);
+    }
     if (lane < kD) xs[lane] = h;
     __builtin_amdgcn_wave_barrier();
     float sval = 0.f;
     if (lane < cfg.dim_state) {
-        sval = dot_row<kD>(w.dec_w + (size_t)lane * kD, xs, w.dec_b[lane]);
+        sval = dot_pre<kD>(pdec, xs, bdec);
         state_out[(size_t)j * state_stride + lane] = sval;
     }
     if (lane == 0) st.len[e] = pos + 1;
@@ -389,12 +473,79 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         float* ths = ffs + 64;   // [64] h1
         __builtin_amdgcn_wave_barrier();
         if (lane < cfg.dim_state) txs[lane] = sval;
-        trunk_compute(tf.cfg, tf.w, txs, ths, lane, j, tf.h2, tf.value, nullptr);
+        if (IMG) {   // trunk_compute (policy_kernels.h) on the prefetched image rows: the same fma chains
+            const int S = tf.cfg.dim_state;
+            __builtin_amdgcn_wave_barrier();
+            float acc = tb1;
+#pragma unroll
+            for (int k = 0; k < kD; ++k)
+                if (k < S) acc = __builtin_fmaf(tw1[k], txs[k], acc);
+            ths[lane] = fmaxf(acc, 0.f);
+            __builtin_amdgcn_wave_barrier();
+            const float h2v = fmaxf(dot_pre<kH>(tw2, ths, tb2), 0.f);
+            tf.h2[(size_t)j * kH + lane] = h2v;
+            __builtin_amdgcn_wave_barrier();
+            txs[lane] = h2v;
+            ths[lane] = twc;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0 && tf.value) {  // critic: sequential chain (bit-reproducible), 64 fma
+                float v = tbc;
+#pragma unroll
+                for (int k = 0; k < kH; ++k) v = __builtin_fmaf(ths[k], txs[k], v);
+                tf.value[j] = v;
+            }
+        } else {
+            trunk_compute(tf.cfg, tf.w, txs, ths, lane, j, tf.h2, tf.value, nullptr);
+        }
     }
     CIRS_STAMP(19);
 #undef CIRS_TRUNK_ZERO
 #undef CIRS_KV_PREFETCH
 #undef CIRS_DROP
+}
+
+// ---- packed weight image (internal.h: TrkImg) -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_tracker_image_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w, cirs_policy_weights pol, int S,
+                                                                 TrkImg L, float* __restrict__ img) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    // img[dst + ((k / 4) * O + o) * 4 + k % 4] = src[o * ld + k0 + k]  (rows >= o_src: zero)
+    auto pk = [&](int dst, const float* src, int O, int o_src, int K, int ld, int k0) {
+        for (int i = t; i < O * K; i += nt) {
+            const int o = i / K, k = i % K;
+            img[dst + ((k >> 2) * O + o) * 4 + (k & 3)] = o < o_src ? src[(size_t)o * ld + k0 + k] : 0.f;
+        }
+    };
+    auto cp = [&](int dst, const float* src, int n) { for (int i = t; i < n; i += nt) img[dst + i] = src[i]; };
+    for (int i = t; i < kD; i += nt) img[L.gate_r + i] = w.gate_w[(size_t)i * (kD + 1)];   // input order [r, a_0..a_31]
+    pk(L.gate_p, w.gate_w, kD, kD, kD, kD + 1, 1); cp(L.gate_b, w.gate_b, kD);
+    for (int l = 0; l < cfg.nlayers; ++l) {
+        const cirs_tracker_layer& y = w.layer[l];
+        pk(L.in_p[l], y.in_proj_w, 96, 96, kD, kD, 0); cp(L.in_b[l], y.in_proj_b, 96);
+        pk(L.out_p[l], y.out_proj_w, kD, kD, kD, kD, 0); cp(L.out_b[l], y.out_proj_b, kD);
+        pk(L.l1_p[l], y.lin1_w, kHid, kHid, kD, kD, 0); cp(L.l1_b[l], y.lin1_b, kHid);
+        pk(L.l2_p[l], y.lin2_w, kD, kD, kHid, kHid, 0); cp(L.l2_b[l], y.lin2_b, kD);
+        cp(L.ln[l], y.norm1_w, kD); cp(L.ln[l] + kD, y.norm1_b, kD); cp(L.ln[l] + 2 * kD, y.norm2_w, kD); cp(L.ln[l] + 3 * kD, y.norm2_b, kD);
+    }
+    pk(L.dec_p, w.dec_w, kD, cfg.dim_state, kD, kD, 0);
+    for (int i = t; i < kD; i += nt) img[L.dec_b + i] = i < cfg.dim_state ? w.dec_b[i] : 0.f;
+    if (pol.w1) {
+        for (int i = t; i < S * kH; i += nt) { const int o = i / S, k = i % S; img[L.w1_t + k * kH + o] = pol.w1[i]; }
+        cp(L.b1, pol.b1, kH);
+        pk(L.w2_p, pol.w2, kH, kH, kH, kH, 0); cp(L.b2, pol.b2, kH);
+        cp(L.wc, pol.wc, kH);
+        if (t == 0) img[L.bc] = pol.bc[0];
+    }
+}
+
+int pack_tracker_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_policy_weights* pol, int S, float* img,
+                       hipStream_t s) {
+    const TrkImg L = trk_img_layout(cfg->nlayers, S);
+    if ((int64_t)L.total * 4 > kTrkImgBytes) return fail(CIRS_E_UNSUPPORTED, "tracker weight image exceeds its reserved workspace");
+    cirs_policy_weights pw{};
+    if (pol) pw = *pol;
+    hipLaunchKernelGGL(pack_tracker_image_kernel, dim3(64), dim3(256), 0, s, *cfg, *w, pw, S, L, img);
+    CIRS_CHECK_LAUNCH("pack_tracker_image_kernel");
+    return CIRS_OK;
 }
 
 static int validate_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st) {
@@ -417,7 +568,7 @@ static int validate_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weig
 static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st,
                           const int32_t* users, const int64_t* items, const double* rew, const int32_t* env_ids,
                           const uint8_t* skip, int n, float* state_out, long state_stride, hipStream_t s,
-                          const TrunkFuse* fuse = nullptr, const TailFuse* tail = nullptr) {
+                          const TrunkFuse* fuse = nullptr, const TailFuse* tail = nullptr, const float* img = nullptr) {
     TailFuse tl{};
     if (tail) tl = *tail;
     TrunkFuse tf{};
@@ -426,19 +577,31 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
         if (tf.on && (tf.cfg.hidden != kH || tf.cfg.dim_state != cfg->dim_state || !tf.h2)) return fail(CIRS_E_INVALID, "fused trunk: bad policy configuration");
     }
     const int lpad = (cfg->max_len + 3) & ~3;
-    const size_t shmem = 4 * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad);
+    // + the row stage of the two-level sampler's item draw when the tail of the vector step is fused in (69.6 KB per workgroup)
+    const size_t shmem = 4 * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad) + (tl.on && tl.pick_on ? 4 * sizeof(float) * kPickStage : 0);
     if (shmem > 160 * 1024) return fail(CIRS_E_UNSUPPORTED, "max_len too large for the LDS score buffer");
     const dim3 grid(cdiv(n, 4)), block(256);
     const bool drop = cfg->dropout_p > 0.f;
+    const TrkImg IL = img ? trk_img_layout(cfg->nlayers, tf.on ? tf.cfg.dim_state : cfg->dim_state) : TrkImg{};
     if (drop && !(cfg->dropout_p < 1.f)) return fail(CIRS_E_INVALID, "dropout_p must be in [0, 1)");
+#define CIRS_TRK_LAUNCH(NH, DR, IM)                                                                                   \
+    do {                                                                                                              \
+        if (shmem > 48 * 1024) {   /* more dynamic LDS than the default window: opt in once per instantiation */        \
+            static bool optin = false;                                                                                \
+            if (!optin) {                                                                                             \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tracker_step_kernel<NH, DR, IM>),              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)        \
+                    return fail(CIRS_E_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");            \
+                optin = true;                                                                                         \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((tracker_step_kernel<NH, DR, IM>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
+                           n, state_out, state_stride, lpad, tf, tl, img, IL);                                        \
+    } while (0)
 #define CIRS_TRK(NH)                                                                                                  \
     do {                                                                                                              \
-        if (drop)                                                                                                     \
-            hipLaunchKernelGGL((tracker_step_kernel<NH, true>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
-                               n, state_out, state_stride, lpad, tf, tl);                                             \
-        else                                                                                                          \
-            hipLaunchKernelGGL((tracker_step_kernel<NH, false>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
-                               n, state_out, state_stride, lpad, tf, tl);                                             \
+        if (drop) { if (img) CIRS_TRK_LAUNCH(NH, true, true); else CIRS_TRK_LAUNCH(NH, true, false); }                \
+        else { if (img) CIRS_TRK_LAUNCH(NH, false, true); else CIRS_TRK_LAUNCH(NH, false, false); }                   \
     } while (0)
     switch (cfg->nhead) {
         case 1: CIRS_TRK(1); break;
@@ -447,14 +610,15 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
         default: CIRS_TRK(8); break;
     }
 #undef CIRS_TRK
+#undef CIRS_TRK_LAUNCH
     CIRS_CHECK_LAUNCH("tracker_step_kernel");
     return CIRS_OK;
 }
 
 int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
-                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail) {
-    return launch_tracker(cfg, w, st, users, items, rew, env_ids, skip, n, state_out, state_stride, s, tf, tail);
+                          long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail, const float* img) {
+    return launch_tracker(cfg, w, st, users, items, rew, env_ids, skip, n, state_out, state_stride, s, tf, tail, img);
 }
 
 }  // namespace cirs

@@ -146,7 +146,7 @@ typedef struct cirs_tracker_weights {
 
 typedef struct cirs_tracker_state {
     float* x_hist;  /* [B, max_len, D]  self.data: slot 0 = user projection, slot k = gated action (state_tracker.py:198,215,242) */
-    float* kcache;  /* [nlayers, B, max_len, D] */
+    float* kcache;  /* nlayers * B * max_len * D floats; per (layer, env) laid out [D/4][max_len][4] (private to the library) */
     float* vcache;  /* [nlayers, B, max_len, D] */
     int32_t* len;   /* [B] self.len_data */
 } cirs_tracker_state;

@@ -31,6 +31,19 @@ for rep in range(6):
         acc = t if acc is None else acc + t
 t = acc / 5
 prev = t[0]
+pick = {1: "kernel entry", 26: "prefetch issue + chunk Gumbels (2 Philox, 2 det_logf pairs)", 20: "chunk masses arrive, fold", 21: "chunk arg-max + log-sum-exp reduce", 22: "row loads issued, bias / visited",
+        23: "rows 0-63: LDS transpose, 64 fma, Gumbel", 24: "rows 64-127", 25: "item arg-max reduce", 2: "action / visited store"}
+if t[20] > 0:
+    print("inside 'merge (tail)' = the sampler's pick (raw ticks):")
+    order = [1, 26, 20, 21, 22, 23, 24, 25, 2]
+    for a, b in zip(order[:-1], order[1:]):
+        print(f"  {pick[b]:60s} {t[b] - t[a]:9.0f}")
+if t[27] > 0:
+    print("inside layer 0's feed-forward (raw ticks):")
+    for a, b, nm in [(8, 27, "tmp write, lin2 half-row loads issued (16 x float4)"), (27, 28, "two 32-term dots from prefetched rows (waits for them)"),
+                     (28, 9, "ffs write, next layer's in_proj rows issued (16 x float4)"), (9, 29, "64-term dot from the prefetched half row (waits for it)"),
+                     (29, 30, "half-wave add + LayerNorm-2")]:
+        print(f"  {nm:60s} {t[b] - t[a]:9.0f}")
 print("stage deltas of workgroup 0 / wave 0 at the LAST step of the rollout (raw s_memtime ticks):")
 for k in sorted(names):
     print(f"  {names[k]:32s} {t[k] - prev:9.0f}   (cum {t[k] - t[0]:9.0f})")
