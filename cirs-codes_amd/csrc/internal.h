@@ -78,6 +78,16 @@ void prof_after(hipStream_t s);
         if (prof_) ::cirs::prof_after(STREAM);                  \
     } while (0)
 
+// chunks of 128 items one workgroup of actor_mass_kernel walks: the smallest count that puts every workgroup on its own CU in ONE
+// round (C3: 84 chunks x 8 row blocks on 256 CUs -> 3; one chunk each = 672 workgroups pays the ~6 k-cycle prologue -- kernel
+// arguments, hidden rows, first staged tile -- per chunk and runs 2.6 rounds: 1.73 vs 1.67 ms per collect).  Results do not depend on it.
+inline int mass_chunks_per_wg(int n_chunks, int n_row_blocks) {
+    const long units = (long)n_chunks * n_row_blocks;
+    const int cus = device_cu_count();
+    const int cpw = (int)((units + cus - 1) / cus);
+    return cpw < 1 ? 1 : cpw;
+}
+
 // ---- packed weight image of the fused rollout's step kernel ----------------------------------------------------------------
 // tracker_step_kernel runs one wavefront per env and lane o owns output feature o of every mat-vec: with the row-major torch
 // layout W[o][k] every load instruction touches 64 different cache lines (one 16-byte piece of 64 rows), which the texture

@@ -171,8 +171,8 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
                        value_out, nullptr);
     CIRS_CHECK_LAUNCH("trunk_kernel");
     if (!gumbel) {   // counter-based sampler: two-level Gumbel-max (chunk masses, then chunk + item draws)
-        const int cpw = (hg.tiles_per_chunk + kTilesPerChunk - 1) / kTilesPerChunk;
         const int nch = n_chunks_of(cfg->n_items);
+        const int cpw = mass_chunks_per_wg(nch, hg.n_row_blocks);
         hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg, w->wa, w->ba, (const float*)h2, n,
                            env_ids, visited, skip, pv.m, n_pad, cpw, 0, 0);
         CIRS_CHECK_LAUNCH("actor_mass_kernel");
@@ -211,8 +211,8 @@ extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const
                        value_out, nullptr);
     CIRS_CHECK_LAUNCH("trunk_kernel");
     CIRS_REQUIRE((item_base % CIRS_SAMPLER_CHUNK) == 0, "item_base must be a multiple of the sampler chunk (128 items)");
-    const int cpw = (hg.tiles_per_chunk + kTilesPerChunk - 1) / kTilesPerChunk;
     const int nch = n_chunks_of(cfg_shard->n_items);
+    const int cpw = mass_chunks_per_wg(nch, hg.n_row_blocks);
     hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg_shard, w_shard->wa, w_shard->ba,
                        (const float*)h2, n, env_ids, visited, skip, pv.m, n_pad, cpw, item_base, n_items_total);
     CIRS_CHECK_LAUNCH("actor_mass_kernel");

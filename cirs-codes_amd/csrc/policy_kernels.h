@@ -317,6 +317,13 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 // M_c = max of the lane pair's valid logits, S_c = sum of det_expf_neg(z - M_c) in register order (tile, r) per half-wave,
 // S_c = S_hi0 + S_hi1, L_c = M_c + det_logf(S_c): bit-identical to oracle/cirs_oracle.c two_level_draw.  One float per (chunk,
 // env row) leaves the kernel: lmass[c][row] (-inf: no valid item).  grid = (ceil(n_chunks / chunks_per_wg), row blocks).
+#ifdef CIRS_MASS_PROF
+// stage timestamps of workgroup (0, 0) / wave 0 (probe builds only: tools/probes/mass_prof.py)
+static __device__ unsigned long long g_mass_prof[32];
+#define CIRS_MSTAMP(K) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_mass_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CIRS_MSTAMP(K) do { } while (0)
+#endif
 static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa,
                                                                    const float* __restrict__ ba, const float* __restrict__ h2, int n,
                                                                    const int32_t* __restrict__ env_ids,
@@ -327,41 +334,16 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
     __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
+    CIRS_MSTAMP(0);
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * 4 + wv) * kTileM;
     const int I = cfg.n_items;
     const int I_tot = n_items_total > 0 ? n_items_total : I;
     const int vis_words = (I_tot + 31) / 32;
-    const int jr = row0 + lo;
-    const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
-    const bool wave_live = __ballot(active) != 0ull;
-    const int e = active ? (env_ids ? env_ids[jr] : env_base + jr) : 0;
-    float hrow[32];
-    if (wave_live && jr < n) {
-        const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)jr * kH + hi * 32);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = src[q];
-            hrow[4 * q + 0] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 32; ++q) hrow[q] = 0.f;
-    }
     const int n_chunks = n_chunks_of(I);
     const int c_begin = blockIdx.x * chunks_per_wg;
     const int c_end = min(n_chunks, c_begin + chunks_per_wg);
-    __shared__ int s_any;
-    if (tid == 0) s_any = 0;
-    __syncthreads();
-    if (wave_live && lane == 0) s_any = 1;
-    __syncthreads();
-    if (s_any == 0) {   // every env of this workgroup has finished: neutral masses, no arithmetic
-        if (row0 < n_pad && hi == 0)
-            for (int c = c_begin; c < c_end; ++c) lmass[(size_t)c * n_pad + jr] = -INFINITY;
-        return;
-    }
     const int st_item = tid >> 3, st_col = (tid & 7) * 8;
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
     float gb = 0.f;
@@ -382,8 +364,39 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
         dst_[0] = g0; dst_[1] = g1;                                                                        \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
-    if (c_begin < c_end) { CIRS_ISSUE(c_begin * kChunkItems); CIRS_COMMIT(0); }
+    // the first tile's rows are requested before anything that waits (the skip flags behind `active`, the vote below): one memory
+    // round trip for both instead of two in a row
+    if (c_begin < c_end) CIRS_ISSUE(c_begin * kChunkItems);
+    const int jr = row0 + lo;
+    const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
+    const bool wave_live = __ballot(active) != 0ull;
+    const int e = active ? (env_ids ? env_ids[jr] : env_base + jr) : 0;
+    float hrow[32];
+    if (wave_live && jr < n) {
+        const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)jr * kH + hi * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = src[q];
+            hrow[4 * q + 0] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) hrow[q] = 0.f;
+    }
+    __shared__ int s_any;
+    if (tid == 0) s_any = 0;
     __syncthreads();
+    if (wave_live && lane == 0) s_any = 1;
+    __syncthreads();
+    CIRS_MSTAMP(1);
+    if (s_any == 0) {   // every env of this workgroup has finished: neutral masses, no arithmetic
+        if (row0 < n_pad && hi == 0)
+            for (int c = c_begin; c < c_end; ++c) lmass[(size_t)c * n_pad + jr] = -INFINITY;
+        return;
+    }
+    if (c_begin < c_end) CIRS_COMMIT(0);
+    __syncthreads();
+    CIRS_MSTAMP(2);
     for (int c = c_begin; c < c_end; ++c) {
         f32x16 acc[4];
         uint32_t vis[4];
@@ -407,8 +420,10 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
                 for (int kk = 0; kk < 32; ++kk) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc[t], 0, 0, 0);
                 vis[t] = (visited && active) ? visited[(size_t)e * vis_words + ((item_base + tile0) >> 5)] : 0u;
             }
+            CIRS_MSTAMP(3 + 2 * t);
             if (more) CIRS_COMMIT(buf ^ 1);
             __syncthreads();
+            CIRS_MSTAMP(4 + 2 * t);
         }
         if (!wave_live) continue;
         // mask, chunk maximum over the lane pair, fixed-order sum of exponentials
@@ -431,18 +446,28 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
                 }
         }
         const float M = fmaxf(mloc, __shfl_xor(mloc, 32, CIRS_WAVE));
+        CIRS_MSTAMP(11);
         float L = -INFINITY;
         if (M > -INFINITY) {        // uniform over the lane pair (M is shared), evaluated by every lane that has a partner
             float sl = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sl += det_expf_neg(acc[t][r] - M);   // masked elements: e^(-inf) = 0
+                for (int r = 0; r < 16; r += 8) {      // 4 pairs at a time on the packed-fp32 pipe; the sum keeps its element order
+                    det_f2 x[4], ex[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { x[i].x = acc[t][r + 2 * i] - M; x[i].y = acc[t][r + 2 * i + 1] - M; }
+                    det_expf_neg8(x, ex);                 // masked elements: e^(-inf) = 0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { sl += ex[i].x; sl += ex[i].y; }
+                }
             const float so = __shfl_xor(sl, 32, CIRS_WAVE);
+            CIRS_MSTAMP(12);
             const float S = hi == 0 ? sl + so : so + sl;                          // S_hi0 + S_hi1, in that order on both lanes
             L = M + det_logf(S);
         }
         if (row0 < n_pad && hi == 0) lmass[(size_t)c * n_pad + jr] = active ? L : -INFINITY;
+        CIRS_MSTAMP(13);
     }
 #undef CIRS_ISSUE
 #undef CIRS_COMMIT
@@ -606,7 +631,8 @@ struct PickArgs {
 constexpr int kPickRow = kH + 4;
 constexpr int kPickStage = 64 * kPickRow;
 struct PickNoHook { __device__ __forceinline__ void operator()() const {} };
-// after_issue(): called once, right after the chunk's row loads are requested -- a caller's own prefetches queue up BEHIND them
+// after_issue(): called once, when the last of the chunk's rows has arrived (the memory queue is empty again) and the second
+// half's dot products are about to start -- the place for a caller's own prefetches
 template <class AfterIssue = PickNoHook>
 __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e, int lane, float* hs, float* stage, const PickPre* pre,
                                                 AfterIssue&& after_issue = AfterIssue()) {
@@ -668,11 +694,12 @@ __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e,
         r = r < a.n_items ? r : a.n_items - 1;
         g1[t] = wa4[(size_t)r * (kH / 4) + (lane & 15)];
     }
-    after_issue();
+    CIRS_PICK_STAMP(36);
     // underneath the loads: the item-level noise of this lane's two items and the log-sum-exp of the chunk masses
     float gi[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) gi[q] = actor_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)(a.item_base + row0 + lane + 64 * q));
+    CIRS_PICK_STAMP(38);
     const Mass mw = mass_wave_reduce(ms);
     hs[lane] = pre ? pre->hv : a.h2[(size_t)j * kH + lane];
     pick_v4* st4 = reinterpret_cast<pick_v4*>(stage);
@@ -682,6 +709,7 @@ __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e,
     do {                                                                                                              \
         _Pragma("unroll") for (int t = 0; t < 16; ++t) st4[(4 * t + (lane >> 4)) * (kPickRow / 4) + (lane & 15)] = G4[t]; \
         __builtin_amdgcn_wave_barrier();                                                                              \
+        if (Q == 1) { CIRS_PICK_STAMP(37); after_issue(); }   /* every row has arrived: the memory queue is empty */     \
         float z = bias[Q];                                                                                            \
         _Pragma("unroll") for (int k4 = 0; k4 < 8; ++k4) {                                                            \
             const pick_v4 lo4 = st4[lane * (kPickRow / 4) + k4], hi4 = st4[lane * (kPickRow / 4) + 8 + k4];           \

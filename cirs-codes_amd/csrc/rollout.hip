@@ -208,7 +208,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         q.h2 = (float*)wsg;
         q.pv = partial_view(wsg, q.n, pol_cfg->n_items);
         q.hg = sampler_grid(pol_cfg->n_items, q.n_pad);
-        q.cpw = (q.hg.tiles_per_chunk + kTilesPerChunk - 1) / kTilesPerChunk;
+        q.cpw = mass_chunks_per_wg(n_mass_chunks, q.hg.n_row_blocks);
         q.st = g == 0 ? s : gs[g];
     }
     const uint8_t* done_all = (const uint8_t*)env_st->done;
@@ -269,3 +269,9 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     }
     return CIRS_OK;
 }
+
+#ifdef CIRS_MASS_PROF
+extern "C" int cirs_debug_mass_prof(unsigned long long* out_host32) {
+    return hipMemcpyFromSymbol(out_host32, HIP_SYMBOL(cirs::g_mass_prof), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -17,7 +17,7 @@
 #include <hip/hip_runtime.h>
 #ifdef CIRS_TRK_PROF
 // probe builds: sub-stage stamps inside the sampler's pick (slots 20..), see CIRS_STAMP below
-namespace cirs { extern __device__ unsigned long long g_trk_prof[32]; }
+namespace cirs { extern __device__ unsigned long long g_trk_prof[64]; }
 #define CIRS_PICK_STAMP(K) do { if (blockIdx.x == 0 && threadIdx.x == 0) cirs::g_trk_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
 #endif
 #include "internal.h"
@@ -98,7 +98,7 @@ __device__ __forceinline__ RowRegs<K> wrow(const float* __restrict__ img, int of
 
 #ifdef CIRS_TRK_PROF
 // stage timestamps of workgroup 0 / wave 0 (probe builds only: tools/probes/trk_prof.py)
-__device__ unsigned long long g_trk_prof[32];
+__device__ unsigned long long g_trk_prof[64];
 #define CIRS_STAMP(K) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_trk_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CIRS_STAMP(K) do { } while (0)
@@ -119,18 +119,9 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wv;
     CIRS_STAMP(0);
-    {   // the ~1.1 KB of by-value arguments are read through the scalar cache, cold at every launch: the compiler fetches them
-        // piecemeal at first use (five to eight dependent round trips before the first vector load goes out).  One dword of every
-        // 64-byte line of the kernarg segment, requested back to back, turns that into a single round trip.
-        typedef const uint32_t __attribute__((address_space(4))) * kernarg_words;
-        kernarg_words ka = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
-        uint32_t warm = 0;
-#pragma unroll
-        for (int o = 0; o < (int)((sizeof(cirs_tracker_cfg) + sizeof(cirs_tracker_weights) + sizeof(cirs_tracker_state) + sizeof(TrunkFuse) +
-                                   sizeof(TailFuse) + sizeof(TrkImg) + 96) / 4); o += 16)
-            warm ^= ka[o];
-        asm volatile("" ::"s"(warm));
-    }
+    // ~1.1 KB of by-value arguments: five to eight dependent scalar-cache misses before the first vector load otherwise (common.h)
+    kernarg_warm<sizeof(cirs_tracker_cfg) + sizeof(cirs_tracker_weights) + sizeof(cirs_tracker_state) + sizeof(TrunkFuse) + sizeof(TailFuse) +
+                 sizeof(TrkImg) + 96>();
     CIRS_STAMP(1);
     if (j >= n) return;
 // rows that do not step still owe the fused trunk its "skipped row" outputs
@@ -225,19 +216,23 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         // the env's own state (user, turn, history entry of this lane, running reward) does not depend on the action: its loads
         // are issued BEFORE the merge of the sampler partials and complete underneath it
         const int et = tl.env_base + j;    // this row's env (env groups: row 0 of the launch is env env_base)
+        CIRS_STAMP(32);
         const EnvPrefetch epf = env_prefetch(tl.cfg, tl.st, et, lane);
+        CIRS_STAMP(33);
         // sampler inputs of this row: same round trip as the env state
         MergePre mpre{};
         PickPre ppre{};
         if (tl.pick_on) ppre = actor_pick_prefetch(j, lane, tl.pick.n_pad, tl.pick.n_chunks, tl.pick.lmass, tl.pick.h2);
         else mpre = actor_merge_prefetch(j, lane, tl.n_pad, tl.n_chunks, tl.pv);
         pos = st.len[e];
+        CIRS_STAMP(34);
         CIRS_GATE_PREFETCH();
+        CIRS_STAMP(35);
         if (epf.done) {  // finished env: the policy skipped it
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
         } else if (tl.pick_on) {   // two-level draw: chunk, then item (per-wave LDS scratch: the feed-forward buffer, free here)
             float* stage = smem + (size_t)4 * (6 * kD + kHid + NHEAD * lpad) + (size_t)wv * kPickStage;   // after the four waves' scratch
-            // the (env, position) prefetch goes out right behind the pick's own row loads: it returns after them, under the item draw
+            // the (env, position) prefetch goes out when the pick's own rows have arrived, under the item draw's second half
             const Cand r = actor_pick_wave(tl.pick, j, et, lane, ffs, stage, &ppre, step_prefetch);
             act = r.bi == 0x7FFFFFFF ? -1 : (int64_t)r.bi;
             if (lane == 0) { tl.act_out[j] = act; tl.logp_out[j] = cand_logp(r); }
@@ -624,8 +619,8 @@ int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
 }  // namespace cirs
 
 #ifdef CIRS_TRK_PROF
-extern "C" int cirs_debug_trk_prof(unsigned long long* out_host32) {
-    return hipMemcpyFromSymbol(out_host32, HIP_SYMBOL(cirs::g_trk_prof), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+extern "C" int cirs_debug_trk_prof(unsigned long long* out_host64) {
+    return hipMemcpyFromSymbol(out_host64, HIP_SYMBOL(cirs::g_trk_prof), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }
 #endif
 

@@ -24,18 +24,18 @@ acc = None
 for rep in range(6):
     eng.collect()
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 64)()
     assert lib.cirs_debug_trk_prof(buf) == 0
     t = np.array(buf[:], dtype=np.float64)
     if rep >= 1:
         acc = t if acc is None else acc + t
 t = acc / 5
 prev = t[0]
-pick = {1: "kernel entry", 26: "prefetch issue + chunk Gumbels (2 Philox, 2 det_logf pairs)", 20: "chunk masses arrive, fold", 21: "chunk arg-max + log-sum-exp reduce", 22: "row loads issued, bias / visited",
-        23: "rows 0-63: LDS transpose, 64 fma, Gumbel", 24: "rows 64-127", 25: "item arg-max reduce", 2: "action / visited store"}
+pick = {1: "kernel entry", 32: "prologue (pointers, lambda set-up)", 33: "env prefetch issued", 34: "sampler prefetch + position issued", 35: "gate row issued", 26: "chunk Gumbels (2 Philox, 2 det_logf pairs)", 20: "chunk masses arrive, fold", 21: "chunk arg-max + log-sum-exp reduce", 36: "bias / visited / 32 row loads issued", 38: "2 item Gumbels", 22: "log-sum-exp reduce of the masses",
+        23: "rows 0-63: LDS transpose, 64 fma", 37: "rows 64-127 to LDS", 24: "caller's prefetch issued; 64 fma", 25: "item arg-max reduce", 2: "action / visited store"}
 if t[20] > 0:
     print("inside 'merge (tail)' = the sampler's pick (raw ticks):")
-    order = [1, 26, 20, 21, 22, 23, 24, 25, 2]
+    order = [1, 32, 33, 34, 35, 26, 20, 21, 36, 38, 22, 23, 37, 24, 25, 2]
     for a, b in zip(order[:-1], order[1:]):
         print(f"  {pick[b]:60s} {t[b] - t[a]:9.0f}")
 if t[27] > 0:
