@@ -22,6 +22,7 @@
 #include "policy_kernels.h"
 
 namespace cirs {
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: a float4 struct array goes through memcpy / scratch
 
 
 constexpr int kBwdWaves = 4;  // row tiles per workgroup of the fused head backward kernel (= rows/32 per dWa slab)
@@ -522,8 +523,10 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 // per-tile stage timestamps of workgroup (0, 0) / wave 0 at its third tile (probe builds only: tools/probes/head_prof.py)
 __device__ unsigned long long g_head_prof[32];
 #define CIRS_HSTAMP(K) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && it == 2) g_head_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CIRS_TSTAMP(B, K) do { if ((int)blockIdx.x == (B) && threadIdx.x == 0) g_head_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CIRS_HSTAMP(K) do { } while (0)
+#define CIRS_TSTAMP(B, K) do { } while (0)
 #endif
 
 __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
@@ -764,27 +767,38 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
 // the workgroup's sum of squares goes to partial_out (clip_grad_norm_ stage 1).  Runs as extra workgroups of the
 // trunk-backward launch: it only depends on the head backward kernel.
 constexpr int kNormBlocks = 256;   // workgroups of sumsq_partial_kernel = its slots of the norm partials
-constexpr int kWaSumBlocks = 128;  // slots [kNormBlocks, kNormBlocks + kWaSumBlocks) of the norm partials
+constexpr int kWaSumBlocks = 176;  // slots [kNormBlocks, kNormBlocks + kWaSumBlocks) of the norm partials
 __device__ __forceinline__ void wa_slab_sum_block(float* __restrict__ g, long wa_beg, long wa_len, const float* __restrict__ dwap,
                                                   long slab_stride, int n_slabs, int b, float* __restrict__ partial_out, float* sh) {
     const int tid = threadIdx.x;  // blockDim.x == 512
     float acc = 0.f;
     const long n4 = wa_len >> 2;
-    for (long q4 = b * 512L + tid; q4 < n4; q4 += (long)kWaSumBlocks * 512) {
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s0 = 0; s0 < n_slabs; s0 += 8) {
-            float4 t8[8];
+    // two float4 per thread and pass, all 2 x 8 slab loads in flight together; kWaSumBlocks x 1024 float4 cover wa|ba of the C3
+    // catalogue (174 k float4) in ONE pass = one memory round trip per workgroup
+    for (long q4 = b * 1024L + tid; q4 < n4; q4 += (long)kWaSumBlocks * 1024) {
+        const long q4b = q4 + 512;
+        const bool has_b = q4b < n4;
+        f32x4 ta[8], tb[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                t8[q] = (s0 + q < n_slabs) ? *reinterpret_cast<const float4*>(dwap + (size_t)(s0 + q) * slab_stride + 4 * q4)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { x.x += t8[q].x; x.y += t8[q].y; x.z += t8[q].z; x.w += t8[q].w; }
+        for (int q = 0; q < 8; ++q) {
+            ta[q] = q < n_slabs ? *reinterpret_cast<const f32x4*>(dwap + (size_t)q * slab_stride + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            tb[q] = (has_b && q < n_slabs) ? *reinterpret_cast<const f32x4*>(dwap + (size_t)q * slab_stride + 4 * q4b) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        *reinterpret_cast<float4*>(g + wa_beg + 4 * q4) = x;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { x += ta[q]; y += tb[q]; }
+        for (int s0 = 8; s0 < n_slabs; ++s0) {   // more than 8 row blocks (minibatches beyond 1024 rows): the rest, in slab order
+            x += *reinterpret_cast<const f32x4*>(dwap + (size_t)s0 * slab_stride + 4 * q4);
+            if (has_b) y += *reinterpret_cast<const f32x4*>(dwap + (size_t)s0 * slab_stride + 4 * q4b);
+        }
+        *reinterpret_cast<f32x4*>(g + wa_beg + 4 * q4) = x;
         acc += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        if (has_b) {
+            *reinterpret_cast<f32x4*>(g + wa_beg + 4 * q4b) = y;
+            acc += (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+        }
     }
-    const long wi = (n4 << 2) + b * 512L + tid;   // the (< 4) elements after the last whole float4
+    const long wi = (n4 << 2) + b * 512L + tid;   // the (< 4) elements after the last whole float4 (b = 0 covers them)
     if (wi < wa_len) {
         float x = 0.f;
         for (int s0 = 0; s0 < n_slabs; ++s0) x += dwap[(size_t)s0 * slab_stride + wi];
@@ -803,17 +817,28 @@ __device__ __forceinline__ void wa_slab_sum_block(float* __restrict__ g, long wa
 // one 32 x 32 tile of dW = dY^T X (+ the bias column sum of dY when k0 == 0) over the 32 rows of a trunk-backward workgroup:
 // A = dY from its LDS copy (sY[row][o]), B = X rows from global memory; written as this workgroup's row slab of the job
 // (partial layout of dw_multi_final / dw_multi_fetch: out[o * (K + 1) + k], k == K the bias column)
-__device__ __forceinline__ void dw_tile_32rows(const float* sY, const float* __restrict__ X, int ldx, int K, int row0, int n_rows, int o0,
-                                               int k0, float* __restrict__ out, int lane) {
+// B operand (the X rows) of a dw_tile_32rows tile: depends on nothing computed in the kernel, so a caller requests it at kernel entry
+__device__ __forceinline__ void dw_tile_load_x(const float* __restrict__ X, int ldx, int K, int row0, int n_rows, int k0, int lane, float (&b)[16]) {
+    const int hi = lane >> 5, k = k0 + (lane & 31);
+    const bool k_ok = k < K;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        b[j] = (k_ok && row0 + 2 * j + hi < n_rows) ? X[(size_t)(row0 + 2 * j + hi) * ldx + k] : 0.f;  // rows beyond the minibatch: dY = 0
+}
+// the same operand from an LDS copy of the tile's X rows (sX[row][k], row stride ldx)
+__device__ __forceinline__ void dw_tile_x_lds(const float* sX, int ldx, int K, int row0, int n_rows, int k0, int lane, float (&b)[16]) {
+    const int hi = lane >> 5, k = k0 + (lane & 31);
+    const bool k_ok = k < K;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) b[j] = (k_ok && row0 + 2 * j + hi < n_rows) ? sX[(2 * j + hi) * ldx + k] : 0.f;
+}
+__device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)[16], int K, int o0, int k0, float* __restrict__ out, int lane) {
     const int hi = lane >> 5, lo = lane & 31;
     const int o = o0 + lo, k = k0 + lo;
     const bool k_ok = k < K;
-    float a[16], b[16];
+    float a[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        a[j] = sY[(2 * j + hi) * kLdsStride + o];
-        b[j] = (k_ok && row0 + 2 * j + hi < n_rows) ? X[(size_t)(row0 + 2 * j + hi) * ldx + k] : 0.f;  // rows beyond the minibatch: dY = 0
-    }
+    for (int j = 0; j < 16; ++j) a[j] = sY[(2 * j + hi) * kLdsStride + o];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -845,23 +870,42 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
                                                         long slab_stride, int n_slabs, DwJobs jobs, float* __restrict__ dwp) {
     __shared__ __attribute__((aligned(16))) float sA[kTileM * kLdsStride];
     __shared__ __attribute__((aligned(16))) float sD[kTileM * kLdsStride];
+    __shared__ __attribute__((aligned(16))) float sW2[kH * kLdsStride];        // W2 [k][n]
+    __shared__ __attribute__((aligned(16))) float sH1[kTileM * kLdsStride];    // h1 rows of the tile
+    __shared__ __attribute__((aligned(16))) float sH2[kTileM * kLdsStride];    // h2 rows of the tile
+    __shared__ float sW1[kH * 32];                                             // W1 [k][S], S <= 32
+    __shared__ float sObs[kTileM * 32];                                        // obs rows of the tile [32][S]
+    __shared__ float sDv[kTileM];
+    CIRS_TSTAMP(0, 16);
+    CIRS_TSTAMP(n_pad / kTileM, 24);
     if ((int)blockIdx.x >= n_pad / kTileM) {   // extra workgroups (single-rank path): slab sums of the wa|ba gradient
         const int b = (int)blockIdx.x - n_pad / kTileM;
         wa_slab_sum_block(g, wa_beg, wa_len, v.dwap, slab_stride, n_slabs, b, v.normp + kNormBlocks + b, sA);
+        CIRS_TSTAMP(n_pad / kTileM, 25);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = blockIdx.x * kTileM;
-    // B operands of the two MFMA stages do not depend on stage 1: issue their loads first (waves 0,1: W2; wave 2: W1)
-    float bcol[32];
-#pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-        float t = 0.f;
-        if (wv < 2) t = w2[(size_t)(hi * 32 + kk) * kH + wv * 32 + lo];
-        else if (wv == 2 && dobs_accum && lo < S) t = w1[(size_t)(hi * 32 + kk) * S + lo];
-        bcol[kk] = t;
+    // Everything the later stages read besides stage 1's own result -- W2, W1, the h1 / h2 / obs rows of the tile, dvalue -- depends on
+    // nothing computed here.  A wavefront's memory instruction costs the CU's address unit ~16 cycles whatever its width, and eight
+    // wavefronts share that unit: per-lane operand loads (32 + 16 dwords per lane, 64 more for the critic row) took longer to ISSUE
+    // than the 31 slab loads below.  So: whole tiles with coalesced 16-byte loads (one or two per thread) into LDS, operands from there.
+    const int f_rl = tid >> 4, f_c4 = (tid & 15) * 4;          // this thread's float4 of a 32 x 64 tile
+    f32x4 w2a, w2b;                                                                        // W2 [64][64]: float4 tid and tid + 512
+    if ((reinterpret_cast<uintptr_t>(w2) & 15) == 0) {
+        w2a = *reinterpret_cast<const f32x4*>(w2 + (size_t)tid * 4);
+        w2b = *reinterpret_cast<const f32x4*>(w2 + (size_t)(tid + 512) * 4);
+    } else {   // a caller's weight pointer need not be 16-byte aligned
+        const float* pa = w2 + (size_t)tid * 4; const float* pb = w2 + (size_t)(tid + 512) * 4;
+        w2a = f32x4{pa[0], pa[1], pa[2], pa[3]}; w2b = f32x4{pb[0], pb[1], pb[2], pb[3]};
     }
+    const f32x4 h1t = *reinterpret_cast<const f32x4*>(v.h1 + (size_t)(row0 + f_rl) * kH + f_c4);
+    float w1t[4], obt[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w1t[q] = (dobs_accum && tid + 512 * q < kH * S) ? w1[tid + 512 * q] : 0.f;   // W1 [64][S], S <= 32
+#pragma unroll
+    for (int q = 0; q < 2; ++q) obt[q] = (dwp && tid + 512 * q < kTileM * S) ? v.obs[(size_t)row0 * S + tid + 512 * q] : 0.f;
     {
         const int f = tid;  // one float4 column group of the 32 x 64 tile per thread
         const int rl = f >> 4, c4 = (f & 15) * 4;
@@ -869,13 +913,13 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* src = v.dh2p + (size_t)r * kH + c4;
         const size_t cstride = (size_t)n_pad * kH;
-        for (int c0 = 0; c0 < n_chunks; c0 += 16) {  // 16 loads in flight, added in chunk order
-            float4 t16[16];
+        for (int c0 = 0; c0 < n_chunks; c0 += 32) {  // 32 loads in flight (C3: all 31 chunk slabs in ONE round trip), added in chunk order
+            f32x4 t32[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                t16[u] = (c0 + u < n_chunks) ? *reinterpret_cast<const float4*>(src + (size_t)(c0 + u) * cstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < 32; ++u)
+                t32[u] = (c0 + u < n_chunks) ? *reinterpret_cast<const f32x4*>(src + (size_t)(c0 + u) * cstride) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { acc.x += t16[u].x; acc.y += t16[u].y; acc.z += t16[u].z; acc.w += t16[u].w; }
+            for (int u = 0; u < 32; ++u) { acc.x += t32[u].x; acc.y += t32[u].y; acc.z += t32[u].z; acc.w += t32[u].w; }
         }
         const float dv = v.dvalue[r];
         const float4 wc4 = *reinterpret_cast<const float4*>(wc + c4);
@@ -888,20 +932,31 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
         t.w = (ok && h4.w > 0.f) ? __builtin_fmaf(dv, wc4.w, acc.w) : 0.f;
         *reinterpret_cast<float4*>(v.da2 + (size_t)r * kH + c4) = t;
         *reinterpret_cast<float4*>(&sA[rl * kLdsStride + c4]) = t;
+        *reinterpret_cast<float4*>(&sH2[rl * kLdsStride + c4]) = h4;
+        if ((f & 15) == 0) sDv[rl] = ok ? dv : 0.f;
     }
+    *reinterpret_cast<f32x4*>(&sW2[(tid >> 4) * kLdsStride + f_c4]) = w2a;
+    *reinterpret_cast<f32x4*>(&sW2[((tid + 512) >> 4) * kLdsStride + f_c4]) = w2b;
+    *reinterpret_cast<f32x4*>(&sH1[f_rl * kLdsStride + f_c4]) = h1t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (tid + 512 * q < kH * S) sW1[tid + 512 * q] = w1t[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) if (tid + 512 * q < kTileM * S) sObs[tid + 512 * q] = obt[q];
+    CIRS_TSTAMP(0, 17);
     if (wv == 7 && lane < kTileM) {
         const int r = row0 + lane;
         float e = 0.f;
-        for (int c0 = 0; c0 < n_chunks; c0 += 16) {
-            float t16[16];
+        for (int c0 = 0; c0 < n_chunks; c0 += 32) {
+            float t32[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t16[u] = (c0 + u < n_chunks) ? v.entp[(size_t)(c0 + u) * n_pad + r] : 0.f;
+            for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_chunks) ? v.entp[(size_t)(c0 + u) * n_pad + r] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) e += t16[u];
+            for (int u = 0; u < 32; ++u) e += t32[u];
         }
         v.ent_row[r] = r < mb ? v.h_ent[r] + e : 0.f;  // (lse - E_p[z]) + clamp correction
     }
     __syncthreads();
+    CIRS_TSTAMP(0, 18);
     if (wv < 2) {  // d a1 tile: columns wv*32 .. +32
         const int n = wv * 32 + lo;
         float arow[32];
@@ -910,6 +965,11 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
             const float4 t4 = *reinterpret_cast<const float4*>(&sA[lo * kLdsStride + hi * 32 + 4 * q]);
             arow[4 * q] = t4.x; arow[4 * q + 1] = t4.y; arow[4 * q + 2] = t4.z; arow[4 * q + 3] = t4.w;
         }
+        float bcol[32], h1g[16];    // W2 column n, the relu gate's h1 values: from the LDS tiles
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) bcol[kk] = sW2[(hi * 32 + kk) * kLdsStride + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1g[r] = sH1[((r & 3) + 8 * (r >> 2) + 4 * hi) * kLdsStride + n];
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -919,27 +979,40 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
         for (int r = 0; r < 16; ++r) {
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * hi;
             const size_t o = (size_t)(row0 + rl) * kH + n;
-            const float d = v.h1[o] > 0.f ? acc[r] : 0.f;
+            const float d = h1g[r] > 0.f ? acc[r] : 0.f;
             v.da1[o] = d;
             sD[rl * kLdsStride + n] = d;
         }
     } else if (dwp && wv < 6) {  // d W2 | d b2 row slab of this workgroup: four 32 x 32 tiles, waves 2..5
         const int t = wv - 2;
-        dw_tile_32rows(sA, v.h1, kH, kH, row0, mb, (t >> 1) * 32, (t & 1) * 32, dwp + jobs.j[1].part_off + (size_t)blockIdx.x * (kH * (kH + 1)), lane);
+        float xrow[16];
+        dw_tile_x_lds(sH1, kLdsStride, kH, row0, mb, (t & 1) * 32, lane, xrow);
+        dw_tile_32rows(sA, xrow, kH, (t >> 1) * 32, (t & 1) * 32, dwp + jobs.j[1].part_off + (size_t)blockIdx.x * (kH * (kH + 1)), lane);
     } else if (dwp && wv == 6) {  // d wc | d bc row slab: lane = column of h2
         float acc = 0.f, bs = 0.f;
-        for (int r = 0; r < kTileM && row0 + r < mb; ++r) {
-            const float dv = v.dvalue[row0 + r];
-            acc = __builtin_fmaf(dv, v.h2[(size_t)(row0 + r) * kH + lane], acc);
-            bs += dv;
+        float dv32[kTileM], h32[kTileM];    // from the LDS tiles (dvalue is 0 there for rows beyond the minibatch)
+#pragma unroll
+        for (int r = 0; r < kTileM; ++r) { dv32[r] = sDv[r]; h32[r] = sH2[r * kLdsStride + lane]; }
+#pragma unroll
+        for (int r = 0; r < kTileM; ++r) {
+            if (row0 + r < mb) {
+                acc = __builtin_fmaf(dv32[r], h32[r], acc);
+                bs += dv32[r];
+            }
         }
         float* out = dwp + jobs.j[0].part_off + (size_t)blockIdx.x * (kH + 1);
         out[lane] = acc;
         if (lane == 0) out[kH] = bs;
     }
+    CIRS_TSTAMP(0, 19);
     __syncthreads();
-    if (dwp && wv < 2)   // d W1 | d b1 row slab: two 32 x 32 tiles (S <= 32 columns), waves 0, 1
-        dw_tile_32rows(sD, v.obs, S, S, row0, mb, wv * 32, 0, dwp + jobs.j[2].part_off + (size_t)blockIdx.x * (kH * (S + 1)), lane);
+    CIRS_TSTAMP(0, 20);
+    if (dwp && wv < 2) {  // d W1 | d b1 row slab: two 32 x 32 tiles (S <= 32 columns), waves 0, 1
+        float xrow[16];
+        dw_tile_x_lds(sObs, S, S, row0, mb, 0, lane, xrow);
+        dw_tile_32rows(sD, xrow, S, wv * 32, 0, dwp + jobs.j[2].part_off + (size_t)blockIdx.x * (kH * (S + 1)), lane);
+    }
+    CIRS_TSTAMP(0, 21);
     if (!dobs_accum) return;
     if (wv == 2) {
         float arow[32];
@@ -948,6 +1021,9 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
             const float4 t4 = *reinterpret_cast<const float4*>(&sD[lo * kLdsStride + hi * 32 + 4 * q]);
             arow[4 * q] = t4.x; arow[4 * q + 1] = t4.y; arow[4 * q + 2] = t4.z; arow[4 * q + 3] = t4.w;
         }
+        float bcol[32];   // W1 column lo
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) bcol[kk] = lo < S ? sW1[(hi * 32 + kk) * S + lo] : 0.f;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -997,7 +1073,10 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
             else if (e < (long)kH * S + kH + (long)kH * kH) { const int r = (int)(e - ((long)kH * S + kH)); ji = 1; q = (r / kH) * (kH + 1) + (r % kH); }
             else if (e < n_trunk) { ji = 1; q = (int)(e - ((long)kH * S + kH + (long)kH * kH)) * (kH + 1) + kH; }
             else { ji = 0; q = (int)(e - n_trunk); }  // wc[0..63] then bc: row 0 of a [1, 64 + 1] problem
-            const float x = dw_multi_fetch(jobs.j[ji], n_dw_slabs, dw_partial, q);
+            // (a per-thread index into the by-value job table would send the whole table through scratch memory: select the two fields)
+            const int n_out = ji == 2 ? jobs.j[2].O * (jobs.j[2].K + 1) : ji == 1 ? jobs.j[1].O * (jobs.j[1].K + 1) : jobs.j[0].O * (jobs.j[0].K + 1);
+            const int p_off = ji == 2 ? jobs.j[2].part_off : ji == 1 ? jobs.j[1].part_off : jobs.j[0].part_off;
+            const float x = dw_multi_fetch(n_out, p_off, n_dw_slabs, dw_partial, q);
             g[i] = x;
             acc += (e < n_trunk ? 2.0f : 1.0f) * x * x;
         }

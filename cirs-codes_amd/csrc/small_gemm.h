@@ -177,17 +177,19 @@ constexpr int kMaxDwJobs = 4;
 struct DwJobs { DwJob j[kMaxDwJobs]; int n; int total_tiles; int total_out; };
 
 // sum of the slab partials of flat output element i of job jb (fixed slab order); device-side twin of dw_multi_final
-__device__ __forceinline__ float dw_multi_fetch(const DwJob& jb, int n_slabs, const float* __restrict__ partial, int i) {
-    const int n_out = jb.O * (jb.K + 1);
+__device__ __forceinline__ float dw_multi_fetch(int n_out, int part_off, int n_slabs, const float* __restrict__ partial, int i) {
     float acc = 0.f;
-    for (int c0 = 0; c0 < n_slabs; c0 += 16) {  // all loads of a batch in flight, added in slab order
-        float t16[16];
+    for (int c0 = 0; c0 < n_slabs; c0 += 32) {  // all loads of a batch in flight (a 1024-row minibatch: its 32 slabs in one round trip), added in slab order
+        float t32[32];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t16[q] = (c0 + q < n_slabs) ? partial[jb.part_off + (size_t)(c0 + q) * n_out + i] : 0.f;
+        for (int q = 0; q < 32; ++q) t32[q] = (c0 + q < n_slabs) ? partial[part_off + (size_t)(c0 + q) * n_out + i] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc += t16[q];
+        for (int q = 0; q < 32; ++q) acc += t32[q];
     }
     return acc;
+}
+__device__ __forceinline__ float dw_multi_fetch(const DwJob& jb, int n_slabs, const float* __restrict__ partial, int i) {
+    return dw_multi_fetch(jb.O * (jb.K + 1), jb.part_off, n_slabs, partial, i);
 }
 
 static __global__ __launch_bounds__(256) void dw_multi_final(DwJobs jobs, int n_slabs, const float* __restrict__ partial) {

@@ -35,3 +35,12 @@ print("head_bwd_fused_kernel, workgroup (0,0) wave 0, third tile (raw s_memtime 
 for k in sorted(names):
     print(f"  {names[k]:36s} {t[k] - prev:9.0f}   (cum {t[k] - t[0]:9.0f})")
     prev = t[k]
+
+tb = {16: "row workgroup 0: entry", 17: "W2/W1 columns requested, 31 dh2 slabs summed, da2 written", 18: "barrier", 19: "da1 tile (32 MFMAs), relu gate, stores", 20: "barrier",
+      21: "dW1 tile (wave 0)"}
+print("trunk_bwd_kernel (raw ticks; the stamps of thread 0 = wave 0):")
+prev = t[16]
+for k in sorted(tb):
+    print(f"  {tb[k]:64s} {t[k] - prev:9.0f}   (cum {t[k] - t[16]:9.0f})")
+    prev = t[k]
+print(f"  first wa|ba slab-sum workgroup: entry at {t[24] - t[16]:+.0f} relative to row workgroup 0, its sums + reduction take {t[25] - t[24]:.0f}")
