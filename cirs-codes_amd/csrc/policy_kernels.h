@@ -43,21 +43,26 @@ __host__ __device__ inline ActorPartialView partial_view(void* ws, int n, int n_
 // ---- trunk: one wave per row ---------------------------------------------------------------------------------
 // trunk on one row whose input already sits in LDS (xs[0..S)): h1 = relu(W1 x + b1), h2 = relu(W2 h1 + b2),
 // value = wc . h2 + bc.  Sequential-k fmaf chains (the order the oracle restates); lane o owns output feature o.
+// LDS copies of the weights (optional; a workgroup that runs several rows stages them once with coalesced loads -- a lane reading
+// its own 256-byte row of W2 from memory costs 64 cache lines per load instruction): lw1 [64][ld1] (ld1 odd), lw2 [64][kLdsRow2],
+// lwc [64].  Same fma chains either way.
+constexpr int kLdsRow2 = kH + 4;
 __device__ __forceinline__ void trunk_compute(const cirs_policy_cfg& cfg, const cirs_policy_weights& w, float* xs, float* hs, int lane,
                                               int j, float* __restrict__ h2_out, float* __restrict__ value_out,
-                                              float* __restrict__ h1_out) {
+                                              float* __restrict__ h1_out, const float* lw1 = nullptr, int ld1 = 0,
+                                              const float* lw2 = nullptr, const float* lwc = nullptr) {
     const int S = cfg.dim_state;
     __builtin_amdgcn_wave_barrier();
     // layer 1: lane o, chain over k = 0..S-1 starting from the bias
     float acc = w.b1[lane];
-    const float* w1r = w.w1 + (size_t)lane * S;
+    const float* w1r = lw1 ? lw1 + lane * ld1 : w.w1 + (size_t)lane * S;
     for (int k = 0; k < S; ++k) acc = __builtin_fmaf(w1r[k], xs[k], acc);
     hs[lane] = fmaxf(acc, 0.f);
     if (h1_out) h1_out[(size_t)j * kH + lane] = hs[lane];
     __builtin_amdgcn_wave_barrier();
     // layer 2
     acc = w.b2[lane];
-    const float4* w2r = reinterpret_cast<const float4*>(w.w2 + (size_t)lane * kH);
+    const float4* w2r = lw2 ? reinterpret_cast<const float4*>(lw2 + lane * kLdsRow2) : reinterpret_cast<const float4*>(w.w2 + (size_t)lane * kH);
 #pragma unroll
     for (int k4 = 0; k4 < kH / 4; ++k4) {
         const float4 wv4 = w2r[k4];
@@ -73,7 +78,8 @@ __device__ __forceinline__ void trunk_compute(const cirs_policy_cfg& cfg, const 
     __builtin_amdgcn_wave_barrier();
     if (lane == 0 && value_out) {  // critic: sequential chain (bit-reproducible), 64 fma
         float v = w.bc[0];
-        for (int k = 0; k < kH; ++k) v = __builtin_fmaf(w.wc[k], xs[k], v);
+        const float* wcr = lwc ? lwc : w.wc;
+        for (int k = 0; k < kH; ++k) v = __builtin_fmaf(wcr[k], xs[k], v);
         value_out[j] = v;
     }
 }
@@ -85,7 +91,8 @@ __device__ __forceinline__ void trunk_rows(const cirs_policy_cfg& cfg, const cir
                                            const uint8_t* __restrict__ skip, float* __restrict__ h2_out,
                                            float* __restrict__ value_out, float* __restrict__ h1_out,
                                            const int32_t* __restrict__ row_index, int n_valid, float* __restrict__ obs_copy,
-                                           float (*lds)[2][kH]) {
+                                           float (*lds)[2][kH], const float* lw1 = nullptr, int ld1 = 0, const float* lw2 = nullptr,
+                                           const float* lwc = nullptr) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wv;
     if (j >= n) return;
@@ -108,7 +115,7 @@ __device__ __forceinline__ void trunk_rows(const cirs_policy_cfg& cfg, const cir
     } else if (lane < S) {
         xs[lane] = state[(size_t)j * state_stride + lane];
     }
-    trunk_compute(cfg, w, xs, hs, lane, j, h2_out, value_out, h1_out);
+    trunk_compute(cfg, w, xs, hs, lane, j, h2_out, value_out, h1_out, lw1, ld1, lw2, lwc);
 }
 
 static __global__ __launch_bounds__(256) void trunk_kernel(cirs_policy_cfg cfg, cirs_policy_weights w,

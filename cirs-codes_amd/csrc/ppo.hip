@@ -378,8 +378,45 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
         adv_stats_block(adv_flat, sidx, m_stats, enable, red, lds_raw);
         return;
     }
-    trunk_rows(cfg, w, obs_flat, stride, n_pad, nullptr, h2_out, value_out, h1_out, idx, mb, obs_copy,
-               reinterpret_cast<float (*)[2][kH]>(lds_raw));
+    // the four rows of this workgroup share the trunk weights: staged once, coalesced (W2 as float4 rows, W1 / wc as dwords), while
+    // the row's own gather (idx -> obs row) is on its way
+    __shared__ __attribute__((aligned(16))) float sW2[kH * kLdsRow2];
+    __shared__ float sW1[kH * 33];
+    __shared__ float sWc[kH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, S = cfg.dim_state;
+    const int j = blockIdx.x * 4 + wv;                     // < n_pad: the grid has n_pad / 4 row workgroups
+    const int ri = idx[j];
+    const int ld1 = S | 1;     // odd row stride: lane o reads sW1[o * ld1 + k] without bank conflicts
+    const bool al16 = (reinterpret_cast<uintptr_t>(w.w2) & 15) == 0;
+    f32x4 t2[4];
+    float t1[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* p = w.w2 + (size_t)(tid + 256 * q) * 4;
+        t2[q] = al16 ? *reinterpret_cast<const f32x4*>(p) : f32x4{p[0], p[1], p[2], p[3]};
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t1[q] = tid + 256 * q < kH * S ? w.w1[tid + 256 * q] : 0.f;
+    const float tc = tid < kH ? w.wc[tid] : 0.f;
+    const float x = (j < mb && lane < S) ? obs_flat[(size_t)ri * stride + lane] : 0.f;    // rows >= mb: zeros (as trunk_rows)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i4 = tid + 256 * q;
+        *reinterpret_cast<f32x4*>(&sW2[(i4 >> 4) * kLdsRow2 + (i4 & 15) * 4]) = t2[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = tid + 256 * q;
+        if (i < kH * S) sW1[(i / S) * ld1 + (i % S)] = t1[q];
+    }
+    if (tid < kH) sWc[tid] = tc;
+    float (*rows)[2][kH] = reinterpret_cast<float (*)[2][kH]>(lds_raw);
+    if (lane < S) {
+        rows[wv][0][lane] = x;
+        obs_copy[(size_t)j * S + lane] = x;
+    }
+    __syncthreads();
+    trunk_compute(cfg, w, rows[wv][0], rows[wv][1], lane, j, h2_out, value_out, h1_out, sW1, ld1, sW2, sWc);
 }
 
 constexpr int kTStride = 36;                 // transpose buffer row stride (floats): 16 B aligned, conflict-free b128 reads
