@@ -179,11 +179,24 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 
     // B operand: this lane's env row of H2, k = hi*32 + kk
     float hrow[32];
-    if (wave_live && jr < n) {
-        const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)jr * kH + hi * 32);
+    if (wave_live) {
+        // the wave's 32 x 64 tile of hidden rows is 8 KB of consecutive memory: read coalesced (8 x 1 KB), handed to the lanes through LDS
+        __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];
+        typedef float mass_v4 __attribute__((ext_vector_type(4)));
+        mass_v4* st4 = reinterpret_cast<mass_v4*>(sH[wv]);
+        mass_v4 t8[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float4 v = src[q];
+            const int r = row0 + 4 * q + (lane >> 4);
+            t8[q] = r < n ? *reinterpret_cast<const mass_v4*>(h2 + (size_t)r * kH + (lane & 15) * 4) : mass_v4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st4[(4 * q + (lane >> 4)) * (kLdsStride / 4) + (lane & 15)] = t8[q];
+        __builtin_amdgcn_wave_barrier();
+        const mass_v4* src = reinterpret_cast<const mass_v4*>(&sH[wv][lo * kLdsStride + hi * 32]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const mass_v4 v = src[q];
             hrow[4 * q + 0] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
         }
     } else {
@@ -379,11 +392,24 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
     const bool wave_live = __ballot(active) != 0ull;
     const int e = active ? (env_ids ? env_ids[jr] : env_base + jr) : 0;
     float hrow[32];
-    if (wave_live && jr < n) {
-        const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)jr * kH + hi * 32);
+    if (wave_live) {
+        // the wave's 32 x 64 tile of hidden rows is 8 KB of consecutive memory: read coalesced (8 x 1 KB), handed to the lanes through LDS
+        __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];
+        typedef float mass_v4 __attribute__((ext_vector_type(4)));
+        mass_v4* st4 = reinterpret_cast<mass_v4*>(sH[wv]);
+        mass_v4 t8[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float4 v = src[q];
+            const int r = row0 + 4 * q + (lane >> 4);
+            t8[q] = r < n ? *reinterpret_cast<const mass_v4*>(h2 + (size_t)r * kH + (lane & 15) * 4) : mass_v4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st4[(4 * q + (lane >> 4)) * (kLdsStride / 4) + (lane & 15)] = t8[q];
+        __builtin_amdgcn_wave_barrier();
+        const mass_v4* src = reinterpret_cast<const mass_v4*>(&sH[wv][lo * kLdsStride + hi * 32]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const mass_v4 v = src[q];
             hrow[4 * q + 0] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
         }
     } else {

@@ -444,10 +444,23 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
     const bool active = jr < mb;
     Planes hz[4];  // B operand: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
     {
-        const float4* src = reinterpret_cast<const float4*>(h2 + (size_t)(active ? jr : 0) * kH + 8 * hi);
+        // the wave's 32 x 64 tile of H2 is 8 KB of consecutive memory: read coalesced (8 x 1 KB) and handed to the lanes through LDS
+        // (a lane reading its own 256-byte row costs 64 cache lines per load instruction, eight wavefronts per CU at once)
+        __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];
+        f32x4* st4 = reinterpret_cast<f32x4*>(sH[wv]);
+        f32x4 t8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = row0 + 4 * q + (lane >> 4);
+            t8[q] = *reinterpret_cast<const f32x4*>(h2 + (size_t)(r < mb ? r : 0) * kH + (lane & 15) * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st4[(4 * q + (lane >> 4)) * (kLdsStride / 4) + (lane & 15)] = t8[q];
+        __builtin_amdgcn_wave_barrier();
+        const f32x4* src = reinterpret_cast<const f32x4*>(&sH[wv][lo * kLdsStride + 8 * hi]);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const float4 p = src[4 * s4], q = src[4 * s4 + 1];
+            const f32x4 p = src[4 * s4], q = src[4 * s4 + 1];
             hz[s4] = split8(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
         }
     }
