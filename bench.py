@@ -327,11 +327,16 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    # test hook (tests/test_gpu_distributed.py on a 1-GPU box): every rank on device 0, collectives through gloo -- the same
+    # multi-process engine path (env sharding, packed all-gather, per-minibatch all-reduce) without a second GPU
+    share_gpu = os.environ.get("CIRS_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+        dist.init_process_group("gloo" if share_gpu else "nccl", rank=rank, world_size=world)  # nccl = RCCL over xGMI
 
     eng, tab = build_engine(wl, rank, world, device)
 

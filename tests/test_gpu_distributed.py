@@ -159,3 +159,24 @@ def test_two_process_rccl_bench_ranks_stay_bit_identical(nproc):
     assert z["n_gpus"] == nproc and z["config"]["envs_total"] == 1024 * nproc and z["scaling"] == "weak"
     assert z["rank_parameters_bit_identical"] is True
     assert z["value"] > 0 and z["steps"] == 3
+
+
+def test_two_process_bench_on_one_gpu_ranks_stay_bit_identical():
+    """The same launch as above on a box with ONE GPU: both ranks on device 0 (CIRS_BENCH_SHARE_GPU=1), collectives through gloo on
+    device tensors.  Everything but the transport is the N > 1 path of the driver's SCALE run: env sharding, the packed
+    all-gather of the trajectory, the data-parallel learner's per-minibatch all-reduce, rank-identity of the parameters."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + os.getpid() % 150
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CIRS_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-probes"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    z = json.loads(line)
+    assert z["n_gpus"] == 2 and z["config"]["envs_total"] == 2048 and z["scaling"] == "weak"
+    assert z["rank_parameters_bit_identical"] is True
+    assert z["value"] > 0 and z["steps"] == 2
