@@ -84,6 +84,12 @@ def test_rollout_c3_shapes():
     assert lengths.min() < lengths.max()
 
 
+def test_rollout_more_envs_than_one_wave_per_simd():
+    """2309 envs (not a multiple of anything): two step-kernel workgroups per CU, seven chunks per mass-kernel workgroup, ragged last
+    row block -- the launch geometries the 1024-env benchmark shape never takes."""
+    check_rollout(7176, 10728, 2309, 8, seed=13)
+
+
 def test_rollout_early_stop_polling_is_equivalent():
     a = check_rollout(200, 400, 40, 30, seed=9, N=4, thr=2, sync_every=4)
     b = check_rollout(200, 400, 40, 30, seed=9, N=4, thr=2)
