@@ -914,6 +914,42 @@ __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)
 //   d a1 = (d a2 * W2) * relu'(h1)                                  waves 0,1: one 32 x 32 MFMA tile each, A from LDS
 //   d obs = d a1 * W1  -> scattered to the [T+1,B,S] tracker-gradient tensor at dst_row (wave 2, only when requested)
 // d a2 / d a1 are also written to global memory for the weight-gradient GEMMs.
+// ---- chunk-slab sums of d h2 and of the entropy partials, on EVERY CU ------------------------------------------------------------
+// head_bwd_fused_kernel leaves one [n_pad, 64] slab of d h2 per item chunk (31 at C3: 8 MB).  Summed inside the trunk-backward
+// kernel that was 254 KB per workgroup through 32 CUs -- and one CU pulls only ~30-60 GB/s from far memory: 6-8 us of that kernel.
+// Here one wavefront per 64 float4: 256 workgroups, 32 KB each, all slabs of an element in flight at once, added in chunk order
+// (the order the trunk-backward kernel used); the sum replaces slab 0.  The last n_pad / 64 workgroups do the same for the
+// entropy partials (one float per row and chunk) and finish ent_row.
+__global__ __launch_bounds__(64) void dh2_sum_kernel(int mb, int n_pad, int n_chunks, MbView v) {
+    const int n_f4_wgs = n_pad * (kH / 4) / 64;
+    if ((int)blockIdx.x < n_f4_wgs) {
+        const size_t q4 = (size_t)blockIdx.x * 64 + threadIdx.x;
+        float* p = v.dh2p + q4 * 4;
+        const size_t cstride = (size_t)n_pad * kH;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < n_chunks; c0 += 32) {
+            f32x4 t32[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_chunks) ? *reinterpret_cast<const f32x4*>(p + (size_t)(c0 + u) * cstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += t32[u];
+        }
+        *reinterpret_cast<f32x4*>(p) = acc;
+        return;
+    }
+    const int r = ((int)blockIdx.x - n_f4_wgs) * 64 + threadIdx.x;
+    if (r >= n_pad) return;
+    float e = 0.f;
+    for (int c0 = 0; c0 < n_chunks; c0 += 32) {
+        float t32[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_chunks) ? v.entp[(size_t)(c0 + u) * n_pad + r] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) e += t32[u];
+    }
+    v.ent_row[r] = r < mb ? v.h_ent[r] + e : 0.f;  // (lse - E_p[z]) + clamp correction
+}
+
 __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n_chunks, int S, const float* __restrict__ w1,
                                                         const float* __restrict__ w2, const float* __restrict__ wc, MbView v,
                                                         float* __restrict__ dobs_accum, float* __restrict__ g, long wa_beg, long wa_len,
@@ -962,14 +998,9 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
         const int r = row0 + rl;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* src = v.dh2p + (size_t)r * kH + c4;
-        const size_t cstride = (size_t)n_pad * kH;
-        for (int c0 = 0; c0 < n_chunks; c0 += 32) {  // 32 loads in flight (C3: all 31 chunk slabs in ONE round trip), added in chunk order
-            f32x4 t32[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u)
-                t32[u] = (c0 + u < n_chunks) ? *reinterpret_cast<const f32x4*>(src + (size_t)(c0 + u) * cstride) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 32; ++u) { acc.x += t32[u].x; acc.y += t32[u].y; acc.z += t32[u].z; acc.w += t32[u].w; }
+        {   // slab 0 holds the sum over the item chunks (dh2_sum_kernel)
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+            acc.x = t.x; acc.y = t.y; acc.z = t.z; acc.w = t.w;
         }
         const float dv = v.dvalue[r];
         const float4 wc4 = *reinterpret_cast<const float4*>(wc + c4);
@@ -993,18 +1024,6 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
 #pragma unroll
     for (int q = 0; q < 2; ++q) if (tid + 512 * q < kTileM * S) sObs[tid + 512 * q] = obt[q];
     CIRS_TSTAMP(0, 17);
-    if (wv == 7 && lane < kTileM) {
-        const int r = row0 + lane;
-        float e = 0.f;
-        for (int c0 = 0; c0 < n_chunks; c0 += 32) {
-            float t32[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_chunks) ? v.entp[(size_t)(c0 + u) * n_pad + r] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 32; ++u) e += t32[u];
-        }
-        v.ent_row[r] = r < mb ? v.h_ent[r] + e : 0.f;  // (lse - E_p[z]) + clamp correction
-    }
     __syncthreads();
     CIRS_TSTAMP(0, 18);
     if (wv < 2) {  // d a1 tile: columns wv*32 .. +32
@@ -1380,6 +1399,8 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         dw_jobs = jobs;
         // (+ the slab sums of the wa|ba gradient as extra workgroups of the same launch: the flat gradient's wa|ba segment is
         // complete after this launch)
+        hipLaunchKernelGGL(dh2_sum_kernel, dim3(n_pad * (kH / 4) / 64 + cdiv(n_pad, 64)), dim3(64), 0, s, (int)mb, n_pad, n_bchunks, v);
+        CIRS_CHECK_LAUNCH("dh2_sum_kernel");
         hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM + kWaSumBlocks), dim3(512), 0, s, (int)mb, n_pad, n_bchunks, S,
                            w.w1, w.w2, w.wc, v, dobs_accum, grads, (long)L.wa, seg, (long)dwa_slab_stride(I), n_slabs, jobs, v.dwp);
         CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
