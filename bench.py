@@ -33,8 +33,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-MINIBATCH_KERNELS = ("trunk_adv_kernel", "head_stats_kernel", "head_stats_merge_kernel", "head_bwd_fused_kernel", "trunk_bwd_kernel",
-                     "sumsq_partial_kernel", "adam2_kernel")
+MINIBATCH_KERNELS = ("trunk_adv_kernel", "head_stats_kernel", "head_stats_merge_kernel", "head_bwd_fused_kernel", "dh2_sum_kernel",
+                     "trunk_bwd_kernel", "sumsq_partial_kernel", "adam2_kernel")
 
 
 def kernel_source_hash():
@@ -403,7 +403,7 @@ def main():
         t_bwd = t_k["head_bwd_fused_kernel"]
         flop_bwd = 4.0 * mb * I * H
         exec_bwd = 6.0 * mb * I * H
-        # whole minibatch step (7 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
+        # whole minibatch step (8 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
         flop_step = 6.0 * mb * (S * H + H * H + H * I)
         exec_step = 8.0 * mb * I * H + 6.0 * mb * (S * H + H * H)
         out = {
@@ -426,11 +426,11 @@ def main():
                          "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (cirs_prof_start/stop)",
                          "peak_note": "fp32 MFMA dense peak: the kernel's results are fp32-accurate (DESIGN.md section 4); its 6x expanded bf16 flops are exec_bf16_flop_per_launch",
                          "exec_bf16_flop_per_launch": 6.0 * exec_bwd},
-            "minibatch_step": {"seconds": t_mb, "launches": 7, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
+            "minibatch_step": {"seconds": t_mb, "launches": 8, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
                                "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "traffic": None,
                                "head_stats_kernel_seconds": t_k["head_stats_kernel"],
-                               "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel + 5 small kernels"},
+                               "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel + 6 small kernels"},
         }
         # HBM traffic per launch from the committed PMC passes -- only when they were taken on exactly these kernel sources
         traffic, src = pmc_traffic(args.workload)
@@ -438,7 +438,7 @@ def main():
         out["roofline"]["traffic_source"] = src
         out["minibatch_step"]["traffic"] = sum(traffic.get(k, 0) for k in MINIBATCH_KERNELS) if traffic and all(k in traffic for k in MINIBATCH_KERNELS) else None
         if traffic:
-            out["hbm_traffic_per_launch"] = {k: v for k, v in traffic.items() if k.split("<")[0] in ("actor_head_kernel", "tracker_step_kernel", "sweep_kernel", "gather_fm_kernel")}
+            out["hbm_traffic_per_launch"] = {k: v for k, v in traffic.items() if k.split("<")[0] in ("actor_head_kernel", "actor_mass_kernel", "tracker_step_kernel", "sweep_kernel", "gather_fm_kernel")}
         if world == 1 and not args.no_probes:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
             out["gather_fm"] = gather_fm_probe(device)
             out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)

@@ -63,7 +63,7 @@ def parse(fetch_csv, write_csv, tag):
             fh.write(f"| `{k}` | {v['launches']} | {v['fetch_kb']} | {v['write_kb']} | {v['bytes_per_launch'] / 1e6:.2f} |\n")
         mb = [kernels[k]["bytes_per_launch"] for k in bench.MINIBATCH_KERNELS if k in kernels]
         if len(mb) == len(bench.MINIBATCH_KERNELS):
-            fh.write(f"\nPPO minibatch step (7 kernels): **{sum(mb) / 1e6:.1f} MB**\n")
+            fh.write(f"\nPPO minibatch step ({len(mb)} kernels): **{sum(mb) / 1e6:.1f} MB**\n")
     print(open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_traffic.md")).read())
 
 
