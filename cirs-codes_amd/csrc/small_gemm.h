@@ -51,6 +51,21 @@ static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __res
             for (int j = 0; j < 16; ++j)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(row_ok ? a[j] : 0.f, n_ok ? bv[j] : 0.f, acc, 0, 0, 0);
         }
+    } else if (!kNT && (Kd & 31) == 0 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0) {
+        // NN form with the same relabelling of the contraction index: the lane's row of X as four float4 per 32 k (a dword per k costs
+        // the address unit 64 cache lines per instruction, four times as many instructions); W[k][n] stays one coalesced dword per k
+        for (int kk = 0; kk < Kd; kk += 32) {
+            float a[16], bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(xr + kk + 16 * hi + 4 * q);
+                a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bv[j] = n_ok ? W[(size_t)(kk + 16 * hi + j) * ldw + n] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(row_ok ? a[j] : 0.f, bv[j], acc, 0, 0, 0);
+        }
     } else {
         for (int kk = 0; kk < Kd; kk += 16) {  // 8 MFMA steps per batch: all 16 loads are issued before the first MFMA
             float a[8], bv[8];
@@ -108,17 +123,17 @@ static __global__ __launch_bounds__(64) void dw_gemm_kernel(const float* __restr
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
     float bsum = 0.f;
-    for (int r = r_beg; r < r_end; r += 32) {  // 16 MFMA steps (32 rows) per batch: 32 loads in flight, then the MFMAs
-        float a[16], b[16];
+    for (int r = r_beg; r < r_end; r += 64) {  // 32 MFMA steps (64 rows) per batch: 64 loads in flight, then the MFMAs (row order unchanged)
+        float a[32], b[32];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 32; ++j) {
             const int rr = r + 2 * j + hi;
             const bool r_ok = rr < r_end;
             a[j] = (r_ok && o_ok) ? dY[(size_t)rr * ldy + o] : 0.f;
             b[j] = (r_ok && k_ok) ? X[(size_t)rr * ldx + k] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 32; ++j) {
             bsum += a[j];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
         }

@@ -13,6 +13,7 @@
 #include "rng.h"
 
 namespace cirs {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int tD = 32, tH = 128;
 constexpr int kChunkRows = 256;
@@ -66,15 +67,30 @@ __global__ __launch_bounds__(256) void attn_fwd(const float* __restrict__ QKV, c
     float* ps = smem + (size_t)(threadIdx.x >> 6) * NH * Lp;
     const int p = row_t[r], base = offsets[row_env[r]];
     const float scale = 1.0f / sqrtf((float)HD);
+    // rows of QKV are 384 bytes (16-byte aligned): eight float4 loads per row instead of 32 dwords
     float q[tD];
+    {
+        const f32x4* q4 = reinterpret_cast<const f32x4*>(QKV + (size_t)r * 96);
 #pragma unroll
-    for (int d = 0; d < tD; ++d) q[d] = QKV[(size_t)r * 96 + d] * scale;
+        for (int d4 = 0; d4 < tD / 4; ++d4) {
+            const f32x4 t = q4[d4];
+            q[4 * d4] = t.x * scale; q[4 * d4 + 1] = t.y * scale; q[4 * d4 + 2] = t.z * scale; q[4 * d4 + 3] = t.w * scale;
+        }
+    }
     float mx[NH], sm[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) mx[h] = -INFINITY;
     float* Pr = P + (size_t)r * NH * Lp;
     for (int jp = lane; jp <= p; jp += CIRS_WAVE) {
-        const float* k = QKV + (size_t)(base + jp) * 96 + tD;
+        float k[tD];
+        {
+            const f32x4* k4 = reinterpret_cast<const f32x4*>(QKV + (size_t)(base + jp) * 96 + tD);
+#pragma unroll
+            for (int d4 = 0; d4 < tD / 4; ++d4) {
+                const f32x4 t = k4[d4];
+                k[4 * d4] = t.x; k[4 * d4 + 1] = t.y; k[4 * d4 + 2] = t.z; k[4 * d4 + 3] = t.w;
+            }
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             float sc = 0.f;
@@ -113,7 +129,15 @@ __global__ __launch_bounds__(256) void attn_fwd(const float* __restrict__ QKV, c
     __builtin_amdgcn_wave_barrier();
     const int half = lane >> 5, d = lane & 31, h = d / HD;
     float acc = 0.f;
-    for (int jp = half; jp <= p; jp += 2) acc = __builtin_fmaf(ps[h * Lp + jp], QKV[(size_t)(base + jp) * 96 + 2 * tD + d], acc);
+    // 8 value rows in flight per pass (a load per iteration inside the fma chain is one L2 round trip per key); same chain order
+    for (int j0 = half; j0 <= p; j0 += 16) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = j0 + 2 * u <= p ? QKV[(size_t)(base + j0 + 2 * u) * 96 + 2 * tD + d] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + 2 * u <= p) acc = __builtin_fmaf(ps[h * Lp + j0 + 2 * u], v8[u], acc);
+    }
     acc += __shfl_xor(acc, 32, CIRS_WAVE);
     if (lane < tD) ATT[(size_t)r * tD + d] = acc;
 }
@@ -132,15 +156,29 @@ __global__ __launch_bounds__(256) void attn_bwd_q(const float* __restrict__ QKV,
     const int p = row_t[r], base = offsets[row_env[r]];
     const float scale = 1.0f / sqrtf((float)HD);
     float da[tD];
+    {
+        const f32x4* a4 = reinterpret_cast<const f32x4*>(dATT + (size_t)r * tD);
 #pragma unroll
-    for (int d = 0; d < tD; ++d) da[d] = dATT[(size_t)r * tD + d];
+        for (int d4 = 0; d4 < tD / 4; ++d4) {
+            const f32x4 t = a4[d4];
+            da[4 * d4] = t.x; da[4 * d4 + 1] = t.y; da[4 * d4 + 2] = t.z; da[4 * d4 + 3] = t.w;
+        }
+    }
     const float* Pr = P + (size_t)r * NH * Lp;
     float* dSr = dS + (size_t)r * NH * Lp;
     float dot[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) dot[h] = 0.f;
     for (int jp = lane; jp <= p; jp += CIRS_WAVE) {
-        const float* v = QKV + (size_t)(base + jp) * 96 + 2 * tD;
+        float v[tD];
+        {
+            const f32x4* v4 = reinterpret_cast<const f32x4*>(QKV + (size_t)(base + jp) * 96 + 2 * tD);
+#pragma unroll
+            for (int d4 = 0; d4 < tD / 4; ++d4) {
+                const f32x4 t = v4[d4];
+                v[4 * d4] = t.x; v[4 * d4 + 1] = t.y; v[4 * d4 + 2] = t.z; v[4 * d4 + 3] = t.w;
+            }
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             float dp = 0.f;
@@ -170,7 +208,14 @@ __global__ __launch_bounds__(256) void attn_bwd_q(const float* __restrict__ QKV,
     // dQ[d] = scale * sum_j dS[h(d), j] * K[j, d]: lane = (half, d), the two halves take every second key (coalesced rows)
     const int half = lane >> 5, d = lane & (tD - 1), hd = d / HD;
     float acc = 0.f;
-    for (int jp = half; jp <= p; jp += 2) acc = __builtin_fmaf(sds[hd * Lp + jp], QKV[(size_t)(base + jp) * 96 + tD + d], acc);
+    for (int j0 = half; j0 <= p; j0 += 16) {   // 8 key rows in flight per pass, same chain order
+        float k8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k8[u] = j0 + 2 * u <= p ? QKV[(size_t)(base + j0 + 2 * u) * 96 + tD + d] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j0 + 2 * u <= p) acc = __builtin_fmaf(sds[hd * Lp + j0 + 2 * u], k8[u], acc);
+    }
     acc += __shfl_xor(acc, 32, CIRS_WAVE);
     if (lane < tD) dQKV[(size_t)r * 96 + d] = acc * scale;  // scores used q*scale
 }
@@ -196,14 +241,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(const float* __restrict__ QKV
     const float cs = which == 0 ? scale : 1.0f;
     float acc = 0.f;
     int p = pk;
-    for (; p + 4 <= len; p += 4) {   // 8 independent loads in flight
-        float c4[4], v4[4];
+    for (; p < len; p += 8) {   // 16 independent loads in flight per pass (predicated tail), same chain order
+        float c8[8], v8[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { c4[u] = coef[(size_t)(p + u) * cstride]; v4[u] = vec[(size_t)(p + u) * vstride]; }
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = p + u < len;
+            c8[u] = ok ? coef[(size_t)(p + u) * cstride] : 0.f;
+            v8[u] = ok ? vec[(size_t)(p + u) * vstride] : 0.f;
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(c4[u] * cs, v4[u], acc);
+        for (int u = 0; u < 8; ++u)
+            if (p + u < len) acc = __builtin_fmaf(c8[u] * cs, v8[u], acc);
     }
-    for (; p < len; ++p) acc = __builtin_fmaf(coef[(size_t)p * cstride] * cs, vec[(size_t)p * vstride], acc);
     dQKV[(size_t)r * 96 + tD + lane] = acc;   // columns [32, 64) = dK, [64, 96) = dV
 }
 
