@@ -184,7 +184,8 @@ typedef struct cirs_policy_weights {
     const float *wc, *bc; /* critic.last.model.0 [1,H],[1] */
 } cirs_policy_weights;
 
-/* bytes of caller-provided scratch for cirs_actor_sample / cirs_actor_logp with batch n */
+/* bytes of caller-provided scratch for cirs_actor_sample / cirs_actor_logp / cirs_rollout_steps* with batch n (h2 rows, sampler
+ * partials, and -- for the fused rollout -- 256 KB for the packed weight image of its step kernel, rebuilt by every call) */
 int64_t cirs_policy_workspace_bytes(const cirs_policy_cfg* cfg, int32_t n);
 
 /* For rows j in [0,n): h2 = trunk(state[j]); value = critic; act = argmax_i (logit_i + g_i) over unmasked items,
