@@ -63,3 +63,25 @@ class StaticRollout:
                                                 int(rng_base) & 0xFFFFFFFF, abi.ptr(visited), int(force_length), self._scratch.data_ptr(),
                                                 torch.cuda.current_stream(env.device).cuda_stream), "cirs_rollout_static")
         return env.turn.clone()
+
+    # ---- one vector step at a time (UCB: the exploration bonus changes after every recommendation) -----------------------------
+    def begin(self, users: torch.Tensor, remove_recommended=False):
+        env = self.env
+        B, I = env.n_env, env.tables.n_items
+        self.act.fill_(-1); self.done.zero_(); self.rew.zero_(); self.value.zero_()
+        env.reset(users)
+        self._visited = torch.zeros((B, (I + 31) // 32), dtype=torch.int32, device=env.device) if remove_recommended else None
+
+    def step(self, t: int, scores: torch.Tensor, *, softmax=False, epsilon=0.0, seed=0, rng_base=0, force_length=0,
+             bonus: Optional[torch.Tensor] = None):
+        """Vector step t of the trajectories opened by begin(): select (scores + bonus) -> mark visited -> env step."""
+        env = self.env
+        B, I = env.n_env, env.tables.n_items
+        assert scores.shape == (B, I) and scores.dtype == torch.float32 and scores.is_cuda and scores.stride(1) == 1
+        bonus = None if bonus is None else bonus.to(env.device, torch.float32).contiguous()
+        abi.check(self._lib.cirs_rollout_static(C.byref(env.cfg), C.byref(env._tab), C.byref(env._st), scores.data_ptr(), scores.stride(0),
+                                                abi.ptr(bonus), C.byref(self._traj), B, int(t), int(t) + 1, int(bool(softmax)), float(epsilon),
+                                                int(seed), int(rng_base) & 0xFFFFFFFF, abi.ptr(self._visited), int(force_length),
+                                                self._scratch.data_ptr(), torch.cuda.current_stream(env.device).cuda_stream),
+                  "cirs_rollout_static")
+

@@ -39,9 +39,9 @@ def interactive_evaluation(model, env, dataset_val, is_softmax, epsilon, is_ucb,
                            remove_recommended, force_length=0, top_rate=0.6, users=None, seed=0):
     """reference evaluation.py:79-151 with the num_trajectory trajectories run in LOCK-STEP on the device: one catalogue
     sweep per trajectory user (the model is static), then per step cirs_select_items -> env step (cirs_rollout_static).
-    Same result dict.  Differences that follow from batching: with is_ucb the arm counts are updated once per vector step
-    (the reference updates them after every single recommendation); users can be supplied (the reference draws them with
-    the unseeded `random`)."""
+    Same result dict.  With is_ucb the arm counts change after every single recommendation of every trajectory
+    (core/user_model.py:303-314, 340-342): that path runs the trajectories one after the other, one device step per
+    recommendation (_interactive_evaluation_ucb).  Users can be supplied (the reference draws them with the unseeded `random`)."""
     from cirs_hip.evalmetrics import CoverageCounter
     from cirs_hip.static_policy import StaticRollout
     assert k == 1 and need_transform, "built for KuaishouEnv (need_transform=True, k=1)"
@@ -61,7 +61,8 @@ def interactive_evaluation(model, env, dataset_val, is_softmax, epsilon, is_ucb,
     ro = StaticRollout(dev_env)
     T = dev_env.max_turn if force_length <= 0 else min(force_length, dev_env.max_turn)
     if is_ucb:
-        raise NotImplementedError("UCB exploration is sequential over recommendations (arm counts); call recommend_k_item per step")
+        return _interactive_evaluation_ucb(model, env, dataset_val, is_softmax, epsilon, B, item_feat_domination, remove_recommended,
+                                           force_length, top_rate, users, raw_users, item_index, feats, dur, seed)
     ro.run(torch.as_tensor(users), scores, softmax=is_softmax, epsilon=epsilon, seed=seed, remove_recommended=remove_recommended,
            force_length=force_length, n_steps=T)
     valid = ro.act >= 0
@@ -83,6 +84,63 @@ def interactive_evaluation(model, env, dataset_val, is_softmax, epsilon, is_ucb,
         eval_result_RL = {f"NX_{force_length}_" + key: v for key, v in eval_result_RL.items()}
     interactive_evaluation.last_rollout = ro
     return eval_result_RL
+
+
+def _interactive_evaluation_ucb(model, env, dataset_val, is_softmax, epsilon, B, item_feat_domination, remove_recommended, force_length,
+                                top_rate, users, raw_users, item_index, feats, dur, seed):
+    """is_ucb=True (reference evaluation.py:87-120 with core/user_model.py:303-314, 340-342): the bonus sqrt(2 ln n_rec / n_each) is
+    added to u_value when nothing is excluded (recommended_ids == [], i.e. always without remove_recommended, only at the first step
+    of a trajectory with it), and (n_rec, n_each) change after EVERY recommendation -- sequential by construction: trajectories one
+    after the other on a 1-env device env, one cirs_rollout_static step per recommendation, counts kept on the model like the
+    reference's.  reward_pred (click_loss) includes the bonus when it was applied, as in the reference (value_rec = u_value[...])."""
+    from cirs_hip.evalmetrics import CoverageCounter
+    from cirs_hip.static_policy import StaticRollout
+    I = len(item_index)
+    dev_env = env.build_device_env(1)
+    ro = StaticRollout(dev_env)
+    T = dev_env.max_turn if force_length <= 0 else min(force_length, dev_env.max_turn)
+    if not hasattr(model, "n_rec"):
+        model.compile_UCB(I)
+    total_turns, cumulative_reward, total_click_loss = 0, 0.0, 0.0
+    all_acts = []
+    for i in range(B):
+        scores, _ = model.device_model().sweep(raw_users[i:i + 1], item_index, feats, dur)   # [1, I]
+        ro.begin(torch.as_tensor(users[i:i + 1]), remove_recommended)
+        n_acts = 0
+        for t in range(T):
+            bonus = None
+            if not remove_recommended or n_acts == 0:
+                bonus = torch.as_tensor(((2 * np.log(model.n_rec) / model.n_each) ** 0.5).astype(np.float32))
+            ro.step(t, scores, softmax=is_softmax, epsilon=epsilon, seed=seed, rng_base=i * dev_env.max_turn, force_length=force_length,
+                    bonus=bonus)
+            a = int(ro.act[t, 0])
+            if a < 0:
+                break
+            model.n_rec += 1
+            model.n_each[a] += 1
+            n_acts += 1
+            all_acts.append(a)
+            r = float(ro.rew[t, 0])
+            total_turns += 1
+            cumulative_reward += r
+            total_click_loss += abs(float(ro.value[t, 0]) - r)
+            if bool(ro.done[t, 0]):
+                break
+    ctr = cumulative_reward / total_turns
+    click_loss = total_click_loss / total_turns
+    acts = torch.as_tensor(np.asarray(all_acts, dtype=np.int64))
+    cc = CoverageCounter(I)
+    flags = None
+    if item_feat_domination is not None and "feat" in item_feat_domination:
+        flags = torch.as_tensor(item_flags(feats, dominated_values(item_feat_domination["feat"], top_rate)))
+    hit_item, n_acts_all, n_fl = cc.count(acts, flags)
+    res = {"click_loss": click_loss, "CV": f"{hit_item / I:.5f}", "CV_turn": f"{hit_item / n_acts_all:.5f}", "ctr": ctr,
+           "len_tra": total_turns / B, "R_tra": cumulative_reward / B}
+    if flags is not None:
+        res["ifeat_feat"] = n_fl / n_acts_all
+    if remove_recommended:
+        res = {f"NX_{force_length}_" + key: v for key, v in res.items()}
+    return res
 
 
 def test_static_model_in_RL_env(model, env, dataset_val, is_softmax=True, epsilon=0, is_ucb=False, k=1, need_transform=False,

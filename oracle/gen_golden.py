@@ -813,8 +813,12 @@ def gen_staticpolicy():
     # ---- interactive_evaluation (greedy: deterministic given the users) ----------------------------------------------
     dom = {"feat": [(1, 0.4), (2, 0.3), (5, 0.2), (7, 0.1)]}
     n_traj = 10
-    for ei, (remove, fl) in enumerate([(False, 0), (True, 0), (True, 5)]):
+    for ei, (remove, fl, ucb) in enumerate([(False, 0, False), (True, 0, False), (True, 5, False), (False, 0, True), (True, 5, True)]):
         env = KuaishouEnv(**kw)
+        if ucb:   # fresh arm counts (core/user_model.py:250-252, 303-306)
+            for attr in ("n_rec", "n_each"):
+                if hasattr(model, attr):
+                    delattr(model, attr)
         pyrandom.seed(100 + ei)
         drawn = []
         orig_reset = env.reset
@@ -824,15 +828,15 @@ def gen_staticpolicy():
             _drawn.append(int(np.asarray(o).reshape(-1)[0]))
             return o
         env.reset = rec_reset
-        res = ev.interactive_evaluation(model, env, dataset_val, is_softmax=False, epsilon=0, is_ucb=False, k=1, need_transform=True,
+        res = ev.interactive_evaluation(model, env, dataset_val, is_softmax=False, epsilon=0, is_ucb=ucb, k=1, need_transform=True,
                                         num_trajectory=n_traj, item_feat_domination=dom, remove_recommended=remove, force_length=fl,
                                         top_rate=0.6)
         pre = f"NX_{fl}_" if remove else ""
         out[f"e{ei}_users"] = np.array(drawn, np.int64)
-        out[f"e{ei}_cfg"] = np.array([int(remove), fl], np.int64)
+        out[f"e{ei}_cfg"] = np.array([int(remove), fl, int(ucb)], np.int64)
         out[f"e{ei}_res"] = np.array([float(res[pre + "click_loss"]), float(res[pre + "CV"]), float(res[pre + "CV_turn"]), float(res[pre + "ctr"]),
                                       float(res[pre + "len_tra"]), float(res[pre + "R_tra"]), float(res[pre + "ifeat_feat"])], np.float64)
-    out["n_eval_cases"] = 3
+    out["n_eval_cases"] = 5
     out["dom_values"] = np.array([p[0] for p in dom["feat"]], np.int64); out["dom_shares"] = np.array([p[1] for p in dom["feat"]])
     np.savez_compressed(os.path.join(GOLDEN, "staticpolicy.npz"), **out)
     print("staticpolicy.npz:", {k: out[k] for k in out if k.endswith("_out") or k.endswith("_res")})

@@ -82,9 +82,14 @@ def test_interactive_evaluation_matches_reference(golden_dir):
     model, ds, env = _model(golden_dir), _dataset(z), _env(z)
     dom = {"feat": list(zip(z["dom_values"].tolist(), z["dom_shares"].tolist()))}
     for ei in range(int(z["n_eval_cases"])):
-        remove, fl = (int(x) for x in z[f"e{ei}_cfg"])
+        cfg = [int(x) for x in z[f"e{ei}_cfg"]]
+        remove, fl, ucb = cfg[0], cfg[1], bool(cfg[2]) if len(cfg) > 2 else False
         users = z[f"e{ei}_users"]
-        res = ev.interactive_evaluation(model, env, ds, is_softmax=False, epsilon=0, is_ucb=False, k=1, need_transform=True,
+        if ucb:   # fresh arm counts, as in the fixture (reference core/user_model.py:250-252, 303-306)
+            for attr in ("n_rec", "n_each"):
+                if hasattr(model, attr):
+                    delattr(model, attr)
+        res = ev.interactive_evaluation(model, env, ds, is_softmax=False, epsilon=0, is_ucb=ucb, k=1, need_transform=True,
                                         num_trajectory=len(users), item_feat_domination=dom, remove_recommended=bool(remove), force_length=fl,
                                         top_rate=0.6, users=users)
         pre = f"NX_{fl}_" if remove else ""
