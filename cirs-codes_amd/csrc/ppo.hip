@@ -254,6 +254,14 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(cirs_ppo_cfg cfg,
         }
         return;
     }
+    // The row's gathers form a chain of dependent round trips (idx -> action -> head row of the action).  The first two are
+    // requested by every lane before the merge of the chunk partials, the head row and the hidden row arrive as ONE coalesced load
+    // each (lane i holds element i) and reach lane 0's fma chain through LDS -- one lane reading 128 floats from memory on its own is
+    // 128 memory instructions behind two serial round trips.
+    __shared__ __attribute__((aligned(16))) float sRow[4][2][kH];
+    const int src = idx[j];
+    const int a = b.act[src];
+    const float hl = v.h2[(size_t)j * kH + lane], wl = wa[(size_t)a * kH + lane];
     float m = -INFINITY, s = 0.f, t = 0.f;
     for (int c = lane; c < n_chunks; c += CIRS_WAVE) {
         const size_t o = (size_t)c * n_pad + j;
@@ -273,12 +281,14 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(cirs_ppo_cfg cfg,
             s = s * fa + os * fb; t = t * fa + ot * fb; m = mn;
         }
     }
+    sRow[threadIdx.x >> 6][0][lane] = hl;
+    sRow[threadIdx.x >> 6][1][lane] = wl;
+    __builtin_amdgcn_wave_barrier();
     if (lane != 0) return;
-    const int src = idx[j];
-    const int a = b.act[src];
-    const float* wr = wa + (size_t)a * kH;
-    const float* hr = v.h2 + (size_t)j * kH;
+    const float* hr = sRow[threadIdx.x >> 6][0];
+    const float* wr = sRow[threadIdx.x >> 6][1];
     float z = ba[a];
+#pragma unroll
     for (int kk = 0; kk < 32; ++kk) {
         z = __builtin_fmaf(hr[kk], wr[kk], z);
         z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
