@@ -439,12 +439,24 @@ constexpr int kWBufB = 3 * kRPlaneB + 3 * kCPlaneB;
 // grid = (n_chunks, ceil(n_pad/32/4)); workgroup = 4 waves = 4 row tiles walking the item tiles of one chunk; the R planes
 // of a Wa tile (12 KB) are staged once per workgroup, double-buffered.  Output: the per-chunk partials (m, s, t) of each
 // row in the ActorPartialView arrays (score = t), merged by head_stats_merge_kernel.
+#ifdef CIRS_HEAD_PROF
+// per-tile stage timestamps of workgroup (0, 0) / wave 0 at its third tile (probe builds only: tools/probes/head_prof.py)
+__device__ unsigned long long g_head_prof[64];
+#define CIRS_HSTAMP(K) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && it == 2) g_head_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CIRS_TSTAMP(B, K) do { if ((int)blockIdx.x == (B) && threadIdx.x == 0) g_head_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CIRS_SSTAMP(K) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_head_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CIRS_HSTAMP(K) do { } while (0)
+#define CIRS_TSTAMP(B, K) do { } while (0)
+#define CIRS_SSTAMP(K) do { } while (0)
+#endif
 __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                             const uint4* __restrict__ planes, const float* __restrict__ ba,
                                                             const float* __restrict__ h2, ActorPartialView pv) {
     __shared__ __attribute__((aligned(16))) unsigned char sW[2][3 * kRPlaneB];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
+    CIRS_SSTAMP(40);
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * 4 + wv) * kTileM;
@@ -494,11 +506,14 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
         *reinterpret_cast<uint4*>(base_ + 2 * kRPlaneB + dst_r) = g2;                                      \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
+    CIRS_SSTAMP(41);
     if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
     __syncthreads();
+    CIRS_SSTAMP(42);
     for (int it = 0; it < n_tiles; ++it) {
         const int buf = it & 1;
         const int tile0 = first_tile + it * kTileN;
+        if (it == 2) CIRS_SSTAMP(43);
         if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);
         if (wave_ok) {
             const unsigned char* tw = sW[buf];
@@ -513,8 +528,10 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = sB[buf][acc_row(r, hi)];
+            if (it == 2) CIRS_SSTAMP(44);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc = mfma_bf16x6(za[s4], hz[s4], acc);
+            if (it == 2) CIRS_SSTAMP(45);
             // log-sum-exp per tile: the lane's maximum first, then ONE rescale of the running sums and one exp per element;
             // items beyond I (last tile only) carry -inf and add exp(-inf) = 0
             f32x16 zt = acc;
@@ -540,9 +557,12 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
                 run_m = mn;
             }
         }
+        if (it == 2) CIRS_SSTAMP(46);
         if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);
         __syncthreads();
+        if (it == 2) CIRS_SSTAMP(47);
     }
+    CIRS_SSTAMP(48);
 #undef CIRS_ISSUE
 #undef CIRS_COMMIT
     if (row0 >= n_pad) return;
@@ -579,15 +599,6 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 // The Wa planes of a tile (24 KB, written by wa_planes_kernel) are staged in LDS once per workgroup, double-buffered with
 // the next tile's global loads in flight; row strides 144 B / 80 B keep the ds_read_b128 of the operands conflict-free.
 
-#ifdef CIRS_HEAD_PROF
-// per-tile stage timestamps of workgroup (0, 0) / wave 0 at its third tile (probe builds only: tools/probes/head_prof.py)
-__device__ unsigned long long g_head_prof[32];
-#define CIRS_HSTAMP(K) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && it == 2) g_head_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
-#define CIRS_TSTAMP(B, K) do { if ((int)blockIdx.x == (B) && threadIdx.x == 0) g_head_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define CIRS_HSTAMP(K) do { } while (0)
-#define CIRS_TSTAMP(B, K) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                                          const uint4* __restrict__ planes,
@@ -1279,7 +1290,7 @@ static int launch_adam(float* p, const float* g, float* m, float* v, long n, lon
 
 #ifdef CIRS_HEAD_PROF
 extern "C" int cirs_debug_head_prof(unsigned long long* out_host32) {
-    return hipMemcpyFromSymbol(out_host32, HIP_SYMBOL(cirs::g_head_prof), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(out_host32, HIP_SYMBOL(cirs::g_head_prof), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }
 #endif
 
@@ -1370,7 +1381,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         //    all workgroups co-resident (2 per CU) with equal tile counts
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         const int n_item_tiles = cdiv(I, kTileN);
-        const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);
+        const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);   // measured: 1 / 2 / 3 workgroups per CU = 17.4 / 14.5 / 16.7 us
         const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
         CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s,
                                                   (const uint4*)v.wa_planes, w.ba, (const float*)v.h2, pv));

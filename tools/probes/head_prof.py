@@ -24,7 +24,7 @@ acc = None
 for rep in range(8):
     bench.hip_event_kernel_time(eng, wl, reps=2)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 64)()
     assert lib.cirs_debug_head_prof(buf) == 0
     t = np.array(buf[:], dtype=np.float64)
     if rep >= 2:
@@ -44,3 +44,12 @@ for k in sorted(tb):
     print(f"  {tb[k]:64s} {t[k] - prev:9.0f}   (cum {t[k] - t[16]:9.0f})")
     prev = t[k]
 print(f"  first wa|ba slab-sum workgroup: entry at {t[24] - t[16]:+.0f} relative to row workgroup 0, its sums + reduction take {t[25] - t[24]:.0f}")
+
+hs = {40: "head_stats workgroup (0,0): entry", 41: "H2 tile coalesced -> LDS -> split into bf16 planes", 42: "first planes tile staged, barrier",
+      43: "(tiles 0, 1)", 44: "tile 2: next tile requested, LDS operand reads, bias init", 45: "tile 2: 24 MFMAs", 46: "tile 2: mask, max, 16 exp, running sums",
+      47: "tile 2: commit next + barrier", 48: "remaining tiles"}
+print("head_stats_kernel (raw ticks; two workgroups per CU share the SIMDs):")
+prev = t[40]
+for k in sorted(hs):
+    print(f"  {hs[k]:64s} {t[k] - prev:9.0f}   (cum {t[k] - t[40]:9.0f})")
+    prev = t[k]
