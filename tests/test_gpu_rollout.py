@@ -53,8 +53,9 @@ def check_rollout(U, I, B, T, seed, *, sync_every=None, **kw):
     for b in range(B):
         L = lengths[b]
         np.testing.assert_allclose(obs[:L + 1, b], states[b, :L + 1], atol=1e-4, rtol=1e-4)
-    # --- the fused step reads its weights from the LDS image, the stand-alone tracker step from global memory: same fma order,
-    #     so a teacher-forced replay through cirs_tracker_init / cirs_tracker_step must reproduce the states BIT FOR BIT
+    # --- the fused step reads its weights from the packed image ([k/4][O][4], coalesced), the stand-alone tracker step from the
+    #     row-major matrices: same fma order, so a teacher-forced replay through cirs_tracker_init / cirs_tracker_step must
+    #     reproduce the states BIT FOR BIT
     from cirs_hip.tracker import DeviceTracker
     trk2 = DeviceTracker({k: v.float().cuda().contiguous() for k, v in tp.items()}, U, I, B, T)
     replay = np.zeros_like(obs)
@@ -64,7 +65,7 @@ def check_rollout(U, I, B, T, seed, *, sync_every=None, **kw):
         out = trk2.step(torch.as_tensor(act[t, live]), torch.as_tensor(rew[t, live]), env_ids=torch.as_tensor(live.astype(np.int32)).cuda())
         replay[t + 1, live] = out.cpu().numpy()
     for b in range(B):
-        assert np.array_equal(obs[:lengths[b] + 1, b], replay[:lengths[b] + 1, b]), f"env {b}: fused (LDS weights) != stand-alone tracker step"
+        assert np.array_equal(obs[:lengths[b] + 1, b], replay[:lengths[b] + 1, b]), f"env {b}: fused step (packed weight image) != stand-alone tracker step"
     return lengths
 
 
