@@ -54,34 +54,46 @@ __global__ __launch_bounds__(256) void gae_kernel(cirs_ppo_cfg cfg, cirs_traj tr
     const double scale = cfg.rew_norm ? sqrt(rms_state[1] + 1e-8) : 1.0;  // a2c.py:95-97, pg.py:60 (_eps = 1e-8)
     const double gamma = (double)cfg.gamma, gl = (double)cfg.gamma * (double)cfg.gae_lambda;
     double gae = 0.0;
-    // the recurrence runs backwards over the episode; the loads of step t-1 are issued before step t is computed (they do not depend
-    // on it), so one memory latency per step is not on the chain
+    // the recurrence runs backwards over the episode, eight steps per pass: the 8 x 5 loads of the NEXT pass are requested before this
+    // pass is computed (they do not depend on it) -- with one step of look-ahead every step still cost a cold memory round trip
+    // (44 us per update for 30 steps); the arithmetic and its order are unchanged
     struct StepIn { bool done; float value, logp; double rew; long act; };
     auto load_step = [&](int t) {
+        if (t < 0) return StepIn{};
         const size_t ti = (size_t)t * B + b;
         return StepIn{traj.done[ti] != 0, traj.value[ti], traj.logp[ti], traj.rew[ti], (long)traj.act[ti]};
     };
-    StepIn cur = L > 0 ? load_step(L - 1) : StepIn{};
+    StepIn cur8[8], nxt8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cur8[u] = load_step(L - 1 - u);
     float value_next = 0.f;   // V(s_{t+1}) as recorded at step t+1
-    for (int t = L - 1; t >= 0; --t) {
-        const StepIn nxt = t > 0 ? load_step(t - 1) : StepIn{};
-        const bool done = cur.done;
-        const double v_s = (double)cur.value * scale;
-        // value_mask (base.py:264): V(s') is zeroed on done; otherwise V(s_{t+1}) recorded at the next step
-        const double v_ns = (done || t + 1 >= L) ? 0.0 : (double)value_next * scale;
-        const double end_flag = (done || t == L - 1) ? 1.0 : 0.0;  // done OR unfinished_index (base.py:307-308)
-        const double delta = cur.rew + v_ns * gamma - v_s;
-        gae = delta + (1.0 - end_flag) * gl * gae;
-        const int row = off + t;
-        out.adv[row] = (float)gae;
-        unnorm_ret[row] = gae + v_s;
-        out.v_s[row] = cur.value;
-        out.logp_old[row] = cur.logp;
-        out.act[row] = (int32_t)cur.act;
-        out.row_env[row] = b;
-        out.row_t[row] = t;
-        value_next = cur.value;
-        cur = nxt;
+    for (int t0 = L - 1; t0 >= 0; t0 -= 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nxt8[u] = load_step(t0 - 8 - u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 - u;
+            if (t < 0) break;
+            const StepIn cur = cur8[u];
+            const bool done = cur.done;
+            const double v_s = (double)cur.value * scale;
+            // value_mask (base.py:264): V(s') is zeroed on done; otherwise V(s_{t+1}) recorded at the next step
+            const double v_ns = (done || t + 1 >= L) ? 0.0 : (double)value_next * scale;
+            const double end_flag = (done || t == L - 1) ? 1.0 : 0.0;  // done OR unfinished_index (base.py:307-308)
+            const double delta = cur.rew + v_ns * gamma - v_s;
+            gae = delta + (1.0 - end_flag) * gl * gae;
+            const int row = off + t;
+            out.adv[row] = (float)gae;
+            unnorm_ret[row] = gae + v_s;
+            out.v_s[row] = cur.value;
+            out.logp_old[row] = cur.logp;
+            out.act[row] = (int32_t)cur.act;
+            out.row_env[row] = b;
+            out.row_t[row] = t;
+            value_next = cur.value;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur8[u] = nxt8[u];
     }
 }
 
@@ -99,7 +111,15 @@ __global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const d
     __shared__ double s_mean;
     const int tid = threadIdx.x;
     double acc = 0.0;
-    for (int i = tid; i < N; i += 1024) acc += unnorm_ret[i];
+    // eight loads in flight per pass, added in the same (index) order as a plain loop
+    for (int i0 = tid; i0 < N; i0 += 8 * 1024) {
+        double x8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x8[u] = i0 + u * 1024 < N ? unnorm_ret[i0 + u * 1024] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < N) acc += x8[u];
+    }
     red[tid] = acc;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
@@ -110,9 +130,13 @@ __global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const d
     __syncthreads();
     const double mean = s_mean;
     acc = 0.0;
-    for (int i = tid; i < N; i += 1024) {
-        const double d = unnorm_ret[i] - mean;
-        acc += d * d;
+    for (int i0 = tid; i0 < N; i0 += 8 * 1024) {
+        double x8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x8[u] = i0 + u * 1024 < N ? unnorm_ret[i0 + u * 1024] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < N) { const double d = x8[u] - mean; acc += d * d; }
     }
     __syncthreads();
     red[tid] = acc;
@@ -123,7 +147,14 @@ __global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const d
     }
     const double var = red[0] / (double)N;  // np.var: population variance
     const double scale = cfg.rew_norm ? sqrt(rms_state[1] + 1e-8) : 1.0;  // OLD variance (a2c.py:101-103)
-    for (int i = tid; i < N; i += 1024) ret_out[i] = (float)(unnorm_ret[i] / scale);
+    for (int i0 = tid; i0 < N; i0 += 8 * 1024) {
+        double x8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x8[u] = i0 + u * 1024 < N ? unnorm_ret[i0 + u * 1024] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < N) ret_out[i0 + u * 1024] = (float)(x8[u] / scale);
+    }
     __syncthreads();
     if (tid == 0 && cfg.rew_norm) {  // RunningMeanStd.update (statistics.py:80-95)
         const double o_mean = rms_state[0], o_var = rms_state[1], o_cnt = rms_state[2];
@@ -1326,7 +1357,9 @@ extern "C" int cirs_ppo_prepare(const cirs_ppo_cfg* cfg, const cirs_traj* traj, 
     // float64 scratch for the un-normalised returns lives in the ret buffer's shadow: allocate on the stream
     double* unnorm = nullptr;
     CIRS_HIP(hipMallocAsync((void**)&unnorm, sizeof(double) * (size_t)n_rows, s));
-    hipLaunchKernelGGL(gae_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, s, *cfg, *traj, lens, offsets, n_env, cfg->dim_state,
+    // one wavefront per workgroup: the per-env row stores touch 64 cache lines per instruction, so the wavefronts are spread over as
+    // many CUs (address units) as there are
+    hipLaunchKernelGGL(gae_kernel, dim3(cdiv(n_env, 64)), dim3(64), 0, s, *cfg, *traj, lens, offsets, n_env, cfg->dim_state,
                        rms_state, *out, unnorm);
     hipLaunchKernelGGL(compact_obs_kernel, dim3(cdiv((long)n_rows * cfg->dim_state, 256)), dim3(256), 0, s, *traj, *out, n_rows, n_env, cfg->dim_state);
     CIRS_CHECK_LAUNCH("gae_kernel");
