@@ -321,6 +321,11 @@ __global__ __launch_bounds__(256) void gather_dstate(const float* __restrict__ d
 // Produces, per row, the "pre" gradient vectors the two small weight-gradient GEMMs need and scatters into the
 // embedding tables:   user rows : DU[r] = dX0 (for ffn_user), EU[r] = Emb_user[u]
 //                     item rows : DPRE[r] = dX0 * a * g(1-g), GIN[r] = [rew, a]  (for fnn_gate)
+// value of lane k (a compile-time or wave-uniform k) in every lane: v_readlane_b32, not a ds_bpermute round trip
+__device__ __forceinline__ float lane_bcast(float x, int k) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), k));
+}
+
 __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const float* __restrict__ dH0, const int32_t* __restrict__ users,
                                                 const int64_t* __restrict__ act, const double* __restrict__ rew,
                                                 const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t, int R, int B,
@@ -329,6 +334,11 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
                                                 int32_t* __restrict__ key_user, int32_t* __restrict__ key_item) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the gate matrix [32][33] once per workgroup, coalesced, into LDS: lane d then walks ITS row with stride-33 reads (no bank
+    // conflicts); from memory that walk is one dword per lane and load, 64 cache lines per instruction, 33 instructions per row
+    __shared__ float sG[tD * (tD + 1)];
+    for (int q = threadIdx.x; q < tD * (tD + 1); q += 256) sG[q] = w.gate_w[q];
+    __syncthreads();
     if (r >= R) return;
     const int b = row_env[r], p = row_t[r];
     const int d = lane & 31;
@@ -343,7 +353,8 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
         if (lane <= tD) GIN[(size_t)r * (tD + 1) + lane] = 0.f;
         // dEmb_user[u, k] += sum_o dx[o] * ffn_user_w[o, k] : lane k
         float acc = 0.f;
-        for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(__shfl(dx, o, CIRS_WAVE), w.ffn_user_w[(size_t)o * tD + d], acc);
+#pragma unroll
+        for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(lane_bcast(dx, o), w.ffn_user_w[(size_t)o * tD + d], acc);
         if (lane < tD) { CU[(size_t)r * tD + d] = acc; CI[(size_t)r * tD + d] = 0.f; }
         if (lane == 0) { key_user[r] = u; key_item[r] = -1; }
     } else {
@@ -352,10 +363,11 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
         const float rw = (float)rew[ti];
         const float a = w.emb_item[(size_t)it * tD + d];
         // recompute the gate for feature d (lane o = d)
-        const float* gw = w.gate_w + (size_t)d * (tD + 1);
+        const float* gw = sG + d * (tD + 1);
         float pre = w.gate_b[d];
         pre = __builtin_fmaf(gw[0], rw, pre);
-        for (int k = 0; k < tD; ++k) pre = __builtin_fmaf(gw[1 + k], __shfl(a, k, CIRS_WAVE), pre);
+#pragma unroll
+        for (int k = 0; k < tD; ++k) pre = __builtin_fmaf(gw[1 + k], lane_bcast(a, k), pre);
         const float g = 1.0f / (1.0f + expf(-pre));
         const float dpre = dx * a * g * (1.0f - g);
         if (lane < tD) {
@@ -366,7 +378,8 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
         if (lane == 0) GIN[(size_t)r * (tD + 1)] = rw;
         // d a[k] = dx[k]*g[k] + sum_o dpre[o] * gate_w[o, 1+k]
         float acc = dx * g;
-        for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(__shfl(dpre, o, CIRS_WAVE), w.gate_w[(size_t)o * (tD + 1) + 1 + d], acc);
+#pragma unroll
+        for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(lane_bcast(dpre, o), sG[o * (tD + 1) + 1 + d], acc);
         if (lane < tD) { CI[(size_t)r * tD + d] = acc; CU[(size_t)r * tD + d] = 0.f; }
         if (lane == 0) { key_item[r] = (int32_t)it; key_user[r] = -1; }
     }
