@@ -16,13 +16,12 @@ typedef float sg_f32x16 __attribute__((ext_vector_type(16)));
 
 // grid = (ceil(R/32), ceil(N/32)), block = 64
 template <bool kNT>
-static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
-                                                              const float* __restrict__ bias, int R, int Kd, int N, int relu,
-                                                              const float* __restrict__ relu_of, int accumulate,
-                                                              float* __restrict__ Y, int ldy,
-                                                              const long* __restrict__ out_row = nullptr) {
+__device__ __forceinline__ void rows_gemm_body(int bx, int by, const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                               const float* __restrict__ bias, int R, int Kd, int N, int relu,
+                                               const float* __restrict__ relu_of, int accumulate, float* __restrict__ Y, int ldy,
+                                               const long* __restrict__ out_row) {
     const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
-    const int row0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int row0 = bx * 32, n0 = by * 32;
     const int row = row0 + lo, n = n0 + lo;
     const bool row_ok = row < R, n_ok = n < N;
     sg_f32x16 acc;
@@ -94,6 +93,15 @@ static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __res
     }
 }
 
+template <bool kNT>
+static __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                              const float* __restrict__ bias, int R, int Kd, int N, int relu,
+                                                              const float* __restrict__ relu_of, int accumulate,
+                                                              float* __restrict__ Y, int ldy,
+                                                              const long* __restrict__ out_row = nullptr) {
+    rows_gemm_body<kNT>(blockIdx.x, blockIdx.y, X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy, out_row);
+}
+
 static inline void launch_rows_gemm(bool nt, const float* X, int ldx, const float* W, int ldw, const float* bias, int R, int Kd, int N,
                                     int relu, const float* relu_of, int accumulate, float* Y, int ldy, hipStream_t s,
                                     const long* out_row = nullptr) {
@@ -110,12 +118,11 @@ __host__ inline int dwg_slabs(long R) {
 __host__ inline size_t dwg_partial_floats(long R, int O, int K) { return (size_t)dwg_slabs(R) * O * (K + 1); }
 
 // grid = (ceil(O/32) * ceil(K/32), n_slabs), block = 64.  partial[slab][o*(K+1)+k], k == K: bias column
-static __global__ __launch_bounds__(64) void dw_gemm_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int R,
-                                                            int O, int K, int rows_per_slab, float* __restrict__ partial) {
+__device__ __forceinline__ void dw_gemm_body(int bx, int slab, const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int R,
+                                             int O, int K, int rows_per_slab, float* __restrict__ partial) {
     const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
     const int k_tiles = (K + 31) / 32;
-    const int o0 = (blockIdx.x / k_tiles) * 32, k0 = (blockIdx.x % k_tiles) * 32;
-    const int slab = blockIdx.y;
+    const int o0 = (bx / k_tiles) * 32, k0 = (bx % k_tiles) * 32;
     const int r_beg = slab * rows_per_slab, r_end = min(R, r_beg + rows_per_slab);
     const int o = o0 + lo, k = k0 + lo;
     const bool o_ok = o < O, k_ok = k < K;
@@ -149,6 +156,28 @@ static __global__ __launch_bounds__(64) void dw_gemm_kernel(const float* __restr
     if (k0 == 0) {
         bsum += __shfl_xor(bsum, 32, CIRS_WAVE);
         if (hi == 0 && o_ok) out[(size_t)o * (K + 1) + K] = bsum;
+    }
+}
+
+static __global__ __launch_bounds__(64) void dw_gemm_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int R,
+                                                            int O, int K, int rows_per_slab, float* __restrict__ partial) {
+    dw_gemm_body(blockIdx.x, blockIdx.y, dY, ldy, X, ldx, R, O, K, rows_per_slab, partial);
+}
+
+// A weight-gradient problem and the row GEMM that follows it in a backward chain read the same dY and do not depend on each other:
+// ONE launch, the first rgx * rgy workgroups are the row GEMM's, the rest the dW problem's (each launch of this size costs ~7 us of
+// boundary + cold start however little it computes).  Same per-workgroup code as the two kernels above: same bits.
+struct RowsGemmArgs { const float* X; int ldx; const float* W; int ldw; const float* bias; int R, Kd, N, relu; const float* relu_of; int accumulate; float* Y; int ldy; };
+struct DwGemmArgs { const float* dY; int ldy; const float* X; int ldx; int R, O, K, rows_per_slab; float* partial; };
+template <bool kNT>
+static __global__ __launch_bounds__(64) void rows_gemm_dw_kernel(RowsGemmArgs ra, int rgx, int rgy, DwGemmArgs da, int dgx) {
+    const int b = blockIdx.x;
+    if (b < rgx * rgy) {
+        rows_gemm_body<kNT>(b % rgx, b / rgx, ra.X, ra.ldx, ra.W, ra.ldw, ra.bias, ra.R, ra.Kd, ra.N, ra.relu, ra.relu_of, ra.accumulate, ra.Y, ra.ldy,
+                            nullptr);
+    } else {
+        const int q = b - rgx * rgy;
+        dw_gemm_body(q % dgx, q / dgx, da.dY, da.ldy, da.X, da.ldx, da.R, da.O, da.K, da.rows_per_slab, da.partial);
     }
 }
 
@@ -243,6 +272,25 @@ static inline void launch_dw_partial(DwList& list, const float* dY, int ldy, con
     list.total_out += O * (K + 1);
     const int tiles = cdiv(O, 32) * cdiv(K, 32);
     hipLaunchKernelGGL(dw_gemm_kernel, dim3(tiles, slabs), dim3(64), 0, s, dY, ldy, X, ldx, R, O, K, rows_per_slab, partial + jb.part_off);
+}
+
+// launch_dw_partial(list, dY, ..) + launch_rows_gemm(nt, ..) as one launch (see rows_gemm_dw_kernel)
+static inline void launch_rows_gemm_dw(DwList& list, const float* dwX, int dw_ldx, int dwO, int dwK, float* dW, float* db, float* partial,
+                                       bool nt, const float* X, int ldx, const float* W, int ldw, const float* bias, int R, int Kd, int N,
+                                       int relu, const float* relu_of, int accumulate, float* Y, int ldy, hipStream_t s) {
+    const int slabs = dwg_slabs(R);
+    int rows_per_slab = (R + slabs - 1) / slabs;
+    rows_per_slab = (rows_per_slab + 15) & ~15;
+    DwListJob& jb = list.j[list.n++];
+    jb.O = dwO; jb.K = dwK; jb.part_off = list.part_floats; jb.diag = 0; jb.dW = dW; jb.db = db;
+    list.part_floats += slabs * dwO * (dwK + 1);
+    list.total_out += dwO * (dwK + 1);
+    const int tiles = cdiv(dwO, 32) * cdiv(dwK, 32);
+    const RowsGemmArgs ra{X, ldx, W, ldw, bias, R, Kd, N, relu, relu_of, accumulate, Y, ldy};
+    const DwGemmArgs da{X, ldx, dwX, dw_ldx, R, dwO, dwK, rows_per_slab, partial + jb.part_off};   // dY of the dW problem = X of the row GEMM
+    const int rgx = cdiv(R, 32), rgy = cdiv(N, 32);
+    if (nt) hipLaunchKernelGGL(rows_gemm_dw_kernel<true>, dim3(rgx * rgy + tiles * slabs), dim3(64), 0, s, ra, rgx, rgy, da, tiles);
+    else hipLaunchKernelGGL(rows_gemm_dw_kernel<false>, dim3(rgx * rgy + tiles * slabs), dim3(64), 0, s, ra, rgx, rgy, da, tiles);
 }
 
 static __global__ __launch_bounds__(256) void dw_list_final(DwList list, int n_slabs, const float* __restrict__ partial) {

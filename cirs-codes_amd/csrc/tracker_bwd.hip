@@ -610,9 +610,10 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     CIRS_CHECK_LAUNCH("tracker forward recompute");
     // ---------------- backward ----------------
     hipLaunchKernelGGL(gather_dstate, g1((long)R * S), dim3(256), 0, s, dstate, row_env, row_t, R, S, B, sc.G);
-    DW(sc.G, sc.H[nl], S, tD, grads->dec_w, grads->dec_b);
     float* dH = sc.T0;  // gradient w.r.t. the current layer output
-    launch_rows_gemm(false, sc.G, S, w->dec_w, tD, nullptr, R, S, tD, 0, nullptr, 0, dH, tD, s);
+    // (each weight-gradient problem rides in the launch of the row GEMM that consumes the same dY: DW_ROWS)
+#define DW_ROWS(X2, O, K, dWp, dbp, ...) launch_rows_gemm_dw(dwl, X2, K, O, K, dWp, dbp, sc.partial, __VA_ARGS__, s)
+    DW_ROWS(sc.H[nl], S, tD, grads->dec_w, grads->dec_b, false, sc.G, S, w->dec_w, tD, nullptr, R, S, tD, 0, nullptr, 0, dH, tD);
     for (int l = nl - 1; l >= 0; --l) {
         const cirs_tracker_layer& y = w->layer[l];
         const cirs_tracker_layer_grads& gy = grads->layer[l];
@@ -627,12 +628,10 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
             hipLaunchKernelGGL(drop_rows, g1((long)R * tD), dim3(256), 0, s, dc, (const float*)dY2, row_env, row_t, R, tD, l, (int)CIRS_DROP_RES2, sc.T3);
             dB2 = sc.T3;
         }
-        DW(dB2, sc.FF1[l], tD, tH, gy.lin2_w, gy.lin2_b);
-        launch_rows_gemm(false, dB2, tD, y.lin2_w, tH, nullptr, R, tD, tH, 0, sc.FF1[l], 0, sc.dFF1, tH, s);
+        DW_ROWS(sc.FF1[l], tD, tH, gy.lin2_w, gy.lin2_b, false, dB2, tD, y.lin2_w, tH, nullptr, R, tD, tH, 0, sc.FF1[l], 0, sc.dFF1, tH);
         if (dc.on) hipLaunchKernelGGL(scale_rows, g1((long)R * tH), dim3(256), 0, s, sc.dFF1, (long)R * tH, dc.inv);
-        DW(sc.dFF1, sc.H1N[l], tH, tD, gy.lin1_w, gy.lin1_b);
         // d H1N = dY2 (residual) + dFF1 * W1
-        launch_rows_gemm(false, sc.dFF1, tH, y.lin1_w, tD, nullptr, R, tH, tD, 0, nullptr, 1, dY2, tD, s);
+        DW_ROWS(sc.H1N[l], tH, tD, gy.lin1_w, gy.lin1_b, false, sc.dFF1, tH, y.lin1_w, tD, nullptr, R, tH, tD, 0, nullptr, 1, dY2, tD);
         // LN1
         launch_dw_partial(dwl, dY2, tD, sc.XH1[l], tD, R, tD, tD, gy.norm1_w, gy.norm1_b, 1, sc.partial, s);
         float* dY1 = sc.T2;
@@ -643,17 +642,15 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
             hipLaunchKernelGGL(drop_rows, g1((long)R * tD), dim3(256), 0, s, dc, (const float*)dY1, row_env, row_t, R, tD, l, (int)CIRS_DROP_RES1, sc.T3);
             dB1 = sc.T3;
         }
-        DW(dB1, sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b);
         float* dATT = sc.T1;
-        launch_rows_gemm(false, dB1, tD, y.out_proj_w, tD, nullptr, R, tD, tD, 0, nullptr, 0, dATT, tD, s);
+        DW_ROWS(sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b, false, dB1, tD, y.out_proj_w, tD, nullptr, R, tD, tD, 0, nullptr, 0, dATT, tD);
         // attention (dropout: V is weighted by the masked probabilities PM; the softmax backward runs on P)
         ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV,
                         (const float*)sc.PM[l], dc.inv);
         ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], dc.on ? sc.PM[l] : sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
         // in_proj
-        DW(sc.dQKV, sc.H[l], 96, tD, gy.in_proj_w, gy.in_proj_b);
         // d H_l = dY1 (residual) + dQKV * W_in
-        launch_rows_gemm(false, sc.dQKV, 96, y.in_proj_w, tD, nullptr, R, 96, tD, 0, nullptr, 1, dY1, tD, s);
+        DW_ROWS(sc.H[l], 96, tD, gy.in_proj_w, gy.in_proj_b, false, sc.dQKV, 96, y.in_proj_w, tD, nullptr, R, 96, tD, 0, nullptr, 1, dY1, tD);
         dH = dY1;
         if (l > 0) {  // keep dH in T0 for the next iteration (T2 is reused as dY1)
             CIRS_HIP(hipMemcpyAsync(sc.T0, dY1, sizeof(float) * (size_t)R * tD, hipMemcpyDeviceToDevice, s));
