@@ -288,6 +288,27 @@ __global__ __launch_bounds__(256) void ln_fwd(const float* __restrict__ Y, const
     out[i] = xh * g[d] + b[d];
 }
 // LayerNorm backward, same mapping: dY = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)), dxh = dOut * g
+// LayerNorm backward + the weight / bias gradient problem of the same LayerNorm (diag(dOut^T xhat), column sums of dOut: a dw_gemm
+// problem) in ONE launch of 64-thread workgroups: the first n_ln of them are the row-wise part, the rest the dW slabs (independent of
+// each other, same inputs; a launch of this size costs ~6 us whatever it computes)
+__global__ __launch_bounds__(64) void ln_bwd_dw_kernel(const float* __restrict__ dOut, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                       const float* __restrict__ g, int R, float* __restrict__ dY, int n_ln, DwGemmArgs da, int dgx) {
+    if ((int)blockIdx.x >= n_ln) {
+        const int q = (int)blockIdx.x - n_ln;
+        dw_gemm_body(q % dgx, q / dgx, da.dY, da.ldy, da.X, da.ldx, da.R, da.O, da.K, da.rows_per_slab, da.partial);
+        return;
+    }
+    const long i = blockIdx.x * 64L + threadIdx.x;
+    const long r = i >> 5;
+    const int d = (int)(i & 31);
+    const bool ok = r < R;
+    const float dxh = ok ? dOut[i] * g[d] : 0.f;
+    const float xh = ok ? xhat[i] : 0.f;
+    const float m1 = half_sum32(dxh) * (1.0f / tD);
+    const float m2 = half_sum32(dxh * xh) * (1.0f / tD);
+    if (ok) dY[i] = rstd[r] * (dxh - m1 - xh * m2);
+}
+
 __global__ __launch_bounds__(256) void ln_bwd(const float* __restrict__ dOut, const float* __restrict__ xhat, const float* __restrict__ rstd,
                                               const float* __restrict__ g, int R, float* __restrict__ dY) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -551,6 +572,22 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
 
 }  // namespace cirs
 
+namespace cirs {
+static inline void launch_ln_bwd_dw(DwList& list, const float* dOut, const float* xhat, const float* rstd, const float* g, int R, float* dY,
+                                    float* dW, float* db, float* partial, hipStream_t s) {
+    const int slabs = dwg_slabs(R);
+    int rows_per_slab = (R + slabs - 1) / slabs;
+    rows_per_slab = (rows_per_slab + 15) & ~15;
+    DwListJob& jb = list.j[list.n++];
+    jb.O = tD; jb.K = tD; jb.part_off = list.part_floats; jb.diag = 1; jb.dW = dW; jb.db = db;
+    list.part_floats += slabs * tD * (tD + 1);
+    list.total_out += tD * (tD + 1);
+    const DwGemmArgs da{dOut, tD, xhat, tD, R, tD, tD, rows_per_slab, partial + jb.part_off};
+    const int n_ln = (int)cdiv((long)R * tD, 64L);
+    hipLaunchKernelGGL(ln_bwd_dw_kernel, dim3(n_ln + slabs), dim3(64), 0, s, dOut, xhat, rstd, g, R, dY, n_ln, da, 1);
+}
+}  // namespace cirs
+
 extern "C" int64_t cirs_tracker_backward_workspace_bytes(const cirs_tracker_cfg* cfg, int32_t n_rows) {
     if (!cfg || n_rows <= 0) return 0;
     return (int64_t)cirs::bwd_floats(cfg, n_rows) * 4;
@@ -618,9 +655,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         const cirs_tracker_layer& y = w->layer[l];
         const cirs_tracker_layer_grads& gy = grads->layer[l];
         // LN2
-        launch_dw_partial(dwl, dH, tD, sc.XH2[l], tD, R, tD, tD, gy.norm2_w, gy.norm2_b, 1, sc.partial, s);   // diag(dH^T Xhat), column sums
         float* dY2 = sc.T1;
-        hipLaunchKernelGGL(ln_bwd, g1((long)R * tD), dim3(256), 0, s, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2);
+        launch_ln_bwd_dw(dwl, dH, sc.XH2[l], sc.RS2[l], y.norm2_w, R, dY2, gy.norm2_w, gy.norm2_b, sc.partial, s);   // + diag(dH^T Xhat), column sums
         // FF: with dropout the lin2 branch sees dY2 * mask2 / (1 - p) (the residual keeps dY2) and the gate of the hidden layer is
         // relu' * mask_ff / (1 - p): FF1 > 0 already encodes "relu active and kept", the scale is applied to dFF1
         const float* dB2 = dY2;
@@ -633,9 +669,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         // d H1N = dY2 (residual) + dFF1 * W1
         DW_ROWS(sc.H1N[l], tH, tD, gy.lin1_w, gy.lin1_b, false, sc.dFF1, tH, y.lin1_w, tD, nullptr, R, tH, tD, 0, nullptr, 1, dY2, tD);
         // LN1
-        launch_dw_partial(dwl, dY2, tD, sc.XH1[l], tD, R, tD, tD, gy.norm1_w, gy.norm1_b, 1, sc.partial, s);
         float* dY1 = sc.T2;
-        hipLaunchKernelGGL(ln_bwd, g1((long)R * tD), dim3(256), 0, s, dY2, sc.XH1[l], sc.RS1[l], y.norm1_w, R, dY1);
+        launch_ln_bwd_dw(dwl, dY2, sc.XH1[l], sc.RS1[l], y.norm1_w, R, dY1, gy.norm1_w, gy.norm1_b, sc.partial, s);
         // out_proj (its branch sees dY1 * mask1 / (1 - p); the residual keeps dY1)
         const float* dB1 = dY1;
         if (dc.on) {
