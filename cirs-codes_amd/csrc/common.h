@@ -123,8 +123,8 @@ __device__ __forceinline__ double jaccard_dist(uint32_t pa, uint32_t pb) {
 // By-value kernel arguments are read through the scalar cache, which is cold at every launch; the compiler fetches them piecemeal
 // at first use, so a kernel with a few hundred bytes of arguments starts with several DEPENDENT scalar-cache misses (~0.8 us
 // each on MI355X) before its first vector load goes out.  One dword of every 64-byte line of the first kBytes of the kernarg
-// segment, requested back to back at kernel entry, turns that into one round trip.  kBytes <= the kernel's explicit argument
-// bytes (the 256-byte implicit block behind them makes a rounded-up figure safe).
+// segment, requested back to back at kernel entry, turns that into one round trip.  kBytes must not exceed the kernel's explicit
+// argument bytes.
 template <int kBytes>
 __device__ __forceinline__ void kernarg_warm() {
     typedef const uint32_t __attribute__((address_space(4))) * kernarg_words;

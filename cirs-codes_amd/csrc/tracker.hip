@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     CIRS_STAMP(0);
     // ~1.1 KB of by-value arguments: five to eight dependent scalar-cache misses before the first vector load otherwise (common.h)
     kernarg_warm<sizeof(cirs_tracker_cfg) + sizeof(cirs_tracker_weights) + sizeof(cirs_tracker_state) + sizeof(TrunkFuse) + sizeof(TailFuse) +
-                 sizeof(TrkImg) + 96>();
+                 sizeof(TrkImg) + 64>();   // <= the explicit argument bytes (the eight pointer / integer arguments add 72)
     CIRS_STAMP(1);
     if (j >= n) return;
 // rows that do not step still owe the fused trunk its "skipped row" outputs
