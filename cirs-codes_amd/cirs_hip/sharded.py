@@ -126,7 +126,10 @@ class ShardedTable:
 
     def lookup(self, ids: torch.Tensor, cap: Optional[int] = None) -> torch.Tensor:
         """ids [n] int64 global row ids (>= 0) -> rows [n, row_floats].  cap: message slots per destination (default n = the worst
-        case, every id owned by one rank)."""
+        case, every id owned by one rank).  No host synchronisation: the per-owner counts are a one-hot column sum (torch.bincount
+        would read its output size back), and a cap smaller than the largest per-owner count does not index out of range -- the
+        overflowing requests are dropped (zero rows) and counted in `self.overflow` (device scalar); `check_overflow()` reads it
+        back and raises.  The FIRST call with a reduced cap checks eagerly (one sync) so that a wrong cap fails at once."""
         W = self.comm.world
         n = ids.numel()
         cap = n if cap is None else int(cap)
@@ -135,17 +138,36 @@ class ShardedTable:
         owner = ids % W
         order = torch.argsort(owner, stable=True)
         owner_s = owner[order]
-        counts = torch.bincount(owner, minlength=W)
+        counts = (owner.unsqueeze(1) == torch.arange(W, device=dev).unsqueeze(0)).sum(0)   # [W], stays on the device
         start = torch.cumsum(counts, 0) - counts
         pos_s = torch.arange(n, device=dev) - start[owner_s]           # slot inside the message to its owner
-        send = torch.full((W, cap), -1, dtype=torch.int64, device=dev)
-        send[owner_s, pos_s] = ids[order] // W
+        fits = pos_s < cap
+        if cap < n:
+            if self.overflow is None:
+                self.overflow = torch.zeros((), dtype=torch.int64, device=dev)
+                first = True
+            else:
+                first = False
+            self.overflow += (~fits).sum()
+            if first:
+                self.check_overflow()
+        # column `cap` is a dump slot for overflowing requests (never sent)
+        send_x = torch.full((W, cap + 1), -1, dtype=torch.int64, device=dev)
+        send_x[owner_s, torch.clamp(pos_s, max=cap)] = ids[order] // W
+        send = send_x[:, :cap].contiguous()
         recv = self.comm.all_to_all(send)                               # [W(src), cap] local row numbers requested from this rank
         rows = self.gather(self.local, recv.reshape(-1)).reshape(W, cap, -1)
         back = self.comm.all_to_all(rows)                               # [W(owner), cap, R]
         slot = torch.empty(n, dtype=torch.int64, device=dev)
-        slot[order] = owner_s * cap + pos_s
+        slot[order] = torch.where(fits, owner_s * cap + pos_s, torch.full_like(pos_s, -1))   # -1 -> zero row
         return self.gather(back.reshape(W * cap, -1), slot)
+
+    overflow: Optional[torch.Tensor] = None
+
+    def check_overflow(self):
+        """Host check of the dropped-request counter (one synchronisation): raises if any lookup exceeded its `cap`."""
+        if self.overflow is not None and int(self.overflow) > 0:
+            raise RuntimeError(f"ShardedTable.lookup: {int(self.overflow)} requests exceeded the per-destination capacity (cap too small)")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -267,6 +289,8 @@ class ShardedRollout:
         self._keep = [rows, emb_item, lin_item, feats, dur, scratch, items, recv, states, done_all]   # alive until the stream consumed them
 
     def collect(self, users: torch.Tensor, seed=0, rng_base=0):
+        if self.tracker.cfg.dropout_p > 0:   # masks per GLOBAL env of the job, fresh per collect (as DeviceRollout.collect)
+            self.tracker.set_dropout_key(seed, rng_base, self.rank * self.B)
         self.reset(users)
         for t in range(self.env.max_turn):
             self.step(t, seed, rng_base)

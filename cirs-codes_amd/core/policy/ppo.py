@@ -109,13 +109,19 @@ class PPOPolicy(nn.Module):
         trk = self._tracker
         if trk is None:
             return None
-        eng = trk.engine(trk._n_env or self._train_n_env or 1)
+        # the Adam moments are shared by every engine of the tracker (StateTrackerTransformer._train_state); a 1-env engine keyed by
+        # the tracker itself creates them when no collector has built one yet -- never a full-size owner-less engine (it would
+        # allocate K/V caches nobody uses and redirect the per-step build_state protocol to another env count)
+        if trk._train_state is None:
+            trk.engine(1, owner=trk)
+        _, _, _, adam_m, adam_v = trk._train_state
 
         def set_steps(steps):
             if steps:
                 trk.adam_steps = steps[0][1]
-                eng.adam_steps = trk.adam_steps
-        return dict(flat=trk.flat, m=eng.adam_m, v=eng.adam_v, steps=lambda off: trk.adam_steps, set_steps=set_steps)
+                for eng in trk._engines.values():
+                    eng.adam_steps = trk.adam_steps
+        return dict(flat=trk.flat, m=adam_m, v=adam_v, steps=lambda off: trk.adam_steps, set_steps=set_steps)
 
     # ---- protocol pieces the Collector / trainer call ----------------------------------------------------------------
     def device_policy(self) -> DevicePolicy:

@@ -38,6 +38,9 @@ class StateTrackerTransformer(nn.Module):
         self._n_env = None
         self._train_state = None  # (flat_grad, grad_views, adam_m, adam_v) shared by whichever engine runs the backward
         self.adam_steps = 0
+        # key of the dropout masks of the per-step protocol (build_state without a DeviceRollout): (seed, reset counter) -- every
+        # reset starts a rollout with fresh masks, like the reference's fresh nn.Dropout noise at every call
+        self._drop_seed, self._drop_resets = int(seed), 0
 
     def _register(self, dotted, param):
         mod = self
@@ -97,7 +100,12 @@ class StateTrackerTransformer(nn.Module):
     def build_state(self, obs=None, env_id=None, obs_next=None, rew=None, done=None, info=None, policy=None, dim_batch=None,
                     reset=False):
         if reset and dim_batch:
-            self.engine(dim_batch).reset()
+            eng = self.engine(dim_batch)
+            eng.reset()
+            # the per-step engine is keyed here (DeviceRollout.collect keys the fused one): without it every episode of the
+            # stepwise protocol (Collector.collect(random=True), external preprocess_fn users) would reuse the masks of key 0
+            self._drop_resets += 1
+            eng.set_dropout_key(self._drop_seed, (1 << 40) + self._drop_resets, 0)
             return
         eng = self.engine(self._n_env)
         ids = None if env_id is None else torch.as_tensor(np.asarray(env_id).astype(np.int32)).to(self.device)

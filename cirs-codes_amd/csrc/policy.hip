@@ -199,7 +199,7 @@ extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const
     if (n <= 0) return CIRS_OK;
     CIRS_REQUIRE(state && tuples_out && workspace, "null state/tuples/workspace");
     CIRS_REQUIRE(state_stride >= cfg_shard->dim_state, "state_stride < dim_state");
-    CIRS_REQUIRE(item_base >= 0 && (item_base & 31) == 0, "item_base must be a non-negative multiple of 32");
+    CIRS_REQUIRE(item_base >= 0 && (item_base % CIRS_SAMPLER_CHUNK) == 0, "item_base must be a non-negative multiple of the sampler chunk (128 items)");
     CIRS_REQUIRE(n_items_total >= item_base + cfg_shard->n_items, "n_items_total < item_base + shard size");
     CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(cfg_shard, n), "workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -210,7 +210,6 @@ extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const
     hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, *cfg_shard, *w_shard, state, (long)state_stride, n, skip, h2,
                        value_out, nullptr);
     CIRS_CHECK_LAUNCH("trunk_kernel");
-    CIRS_REQUIRE((item_base % CIRS_SAMPLER_CHUNK) == 0, "item_base must be a multiple of the sampler chunk (128 items)");
     const int nch = n_chunks_of(cfg_shard->n_items);
     const int cpw = mass_chunks_per_wg(nch, hg.n_row_blocks);
     hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg_shard, w_shard->wa, w_shard->ba,

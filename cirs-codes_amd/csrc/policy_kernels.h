@@ -451,7 +451,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
                 for (int r = 0; r < 16; ++r) acc[t][r] = sB[buf][(r & 3) + 8 * (r >> 2) + 4 * hi];
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc[t], 0, 0, 0);
-                vis[t] = (visited && active) ? visited[(size_t)e * vis_words + ((item_base + tile0) >> 5)] : 0u;
+                vis[t] = (visited && active && tile0 < I) ? visited[(size_t)e * vis_words + ((item_base + tile0) >> 5)] : 0u;   // tiles beyond the catalogue: no word exists
             }
             CIRS_MSTAMP(3 + 2 * t);
             if (more) CIRS_COMMIT(buf ^ 1);

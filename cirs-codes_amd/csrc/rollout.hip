@@ -165,8 +165,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     // overlaps another group's mass kernel.  Results are identical to G = 1 (tests/test_gpu_rollout.py).
     int G = 1;
     if (!gumbel) {
-        static int forced = -1;
-        if (forced < 0) { const char* ev = getenv("CIRS_ROLLOUT_GROUPS"); forced = ev ? atoi(ev) : 0; }
+        static const int forced = [] { const char* ev = getenv("CIRS_ROLLOUT_GROUPS"); return ev ? atoi(ev) : 0; }();   // thread-safe magic static
         // measured at C3 (1024 envs): rollout alone 1.96 ms (G = 1), 1.81 ms (2), 1.87 ms (4); the whole step (rollout + update)
         // 8.82 / 8.93 / 10.46 ms -- the additional launches and the fork / join of the streams cost more host and queue time than the
         // overlap returns, so one group is the default and CIRS_ROLLOUT_GROUPS opts in
@@ -184,8 +183,18 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     // caller's stream, before the group streams fork from it
     float* img = (float*)((char*)workspace + ((workspace_bytes - kTrkImgBytes) & ~(int64_t)255));
     if (int rc = pack_tracker_image(trk_cfg, trk_w, pol_w, S, img, s)) return rc;
-    static hipStream_t gs[kMaxGroups] = {};
-    static hipEvent_t gev[kMaxGroups + 1] = {};
+    // group streams / events: one set per (host thread, device) -- a stream belongs to the device that was current when it was
+    // created, and two host threads driving rollouts concurrently (the virtual-rank tests) must not share the event array
+    constexpr int kMaxDevices = 16;
+    struct GroupQueues { hipStream_t gs[kMaxGroups]; hipEvent_t gev[kMaxGroups + 1]; };
+    static thread_local GroupQueues tl_queues[kMaxDevices] = {};
+    int cur_dev = 0;
+    if (G > 1) {
+        CIRS_HIP(hipGetDevice(&cur_dev));
+        CIRS_REQUIRE(cur_dev >= 0 && cur_dev < kMaxDevices, "CIRS_ROLLOUT_GROUPS > 1 supports device ids below 16");
+    }
+    hipStream_t* gs = tl_queues[cur_dev].gs;
+    hipEvent_t* gev = tl_queues[cur_dev].gev;
     if (G > 1) {
         for (int g = 1; g < G; ++g)
             if (!gs[g]) CIRS_HIP(hipStreamCreateWithFlags(&gs[g], hipStreamNonBlocking));

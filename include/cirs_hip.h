@@ -208,7 +208,8 @@ int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, 
  * id mod W, per step an all-to-all of requested ids and returned rows".  Semantics to match: cirs_actor_sample on one device.
  *
  * cirs_actor_shard_partials: THIS rank's item shard (cfg_shard->n_items items whose first global id is item_base, a multiple of
- * 32; w_shard->wa / ba = the shard's rows, trunk / critic weights replicated) against n env rows (all envs of the job; env_ids =
+ * 128 = the sampler's chunk (chunk ids are item_base / 128: every shard but the last must hold a multiple of 128 items);
+ * w_shard->wa / ba = the shard's rows, trunk / critic weights replicated) against n env rows (all envs of the job; env_ids =
  * their global ids).  Noise counters, the visited bitmap and candidate ids use GLOBAL item ids, so a shard computes exactly what
  * the full kernel computes for its items.  tuples_out [5, n] f32: {noisy score, candidate id (int32 bits), candidate logit,
  * running max, running sum-exp}.  cirs_actor_merge_shards: tuples [n_shards, 5, n] folded in shard order -> act (argmax of the

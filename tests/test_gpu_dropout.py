@@ -106,3 +106,30 @@ def test_engine_dropout_mode_keys_and_determinism():
     assert torch.equal(eng.policy_flat, eng2.policy_flat) and torch.equal(eng.tracker_flat, eng2.tracker_flat)
     eng0, _ = run(0.0)
     assert not torch.equal(eng0.rollout.traj.obs, eng.rollout.traj.obs)
+
+
+def test_stepwise_protocol_draws_fresh_masks_per_episode():
+    """the per-step build_state protocol (Collector.collect(random=True), external preprocess_fn users) must key
+    the dropout masks per reset -- two consecutive episodes with the SAME users / actions / rewards must not reuse the same masks
+    (the reference draws fresh nn.Dropout noise on every call); eval() stays deterministic."""
+    from core.inputs import SparseFeatP
+    from core.state_tracker import StateTrackerTransformer
+    U, I, B, T = 30, 40, 6, 8
+    st = StateTrackerTransformer([SparseFeatP("feat_user", U, embedding_dim=32)], [SparseFeatP("feat_item", I, embedding_dim=32)],
+                                 [], 32, 20, B, dropout=0.1, nhead=4, device="cuda", MAX_TURN=T, init_std=0.5)
+    rng = np.random.RandomState(0)
+    users, acts, rews = rng.randint(0, U, B), rng.randint(0, I, (T, B)), rng.uniform(0, 1, (T, B))
+
+    def episode():
+        st.build_state(reset=True, dim_batch=B)
+        out = [st.build_state(obs=users, env_id=np.arange(B))["obs"].cpu().numpy()]
+        for t in range(T):
+            out.append(st.build_state(obs_next=acts[t], rew=rews[t], env_id=np.arange(B))["obs_next"].cpu().numpy())
+        return np.stack(out)
+
+    st.train()
+    a, b = episode(), episode()
+    assert np.abs(a - b).max() > 1e-6, "two stepwise episodes reused the same dropout masks"
+    st.eval()
+    c, d = episode(), episode()
+    assert np.array_equal(c, d)

@@ -61,3 +61,33 @@ def test_sharded_table_lookup_world2():
         p.join(120)
     res = sorted(q.get(timeout=5) for _ in range(world))
     assert res == [(0, True), (1, True)], res
+
+
+class _LoopComm:
+    """world 1: every collective is the identity (single process, no process group)."""
+    world, rank = 1, 0
+
+    def all_gather(self, t):
+        return t.unsqueeze(0)
+
+    def all_to_all(self, t):
+        return t
+
+
+def test_lookup_reduced_capacity_overflow_is_detected_not_out_of_range():
+    """A capacity smaller than the largest per-owner count must not index out of range: overflowing requests are
+    dropped (zero rows), counted on the device, and the first reduced-capacity call raises a clear error."""
+    sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd"))
+    from cirs_hip.sharded import ShardedTable
+    full = torch.arange(50 * 4, dtype=torch.float32).reshape(50, 4) + 1
+    tab = ShardedTable(full.clone(), 50, _LoopComm(), gather=_torch_gather)
+    ids = torch.arange(10)
+    assert torch.equal(tab.lookup(ids, cap=10), full[ids])
+    assert torch.equal(tab.lookup(ids, cap=12), full[ids])
+    tab2 = ShardedTable(full.clone(), 50, _LoopComm(), gather=_torch_gather)
+    with pytest.raises(RuntimeError, match="capacity"):
+        tab2.lookup(ids, cap=6)
+    # later calls do not sync; the rows that fitted are right, the dropped ones are zero rows, the counter keeps counting
+    got = tab2.lookup(ids, cap=6)
+    assert torch.equal(got[:6], full[:6]) and float(got[6:].abs().sum()) == 0.0
+    assert int(tab2.overflow) == 8
