@@ -61,7 +61,7 @@ def pmc_traffic(workload):
     return {k: int(v["bytes_per_launch"]) for k, v in z["kernels"].items()}, f"profiles/pmc_traffic.json ({z.get('taken', '?')}; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
-def build_engine(wl, rank, world, device):
+def build_engine(wl, rank, world, device, learner="dp", dropout=0.0):
     from cirs_hip.engine import CirsEngine
     from cirs_hip.env import DeviceEnvTables
     from cirs_hip.synthetic import make_tables
@@ -73,7 +73,7 @@ def build_engine(wl, rank, world, device):
                          build_dist_on_device=True)
     eng = CirsEngine(dt, wl["B"], max_turn=wl["T"], num_leave_compute=wl["N"], leave_threshold=wl["thr"], tau=wl["tau"],
                      gamma_exposure=wl["gamma_exposure"], seed=2023, world_size=world, rank=rank,
-                     dist_group=None)
+                     dist_group=None, learner_mode=learner, dropout=dropout)
     return eng, tab
 
 
@@ -301,6 +301,7 @@ def cpu_baseline(wl, eng):
     if os.path.exists(ref_json):
         ref = json.load(open(ref_json))
     return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["cores"], "host_cores": host, "kind": "port",
+            "envs_gpu_leg": wl["B"], "envs_cpu_leg": best["envs"], "envs_cpu_single_thread_leg": legs[0]["envs"],
             "sample": f"1 step (collect + update, same tables / policy / tracker weights as the GPU leg) with {best['envs']} envs on the {wl['U']}x{wl['I']} tables: "
                       f"{best['env_steps']} env-steps, {best['minibatches']} PPO minibatch steps in {best['seconds']:.1f}s "
                       "(C oracle env/actor via OpenMP, torch-fp32 tracker/PPO restatement)",
@@ -316,6 +317,16 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--learner", default="dp", choices=["dp", "dp_sharded", "replicated"],
+                    help="N > 1 only: how the PPO update runs over the gathered buffer.  Every mode keeps the reference's PPO configuration "
+                         "(global minibatch = --global-batch rows): dp = rows of each minibatch sharded over the ranks + one gradient all-reduce; "
+                         "dp_sharded = reduce-scatter + sharded Adam + parameter all-gather; replicated = every rank runs the whole update")
+    ap.add_argument("--global-batch", type=int, default=1024, help="PPO minibatch size over ALL ranks (reference batch_size, CIRS-RL-kuaishou.py:89)")
+    ap.add_argument("--dropout", type=float, default=0.0, help="tracker dropout probability (0 = eval-mode tracker of the parity fixtures; "
+                                                               "0.1 = the mode the reference trains in, SURVEY Q7)")
+    ap.add_argument("--scaled-batch-steps", type=int, default=-1,
+                    help="N > 1: extra steps timed with the global minibatch scaled to --global-batch x N (constant optimiser steps per update; "
+                         "reported under scaled_batch_variant, never as value).  -1 = min(steps, 5), 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true", help="skip the secondary probes (gather_fm / sweep / cpu baseline): contract line only")
     args = ap.parse_args()
@@ -336,9 +347,15 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if share_gpu else "nccl", rank=rank, world_size=world)  # nccl = RCCL over xGMI
+        # nccl = RCCL over xGMI; device_id binds the communicator to this rank's GPU at creation (no lazy init on first use, no
+        # ambiguity about which device a rank drives)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    eng, tab = build_engine(wl, rank, world, device)
+    G = int(args.global_batch)
+    eng, tab = build_engine(wl, rank, world, device, learner=args.learner, dropout=args.dropout)
 
     def barrier():
         if world > 1:
@@ -347,7 +364,7 @@ def main():
 
     def one_step():
         eng.collect()
-        losses, n = eng.update(batch_size=1024, repeat=2)
+        losses, n = eng.update(batch_size=G, repeat=2)
         return losses.shape[0]
 
     for _ in range(args.warmup):
@@ -359,7 +376,7 @@ def main():
     t_collect = 0.0
     for _ in range(args.steps):
         eng.collect()
-        losses, n = eng.update(batch_size=1024, repeat=2)
+        losses, n = eng.update(batch_size=G, repeat=2)
         steps_local += n   # rows of the update = env-steps of this collect over ALL ranks (update() reads the lengths back once)
         mb_steps += losses.shape[0]
     barrier()
@@ -378,6 +395,28 @@ def main():
         dist.all_gather(allh, h)
         ranks_identical = all(bool(torch.equal(allh[0], x)) for x in allh)
 
+    # N > 1, extra: the same job with the global minibatch scaled by the number of ranks (G x N rows: the number of optimiser steps per
+    # update stays that of one GPU).  A DIFFERENT PPO configuration than BASELINE's -- reported beside the headline, never as `value`.
+    scaled = None
+    k_scaled = (min(args.steps, 5) if args.scaled_batch_steps < 0 else args.scaled_batch_steps) if world > 1 else 0
+    if k_scaled > 0:
+        eng.collect(); eng.update(batch_size=G * world, repeat=2)
+        barrier()
+        ts = time.perf_counter()
+        n_s, mb_s = 0, 0
+        for _ in range(k_scaled):
+            eng.collect()
+            l_s, nn_s = eng.update(batch_size=G * world, repeat=2)
+            n_s += nn_s; mb_s += l_s.shape[0]
+        barrier()
+        el_s = time.perf_counter() - ts
+        t = torch.tensor([el_s], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_s = float(t)
+        scaled = {"global_minibatch": G * world, "steps": k_scaled, "env_steps_per_s": n_s / el_s, "ms_per_step": 1e3 * el_s / k_scaled,
+                  "minibatch_steps_per_update": mb_s / k_scaled,
+                  "note": "PPO batch_size scaled by the number of ranks: NOT the reference's configuration, shown for the Amdahl comparison only"}
+
     # split (untimed extra pass, same state): rollout-only and update-only rates
     barrier()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -390,7 +429,7 @@ def main():
     t_ro = ev[0].elapsed_time(ev[1]) * 1e-3 / reps_ro
     n_ro = int(eng.lengths.sum())    # env-steps of the LAST of the collects (same policy: the others differ by sampling noise only)
     tb = time.perf_counter()
-    l2, n2 = eng.update(1024, 2); torch.cuda.synchronize(); tc = time.perf_counter()
+    l2, n2 = eng.update(G, 2); torch.cuda.synchronize(); tc = time.perf_counter()
 
     if rank == 0:
         t_mb, mb, t_k = hip_event_kernel_time(eng, wl)
@@ -412,9 +451,16 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (policy/tracker; rollout on the fp32 MFMA, PPO head products fp32-accurate from 3 bf16 pieces per operand on the bf16 MFMA, fp32 accumulate) + f64 (env rewards, GAE)", "data": "synthetic",
             "config": {"workload": wl["name"], "envs_total": wl["B"] * world,
-                       "parallelism": (f"env-sharded x{world}; one all-gather of trajectory records per update; data-parallel learner: "
-                                       f"global minibatch = 1024 x {world} rows sharded by rows, one flat-gradient all-reduce per minibatch")
+                       "learner": args.learner if world > 1 else "single",
+                       "global_minibatch": G, "minibatch_steps_per_update": mb_steps / args.steps,
+                       "rows_per_rank_per_minibatch": G if (world == 1 or args.learner == "replicated") else G / world,
+                       "ppo_repeat": 2, "tracker_dropout": args.dropout,
+                       "parallelism": (f"env-sharded x{world}; one all-gather of trajectory records per update; learner '{args.learner}': "
+                                       + {"dp": f"global minibatch of {G} rows sharded by rows over the ranks, one flat-gradient all-reduce per minibatch",
+                                          "dp_sharded": f"global minibatch of {G} rows sharded by rows, reduce-scatter + sharded Adam + parameter all-gather per minibatch",
+                                          "replicated": f"every rank runs all minibatches of {G} rows on the gathered buffer (no further communication)"}[args.learner])
                        if world > 1 else "single GPU"},
+            "dropout": args.dropout,
             "ppo_minibatch_steps_per_s": mb_steps / elapsed, "rank_parameters_bit_identical": ranks_identical,
             "rollout_only_env_steps_per_s": n_ro / t_ro, "rollout_only_ms_per_collect": 1e3 * t_ro,
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
@@ -439,6 +485,11 @@ def main():
         out["minibatch_step"]["traffic"] = sum(traffic.get(k, 0) for k in MINIBATCH_KERNELS) if traffic and all(k in traffic for k in MINIBATCH_KERNELS) else None
         if traffic:
             out["hbm_traffic_per_launch"] = {k: v for k, v in traffic.items() if k.split("<")[0] in ("actor_head_kernel", "actor_mass_kernel", "tracker_step_kernel", "sweep_kernel", "gather_fm_kernel")}
+        if scaled is not None:
+            out["scaled_batch_variant"] = scaled
+        if world > 1:
+            out["collectives_per_rank"] = {"calls": dict(eng.coll.calls), "bytes": dict(eng.coll.bytes),
+                                           "note": "totals over warm-up, timed and extra steps of this process"}
         if world == 1 and not args.no_probes:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
             out["gather_fm"] = gather_fm_probe(device)
             out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)

@@ -49,12 +49,81 @@ def unpack_records(buf: torch.Tensor, world: int, T: int, B_local: int, S: int, 
     return out
 
 
-def all_gather_records(fields: Dict[str, torch.Tensor], T: int, B_local: int, S: int, D: int, group=None) -> Dict[str, torch.Tensor]:
-    """The single collective of the data path: all-gather of the packed per-rank trajectory records."""
+def all_gather_records(fields: Dict[str, torch.Tensor], T: int, B_local: int, S: int, D: int, group=None, coll=None) -> Dict[str, torch.Tensor]:
+    """The single collective of the data path: all-gather of the packed per-rank trajectory records (through `coll`, a
+    Collectives, when given: same explicit stream ordering as the learner's collectives)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     local = pack_records(fields)
     if world == 1:
         return unpack_records(local.unsqueeze(0), 1, T, B_local, S, D)
     gathered = torch.empty(world * local.numel(), dtype=torch.uint8, device=local.device)
-    dist.all_gather_into_tensor(gathered, local, group=group)
+    if coll is not None:
+        coll.all_gather(gathered, local)
+    else:
+        dist.all_gather_into_tensor(gathered, local, group=group)
     return unpack_records(gathered.view(world, local.numel()), world, T, B_local, S, D)
+
+
+class Collectives:
+    """The learner's collectives over torch.distributed (backend "nccl" = RCCL over xGMI on MI355X, gloo on CPU / shared-GPU tests).
+
+    Stream ordering, made explicit: every libcirs_hip launch goes to torch's CURRENT stream of the device (the `_stream()` of the
+    engines reads it at every call) and every collective here is issued with async_op=True followed by `work.wait()`, i.e.
+      * c10d records an event on the current stream when the collective is enqueued and makes its communication stream wait for it
+        (the gradients written by the preceding launches are complete before RCCL reads them), and
+      * `work.wait()` makes the current stream wait for the collective's completion event -- without blocking the host --, so the next
+        library launch on that stream sees the reduced data.
+    `check=True` (CIRS_DIST_CHECK=1) additionally asserts, per call, that the stream current at the call is the one the engines were
+    bound to, and -- with events recorded on it before and after the collective -- that the "before" event has completed whenever the
+    "after" event has (the collective did not overtake the launches it depends on)."""
+
+    def __init__(self, group=None, device=None, check=None):
+        import os
+        self.group, self.device = group, (torch.device(device) if device is not None else None)
+        self.check = (os.environ.get("CIRS_DIST_CHECK", "0") == "1") if check is None else bool(check)
+        self._bound = None
+        self.calls = {"all_reduce": 0, "reduce_scatter": 0, "all_gather": 0}
+        self.bytes = {"all_reduce": 0, "reduce_scatter": 0, "all_gather": 0}
+
+    def _backend(self):
+        try:
+            return dist.get_backend(self.group)
+        except Exception:   # noqa: BLE001  (patched / uninitialised in the virtual-rank tests)
+            return "nccl"
+
+    def _ordered(self, kind, t, issue):
+        self.calls[kind] += 1
+        self.bytes[kind] += t.numel() * t.element_size()
+        cuda = t.is_cuda
+        if cuda:
+            cur = torch.cuda.current_stream(t.device)
+            if self._bound is None:
+                self._bound = cur.cuda_stream
+            assert cur.cuda_stream == self._bound, "collective issued on another stream than the library launches it orders against"
+            if self.check:
+                before = torch.cuda.Event(); before.record(cur)
+        work = issue()
+        if work is not None:
+            work.wait()          # current stream waits for the collective; the host does not
+        if cuda and self.check:
+            after = torch.cuda.Event(); after.record(cur)
+            after.synchronize()
+            assert before.query(), "stream order violated: work enqueued before the collective is still pending after it"
+
+    def all_reduce(self, t):
+        self._ordered("all_reduce", t, lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def all_gather(self, out, inp):
+        self._ordered("all_gather", out, lambda: dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True))
+
+    def reduce_scatter(self, out, inp):
+        if self._backend() == "gloo":     # gloo has no reduce_scatter: all-reduce + own slice (shared-GPU / CPU tests only)
+            def issue():
+                tmp = inp.clone()
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                r = dist.get_rank(self.group)
+                out.copy_(tmp[r * out.numel():(r + 1) * out.numel()])
+                return None
+            self._ordered("reduce_scatter", inp, issue)
+            return
+        self._ordered("reduce_scatter", inp, lambda: dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

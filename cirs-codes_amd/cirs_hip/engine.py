@@ -81,10 +81,18 @@ class CirsEngine:
         self.world, self.rank, self.group = world_size, rank, dist_group
         self.force_gather = force_gather  # exercise the packed all-gather path even with one rank (tests)
         self.force_dp = force_gather and os.environ.get("CIRS_FORCE_DP", "0") == "1"   # + the data-parallel learner with one rank (tests)
-        # "dp": global minibatch = batch_size * world rows, sharded by rows, gradients all-reduced per minibatch;
-        # "replicated": every rank runs the identical learner on the gathered buffer (no further communication)
-        assert learner_mode in ("dp", "replicated")
+        # Learners over the gathered buffer.  In EVERY mode `update(batch_size)` means the reference's PPO configuration: global
+        # minibatches of batch_size rows (CIRS-RL-kuaishou.py:89, core/policy/ppo.py:180-181), however many ranks there are.
+        #   "dp":         each global minibatch is sharded by rows (rank r takes rows r::W), ONE all-reduce of the flat gradient per
+        #                 minibatch, identical clip + Adam on every rank
+        #   "dp_sharded": same gradients; reduce-scatter -> clip + Adam on this rank's 1/W of the parameters -> all-gather of the
+        #                 parameter shards (Adam moments sharded)
+        #   "replicated": every rank runs the identical single-device learner on the gathered buffer (no further communication)
+        # (the batch_size x W variant that keeps the number of optimiser steps per update constant is the caller's choice:
+        #  update(batch_size * W); bench.py reports it as an extra key, never as the headline)
+        assert learner_mode in ("dp", "dp_sharded", "replicated")
         self.learner_mode = learner_mode
+        self.coll = distributed.Collectives(group=dist_group, device=self.device)
         self.env = DeviceEnv(tables, n_env, num_leave_compute=num_leave_compute, leave_threshold=leave_threshold,
                              max_turn=max_turn, tau=tau, gamma_exposure=gamma_exposure, version=version, r_decay=r_decay)
         tp = tracker_params or init_tracker_params(U, I, max_turn, seed=seed, dim_model=dim_model, dim_state=dim_state, nhead=nhead)
@@ -95,7 +103,7 @@ class CirsEngine:
                                      dropout_p=dropout)
         self.tracker.enable_training(self.tracker_flat, lr=lr)
         pp = policy_params or init_policy_params(I, seed=seed, dim_state=dim_state, hidden=hidden)
-        self.policy_flat, pviews = flat_policy_params(I, dim_state, hidden, device=self.device, init=pp)
+        self.policy_flat, pviews = flat_policy_params(I, dim_state, hidden, device=self.device, init=pp, world=world_size)
         self.policy_views = pviews
         self.tracker_views = tviews
         self.policy = DevicePolicy(pviews, I, dim_state=dim_state, hidden=hidden, device=self.device)
@@ -105,7 +113,8 @@ class CirsEngine:
         self.B_total = n_env * world_size
         self.learner = DeviceLearner(self.policy_flat, I, self.B_total, max_turn, dim_state=dim_state, hidden=hidden, gamma=gamma,
                                      gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
-                                     max_grad_norm=max_grad_norm, lr=lr, norm_adv=norm_adv, value_clip=value_clip, rew_norm=rew_norm)
+                                     max_grad_norm=max_grad_norm, lr=lr, norm_adv=norm_adv, value_clip=value_clip, rew_norm=rew_norm,
+                                     world=world_size)
         # size every lazily grown buffer for the worst case now (B*T rows, merged last minibatch < 2*batch_size):
         # no allocation (= implicit device sync) ever happens inside the collect/update loop
         self.learner.reserve(self.B_total * max_turn, 2 * batch_size_hint)
@@ -165,7 +174,7 @@ class CirsEngine:
             return tr, self.tracker.x_hist, self.lengths, self.users
         fields = dict(obs=tr.obs, act=tr.act, rew=tr.rew, done=tr.done, logp=tr.logp, value=tr.value, ctr=tr.ctr,
                       x_hist=self.tracker.x_hist, lens=self.lengths.to(torch.int32), users=self.users)
-        g = distributed.all_gather_records(fields, self.max_turn, self.n_env, self.S, self.D, group=self.group)
+        g = distributed.all_gather_records(fields, self.max_turn, self.n_env, self.S, self.D, group=self.group, coll=self.coll)
         if self._gtraj is None:
             self._gtraj = Trajectory(self.B_total, self.max_turn, self.S, self.device)
         gt = self._gtraj
@@ -183,7 +192,7 @@ class CirsEngine:
             # identical permutations on every rank (same key): learners stay bit-identical
             ln.perm_seed, ln.perm_tag = self.seed * 7919 + 1, self.collect_count * 64
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
-        if (self.world > 1 or self.force_dp) and self.learner_mode == "dp":
+        if (self.world > 1 or self.force_dp) and self.learner_mode in ("dp", "dp_sharded"):
             return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms)
         losses = ln.learn(batch_size, repeat, perms=perms)
         self.tracker.backward(users, traj, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs,
@@ -192,15 +201,15 @@ class CirsEngine:
         return losses, n
 
     def _update_dp(self, traj, lens, offsets, n, batch_size, repeat, perms):
-        """Data-parallel learner: per global minibatch one all-reduce of the flat policy gradients; per update one
-        all-reduce of d loss/d obs and one of the tracker gradients.  Every rank applies identical updates."""
-        import torch.distributed as dist
+        """Data-parallel learner over global minibatches of batch_size rows: per minibatch one all-reduce of the flat policy
+        gradients ("dp") or reduce-scatter + sharded Adam + all-gather ("dp_sharded"); per update one all-reduce of d loss/d obs and
+        one of the tracker gradients.  Every rank ends with identical parameters."""
         ln = self.learner
-
-        def all_reduce(t):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-
-        losses = ln.learn_dp(batch_size, repeat, perms, self.rank, self.world, all_reduce)
+        all_reduce = self.coll.all_reduce
+        if self.learner_mode == "dp_sharded":
+            losses = ln.learn_dp_sharded(batch_size, repeat, perms, self.rank, self.world, self.coll)
+        else:
+            losses = ln.learn_dp(batch_size, repeat, perms, self.rank, self.world, all_reduce)
         all_reduce(ln.dobs)  # each (t, env) row was written by exactly one rank
         # tracker backward over THIS rank's envs only (its own trajectory / slots), then sum the gradients
         Bl = self.n_env

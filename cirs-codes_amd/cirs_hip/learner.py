@@ -14,12 +14,19 @@ FLAT_ORDER = ["w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc"]
 FIELD_TO_NAME = dict(POLICY_FIELDS)
 
 
-def flat_policy_params(n_items, dim_state=20, hidden=64, device="cuda", init: Optional[Dict[str, torch.Tensor]] = None):
-    """Allocate the flat fp32 parameter buffer and return (flat, {reference state_dict name: view})."""
+def padded_param_count(total, world):
+    """P_pad: the flat gradient incl. its 4 loss partials, rounded up so that `world` equal shards are whole float4s."""
+    q = 4 * max(1, int(world))
+    return (total + 4 + q - 1) // q * q
+
+
+def flat_policy_params(n_items, dim_state=20, hidden=64, device="cuda", init: Optional[Dict[str, torch.Tensor]] = None, world=1):
+    """Allocate the flat fp32 parameter buffer and return (flat, {reference state_dict name: view}).  The allocation holds
+    padded_param_count(P, world) floats (flat = its first P): the sharded optimiser all-gathers parameter shards straight into it."""
     shapes = dict(w1=(hidden, dim_state), b1=(hidden,), w2=(hidden, hidden), b2=(hidden,), wa=(n_items, hidden),
                   ba=(n_items,), wc=(1, hidden), bc=(1,))
     total = sum(int(np.prod(shapes[k])) for k in FLAT_ORDER)
-    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    flat = torch.zeros(padded_param_count(total, world), dtype=torch.float32, device=device)[:total]
     views, off = {}, 0
     for k in FLAT_ORDER:
         n = int(np.prod(shapes[k]))
@@ -47,7 +54,7 @@ def minibatch_slices(n, batch_size):
 class DeviceLearner:
     def __init__(self, flat_params: torch.Tensor, n_items, n_env, max_turn, *, dim_state=20, hidden=64, gamma=0.99,
                  gae_lambda=0.95, eps_clip=0.2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=None, lr=1e-3, norm_adv=True,
-                 value_clip=False, rew_norm=False, betas=(0.9, 0.999), adam_eps=1e-8):
+                 value_clip=False, rew_norm=False, betas=(0.9, 0.999), adam_eps=1e-8, world=1):
         self.device = flat_params.device
         self.cfg = abi.PpoCfg(n_items=n_items, dim_state=dim_state, hidden=hidden, norm_adv=int(bool(norm_adv)),
                               value_clip=int(bool(value_clip)), rew_norm=int(bool(rew_norm)), gamma=gamma,
@@ -57,9 +64,20 @@ class DeviceLearner:
         self._lib = abi.lib()
         assert flat_params.numel() == self._lib.cirs_ppo_param_count(C.byref(self.cfg))
         self.params = flat_params
-        self.grads = torch.zeros(flat_params.numel() + 4, dtype=torch.float32, device=self.device)  # + loss partials tail
-        self.adam_m = torch.zeros_like(flat_params)
-        self.adam_v = torch.zeros_like(flat_params)
+        # flat gradient + 4 loss partials, padded to `world` equal float4-aligned shards (the padding stays zero); the Adam moments
+        # and -- when the caller allocated it that way (flat_policy_params(world=...)) -- the parameters have the same padded extent,
+        # so that shard r of every buffer is the slice [r * P_pad / world, (r + 1) * P_pad / world)
+        P = flat_params.numel()
+        self.P, self.P_pad, self.world = P, padded_param_count(P, world), int(world)
+        self.grads = torch.zeros(self.P_pad, dtype=torch.float32, device=self.device)
+        self._m_pad = torch.zeros(self.P_pad, dtype=torch.float32, device=self.device)
+        self._v_pad = torch.zeros(self.P_pad, dtype=torch.float32, device=self.device)
+        self.adam_m, self.adam_v = self._m_pad[:P], self._v_pad[:P]
+        st = flat_params.untyped_storage()
+        if flat_params.storage_offset() == 0 and st.nbytes() >= 4 * self.P_pad and flat_params.is_contiguous():
+            self._p_pad = torch.empty(0, dtype=torch.float32, device=self.device).set_(st, 0, (self.P_pad,), (1,))
+        else:
+            self._p_pad = None   # sharded optimiser then gathers into a scratch buffer and copies P floats back
         self.opt_step = 0
         self.perm_seed, self.perm_tag = 20230, 0   # key of the minibatch shuffles (see _perms_on_device)
         self.n_env, self.max_turn, self.S = n_env, max_turn, dim_state
@@ -153,11 +171,12 @@ class DeviceLearner:
             self.perm_tag += 1
         return out
 
-    def learn_dp(self, batch_size, repeat, perms, rank, world, all_reduce, want_tracker_grad=True):
-        """Data-parallel learn(): global minibatches of batch_size*world rows, rows rank::world of each belong to this
-        rank; `all_reduce(tensor)` sums a flat tensor over the ranks in place (torch.distributed.all_reduce)."""
+    def learn_dp(self, global_batch, repeat, perms, rank, world, all_reduce, want_tracker_grad=True):
+        """Data-parallel learn(): GLOBAL minibatches of `global_batch` rows (the reference's batch_size, CIRS-RL-kuaishou.py:89 /
+        core/policy/ppo.py:180-181: the PPO configuration does not change with the number of ranks), rows rank::world of each
+        belong to this rank; `all_reduce(tensor)` sums a flat tensor over the ranks in place (torch.distributed.all_reduce)."""
         n = self.n_rows
-        slices = minibatch_slices(n, batch_size * world)
+        slices = minibatch_slices(n, global_batch)
         losses = torch.zeros((repeat * len(slices), 4), dtype=torch.float32, device=self.device)
         perm_all_d = self._perms_on_device(n, repeat, perms)
         k = 0
@@ -173,6 +192,58 @@ class DeviceLearner:
                 self.mb_phase1(l_idx, g_idx, last and want_tracker_grad, losses[k])
                 all_reduce(self.grads)
                 self.mb_phase2(int(l_idx.numel()), int(g_idx.numel()), losses[k])
+                k += 1
+        return losses
+
+    def learn_dp_sharded(self, global_batch, repeat, perms, rank, world, coll, want_tracker_grad=True):
+        """learn_dp with the optimiser sharded over the ranks (ZeRO-1 form): per global minibatch
+            phase 1                                  this rank's row shard -> flat gradient (+ loss partials)
+            reduce_scatter(grads[P_pad])             -> this rank's summed shard of P_pad / world floats
+            cirs_ppo_shard_norm + all_gather(stats)  -> squared-norm partials of every shard on every rank (72 floats per rank)
+            cirs_ppo_shard_adam                      clip coefficient (fixed (rank, block) order) + Adam on the shard only
+            all_gather(parameter shards)             -> every rank holds the updated parameters
+        Same bytes on the wire as the all-reduce of learn_dp (a ring all-reduce IS reduce-scatter + all-gather), Adam and the
+        norm pass over 1 / world of the buffer, Adam moments only maintained for the rank's own shard.  `coll` provides
+        reduce_scatter(out, inp) / all_gather(out, inp) (cirs_hip.distributed.Collectives)."""
+        assert world == self.world, "DeviceLearner(world=...) fixes the shard layout"
+        n = self.n_rows
+        slices = minibatch_slices(n, global_batch)
+        losses = torch.zeros((repeat * len(slices), 4), dtype=torch.float32, device=self.device)
+        perm_all_d = self._perms_on_device(n, repeat, perms)
+        sl = self.P_pad // world
+        b0 = rank * sl
+        nstat = int(self._lib.cirs_ppo_shard_stat_floats())
+        if getattr(self, "_gshard", None) is None or self._gshard.numel() != sl:
+            self._gshard = torch.zeros(sl, dtype=torch.float32, device=self.device)
+            self._stats = torch.zeros(nstat, dtype=torch.float32, device=self.device)
+            self._stats_all = torch.zeros(world * nstat, dtype=torch.float32, device=self.device)
+            self._p_scratch = None if self._p_pad is not None else torch.zeros(self.P_pad, dtype=torch.float32, device=self.device)
+        p_pad = self._p_pad if self._p_pad is not None else self._p_scratch
+        if self._p_pad is None:
+            p_pad[:self.P].copy_(self.params)
+        k = 0
+        for rep in range(repeat):
+            perm_d = perm_all_d[rep]
+            last = rep == repeat - 1
+            if last and want_tracker_grad:
+                self.dobs.zero_()
+            for s0, e0 in slices:
+                g_idx = perm_d[s0:e0]
+                l_idx = g_idx[rank::world].contiguous()
+                assert l_idx.numel() >= 1, "global minibatch smaller than the world size"
+                self.mb_phase1(l_idx, g_idx, last and want_tracker_grad, losses[k])
+                coll.reduce_scatter(self._gshard, self.grads)
+                abi.check(self._lib.cirs_ppo_shard_norm(C.byref(self.cfg), self._gshard.data_ptr(), b0, sl, self._stats.data_ptr(),
+                                                        self._stream()), "cirs_ppo_shard_norm")
+                coll.all_gather(self._stats_all, self._stats)
+                abi.check(self._lib.cirs_ppo_shard_adam(
+                    C.byref(self.cfg), p_pad.data_ptr() + 4 * b0, self._gshard.data_ptr(), self._m_pad.data_ptr() + 4 * b0,
+                    self._v_pad.data_ptr() + 4 * b0, b0, sl, self.opt_step, self._stats_all.data_ptr(), world, losses[k].data_ptr(),
+                    self._stream()), "cirs_ppo_shard_adam")
+                coll.all_gather(p_pad, p_pad[b0:b0 + sl])
+                if self._p_pad is None:
+                    self.params.copy_(p_pad[:self.P])
+                self.opt_step += 1
                 k += 1
         return losses
 

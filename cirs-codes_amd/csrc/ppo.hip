@@ -1304,6 +1304,81 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
+// ---- sharded optimiser of the data-parallel learner (reduce-scatter -> this rank's gradient shard -> Adam -> all-gather) --------
+// stats layout per rank (kShardStatFloats): [0, kShardNormBlocks) partial sums of squares of the rank's shard (trunk elements
+// weighted twice, as sumsq_partial_kernel), [kShardNormBlocks, +4) the loss partials {clip, vf, ent, 0} that live in the
+// gradient tail [P, P+4) -- only where the shard holds them, 0 elsewhere, so the sum over ranks is exact.
+constexpr int kShardNormBlocks = 64;
+constexpr int kShardStatFloats = kShardNormBlocks + 8;
+__global__ __launch_bounds__(256) void shard_sumsq_kernel(const float* __restrict__ g_shard, long begin, long len, long n_trunk, long P,
+                                                          float* __restrict__ stats) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x;
+    const long per = (len + kShardNormBlocks - 1) / kShardNormBlocks;
+    const long lo = blockIdx.x * per, hi = min(len, lo + per);
+    float acc = 0.f;
+    for (long i = lo + tid; i < hi; i += 256) {
+        const long gi = begin + i;
+        if (gi < P) {
+            const float x = g_shard[i];
+            acc += (gi < n_trunk ? 2.0f : 1.0f) * x * x;
+        }
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) stats[blockIdx.x] = sh[0];
+    if (blockIdx.x == 0 && tid < 8) {
+        const long gi = P + tid;
+        stats[kShardNormBlocks + tid] = (tid < 4 && gi >= begin && gi < begin + len) ? g_shard[gi - begin] : 0.f;
+    }
+}
+// Adam over the shard from the all-gathered stats of every rank: the norm is the sum of the W x kShardNormBlocks partials in
+// (rank, block) order -- identical on every rank --, the clip coefficient and the two segments as in adam2_kernel.
+__global__ __launch_bounds__(256) void shard_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long begin, long len, long n_first, long P, AdamSeg sa,
+                                                         AdamSeg sb, float beta1, float beta2, float eps, cirs_ppo_cfg cfg,
+                                                         const float* __restrict__ stats_all, int world, float* __restrict__ loss_out) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x;
+    float acc = 0.f;
+    const int n_part = world * kShardNormBlocks;
+    for (int q = tid; q < n_part; q += 256) acc += stats_all[(size_t)(q / kShardNormBlocks) * kShardStatFloats + (q % kShardNormBlocks)];
+    sh[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const float total_norm = sqrtf(sh[0]);
+    float c = 1.0f;
+    if (cfg.max_grad_norm > 0.f) c = fminf(cfg.max_grad_norm / (total_norm + 1e-6f), 1.0f);
+    if (blockIdx.x == 0 && tid == 0 && loss_out) {
+        float t3[3] = {0.f, 0.f, 0.f};
+        for (int r = 0; r < world; ++r)
+            for (int j = 0; j < 3; ++j) t3[j] += stats_all[(size_t)r * kShardStatFloats + kShardNormBlocks + j];
+        loss_out[0] = t3[0] + cfg.vf_coef * t3[1] - cfg.ent_coef * t3[2];
+        loss_out[1] = t3[0]; loss_out[2] = t3[1]; loss_out[3] = t3[2];
+    }
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= len || begin + i >= P) return;
+    const AdamSeg sg = begin + i < n_first ? sa : sb;
+    float gi = g[i];
+    for (int q = 0; q < sg.scale_pow; ++q) gi *= c;
+    float pi = p[i], mi = m[i], vi = v[i];
+    for (int sub = 0; sub < sg.n_sub; ++sub) {
+        mi = mi + (1.0f - beta1) * (gi - mi);
+        vi = vi * beta2 + (1.0f - beta2) * gi * gi;
+        const float ss = sub == 0 ? sg.step_size0 : sg.step_size1;
+        const float b2 = sub == 0 ? sg.bc2s0 : sg.bc2s1;
+        pi = pi - ss * (mi / (sqrtf(vi) / b2 + eps));
+    }
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
 static int launch_adam(float* p, const float* g, float* m, float* v, long n, long step_before, int n_sub, float lr, float b1,
                        float b2, float eps, const float* grad_scale, int scale_pow, hipStream_t s) {
     CIRS_REQUIRE(n_sub == 1 || n_sub == 2, "n_sub must be 1 or 2");
@@ -1505,4 +1580,44 @@ extern "C" int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, flo
     if (phase != 2 && !idx_global) return cirs::fail(CIRS_E_INVALID, "idx_global is null");
     return ppo_minibatch_impl(cfg, params, grads, adam_m, adam_v, opt_step, batch, idx_local, mb_local, idx_global, mb_global,
                               dobs_accum, n_env, loss_out, workspace, workspace_bytes, phase, stream);
+}
+
+// ---- sharded optimiser step of the data-parallel learner -------------------------------------------------------------------
+extern "C" int32_t cirs_ppo_shard_stat_floats(void) { return cirs::kShardStatFloats; }
+
+extern "C" int cirs_ppo_shard_norm(const cirs_ppo_cfg* cfg, const float* grads_shard, int64_t shard_begin, int64_t shard_len,
+                                   float* stats_out, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_ppo(cfg)) return rc;
+    CIRS_REQUIRE(grads_shard && stats_out && shard_begin >= 0 && shard_len > 0, "bad shard arguments");
+    const PpoLayout L = ppo_layout(cfg->n_items, cfg->dim_state);
+    hipLaunchKernelGGL(shard_sumsq_kernel, dim3(kShardNormBlocks), dim3(256), 0, (hipStream_t)stream, grads_shard, (long)shard_begin,
+                       (long)shard_len, L.trunk, L.total, stats_out);
+    CIRS_CHECK_LAUNCH("shard_sumsq_kernel");
+    return CIRS_OK;
+}
+
+extern "C" int cirs_ppo_shard_adam(const cirs_ppo_cfg* cfg, float* params_shard, const float* grads_shard, float* adam_m_shard,
+                                   float* adam_v_shard, int64_t shard_begin, int64_t shard_len, int64_t opt_step,
+                                   const float* stats_all, int32_t world, float* loss_out, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_ppo(cfg)) return rc;
+    CIRS_REQUIRE(params_shard && grads_shard && adam_m_shard && adam_v_shard && stats_all, "null argument");
+    CIRS_REQUIRE(shard_begin >= 0 && shard_len > 0 && world >= 1, "bad shard arguments");
+    const PpoLayout L = ppo_layout(cfg->n_items, cfg->dim_state);
+    auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
+        AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};
+        for (int q = 0; q < n_sub; ++q) {
+            const double t = (double)(step_before + 1 + q);
+            const float ss = (float)((double)cfg->lr / (1.0 - pow((double)cfg->beta1, t)));
+            const float bs = (float)sqrt(1.0 - pow((double)cfg->beta2, t));
+            if (q == 0) { sg.step_size0 = ss; sg.bc2s0 = bs; } else { sg.step_size1 = ss; sg.bc2s1 = bs; }
+        }
+        return sg;
+    };
+    hipLaunchKernelGGL(shard_adam_kernel, dim3(cdiv(shard_len, 256)), dim3(256), 0, (hipStream_t)stream, params_shard, grads_shard,
+                       adam_m_shard, adam_v_shard, (long)shard_begin, (long)shard_len, L.trunk, L.total, seg_of(2 * opt_step, 2, 2),
+                       seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, *cfg, stats_all, (int)world, loss_out);
+    CIRS_CHECK_LAUNCH("shard_adam_kernel");
+    return CIRS_OK;
 }

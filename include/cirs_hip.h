@@ -356,6 +356,23 @@ int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, float* grads, 
                           const int32_t* idx_global, int32_t mb_global, float* dobs_accum, int32_t n_env,
                           float* loss_out, void* workspace, int64_t workspace_bytes, int32_t phase, void* stream);
 
+/* Sharded optimiser step of the data-parallel learner (the reduce-scatter -> sharded Adam -> all-gather form of the step above):
+ * after phase 1 the caller reduce-scatters grads[0 .. P_pad) (P_pad = P + 4 rounded up to a multiple of 4 * world; the padding
+ * stays zero) so that this rank holds the summed shard [shard_begin, shard_begin + shard_len) of the flat gradient.
+ *   cirs_ppo_shard_norm   stats_out[cirs_ppo_shard_stat_floats()] = fixed-order partial sums of squares of the shard (trunk elements
+ *                         counted twice) + the loss partials of the gradient tail where the shard holds them
+ *   -- caller all-gathers the stats of all ranks: stats_all [world, cirs_ppo_shard_stat_floats()] --
+ *   cirs_ppo_shard_adam   clip_grad_norm_ coefficient from stats_all (summed in rank order: identical on every rank), Adam on the
+ *                         shard only (params / moments pointers are those OF THE SHARD), loss_out[4] (nullable)
+ *   -- caller all-gathers the parameter shards --
+ * No reference counterpart (the reference is single-process); semantics = cirs_ppo_minibatch_dp phase 2. */
+int32_t cirs_ppo_shard_stat_floats(void);
+int cirs_ppo_shard_norm(const cirs_ppo_cfg* cfg, const float* grads_shard, int64_t shard_begin, int64_t shard_len,
+                        float* stats_out, void* stream);
+int cirs_ppo_shard_adam(const cirs_ppo_cfg* cfg, float* params_shard, const float* grads_shard, float* adam_m_shard,
+                        float* adam_v_shard, int64_t shard_begin, int64_t shard_len, int64_t opt_step, const float* stats_all,
+                        int32_t world, float* loss_out, void* stream);
+
 /* torch.optim.Adam single-tensor update over a flat buffer, `n_sub` sequential sub-steps with the same gradient
  * starting at step `step_before`+1; grad is multiplied by (*grad_scale)^scale_pow when grad_scale != NULL. */
 int cirs_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t step_before,

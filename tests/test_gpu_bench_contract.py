@@ -36,3 +36,15 @@ def test_bench_json_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+    # the PPO configuration is part of the line (VERDICT r02 next #1a): learner, global minibatch, steps per update, dropout mode
+    cfg = d["config"]
+    assert cfg["learner"] == "single" and cfg["global_minibatch"] == 1024 and cfg["minibatch_steps_per_update"] >= 2
+    assert cfg["rows_per_rank_per_minibatch"] == 1024 and cfg["tracker_dropout"] == 0.0 and d["dropout"] == 0.0
+    assert c["envs_gpu_leg"] == 64 and c["envs_cpu_leg"] >= 1
+
+
+def test_bench_dropout_mode_line():
+    """--dropout 0.1: the mode the reference trains in (tracker in train mode, masks in rollout and BPTT) is measurable and labelled."""
+    d = run_bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "c2", "--dropout", "0.1", "--no-probes")
+    assert d["dropout"] == 0.1 and d["config"]["tracker_dropout"] == 0.1 and d["value"] > 0
+

@@ -138,8 +138,9 @@ def test_data_parallel_path_over_rccl_with_one_rank(monkeypatch):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on the node (RCCL over xGMI with N > 1 ranks)")
+@pytest.mark.parametrize("learner", ["dp", "dp_sharded", "replicated"])
 @pytest.mark.parametrize("nproc", [2])
-def test_two_process_rccl_bench_ranks_stay_bit_identical(nproc):
+def test_two_process_rccl_bench_ranks_stay_bit_identical(nproc, learner):
     """The driver's SCALE run must not be the first time RCCL sees N > 1 ranks: launch bench.py exactly as the driver does
     (torch.distributed.run, one process per GPU), 3 timed steps, and require (a) a valid JSON line, (b) n_gpus == nproc and
     envs_total == 1024 * nproc (env-sharded, weak scaling), (c) bit-identical policy / tracker parameters on every rank after
@@ -151,17 +152,22 @@ def test_two_process_rccl_bench_ranks_stay_bit_identical(nproc):
     port = 29700 + os.getpid() % 200
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
+           "--learner", learner, "--scaled-batch-steps", "1"]
+    env["CIRS_DIST_CHECK"] = "1"     # per-collective stream-order assertions (cirs_hip.distributed.Collectives)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     z = json.loads(line)
     assert z["n_gpus"] == nproc and z["config"]["envs_total"] == 1024 * nproc and z["scaling"] == "weak"
+    assert z["config"]["learner"] == learner and z["config"]["global_minibatch"] == 1024
     assert z["rank_parameters_bit_identical"] is True
     assert z["value"] > 0 and z["steps"] == 3
+    assert z["scaled_batch_variant"]["global_minibatch"] == 1024 * nproc
 
 
-def test_two_process_bench_on_one_gpu_ranks_stay_bit_identical():
+@pytest.mark.parametrize("learner", ["dp", "dp_sharded"])
+def test_two_process_bench_on_one_gpu_ranks_stay_bit_identical(learner):
     """The same launch as above on a box with ONE GPU: both ranks on device 0 (CIRS_BENCH_SHARE_GPU=1), collectives through gloo on
     device tensors.  Everything but the transport is the N > 1 path of the driver's SCALE run: env sharding, the packed
     all-gather of the trajectory, the data-parallel learner's per-minibatch all-reduce, rank-identity of the parameters."""
@@ -172,11 +178,21 @@ def test_two_process_bench_on_one_gpu_ranks_stay_bit_identical():
     port = 29500 + os.getpid() % 150
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CIRS_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-probes"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-probes",
+           "--learner", learner, "--scaled-batch-steps", "1"]
+    env["CIRS_DIST_CHECK"] = "1"
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     z = json.loads(line)
     assert z["n_gpus"] == 2 and z["config"]["envs_total"] == 2048 and z["scaling"] == "weak"
+    # the headline keeps the reference's PPO configuration: global minibatch 1024 rows = 512 per rank, ~2 x the single-GPU step count
+    assert z["config"]["learner"] == learner and z["config"]["global_minibatch"] == 1024 and z["config"]["rows_per_rank_per_minibatch"] == 512
     assert z["rank_parameters_bit_identical"] is True
     assert z["value"] > 0 and z["steps"] == 2
+    sv = z["scaled_batch_variant"]
+    # same buffer sizes, half the minibatch size -> about twice the optimiser steps per update (episode lengths drift a little between
+    # the two measurements: the policy keeps learning)
+    assert sv["global_minibatch"] == 2048 and 1.2 < z["config"]["minibatch_steps_per_update"] / sv["minibatch_steps_per_update"] < 3.0
+    calls = z["collectives_per_rank"]["calls"]
+    assert (calls["reduce_scatter"] > 0) == (learner == "dp_sharded")

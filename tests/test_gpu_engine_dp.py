@@ -1,7 +1,8 @@
 """GPU (single device): the engine's data-parallel update (`CirsEngine._update_dp`, the path the 2/4/8-GPU bench runs) with
-W virtual ranks = W threads on one GPU and a thread-synchronised stand-in for the two collectives it uses
-(all_gather_into_tensor of the packed trajectory records, all_reduce of gradients).  Checks: ranks stay bit-identical,
-and the result equals a single-device update of the gathered buffer with the global minibatch (batch_size * W)."""
+W virtual ranks = W threads on one GPU and a thread-synchronised stand-in for the collectives it uses (all_gather_into_tensor of
+the packed trajectory records; all_reduce of gradients for learner "dp"; reduce_scatter_tensor + two all-gathers per minibatch for
+"dp_sharded").  Checks: ranks stay bit-identical, and the result equals a single-device update of the gathered buffer with the SAME
+batch_size -- the global minibatch is the reference's batch_size (CIRS-RL-kuaishou.py:89) for every W (VERDICT r02 next #1b)."""
 import threading
 
 import numpy as np
@@ -37,15 +38,31 @@ class FakeCollectives:
 
     def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
         torch.cuda.synchronize()
-        self.slots[self.rank()] = inp
+        self.slots[self.rank()] = inp.clone()     # the input may alias this rank's slice of `out` (in-place all-gather)
         self.bar.wait()
         out.copy_(torch.cat([s.reshape(-1) for s in self.slots]).view_as(out))
         torch.cuda.synchronize()
         self.bar.wait()
 
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None, async_op=False):
+        torch.cuda.synchronize()
+        self.slots[self.rank()] = inp
+        self.bar.wait()
+        n = out.numel()
+        r = self.rank()
+        total = self.slots[0][r * n:(r + 1) * n].clone()
+        for q in range(1, self.world):      # rank order: every element is reduced exactly once, by its owner
+            total += self.slots[q][r * n:(r + 1) * n]
+        self.bar.wait()
+        out.copy_(total)
+        torch.cuda.synchronize()
+        self.bar.wait()
 
-@pytest.mark.parametrize("W,B,I,U,T,bs", [(2, 24, 300, 90, 10, 32), (4, 16, 1000, 90, 10, 32), (2, 512, 10728, 7176, 30, 1024)])
-def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs):
+
+@pytest.mark.parametrize("mode", ["dp", "dp_sharded"])
+@pytest.mark.parametrize("W,B,I,U,T,bs", [(2, 24, 300, 90, 10, 32), (4, 16, 1000, 90, 10, 32), (8, 12, 500, 90, 10, 64),
+                                          (2, 512, 10728, 7176, 30, 1024), (4, 256, 10728, 7176, 30, 1024), (8, 128, 10728, 7176, 30, 1024)])
+def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs, mode):
     from cirs_hip.engine import CirsEngine
     from cirs_hip.env import DeviceEnvTables
     from cirs_hip.synthetic import make_tables
@@ -55,10 +72,12 @@ def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs):
     fake = FakeCollectives(W)
     monkeypatch.setattr(dist, "all_reduce", fake.all_reduce)
     monkeypatch.setattr(dist, "all_gather_into_tensor", fake.all_gather_into_tensor)
+    monkeypatch.setattr(dist, "reduce_scatter_tensor", fake.reduce_scatter_tensor)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: W)
-    kw = dict(max_turn=T, num_leave_compute=3 if T < 30 else 10, leave_threshold=1 if T < 30 else 4, tau=10.0, gamma_exposure=10.0, seed=5, batch_size_hint=bs * W)
-    engines = [CirsEngine(dt, B, world_size=W, rank=r, learner_mode="dp", **kw) for r in range(W)]
+    kw = dict(max_turn=T, num_leave_compute=3 if T < 30 else 10, leave_threshold=1 if T < 30 else 4, tau=10.0, gamma_exposure=10.0, seed=5, batch_size_hint=bs)
+    engines = [CirsEngine(dt, B, world_size=W, rank=r, learner_mode=mode, **kw) for r in range(W)]
     rng = np.random.RandomState(2)
     users = [torch.as_tensor(rng.randint(0, U, B)) for _ in range(W)]
     for r, eng in enumerate(engines):
@@ -95,14 +114,22 @@ def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs):
         assert torch.equal(engines[0].tracker_flat, engines[r].tracker_flat)
         assert torch.equal(results[0][0], results[r][0])
     assert results[0][1] == n_total
-    # single device: the gathered buffer, global minibatch = bs * W
+    # the collectives the mode promises, per minibatch step (+ the trajectory all-gather: once by this test's explicit _gather(), once
+    # inside update(); + the d obs and tracker-gradient all-reduces per update)
+    n_mb = results[0][0].shape[0]
+    c = engines[0].coll.calls
+    if mode == "dp":
+        assert c == {"all_reduce": n_mb + 2, "reduce_scatter": 0, "all_gather": 2}, c
+    else:
+        assert c == {"all_reduce": 2, "reduce_scatter": n_mb, "all_gather": 2 + 2 * n_mb}, c
+    # single device: the gathered buffer, the SAME batch size
     monkeypatch.undo()
-    ref = CirsEngine(dt, B * W, world_size=1, rank=0, **{**kw, "batch_size_hint": bs * W})
+    ref = CirsEngine(dt, B * W, world_size=1, rank=0, **kw)
     for k, v in gathered["traj"].items():
         getattr(ref.rollout.traj, k).copy_(v)
     ref.tracker.x_hist.copy_(gathered["x_hist"])
     ref.lengths, ref.users = gathered["lens"].to(torch.int32), gathered["users"].to(torch.int32)
-    ref_losses, ref_n = ref.update(bs * W, 2, perms=perms)
+    ref_losses, ref_n = ref.update(bs, 2, perms=perms)
     assert ref_n == n_total
     np.testing.assert_allclose(results[0][0].cpu().numpy(), ref_losses.cpu().numpy(), rtol=3e-4, atol=3e-5)
     np.testing.assert_allclose(engines[0].policy_flat.cpu().numpy(), ref.policy_flat.cpu().numpy(), rtol=3e-4, atol=3e-6)
