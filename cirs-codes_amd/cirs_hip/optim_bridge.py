@@ -22,10 +22,19 @@ def _slices(params, flat: torch.Tensor):
     return out
 
 
-def bind(optimizer, get_state):
+def bind(optimizer, get_state, flat=None):
     """get_state() -> None (nothing trained yet) or dict(flat=, m=, v=, steps=callable(param_offset) -> int, set_steps=callable(list))
-    Patches optimizer.state_dict / load_state_dict on the INSTANCE."""
+    Patches optimizer.state_dict / load_state_dict on the INSTANCE.
+    The (parameter -> offset in the flat buffer) map is taken while the parameters still ARE views of it -- at bind time when `flat`
+    is given, else at the first state access -- and kept: the reference's checkpoint line evaluates `policy.cpu().state_dict()`
+    BEFORE `optim[0].state_dict()` (CIRS-RL-kuaishou.py:340-343), i.e. the modules' parameters have left the device by then."""
     cls = type(optimizer)
+    cache = {}
+
+    def slices_of(params, flat_buf):
+        if "sl" not in cache:
+            cache["sl"] = _slices(params, flat_buf)
+        return cache["sl"]
 
     def unique_params():
         seen, out = set(), []
@@ -39,7 +48,7 @@ def bind(optimizer, get_state):
     def state_dict(self):
         st = get_state()
         if st is not None:
-            for p, off, n in _slices(unique_params(), st["flat"]):
+            for p, off, n in slices_of(unique_params(), st["flat"]):
                 self.state[p] = {"step": torch.tensor(float(st["steps"](off))),
                                  "exp_avg": st["m"][off:off + n].view(p.shape).clone(),
                                  "exp_avg_sq": st["v"][off:off + n].view(p.shape).clone()}
@@ -51,7 +60,7 @@ def bind(optimizer, get_state):
         if st is None:
             return
         steps = []
-        for p, off, n in _slices(unique_params(), st["flat"]):
+        for p, off, n in slices_of(unique_params(), st["flat"]):
             s = self.state.get(p)
             if not s:
                 continue
@@ -60,6 +69,8 @@ def bind(optimizer, get_state):
             steps.append((off, int(float(s["step"]))))
         st["set_steps"](steps)
 
+    if flat is not None:
+        slices_of(unique_params(), flat)
     optimizer.state_dict = types.MethodType(state_dict, optimizer)
     optimizer.load_state_dict = types.MethodType(load_state_dict, optimizer)
     return optimizer

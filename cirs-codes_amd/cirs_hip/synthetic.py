@@ -120,3 +120,50 @@ def make_tables(n_users: int, n_items: int, seed: int = 0, *, with_ab: bool = Tr
                       raw_pid=raw_pid, list_feat=list_feat, item_cats=item_cats, duration=duration,
                       alpha_u=alpha_u, beta_i=beta_i, dist=dist,
                       meta=dict(seed=seed, raw_user_space=raw_user_space, raw_item_space=raw_item_space))
+
+
+def write_kuairec_workspace(datapath: str, *, n_users: int = 48, n_items: int = 1400, n_env_users: int = 24, n_env_items: int = 160,
+                            log_len=(20, 60), seed: int = 0) -> dict:
+    """Write synthetic files in the KuaiRec on-disk layout under `datapath` -- what the reference expects in
+    environments/KuaishouRec/data/ and does not ship (.gitignore): `big_matrix.csv` (the training log: user_id, photo_id,
+    timestamp, watch_ratio, photo_duration [ms]; a user's rows contiguous and time-ordered), `small_matrix.csv` (the fully
+    observed user x item block the env is built from), `item_categories.json`, `photo_mean_duration.json`.  Raw ids run to
+    n_users / n_items (> 1225: the absent photo id of the reference's negative search, core/util.py:173-196); the env block is a
+    subset of both.  Returns the generated arrays (for tests)."""
+    import json
+    import os
+
+    import pandas as pd
+    assert n_items > 1300 and n_env_users <= n_users and n_env_items <= n_items
+    rng = np.random.RandomState(seed)
+    os.makedirs(datapath, exist_ok=True)
+    pop = 1.0 / np.arange(1, N_CATEGORIES + 1) ** 1.2
+    pop /= pop.sum()
+    list_feat = [sorted(rng.choice(N_CATEGORIES, size=rng.randint(1, 5), replace=False, p=pop).tolist()) for _ in range(n_items)]
+    durations = rng.uniform(2.0, 60.0, n_items)
+    env_users = np.sort(rng.choice(n_users, n_env_users, replace=False))
+    env_items = np.sort(rng.choice(n_items, n_env_items, replace=False))
+    hot = np.unique(np.r_[env_items, np.arange(1215, 1235), rng.choice(n_items, 3 * n_env_items, replace=False), [n_items - 1]])
+    affinity = rng.gamma(2.0, 0.6, size=(n_users, N_CATEGORIES))      # users like categories: the watch ratio is learnable
+    rows, t0 = [], 1.6e9
+    for u in range(n_users):
+        L = int(rng.randint(log_len[0], log_len[1]))
+        ts = np.sort(t0 + rng.randint(0, 60000, L).astype(np.float64))
+        items = rng.choice(hot, L)
+        for k in range(L):
+            ratio = float(np.mean(affinity[u, list_feat[items[k]]]) * rng.gamma(4.0, 0.25))
+            rows.append((u, int(items[k]), ts[k], ratio, float(durations[items[k]] * 1000.0)))
+    rows.append((n_users - 1, n_items - 1, t0 + 70000.0, 1.0, float(durations[n_items - 1] * 1000.0)))   # the largest ids occur in the log
+    big = pd.DataFrame(rows, columns=["user_id", "photo_id", "timestamp", "watch_ratio", "photo_duration"])
+    big.to_csv(os.path.join(datapath, "big_matrix.csv"), index=False)
+    uu, pp = np.meshgrid(env_users, env_items, indexing="ij")
+    order = rng.permutation(uu.size)
+    su, sp = uu.ravel()[order], pp.ravel()[order]
+    sr = np.array([np.mean(affinity[u, list_feat[p]]) for u, p in zip(su, sp)]) * rng.gamma(4.0, 0.25, su.size)
+    pd.DataFrame({"user_id": su, "photo_id": sp, "play_duration": 1, "watch_ratio": sr,
+                  "photo_duration": durations[sp] * 1000.0}).to_csv(os.path.join(datapath, "small_matrix.csv"), index=False)
+    with open(os.path.join(datapath, "item_categories.json"), "w") as fh:
+        json.dump({str(i): {"feature_index": f} for i, f in enumerate(list_feat)}, fh)
+    with open(os.path.join(datapath, "photo_mean_duration.json"), "w") as fh:
+        json.dump({str(i): float(d) for i, d in enumerate(durations)}, fh)
+    return dict(list_feat=list_feat, durations=durations, env_users=env_users, env_items=env_items, big=big)

@@ -62,7 +62,7 @@ class PPOPolicy(nn.Module):
         # checkpoints: optim[i].state_dict() / load_state_dict() carry the device Adam state (CIRS-RL-kuaishou.py:340-358)
         from cirs_hip import optim_bridge
         self._restored_RL = None  # Adam state loaded before the learner exists
-        optim_bridge.bind(optim_RL, self._adam_state_RL)
+        optim_bridge.bind(optim_RL, self._adam_state_RL, flat=self.flat)
         if isinstance(optim, (list, tuple)) and len(optim) > 1:
             optim_bridge.bind(optim[1], self._adam_state_tracker)
 

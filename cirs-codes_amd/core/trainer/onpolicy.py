@@ -43,7 +43,10 @@ def onpolicy_trainer(policy, train_collector, test_collector, state_tracker, max
     start_time = time.time()
     train_collector.reset_stat()
     test_collector.reset_stat()
-    best_epoch, best_reward, best_reward_std = -1, -1.0, 0.0
+    test_in_train = test_in_train and getattr(train_collector, "policy", policy) is policy
+    # the reference evaluates the untrained policy once before the first epoch and starts `best_*` from it (onpolicy.py:126-129)
+    test_result = test_episode(policy, test_collector, test_fn, start_epoch, episode_per_test, logger, None, reward_metric)
+    best_epoch, best_reward, best_reward_std = start_epoch, test_result["rew"], test_result["rew_std"]
     for cb in getattr(policy, "callbacks", []):
         cb.on_train_begin()
     for epoch in range(1 + start_epoch, 1 + max_epoch):

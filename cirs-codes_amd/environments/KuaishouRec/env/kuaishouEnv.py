@@ -90,7 +90,7 @@ class KuaishouEnv(gym.Env):
         import pandas as pd
         from sklearn.preprocessing import LabelEncoder
         from core.util import get_distance_mat
-        root = DATAPATH or globals()["DATAPATH"]
+        root = DATAPATH or os.environ.get("CIRS_DATAPATH") or globals()["DATAPATH"]
         log = pd.read_csv(os.path.join(root, "small_matrix.csv"), usecols=["user_id", "photo_id", "watch_ratio"])
         ratio = np.minimum(log["watch_ratio"].to_numpy(dtype=np.float64), 5.0)
         lbe_user, lbe_photo = LabelEncoder().fit(log["user_id"].unique()), LabelEncoder().fit(log["photo_id"].unique())

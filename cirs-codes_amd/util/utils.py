@@ -3,11 +3,57 @@
 After every epoch the trainer hands the merged result dict of the three test collectors (free browsing "", "NX_0_" and
 "NX_<k>_") to `on_epoch_end`; the callback derives, per collector, trajectory length, trajectory reward and their ratio
 (the "ctr" of the paper's tables), formats coverage with five decimals, carries the ifeat_* feature-domination entries over
-and logs one line "Epoch: [e], Info: [{...}]".  logzero is not a dependency here: the line goes to the standard `logging`
-logger named "cirs" and the dict is also returned / kept in `last_results`."""
-import logging
+and logs one line "Epoch: [e], Info: [{...}]" through logzero's logger (the script's logzero.logfile receives it); the dict is also
+returned / kept in `last_results`.  create_dir, LoggerCallback_Update and LoggerCallback_RL (reference util/utils.py:14-80) live
+here as well."""
+import os
 
-logger = logging.getLogger("cirs")
+from logzero import logger   # the real logzero, or the stand-in package of this mirror (same `logger` / `logfile` protocol)
+
+
+def create_dir(create_dirs):
+    """Create the listed directories, parents first as listed (reference util/utils.py:14-24: os.mkdir per entry, an existing
+    directory is left alone)."""
+    for d in create_dirs:
+        if not os.path.exists(d):
+            logger.info("Create dir: %s" % d)
+            try:
+                os.mkdir(d)
+            except FileExistsError:
+                print("The dir [{}] already existed".format(d))
+
+
+class LoggerCallback_Update:
+    """Trainer callback that writes one log line per epoch (reference util/utils.py:30-56; the NAS upload is not part of the path)."""
+
+    def __init__(self, logger_path):
+        self.LOCAL_PATH = logger_path
+
+    def on_epoch_begin(self, epoch, **kwargs):
+        pass
+
+    def on_train_begin(self, **kwargs):
+        pass
+
+    def on_train_end(self, **kwargs):
+        pass
+
+    def on_epoch_end(self, epoch, logs=None, **kwargs):
+        logger.info("Epoch: [{}], Info: [{}]".format(epoch, logs))
+
+
+class LoggerCallback_RL(LoggerCallback_Update):
+    """Epoch line of CIRS-RL-taobao.py (reference util/utils.py:60-80): trajectory length, trajectory reward and their ratio."""
+
+    def on_epoch_end(self, epoch, logs=None, **kwargs):
+        logs = logs if logs is not None else kwargs.get("results")
+        episodes = logs["n/ep"]
+        length = logs["n/st"] / episodes
+        reward = logs["rew"]
+        result = {"num_test": episodes, "len_tra": length, "R_tra": reward, "ctr": f"{reward / length:.5f}"}
+        self.last_results = result
+        logger.info("Epoch: [{}], Info: [{}]".format(epoch, result))
+        return result
 
 
 class LoggerCallback_Policy:

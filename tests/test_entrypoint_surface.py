@@ -1,0 +1,193 @@
+"""CPU: the surface the reference's entry points use resolves against the mirror.
+
+tests/golden/entrypoint_surface.json is the AST of /root/reference/CIRS-RL-kuaishou.py and CIRS-RL-taobao.py reduced to NAMES
+(oracle/pin_entrypoint.py): every `import` / `from ... import ...`, and every call whose callee is an imported name with its
+positional count and keyword names.  Here: (1) every import resolves with cirs-codes_amd/ on sys.path -- `gym`, `logzero` and
+`torch.utils.tensorboard` included, without any explicit install() call; (2) every recorded call binds to the mirror's callable
+(`inspect.signature(...).bind`), the `**model_params` of UserModel_Pairwise with the keys of the shipped params pickle; (3) in the dev
+container, where the reference exists, its two scripts are imported AS THEY ARE against the mirror (module level only: the import
+block, get_args, the function definitions) and the fixture is regenerated and compared."""
+import importlib
+import inspect
+import json
+import os
+import pickle
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cirs-codes_amd")
+REF = "/root/reference"
+SURFACE = json.load(open(os.path.join(ROOT, "tests", "golden", "entrypoint_surface.json")))
+SCRIPTS = sorted(SURFACE["scripts"])
+
+
+def _resolve(origin, callee):
+    """origin 'module' or 'module:name', callee 'head.attr.attr' -> the object the script would call."""
+    if ":" in origin:
+        mod, name = origin.split(":")
+        obj = getattr(importlib.import_module(mod), name)
+    else:
+        obj = importlib.import_module(origin)
+    for attr in callee.split(".")[1:]:
+        obj = getattr(obj, attr)
+    return obj
+
+
+@pytest.mark.parametrize("script", SCRIPTS)
+def test_every_import_of_the_entry_point_resolves(script):
+    missing = []
+    for imp in SURFACE["scripts"][script]["imports"]:
+        try:
+            mod = importlib.import_module(imp["module"])
+            if imp["name"] is not None and not hasattr(mod, imp["name"]):
+                importlib.import_module(imp["module"] + "." + imp["name"])   # `from pkg import submodule`
+        except Exception as exc:  # noqa: BLE001
+            missing.append((imp["line"], imp["module"], imp["name"], repr(exc)))
+    assert not missing, missing
+
+
+@pytest.mark.parametrize("script", SCRIPTS)
+def test_every_recorded_call_binds_to_the_mirror(script):
+    bad = []
+    for c in SURFACE["scripts"][script]["calls"]:
+        try:
+            fn = _resolve(c["origin"], c["callee"])
+        except Exception as exc:  # noqa: BLE001
+            bad.append((c["line"], c["callee"], "unresolved: " + repr(exc)))
+            continue
+        mod = c["origin"].split(":")[0]
+        mirrored = os.path.exists(os.path.join(PKG, *mod.split("."))) or os.path.exists(os.path.join(PKG, *mod.split(".")) + ".py")
+        if not mirrored:
+            continue      # stdlib / torch / numpy: resolving is all that is pinned
+        try:
+            sig = inspect.signature(fn)
+        except (TypeError, ValueError):
+            continue
+        args, kwargs = [None] * c["n_positional"], {k: None for k in c["keywords"]}
+        try:
+            (sig.bind_partial if (c["star_args"] or c["star_kwargs"]) else sig.bind)(*args, **kwargs)
+        except TypeError as exc:
+            bad.append((c["line"], c["callee"], str(exc)))
+    assert not bad, bad
+
+
+def test_user_model_params_pickle_binds():
+    """`UserModel_Pairwise(**model_params)` (CIRS-RL-kuaishou.py:147-150) with the keys of the params pickle the reference ships."""
+    from core.user_model_pairwise import UserModel_Pairwise
+    with open(os.path.join(ROOT, "tests", "golden", "DeepFM_params_Pair11.pickle"), "rb") as fh:
+        params = pickle.load(fh)
+    params["device"] = "cpu"
+    inspect.signature(UserModel_Pairwise).bind(**params)
+
+
+def test_stand_ins_are_used_only_when_the_real_package_is_absent():
+    import gym
+    import logzero
+    from torch.utils.tensorboard import SummaryWriter
+    for mod, name in ((gym, "gym"), (logzero, "logzero")):
+        real = importlib.util.find_spec(name).origin
+        assert real.startswith(PKG) == bool(getattr(mod, "__cirs_stand_in__", False))
+    assert hasattr(gym, "make") and hasattr(gym.envs.registration, "register") and hasattr(gym.spaces, "Box")
+    assert hasattr(logzero, "logfile") and hasattr(logzero.logger, "info")
+    assert hasattr(SummaryWriter, "add_scalar")
+
+
+def test_basic_logger_protocol(tmp_path):
+    """tianshou.utils.BasicLogger over the writer: intervals, in-place result keys, save / restore (log_tools.py:84-189)."""
+    import numpy as np
+    from torch.utils.tensorboard import SummaryWriter
+    from tianshou.utils import BasicLogger
+    w = SummaryWriter(str(tmp_path))
+    lg = BasicLogger(w, train_interval=10, update_interval=5, save_interval=2)
+    res = {"n/ep": 2, "rews": np.array([1.0, 3.0]), "lens": np.array([4, 6])}
+    lg.log_train_data(res, 12)
+    assert res["rew"] == 2.0 and res["len"] == 5.0 and lg.last_log_train_step == 12
+    lg.log_train_data(dict(res), 15)
+    assert lg.last_log_train_step == 12           # inside the interval: not written
+    t = {"n/ep": 2, "rews": np.array([1.0, 3.0]), "lens": np.array([4, 6])}
+    lg.log_test_data(t, 1)
+    assert t["rew_std"] == 1.0 and t["len_std"] == 1.0
+    lg.log_update_data({"loss": 0.5}, 7)
+    calls = []
+    lg.save_data(1, 100, 7, lambda e, s, g: calls.append((e, s, g)))
+    lg.save_data(2, 200, 9, lambda e, s, g: calls.append((e, s, g)))     # 2 - 1 < save_interval: skipped
+    lg.save_data(3, 300, 11, lambda e, s, g: calls.append((e, s, g)))
+    assert calls == [(1, 100, 7), (3, 300, 11)]
+    if hasattr(w, "scalars"):
+        w.flush()
+        assert BasicLogger(w).restore_data() == (3, 300, 11)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree only exists in the dev container")
+@pytest.mark.parametrize("script", SCRIPTS)
+def test_reference_script_imports_unmodified_against_the_mirror(script):
+    """The reference's own file, imported as a module (not __main__) in a fresh interpreter whose only extra path is the mirror:
+    its whole import block, get_args() and the function definitions execute; main() -- which needs the KuaiRec files and a GPU --
+    is exercised by examples/cirs_rl_kuaishou_synth.py (tests/test_gpu_entrypoint.py)."""
+    code = ("import importlib.util, sys; sys.argv = ['x'];"
+            f"spec = importlib.util.spec_from_file_location('ref_entry', {os.path.join(REF, script)!r});"
+            "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m);"
+            "a = m.get_args(); assert callable(m.main); print('OK', a.env, a.batch_size)")
+    env = dict(os.environ, PYTHONPATH=PKG)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(ROOT), timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree only exists in the dev container")
+def test_fixture_is_current(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pin_entrypoint
+    fresh = {"scripts": {s: pin_entrypoint.pin(s) for s in pin_entrypoint.SCRIPTS}}
+    assert json.loads(json.dumps(fresh["scripts"], sort_keys=True)) == SURFACE["scripts"]
+
+
+def _example_surface():
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "examples", "cirs_rl_kuaishou.py")).read())
+    imports = set()
+    for node in tree.body:
+        if isinstance(node, ast.Import):
+            imports |= {(a.name, None) for a in node.names}
+        elif isinstance(node, ast.ImportFrom):
+            imports |= {(node.module, a.name) for a in node.names}
+    calls = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call):
+            f = node.func
+            name = f.id if isinstance(f, ast.Name) else (f.attr if isinstance(f, ast.Attribute) else None)
+            if name:
+                calls.setdefault(name, []).append((len(node.args), sorted(k.arg for k in node.keywords if k.arg)))
+    return imports, calls
+
+
+def test_example_entry_point_follows_the_reference_surface():
+    """examples/cirs_rl_kuaishou.py is the step-for-step walk of the reference's main(): its import block contains every import of the
+    reference entry point, its command line has the reference's options with the reference's defaults (--cuda excepted), and every
+    call the reference makes into the mirrored modules appears with the same positional count and keyword set."""
+    ref = SURFACE["scripts"]["CIRS-RL-kuaishou.py"]
+    imports, calls = _example_surface()
+    missing = [(i["module"], i["name"]) for i in ref["imports"] if (i["module"], i["name"]) not in imports]
+    assert not missing, missing
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import cirs_rl_kuaishou as ex
+    defaults = vars(ex.get_args([]))
+    for opt in ref["cli"]:
+        if "set_defaults" in opt:
+            for k, v in opt["set_defaults"].items():
+                assert defaults[k] == v, (k, defaults[k], v)
+            continue
+        dest = opt.get("dest") or opt["options"][0].lstrip("-").replace("-", "_")
+        assert dest in defaults, dest
+        if "default" in opt and dest != "cuda" and opt.get("action") is None:
+            assert defaults[dest] == opt["default"], (dest, defaults[dest], opt["default"])
+    for c in ref["calls"]:
+        mod = c["origin"].split(":")[0]
+        if not (os.path.exists(os.path.join(PKG, *mod.split("."))) or os.path.exists(os.path.join(PKG, *mod.split(".")) + ".py")):
+            continue
+        if c["origin"].startswith("logzero") or c["callee"] == "gym.make":
+            continue
+        name = c["callee"].split(".")[-1]
+        assert (c["n_positional"], sorted(c["keywords"])) in calls.get(name, []), (c["callee"], c["n_positional"], c["keywords"], calls.get(name))

@@ -102,7 +102,7 @@ def test_trainer_loop_with_test_collector_set():
     info = onpolicy_trainer(policy, coll, cs, st, args.epoch, args.step_per_epoch, args.repeat_per_collect, args.test_num, args.batch_size,
                             episode_per_collect=args.episode_per_collect, save_model_fn=lambda epoch, policy: None, verbose=False)
     assert events[0] == "begin" and events[-1] == "done" and ("epoch", 2) in events
-    assert info["train_step"] >= 2 * args.step_per_epoch and info["test_episode"] == 2 * 8
+    assert info["train_step"] >= 2 * args.step_per_epoch and info["test_episode"] == 3 * 8   # pre-training evaluation + one per epoch (reference onpolicy.py:126)
     assert float((policy.flat - before).abs().max()) > 0 and float((st.flat - tbefore).abs().max()) > 0
     res = cs.collect(n_episode=8)
     assert {"n/st", "rew", "NX_0_n/st", "NX_0_rew", "NX_10_lens"} <= set(res)
