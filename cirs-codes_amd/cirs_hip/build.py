@@ -12,7 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(_HERE, "libcirs_hip.so")
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators / operands stay in the architectural VGPRs.  With the default heuristics the fused head
+# backward kernel kept its accumulators in AGPRs and spent 140 of ~720 VALU instructions per tile on v_accvgpr_read / _write copies
+# (VALU cannot address AGPRs, and on this part VALU time adds to MFMA time: DESIGN.md section 4).
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def sources():

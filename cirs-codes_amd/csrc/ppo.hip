@@ -631,6 +631,26 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 // the next tile's global loads in flight; row strides 144 B / 80 B keep the ds_read_b128 of the operands conflict-free.
 
 
+// logits of one tile as TWO independent accumulator chains (k-steps {0, 1} on the bias, {2, 3} on zero), issued alternately: a
+// dependent bf16 MFMA waits ~8 cycles for its predecessor, an independent one issues back to back
+__device__ __forceinline__ void mfma_bf16x6_two(const Planes& a0, const Planes& b0, f32x16& c0, const Planes& a1, const Planes& b1, f32x16& c1) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.l, b1.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.l, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.l, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b0.m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b1.m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b1.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.m, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.m, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.h, c1, 0, 0, 0);
+}
+
+// kEnt: the entropy term of dZ is compiled in (ent_coef != 0); the reference's scripts train with ent_coef = 0 (CIRS-RL-kuaishou.py:97),
+// where dZ = c_logp (delta - p) and the entropy is only reported.
+template <bool kEnt>
 __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                                          const uint4* __restrict__ planes,
                                                                          const float* __restrict__ ba, MbView v,
@@ -674,7 +694,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         hb[0][t] = split8(x0[0], x0[1], x0[2], x0[3], x0[4], x0[5], x0[6], x0[7]);
         hb[1][t] = split8(x1[0], x1[1], x1[2], x1[3], x1[4], x1[5], x1[6], x1[7]);
     }
-    const float lse = v.lse[jr], c_logp = v.c_logp[jr], c_ent = v.c_ent[jr], h_ent = v.h_ent[jr];
+    const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    const float lse = v.lse[jr], c_logp = v.c_logp[jr], c_ent = kEnt ? v.c_ent[jr] : 0.f, h_ent = kEnt ? v.h_ent[jr] : 0.f;
+    const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
     const int act = v.act[jr];
     const bool row_ok = wave_ok && jr < mb;
     f32x16 dh0, dh1;
@@ -732,9 +754,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);
                 za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);
             }
-            f32x16 acc;
+            f32x16 acc, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = sB[buf][acc_row(r, hi)];
+            for (int r = 0; r < 16; ++r) { acc[r] = sB[buf][acc_row(r, hi)]; acc1[r] = 0.f; }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -745,25 +767,37 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                     cb[c][t].l = *reinterpret_cast<const bf16x8*>(bp + 2 * kCPlaneB);
                 }
             CIRS_HSTAMP(1);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = mfma_bf16x6(za[s4], hz[s4], acc);
+            mfma_bf16x6_two(za[0], hz[0], acc, za[2], hz[2], acc1);
+            mfma_bf16x6_two(za[1], hz[1], acc, za[3], hz[3], acc1);
             CIRS_HSTAMP(2);
             float* tt = sT[wv];
-            // dZ in place.  Padded rows carry zero coefficients and lse = 1e30 (p = 0, d = 0); items beyond I exist only in
-            // the last tile (zero weights -> finite z) and are masked there.  Categorical.entropy uses
-            // log(clamp(p, eps, 1-eps)): the un-clamped entropy lse - E_p[z] comes from the forward statistics and only
-            // clamped elements (p < eps or p > 1 - eps) contribute a correction, applied below when the wave has any.
-            f32x16 zkeep, pkeep;
-            bool any_clamped = false;
+            // dZ.  t = (z - lse) log2 e as ONE fma, p = exp2(t), d = -c_logp p (+ the entropy term when compiled in); the action's
+            // element gets + c_logp in a second pass that only tiles containing some row's action execute (wave-uniform branch: ~9 % of
+            // the tiles at 32 rows x 336 tiles).  Padded rows carry zero coefficients and lse = 1e30 (p = 0, d = 0); items beyond I exist
+            // only in the last tile (zero weights -> finite z) and are masked there.  Categorical.entropy uses log(clamp(p, eps, 1-eps)):
+            // the un-clamped entropy lse - E_p[z] comes from the forward statistics and only clamped elements (p < eps or p > 1 - eps)
+            // contribute a correction, applied below when the wave has any (t is kept for that; p is recomputed there).
+            f32x16 tk;
+            float pmin = 1.0f, pmax = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = acc_row(r, hi);
-                float p;
-                zkeep[r] = acc[r] - lse;
-                const float d = dz_of(acc[r], lse, c_logp, c_ent, h_ent, tile0 + il == act, p);
-                pkeep[r] = p;
-                any_clamped |= fabsf(p - 0.5f) > 0.5f - 2.0f * eps;   // superset of the clamp condition
-                acc[r] = d;
+            for (int r = 0; r < 16; r += 2) {
+                const float t0 = __builtin_fmaf(acc[r] + acc1[r], kLog2e, nlse2), t1 = __builtin_fmaf(acc[r + 1] + acc1[r + 1], kLog2e, nlse2);
+                const float p0 = __builtin_amdgcn_exp2f(t0), p1 = __builtin_amdgcn_exp2f(t1);
+                tk[r] = t0; tk[r + 1] = t1;
+                pmin = __builtin_fminf(__builtin_fminf(pmin, p0), p1);      // v_min3_f32 / v_max3_f32
+                pmax = __builtin_fmaxf(__builtin_fmaxf(pmax, p0), p1);
+                if (kEnt) {   // + c_ent p (z - lse + H)
+                    acc[r] = __builtin_fmaf(c_ent * p0, __builtin_fmaf(t0, kLn2, h_ent), ncl * p0);
+                    acc[r + 1] = __builtin_fmaf(c_ent * p1, __builtin_fmaf(t1, kLn2, h_ent), ncl * p1);
+                } else {
+                    acc[r] = ncl * p0; acc[r + 1] = ncl * p1;
+                }
+            }
+            if (!row_ok) { pmin = 1.0f; pmax = 0.f; }     // padded rows (p = 0) must not send the wave into the correction pass
+            if (__any(act >= tile0 && act < tile0 + kTileN)) {
+                const int rel = act - tile0 - 4 * hi;     // accumulator register r holds item (r & 3) + 8 (r >> 2) + 4 hi of the tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += (rel == (r & 3) + 8 * (r >> 2)) ? c_logp : 0.f;
             }
             if (tile0 + kTileN > I) {
 #pragma unroll
@@ -772,14 +806,14 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
             CIRS_HSTAMP(3);
 #pragma unroll
             for (int r = 0; r < 16; ++r) tt[acc_row(r, hi) * kTStride + lo] = acc[r];   // transposed exchange: T[item][row]
-            if (__any(any_clamped)) {
+            if (__any(pmin < eps || pmax > 1.0f - eps)) {
                 const bool last = tile0 + kTileN > I;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = pkeep[r];
+                    const float p = __builtin_amdgcn_exp2f(tk[r]);
                     const bool c_lo = p < eps, c_hi = p > 1.0f - eps;
                     const bool ok = row_ok && (!last || tile0 + acc_row(r, hi) < I);
-                    const float corr = p * ((c_lo ? kLogEps : kLog1mEps) - zkeep[r]);
+                    const float corr = p * ((c_lo ? kLogEps : kLog1mEps) - tk[r] * kLn2);
                     ent -= (ok && (c_lo || c_hi)) ? corr : 0.f;
                 }
             }
@@ -1502,8 +1536,13 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
         const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
         const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
-        CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
-                                                  (const uint4*)v.wa_planes, w.ba, v, v.dwap));
+        if (cfg->ent_coef != 0.f) {
+            CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel<true>, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
+                                                      (const uint4*)v.wa_planes, w.ba, v, v.dwap));
+        } else {
+            CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel<false>, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
+                                                      (const uint4*)v.wa_planes, w.ba, v, v.dwap));
+        }
         CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
         // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
         static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");

@@ -5,9 +5,9 @@ cd "$(dirname "$0")/../.."
 OUT=tools/probes/_prof_obj; mkdir -p $OUT
 for f in cirs-codes_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  if [ "$b" = "tracker" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DCIRS_TRK_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
-  elif [ "$b" = "ppo" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DCIRS_HEAD_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
-  elif [ "$b" = "rollout" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DCIRS_MASS_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
+  if [ "$b" = "tracker" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -DCIRS_TRK_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
+  elif [ "$b" = "ppo" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -DCIRS_HEAD_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
+  elif [ "$b" = "rollout" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -DCIRS_MASS_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
   else cp cirs-codes_amd/csrc/_obj/$b.o $OUT/$b.o; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/*.o -o tools/probes/libcirs_prof.so
