@@ -77,7 +77,7 @@ def build_engine(wl, rank, world, device, learner="dp", dropout=0.0):
     return eng, tab
 
 
-def hip_event_kernel_time(eng, wl, reps=20):
+def hip_event_kernel_time(eng, wl, reps=100):
     """HIP-event timing on the launch stream, PPO minibatch step of mb rows launched exactly as inside the timed region:
     -> (seconds per whole cirs_ppo_minibatch call, mb, {kernel name: average seconds per launch}) where the per-kernel numbers
     come from event pairs the library records around each launch of that kernel (cirs_prof_start / cirs_prof_stop): the same
@@ -110,6 +110,7 @@ def hip_event_kernel_time(eng, wl, reps=20):
     t_step = start.elapsed_time(stop) / reps * 1e-3
     per_kernel = {}
     for kid, name in ((1, "head_bwd_fused_kernel"), (2, "head_stats_kernel")):
+        run(10)    # the event pairs are taken in steady state, like the kernel's average in a rocprofv3 trace of the timed loop
         abi.check(lib.cirs_prof_start(kid, reps), "cirs_prof_start")
         run(reps)
         tot, cnt = C.c_double(0.0), C.c_int32(0)

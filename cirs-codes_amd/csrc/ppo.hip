@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
 }
 
 constexpr int kTStride = 36;                 // transpose buffer row stride (floats): 16 B aligned, conflict-free b128 reads
-constexpr int kRSize = kTileN * kH + kTileN; // per-wave dWa partial tile + dba partial
+constexpr int kRSize = kTileN * kH + 2 * kTileN; // per-wave dWa partial tile + the two half-waves' dba partials (no cross-half shuffle)
 constexpr int kRowB = 144, kColB = 80;       // LDS row strides (bytes) of the R and C planes
 constexpr int kRPlaneB = kTileN * kRowB, kCPlaneB = kH * kColB;
 constexpr int kWBufB = 3 * kRPlaneB + 3 * kCPlaneB;
@@ -631,6 +631,13 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 // the next tile's global loads in flight; row strides 144 B / 80 B keep the ds_read_b128 of the operands conflict-free.
 
 
+// schedule knobs of head_bwd_fused_kernel (A/B-measured on one box with tools/ab_headbwd.py; defaults = the measured best)
+#ifndef CIRS_BWD_COMMIT_EARLY
+#define CIRS_BWD_COMMIT_EARLY 1   // 1: next tile's planes -> LDS before the dH2 product; 0: at the end of the iteration
+#endif
+#ifndef CIRS_BWD_REDUCE_POS
+#define CIRS_BWD_REDUCE_POS 0     // where the previous tile's dWa sum runs: 0 around the second logits MFMA group, 1 around the dH2 product
+#endif
 // logits of one tile as TWO independent accumulator chains (k-steps {0, 1} on the bias, {2, 3} on zero), issued alternately: a
 // dependent bf16 MFMA waits ~8 cycles for its predecessor, an independent one issues back to back
 __device__ __forceinline__ void mfma_bf16x6_two(const Planes& a0, const Planes& b0, f32x16& c0, const Planes& a1, const Planes& b1, f32x16& c1) {
@@ -660,8 +667,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     __shared__ __attribute__((aligned(16))) unsigned char sW[2][kWBufB];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     __shared__ __attribute__((aligned(16))) float sT[kBwdWaves][kTileN * kTStride];
-    __shared__ __attribute__((aligned(16))) float sR[kBwdWaves][kRSize];
+    __shared__ __attribute__((aligned(16))) float sR[2][kBwdWaves][kRSize];   // double-buffered: the sum of tile t runs inside iteration t + 1
     const int tid = threadIdx.x;
+    CIRS_SSTAMP(30);
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * kBwdWaves + wv) * kTileM;
@@ -671,33 +679,51 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     // and the row blocks that walk the same chunk share one L2 (the Wa planes of a tile leave HBM / MALL once, not 8 times)
     if (chunk * tiles_per_chunk * kTileN >= I) return;
     const int jr = wave_ok ? row0 + lo : 0;
-    // B operand of ZT: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
-    Planes hz[4];
-    {
-        const float4* src = reinterpret_cast<const float4*>(v.h2 + (size_t)jr * kH + 8 * hi);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const float4 p = src[4 * s4], q = src[4 * s4 + 1];
-            hz[s4] = split8(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
-        }
-    }
-    // B operand of the dWa product: element j of k-step t = H2[row acc_row(8 t + j, hi)][32 c + lo]
-    Planes hb[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float x0[8], x1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float* hp = v.h2 + (size_t)(wave_ok ? row0 + acc_row(8 * t + j, hi) : 0) * kH;
-            x0[j] = hp[lo]; x1[j] = hp[32 + lo];
-        }
-        hb[0][t] = split8(x0[0], x0[1], x0[2], x0[3], x0[4], x0[5], x0[6], x0[7]);
-        hb[1][t] = split8(x1[0], x1[1], x1[2], x1[3], x1[4], x1[5], x1[6], x1[7]);
-    }
+    // The wave's 32 x 64 tile of H2 is 8 KB of consecutive memory: read coalesced (8 x 1 KB per wave) and handed to the lanes through
+    // LDS -- a lane reading its own 256-byte row costs 64 cache lines per load instruction (the prologue was 6.1 k of the kernel's
+    // 77 k ticks).  The row scalars are requested first; they travel while the tile does.
     const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     const float lse = v.lse[jr], c_logp = v.c_logp[jr], c_ent = kEnt ? v.c_ent[jr] : 0.f, h_ent = kEnt ? v.h_ent[jr] : 0.f;
-    const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
     const int act = v.act[jr];
+    Planes hz[4];      // B operand of ZT: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
+    Planes hb[2][2];   // B operand of the dWa product: element j of k-step t = H2[row acc_row(8 t + j, hi)][32 c + lo]
+    {
+        constexpr int kHS = kH + 1;                      // odd row stride: both read patterns below are conflict-free
+        static_assert(kTileM * kHS <= kRSize, "the H2 tile borrows the wave's dWa partial-tile buffer before the first tile");
+        float* sh = sR[0][wv];
+        f32x4 t8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = row0 + 4 * q + (lane >> 4);
+            t8[q] = *reinterpret_cast<const f32x4*>(v.h2 + (size_t)(wave_ok ? r : 0) * kH + (lane & 15) * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float* d = sh + (4 * q + (lane >> 4)) * kHS + (lane & 15) * 4;
+            d[0] = t8[q].x; d[1] = t8[q].y; d[2] = t8[q].z; d[3] = t8[q].w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float* r = sh + lo * kHS + 16 * s4 + 8 * hi;
+            hz[s4] = split8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float x0[8], x1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* hp = sh + acc_row(8 * t + j, hi) * kHS;
+                x0[j] = hp[lo]; x1[j] = hp[32 + lo];
+            }
+            hb[0][t] = split8(x0[0], x0[1], x0[2], x0[3], x0[4], x0[5], x0[6], x0[7]);
+            hb[1][t] = split8(x1[0], x1[1], x1[2], x1[3], x1[4], x1[5], x1[6], x1[7]);
+        }
+        __builtin_amdgcn_wave_barrier();    // the buffer is first written as a partial tile at the end of iteration 0
+    }
+    const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
     const bool row_ok = wave_ok && jr < mb;
     f32x16 dh0, dh1;
 #pragma unroll
@@ -706,7 +732,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     const float eps = 1.1920928955078125e-7f;
     const float kLogEps = -15.942385152878742f, kLog1mEps = -1.1920929665620834e-7f;
     if (!wave_ok) {
-        for (int q = lane; q < kRSize; q += 64) sR[wv][q] = 0.f;
+        for (int q = lane; q < kRSize; q += 64) { sR[0][wv][q] = 0.f; sR[1][wv][q] = 0.f; }
     }
 
     const int first_tile = chunk * tiles_per_chunk * kTileN;
@@ -733,9 +759,42 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         *reinterpret_cast<uint4*>(base_ + 2 * kCPlaneB + dst_c) = gc2;                                     \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
+    CIRS_SSTAMP(31);
     if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
     __syncthreads();
+    CIRS_SSTAMP(32);
     float* slab = dwap + (size_t)blockIdx.y * dwa_slab_stride(I);
+    // sum of the kBwdWaves partial dWa tiles of one item tile in wave order -> slab of this row block (coalesced float4 stores).
+    // It runs one iteration late, between the operand reads and the MFMAs of the NEXT tile: its LDS round trip and its stores hide
+    // behind that tile's operand latency / matrix work instead of standing alone behind a second workgroup barrier.
+    // two halves, so that the caller can put matrix work between them: the LDS reads of all partial tiles, then the adds + stores
+    constexpr int kRedQ = (kTileN * kH / 4) / kThreads;
+    struct RedRegs { f32x4 t[kRedQ][kBwdWaves]; float b[kBwdWaves]; };
+    auto reduce_load = [&](int rb, RedRegs& rg) {
+#pragma unroll
+        for (int q = 0; q < kRedQ; ++q)
+#pragma unroll
+            for (int w2 = 0; w2 < kBwdWaves; ++w2) rg.t[q][w2] = reinterpret_cast<const f32x4*>(sR[rb][w2])[tid + kThreads * q];
+#pragma unroll
+        for (int w2 = 0; w2 < kBwdWaves; ++w2) rg.b[w2] = tid < kTileN ? sR[rb][w2][kTileN * kH + tid] + sR[rb][w2][kTileN * kH + kTileN + tid] : 0.f;
+    };
+    auto reduce_store = [&](const RedRegs& rg, int t0) {
+#pragma unroll
+        for (int q = 0; q < kRedQ; ++q) {
+            const int f = tid + kThreads * q;  // float4 index within the 32 x 64 tile
+            f32x4 t = rg.t[q][0];
+#pragma unroll
+            for (int w2 = 1; w2 < kBwdWaves; ++w2) t += rg.t[q][w2];
+            if (t0 + (f >> 4) < I) *reinterpret_cast<f32x4*>(slab + (size_t)t0 * kH + 4 * f) = t;
+        }
+        if (tid < kTileN) {
+            float t = rg.b[0];
+#pragma unroll
+            for (int w2 = 1; w2 < kBwdWaves; ++w2) t += rg.b[w2];
+            if (t0 + tid < I) slab[(size_t)I * kH + t0 + tid] = t;
+        }
+    };
+    auto reduce_tile = [&](int rb, int t0) { RedRegs rg; reduce_load(rb, rg); reduce_store(rg, t0); };
     for (int it = 0; it < n_tiles; ++it) {
         const int buf = it & 1;
         const int tile0 = first_tile + it * kTileN;
@@ -743,6 +802,10 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);  // global loads in flight during the MFMAs below
         f32x16 dw0, dw1;
         float db = 0.f;
+        if (!wave_ok) {     // idle row tile (padding of the last row block): staging and the reduction only
+            if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);
+            if (it > 0) reduce_tile(buf ^ 1, tile0 - kTileN);
+        }
         if (wave_ok) {
             const unsigned char* tw = sW[buf];
             // every LDS operand of this tile up front: one latency exposure instead of one per k-step
@@ -768,7 +831,10 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 }
             CIRS_HSTAMP(1);
             mfma_bf16x6_two(za[0], hz[0], acc, za[2], hz[2], acc1);
+            RedRegs rg;
+            if (CIRS_BWD_REDUCE_POS == 0 && it > 0) reduce_load(buf ^ 1, rg);
             mfma_bf16x6_two(za[1], hz[1], acc, za[3], hz[3], acc1);
+            if (CIRS_BWD_REDUCE_POS == 0 && it > 0) reduce_store(rg, tile0 - kTileN);
             CIRS_HSTAMP(2);
             float* tt = sT[wv];
             // dZ.  t = (z - lse) log2 e as ONE fma, p = exp2(t), d = -c_logp p (+ the entropy term when compiled in); the action's
@@ -818,13 +884,8 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 }
             }
             CIRS_HSTAMP(4);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const Planes a = split8(acc, 8 * t);  // element j: dZ[row lo][item acc_row(8 t + j, hi)]
-                mfma_bf16x6_pair(a, cb[0][t], cb[1][t], dh0, dh1);
-            }
-            CIRS_HSTAMP(5);
-            // the wave's own LDS writes above are read back by other lanes of the same wave
+            // the wave's own LDS writes above are read back by other lanes of the same wave.  The read-back is requested BEFORE the dH2
+            // product: its latency and the second split (VALU) then sit in the issue gaps of the 24 dH2 MFMAs, which do not depend on them
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -834,55 +895,45 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 const float4 t4 = *reinterpret_cast<const float4*>(&tt[lo * kTStride + 8 * g + 4 * hi]);
                 dzt[4 * g] = t4.x; dzt[4 * g + 1] = t4.y; dzt[4 * g + 2] = t4.z; dzt[4 * g + 3] = t4.w;
             }
+            // next tile's planes -> the other LDS buffer (last read in iteration it - 1, one barrier ago): the prefetch was requested at
+            // the top of this iteration, and no store of this iteration has been issued yet (the wait is for loads only)
+            if (CIRS_BWD_COMMIT_EARLY && it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);
+            if (CIRS_BWD_REDUCE_POS == 1 && it > 0) reduce_load(buf ^ 1, rg);      // the previous tile's partial dWa tiles: their LDS round trip hides behind the dH2 product
+            {
+                const Planes a0 = split8(acc, 0), a1 = split8(acc, 8);   // element j: dZ[row lo][item acc_row(8 t + j, hi)]
+                mfma_bf16x6_pair(a0, cb[0][0], cb[1][0], dh0, dh1);
+                mfma_bf16x6_pair(a1, cb[0][1], cb[1][1], dh0, dh1);
+            }
+            if (CIRS_BWD_REDUCE_POS == 1 && it > 0) reduce_store(rg, tile0 - kTileN);
+            CIRS_HSTAMP(5);
             CIRS_HSTAMP(6);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; db += dzt[r]; }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const Planes a = split8(dzt, 8 * t);  // element j: dZ[row acc_row(8 t + j, hi)][item lo]
-                mfma_bf16x6_pair(a, hb[0][t], hb[1][t], dw0, dw1);
+            {
+                const Planes b0 = split8(dzt, 0), b1 = split8(dzt, 8);   // element j: dZ[row acc_row(8 t + j, hi)][item lo]
+                mfma_bf16x6_pair(b0, hb[0][0], hb[1][0], dw0, dw1);
+                mfma_bf16x6_pair(b1, hb[0][1], hb[1][1], dw0, dw1);
             }
         }
         CIRS_HSTAMP(7);
-        lds_barrier();  // the slab reduction of the previous tile has finished reading sR
-        CIRS_HSTAMP(8);
         if (wave_ok) {
-            float* rr = sR[wv];
+            float* rr = sR[buf][wv];    // this buffer was last read in iteration it - 1 (the sum of tile it - 2), one barrier ago
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int il = acc_row(r, hi);
                 rr[il * kH + lo] = dw0[r];
                 rr[il * kH + 32 + lo] = dw1[r];
             }
-            db += __shfl_xor(db, 32, CIRS_WAVE);
-            if (hi == 0) rr[kTileN * kH + lo] = db;
+            rr[kTileN * kH + lane] = db;     // slot 32 hi + lo: the reducer adds the two halves
         }
-        if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);  // the other buffer was last read in iteration it-1
+        if (!CIRS_BWD_COMMIT_EARLY && wave_ok && it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);
         CIRS_HSTAMP(9);
-        lds_barrier();
+        lds_barrier();   // ONE workgroup barrier per tile: partial tiles + next tile's planes are visible
         CIRS_HSTAMP(10);
-        // sum the kBwdWaves partial tiles in wave order -> slab of this row block (coalesced float4 stores)
-        {
-#pragma unroll
-            for (int q = 0; q < (kTileN * kH / 4) / kThreads; ++q) {
-                const int f = tid + kThreads * q;  // float4 index within the 32 x 64 tile
-                float4 t = reinterpret_cast<const float4*>(sR[0])[f];
-#pragma unroll
-                for (int w2 = 1; w2 < kBwdWaves; ++w2) {
-                    const float4 u = reinterpret_cast<const float4*>(sR[w2])[f];
-                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-                }
-                if (tile0 + (f >> 4) < I) *reinterpret_cast<float4*>(slab + (size_t)tile0 * kH + 4 * f) = t;
-            }
-            if (tid < kTileN) {
-                float t = sR[0][kTileN * kH + tid];
-#pragma unroll
-                for (int w2 = 1; w2 < kBwdWaves; ++w2) t += sR[w2][kTileN * kH + tid];
-                if (tile0 + tid < I) slab[(size_t)I * kH + tile0 + tid] = t;
-            }
-        }
-        CIRS_HSTAMP(11);
     }
+    CIRS_SSTAMP(33);
+    if (n_tiles > 0) reduce_tile((n_tiles - 1) & 1, first_tile + (n_tiles - 1) * kTileN);
+    CIRS_SSTAMP(34);
 #undef CIRS_ISSUE
 #undef CIRS_COMMIT
     if (!wave_ok) return;
@@ -895,6 +946,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     }
     ent += __shfl_xor(ent, 32, CIRS_WAVE);
     if (hi == 0) v.entp[(size_t)chunk * n_pad + jr] = ent;
+    CIRS_SSTAMP(35);
 }
 
 // ---- slab sums of the wa|ba gradient (one of kWaSumBlocks workgroups of 512 threads) ------------------------------------

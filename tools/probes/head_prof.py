@@ -36,6 +36,13 @@ for k in sorted(names):
     print(f"  {names[k]:36s} {t[k] - prev:9.0f}   (cum {t[k] - t[0]:9.0f})")
     prev = t[k]
 
+ks = {30: "kernel entry", 31: "H2 operands loaded + split (hz, hb), row scalars", 32: "first planes tile staged + barrier", 33: "all tiles", 34: "last tile's dWa sum",
+      35: "dH2 / entropy partial stores"}
+print("head_bwd_fused_kernel, workgroup (0,0) thread 0, whole kernel:")
+prev = t[30]
+for k in sorted(ks):
+    print(f"  {ks[k]:52s} {t[k] - prev:9.0f}   (cum {t[k] - t[30]:9.0f})")
+    prev = t[k]
 tb = {16: "row workgroup 0: entry", 17: "W2/W1 columns requested, 31 dh2 slabs summed, da2 written", 18: "barrier", 19: "da1 tile (32 MFMAs), relu gate, stores", 20: "barrier",
       21: "dW1 tile (wave 0)"}
 print("trunk_bwd_kernel (raw ticks; the stamps of thread 0 = wave 0):")
