@@ -36,9 +36,27 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t& h, uint32
     l = cvt_pk_bf16(t.x, t.y);
 }
 __device__ __forceinline__ Planes split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+    // the four pairs advance level by level: every v_cvt_pk_bf16_f32 has three independent ones behind it before its result is
+    // consumed (written pair after pair the compiler left an s_nop behind each conversion)
+    const f32x2_b x[4] = {{x0, x1}, {x2, x3}, {x4, x5}, {x6, x7}};
     uint32_t hh[4], mm[4], ll[4];
-    split_pair(x0, x1, hh[0], mm[0], ll[0]); split_pair(x2, x3, hh[1], mm[1], ll[1]);
-    split_pair(x4, x5, hh[2], mm[2], ll[2]); split_pair(x6, x7, hh[3], mm[3], ll[3]);
+    f32x2_b r[4], t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hh[i] = cvt_pk_bf16(x[i].x, x[i].y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_b hf = {__uint_as_float(hh[i] << 16), __uint_as_float(hh[i] & 0xffff0000u)};
+        r[i] = x[i] - hf;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mm[i] = cvt_pk_bf16(r[i].x, r[i].y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_b mf = {__uint_as_float(mm[i] << 16), __uint_as_float(mm[i] & 0xffff0000u)};
+        t[i] = r[i] - mf;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ll[i] = cvt_pk_bf16(t[i].x, t[i].y);
     const pk4 h = {hh[0], hh[1], hh[2], hh[3]}, m = {mm[0], mm[1], mm[2], mm[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
     Planes o;
     o.h = __builtin_bit_cast(bf16x8, h); o.m = __builtin_bit_cast(bf16x8, m); o.l = __builtin_bit_cast(bf16x8, l);

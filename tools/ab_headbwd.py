@@ -12,9 +12,10 @@ abi.LIB_PATH = os.path.abspath(sys.argv[1])
 import bench
 
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+pre = int(sys.argv[3]) if len(sys.argv) > 3 else 3     # updates before timing: a trained policy has clamped probabilities (p < eps)
 wl = bench.WORKLOADS["c3"]
 eng, _ = bench.build_engine(wl, 0, 1, torch.device("cuda:0"))
-for _ in range(3):
+for _ in range(pre):
     eng.collect(); eng.update(1024, 2)
 eng.collect(); eng.learner.prepare(eng.rollout.traj, eng.lengths.cpu().numpy(), lens_dev=eng.lengths)
 out = []
