@@ -218,7 +218,10 @@ def gather_fm_probe(device, reps=10):
     from cirs_hip.deepfm import DeviceDeepFM
     out = []
     traffic, src = pmc_traffic("c3")
-    for name, U, I, E, n in (("c3_E32", 7176, 10728, 32, 1 << 24), ("c3_E16", 7176, 10728, 16, 1 << 24), ("c5_E64", 1 << 20, 1 << 20, 64, 1 << 23)):
+    # mid_E64: 2 x 2^17 rows x 260 B = 68 MB -- past the 8 x 4 MiB L2s, inside the 256 MiB Infinity Cache: where the logical rate of the
+    # C3 shape turns into the physical rate of the C5 shape
+    for name, U, I, E, n in (("c3_E32", 7176, 10728, 32, 1 << 24), ("c3_E16", 7176, 10728, 16, 1 << 24), ("mid_E64", 1 << 17, 1 << 17, 64, 1 << 23),
+                             ("c5_E64", 1 << 20, 1 << 20, 64, 1 << 23)):
         g = torch.Generator(device="cpu").manual_seed(E)
         # weights on the device directly (the C5 tables are 2 x 268 MB)
         w = {"emb_user": torch.randn(U, E, generator=g) * 0.3, "emb_item": torch.randn(I + 1, E, generator=g) * 0.3,
@@ -249,7 +252,8 @@ def gather_fm_probe(device, reps=10):
                             "traffic": (traffic or {}).get(f"gather_fm_kernel<{E}, true>"),
                             "compulsory_stream_bytes_per_pair": 32,
                             "note": "tables L2-resident: achieved is a logical gather rate, physical HBM traffic ~ 32 B/pair" if U < 100000 else
-                                    "tables past L2 / Infinity Cache: algorithmic ~ physical"}}
+                                    ("tables past L2, inside the Infinity Cache (MALL): rows come from MALL, HBM sees the X / out streams" if U < (1 << 19) else
+                                     "tables past L2 / Infinity Cache: algorithmic ~ physical")}}
         out.append(rec)
         del m, X, w, y
         torch.cuda.empty_cache()

@@ -38,6 +38,13 @@ def result_from_trajectory(traj, lengths: np.ndarray, offsets: np.ndarray) -> Di
 
 
 class Collector:
+    def __new__(cls, policy=None, env=None, *args, **kwargs):
+        """Host vector envs (VirtualTB-v0: BASELINE configs[0], CPU plumbing) are collected by the per-step loop of core.host_rl."""
+        if cls is Collector and getattr(env, "host_mode", False):
+            from core.host_rl import HostCollector
+            return HostCollector(policy, env, *args, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, policy, env, buffer: Optional[VectorReplayBuffer] = None, preprocess_fn: Optional[Callable[..., Any]] = None,
                  exploration_noise: bool = False, remove_recommended_ids=False, force_length=0):
         assert hasattr(env, "__len__"), "pass a tianshou.env.DummyVectorEnv"

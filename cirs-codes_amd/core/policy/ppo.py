@@ -17,6 +17,15 @@ from tianshou.data import Batch
 
 
 class PPOPolicy(nn.Module):
+    def __new__(cls, actor=None, critic=None, optim=None, dist_fn=None, *args, **kwargs):
+        """A continuous actor (tianshou.utils.net.continuous.ActorProb: CIRS-RL-taobao.py:208, BASELINE configs[0], CPU plumbing) is
+        served by the host PPO of core.host_rl; the discrete catalogue actor by the device learner below."""
+        from tianshou.utils.net.continuous import ActorProb
+        if cls is PPOPolicy and isinstance(actor, ActorProb):
+            from core.host_rl import HostPPOPolicy
+            return HostPPOPolicy(actor, critic, optim, dist_fn, *args, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, actor, critic, optim, dist_fn=None, eps_clip=0.2, dual_clip=None, value_clip=False,
                  advantage_normalization=True, recompute_advantage=False, discount_factor=0.99, vf_coef=0.5, ent_coef=0.01,
                  max_grad_norm=None, gae_lambda=0.95, max_batchsize=256, reward_normalization=False, action_scaling=True,

@@ -14,8 +14,12 @@ class BaseVectorEnv:
         self._specs = [fn() for fn in env_fns]
         self.env_num = len(self._specs)
         first = self._specs[0]
-        for s in self._specs[1:]:
-            assert type(s) is type(first) and s.batch_key() == first.batch_key(), "all envs of a vector env must share tables and parameters"
+        # host mode: envs that step on the CPU with gym's reset / step protocol (VirtualTB-v0 and SimulatedEnv over it: BASELINE
+        # configs[0], CPU plumbing like in the reference) are looped over like the reference's DummyVectorEnv does
+        self.host_mode = getattr(first, "env_name", None) == "VirtualTB-v0" or type(first).__name__ == "VirtualTB"
+        if not self.host_mode:
+            for s in self._specs[1:]:
+                assert type(s) is type(first) and s.batch_key() == first.batch_key(), "all envs of a vector env must share tables and parameters"
         self.workers = self._specs
         self._dev = None  # cirs_hip.env.DeviceEnv, built on first use (needs the GPU)
         self._user_rng = np.random.RandomState()
@@ -39,6 +43,9 @@ class BaseVectorEnv:
         return self._dev
 
     def seed(self, seed=None):
+        if self.host_mode:       # venvs.py:263-283: worker i is seeded with seed + i (SimulatedEnv.seed seeds torch's generator)
+            seeds = [None] * self.env_num if seed is None else ([seed + i for i in range(self.env_num)] if np.isscalar(seed) else list(seed))
+            return [w.seed(s) for w, s in zip(self._specs, seeds)]
         if seed is not None:
             s0 = seed if np.isscalar(seed) else seed[0]
             self._user_rng = np.random.RandomState(int(s0))
@@ -50,6 +57,9 @@ class BaseVectorEnv:
         return self._user_rng.randint(0, self._specs[0].n_users, n)
 
     def reset(self, id=None, users=None):
+        if self.host_mode:
+            ids = range(self.env_num) if id is None else np.atleast_1d(id)
+            return np.stack([self._specs[i].reset() for i in ids])
         dev = self.device_env()
         ids = np.arange(self.env_num) if id is None else np.atleast_1d(id)
         users = self.draw_users(len(ids)) if users is None else np.asarray(users)
@@ -57,6 +67,14 @@ class BaseVectorEnv:
         return obs.cpu().numpy().reshape(-1, 1)
 
     def step(self, action, id=None):
+        if self.host_mode:
+            from tianshou.data import Batch
+            ids = range(self.env_num) if id is None else np.atleast_1d(id)
+            res = [self._specs[i].step(action[j]) for j, i in enumerate(ids)]
+            obs, rew, done, infos = zip(*res)
+            keys = infos[0].keys() if len(infos) and isinstance(infos[0], dict) else []
+            info = Batch({k: np.array([inf[k] for inf in infos]) for k in keys}, env_id=np.asarray(list(ids)))
+            return np.stack(obs), np.stack(rew), np.stack(done), info
         dev = self.device_env()
         ids = np.arange(self.env_num) if id is None else np.atleast_1d(id)
         o, r, d, c, _ = dev.step(torch.as_tensor(np.asarray(action).reshape(-1)), torch.as_tensor(ids))

@@ -1045,7 +1045,104 @@ def gen_userval():
     print("userval.npz: x", out["x"].shape, "env table", out["env_values"].shape, list(out["env_columns"]))
 
 
-FAMILIES = {"virtualtb": gen_virtualtb, "collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+# --------------------------------------------------------------------------------------------------
+# c1rl family: the RL loop of CIRS-RL-taobao.py (BASELINE configs[0]: VirtualTaobao, 4 envs, CPU) -- two collect + update rounds
+# --------------------------------------------------------------------------------------------------
+def _stressed_mmoe():
+    import collections
+    from core.user_model_mmoe import UserModel_MMOE
+    from deepctr_torch.inputs import DenseFeat
+    x_columns = [DenseFeat("user_feat", 91), DenseFeat("feat_item", 27)]
+    y_columns = [DenseFeat("y", 1)]
+    tasks = collections.OrderedDict({f.name: "regression" for f in y_columns})
+    task_logit_dim = {f.name: f.dimension for f in y_columns}
+    model = UserModel_MMOE(x_columns, y_columns, len(tasks), tasks, task_logit_dim, dnn_hidden_units=(128, 128), seed=2022, device="cpu")
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for name, p_ in model.named_parameters():
+            if name.startswith("dnn.") and name.endswith("weight"):
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.15)
+            elif name.endswith("weight") and "linear_model" in name:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.3)
+            elif name.endswith("bias"):
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+        model.tower_network[0].weight.mul_(0.05)
+    return model.eval()
+
+
+def gen_c1rl():
+    """CIRS-RL-taobao.py:150-300 with 4 envs: SimulatedEnv(VirtualTB) x 4 -> dense-feature StateTrackerTransformer (dropout 0.1 live,
+    as in the script) -> ActorProb / Critic, Independent(Normal) PPO with action scaling -> Collector.collect(n_episode=4) +
+    policy.update, twice.  Recorded: initial parameters, per-round buffer rows (states, raw actions, rewards, dones), result
+    dicts, loss lists, parameters after every update, the return statistics."""
+    import gym
+    from torch.distributions import Independent, Normal
+    from core.collector import Collector
+    from core.inputs import get_dataset_columns
+    from core.policy.ppo import PPOPolicy
+    from core.state_tracker import StateTrackerTransformer
+    from core.user_model import compute_input_dim
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.env import DummyVectorEnv
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ActorProb, Critic
+    N, thr, T, B = 4, 2.4, 9, 4
+    gym.register(id="VirtualTB-v0", entry_point="virtualTB.envs.virtualTB:VirtualTB", kwargs=dict(num_leave_compute=N, leave_threshold=thr, max_turn=T))
+    model = _stressed_mmoe()
+    gym.register(id="SimulatedEnv-v0", entry_point="core.env.simulatedEnv.simulated_env:SimulatedEnv",
+                 kwargs=dict(user_model=model, task_name="VirtualTB-v0", version="v1", tau=10.0, gamma_exposure=3.0))
+    sim = gym.make("SimulatedEnv-v0")
+    train_envs = DummyVectorEnv([lambda: gym.make("SimulatedEnv-v0") for _ in range(B)])
+    seed = 2022
+    np.random.seed(seed); torch.manual_seed(seed); train_envs.seed(seed)
+    dim_model, dim_state = 27, 20
+    uc, ac, fc, hu, ha, hf = get_dataset_columns(dim_model, envname="VirtualTB-v0")
+    assert dim_model == compute_input_dim(ac)
+    tracker = StateTrackerTransformer(uc, ac, fc, dim_model=dim_model, dim_state=dim_state, dim_max_batch=B, dataset="VirtualTB-v0",
+                                      has_user_embedding=hu, has_action_embedding=ha, has_feedback_embedding=hf, nhead=3, d_hid=128,
+                                      nlayers=2, dropout=0.1, device="cpu", seed=seed, MAX_TURN=T)
+    net = Net(dim_state, hidden_sizes=[64, 64], device="cpu")
+    actor = ActorProb(net, sim.action_space.shape, max_action=sim.action_space.high[0], device="cpu")
+    critic = Critic(net, device="cpu")
+    for m in list(actor.modules()) + list(critic.modules()):
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight); torch.nn.init.zeros_(m.bias)
+    optim = [torch.optim.Adam(list(actor.parameters()) + list(critic.parameters()), lr=1e-3), torch.optim.Adam(tracker.parameters(), lr=1e-3)]
+
+    def dist(*logits):
+        return Independent(Normal(*logits), 1)
+
+    policy = PPOPolicy(actor, critic, optim, dist, discount_factor=0.95, max_grad_norm=0.5, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0,
+                       reward_normalization=1, advantage_normalization=1, recompute_advantage=0, value_clip=1, gae_lambda=0.95,
+                       action_space=sim.action_space)
+    collector = Collector(policy, train_envs, VectorReplayBuffer(400, B), preprocess_fn=tracker.build_state)
+    out = dict(cfg=np.array([N, thr, T, B, dim_model, dim_state], np.float64), action_low=sim.action_space.low, action_high=sim.action_space.high)
+    out.update({"mmoe_" + k: v.detach().numpy() for k, v in model.state_dict().items()})
+    snap = lambda tag: out.update({f"{tag}_actor_{k}": v.detach().numpy().copy() for k, v in actor.state_dict().items()} |
+                                  {f"{tag}_critic_{k}": v.detach().numpy().copy() for k, v in critic.state_dict().items()} |
+                                  {f"{tag}_tracker_{k}": v.detach().numpy().copy() for k, v in tracker.state_dict().items()})
+    snap("init")
+    for rnd in range(2):
+        torch.manual_seed(100 + rnd); np.random.seed(200 + rnd)
+        res = collector.collect(n_episode=B)
+        buf = collector.buffer
+        idx = buf.sample_index(0)
+        b = buf[idx]
+        out.update({f"r{rnd}_idx": idx, f"r{rnd}_obs": b.obs.detach().numpy(), f"r{rnd}_obs_next": b.obs_next.detach().numpy(),
+                    f"r{rnd}_act": np.asarray(b.act), f"r{rnd}_rew": np.asarray(b.rew, np.float64), f"r{rnd}_done": np.asarray(b.done),
+                    f"r{rnd}_res_rews": res["rews"], f"r{rnd}_res_lens": res["lens"], f"r{rnd}_res_idxs": res["idxs"],
+                    f"r{rnd}_res_n": np.array([res["n/ep"], res["n/st"]])})
+        losses = policy.update(0, buf, batch_size=16, repeat=2)
+        out.update({f"r{rnd}_loss_" + k.replace("/", "_"): np.array(v) for k, v in losses.items()})
+        out[f"r{rnd}_ret_rms"] = np.array([policy.ret_rms.mean, policy.ret_rms.var, policy.ret_rms.count], np.float64)
+        snap(f"r{rnd}")
+    np.savez_compressed(os.path.join(GOLDEN, "c1rl.npz"), **out)
+    print("c1rl.npz: n/st", out["r0_res_n"], out["r1_res_n"], "losses", np.round(out["r0_loss_loss"][:4], 5), "lens", out["r0_res_lens"], out["r1_res_lens"],
+          "act[0,:3]", out["r0_act"][0, :3])
+
+
+
+FAMILIES = {"c1rl": gen_c1rl, "virtualtb": gen_virtualtb, "collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

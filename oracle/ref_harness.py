@@ -54,6 +54,9 @@ def _install_gym():
         def sample(self):
             raise NotImplementedError
 
+        def seed(self, seed=None):     # gym seeds the space's own generator; the stub samples from numpy's global one
+            return [seed]
+
     class Box(Space):
         def __init__(self, low, high, shape=None, dtype=np.float32):
             if shape is None:

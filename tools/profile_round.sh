@@ -1,0 +1,30 @@
+#!/bin/bash
+# All measurements of a round in one GPU call:  bash tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
+#   bench JSON lines (c3, c2, c3 with --dropout 0.1), rocprofv3 kernel-trace summaries of the timed step (eval-mode and dropout-mode)
+#   and of the K1-K2 / sweep workload (tools/pmc_workload.py), the phase timeline, the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs).
+tag=${1:-r03}
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out/$tag; mkdir -p $out
+export TMPDIR=/tmp
+cd $root
+python bench.py > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
+python bench.py --workload c2 --no-cpu-baseline --no-probes > $out/${tag}_bench_c2.json 2>> $out/bench_c3.err
+python bench.py --dropout 0.1 --no-cpu-baseline --no-probes > $out/${tag}_bench_c3_dropout.json 2>> $out/bench_c3.err
+cd /tmp
+for mode in eval dropout; do
+  flags="--no-probes --no-cpu-baseline --steps 50 --warmup 15"; [ $mode = dropout ] && flags="$flags --dropout 0.1"
+  rm -rf /tmp/prof_$mode
+  timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_$mode -o p -- python $root/bench.py $flags > $out/${tag}_bench_c3_prof_$mode.json 2> $out/prof_$mode.err
+  db=$(find /tmp/prof_$mode -name "*.db" | head -1)
+  sfx=""; [ $mode = dropout ] && sfx="_dropout"
+  python $root/tools/kstats.py $db $out/${tag}_bench_c3${sfx}_kernel_stats.csv 40 > $out/kstats_$mode.txt
+  [ $mode = eval ] && python $root/tools/step_timeline.py $db $out/${tag}_step_timeline.md > /dev/null
+done
+rm -rf /tmp/prof_k12
+timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_k12 -o p -- python $root/tools/pmc_workload.py > /dev/null 2> $out/prof_k12.err
+db=$(find /tmp/prof_k12 -name "*.db" | head -1)
+python $root/tools/kstats.py $db $out/${tag}_k1k2_sweep_kernel_stats.csv 40 > $out/kstats_k12.txt
+cd $root
+python tools/pmc_traffic.py collect $tag > $out/pmc.txt 2>&1
+cp gpurun_out/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.md $out/ 2>/dev/null
+tail -3 $out/kstats_eval.txt; head -c 600 $out/${tag}_bench_c3.json
