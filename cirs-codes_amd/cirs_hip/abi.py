@@ -152,6 +152,9 @@ SIGNATURES = {
     "cirs_normed_reward": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "cirs_ppo_minibatch_dp": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, _P,
                                         C.c_int32, _P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P]),
+    "cirs_ppo_tp_exchange_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "cirs_ppo_minibatch_tp": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, C.c_int32, _P]),
     "cirs_ppo_shard_stat_floats": (C.c_int32, []),
     "cirs_ppo_shard_norm": (C.c_int, [C.POINTER(PpoCfg), _P, C.c_int64, C.c_int64, _P, _P]),
     "cirs_ppo_shard_adam": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int32, _P, _P]),

@@ -247,6 +247,55 @@ class DeviceLearner:
                 k += 1
         return losses
 
+    def learn_tp(self, batch_size, repeat, perms, rank, world, item_base, coll, want_tracker_grad=True):
+        """learn() for an ITEM-SHARDED actor head (tensor-parallel; BASELINE configs[4]): this learner was built over the shard
+        (n_items = the rank's item count, flat parameters [trunk | wa_shard | ba_shard | critic]); the batch holds global item ids
+        and every rank runs every row.  Per minibatch: phase 1 -> all-gather of 16 B per row (max, sum-exp, sum exp z, the
+        action's logit from its owner) -> phase 2 (merge in rank order, fused backward over the local items: the shard's head
+        gradient is complete) -> all-reduce of the d h2 partials (+ entropy clamp partials + squared-norm slots) -> phase 3
+        (replicated trunk backward, global clip coefficient, Adam on the shard + trunk).  Trunk, critic and the row statistics
+        stay bit-identical across ranks; `coll`: all_gather(out, inp), all_reduce(t) (cirs_hip.distributed.Collectives)."""
+        n = self.n_rows
+        slices = minibatch_slices(n, batch_size)
+        max_mb = max(e - s for s, e in slices)
+        ws = self.workspace(max_mb)
+        losses = torch.zeros((repeat * len(slices), 4), dtype=torch.float32, device=self.device)
+        perm_all_d = self._perms_on_device(n, repeat, perms)
+        pad = lambda m: (m + 31) // 32 * 32
+        nred_max = int(self._lib.cirs_ppo_tp_exchange_floats(max_mb, world))
+        if getattr(self, "_tp_red", None) is None or self._tp_red.numel() < nred_max or self._tp_all.numel() < world * 4 * pad(max_mb):
+            self._tp_stats = torch.zeros(4 * pad(max_mb), dtype=torch.float32, device=self.device)
+            self._tp_all = torch.zeros(world * 4 * pad(max_mb), dtype=torch.float32, device=self.device)
+            self._tp_red = torch.zeros(nred_max, dtype=torch.float32, device=self.device)
+
+        def call(phase, idx_ptr, mb, stats4, stats_all, red, want_dobs, loss_ptr):
+            abi.check(self._lib.cirs_ppo_minibatch_tp(
+                C.byref(self.cfg), self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                self.opt_step, C.byref(self.batch), idx_ptr, mb, int(item_base), int(rank), int(world), stats4, stats_all, red,
+                self.dobs.data_ptr() if want_dobs else None, self.n_env, loss_ptr, ws.data_ptr(), ws.numel(), phase, self._stream()),
+                f"cirs_ppo_minibatch_tp(phase {phase})")
+
+        k = 0
+        for rep in range(repeat):
+            perm_d = perm_all_d[rep]
+            last = rep == repeat - 1
+            if last and want_tracker_grad:
+                self.dobs.zero_()
+            for s0, e0 in slices:
+                mb, npad = e0 - s0, pad(e0 - s0)
+                idx_ptr = perm_d.data_ptr() + 4 * s0
+                stats4, gathered = self._tp_stats[:4 * npad], self._tp_all[:world * 4 * npad]
+                red = self._tp_red[:int(self._lib.cirs_ppo_tp_exchange_floats(mb, world))]
+                call(1, idx_ptr, mb, stats4.data_ptr(), None, red.data_ptr(), False, None)
+                coll.all_gather(gathered, stats4)
+                stats_all = gathered.view(world, 4, npad).permute(1, 0, 2).contiguous()     # field-major: [4][world][n_pad]
+                call(2, idx_ptr, mb, None, stats_all.data_ptr(), red.data_ptr(), False, None)
+                coll.all_reduce(red)
+                call(3, idx_ptr, mb, None, None, red.data_ptr(), last and want_tracker_grad, losses.data_ptr() + 16 * k)
+                self.opt_step += 1
+                k += 1
+        return losses
+
     def learn(self, batch_size, repeat, perms: Optional[List[np.ndarray]] = None, want_tracker_grad=True):
         """learn(): `repeat` passes of shuffled minibatches.  Returns loss arrays + leaves d loss / d obs of the LAST
         repeat in self.dobs ([T+1, B, S]) for the tracker backward.  perms: recorded permutations (parity tests);

@@ -274,7 +274,8 @@ __device__ __forceinline__ void adv_stats_block(const float* __restrict__ adv_fl
 __global__ __launch_bounds__(256) void head_stats_merge_kernel(cirs_ppo_cfg cfg, cirs_ppo_batch b, const int32_t* __restrict__ idx,
                                                                int mb, int mb_norm, int n_pad, int n_chunks, int n_env,
                                                                ActorPartialView pv, const float* __restrict__ wa,
-                                                               const float* __restrict__ ba, MbView v) {
+                                                               const float* __restrict__ ba, MbView v,
+                                                               const float* __restrict__ za_in, int item_base) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_pad) return;
@@ -290,9 +291,12 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(cirs_ppo_cfg cfg,
     // each (lane i holds element i) and reach lane 0's fma chain through LDS -- one lane reading 128 floats from memory on its own is
     // 128 memory instructions behind two serial round trips.
     __shared__ __attribute__((aligned(16))) float sRow[4][2][kH];
+    // Item-sharded head (za_in != null): the partials are one (m, s, t) triple per shard, folded by head_tp_fold_kernel and
+    // all-gathered; za_in [n_chunks][n_pad] carries the action's logit from the shard that owns the item (NaN elsewhere), and the
+    // action is stored relative to THIS shard's first item (item_base) for the backward kernel's `item == action` test.
     const int src = idx[j];
     const int a = b.act[src];
-    const float hl = v.h2[(size_t)j * kH + lane], wl = wa[(size_t)a * kH + lane];
+    const float hl = v.h2[(size_t)j * kH + lane], wl = za_in ? 0.f : wa[(size_t)a * kH + lane];
     float m = -INFINITY, s = 0.f, t = 0.f;
     for (int c = lane; c < n_chunks; c += CIRS_WAVE) {
         const size_t o = (size_t)c * n_pad + j;
@@ -318,15 +322,24 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(cirs_ppo_cfg cfg,
     if (lane != 0) return;
     const float* hr = sRow[threadIdx.x >> 6][0];
     const float* wr = sRow[threadIdx.x >> 6][1];
-    float z = ba[a];
+    float z;
+    if (za_in) {
+        z = 0.f;
+        for (int c = 0; c < n_chunks; ++c) {
+            const float zc = za_in[(size_t)c * n_pad + j];
+            if (zc == zc) z = zc;      // exactly one shard owns the action
+        }
+    } else {
+        z = ba[a];
 #pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-        z = __builtin_fmaf(hr[kk], wr[kk], z);
-        z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
+        for (int kk = 0; kk < 32; ++kk) {
+            z = __builtin_fmaf(hr[kk], wr[kk], z);
+            z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
+        }
     }
     const float lse = m + __logf(s);
     v.lse[j] = lse;
-    v.act[j] = a;
+    v.act[j] = a - item_base;
     v.dst_row[j] = (long)b.row_t[src] * n_env + b.row_env[src];
     // ---- row losses + backward coefficients; every mean is over the (global) minibatch of mb_norm rows --------------
     const float inv_mb = 1.0f / (float)mb_norm;
@@ -1076,7 +1089,10 @@ __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)
 // Here one wavefront per 64 float4: 256 workgroups, 32 KB each, all slabs of an element in flight at once, added in chunk order
 // (the order the trunk-backward kernel used); the sum replaces slab 0.  The last n_pad / 64 workgroups do the same for the
 // entropy partials (one float per row and chunk) and finish ent_row.
-__global__ __launch_bounds__(64) void dh2_sum_kernel(int mb, int n_pad, int n_chunks, MbView v) {
+// tp_dh2 / tp_ent (item-sharded head): the sums go to the exchange buffer instead (they are PARTIAL over this rank's items: the caller
+// all-reduces them, tp_post_kernel finishes ent_row).
+__global__ __launch_bounds__(64) void dh2_sum_kernel(int mb, int n_pad, int n_chunks, MbView v, float* __restrict__ tp_dh2 = nullptr,
+                                                     float* __restrict__ tp_ent = nullptr) {
     const int n_f4_wgs = n_pad * (kH / 4) / 64;
     if ((int)blockIdx.x < n_f4_wgs) {
         const size_t q4 = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -1090,7 +1106,7 @@ __global__ __launch_bounds__(64) void dh2_sum_kernel(int mb, int n_pad, int n_ch
 #pragma unroll
             for (int u = 0; u < 32; ++u) acc += t32[u];
         }
-        *reinterpret_cast<f32x4*>(p) = acc;
+        *reinterpret_cast<f32x4*>(tp_dh2 ? tp_dh2 + q4 * 4 : p) = acc;
         return;
     }
     const int r = ((int)blockIdx.x - n_f4_wgs) * 64 + threadIdx.x;
@@ -1103,7 +1119,64 @@ __global__ __launch_bounds__(64) void dh2_sum_kernel(int mb, int n_pad, int n_ch
 #pragma unroll
         for (int u = 0; u < 32; ++u) e += t32[u];
     }
-    v.ent_row[r] = r < mb ? v.h_ent[r] + e : 0.f;  // (lse - E_p[z]) + clamp correction
+    if (tp_ent) tp_ent[r] = r < mb ? e : 0.f;
+    else v.ent_row[r] = r < mb ? v.h_ent[r] + e : 0.f;  // (lse - E_p[z]) + clamp correction
+}
+
+// ---- item-sharded head (tensor-parallel learner; BASELINE configs[4], SURVEY 8(e) last paragraph) ----------------------------
+// head_tp_fold_kernel: this rank's chunk partials of the forward statistics -> ONE (m, s, t) triple per minibatch row, plus the
+// action's logit when this shard owns the action's item (NaN otherwise): out4 [4][n_pad], the 16-byte-per-row message of the
+// all-gather.  One wavefront per row; the logit is the fma chain of head_stats_merge_kernel.
+__global__ __launch_bounds__(256) void head_tp_fold_kernel(cirs_ppo_batch b, const int32_t* __restrict__ idx, int mb, int n_pad, int n_chunks,
+                                                           ActorPartialView pv, const float* __restrict__ wa_shard,
+                                                           const float* __restrict__ ba_shard, int item_base, int n_items_shard,
+                                                           const float* __restrict__ h2, float* __restrict__ out4) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n_pad) return;
+    if (j >= mb) {
+        if (lane == 0) { out4[j] = -INFINITY; out4[n_pad + j] = 0.f; out4[2 * n_pad + j] = 0.f; out4[3 * n_pad + j] = __builtin_nanf(""); }
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float sRow[4][2][kH];
+    const int a = b.act[idx[j]] - item_base;
+    const bool mine = a >= 0 && a < n_items_shard;
+    const float hl = h2[(size_t)j * kH + lane], wl = mine ? wa_shard[(size_t)a * kH + lane] : 0.f;
+    float m = -INFINITY, s = 0.f, t = 0.f;
+    for (int c = lane; c < n_chunks; c += CIRS_WAVE) {
+        const size_t o = (size_t)c * n_pad + j;
+        const float om = pv.m[o], os = pv.s[o], ot = pv.score[o];
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            const float fa = __expf(m - mn), fb = __expf(om - mn);
+            s = s * fa + os * fb; t = t * fa + ot * fb; m = mn;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(m, off, CIRS_WAVE), os = __shfl_xor(s, off, CIRS_WAVE), ot = __shfl_xor(t, off, CIRS_WAVE);
+        const float mn = fmaxf(m, om);
+        if (mn > -INFINITY) {
+            const float fa = __expf(m - mn), fb = __expf(om - mn);
+            s = s * fa + os * fb; t = t * fa + ot * fb; m = mn;
+        }
+    }
+    sRow[threadIdx.x >> 6][0][lane] = hl;
+    sRow[threadIdx.x >> 6][1][lane] = wl;
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
+    float z = __builtin_nanf("");
+    if (mine) {
+        const float* hr = sRow[threadIdx.x >> 6][0];
+        const float* wr = sRow[threadIdx.x >> 6][1];
+        z = ba_shard[a];
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            z = __builtin_fmaf(hr[kk], wr[kk], z);
+            z = __builtin_fmaf(hr[32 + kk], wr[32 + kk], z);
+        }
+    }
+    out4[j] = m; out4[n_pad + j] = s; out4[2 * n_pad + j] = t; out4[3 * n_pad + j] = z;
 }
 
 __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n_chunks, int S, const float* __restrict__ w1,
@@ -1261,6 +1334,28 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
                 if (row < mb) dobs_accum[(size_t)v.dst_row[row] * S + lo] = acc[r];
             }
         }
+    }
+}
+
+// ---- item-sharded head: pieces around the all-reduce of the d h2 partials ------------------------------------------------------
+// wa_slab_sum_kernel: the slab sums of THIS shard's wa|ba gradient (complete: the shard saw every row of the minibatch) into the flat
+// gradient + its kWaSumBlocks sum-of-squares partials into the rank's slots of the exchange buffer (the other ranks' slots are zero:
+// the sum over ranks hands every rank all partials).
+__global__ __launch_bounds__(512) void wa_slab_sum_kernel(float* __restrict__ g, long wa_beg, long wa_len, const float* __restrict__ dwap,
+                                                          long slab_stride, int n_slabs, float* __restrict__ slots) {
+    __shared__ float sh[512];
+    wa_slab_sum_block(g, wa_beg, wa_len, dwap, slab_stride, n_slabs, (int)blockIdx.x, slots + blockIdx.x, sh);
+}
+// tp_post_kernel (after the all-reduce): entropy per row = (lse - E_p[z]) + the clamp corrections of all shards; the squared-norm
+// partials of the wa|ba gradient of ALL shards folded in (rank, block) order into the slots adam2_kernel reads.
+__global__ __launch_bounds__(256) void tp_post_kernel(int mb, int n_pad, int world, const float* __restrict__ red_ent,
+                                                      const float* __restrict__ red_slots, MbView v) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n_pad) v.ent_row[r] = r < mb ? v.h_ent[r] + red_ent[r] : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x < kWaSumBlocks) {
+        float acc = 0.f;
+        for (int q = 0; q < world; ++q) acc += red_slots[(size_t)q * kWaSumBlocks + threadIdx.x];
+        v.normp[kNormBlocks + threadIdx.x] = acc;
     }
 }
 
@@ -1600,7 +1695,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         CIRS_CHECK_LAUNCH("head_stats_kernel");
         // 4. merge + row losses + backward coefficients (means over the global minibatch)
         hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
-                           (int)(idx_global ? mb_global : mb), n_pad, n_schunks, (int)n_env, pv, w.wa, w.ba, v);
+                           (int)(idx_global ? mb_global : mb), n_pad, n_schunks, (int)n_env, pv, w.wa, w.ba, v, (const float*)nullptr, 0);
         CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
         // 5. head backward
         // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
@@ -1689,6 +1784,127 @@ extern "C" int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, flo
     if (phase != 2 && !idx_global) return cirs::fail(CIRS_E_INVALID, "idx_global is null");
     return ppo_minibatch_impl(cfg, params, grads, adam_m, adam_v, opt_step, batch, idx_local, mb_local, idx_global, mb_global,
                               dobs_accum, n_env, loss_out, workspace, workspace_bytes, phase, stream);
+}
+
+// ---- tensor-parallel (item-sharded head) minibatch step ------------------------------------------------------------------------
+extern "C" int64_t cirs_ppo_tp_exchange_floats(int32_t n_rows, int32_t world) {
+    return (int64_t)cirs::n_pad_of(n_rows) * (cirs::kH + 1) + (int64_t)world * cirs::kWaSumBlocks;
+}
+
+extern "C" int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
+                                     const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb, int32_t item_base, int32_t rank,
+                                     int32_t world, float* stats4, const float* stats_all, float* red, float* dobs_accum, int32_t n_env,
+                                     float* loss_out, void* workspace, int64_t workspace_bytes, int32_t phase, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_ppo(cfg)) return rc;
+    CIRS_REQUIRE(params && grads && adam_m && adam_v && batch && idx && workspace && red, "null argument");
+    CIRS_REQUIRE(phase >= 1 && phase <= 3, "phase must be 1, 2 or 3");
+    CIRS_REQUIRE(mb >= 2 && world >= 1 && rank >= 0 && rank < world && item_base >= 0, "bad minibatch / rank arguments");
+    CIRS_REQUIRE(workspace_bytes >= cirs_ppo_workspace_bytes(cfg, mb), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int I = cfg->n_items, S = cfg->dim_state;      // I = items of THIS shard
+    CIRS_REQUIRE(S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
+    const int n_pad = n_pad_of(mb);
+    const PpoLayout L = ppo_layout(I, S);
+    MbView v = carve(workspace, n_pad, I, S);
+    cirs_policy_cfg pcfg{I, S, kH};
+    cirs_policy_weights w{params + L.w1, params + L.b1, params + L.w2, params + L.b2, params + L.wa, params + L.ba, params + L.wc, params + L.bc};
+    const long seg = (long)I * kH + I;
+    const int n_slabs = n_row_blocks_of(n_pad);
+    const int n_item_tiles = cdiv(I, kTileN);
+    float* red_dh2 = red;
+    float* red_ent = red + (size_t)n_pad * kH;
+    float* red_slots = red_ent + n_pad;
+    float* tail = grads + L.total;
+    if (phase == 1) {
+        CIRS_REQUIRE(stats4, "stats4 is null");
+        hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
+                           v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, idx, (int)mb, (int)cfg->norm_adv, v.red,
+                           (int)cdiv(n_pad, 4), v.wa_planes);
+        CIRS_CHECK_LAUNCH("trunk_adv_kernel");
+        ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
+        const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);
+        const int n_schunks = cdiv(n_item_tiles, tpc_s);
+        hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s, (const uint4*)v.wa_planes, w.ba,
+                           (const float*)v.h2, pv);
+        CIRS_CHECK_LAUNCH("head_stats_kernel");
+        hipLaunchKernelGGL(head_tp_fold_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *batch, idx, (int)mb, n_pad, n_schunks, pv, (const float*)w.wa,
+                           (const float*)w.ba, (int)item_base, I, (const float*)v.h2, stats4);
+        CIRS_CHECK_LAUNCH("head_tp_fold_kernel");
+        return CIRS_OK;
+    }
+    if (phase == 2) {
+        CIRS_REQUIRE(stats_all, "stats_all is null");
+        // stats_all [4][world][n_pad]: the triples of all shards in rank order are the chunk partials of the merge (fixed order: every
+        // rank computes identical row statistics and coefficients)
+        ActorPartialView pa;
+        pa.m = const_cast<float*>(stats_all); pa.s = pa.m + (size_t)world * n_pad; pa.score = pa.s + (size_t)world * n_pad;
+        pa.idx = nullptr; pa.z = nullptr;
+        const float* za = pa.score + (size_t)world * n_pad;
+        hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb, (int)mb, n_pad, (int)world,
+                           (int)n_env, pa, (const float*)nullptr, (const float*)nullptr, v, za, (int)item_base);
+        CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
+        const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
+        const int n_bchunks = cdiv(n_item_tiles, tpc);
+        if (cfg->ent_coef != 0.f) {
+            hipLaunchKernelGGL(head_bwd_fused_kernel<true>, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
+                               (const uint4*)v.wa_planes, w.ba, v, v.dwap);
+        } else {
+            hipLaunchKernelGGL(head_bwd_fused_kernel<false>, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
+                               (const uint4*)v.wa_planes, w.ba, v, v.dwap);
+        }
+        CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
+        CIRS_HIP(hipMemsetAsync(red_slots, 0, sizeof(float) * (size_t)world * kWaSumBlocks, s));
+        hipLaunchKernelGGL(dh2_sum_kernel, dim3(n_pad * (kH / 4) / 64 + cdiv(n_pad, 64)), dim3(64), 0, s, (int)mb, n_pad, n_bchunks, v, red_dh2, red_ent);
+        CIRS_CHECK_LAUNCH("dh2_sum_kernel");
+        hipLaunchKernelGGL(wa_slab_sum_kernel, dim3(kWaSumBlocks), dim3(512), 0, s, grads, (long)L.wa, seg, (const float*)v.dwap,
+                           (long)dwa_slab_stride(I), n_slabs, red_slots + (size_t)rank * kWaSumBlocks);
+        CIRS_CHECK_LAUNCH("wa_slab_sum_kernel");
+        return CIRS_OK;
+    }
+    // phase 3: `red` holds the sums over the ranks
+    CIRS_REQUIRE(loss_out, "loss_out is null");
+    hipLaunchKernelGGL(tp_post_kernel, dim3(cdiv(n_pad, 256)), dim3(256), 0, s, (int)mb, n_pad, (int)world, (const float*)red_ent,
+                       (const float*)red_slots, v);
+    CIRS_CHECK_LAUNCH("tp_post_kernel");
+    DwJobs jobs;
+    jobs.n = 3;
+    jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
+    jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
+    jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
+    const int n_dw_slabs = n_pad / kTileM;
+    {
+        int off = 0, out = 0;
+        for (int q = 0; q < 3; ++q) {
+            jobs.j[q].part_off = off;
+            off += n_dw_slabs * jobs.j[q].O * (jobs.j[q].K + 1);
+            out += jobs.j[q].O * (jobs.j[q].K + 1);
+        }
+        jobs.total_out = out;
+    }
+    MbView v3 = v;
+    v3.dh2p = red_dh2;      // the trunk backward reads the summed d h2 (slab 0 position) from the exchange buffer
+    hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM), dim3(512), 0, s, (int)mb, n_pad, 1, S, w.w1, w.w2, w.wc, v3, dobs_accum, grads,
+                       (long)L.wa, seg, (long)dwa_slab_stride(I), n_slabs, jobs, v.dwp);
+    CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg, 1, jobs, n_dw_slabs,
+                       (const float*)v.dwp, S, v.normp);
+    CIRS_CHECK_LAUNCH("sumsq_partial_kernel");
+    auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
+        AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};
+        for (int q = 0; q < n_sub; ++q) {
+            const double t = (double)(step_before + 1 + q);
+            const float ss = (float)((double)cfg->lr / (1.0 - pow((double)cfg->beta1, t)));
+            const float bs = (float)sqrt(1.0 - pow((double)cfg->beta2, t));
+            if (q == 0) { sg.step_size0 = ss; sg.bc2s0 = bs; } else { sg.step_size1 = ss; sg.bc2s1 = bs; }
+        }
+        return sg;
+    };
+    hipLaunchKernelGGL(adam2_kernel, dim3(cdiv(L.total, 256)), dim3(256), 0, s, params, grads, adam_m, adam_v, L.total, L.trunk,
+                       seg_of(2 * opt_step, 2, 2), seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, *cfg, v.normp, tail, v3, loss_out,
+                       (int)mb, (int)mb);
+    CIRS_CHECK_LAUNCH("adam2_kernel");
+    return CIRS_OK;
 }
 
 // ---- sharded optimiser step of the data-parallel learner -------------------------------------------------------------------

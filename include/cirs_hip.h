@@ -356,6 +356,28 @@ int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, float* grads, 
                           const int32_t* idx_global, int32_t mb_global, float* dobs_accum, int32_t n_env,
                           float* loss_out, void* workspace, int64_t workspace_bytes, int32_t phase, void* stream);
 
+/* Tensor-parallel form of cirs_ppo_minibatch for an ITEM-SHARDED actor head (BASELINE configs[4]: the catalogue does not fit / is not
+ * replicated; SURVEY 8(e): "actor head column-sharded over items with a cross-rank (max, sum-exp, ...) reduction").  No reference
+ * counterpart (the reference is single-process); semantics = cirs_ppo_minibatch on one device with the whole catalogue.
+ * Rank r holds rows [item_base, item_base + cfg->n_items) of wa / ba -- cfg, params, grads and the Adam moments describe the SHARD
+ * (flat layout as above with I = the shard's item count); trunk and critic are replicated, batch->act holds GLOBAL item ids and every
+ * rank processes every row of the minibatch.  Per minibatch, two collectives:
+ *   phase 1  trunk forward, statistics of the local items -> stats4 [4][n_pad] = {max, sum-exp, sum exp z, logit of the row's action
+ *            if this shard owns it else NaN}                                            (n_pad = rows rounded up to 32)
+ *   -- all-gather; the caller hands the result back as stats_all [4][world][n_pad] (field-major) --
+ *   phase 2  merge in rank order (identical on every rank) -> row losses / coefficients; fused head backward on the local items:
+ *            the shard's wa|ba gradient is COMPLETE (it saw every row); red = {d h2 partial [n_pad,64], entropy clamp partial
+ *            [n_pad], this rank's squared-norm partials of the wa|ba gradient in its slots of [world, 176]} =
+ *            cirs_ppo_tp_exchange_floats(mb, world) floats
+ *   -- all-reduce (sum) of red --
+ *   phase 3  trunk / critic backward (replicated, identical inputs), clip_grad_norm_ over trunk x 2 + every shard's head + critic,
+ *            Adam on the shard + the replicated trunk; loss_out[4]; dobs_accum as in cirs_ppo_minibatch. */
+int64_t cirs_ppo_tp_exchange_floats(int32_t n_rows, int32_t world);
+int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
+                          const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb, int32_t item_base, int32_t rank,
+                          int32_t world, float* stats4, const float* stats_all, float* red, float* dobs_accum, int32_t n_env,
+                          float* loss_out, void* workspace, int64_t workspace_bytes, int32_t phase, void* stream);
+
 /* Sharded optimiser step of the data-parallel learner (the reduce-scatter -> sharded Adam -> all-gather form of the step above):
  * after phase 1 the caller reduce-scatters grads[0 .. P_pad) (P_pad = P + 4 rounded up to a multiple of 4 * world; the padding
  * stays zero) so that this rank holds the summed shard [shard_begin, shard_begin + shard_len) of the flat gradient.
