@@ -61,7 +61,7 @@ def pmc_traffic(workload):
     return {k: int(v["bytes_per_launch"]) for k, v in z["kernels"].items()}, f"profiles/pmc_traffic.json ({z.get('taken', '?')}; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
-def build_engine(wl, rank, world, device, learner="dp", dropout=0.0):
+def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_backward=None):
     from cirs_hip.engine import CirsEngine
     from cirs_hip.env import DeviceEnvTables
     from cirs_hip.synthetic import make_tables
@@ -73,7 +73,7 @@ def build_engine(wl, rank, world, device, learner="dp", dropout=0.0):
                          build_dist_on_device=True)
     eng = CirsEngine(dt, wl["B"], max_turn=wl["T"], num_leave_compute=wl["N"], leave_threshold=wl["thr"], tau=wl["tau"],
                      gamma_exposure=wl["gamma_exposure"], seed=2023, world_size=world, rank=rank,
-                     dist_group=None, learner_mode=learner, dropout=dropout)
+                     dist_group=None, learner_mode=learner, dropout=dropout, tracker_backward=tracker_backward)
     return eng, tab
 
 
@@ -85,6 +85,9 @@ def hip_event_kernel_time(eng, wl, reps=100):
     from cirs_hip import abi
     import ctypes as C
     ln = eng.learner
+    if not hasattr(ln, "n_rows"):      # learner "tp": the updates ran on the item-sharded learner; the probe times the full-catalogue kernels
+        traj, lens, lens_d = eng._last_prepared
+        ln.prepare(traj, lens, lens_dev=lens_d)
     n = ln.n_rows
     mb = min(1024, n)
     ws = ln.workspace(mb)
@@ -322,10 +325,14 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--learner", default="dp", choices=["dp", "dp_sharded", "replicated"],
+    ap.add_argument("--learner", default="replicated", choices=["dp", "dp_sharded", "replicated", "tp"],
                     help="N > 1 only: how the PPO update runs over the gathered buffer.  Every mode keeps the reference's PPO configuration "
                          "(global minibatch = --global-batch rows): dp = rows of each minibatch sharded over the ranks + one gradient all-reduce; "
-                         "dp_sharded = reduce-scatter + sharded Adam + parameter all-gather; replicated = every rank runs the whole update")
+                         "dp_sharded = reduce-scatter + sharded Adam + parameter all-gather; replicated = every rank runs the whole update; "
+                         "tp = actor head sharded by items for the update (16 B/row all-gather + d h2 all-reduce per minibatch, head shards all-gathered once per update)")
+    ap.add_argument("--tracker-backward", default="sharded", choices=["sharded", "replicated"],
+                    help="N > 1, learner replicated only: tracker BPTT over the rank's own envs + one gradient all-reduce (sharded) or over all "
+                         "envs on every rank (replicated: no communication, results identical to one device).  Other learners always shard it")
     ap.add_argument("--global-batch", type=int, default=1024, help="PPO minibatch size over ALL ranks (reference batch_size, CIRS-RL-kuaishou.py:89)")
     ap.add_argument("--dropout", type=float, default=0.0, help="tracker dropout probability (0 = eval-mode tracker of the parity fixtures; "
                                                                "0.1 = the mode the reference trains in, SURVEY Q7)")
@@ -360,7 +367,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     G = int(args.global_batch)
-    eng, tab = build_engine(wl, rank, world, device, learner=args.learner, dropout=args.dropout)
+    eng, tab = build_engine(wl, rank, world, device, learner=args.learner, dropout=args.dropout,
+                            tracker_backward=args.tracker_backward if args.learner == "replicated" else None)
 
     def barrier():
         if world > 1:
@@ -456,14 +464,16 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (policy/tracker; rollout on the fp32 MFMA, PPO head products fp32-accurate from 3 bf16 pieces per operand on the bf16 MFMA, fp32 accumulate) + f64 (env rewards, GAE)", "data": "synthetic",
             "config": {"workload": wl["name"], "envs_total": wl["B"] * world,
-                       "learner": args.learner if world > 1 else "single",
+                       "learner": args.learner if world > 1 else "single", "tracker_backward": eng.tracker_backward if world > 1 else "single",
                        "global_minibatch": G, "minibatch_steps_per_update": mb_steps / args.steps,
-                       "rows_per_rank_per_minibatch": G if (world == 1 or args.learner == "replicated") else G / world,
+                       "rows_per_rank_per_minibatch": G if (world == 1 or args.learner in ("replicated", "tp")) else G / world,
                        "ppo_repeat": 2, "tracker_dropout": args.dropout,
                        "parallelism": (f"env-sharded x{world}; one all-gather of trajectory records per update; learner '{args.learner}': "
                                        + {"dp": f"global minibatch of {G} rows sharded by rows over the ranks, one flat-gradient all-reduce per minibatch",
                                           "dp_sharded": f"global minibatch of {G} rows sharded by rows, reduce-scatter + sharded Adam + parameter all-gather per minibatch",
-                                          "replicated": f"every rank runs all minibatches of {G} rows on the gathered buffer (no further communication)"}[args.learner])
+                                          "replicated": f"every rank runs all minibatches of {G} rows on the gathered buffer (no further communication)",
+                                          "tp": f"every rank runs all {G} rows of a minibatch against its 1/{world} of the catalogue (item-sharded head), "
+                                                "all-gather of 16 B/row + all-reduce of the d h2 partials per minibatch, head shards all-gathered per update"}[args.learner])
                        if world > 1 else "single GPU"},
             "dropout": args.dropout,
             "ppo_minibatch_steps_per_s": mb_steps / elapsed, "rank_parameters_bit_identical": ranks_identical,

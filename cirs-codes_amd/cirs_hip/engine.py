@@ -70,7 +70,7 @@ class CirsEngine:
                  hidden=64, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
                  lr=1e-3, rew_norm=True, value_clip=True, norm_adv=True, seed=2023, tracker_params=None,
                  policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False, learner_mode="dp",
-                 online_reward=None, batch_size_hint=1024, dropout=0.0):
+                 online_reward=None, batch_size_hint=1024, dropout=0.0, tracker_backward=None):
         """dropout: probability of the tracker's five dropout sites.  0.0 (default) is the mode of every parity fixture and of
         the benchmark; 0.1 reproduces the reference's training procedure, whose tracker is never put in eval()."""
         self.device = tables.device
@@ -90,8 +90,16 @@ class CirsEngine:
         #   "replicated": every rank runs the identical single-device learner on the gathered buffer (no further communication)
         # (the batch_size x W variant that keeps the number of optimiser steps per update constant is the caller's choice:
         #  update(batch_size * W); bench.py reports it as an extra key, never as the headline)
-        assert learner_mode in ("dp", "dp_sharded", "replicated")
+        #   "tp":         the actor head is sharded by ITEMS for the update (rank r owns rows r*Is .. of wa / ba and their Adam moments;
+        #                 trunk / critic replicated): every rank runs every row of a minibatch against its 1/W of the catalogue, two
+        #                 small collectives per minibatch (16 B per row of statistics, the d h2 partials), no gradient all-reduce; the
+        #                 updated head shards are all-gathered into the replicated rollout policy once per update
+        assert learner_mode in ("dp", "dp_sharded", "replicated", "tp")
         self.learner_mode = learner_mode
+        # tracker BPTT of a multi-rank job: "sharded" = own envs + one gradient all-reduce (always for dp / dp_sharded / tp);
+        # "replicated" = every rank over all envs, no communication (default of learner "replicated": results identical to one device)
+        self.tracker_backward = tracker_backward or ("replicated" if learner_mode == "replicated" else "sharded")
+        assert self.tracker_backward in ("sharded", "replicated") and (learner_mode == "replicated" or self.tracker_backward == "sharded")
         self.coll = distributed.Collectives(group=dist_group, device=self.device)
         self.env = DeviceEnv(tables, n_env, num_leave_compute=num_leave_compute, leave_threshold=leave_threshold,
                              max_turn=max_turn, tau=tau, gamma_exposure=gamma_exposure, version=version, r_decay=r_decay)
@@ -118,7 +126,24 @@ class CirsEngine:
         # size every lazily grown buffer for the worst case now (B*T rows, merged last minibatch < 2*batch_size):
         # no allocation (= implicit device sync) ever happens inside the collect/update loop
         self.learner.reserve(self.B_total * max_turn, 2 * batch_size_hint)
-        self.tracker.reserve_backward((self.B_total if world_size == 1 or learner_mode == "replicated" else n_env) * max_turn)
+        self.tracker.reserve_backward((self.B_total if world_size == 1 or self.tracker_backward == "replicated" else n_env) * max_turn)
+        self.tp_learner = None
+        if learner_mode == "tp" and world_size > 1:
+            Is = -(-(-(-I // world_size)) // 32) * 32          # items per shard: ceil(I / W) rounded up to whole 32-item tiles
+            self.tp_Is, self.tp_base = Is, rank * Is
+            Il = min(Is, I - self.tp_base)
+            assert Il > 0, "more ranks than 32-item tiles of the catalogue"
+            self.tp_Il = Il
+            init = {k: v for k, v in pviews.items() if not k.startswith("actor.last")}
+            init["actor.last.model.0.weight"] = pviews["actor.last.model.0.weight"][self.tp_base:self.tp_base + Il]
+            init["actor.last.model.0.bias"] = pviews["actor.last.model.0.bias"][self.tp_base:self.tp_base + Il]
+            self.tp_flat, self.tp_views = flat_policy_params(Il, dim_state, hidden, device=self.device, init=init)
+            self.tp_learner = DeviceLearner(self.tp_flat, Il, self.B_total, max_turn, dim_state=dim_state, hidden=hidden, gamma=gamma,
+                                            gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
+                                            max_grad_norm=max_grad_norm, lr=lr, norm_adv=norm_adv, value_clip=value_clip, rew_norm=rew_norm)
+            self.tp_learner.reserve(self.B_total * max_turn, 2 * batch_size_hint)
+            self._tp_send = torch.zeros(Is * (hidden + 1), dtype=torch.float32, device=self.device)
+            self._tp_recv = torch.zeros(world_size * Is * (hidden + 1), dtype=torch.float32, device=self.device)
         self.seed = seed
         self.collect_count = 0
         self.users = None
@@ -186,7 +211,8 @@ class CirsEngine:
         """policy.update(0, buffer, batch_size, repeat): process_fn + learn + tracker step (base.py:219-244)."""
         traj, x_hist, lens_d, users = self._gather()
         lens = lens_d.cpu().numpy().astype(np.int32)   # host needs N to schedule minibatches (the only sync)
-        ln = self.learner
+        ln = self.tp_learner if self.tp_learner is not None else self.learner
+        self._last_prepared = (traj, lens, lens_d)      # bench.py's kernel probe re-prepares the full-catalogue learner from it in tp mode
         n = ln.prepare(traj, lens, lens_dev=lens_d)
         if perms is None and self.world > 1:
             # identical permutations on every rank (same key): learners stay bit-identical
@@ -194,24 +220,54 @@ class CirsEngine:
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
         if (self.world > 1 or self.force_dp) and self.learner_mode in ("dp", "dp_sharded"):
             return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms)
+        if self.tp_learner is not None:
+            return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms, ln=ln)
         losses = ln.learn(batch_size, repeat, perms=perms)
+        if self.world > 1 and self.tracker_backward == "sharded":
+            # replicated policy learner, but the BPTT through the tracker (independent per env) over this rank's envs only + one
+            # all-reduce of the tracker gradients per update: its cost does not grow with the number of ranks
+            self._tracker_backward_sharded(ln, lens, offsets)
+            return losses, n
         self.tracker.backward(users, traj, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs,
                               x_hist=x_hist if (self.world > 1 or self.force_gather) else None)
         self.tracker.adam_update()
         return losses, n
 
-    def _update_dp(self, traj, lens, offsets, n, batch_size, repeat, perms):
+    def _publish_tp(self):
+        """The updated head shards -> the replicated rollout policy (one all-gather per update); trunk / critic are replicated."""
+        H, Is, Il, W, I = 64, self.tp_Is, self.tp_Il, self.world, self.n_items
+        v, pv = self.tp_views, self.policy_views
+        self._tp_send[:Il * H].copy_(v["actor.last.model.0.weight"].reshape(-1))
+        self._tp_send[Is * H:Is * H + Il].copy_(v["actor.last.model.0.bias"])
+        self.coll.all_gather(self._tp_recv, self._tp_send)
+        r = self._tp_recv.view(W, Is * (H + 1))
+        pv["actor.last.model.0.weight"].copy_(r[:, :Is * H].reshape(W * Is, H)[:I])
+        pv["actor.last.model.0.bias"].copy_(r[:, Is * H:].reshape(W * Is)[:I])
+        for k in pv:
+            if not k.startswith("actor.last"):
+                pv[k].copy_(v[k])
+
+    def _update_dp(self, traj, lens, offsets, n, batch_size, repeat, perms, ln=None):
         """Data-parallel learner over global minibatches of batch_size rows: per minibatch one all-reduce of the flat policy
         gradients ("dp") or reduce-scatter + sharded Adam + all-gather ("dp_sharded"); per update one all-reduce of d loss/d obs and
         one of the tracker gradients.  Every rank ends with identical parameters."""
-        ln = self.learner
+        ln = ln or self.learner
         all_reduce = self.coll.all_reduce
-        if self.learner_mode == "dp_sharded":
+        if self.learner_mode == "tp":
+            losses = ln.learn_tp(batch_size, repeat, perms, self.rank, self.world, self.tp_base, self.coll)
+            self._publish_tp()          # d loss / d obs is replicated (the trunk backward runs on every rank): no all-reduce
+        elif self.learner_mode == "dp_sharded":
             losses = ln.learn_dp_sharded(batch_size, repeat, perms, self.rank, self.world, self.coll)
+            all_reduce(ln.dobs)  # each (t, env) row was written by exactly one rank
         else:
             losses = ln.learn_dp(batch_size, repeat, perms, self.rank, self.world, all_reduce)
-        all_reduce(ln.dobs)  # each (t, env) row was written by exactly one rank
-        # tracker backward over THIS rank's envs only (its own trajectory / slots), then sum the gradients
+            all_reduce(ln.dobs)  # each (t, env) row was written by exactly one rank
+        self._tracker_backward_sharded(ln, lens, offsets)
+        return losses, n
+
+    def _tracker_backward_sharded(self, ln, lens, offsets):
+        """Tracker backward over THIS rank's envs only (its own trajectory / slots), then the sum of the gradients over the ranks."""
+        all_reduce = self.coll.all_reduce
         Bl = self.n_env
         lo_env, hi_env = self.rank * Bl, (self.rank + 1) * Bl
         r0 = int(offsets[lo_env])
@@ -225,4 +281,3 @@ class CirsEngine:
         self.tracker.backward(self.users, self.rollout.traj, row_env_l, row_t_l, off_l, lens_l, r1 - r0, dstate_l)
         all_reduce(self.tracker.flat_grad)
         self.tracker.adam_update()
-        return losses, n

@@ -138,7 +138,7 @@ def test_data_parallel_path_over_rccl_with_one_rank(monkeypatch):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on the node (RCCL over xGMI with N > 1 ranks)")
-@pytest.mark.parametrize("learner", ["dp", "dp_sharded", "replicated"])
+@pytest.mark.parametrize("learner", ["dp", "dp_sharded", "replicated", "tp"])
 @pytest.mark.parametrize("nproc", [2])
 def test_two_process_rccl_bench_ranks_stay_bit_identical(nproc, learner):
     """The driver's SCALE run must not be the first time RCCL sees N > 1 ranks: launch bench.py exactly as the driver does
@@ -166,7 +166,7 @@ def test_two_process_rccl_bench_ranks_stay_bit_identical(nproc, learner):
     assert z["scaled_batch_variant"]["global_minibatch"] == 1024 * nproc
 
 
-@pytest.mark.parametrize("learner", ["dp", "dp_sharded"])
+@pytest.mark.parametrize("learner", ["dp", "dp_sharded", "tp", "replicated"])
 def test_two_process_bench_on_one_gpu_ranks_stay_bit_identical(learner):
     """The same launch as above on a box with ONE GPU: both ranks on device 0 (CIRS_BENCH_SHARE_GPU=1), collectives through gloo on
     device tensors.  Everything but the transport is the N > 1 path of the driver's SCALE run: env sharding, the packed
@@ -187,7 +187,7 @@ def test_two_process_bench_on_one_gpu_ranks_stay_bit_identical(learner):
     z = json.loads(line)
     assert z["n_gpus"] == 2 and z["config"]["envs_total"] == 2048 and z["scaling"] == "weak"
     # the headline keeps the reference's PPO configuration: global minibatch 1024 rows = 512 per rank, ~2 x the single-GPU step count
-    assert z["config"]["learner"] == learner and z["config"]["global_minibatch"] == 1024 and z["config"]["rows_per_rank_per_minibatch"] == 512
+    assert z["config"]["learner"] == learner and z["config"]["global_minibatch"] == 1024 and z["config"]["rows_per_rank_per_minibatch"] == (1024 if learner in ("tp", "replicated") else 512)
     assert z["rank_parameters_bit_identical"] is True
     assert z["value"] > 0 and z["steps"] == 2
     sv = z["scaled_batch_variant"]

@@ -59,7 +59,7 @@ class FakeCollectives:
         self.bar.wait()
 
 
-@pytest.mark.parametrize("mode", ["dp", "dp_sharded"])
+@pytest.mark.parametrize("mode", ["dp", "dp_sharded", "tp", "replicated"])
 @pytest.mark.parametrize("W,B,I,U,T,bs", [(2, 24, 300, 90, 10, 32), (4, 16, 1000, 90, 10, 32), (8, 12, 500, 90, 10, 64),
                                           (2, 512, 10728, 7176, 30, 1024), (4, 256, 10728, 7176, 30, 1024), (8, 128, 10728, 7176, 30, 1024)])
 def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs, mode):
@@ -77,7 +77,7 @@ def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs, mod
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: W)
     kw = dict(max_turn=T, num_leave_compute=3 if T < 30 else 10, leave_threshold=1 if T < 30 else 4, tau=10.0, gamma_exposure=10.0, seed=5, batch_size_hint=bs)
-    engines = [CirsEngine(dt, B, world_size=W, rank=r, learner_mode=mode, **kw) for r in range(W)]
+    engines = [CirsEngine(dt, B, world_size=W, rank=r, learner_mode=mode, tracker_backward="sharded", **kw) for r in range(W)]
     rng = np.random.RandomState(2)
     users = [torch.as_tensor(rng.randint(0, U, B)) for _ in range(W)]
     for r, eng in enumerate(engines):
@@ -120,6 +120,10 @@ def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs, mod
     c = engines[0].coll.calls
     if mode == "dp":
         assert c == {"all_reduce": n_mb + 2, "reduce_scatter": 0, "all_gather": 2}, c
+    elif mode == "replicated":     # replicated policy learner (no per-minibatch collective) + sharded tracker BPTT: one gradient all-reduce
+        assert c == {"all_reduce": 1, "reduce_scatter": 0, "all_gather": 2}, c
+    elif mode == "tp":     # per minibatch: statistics all-gather + d h2 all-reduce; per update: head shards all-gather + tracker gradients
+        assert c == {"all_reduce": n_mb + 1, "reduce_scatter": 0, "all_gather": 2 + n_mb + 1}, c
     else:
         assert c == {"all_reduce": 2, "reduce_scatter": n_mb, "all_gather": 2 + 2 * n_mb}, c
     # single device: the gathered buffer, the SAME batch size
