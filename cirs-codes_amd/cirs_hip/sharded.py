@@ -25,6 +25,7 @@ import ctypes as C
 import threading
 from typing import Callable, Dict, List, Optional
 
+import numpy as np
 import torch
 
 from . import abi
@@ -50,6 +51,11 @@ class DistComm:
         else:
             self._dist.all_gather_into_tensor(out, t, group=self.group)
         return out
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """sum over the ranks, in place (identical bits on every rank)."""
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t
 
     def all_to_all(self, t: torch.Tensor) -> torch.Tensor:
         """t[d] goes to rank d; returns r with r[s] = what rank s sent here.  Equal splits."""
@@ -96,6 +102,14 @@ class ThreadComm:
     def all_to_all(self, t):
         got = self._exchange(t.contiguous())
         return torch.stack([g[self.rank] for g in got], 0)
+
+    def all_reduce(self, t):
+        got = self._exchange(t.clone())
+        total = got[0].clone()
+        for g in got[1:]:       # rank order: identical bits on every rank
+            total += g
+        t.copy_(total)
+        return t
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -163,6 +177,58 @@ class ShardedTable:
         return self.gather(back.reshape(W * cap, -1), slot)
 
     overflow: Optional[torch.Tensor] = None
+
+    # ---- training side: gradient rows travel to their owners, the owner scatters them in a fixed order and runs Adam on its shard ----
+    def enable_training(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        assert self.local.shape[1] == 32, "the ordered scatter serves dim_model == 32 rows"
+        self.grad = torch.zeros_like(self.local)
+        self.adam_m, self.adam_v = torch.zeros_like(self.local), torch.zeros_like(self.local)
+        self.adam_steps, self.lr, self.betas, self.adam_eps = 0, lr, betas, eps
+        self._scatter_ws = None
+
+    def push_grads(self, ids: torch.Tensor, rows: torch.Tensor, cap: Optional[int] = None):
+        """ids [n] int64 global row ids (< 0: no contribution), rows [n, 32] their gradient rows -> self.grad [local rows, 32] = for every
+        local row the sum of ALL ranks' contributions, added in (source rank, position) order: one all-to-all of the local row numbers
+        and one of the rows (the mirror image of `lookup`), then cirs_embedding_scatter (stable sort + ordered segment sums: no float
+        atomics).  With envs sharded contiguously over the ranks that order is the single-device buffer order."""
+        W = self.comm.world
+        n = ids.numel()
+        cap = n if cap is None else int(cap)
+        dev = ids.device
+        ids = ids.to(torch.int64)
+        valid = ids >= 0
+        owner = torch.where(valid, ids % W, torch.full_like(ids, W))        # pseudo-owner W: dropped
+        order = torch.argsort(owner, stable=True)
+        owner_s = owner[order]
+        counts = (owner.unsqueeze(1) == torch.arange(W + 1, device=dev).unsqueeze(0)).sum(0)
+        start = torch.cumsum(counts, 0) - counts
+        pos_s = torch.arange(n, device=dev) - start[owner_s]
+        keep = (owner_s < W) & (pos_s < cap)
+        send_id = torch.full((W + 1, cap + 1), -1, dtype=torch.int64, device=dev)
+        send_id[owner_s, torch.clamp(pos_s, max=cap)] = torch.where(keep, ids[order] // W, torch.full_like(pos_s, -1))
+        send_rows = torch.zeros((W + 1, cap + 1, rows.shape[1]), dtype=torch.float32, device=dev)
+        send_rows[owner_s, torch.clamp(pos_s, max=cap)] = rows[order].to(torch.float32)
+        recv_id = self.comm.all_to_all(send_id[:W, :cap].contiguous())            # [W(src), cap]
+        recv_rows = self.comm.all_to_all(send_rows[:W, :cap].contiguous())        # [W(src), cap, 32]
+        keys = recv_id.reshape(-1).to(torch.int32).contiguous()
+        contrib = recv_rows.reshape(-1, rows.shape[1]).contiguous()
+        lib = abi.lib()
+        need = int(lib.cirs_embedding_scatter_workspace_bytes(keys.numel()))
+        if self._scatter_ws is None or self._scatter_ws.numel() < need:
+            self._scatter_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        abi.check(lib.cirs_embedding_scatter(keys.data_ptr(), contrib.data_ptr(), keys.numel(), self.local.shape[0], self.grad.data_ptr(),
+                                             self._scatter_ws.data_ptr(), self._scatter_ws.numel(),
+                                             torch.cuda.current_stream(dev).cuda_stream), "cirs_embedding_scatter")
+        self._keep = (keys, contrib)
+
+    def adam_update(self):
+        """torch.optim.Adam over the whole local shard (rows without a gradient still decay their moments, like the dense optimiser of
+        the reference over the full table)."""
+        n = self.local.numel()
+        abi.check(abi.lib().cirs_adam_step(self.local.data_ptr(), self.grad.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(), n,
+                                           self.adam_steps, 1, self.lr, self.betas[0], self.betas[1], self.adam_eps, None, 0,
+                                           torch.cuda.current_stream(self.local.device).cuda_stream), "cirs_adam_step")
+        self.adam_steps += 1
 
     def check_overflow(self):
         """Host check of the dropped-request counter (one synchronisation): raises if any lookup exceeded its `cap`."""
@@ -295,3 +361,117 @@ class ShardedRollout:
         for t in range(self.env.max_turn):
             self.step(t, seed, rng_base)
         return self.env.turn.clone()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# sharded trainer: the PPO update of the split configuration
+# ------------------------------------------------------------------------------------------------------------------------------
+class _CollAdapter:
+    """cirs_hip.distributed.Collectives' (out, inp) calling convention over a Comm of this module."""
+
+    def __init__(self, comm):
+        self.comm = comm
+
+    def all_gather(self, out, inp):
+        out.copy_(self.comm.all_gather(inp).reshape(out.shape))
+
+    def all_reduce(self, t):
+        self.comm.all_reduce(t)
+
+
+class ShardedTrainer:
+    """One rank of `policy.update` for BASELINE configs[4] on top of a ShardedRollout (reference semantics: core/policy/ppo.py:96-246 on
+    the gathered buffer; no reference counterpart for the split itself):
+      1. all-gather of the packed trajectory records (as C4) -> every rank holds the buffer, GAE / returns replicated;
+      2. DeviceLearner.learn_tp over this rank's ITEM shard of the actor head (the tensors the rollout samples from ARE the learner's
+         flat shard parameters) -- trunk / critic replicated;
+      3. tracker BPTT over this rank's envs with COMPACT embedding tables (the rows its users / actions looked up: id = slot), so the
+         kernels never see a 10^6-row table; dense tracker gradients are all-reduced and stepped on every rank;
+      4. the per-slot embedding gradient rows go to their owners (ShardedTable.push_grads: all-to-all + ordered scatter) and every
+         owner runs Adam on its shard of feat_user / feat_item."""
+
+    def __init__(self, rollout: ShardedRollout, policy_flat: torch.Tensor, B_total: int, *, gamma=0.95, gae_lambda=0.95, eps_clip=0.2,
+                 vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, lr=1e-3, norm_adv=True, value_clip=True, rew_norm=True):
+        from .learner import DeviceLearner
+        from .rollout import Trajectory
+        self.ro = rollout
+        self.comm, self.W, self.rank, self.Bl = rollout.comm, rollout.W, rollout.rank, rollout.B
+        self.device = rollout.device
+        T, S = rollout.env.max_turn, rollout.tracker.dim_state
+        self.T, self.S, self.B_total = T, S, B_total
+        self.learner = DeviceLearner(policy_flat, rollout.I_shard, B_total, T, dim_state=S, gamma=gamma, gae_lambda=gae_lambda, eps_clip=eps_clip,
+                                     vf_coef=vf_coef, ent_coef=ent_coef, max_grad_norm=max_grad_norm, lr=lr, norm_adv=norm_adv,
+                                     value_clip=value_clip, rew_norm=rew_norm)
+        self.gtraj = Trajectory(B_total, T, S, self.device)
+        self.coll = _CollAdapter(self.comm)
+        for tab in (rollout.trk_user, rollout.trk_item):
+            tab.enable_training(lr=lr)
+        D = rollout.tracker.cfg.dim_model
+        self._gU = torch.zeros((self.Bl, D), dtype=torch.float32, device=self.device)
+        self._gI = torch.zeros((T * self.Bl, D), dtype=torch.float32, device=self.device)
+        self._bws = None
+
+    def _gather(self, lens_local):
+        from . import distributed
+        tr, trk = self.ro.traj, self.ro.tracker
+        fields = dict(obs=tr.obs, act=tr.act, rew=tr.rew, done=tr.done, logp=tr.logp, value=tr.value, ctr=tr.ctr, x_hist=trk.x_hist,
+                      lens=lens_local.to(torch.int32), users=self.ro.users.to(torch.int32))
+        local = distributed.pack_records(fields)
+        g = distributed.unpack_records(self.comm.all_gather(local), self.W, self.T, self.Bl, self.S, trk.cfg.dim_model)
+        for name in ("obs", "act", "rew", "done", "logp", "value", "ctr"):
+            getattr(self.gtraj, name).copy_(g[name])
+        return g["lens"]
+
+    def update(self, lens_local: torch.Tensor, batch_size=1024, repeat=2, perms=None, perm_key=(20230, 0)):
+        ro, ln, W, r, Bl, T = self.ro, self.learner, self.W, self.rank, self.Bl, self.T
+        lens_d = self._gather(lens_local)
+        lens = lens_d.cpu().numpy().astype(np.int32)
+        n = ln.prepare(self.gtraj, lens, lens_dev=lens_d)
+        if perms is None:
+            ln.perm_seed, ln.perm_tag = perm_key          # the same key on every rank: identical shuffles
+        losses = ln.learn_tp(batch_size, repeat, perms, r, W, ro.item_base, self.coll)
+        # ---- tracker BPTT over this rank's envs, compact embedding tables --------------------------------------------------------
+        offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        lo_env, hi_env = r * Bl, (r + 1) * Bl
+        r0, r1 = int(offsets[lo_env]), int(offsets[hi_env - 1] + lens[hi_env - 1])
+        off_l = (ln.offsets_dev[lo_env:hi_env] - r0).contiguous()
+        lens_l = ln.lens_dev[lo_env:hi_env].contiguous()
+        row_env_l = (ln.b_env[r0:r1] - lo_env).contiguous()
+        row_t_l = ln.b_t[r0:r1].contiguous()
+        dstate_l = ln.dobs[:, lo_env:hi_env, :].contiguous()
+        tr, trk = ro.traj, ro.tracker
+        act = tr.act                                                     # [T, Bl] global item ids, -1 once finished
+        slot = (torch.arange(T, device=self.device).unsqueeze(1) * Bl + torch.arange(Bl, device=self.device).unsqueeze(0))
+        act_c = torch.where(act >= 0, slot, torch.full_like(slot, -1)).contiguous()      # item id = its own slot t * Bl + b
+        rows_u = ro.trk_user.lookup(ro.users)                                               # [Bl, D]
+        rows_i = ro.trk_item.lookup(act.clamp(min=0).reshape(-1))                           # [T * Bl, D]
+        cfg = type(trk.cfg).from_buffer_copy(trk.cfg)
+        cfg.n_users, cfg.n_items = Bl, T * Bl
+        w = type(trk.w).from_buffer_copy(trk.w)
+        w.emb_user, w.emb_item = rows_u.data_ptr(), rows_i.data_ptr()
+        g = type(trk.g).from_buffer_copy(trk.g)
+        g.emb_user, g.emb_item = self._gU.data_ptr(), self._gI.data_ptr()
+        lib = abi.lib()
+        need = lib.cirs_tracker_backward_workspace_bytes(C.byref(cfg), r1 - r0)
+        if self._bws is None or self._bws.numel() < need:
+            self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        users_c = self._arange32(Bl)
+        abi.check(lib.cirs_tracker_backward(C.byref(cfg), C.byref(w), C.byref(trk.st), users_c.data_ptr(), act_c.data_ptr(), tr.rew.data_ptr(),
+                                            row_env_l.data_ptr(), row_t_l.data_ptr(), off_l.data_ptr(), lens_l.data_ptr(), r1 - r0,
+                                            dstate_l.data_ptr(), C.byref(g), self._bws.data_ptr(), self._bws.numel(),
+                                            torch.cuda.current_stream(self.device).cuda_stream), "cirs_tracker_backward")
+        # dense tracker parameters: replicated, gradients summed over the ranks (the placeholder embedding rows of the flat buffer ride along)
+        self.comm.all_reduce(trk.flat_grad)
+        trk.adam_update()
+        # embedding rows: to their owners, in buffer (env-major) order
+        ro.trk_user.push_grads(ro.users.to(torch.int64), self._gU)
+        rows_env_major = slot.t().reshape(-1)                               # slot ids env by env, t ascending
+        ids_env_major = act.t().reshape(-1)
+        ro.trk_item.push_grads(ids_env_major, self._gI[rows_env_major])
+        ro.trk_user.adam_update()
+        ro.trk_item.adam_update()
+        self._keep = (rows_u, rows_i, act_c, off_l, lens_l, row_env_l, row_t_l, dstate_l)
+        return losses, n
+
+    def _arange32(self, n):
+        return torch.arange(n, dtype=torch.int32, device=self.device)

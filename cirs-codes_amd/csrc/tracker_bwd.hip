@@ -722,3 +722,17 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
 #undef ATT_DISPATCH_SH
     return CIRS_OK;
 }
+
+// ---- row-sharded embedding tables (BASELINE configs[4]): the owner rank's ordered scatter of received gradient rows ----------------
+extern "C" int64_t cirs_embedding_scatter_workspace_bytes(int64_t n_rows) { return (int64_t)cirs::emb_sort_bytes(n_rows) + 1024; }
+
+extern "C" int cirs_embedding_scatter(const int32_t* keys, const float* contrib, int64_t n_rows, int32_t n_table_rows, float* grad_table,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+    using namespace cirs;
+    CIRS_REQUIRE(keys && contrib && grad_table && workspace && n_rows > 0 && n_table_rows > 0, "bad arguments");
+    CIRS_REQUIRE(n_rows < (1ll << 31), "too many rows");
+    CIRS_REQUIRE(workspace_bytes >= cirs_embedding_scatter_workspace_bytes(n_rows), "workspace too small");
+    void* ws = (void*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    return emb_scatter_sorted(keys, contrib, (int)n_rows, n_table_rows, grad_table, ws, (size_t)workspace_bytes - 256, (hipStream_t)stream);
+}
+

@@ -433,6 +433,15 @@ int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
                           const float* dstate, const cirs_tracker_grads* grads, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* Ordered scatter of embedding-gradient rows (dim_model == 32) into a table: grad_table [n_table_rows, 32] is OVERWRITTEN with, per row k,
+ * the sum of contrib[r] over the rows r with keys[r] == k, added in ascending r (stable radix sort + ordered segment sums: no float
+ * atomics, cost O(n_rows) whatever the table size); keys outside [0, n_table_rows) contribute nothing.  It is the scatter of
+ * cirs_tracker_backward's embedding gradients as an entry point of its own: the OWNER side of row-sharded tables (BASELINE configs[4],
+ * "tables row-sharded by id mod W") after the all-to-all of (row id, gradient row) pairs.  No reference counterpart. */
+int64_t cirs_embedding_scatter_workspace_bytes(int64_t n_rows);
+int cirs_embedding_scatter(const int32_t* keys, const float* contrib, int64_t n_rows, int32_t n_table_rows, float* grad_table,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * DeepFM user model (UserModel_Pairwise) and the full-catalogue sweep
  * replaces  core/user_model_pairwise.py:98-154 (_deepfm/forward), core/user_model.py:419-447 (input_from_feature_columns),

@@ -116,3 +116,121 @@ def test_sharded_rollout_bit_identical_to_single_device(W, E):
         assert torch.equal(tr.obs[1:][live], ref["obs"][1:, sl][live]), "tracker states: same rows, same arithmetic -> same bits"
         torch.testing.assert_close(tr.logp[live], ref["logp"][:, sl][live], rtol=2e-5, atol=2e-5)   # sum-exp folded in a different order
     assert int(ref["act"].max()) >= I - I // W, "the sampler must reach the last rank's item shard"
+
+
+@pytest.mark.parametrize("W,U,I,Bl,T", [(4, 4096, 4096, 16, 6), (8, 1 << 20, 1 << 20, 16, 5)])
+def test_sharded_training_step_equals_single_device(W, U, I, Bl, T):
+    """BASELINE configs[4] TRAINS in its split form (VERDICT r02 missing #1): ShardedRollout.collect + ShardedTrainer.update (item-sharded
+    head via cirs_ppo_minibatch_tp, tracker BPTT over compact embedding tables, gradient rows pushed to their owners and scattered in
+    buffer order, Adam on every shard) against the single-device engine on the same users / noise / minibatches: losses, the
+    concatenated head shards, trunk / critic, dense tracker parameters and the re-assembled embedding tables."""
+    from cirs_hip.deepfm import DeviceDeepFM
+    from cirs_hip.engine import CirsEngine
+    from cirs_hip.env import DeviceEnv, DeviceEnvTables
+    from cirs_hip.learner import flat_policy_params
+    from cirs_hip.rollout import OnlineReward, Trajectory
+    from cirs_hip.sharded import ShardedRollout, ShardedTable, ShardedTrainer, ThreadComm
+    from cirs_hip.tracker import DeviceTracker, flat_tracker_params, tracker_param_shapes
+    E, B, bs, seed = 16, Bl * W, 32, 77
+    rng = np.random.RandomState(5 + W)
+    cats = np.where(np.arange(4)[None, :] < rng.randint(1, 5, I)[:, None], rng.randint(0, 31, (I, 4)), -1).astype(np.int32)
+    feats = np.where(cats >= 0, cats + 1, 0).astype(np.int32)
+    dur = rng.uniform(2, 60, I).astype(np.float32)
+    wfm = deepfmcase.random_weights(rng, U, I, E)
+    um = DeviceDeepFM(wfm)
+    ident = np.arange(I, dtype=np.int64)
+    mm = (-60.0, 60.0)
+    tp = rolloutcase.tracker_param_dict(U, I, T, 4)
+    tp = {k: (v * 200.0 if k.startswith("embedding_dict") else v) for k, v in tp.items()}      # embeddings large enough to matter
+    arrs = policycase.random_weights(rng, I)
+    pol_named = {rolloutcase.POLICY_NAMES[k]: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)) for k, v in arrs.items()}
+    env_kw = dict(num_leave_compute=3, leave_threshold=1, max_turn=T, tau=10.0, gamma_exposure=10.0)
+    users = torch.as_tensor(rng.randint(0, U, B).astype(np.int32)).cuda()
+
+    # ---- single device ----
+    dt = DeviceEnvTables(None, None, cats, n_users=U, n_items=I)
+    eng = CirsEngine(dt, B, seed=seed, tracker_params={k: v.float() for k, v in tp.items()}, policy_params=pol_named, batch_size_hint=bs,
+                     online_reward=OnlineReward(um, ident, ident, feats, dur, mm, B), **env_kw)
+    lengths = eng.collect(users).cpu().numpy()
+    n_total = int(lengths.sum())
+    perms = [rng.permutation(n_total) for _ in range(2)]
+    ref_losses, ref_n = eng.update(bs, 2, perms=perms)
+    torch.cuda.synchronize()
+
+    # ---- W virtual ranks ----
+    fm_user_full = torch.zeros((U, E + 4)); fm_user_full[:, :E] = torch.as_tensor(wfm["emb_user"]); fm_user_full[:, E] = torch.as_tensor(wfm["lin_user"])
+    fm_item_full = torch.zeros((I, E + 4)); fm_item_full[:, :E] = torch.as_tensor(wfm["emb_item"]); fm_item_full[:, E] = torch.as_tensor(wfm["lin_item"])
+    trk_user_full, trk_item_full = tp["embedding_dict.feat_user.weight"].float(), tp["embedding_dict.feat_item.weight"].float()
+    comms = ThreadComm.make(W)
+    out, err = [None] * W, [None] * W
+    Is = I // W
+    names = rolloutcase.POLICY_NAMES
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            comm = comms[r]
+            envl = DeviceEnv(DeviceEnvTables(None, None, cats, n_users=U, n_items=I), Bl, dist_mode=1, **env_kw)
+            shapes = tracker_param_shapes(4, 4, 32, 20)
+            init = {k: (v.float() if not k.startswith("embedding_dict") else torch.zeros(4, 32)) for k, v in tp.items()}
+            tflat, tviews = flat_tracker_params(shapes, device="cuda", init=init)
+            tparams = dict(tviews); tparams["pos_encoder.pe"] = tp["pos_encoder.pe"].float().cuda().contiguous()
+            trkl = DeviceTracker(tparams, Bl, Bl, Bl, T)
+            trkl.enable_training(tflat, lr=1e-3)
+            wl = {k: (v if k not in ("emb_user", "emb_item", "lin_user", "lin_item") else np.zeros((4,) + v.shape[1:], np.float32)) for k, v in wfm.items()}
+            fml = DeviceDeepFM(wl)
+            shard_named = dict(pol_named)
+            shard_named[names["wa"]] = pol_named[names["wa"]][r * Is:(r + 1) * Is]
+            shard_named[names["ba"]] = pol_named[names["ba"]][r * Is:(r + 1) * Is]
+            pflat, pviews = flat_policy_params(Is, init=shard_named)
+            shard = {k: pviews[names[k]] for k in ("w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc")}     # views: the rollout samples from the learner's parameters
+            mk = lambda full, n: ShardedTable(ShardedTable.shard_of(full, r, W).cuda(), n, comm)  # noqa: E731
+            sr = ShardedRollout(comm, envl, trkl, Trajectory(Bl, T, 20, "cuda"), shard, r * Is, I, fml, mk(fm_user_full, U), mk(fm_item_full, I),
+                                mk(trk_user_full, U), mk(trk_item_full, I), ident, ident, feats, dur, mm)
+            trainer = ShardedTrainer(sr, pflat, B, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, lr=1e-3)
+            ln = sr.collect(users[r * Bl:(r + 1) * Bl], seed=seed << 8, rng_base=0)
+            losses, n = trainer.update(ln, bs, 2, perms=perms)
+            torch.cuda.synchronize()
+            out[r] = dict(lens=ln.cpu().numpy(), losses=losses, n=n, pviews=pviews, tviews=tviews, user=sr.trk_user.local, item=sr.trk_item.local)
+        except Exception as e:  # noqa: BLE001
+            err[r] = e
+            comms[r].s.barrier.abort()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    [t.start() for t in th]; [t.join(900) for t in th]
+    assert all(e is None for e in err), err
+    assert np.array_equal(np.concatenate([out[r]["lens"] for r in range(W)]), lengths) and out[0]["n"] == ref_n == n_total
+    for r in range(1, W):
+        assert torch.equal(out[0]["losses"], out[r]["losses"])
+        for k in ("w1", "b1", "w2", "b2", "wc", "bc"):
+            assert torch.equal(out[0]["pviews"][names[k]], out[r]["pviews"][names[k]]), k
+        for k, v in out[0]["tviews"].items():
+            if not k.startswith("embedding_dict"):
+                assert torch.equal(v, out[r]["tviews"][k]), k
+    np.testing.assert_allclose(out[0]["losses"].cpu().numpy(), ref_losses.cpu().numpy(), rtol=3e-4, atol=3e-5)
+    wa = torch.cat([out[r]["pviews"][names["wa"]] for r in range(W)]).cpu().numpy()
+    np.testing.assert_allclose(wa, eng.policy_views[names["wa"]].cpu().numpy(), rtol=3e-4, atol=3e-6)
+    for k in ("w1", "b1", "w2", "b2", "wc", "bc", "ba"):
+        got = (torch.cat([out[r]["pviews"][names[k]] for r in range(W)]) if k == "ba" else out[0]["pviews"][names[k]]).cpu().numpy()
+        np.testing.assert_allclose(got, eng.policy_views[names[k]].cpu().numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
+    close = []
+    for k, v in out[0]["tviews"].items():
+        if k.startswith("embedding_dict"):
+            continue
+        got, want = v.cpu().numpy(), eng.tracker_views[k].cpu().numpy()
+        if k.endswith("in_proj_bias"):       # key bias: analytically zero gradient, Adam noise (DESIGN.md section 2, note iv)
+            got, want = np.r_[got[:32], got[64:]], np.r_[want[:32], want[64:]]
+        # first Adam step = lr * sign(g): where a gradient is ~0 (the K projection of a soft-max that barely moves) the summation order of
+        # the four ranks' partials decides the sign -- the bound is one full step, the bulk must agree to round-off
+        np.testing.assert_allclose(got, want, rtol=0, atol=2.5e-3, err_msg=k)
+        close.append(np.abs(got - want).reshape(-1) < 2e-5)
+        assert np.mean(close[-1]) > 0.6, k
+    assert np.mean(np.concatenate(close)) > 0.93
+    for key, name in (("user", "embedding_dict.feat_user.weight"), ("item", "embedding_dict.feat_item.weight")):
+        full = eng.tracker_views[name]
+        moved = 0
+        for r in range(W):
+            got, want = out[r][key].cpu().numpy(), full[r::W].cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=0, atol=2.5e-3, err_msg=f"{name} shard {r}")
+            assert np.mean(np.abs(got - want) < 2e-5) > 0.999
+            moved += int((np.abs(got - ShardedTable.shard_of(tp[name].float(), r, W).numpy()).max(1) > 1e-4).sum())
+        assert moved >= (B // 2 if key == "user" else n_total // 4), "the embedding rows the episodes touched must have been trained"   # (an episode's last action only enters a state nobody differentiates)
