@@ -263,6 +263,71 @@ def gather_fm_probe(device, reps=10):
     return out
 
 
+def c5_split_probe(device, B=1024, T=10, E=64, reps=3):
+    """BASELINE configs[4] shape on ONE rank through the SPLIT code path (cirs_hip.sharded: row-sharded table lookups, shard partials +
+    merge of the sampler, online DeepFM reward, compact-table tracker BPTT, tensor-parallel head learner, gradient rows pushed to
+    their owners) with identity collectives: U = I = 2^20, emb_dim 64, hashed-id sized tables.  What a rank of the 8-GPU job executes,
+    minus the wire.  -> env-steps/s of collect, ms per update."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import deepfmcase
+    import policycase
+    import rolloutcase
+    from cirs_hip.deepfm import DeviceDeepFM
+    from cirs_hip.env import DeviceEnv, DeviceEnvTables
+    from cirs_hip.learner import flat_policy_params
+    from cirs_hip.rollout import Trajectory
+    from cirs_hip.sharded import LocalComm, ShardedRollout, ShardedTable, ShardedTrainer
+    from cirs_hip.tracker import DeviceTracker, flat_tracker_params, tracker_param_shapes
+    U = I = 1 << 20
+    rng = np.random.RandomState(0)
+    cats = np.where(np.arange(4)[None, :] < rng.randint(1, 5, I)[:, None], rng.randint(0, 31, (I, 4)), -1).astype(np.int32)
+    feats = np.where(cats >= 0, cats + 1, 0).astype(np.int32)
+    dur = rng.uniform(2, 60, I).astype(np.float32)
+    wfm = deepfmcase.random_weights(rng, U, I, E)
+    tp = rolloutcase.tracker_param_dict(U, I, T, 4)
+    arrs = policycase.random_weights(rng, I)
+    names = rolloutcase.POLICY_NAMES
+    comm = LocalComm()
+    env = DeviceEnv(DeviceEnvTables(None, None, cats, n_users=U, n_items=I, device=device), B, num_leave_compute=10, leave_threshold=4, max_turn=T, tau=10.0,
+                    gamma_exposure=10.0, dist_mode=1)
+    init = {k: (v.float() if not k.startswith("embedding_dict") else torch.zeros(4, 32)) for k, v in tp.items()}
+    tflat, tviews = flat_tracker_params(tracker_param_shapes(4, 4, 32, 20), device=device, init=init)
+    tparams = dict(tviews); tparams["pos_encoder.pe"] = tp["pos_encoder.pe"].float().to(device).contiguous()
+    trk = DeviceTracker(tparams, B, B, B, T, device=device)
+    trk.enable_training(tflat, lr=1e-3)
+    wl = {k: (v if k not in ("emb_user", "emb_item", "lin_user", "lin_item") else np.zeros((4,) + v.shape[1:], np.float32)) for k, v in wfm.items()}
+    fm = DeviceDeepFM(wl, device=device)
+    pflat, pviews = flat_policy_params(I, init={names[k]: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)) for k, v in arrs.items()}, device=device)
+    shard = {k: pviews[names[k]] for k in ("w1", "b1", "w2", "b2", "wa", "ba", "wc", "bc")}
+    fu = torch.zeros((U, E + 4)); fu[:, :E] = torch.as_tensor(wfm["emb_user"]); fu[:, E] = torch.as_tensor(wfm["lin_user"])
+    fi = torch.zeros((I, E + 4)); fi[:, :E] = torch.as_tensor(wfm["emb_item"]); fi[:, E] = torch.as_tensor(wfm["lin_item"])
+    mk = lambda full, n: ShardedTable(full.to(device).contiguous(), n, comm)  # noqa: E731
+    ident = np.arange(I, dtype=np.int64)
+    sr = ShardedRollout(comm, env, trk, Trajectory(B, T, 20, device), shard, 0, I, fm, mk(fu, U), mk(fi, I),
+                        mk(tp["embedding_dict.feat_user.weight"].float(), U), mk(tp["embedding_dict.feat_item.weight"].float(), I), ident, ident, feats,
+                        dur, (-60.0, 60.0))
+    trainer = ShardedTrainer(sr, pflat, B)
+    users = torch.as_tensor(rng.randint(0, U, B).astype(np.int32)).to(device)
+    lens = sr.collect(users, seed=1, rng_base=0)
+    trainer.update(lens, 1024, 2)
+    torch.cuda.synchronize()
+    t_c = t_u = 0.0
+    n_steps = 0
+    for k in range(reps):
+        t0 = time.perf_counter()
+        lens = sr.collect(users, seed=1, rng_base=(k + 1) * T)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        losses, n = trainer.update(lens, 1024, 2, perm_key=(1, 64 * k))
+        torch.cuda.synchronize()
+        t_c += t1 - t0; t_u += time.perf_counter() - t1; n_steps += n
+    return {"users": U, "items": I, "emb_dim": E, "envs": B, "max_turn": T, "ranks": 1,
+            "collect_env_steps_per_s": n_steps / t_c, "ms_per_collect": 1e3 * t_c / reps, "ms_per_update": 1e3 * t_u / reps,
+            "minibatch_steps_per_update": int(losses.shape[0]),
+            "note": "the split (row-sharded tables, item-sharded head, tensor-parallel learner) code path of BASELINE configs[4] with identity "
+                    "collectives on one device: per-stage launches, no fused rollout; the 8-rank wire time is not in it"}
+
+
 def _set_omp_threads(n):
     import ctypes
     torch.set_num_threads(n)
@@ -509,6 +574,7 @@ def main():
             out["gather_fm"] = gather_fm_probe(device)
             out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
             out["sweep_mode"] = sweep_mode_probe(wl, eng, device)
+            out["c5_split"] = c5_split_probe(device)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl, eng)
         print(json.dumps(out), flush=True)

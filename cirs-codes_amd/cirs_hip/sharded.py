@@ -69,6 +69,20 @@ class DistComm:
         return out
 
 
+class LocalComm:
+    """world 1: every collective is the identity (the split code path on ONE device: bench.py's c5_split probe)."""
+    world, rank = 1, 0
+
+    def all_gather(self, t):
+        return t.contiguous().unsqueeze(0)
+
+    def all_to_all(self, t):
+        return t.contiguous()
+
+    def all_reduce(self, t):
+        return t
+
+
 class ThreadComm:
     """W virtual ranks = W threads of one process (one GPU).  Every collective is a barrier-separated exchange through shared slots;
     device work is ordered by a device synchronisation at the barrier (test vehicle: simplicity over speed)."""
