@@ -70,7 +70,7 @@ class CirsEngine:
                  hidden=64, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
                  lr=1e-3, rew_norm=True, value_clip=True, norm_adv=True, seed=2023, tracker_params=None,
                  policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False, learner_mode="dp",
-                 online_reward=None, batch_size_hint=1024, dropout=0.0, tracker_backward=None):
+                 online_reward=None, batch_size_hint=1024, dropout=0.0, tracker_backward=None, dropout_redraw=False):
         """dropout: probability of the tracker's five dropout sites.  0.0 (default) is the mode of every parity fixture and of
         the benchmark; 0.1 reproduces the reference's training procedure, whose tracker is never put in eval()."""
         self.device = tables.device
@@ -115,7 +115,15 @@ class CirsEngine:
         self.policy_views = pviews
         self.tracker_views = tviews
         self.policy = DevicePolicy(pviews, I, dim_state=dim_state, hidden=hidden, device=self.device)
-        self.rollout = DeviceRollout(self.env, self.tracker, self.policy, online=online_reward)
+        # dropout_redraw: the reference's exact procedure (fresh masks over the whole prefix at every build_state call,
+        # core/state_tracker.py:170-186,243-246) as a study option: O(T^2) tracker launches per collect (cirs_hip/redraw.py)
+        self.dropout_redraw = bool(dropout_redraw)
+        if self.dropout_redraw:
+            from .redraw import RedrawRollout
+            assert world_size == 1 and online_reward is None, "the exact-redraw option is a single-device study mode"
+            self.rollout = RedrawRollout(self.env, self.tracker, self.policy)
+        else:
+            self.rollout = DeviceRollout(self.env, self.tracker, self.policy, online=online_reward)
         self.rollout.dropout_env_base = rank * n_env
         self.rollout.dropout_key_from_high_bits = True
         self.B_total = n_env * world_size
@@ -227,6 +235,11 @@ class CirsEngine:
             # replicated policy learner, but the BPTT through the tracker (independent per env) over this rank's envs only + one
             # all-reduce of the tracker gradients per update: its cost does not grow with the number of ranks
             self._tracker_backward_sharded(ln, lens, offsets)
+            return losses, n
+        if self.dropout_redraw:
+            from .redraw import redraw_tracker_backward
+            redraw_tracker_backward(self.rollout, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs)
+            self.tracker.adam_update()
             return losses, n
         self.tracker.backward(users, traj, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs,
                               x_hist=x_hist if (self.world > 1 or self.force_gather) else None)

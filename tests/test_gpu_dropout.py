@@ -133,3 +133,79 @@ def test_stepwise_protocol_draws_fresh_masks_per_episode():
     st.eval()
     c, d = episode(), episode()
     assert np.array_equal(c, d)
+
+
+def test_exact_redraw_mode_matches_the_reference_procedure():
+    """the reference redraws the masks of the WHOLE prefix at every build_state call (core/state_tracker.py:170-186,
+    243-246).  The exact-redraw option (cirs_hip/redraw.py, CirsEngine(dropout_redraw=True)) must (a) produce, for every call t, the
+    state of the restatement run with call t's masks over positions 0..t, (b) back-propagate d loss / d s_t through call t's graph only
+    (sum over the calls == autograd through the per-call restatement), (c) differ from the sticky production mode for t >= 1 and
+    coincide with it when p = 0."""
+    from cirs_hip.engine import CirsEngine
+    from cirs_hip.env import DeviceEnvTables
+    from cirs_hip.redraw import call_tag, redraw_tracker_backward
+    from cirs_hip.synthetic import make_tables
+    U, I, B, T, p, seed = 60, 150, 12, 7, 0.1, 11
+    tab = make_tables(U, I, seed=0, build_dist=False)
+    a_env = tab.alpha_u[tab.raw_uid, 0].astype(np.float64); b_env = tab.beta_i[tab.raw_pid, 0].astype(np.float64)
+    users = torch.as_tensor(np.random.RandomState(1).randint(0, U, B))
+
+    def make(dropout, redraw):
+        dt = DeviceEnvTables(tab.mat, tab.normed_mat, tab.item_cats, alpha_env=a_env, beta_env=b_env)
+        return CirsEngine(dt, B, max_turn=T, num_leave_compute=3, leave_threshold=1, tau=10.0, gamma_exposure=10.0, seed=seed, dropout=dropout,
+                          dropout_redraw=redraw)
+
+    eng = make(p, True)
+    lens = eng.collect(users).cpu().numpy()
+    tr = eng.rollout.traj
+    act = tr.act.cpu().numpy().T; rew = tr.rew.cpu().numpy().T; obs = tr.obs.cpu().numpy()
+    assert lens.min() >= 1 and (act[np.arange(T)[None, :] < lens[:, None]] >= 0).all()
+    tp = {k: v.detach().cpu().clone() for k, v in eng.tracker.params.items()}
+    acts0 = np.maximum(act, 0)
+    # (a) call by call against the restatement
+    sticky_like = None
+    for t in range(int(lens.max()) + 1):
+        d = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, t)), envs=np.arange(B))
+        with torch.no_grad():
+            want = nn_oracle.tracker_states(tp, users.numpy(), acts0, rew, dropout=d).numpy()
+        live = lens >= t
+        np.testing.assert_allclose(obs[t][live], want[live, t], atol=5e-5, rtol=1e-4, err_msg=f"call {t}")
+        if t == 2:
+            d1 = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, 1)), envs=np.arange(B))
+            with torch.no_grad():
+                other = nn_oracle.tracker_states(tp, users.numpy(), acts0, rew, dropout=d1).numpy()
+            assert np.abs(other[live, 2] - want[live, 2]).max() > 1e-3, "a call's masks must differ from the previous call's"
+    # (b) backward: sum over calls
+    G = np.random.RandomState(3).randn(T + 1, B, 20).astype(np.float32)
+    tpo = {k: v.clone() for k, v in tp.items()}
+    for k, v in tpo.items():
+        if k != "pos_encoder.pe":
+            v.requires_grad_(True)
+    total = 0.0
+    for t in range(int(lens.max())):
+        d = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, t)), envs=np.arange(B))
+        st = nn_oracle.tracker_forward_all(tpo, nn_oracle.tracker_inputs(tpo, users.numpy(), acts0, rew), 4, dropout=d)
+        w = torch.zeros(B, 20)
+        sel = torch.as_tensor(lens > t)
+        w[sel] = torch.as_tensor(G[t])[sel]
+        total = total + (st[:, t] * w).sum()
+    total.backward()
+    offsets, row_env, row_t = rows_of(lens)
+    dd = lambda x: torch.as_tensor(x).cuda()  # noqa: E731
+    redraw_tracker_backward(eng.rollout, dd(row_env), dd(row_t), dd(offsets), dd(lens.astype(np.int32)), int(lens.sum()), dd(G))
+    for k, gv in eng.tracker.grad_views.items():
+        want, got = tpo[k].grad.numpy(), gv.cpu().numpy()
+        if k.endswith("self_attn.in_proj_bias"):
+            want, got = np.delete(want, slice(32, 64)), np.delete(got, slice(32, 64))
+        scale = np.abs(want).max() + 1e-12
+        np.testing.assert_allclose(got / scale, want / scale, atol=5e-4, err_msg=k)
+    # the engine's update runs through it
+    losses, n = eng.update(batch_size=32, repeat=2)
+    assert n == int(lens.sum()) and torch.isfinite(losses).all() and torch.isfinite(eng.tracker_flat).all()
+    # (c) p = 0: the option is the ordinary rollout
+    e0, e1 = make(0.0, True), make(0.0, False)
+    l0, l1 = e0.collect(users), e1.collect(users)
+    assert torch.equal(l0, l1) and torch.equal(e0.rollout.traj.act, e1.rollout.traj.act)
+    live = (e1.rollout.traj.act >= 0)
+    torch.testing.assert_close(e0.rollout.traj.obs[:-1][live], e1.rollout.traj.obs[:-1][live], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(e0.rollout.traj.rew[live], e1.rollout.traj.rew[live], rtol=1e-12, atol=0)
