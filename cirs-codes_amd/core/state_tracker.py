@@ -15,14 +15,17 @@ class StateTrackerTransformer(nn.Module):
     def __new__(cls, user_columns=None, action_columns=None, feedback_columns=None, *args, **kwargs):
         """VirtualTB-v0 (BASELINE configs[0]: CPU plumbing, dense features) is served by the host tracker of core.host_rl, exactly
         as the reference runs it on the CPU; KuaishouEnv-v0 by the device engine below."""
-        dataset = kwargs.get("dataset", args[4] if len(args) > 4 else "VirtualTB-v0")
+        dataset = kwargs.get("dataset", args[4] if len(args) > 4 else None)
+        if dataset is None:      # not given: sparse id columns mean the KuaishouEnv tracker, all-dense columns the VirtualTB one
+            from deepctr_torch.inputs import SparseFeat
+            dataset = "KuaishouEnv-v0" if any(isinstance(c, SparseFeat) for c in list(user_columns or []) + list(action_columns or [])) else "VirtualTB-v0"
         if cls is StateTrackerTransformer and dataset == "VirtualTB-v0":
             from core.host_rl import HostStateTracker
             return HostStateTracker(user_columns, action_columns, feedback_columns, *args, **kwargs)
         return super().__new__(cls)
 
     def __init__(self, user_columns, action_columns, feedback_columns, dim_model, dim_state, dim_max_batch, dropout=0.1,
-                 dataset="VirtualTB-v0", has_user_embedding=True, has_action_embedding=True, has_feedback_embedding=False,
+                 dataset="KuaishouEnv-v0", has_user_embedding=True, has_action_embedding=True, has_feedback_embedding=False,
                  nhead=8, d_hid=128, nlayers=2, device="cpu", seed=2021, init_std=0.0001, padding_idx=None, MAX_TURN=100):
         super().__init__()
         if dataset != "KuaishouEnv-v0":

@@ -42,6 +42,7 @@ def test_tracker_matches_reference_golden(golden_dir):
     m = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), m)
     # s_t <= 1e-5 abs with dropout disabled, every step of the episode
+    print(f"[tracker vs reference golden] max |err| = {np.abs(got[m] - want[m]).max():.3e} over {int(m.sum())} state entries (bar 2e-5)")
     np.testing.assert_allclose(got[m], want[m], atol=2e-5, rtol=1e-5)
     # x_hist (the reference's self.data) matches too
     x = nn_oracle.tracker_inputs(p, z["users"], z["acts"], z["rews"]).numpy()
@@ -76,5 +77,6 @@ def test_tracker_vs_restatement_at_baseline_sizes(U, I, B, T, nhead):
     want = nn_oracle.tracker_states(p, users, acts, rews, nhead=nhead).numpy()
     trk = dev_tracker(p, U, I, B, T, nhead=nhead)
     got = run_device(trk, users, acts, rews, np.full(B, T))
+    print(f"[tracker vs restatement U={U} I={I} B={B} T={T} nhead={nhead}] max |err| = {np.abs(got - want).max():.3e}, max |state| = {np.abs(want).max():.2f}")
     np.testing.assert_allclose(got, want, atol=5e-5, rtol=1e-4)
     assert int(trk.len.min()) == T + 1
