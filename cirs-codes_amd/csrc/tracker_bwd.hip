@@ -256,6 +256,238 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(const float* __restrict__ QKV
     dQKV[(size_t)r * 96 + tD + lane] = acc;   // columns [32, 64) = dK, [64, 96) = dV
 }
 
+// ---- per-episode attention (round 3): one workgroup per env, the episode's Q / K / V rows staged in LDS ONCE --------------------------
+// The per-row kernels above give every query row its own wavefront: <= max_turn of the 64 lanes hold a key, and every wavefront re-reads
+// the keys / values of its episode from L2 (3 launches x 30 k wavefronts x ~40 dependent global loads at C3: 34 + 48 + 28 us per
+// layer).  Here a wavefront owns a head group of one env and a lane owns a QUERY (its keys are walked out of LDS: soft-max statistics,
+// dQ and the output need no cross-lane reduction) and, in the second phase of the backward, a KEY (dK / dV accumulated over the later
+// queries in order).  The probabilities are not kept between the forward and the backward pass: the backward recomputes them from
+// Q, K (cheaper than 15 MB of P through HBM).  Used when max_len <= 64 and the LDS image fits 64 KB (max_len <= 50 at 4 heads); longer
+// episodes take the per-row kernels.
+template <int NH> struct EpGeo {
+    static constexpr int NW = NH < 4 ? NH : 4;      // wavefronts per env = head groups
+    static constexpr int HPL = NH / NW;             // heads per lane
+    static constexpr int HD = tD / NH;
+    static constexpr int DPL = HPL * HD;            // dims per lane
+    __host__ __device__ static constexpr int strip(int Lp) { return (HPL * Lp) | 1; }   // odd stride between queries: conflict-free both ways
+    __host__ __device__ static constexpr size_t fwd_floats(int Lp) { return (size_t)Lp * 64 + (size_t)NW * Lp * strip(Lp); }
+    __host__ __device__ static constexpr size_t bwd_floats(int Lp) { return (size_t)Lp * 128 + (size_t)NW * Lp * strip(Lp) + 2 * (size_t)NH * Lp; }
+};
+
+// stage `cols` floats (multiple of 4) per row of an episode, rows `src_stride` apart, into LDS rows of `cols` floats
+__device__ __forceinline__ void ep_stage(float* __restrict__ dst, const float* __restrict__ src, int rows, int src_stride, int cols, int tid, int nt) {
+    const int c4n = cols >> 2;
+    for (int i = tid; i < rows * c4n; i += nt) {
+        const int row = i / c4n, c4 = i - row * c4n;
+        *reinterpret_cast<f32x4*>(dst + (size_t)row * cols + 4 * c4) = *reinterpret_cast<const f32x4*>(src + (size_t)row * src_stride + 4 * c4);
+    }
+}
+template <int N> __device__ __forceinline__ void ep_load(float (&v)[N], const float* __restrict__ src) {
+#pragma unroll
+    for (int d4 = 0; d4 < N / 4; ++d4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * d4);
+        v[4 * d4] = t.x; v[4 * d4 + 1] = t.y; v[4 * d4 + 2] = t.z; v[4 * d4 + 3] = t.w;
+    }
+}
+template <int N> __device__ __forceinline__ void ep_store(float* __restrict__ dst, const float (&v)[N], float a) {
+#pragma unroll
+    for (int d4 = 0; d4 < N / 4; ++d4)
+        *reinterpret_cast<f32x4*>(dst + 4 * d4) = f32x4{v[4 * d4] * a, v[4 * d4 + 1] * a, v[4 * d4 + 2] * a, v[4 * d4 + 3] * a};
+}
+// exp(x) for x <= 0 on the transcendental unit (v_exp_f32, ~1 ulp): the per-episode kernels keep their scores in log2 units
+__device__ __forceinline__ float ep_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+template <int HD> __device__ __forceinline__ float ep_dot(const float* a, const float* b) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = __builtin_fmaf(a[d], b[d], s);
+    return s;
+}
+#define EP_KEEP(POS, ELEM) dropout_keep(dc.seed, (uint32_t)(dc.env_base + b), (uint32_t)(POS), (uint32_t)layer, (uint32_t)CIRS_DROP_ATTN, (uint32_t)(ELEM), dc.thr)
+
+template <int NH, bool kDrop>
+__global__ __launch_bounds__(64 * EpGeo<NH>::NW) void attn_fwd_ep(const float* __restrict__ QKV, const int32_t* __restrict__ offsets,
+                                                                  const int32_t* __restrict__ lens, int Lp, float* __restrict__ ATT,
+                                                                  DropCfg dc, int layer) {
+    using G = EpGeo<NH>;
+    constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, len = lens[b];
+    if (len <= 0) return;
+    const int lane = threadIdx.x & 63, hg = threadIdx.x >> 6, p = lane;
+    const int base = offsets[b], STR = G::strip(Lp);
+    float* sKV = smem;                          // [len][K 32 | V 32]
+    float* sS = smem + (size_t)Lp * 64;         // [head group][query][HPL][Lp] (query stride STR)
+    ep_stage(sKV, QKV + (size_t)base * 96 + tD, len, 96, 64, threadIdx.x, 64 * G::NW);
+    __syncthreads();
+    if (p >= len) return;
+    const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;   // q * scale * log2(e): scores in log2 units
+    float* my = sS + ((size_t)hg * Lp + p) * STR;
+    float q[DPL];
+    ep_load(q, QKV + (size_t)(base + p) * 96 + hg * DPL);
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) q[d] *= qs;
+    float mx[HPL], sm[HPL];
+#pragma unroll
+    for (int h = 0; h < HPL; ++h) { mx[h] = -INFINITY; sm[h] = 0.f; }
+#pragma unroll 4
+    for (int j = 0; j <= p; ++j) {
+        float k[DPL];
+        ep_load(k, sKV + (size_t)j * 64 + hg * DPL);
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) {
+            const float sc = ep_dot<HD>(q + h * HD, k + h * HD);
+            my[h * Lp + j] = sc;
+            mx[h] = fmaxf(mx[h], sc);
+        }
+    }
+    float acc[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) acc[d] = 0.f;
+#pragma unroll 4
+    for (int j = 0; j <= p; ++j) {
+        float v[DPL];
+        ep_load(v, sKV + (size_t)j * 64 + 32 + hg * DPL);
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) {
+            float e = ep_exp2(my[h * Lp + j] - mx[h]);
+            sm[h] += e;
+            if (kDrop && !EP_KEEP(p, j * NH + hg * HPL + h)) e = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[h * HD + d] = __builtin_fmaf(e, v[h * HD + d], acc[h * HD + d]);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < HPL; ++h) {
+        const float inv = (kDrop ? dc.inv : 1.0f) / sm[h];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[h * HD + d] *= inv;
+    }
+    ep_store(ATT + (size_t)(base + p) * tD + hg * DPL, acc, 1.0f);
+}
+
+// backward of the same attention: dQKV[r] = [dQ | dK | dV] for every row of the episode.
+//   phase A (lane = query p):  scores -> soft-max statistics (m, 1/sum) -> dot = sum_j P dP -> dS = P (dP - dot) into the strip, dQ
+//   phase B (lane = key j):    dK[j] = sum_{p >= j} dS[p, j] q[p] scale,  dV[j] = sum_{p >= j} PM[p, j] dATT[p], queries in order; P is
+//                              recomputed from the statistics of phase A (one strip instead of two keeps four episodes per CU)
+template <int NH, bool kDrop>
+__global__ __launch_bounds__(64 * EpGeo<NH>::NW) void attn_bwd_ep(const float* __restrict__ QKV, const float* __restrict__ dATT,
+                                                                  const int32_t* __restrict__ offsets, const int32_t* __restrict__ lens,
+                                                                  int Lp, float* __restrict__ dQKV, DropCfg dc, int layer) {
+    using G = EpGeo<NH>;
+    constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, len = lens[b];
+    if (len <= 0) return;
+    const int lane = threadIdx.x & 63, hg = threadIdx.x >> 6;
+    const int base = offsets[b], STR = G::strip(Lp);
+    float* sQKV = smem;                                  // [len][96]
+    float* sdA = smem + (size_t)Lp * 96;                 // [len][32]
+    float* sS = sdA + (size_t)Lp * 32;                   // [head group][query][HPL][Lp] (query stride STR): scores -> e -> dS
+    float* sM = sS + (size_t)G::NW * Lp * STR;           // [head group][query][HPL]: row max
+    float* sI = sM + (size_t)NH * Lp;                    //                           1 / sum
+    ep_stage(sQKV, QKV + (size_t)base * 96, len, 96, 96, threadIdx.x, 64 * G::NW);
+    ep_stage(sdA, dATT + (size_t)base * tD, len, tD, tD, threadIdx.x, 64 * G::NW);
+    __syncthreads();
+    const bool act = lane < len;
+    const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;   // q * scale * log2(e): scores in log2 units
+    const float dinv = kDrop ? dc.inv : 1.0f;
+    if (act) {   // ---------------- phase A: lane = query p ----------------
+        const int p = lane;
+        float* my = sS + ((size_t)hg * Lp + p) * STR;
+        float q[DPL], da[DPL];
+        ep_load(q, sQKV + (size_t)p * 96 + hg * DPL);
+        ep_load(da, sdA + (size_t)p * tD + hg * DPL);
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) q[d] *= qs;
+        float mx[HPL], sm[HPL], dot[HPL];
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) { mx[h] = -INFINITY; sm[h] = 0.f; dot[h] = 0.f; }
+#pragma unroll 4
+        for (int j = 0; j <= p; ++j) {
+            float k[DPL];
+            ep_load(k, sQKV + (size_t)j * 96 + 32 + hg * DPL);
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                const float sc = ep_dot<HD>(q + h * HD, k + h * HD);
+                my[h * Lp + j] = sc;
+                mx[h] = fmaxf(mx[h], sc);
+            }
+        }
+#pragma unroll 4
+        for (int j = 0; j <= p; ++j) {
+            float v[DPL];
+            ep_load(v, sQKV + (size_t)j * 96 + 64 + hg * DPL);
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                const float e = ep_exp2(my[h * Lp + j] - mx[h]);
+                my[h * Lp + j] = e;
+                sm[h] += e;
+                float dp = ep_dot<HD>(da + h * HD, v + h * HD);
+                if (kDrop) dp = EP_KEEP(p, j * NH + hg * HPL + h) ? dp * dinv : 0.f;
+                dot[h] = __builtin_fmaf(e, dp, dot[h]);       // sum_j e dP; normalised below
+            }
+        }
+        float inv[HPL];
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) {
+            inv[h] = 1.0f / sm[h];
+            dot[h] *= inv[h];
+            sM[((size_t)hg * Lp + p) * HPL + h] = mx[h];
+            sI[((size_t)hg * Lp + p) * HPL + h] = inv[h];
+        }
+        float dq[DPL];
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) dq[d] = 0.f;
+#pragma unroll 4
+        for (int j = 0; j <= p; ++j) {
+            float k[DPL], v[DPL];
+            ep_load(k, sQKV + (size_t)j * 96 + 32 + hg * DPL);
+            ep_load(v, sQKV + (size_t)j * 96 + 64 + hg * DPL);
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                float dp = ep_dot<HD>(da + h * HD, v + h * HD);
+                if (kDrop) dp = EP_KEEP(p, j * NH + hg * HPL + h) ? dp * dinv : 0.f;
+                const float ds = my[h * Lp + j] * inv[h] * (dp - dot[h]);
+                my[h * Lp + j] = ds;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) dq[h * HD + d] = __builtin_fmaf(ds, k[h * HD + d], dq[h * HD + d]);
+            }
+        }
+        ep_store(dQKV + (size_t)(base + p) * 96 + hg * DPL, dq, scale);
+    }
+    __syncthreads();
+    if (act) {   // ---------------- phase B: lane = key j ----------------
+        const int j = lane;
+        float kk[DPL], dK[DPL], dV[DPL];
+        ep_load(kk, sQKV + (size_t)j * 96 + 32 + hg * DPL);
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) { kk[d] *= qs; dK[d] = 0.f; dV[d] = 0.f; }     // scores in log2 units, like phase A's statistics
+#pragma unroll 2
+        for (int pq = j; pq < len; ++pq) {
+            float q[DPL], da[DPL];
+            ep_load(q, sQKV + (size_t)pq * 96 + hg * DPL);
+            ep_load(da, sdA + (size_t)pq * tD + hg * DPL);
+            const size_t st = ((size_t)hg * Lp + pq);
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                const float sc = ep_dot<HD>(q + h * HD, kk + h * HD);
+                float pm = ep_exp2(sc - sM[st * HPL + h]) * sI[st * HPL + h];
+                if (kDrop) pm = EP_KEEP(pq, j * NH + hg * HPL + h) ? pm * dinv : 0.f;
+                const float ds = sS[st * STR + h * Lp + j];
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    dK[h * HD + d] = __builtin_fmaf(ds, q[h * HD + d], dK[h * HD + d]);
+                    dV[h * HD + d] = __builtin_fmaf(pm, da[h * HD + d], dV[h * HD + d]);
+                }
+            }
+        }
+        float* o = dQKV + (size_t)(base + j) * 96 + 32 + hg * DPL;
+        ep_store(o, dK, scale);
+        ep_store(o + 32, dV, 1.0f);
+    }
+}
+#undef EP_KEEP
+
 // sum over the 32 lanes of a half-wave (one LayerNorm row per half-wave), result in every lane of the half
 __device__ __forceinline__ float half_sum32(float v) {
 #pragma unroll
@@ -621,6 +853,30 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         }                                                                                                 \
     } while (0)
 #define ATT_DISPATCH(KERNEL, ...) ATT_DISPATCH_SH(KERNEL, 0, __VA_ARGS__)
+    // per-episode attention kernels (one wavefront per env, Q/K/V in LDS) whenever their LDS image fits the default 64 KB window
+    auto ep_bytes = [&](bool bwd) -> size_t {
+        switch (NH) {
+            case 1: return 4 * (bwd ? EpGeo<1>::bwd_floats(L) : EpGeo<1>::fwd_floats(L));
+            case 2: return 4 * (bwd ? EpGeo<2>::bwd_floats(L) : EpGeo<2>::fwd_floats(L));
+            case 4: return 4 * (bwd ? EpGeo<4>::bwd_floats(L) : EpGeo<4>::fwd_floats(L));
+            default: return 4 * (bwd ? EpGeo<8>::bwd_floats(L) : EpGeo<8>::fwd_floats(L));
+        }
+    };
+    const bool ep = L <= 64 && ep_bytes(true) <= 64 * 1024 && !getenv("CIRS_TRACKER_ATTN_ROWS");
+#define ATT_EP1(KERNEL, N, BWD, ...)                                                                                            \
+    do {                                                                                                                        \
+        if (dc.on) hipLaunchKernelGGL((KERNEL<N, true>), dim3(B), dim3(64 * EpGeo<N>::NW), ep_bytes(BWD), s, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((KERNEL<N, false>), dim3(B), dim3(64 * EpGeo<N>::NW), ep_bytes(BWD), s, __VA_ARGS__);           \
+    } while (0)
+#define ATT_EP(KERNEL, BWD, ...)                                  \
+    do {                                                          \
+        switch (NH) {                                             \
+            case 1: ATT_EP1(KERNEL, 1, BWD, __VA_ARGS__); break;  \
+            case 2: ATT_EP1(KERNEL, 2, BWD, __VA_ARGS__); break;  \
+            case 4: ATT_EP1(KERNEL, 4, BWD, __VA_ARGS__); break;  \
+            default: ATT_EP1(KERNEL, 8, BWD, __VA_ARGS__); break; \
+        }                                                         \
+    } while (0)
 
     DropCfg dc{};
     if (cfg->dropout_p > 0.f) {
@@ -633,7 +889,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     for (int l = 0; l < nl; ++l) {
         const cirs_tracker_layer& y = w->layer[l];
         launch_rows_gemm(true, sc.H[l], tD, y.in_proj_w, tD, y.in_proj_b, R, tD, 96, 0, nullptr, 0, sc.QKV[l], 96, s);
-        ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l], dc, l, sc.PM[l]);
+        if (ep) ATT_EP(attn_fwd_ep, false, (const float*)sc.QKV[l], offsets, lens, L, sc.ATT[l], dc, l);
+        else ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l], dc, l, sc.PM[l]);
         launch_rows_gemm(true, sc.ATT[l], tD, y.out_proj_w, tD, y.out_proj_b, R, tD, tD, 0, nullptr, 0, sc.T0, tD, s);
         hipLaunchKernelGGL(ln_fwd, g1((long)R * tD), dim3(256), 0, s, sc.H[l], sc.T0, y.norm1_w, y.norm1_b, R, sc.XH1[l], sc.RS1[l], sc.H1N[l],
                            dc, row_env, row_t, l, (int)CIRS_DROP_RES1);
@@ -680,9 +937,13 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         float* dATT = sc.T1;
         DW_ROWS(sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b, false, dB1, tD, y.out_proj_w, tD, nullptr, R, tD, tD, 0, nullptr, 0, dATT, tD);
         // attention (dropout: V is weighted by the masked probabilities PM; the softmax backward runs on P)
-        ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV,
-                        (const float*)sc.PM[l], dc.inv);
-        ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], dc.on ? sc.PM[l] : sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
+        if (ep) {
+            ATT_EP(attn_bwd_ep, true, (const float*)sc.QKV[l], (const float*)dATT, offsets, lens, L, sc.dQKV, dc, l);
+        } else {
+            ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV,
+                            (const float*)sc.PM[l], dc.inv);
+            ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], dc.on ? sc.PM[l] : sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
+        }
         // in_proj
         // d H_l = dY1 (residual) + dQKV * W_in
         DW_ROWS(sc.H[l], 96, tD, gy.in_proj_w, gy.in_proj_b, false, sc.dQKV, 96, y.in_proj_w, tD, nullptr, R, 96, tD, 0, nullptr, 1, dY1, tD);
@@ -719,6 +980,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     CIRS_CHECK_LAUNCH("tracker backward slots");
 #undef DW
 #undef ATT_DISPATCH
+#undef ATT_EP
+#undef ATT_EP1
 #undef ATT_DISPATCH_SH
     return CIRS_OK;
 }
