@@ -16,6 +16,13 @@ namespace cirs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int tD = 32, tH = 128;
+#ifdef CIRS_TBWD_PROF
+// stage timestamps of one mid-grid workgroup (probe builds only: tools/probes/tbwd_prof.py)
+__device__ unsigned long long g_tbwd_prof[64];
+#define CIRS_BSTAMP(K) do { if ((int)blockIdx.x == 300 && threadIdx.x == 0) g_tbwd_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CIRS_BSTAMP(K) do { } while (0)
+#endif
 constexpr int kChunkRows = 256;
 
 // dropout of the recompute / backward (production mode): the masks the forward decode steps applied, regenerated from their
@@ -519,6 +526,461 @@ __global__ __launch_bounds__(256) void ln_fwd(const float* __restrict__ Y, const
     xhat[i] = xh;
     out[i] = xh * g[d] + b[d];
 }
+// ---- fused row chains of the forward recompute (round 3) ------------------------------------------------------------------------
+// Everything between two attention stages is row-local: out_proj + residual + LayerNorm1 + lin1 (relu) + lin2 + residual + LayerNorm2 +
+// the next layer's in_proj.  One wavefront owns a 32-row tile and walks the whole chain: the GEMMs on v_mfma_f32_32x32x2_f32 with the
+// same operand order as rows_gemm_body (same bits), the LayerNorms in the "lane = (row, column half)" layout the next GEMM wants as
+// its A operand (tile transposed through LDS), every activation the backward pass needs written on the way.  5 launches instead of 15.
+constexpr int kRowT = 132;   // LDS tile row stride (floats): 128 columns + 4 -> conflict-free b128 row reads
+__device__ __forceinline__ int acc_row(int s, int hi) { return (s & 3) + 8 * (s >> 2) + 4 * hi; }   // row of accumulator register s
+// acc += A (16 k of this lane's row, lane half hi owns k in [16 hi, 16 hi + 16) of the 32-k block) x W rows (wr = &W[n][kk + 16 hi])
+__device__ __forceinline__ void mm_block(sg_f32x16& acc, const float (&a)[16], const float* __restrict__ wr) {
+    float bv[16];
+    ep_load(bv, wr);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void acc_to_lds(float* __restrict__ sT, const sg_f32x16& acc, int col, int hi) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sT[acc_row(s, hi) * kRowT + col] = acc[s];
+}
+// LayerNorm of the lane's half row (16 values; the other half sits in lane ^ 32)
+__device__ __forceinline__ void ln_half_row(const float (&y)[16], const float* __restrict__ g, const float* __restrict__ b, int hi,
+                                            float (&xh)[16], float (&out)[16], float& rs) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += y[j];
+    sum += __shfl_xor(sum, 32, CIRS_WAVE);
+    const float mean = sum * (1.0f / tD);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float t = y[j] - mean; q = __builtin_fmaf(t, t, q); }
+    q += __shfl_xor(q, 32, CIRS_WAVE);
+    rs = 1.0f / sqrtf(q * (1.0f / tD) + 1e-5f);
+    float gg[16], bb[16];
+    ep_load(gg, g + 16 * hi);
+    ep_load(bb, b + 16 * hi);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { xh[j] = (y[j] - mean) * rs; out[j] = xh[j] * gg[j] + bb[j]; }
+}
+
+struct LayerFwdArgs {
+    const float *ATT, *H;                                   // [R, 32] inputs: attention output, layer input (residual)
+    cirs_tracker_layer y;                                   // this layer's weights
+    const float *win_next, *bin_next;                       // the next layer's in_proj (null after the last layer)
+    float *XH1, *RS1, *H1N, *FF1, *XH2, *RS2, *Hout, *QKVnext;
+    const int32_t *row_env, *row_t;
+    int R, layer;
+};
+// acc += A x B with the B rows already in registers
+__device__ __forceinline__ void mm_regs(sg_f32x16& acc, const float (&a)[16], const float (&bv)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void ln_apply(const float (&y)[16], const float (&gg)[16], const float (&bb)[16], float (&xh)[16], float (&out)[16], float& rs) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += y[j];
+    sum += __shfl_xor(sum, 32, CIRS_WAVE);
+    const float mean = sum * (1.0f / tD);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float t = y[j] - mean; q = __builtin_fmaf(t, t, q); }
+    q += __shfl_xor(q, 32, CIRS_WAVE);
+    rs = 1.0f / sqrtf(q * (1.0f / tD) + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { xh[j] = (y[j] - mean) * rs; out[j] = xh[j] * gg[j] + bb[j]; }
+}
+// One wavefront per SIMD and a strict dependency chain: what the kernel waits for is memory latency, so every weight row is requested a
+// stage ahead of its MFMAs (the registers are there: one wavefront per SIMD may use all 512).
+template <bool kDrop>
+__global__ __launch_bounds__(64) void layer_rows_fwd(LayerFwdArgs a, DropCfg dc) {
+    // 40 KB although the tile needs 17: at most four of these one-wavefront workgroups per CU, i.e. one per SIMD (the dispatcher
+    // otherwise stacks up to nine on a CU while other CUs idle, and the slowest CU is the kernel)
+    __shared__ __attribute__((aligned(16))) float sT[10 * 1024];
+    CIRS_BSTAMP(0);
+    const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
+    const int row0 = blockIdx.x * 32, row = row0 + lo;
+    const bool row_ok = row < a.R;
+    const size_t rr = (size_t)(row_ok ? row : 0);
+    const int env = kDrop ? a.row_env[rr] : 0, pos = kDrop ? a.row_t[rr] : 0;
+    // ---- requests of the first two stages ----------------------------------------------------------------------------------------
+    float x[16], hrow[16], wo[16], w1[4][16], g1[16], be1[16];
+    ep_load(x, a.ATT + rr * tD + 16 * hi);
+    ep_load(wo, a.y.out_proj_w + (size_t)lo * tD + 16 * hi);
+    ep_load(hrow, a.H + rr * tD + 16 * hi);
+    ep_load(g1, a.y.norm1_w + 16 * hi);
+    ep_load(be1, a.y.norm1_b + 16 * hi);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) ep_load(w1[nt], a.y.lin1_w + (size_t)(nt * 32 + lo) * tD + 16 * hi);
+    const float bo = a.y.out_proj_b[lo], bl2 = a.y.lin2_b[lo];
+    float bl1[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bl1[nt] = a.y.lin1_b[nt * 32 + lo];
+    if (!row_ok) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = 0.f;
+    }
+    // ---- out_proj -------------------------------------------------------------------------------------------------------------
+    sg_f32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = bo;
+    CIRS_BSTAMP(1);
+    mm_regs(acc, x, wo);
+    CIRS_BSTAMP(2);
+    acc_to_lds(sT, acc, lo, hi);
+    __syncthreads();
+    // ---- residual + LayerNorm1 (lane = row, column half); lin2's weight rows requested meanwhile -----------------------------------
+    float w2[4][16];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ep_load(w2[kb], a.y.lin2_w + (size_t)lo * tH + kb * 32 + 16 * hi);
+    float y[16], xh[16], h1n[16], rs;
+    {
+        float t[16];
+        ep_load(t, sT + lo * kRowT + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = t[j];
+            if (kDrop) v = drop_apply(dc, v, env, pos, a.layer, CIRS_DROP_RES1, 16 * hi + j);
+            y[j] = row_ok ? hrow[j] + v : 0.f;
+        }
+    }
+    CIRS_BSTAMP(3);
+    ln_apply(y, g1, be1, xh, h1n, rs);
+    CIRS_BSTAMP(4);
+    if (row_ok) {
+        ep_store(a.XH1 + rr * tD + 16 * hi, xh, 1.0f);
+        ep_store(a.H1N + rr * tD + 16 * hi, h1n, 1.0f);
+        if (hi == 0) a.RS1[rr] = rs;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h1n[j] = 0.f;
+    }
+    __syncthreads();
+    CIRS_BSTAMP(5);
+    // ---- lin1 + relu (+ dropout): 4 column tiles; FF1 to global (accumulator layout: 128-byte row pieces) and to LDS for lin2 ------
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = nt * 32 + lo;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = bl1[nt];
+        mm_regs(acc, h1n, w1[nt]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = row0 + acc_row(s, hi);
+            float v = fmaxf(acc[s], 0.f);
+            if (kDrop && r < a.R) v = drop_apply(dc, v, a.row_env[r], a.row_t[r], a.layer, CIRS_DROP_FF, n);
+            acc[s] = v;
+            if (r < a.R) a.FF1[(size_t)r * tH + n] = v;
+        }
+        acc_to_lds(sT, acc, n, hi);
+    }
+    __syncthreads();
+    CIRS_BSTAMP(6);
+    // ---- lin2; LayerNorm2's parameters and the next in_proj's rows requested meanwhile ------------------------------------------------
+    float g2[16], be2[16], wn[3][16], bn[3];
+    ep_load(g2, a.y.norm2_w + 16 * hi);
+    ep_load(be2, a.y.norm2_b + 16 * hi);
+    if (a.win_next) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            ep_load(wn[nt], a.win_next + (size_t)(nt * 32 + lo) * tD + 16 * hi);
+            bn[nt] = a.bin_next[nt * 32 + lo];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = bl2;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        float f[16];
+        ep_load(f, sT + lo * kRowT + kb * 32 + 16 * hi);
+        if (!row_ok) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) f[j] = 0.f;
+        }
+        mm_regs(acc, f, w2[kb]);
+    }
+    CIRS_BSTAMP(7);
+    __syncthreads();
+    acc_to_lds(sT, acc, lo, hi);
+    __syncthreads();
+    // ---- residual + LayerNorm2 ---------------------------------------------------------------------------------------------------
+    float hn[16];
+    {
+        float t[16];
+        ep_load(t, sT + lo * kRowT + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = t[j];
+            if (kDrop) v = drop_apply(dc, v, env, pos, a.layer, CIRS_DROP_RES2, 16 * hi + j);
+            y[j] = row_ok ? h1n[j] + v : 0.f;
+        }
+    }
+    CIRS_BSTAMP(8);
+    ln_apply(y, g2, be2, xh, hn, rs);
+    CIRS_BSTAMP(9);
+    if (row_ok) {
+        ep_store(a.XH2 + rr * tD + 16 * hi, xh, 1.0f);
+        ep_store(a.Hout + rr * tD + 16 * hi, hn, 1.0f);
+        if (hi == 0) a.RS2[rr] = rs;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hn[j] = 0.f;
+    }
+    CIRS_BSTAMP(10);
+    // ---- the next layer's in_proj ------------------------------------------------------------------------------------------------
+    if (a.win_next) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int n = nt * 32 + lo;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[s] = bn[nt];
+            mm_regs(acc, hn, wn[nt]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int r = row0 + acc_row(s, hi);
+                if (r < a.R) a.QKVnext[(size_t)r * 96 + n] = acc[s];
+            }
+        }
+    }
+    CIRS_BSTAMP(11);
+}
+
+// slot gather + scale + positional encoding (embed_rows) + the first layer's in_proj, one wavefront per 32 rows
+template <bool kDrop>
+__global__ __launch_bounds__(64) void embed_inproj(const float* __restrict__ x_hist, const float* __restrict__ pe,
+                                                   const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t, int R, int L,
+                                                   const float* __restrict__ win, const float* __restrict__ bin, float* __restrict__ H0,
+                                                   float* __restrict__ QKV, DropCfg dc) {
+    const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
+    const int row0 = blockIdx.x * 32, row = row0 + lo;
+    const bool row_ok = row < R;
+    const size_t rr = (size_t)(row_ok ? row : 0);
+    const int b = row_env[rr], p = row_t[rr];
+    float x[16], pp[16], h[16];
+    ep_load(x, x_hist + ((size_t)b * L + p) * tD + 16 * hi);
+    ep_load(pp, pe + (size_t)p * tD + 16 * hi);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float v = x[j] * 5.656854249492381f + pp[j];
+        if (kDrop) v = drop_apply(dc, v, b, p, 0, CIRS_DROP_POS, 16 * hi + j);
+        h[j] = row_ok ? v : 0.f;
+    }
+    if (row_ok) ep_store(H0 + rr * tD + 16 * hi, h, 1.0f);
+    sg_f32x16 acc;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int n = nt * 32 + lo;
+        const float bias = bin[n];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = bias;
+        mm_block(acc, h, win + (size_t)n * tD + 16 * hi);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = row0 + acc_row(s, hi);
+            if (r < R) QKV[(size_t)r * 96 + n] = acc[s];
+        }
+    }
+}
+
+// ---- fused row chain of the backward pass (round 3) ------------------------------------------------------------------------------
+// Per layer, between the attention backward of the layer above and its own:  [in_proj backward of the layer above] -> LayerNorm2
+// backward -> lin2 backward (relu / dropout gate) -> lin1 backward + residual -> LayerNorm1 backward -> out_proj backward.  One wavefront
+// per 32-row tile, GEMMs ("NN": dX = dY W, W[k][n] read coalesced over n) on v_mfma_f32_32x32x2_f32, LayerNorm backward in the
+// "lane = (row, column half)" layout; every dY / X pair a weight-gradient problem needs is left in global memory and the problems
+// of the layer run as ONE batched launch afterwards (dw_batch_kernel).
+__device__ __forceinline__ void load_wcols(float (&bv)[16], const float* __restrict__ W, int ldw, int k0, int n) {   // bv[j] = W[k0 + j][n]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = W[(size_t)(k0 + j) * ldw + n];
+}
+// LayerNorm backward of the lane's half row: dy = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)), dxh = dout * g
+__device__ __forceinline__ void ln_bwd_half_row(const float (&dout)[16], const float (&xh)[16], const float (&gg)[16], float rs, float (&dy)[16]) {
+    float s1 = 0.f, s2 = 0.f, dxh[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { dxh[j] = dout[j] * gg[j]; s1 += dxh[j]; s2 = __builtin_fmaf(dxh[j], xh[j], s2); }
+    s1 += __shfl_xor(s1, 32, CIRS_WAVE);
+    s2 += __shfl_xor(s2, 32, CIRS_WAVE);
+    const float m1 = s1 * (1.0f / tD), m2 = s2 * (1.0f / tD);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dy[j] = rs * (dxh[j] - m1 - xh[j] * m2);
+}
+struct LayerBwdArgs {
+    // pre stage = in_proj backward of the layer above: dh = dY1p + dQKVp * Winp (written to dHout); without it dh = dHin
+    const float *dHin, *dY1p, *dQKVp, *winp;
+    float* dHout;
+    int only_pre;                      // layer 0's in_proj backward: stop after the pre stage (positional-encoding dropout applied)
+    cirs_tracker_layer y;
+    const float *XH2, *RS2, *FF1, *XH1, *RS1;
+    float *dB2, *dFF1, *dH1N, *dY1, *dB1, *dATT;
+    const int32_t *row_env, *row_t;
+    int R, layer;
+};
+template <bool kDrop>
+__global__ __launch_bounds__(64) void layer_rows_bwd(LayerBwdArgs a, DropCfg dc) {
+    __shared__ __attribute__((aligned(16))) float sT[10 * 1024];   // 40 KB: at most one of these workgroups per SIMD (see layer_rows_fwd)
+    const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
+    const int row0 = blockIdx.x * 32, row = row0 + lo;
+    const bool row_ok = row < a.R;
+    const size_t rr = (size_t)(row_ok ? row : 0);
+    const int env = kDrop ? a.row_env[rr] : 0, pos = kDrop ? a.row_t[rr] : 0;
+    const float dinv = kDrop ? dc.inv : 1.0f;
+    sg_f32x16 acc;
+    float dh[16];
+    if (a.dQKVp) {
+        float q[3][16], res[16], bv[16];
+        ep_load(res, a.dY1p + rr * tD + 16 * hi);
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) ep_load(q[kb], a.dQKVp + rr * 96 + kb * 32 + 16 * hi);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+            load_wcols(bv, a.winp, tD, kb * 32 + 16 * hi, lo);
+            if (!row_ok) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) q[kb][j] = 0.f;
+            }
+            mm_regs(acc, q[kb], bv);
+        }
+        acc_to_lds(sT, acc, lo, hi);
+        __syncthreads();
+        float t[16];
+        ep_load(t, sT + lo * kRowT + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            dh[j] = row_ok ? res[j] + t[j] : 0.f;
+            if (kDrop && a.only_pre) dh[j] = drop_apply(dc, dh[j], env, pos, 0, CIRS_DROP_POS, 16 * hi + j);
+        }
+        if (row_ok) ep_store(a.dHout + rr * tD + 16 * hi, dh, 1.0f);
+        if (a.only_pre) return;
+        __syncthreads();
+    } else {
+        ep_load(dh, a.dHin + rr * tD + 16 * hi);
+        if (!row_ok) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dh[j] = 0.f;
+        }
+    }
+    // ---- LayerNorm2 backward -------------------------------------------------------------------------------------------------------
+    float dy2[16], db2[16];
+    {
+        float xh[16], gg[16];
+        ep_load(xh, a.XH2 + rr * tD + 16 * hi);
+        ep_load(gg, a.y.norm2_w + 16 * hi);
+        ln_bwd_half_row(dh, xh, gg, a.RS2[rr], dy2);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (!row_ok) dy2[j] = 0.f;
+            db2[j] = kDrop ? drop_apply(dc, dy2[j], env, pos, a.layer, CIRS_DROP_RES2, 16 * hi + j) : dy2[j];
+        }
+        if (row_ok) ep_store(a.dB2 + rr * tD + 16 * hi, db2, 1.0f);
+    }
+    // ---- lin2 backward: dFF1 = (dB2 W2) gated by relu (and the feed-forward dropout) ----------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = nt * 32 + lo;
+        float bv[16], ff[16];
+        load_wcols(bv, a.y.lin2_w, tH, 16 * hi, n);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = row0 + acc_row(s, hi);
+            ff[s] = r < a.R ? a.FF1[(size_t)r * tH + n] : 0.f;
+            acc[s] = 0.f;
+        }
+        mm_regs(acc, db2, bv);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = ff[s] > 0.f ? acc[s] * dinv : 0.f;
+        acc_to_lds(sT, acc, n, hi);
+    }
+    __syncthreads();
+    float f[4][16];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        ep_load(f[kb], sT + lo * kRowT + kb * 32 + 16 * hi);
+        if (row_ok) ep_store(a.dFF1 + rr * tH + kb * 32 + 16 * hi, f[kb], 1.0f);
+    }
+    // ---- lin1 backward + residual ----------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        float bv[16];
+        load_wcols(bv, a.y.lin1_w, tD, kb * 32 + 16 * hi, lo);
+        mm_regs(acc, f[kb], bv);
+    }
+    __syncthreads();
+    acc_to_lds(sT, acc, lo, hi);
+    __syncthreads();
+    float dh1n[16];
+    {
+        float t[16];
+        ep_load(t, sT + lo * kRowT + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dh1n[j] = row_ok ? dy2[j] + t[j] : 0.f;
+        if (row_ok) ep_store(a.dH1N + rr * tD + 16 * hi, dh1n, 1.0f);
+    }
+    // ---- LayerNorm1 backward -------------------------------------------------------------------------------------------------------
+    float dy1[16], db1[16];
+    {
+        float xh[16], gg[16];
+        ep_load(xh, a.XH1 + rr * tD + 16 * hi);
+        ep_load(gg, a.y.norm1_w + 16 * hi);
+        ln_bwd_half_row(dh1n, xh, gg, a.RS1[rr], dy1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (!row_ok) dy1[j] = 0.f;
+            db1[j] = kDrop ? drop_apply(dc, dy1[j], env, pos, a.layer, CIRS_DROP_RES1, 16 * hi + j) : dy1[j];
+        }
+        if (row_ok) {
+            ep_store(a.dY1 + rr * tD + 16 * hi, dy1, 1.0f);
+            if (kDrop) ep_store(a.dB1 + rr * tD + 16 * hi, db1, 1.0f);
+        }
+    }
+    // ---- out_proj backward ---------------------------------------------------------------------------------------------------------
+    {
+        float bv[16];
+        load_wcols(bv, a.y.out_proj_w, tD, 16 * hi, lo);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+        mm_regs(acc, db1, bv);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = row0 + acc_row(s, hi);
+            if (r < a.R) a.dATT[(size_t)r * tD + lo] = acc[s];
+        }
+    }
+}
+
+// every weight-gradient problem of a layer in one launch: grid = (sum of the problems' 32 x 32 output tiles, row slabs), the slab
+// partials go to each problem's own region (summed by dw_list_final at the end of the pass, like every other problem)
+constexpr int kMaxDwBatch = 8;
+struct DwBatchJob { const float* dY; int ldy; const float* X; int ldx; int O, K, tile_begin; float* partial; };
+struct DwBatch { DwBatchJob j[kMaxDwBatch]; int n, total_tiles; };
+__global__ __launch_bounds__(64) void dw_batch_kernel(DwBatch jobs, int R, int rows_per_slab) {
+    int ji = 0;
+    for (; ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].tile_begin; ++ji) {}
+    const DwBatchJob& jb = jobs.j[ji];
+    dw_gemm_body((int)blockIdx.x - jb.tile_begin, blockIdx.y, jb.dY, jb.ldy, jb.X, jb.ldx, R, jb.O, jb.K, rows_per_slab, jb.partial);
+}
+static inline void dw_batch_add(DwBatch& b, DwList& list, const float* dY, int ldy, const float* X, int ldx, int R, int O, int K, float* dW,
+                                float* db, int diag, float* partial) {
+    const int slabs = dwg_slabs(R);
+    DwListJob& lj = list.j[list.n++];
+    lj.O = O; lj.K = K; lj.part_off = list.part_floats; lj.diag = diag; lj.dW = dW; lj.db = db;
+    DwBatchJob& jb = b.j[b.n++];
+    jb.dY = dY; jb.ldy = ldy; jb.X = X; jb.ldx = ldx; jb.O = O; jb.K = K; jb.tile_begin = b.total_tiles; jb.partial = partial + lj.part_off;
+    b.total_tiles += cdiv(O, 32) * cdiv(K, 32);
+    list.part_floats += slabs * O * (K + 1);
+    list.total_out += O * (K + 1);
+}
+static inline void dw_batch_launch(const DwBatch& b, int R, hipStream_t s) {
+    if (!b.n) return;
+    const int slabs = dwg_slabs(R);
+    int rows_per_slab = (R + slabs - 1) / slabs;
+    rows_per_slab = (rows_per_slab + 15) & ~15;
+    hipLaunchKernelGGL(dw_batch_kernel, dim3(b.total_tiles, slabs), dim3(64), 0, s, b, R, rows_per_slab);
+}
+
 // LayerNorm backward, same mapping: dY = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)), dxh = dOut * g
 // LayerNorm backward + the weight / bias gradient problem of the same LayerNorm (diag(dOut^T xhat), column sums of dOut: a dw_gemm
 // problem) in ONE launch of 64-thread workgroups: the first n_ln of them are the row-wise part, the rest the dW slabs (independent of
@@ -584,7 +1046,8 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
                                                 const int32_t* __restrict__ row_env, const int32_t* __restrict__ row_t, int R, int B,
                                                 float* __restrict__ DU, float* __restrict__ EU, float* __restrict__ DPRE,
                                                 float* __restrict__ GIN, float* __restrict__ CU, float* __restrict__ CI,
-                                                int32_t* __restrict__ key_user, int32_t* __restrict__ key_item) {
+                                                int32_t* __restrict__ key_user, int32_t* __restrict__ key_item,
+                                                float* __restrict__ contrib_c /* [B, 32] per-env user contribution (merged scatter) or null */) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     // the gate matrix [32][33] once per workgroup, coalesced, into LDS: lane d then walks ITS row with stride-33 reads (no bank
@@ -608,7 +1071,10 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
         float acc = 0.f;
 #pragma unroll
         for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(lane_bcast(dx, o), w.ffn_user_w[(size_t)o * tD + d], acc);
-        if (lane < tD) { CU[(size_t)r * tD + d] = acc; CI[(size_t)r * tD + d] = 0.f; }
+        if (lane < tD) {
+            CU[(size_t)r * tD + d] = acc; CI[(size_t)r * tD + d] = 0.f;
+            if (contrib_c) contrib_c[(size_t)b * tD + d] = acc;
+        }
         if (lane == 0) { key_user[r] = u; key_item[r] = -1; }
     } else {
         const size_t ti = (size_t)(p - 1) * B + b;
@@ -672,34 +1138,44 @@ __global__ __launch_bounds__(256) void compact_user_rows(const int32_t* __restri
 //   segments   the head of a segment adds its sub-run partials in position order (every 64th position) -> g_emb[key]
 // Fixed order, no atomics; rows of keys outside the table are skipped.
 constexpr int kSubRun = 64;
+// One half-wave (lane = embedding dimension) per sub-run start.  The keys and rows of the sub-run's 64-position block are read once
+// (two per lane), the run length comes from a ballot, the row numbers travel between lanes by shuffle: every contribution row of the
+// sub-run can then be requested without waiting for a key comparison (2 dependent round trips + one per 16 rows instead of two per 8).
 __global__ __launch_bounds__(256) void emb_subrun_kernel(const uint32_t* __restrict__ ks, const int32_t* __restrict__ rs,
                                                          const float* __restrict__ contrib, int R, int n_table, float* __restrict__ part) {
-    const int d = threadIdx.x & 31;
+    const int d = threadIdx.x & 31, half = (threadIdx.x >> 5) & 1;
     const int p = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (p >= R) return;
-    const uint32_t key = ks[p];
-    if (key >= (uint32_t)n_table) return;
-    if ((p % kSubRun) != 0 && ks[p - 1] == key) return;   // neither a block start nor a segment head
+    const bool in = p < R;
+    const uint32_t key = in ? ks[p] : 0xffffffffu;
+    const bool start = in && key < (uint32_t)n_table && ((p % kSubRun) == 0 || ks[p - 1] != key);   // block start or segment head
     const int end = min(R, (p / kSubRun + 1) * kSubRun);
+    // positions p + d and p + 32 + d of the block (the ballot needs every lane of the wavefront: no early return above)
+    const int q0 = p + d, q1 = p + 32 + d;
+    const bool s0 = start && q0 < end && ks[q0] == key, s1 = start && q1 < end && ks[q1] == key;
+    const int r0 = s0 ? rs[q0] : 0, r1 = s1 ? rs[q1] : 0;
+    const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
+    if (!start) return;
+    const uint32_t h0 = (uint32_t)(m0 >> (32 * half)), h1 = (uint32_t)(m1 >> (32 * half));
+    // run length: leading positions with the same key (the sort makes them contiguous)
+    const int n = h0 == 0xffffffffu ? 32 + (h1 == 0xffffffffu ? 32 : __builtin_ctz(~h1)) : __builtin_ctz(~h0);
     float acc = 0.f;
-    for (int q = p; q < end; q += 8) {  // batches of 8 rows: loads in flight together, added in row order
-        float t8[8];
-        int n_ok = 0;
+    for (int q = 0; q < n; q += 16) {   // 16 rows in flight, added in row order
+        float t[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool ok = (n_ok == u) && (q + u < end) && ks[q + u] == key;
-            t8[u] = ok ? contrib[(size_t)rs[q + u] * tD + d] : 0.f;
-            n_ok += ok;
+        for (int u = 0; u < 16; ++u) {
+            const int qq = q + u;
+            const int row = __shfl(qq < 32 ? r0 : r1, (qq & 31) + 32 * half, CIRS_WAVE);
+            t[u] = qq < n ? contrib[(size_t)row * tD + d] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (u < n_ok) ? t8[u] : 0.f;
-        if (n_ok < 8) break;
+        for (int u = 0; u < 16; ++u) acc += (q + u < n) ? t[u] : 0.f;
     }
     part[(size_t)p * tD + d] = acc;
 }
 
 __global__ __launch_bounds__(256) void emb_segment_sum_kernel(const uint32_t* __restrict__ ks, const float* __restrict__ part, int R,
-                                                              int n_table, float* __restrict__ g_emb) {
+                                                              int n_table, float* __restrict__ g_emb, int n_first = 0x7fffffff,
+                                                              float* __restrict__ g_second = nullptr) {   // keys >= n_first: rows of g_second
     const int d = threadIdx.x & 31;
     const int p = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (p >= R) return;
@@ -720,7 +1196,8 @@ __global__ __launch_bounds__(256) void emb_segment_sum_kernel(const uint32_t* __
         for (int u = 0; u < 8; ++u) acc += (u < n_ok) ? t8[u] : 0.f;
         if (n_ok < 8) break;
     }
-    g_emb[(size_t)key * tD + d] = acc;
+    if (key < (uint32_t)n_first) g_emb[(size_t)key * tD + d] = acc;
+    else g_second[(size_t)(key - (uint32_t)n_first) * tD + d] = acc;
 }
 
 static size_t emb_sort_bytes(long R) { return (size_t)R * (64 + 4 * tD) + (1u << 20); }   // keys/rows in+out, sub-run partials, sort temp
@@ -750,12 +1227,64 @@ static int emb_scatter_sorted(const int32_t* keys, const float* contrib, int R, 
     return CIRS_OK;
 }
 
+// Both embedding tables of the tracker in ONE sort: R item pairs (key = item id) followed by one user pair per env (key = n_items +
+// user id, present when the env has rows in this call); contrib = [R + B, 32] (item rows, then the per-env user rows).  Same ordered
+// sub-run / segment sums, half the launches of two separate scatters.
+__global__ __launch_bounds__(256) void scatter_keys2_kernel(const int32_t* __restrict__ key_item, const int32_t* __restrict__ users,
+                                                            const int32_t* __restrict__ lens, int R, int B, int n_items, int n_users,
+                                                            uint32_t* __restrict__ keys_u, int32_t* __restrict__ rows) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= R + B) return;
+    const uint32_t sent = (uint32_t)n_items + (uint32_t)n_users;
+    uint32_t k = sent;
+    if (p < R) {
+        const int32_t v = key_item[p];
+        if (v >= 0 && v < n_items) k = (uint32_t)v;
+    } else {
+        const int b = p - R;
+        const int32_t u = users[b];
+        if (lens[b] > 0 && u >= 0 && u < n_users) k = (uint32_t)n_items + (uint32_t)u;
+    }
+    keys_u[p] = k;
+    rows[p] = p;
+}
+static int emb_scatter_merged(const int32_t* key_item, const int32_t* users, const int32_t* lens, const float* contrib, int R, int B,
+                              int n_items, int n_users, float* g_item, float* g_user, void* scratch, size_t scratch_bytes, hipStream_t s) {
+    const int N = R + B, n_table = n_items + n_users;
+    uint32_t* k_in = (uint32_t*)scratch;
+    uint32_t* k_out = k_in + N;
+    int32_t* r_in = (int32_t*)(k_out + N);
+    int32_t* r_out = r_in + N;
+    float* part = (float*)(((uintptr_t)(r_out + N) + 255) & ~(uintptr_t)255);
+    char* temp = (char*)(((uintptr_t)(part + (size_t)N * tD) + 255) & ~(uintptr_t)255);
+    const size_t avail = scratch_bytes - (size_t)(temp - (char*)scratch);
+    int end_bit = 1;
+    while ((1u << end_bit) <= (uint32_t)n_table && end_bit < 32) ++end_bit;
+    size_t need = 0;
+    CIRS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, r_in, r_out, N, 0, end_bit, s));
+    CIRS_REQUIRE(need <= avail, "embedding scatter: sort scratch too small");
+    if (g_user + (size_t)n_users * tD == g_item) {
+        CIRS_HIP(hipMemsetAsync(g_user, 0, (size_t)n_table * tD * sizeof(float), s));
+    } else if (g_item + (size_t)n_items * tD == g_user) {
+        CIRS_HIP(hipMemsetAsync(g_item, 0, (size_t)n_table * tD * sizeof(float), s));
+    } else {
+        CIRS_HIP(hipMemsetAsync(g_item, 0, (size_t)n_items * tD * sizeof(float), s));
+        CIRS_HIP(hipMemsetAsync(g_user, 0, (size_t)n_users * tD * sizeof(float), s));
+    }
+    hipLaunchKernelGGL(scatter_keys2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, key_item, users, lens, R, B, n_items, n_users, k_in, r_in);
+    CIRS_HIP(hipcub::DeviceRadixSort::SortPairs(temp, need, k_in, k_out, r_in, r_out, N, 0, end_bit, s));
+    hipLaunchKernelGGL(emb_subrun_kernel, dim3(cdiv(N, 8)), dim3(256), 0, s, k_out, r_out, contrib, N, n_table, part);
+    hipLaunchKernelGGL(emb_segment_sum_kernel, dim3(cdiv(N, 8)), dim3(256), 0, s, k_out, (const float*)part, N, n_table, g_item, n_items, g_user);
+    CIRS_CHECK_LAUNCH("emb_segment_sum_kernel (merged)");
+    return CIRS_OK;
+}
+
 struct BwdScratch {
     float *G, *H[CIRS_MAX_TRACKER_LAYERS + 1];
     float *QKV[CIRS_MAX_TRACKER_LAYERS], *P[CIRS_MAX_TRACKER_LAYERS], *ATT[CIRS_MAX_TRACKER_LAYERS];
     float *XH1[CIRS_MAX_TRACKER_LAYERS], *RS1[CIRS_MAX_TRACKER_LAYERS], *H1N[CIRS_MAX_TRACKER_LAYERS], *FF1[CIRS_MAX_TRACKER_LAYERS];
     float *XH2[CIRS_MAX_TRACKER_LAYERS], *RS2[CIRS_MAX_TRACKER_LAYERS];
-    float *T0, *T1, *T2, *T3, *dQKV, *dFF1, *dS, *partial, *GIN;
+    float *T0, *T1, *T2, *T3, *T4, *T5, *dQKV, *dFF1, *dS, *partial, *GIN;
     float* PM[CIRS_MAX_TRACKER_LAYERS];   // dropout: attention probabilities after the mask
     void* sort;  // emb_sort_bytes(R)
 };
@@ -773,11 +1302,11 @@ static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     f += (size_t)R * 32;                          // G (S <= 32)
     f += (size_t)(nl + 1) * R * tD;               // H
     f += (size_t)nl * R * (96 + NH * Lp + tD + tD + 1 + tD + tH + tD + 1);
-    f += 4 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp;  // T0..3, dQKV, dFF1, dS
+    f += 6 * (size_t)R * tD + (size_t)R * 96 + (size_t)R * tH + (size_t)R * NH * Lp + 64;  // T0..5, dQKV, dFF1, dS
     if (cfg->dropout_p > 0.f) f += (size_t)nl * R * NH * Lp + 64;                      // PM
     f += bwd_partial_floats(cfg, R) + 4096;       // slab partials of every dW problem of the pass (one final launch)
     f += (size_t)R * (tD + 1);                    // GIN
-    f += emb_sort_bytes(R) / 4 + 64;              // (key, row) sort of the embedding scatter
+    f += emb_sort_bytes(R + cfg->n_env) / 4 + 64;  // (key, row) sort of the embedding scatter (item rows + one user pair per env)
     return f + 64 * 32;
 }
 
@@ -794,11 +1323,12 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
         s.XH2[l] = take((size_t)R * tD); s.RS2[l] = take(R);
     }
     s.T0 = take((size_t)R * tD); s.T1 = take((size_t)R * tD); s.T2 = take((size_t)R * tD); s.T3 = take((size_t)R * tD);
+    s.T4 = take((size_t)R * tD); s.T5 = take((size_t)R * tD);
     for (int l = 0; l < nl; ++l) s.PM[l] = cfg->dropout_p > 0.f ? take((size_t)R * NH * Lp) : nullptr;
     s.dQKV = take((size_t)R * 96); s.dFF1 = take((size_t)R * tH); s.dS = take((size_t)R * NH * Lp);
     s.partial = take(bwd_partial_floats(cfg, R) + 4096);
     s.GIN = take((size_t)R * (tD + 1));
-    s.sort = (void*)take(emb_sort_bytes(R) / 4 + 64);
+    s.sort = (void*)take(emb_sort_bytes(R + cfg->n_env) / 4 + 64);
     return s;
 }
 
@@ -819,6 +1349,12 @@ static inline void launch_ln_bwd_dw(DwList& list, const float* dOut, const float
     hipLaunchKernelGGL(ln_bwd_dw_kernel, dim3(n_ln + slabs), dim3(64), 0, s, dOut, xhat, rstd, g, R, dY, n_ln, da, 1);
 }
 }  // namespace cirs
+
+#ifdef CIRS_TBWD_PROF
+extern "C" int cirs_debug_tbwd_prof(unsigned long long* out_host64) {
+    return hipMemcpyFromSymbol(out_host64, HIP_SYMBOL(cirs::g_tbwd_prof), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int64_t cirs_tracker_backward_workspace_bytes(const cirs_tracker_cfg* cfg, int32_t n_rows) {
     if (!cfg || n_rows <= 0) return 0;
@@ -885,12 +1421,31 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         dc.seed = cfg->dropout_seed; dc.env_base = cfg->drop_env_base;
     }
     // ---------------- forward recompute ----------------
-    hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0], dc);
+    // fused row chains (embed + in_proj; out_proj .. LayerNorm2 + the next in_proj) unless CIRS_TRACKER_ROWS_UNFUSED asks for the
+    // per-op launches (kept for A/B runs and for alignment-free inputs)
+    const bool fused_rows = !getenv("CIRS_TRACKER_ROWS_UNFUSED");
+    if (fused_rows) {
+        const dim3 gt(cdiv(R, 32));
+        if (dc.on) hipLaunchKernelGGL(embed_inproj<true>, gt, dim3(64), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, w->layer[0].in_proj_w,
+                                      w->layer[0].in_proj_b, sc.H[0], sc.QKV[0], dc);
+        else hipLaunchKernelGGL(embed_inproj<false>, gt, dim3(64), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, w->layer[0].in_proj_w,
+                                w->layer[0].in_proj_b, sc.H[0], sc.QKV[0], dc);
+    } else {
+        hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0], dc);
+    }
     for (int l = 0; l < nl; ++l) {
         const cirs_tracker_layer& y = w->layer[l];
-        launch_rows_gemm(true, sc.H[l], tD, y.in_proj_w, tD, y.in_proj_b, R, tD, 96, 0, nullptr, 0, sc.QKV[l], 96, s);
+        if (!fused_rows) launch_rows_gemm(true, sc.H[l], tD, y.in_proj_w, tD, y.in_proj_b, R, tD, 96, 0, nullptr, 0, sc.QKV[l], 96, s);
         if (ep) ATT_EP(attn_fwd_ep, false, (const float*)sc.QKV[l], offsets, lens, L, sc.ATT[l], dc, l);
         else ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l], dc, l, sc.PM[l]);
+        if (fused_rows) {
+            LayerFwdArgs fa{sc.ATT[l], sc.H[l], y, l + 1 < nl ? w->layer[l + 1].in_proj_w : nullptr, l + 1 < nl ? w->layer[l + 1].in_proj_b : nullptr,
+                            sc.XH1[l], sc.RS1[l], sc.H1N[l], sc.FF1[l], sc.XH2[l], sc.RS2[l], sc.H[l + 1], l + 1 < nl ? sc.QKV[l + 1] : nullptr,
+                            row_env, row_t, R, l};
+            if (dc.on) hipLaunchKernelGGL(layer_rows_fwd<true>, dim3(cdiv(R, 32)), dim3(64), 0, s, fa, dc);
+            else hipLaunchKernelGGL(layer_rows_fwd<false>, dim3(cdiv(R, 32)), dim3(64), 0, s, fa, dc);
+            continue;
+        }
         launch_rows_gemm(true, sc.ATT[l], tD, y.out_proj_w, tD, y.out_proj_b, R, tD, tD, 0, nullptr, 0, sc.T0, tD, s);
         hipLaunchKernelGGL(ln_fwd, g1((long)R * tD), dim3(256), 0, s, sc.H[l], sc.T0, y.norm1_w, y.norm1_b, R, sc.XH1[l], sc.RS1[l], sc.H1N[l],
                            dc, row_env, row_t, l, (int)CIRS_DROP_RES1);
@@ -908,7 +1463,42 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     // (each weight-gradient problem rides in the launch of the row GEMM that consumes the same dY: DW_ROWS)
 #define DW_ROWS(X2, O, K, dWp, dbp, ...) launch_rows_gemm_dw(dwl, X2, K, O, K, dWp, dbp, sc.partial, __VA_ARGS__, s)
     DW_ROWS(sc.H[nl], S, tD, grads->dec_w, grads->dec_b, false, sc.G, S, w->dec_w, tD, nullptr, R, S, tD, 0, nullptr, 0, dH, tD);
-    for (int l = nl - 1; l >= 0; --l) {
+    for (int l = nl - 1; l >= 0 && fused_rows; --l) {
+        // fused row chain (layer_rows_bwd) + one batched launch of the layer's weight-gradient problems + the attention backward
+        const cirs_tracker_layer& y = w->layer[l];
+        const cirs_tracker_layer_grads& gy = grads->layer[l];
+        const bool pre = l + 1 < nl;     // the in_proj backward of the layer above opens this layer's chain
+        float* dB1 = dc.on ? sc.T4 : sc.T2;
+        LayerBwdArgs ba{sc.T0, pre ? sc.T2 : nullptr, pre ? sc.dQKV : nullptr, pre ? w->layer[l + 1].in_proj_w : nullptr, sc.T0, 0, y,
+                        sc.XH2[l], sc.RS2[l], sc.FF1[l], sc.XH1[l], sc.RS1[l], sc.T3, sc.dFF1, sc.T1, sc.T2, dB1, sc.T5, row_env, row_t, R, l};
+        if (dc.on) hipLaunchKernelGGL(layer_rows_bwd<true>, dim3(cdiv(R, 32)), dim3(64), 0, s, ba, dc);
+        else hipLaunchKernelGGL(layer_rows_bwd<false>, dim3(cdiv(R, 32)), dim3(64), 0, s, ba, dc);
+        DwBatch bt{};
+        if (pre) dw_batch_add(bt, dwl, sc.dQKV, 96, sc.H[l + 1], tD, R, 96, tD, grads->layer[l + 1].in_proj_w, grads->layer[l + 1].in_proj_b, 0, sc.partial);
+        dw_batch_add(bt, dwl, sc.T0, tD, sc.XH2[l], tD, R, tD, tD, gy.norm2_w, gy.norm2_b, 1, sc.partial);       // diag(dH^T Xhat2), column sums
+        dw_batch_add(bt, dwl, sc.T3, tD, sc.FF1[l], tH, R, tD, tH, gy.lin2_w, gy.lin2_b, 0, sc.partial);
+        dw_batch_add(bt, dwl, sc.dFF1, tH, sc.H1N[l], tD, R, tH, tD, gy.lin1_w, gy.lin1_b, 0, sc.partial);
+        dw_batch_add(bt, dwl, sc.T1, tD, sc.XH1[l], tD, R, tD, tD, gy.norm1_w, gy.norm1_b, 1, sc.partial);
+        dw_batch_add(bt, dwl, dB1, tD, sc.ATT[l], tD, R, tD, tD, gy.out_proj_w, gy.out_proj_b, 0, sc.partial);
+        dw_batch_launch(bt, R, s);
+        const float* dATT = sc.T5;
+        if (ep) {
+            ATT_EP(attn_bwd_ep, true, (const float*)sc.QKV[l], dATT, offsets, lens, L, sc.dQKV, dc, l);
+        } else {
+            ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV,
+                            (const float*)sc.PM[l], dc.inv);
+            ATT_DISPATCH(attn_bwd_kv, sc.QKV[l], dc.on ? sc.PM[l] : sc.P[l], sc.dS, dATT, row_env, row_t, offsets, lens, R, L, sc.dQKV);
+        }
+    }
+    if (fused_rows) {   // layer 0's in_proj backward (+ the positional-encoding dropout): the pre stage alone; its dW problem joins the slot problems below
+        LayerBwdArgs ba{};
+        ba.dY1p = sc.T2; ba.dQKVp = sc.dQKV; ba.winp = w->layer[0].in_proj_w; ba.dHout = sc.T0; ba.only_pre = 1;
+        ba.row_env = row_env; ba.row_t = row_t; ba.R = R;
+        if (dc.on) hipLaunchKernelGGL(layer_rows_bwd<true>, dim3(cdiv(R, 32)), dim3(64), 0, s, ba, dc);
+        else hipLaunchKernelGGL(layer_rows_bwd<false>, dim3(cdiv(R, 32)), dim3(64), 0, s, ba, dc);
+        dH = sc.T0;
+    }
+    for (int l = nl - 1; l >= 0 && !fused_rows; --l) {
         const cirs_tracker_layer& y = w->layer[l];
         const cirs_tracker_layer_grads& gy = grads->layer[l];
         // LN2
@@ -954,18 +1544,23 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         }
     }
     CIRS_CHECK_LAUNCH("tracker backward layers");
-    if (dc.on)   // gradient through the PositionalEncoding dropout
+    if (dc.on && !fused_rows)   // gradient through the PositionalEncoding dropout
         hipLaunchKernelGGL(drop_rows, g1((long)R * tD), dim3(256), 0, s, dc, (const float*)dH, row_env, row_t, R, tD, 0, (int)CIRS_DROP_POS, dH);
     // input slots + embeddings (forward activations are no longer needed: reuse their scratch)
     float* DU = sc.T1;
     float* EU = sc.H[nl];
-    float* DPRE = sc.H[0];
+    float* DPRE = fused_rows ? sc.H1N[0] : sc.H[0];   // (fused: H[0] is still an operand of layer 0's in_proj weight-gradient problem)
     float* CU = sc.QKV[0];                 // [R,32] per-row contribution to Emb_user
     float* CI = sc.QKV[0] + (size_t)R * tD; // [R,32] per-row contribution to Emb_item  (QKV is [R,96])
     int32_t* key_user = (int32_t*)sc.RS1[0];
     int32_t* key_item = (int32_t*)sc.RS2[0];
+    const bool merged = fused_rows && B <= R;      // one sort for both tables: the per-env user rows sit behind the item rows (third part of QKV[0])
     hipLaunchKernelGGL(slot_bwd, dim3(cdiv(R, 4)), dim3(256), 0, s, *w, dH, users, act, rew, row_env, row_t, R, B, DU, EU, DPRE,
-                       sc.GIN, CU, CI, key_user, key_item);
+                       sc.GIN, CU, CI, key_user, key_item, merged ? CI + (size_t)R * tD : nullptr);
+    if (merged) {
+        if (int rc = emb_scatter_merged(key_item, users, lens, CI, R, B, cfg->n_items, cfg->n_users, grads->emb_item, grads->emb_user, sc.sort,
+                                        emb_sort_bytes(R + B), s)) return rc;
+    } else {
     {   // user embeddings: one pair per env (T0 and T2 = [R, 32] each, R >= B, are free after slot_bwd)
         int32_t* keys_c = (int32_t*)sc.T0;
         float* contrib_c = sc.T2;
@@ -974,8 +1569,17 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
         if (int rc = emb_scatter_sorted(keys_c, contrib_c, B, cfg->n_users, grads->emb_user, sc.sort, emb_sort_bytes(R), s)) return rc;
     }
     if (int rc = emb_scatter_sorted(key_item, CI, R, cfg->n_items, grads->emb_item, sc.sort, emb_sort_bytes(R), s)) return rc;
-    DW(DU, EU, tD, tD, grads->ffn_user_w, grads->ffn_user_b);
-    DW(DPRE, sc.GIN, tD, tD + 1, grads->gate_w, grads->gate_b);
+    }
+    if (fused_rows) {
+        DwBatch bt{};
+        dw_batch_add(bt, dwl, sc.dQKV, 96, sc.H[0], tD, R, 96, tD, grads->layer[0].in_proj_w, grads->layer[0].in_proj_b, 0, sc.partial);
+        dw_batch_add(bt, dwl, DU, tD, EU, tD, R, tD, tD, grads->ffn_user_w, grads->ffn_user_b, 0, sc.partial);
+        dw_batch_add(bt, dwl, DPRE, tD, sc.GIN, tD + 1, R, tD, tD + 1, grads->gate_w, grads->gate_b, 0, sc.partial);
+        dw_batch_launch(bt, R, s);
+    } else {
+        DW(DU, EU, tD, tD, grads->ffn_user_w, grads->ffn_user_b);
+        DW(DPRE, sc.GIN, tD, tD + 1, grads->gate_w, grads->gate_b);
+    }
     launch_dw_list_final(dwl, R, sc.partial, s);   // every weight / bias gradient of the pass: slab sums in one launch
     CIRS_CHECK_LAUNCH("tracker backward slots");
 #undef DW

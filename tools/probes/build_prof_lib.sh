@@ -7,6 +7,7 @@ for f in cirs-codes_amd/csrc/*.hip; do
   b=$(basename $f .hip)
   if [ "$b" = "tracker" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -DCIRS_TRK_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
   elif [ "$b" = "ppo" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -DCIRS_HEAD_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
+  elif [ "$b" = "tracker_bwd" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -DCIRS_TBWD_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
   elif [ "$b" = "rollout" ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -DCIRS_MASS_PROF ${CIRS_PROF_FLAGS} -c $f -o $OUT/$b.o;
   else cp cirs-codes_amd/csrc/_obj/$b.o $OUT/$b.o; fi
 done
