@@ -293,36 +293,57 @@ static inline void launch_rows_gemm_dw(DwList& list, const float* dwX, int dw_ld
     else hipLaunchKernelGGL(rows_gemm_dw_kernel<false>, dim3(rgx * rgy + tiles * slabs), dim3(64), 0, s, ra, rgx, rgy, da, tiles);
 }
 
+// 8 lanes per output element: lane q of the group adds slabs q*ceil(n/8) .. in slab order, the eight partial sums are then added in lane
+// order (fixed shape: deterministic); one thread per element left 100 workgroups walking 256 slabs each (17 us for 25 MB)
 static __global__ __launch_bounds__(256) void dw_list_final(DwList list, int n_slabs, const float* __restrict__ partial) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= list.total_out) return;
-    int ji = 0;
-    for (; ji < list.n; ++ji) {
-        const int n_out = list.j[ji].O * (list.j[ji].K + 1);
-        if (i < n_out) break;
-        i -= n_out;
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, q = threadIdx.x & 7;
+    int i = g;
+    const bool live = i < list.total_out;
+    if (!live) i = 0;
+    // the element's problem: a compile-time walk over the by-value list (a per-thread index would send the whole array through scratch)
+    int O = 1, K = 0, part_off = 0, diag = 0;
+    float* dW = nullptr;
+    float* db = nullptr;
+    bool found = false;
+#pragma unroll
+    for (int ji = 0; ji < kMaxDwList; ++ji) {
+        if (ji < list.n && !found) {
+            const int n_out_j = list.j[ji].O * (list.j[ji].K + 1);
+            if (i < n_out_j) {
+                O = list.j[ji].O; K = list.j[ji].K; part_off = list.j[ji].part_off; diag = list.j[ji].diag; dW = list.j[ji].dW; db = list.j[ji].db;
+                found = true;
+            } else {
+                i -= n_out_j;
+            }
+        }
     }
-    const DwListJob jb = list.j[ji];
-    const int n_out = jb.O * (jb.K + 1);
+    const int n_out = O * (K + 1);
+    const int per = (n_slabs + 7) >> 3;
+    const int c_beg = q * per, c_end = min(n_slabs, c_beg + per);
     float acc = 0.f;
-    for (int c0 = 0; c0 < n_slabs; c0 += 16) {  // 16 loads in flight, added in slab order
+    for (int c0 = c_beg; c0 < c_end; c0 += 16) {  // 16 loads in flight, added in slab order
         float t16[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t16[q] = (c0 + q < n_slabs) ? partial[jb.part_off + (size_t)(c0 + q) * n_out + i] : 0.f;
+        for (int u = 0; u < 16; ++u) t16[u] = (c0 + u < c_end) ? partial[part_off + (size_t)(c0 + u) * n_out + i] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc += t16[q];
+        for (int u = 0; u < 16; ++u) acc += t16[u];
     }
-    const int o = i / (jb.K + 1), k = i % (jb.K + 1);
-    if (k < jb.K) {
-        if (!jb.diag) jb.dW[(size_t)o * jb.K + k] = acc;
-        else if (o == k) jb.dW[o] = acc;
-    } else if (jb.db) {
-        jb.db[o] = acc;
+    // the group's eight partial sums in lane order
+    float tot = __shfl(acc, (threadIdx.x & 63) & 56, CIRS_WAVE);
+#pragma unroll
+    for (int u = 1; u < 8; ++u) tot += __shfl(acc, ((threadIdx.x & 63) & 56) | u, CIRS_WAVE);
+    if (!live || q != 0) return;
+    const int o = i / (K + 1), k = i % (K + 1);
+    if (k < K) {
+        if (!diag) dW[(size_t)o * K + k] = tot;
+        else if (o == k) dW[o] = tot;
+    } else if (db) {
+        db[o] = tot;
     }
 }
 
 static inline void launch_dw_list_final(const DwList& list, int R, const float* partial, hipStream_t s) {
-    hipLaunchKernelGGL(dw_list_final, dim3(cdiv(list.total_out, 256)), dim3(256), 0, s, list, dwg_slabs(R), partial);
+    hipLaunchKernelGGL(dw_list_final, dim3(cdiv(list.total_out * 8, 256)), dim3(256), 0, s, list, dwg_slabs(R), partial);
 }
 
 // slab-partial floats of one problem (for workspace sizing)

@@ -20,8 +20,13 @@ constexpr int tD = 32, tH = 128;
 // stage timestamps of one mid-grid workgroup (probe builds only: tools/probes/tbwd_prof.py)
 __device__ unsigned long long g_tbwd_prof[64];
 #define CIRS_BSTAMP(K) do { if ((int)blockIdx.x == 300 && threadIdx.x == 0) g_tbwd_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+// entry / exit time and hardware id of EVERY workgroup of one launch (SEL selects the launch)
+__device__ unsigned long long g_tbwd_wg[2048 * 3];
+#define CIRS_BWG(SEL, WHICH) do { if ((SEL) && threadIdx.x == 0 && blockIdx.x < 2048) { g_tbwd_wg[blockIdx.x * 3 + (WHICH)] = __builtin_amdgcn_s_memtime(); \
+    if ((WHICH) == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_tbwd_wg[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hw; } } } while (0)
 #else
 #define CIRS_BSTAMP(K) do { } while (0)
+#define CIRS_BWG(SEL, WHICH) do { } while (0)
 #endif
 constexpr int kChunkRows = 256;
 
@@ -599,6 +604,7 @@ __global__ __launch_bounds__(64) void layer_rows_fwd(LayerFwdArgs a, DropCfg dc)
     // otherwise stacks up to nine on a CU while other CUs idle, and the slowest CU is the kernel)
     __shared__ __attribute__((aligned(16))) float sT[10 * 1024];
     CIRS_BSTAMP(0);
+    CIRS_BWG(a.layer == 1, 0);
     const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
     const int row0 = blockIdx.x * 32, row = row0 + lo;
     const bool row_ok = row < a.R;
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(64) void layer_rows_fwd(LayerFwdArgs a, DropCfg dc)
     }
     __syncthreads();
     CIRS_BSTAMP(5);
-    // ---- lin1 + relu (+ dropout): 4 column tiles; FF1 to global (accumulator layout: 128-byte row pieces) and to LDS for lin2 ------
+    // ---- lin1 + relu: 4 column tiles into LDS; FF1 (after the dropout) goes to global from the row layout lin2 reads it in ------------
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = nt * 32 + lo;
@@ -666,13 +672,7 @@ __global__ __launch_bounds__(64) void layer_rows_fwd(LayerFwdArgs a, DropCfg dc)
         for (int s = 0; s < 16; ++s) acc[s] = bl1[nt];
         mm_regs(acc, h1n, w1[nt]);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int r = row0 + acc_row(s, hi);
-            float v = fmaxf(acc[s], 0.f);
-            if (kDrop && r < a.R) v = drop_apply(dc, v, a.row_env[r], a.row_t[r], a.layer, CIRS_DROP_FF, n);
-            acc[s] = v;
-            if (r < a.R) a.FF1[(size_t)r * tH + n] = v;
-        }
+        for (int s = 0; s < 16; ++s) acc[s] = fmaxf(acc[s], 0.f);
         acc_to_lds(sT, acc, n, hi);
     }
     __syncthreads();
@@ -694,10 +694,12 @@ __global__ __launch_bounds__(64) void layer_rows_fwd(LayerFwdArgs a, DropCfg dc)
     for (int kb = 0; kb < 4; ++kb) {
         float f[16];
         ep_load(f, sT + lo * kRowT + kb * 32 + 16 * hi);
-        if (!row_ok) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) f[j] = 0.f;
+        for (int j = 0; j < 16; ++j) {      // the feed-forward dropout in the row layout (lane = row: one (env, position) per lane)
+            if (kDrop) f[j] = drop_apply(dc, f[j], env, pos, a.layer, CIRS_DROP_FF, kb * 32 + 16 * hi + j);
+            if (!row_ok) f[j] = 0.f;
         }
+        if (row_ok) ep_store(a.FF1 + rr * tH + kb * 32 + 16 * hi, f, 1.0f);     // 16 b128 stores per lane instead of 64 dword stores
         mm_regs(acc, f, w2[kb]);
     }
     CIRS_BSTAMP(7);
@@ -744,6 +746,7 @@ __global__ __launch_bounds__(64) void layer_rows_fwd(LayerFwdArgs a, DropCfg dc)
         }
     }
     CIRS_BSTAMP(11);
+    CIRS_BWG(a.layer == 1, 1);
 }
 
 // slot gather + scale + positional encoding (embed_rows) + the first layer's in_proj, one wavefront per 32 rows
@@ -815,9 +818,14 @@ struct LayerBwdArgs {
     const int32_t *row_env, *row_t;
     int R, layer;
 };
+template <int LDW> __device__ __forceinline__ void load_wcols_c(float (&bv)[16], const float* __restrict__ W, int k0, int n) {   // bv[j] = W[k0 + j][n]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bv[j] = W[(k0 + j) * LDW + n];
+}
 template <bool kDrop>
 __global__ __launch_bounds__(64) void layer_rows_bwd(LayerBwdArgs a, DropCfg dc) {
     __shared__ __attribute__((aligned(16))) float sT[10 * 1024];   // 40 KB: at most one of these workgroups per SIMD (see layer_rows_fwd)
+    CIRS_BSTAMP(20);
     const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
     const int row0 = blockIdx.x * 32, row = row0 + lo;
     const bool row_ok = row < a.R;
@@ -827,20 +835,22 @@ __global__ __launch_bounds__(64) void layer_rows_bwd(LayerBwdArgs a, DropCfg dc)
     sg_f32x16 acc;
     float dh[16];
     if (a.dQKVp) {
-        float q[3][16], res[16], bv[16];
+        float q[3][16], res[16], bv[3][16];
         ep_load(res, a.dY1p + rr * tD + 16 * hi);
 #pragma unroll
-        for (int kb = 0; kb < 3; ++kb) ep_load(q[kb], a.dQKVp + rr * 96 + kb * 32 + 16 * hi);
+        for (int kb = 0; kb < 3; ++kb) {
+            ep_load(q[kb], a.dQKVp + rr * 96 + kb * 32 + 16 * hi);
+            load_wcols_c<tD>(bv[kb], a.winp, kb * 32 + 16 * hi, lo);
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc[s] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb) {
-            load_wcols(bv, a.winp, tD, kb * 32 + 16 * hi, lo);
             if (!row_ok) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) q[kb][j] = 0.f;
             }
-            mm_regs(acc, q[kb], bv);
+            mm_regs(acc, q[kb], bv[kb]);
         }
         acc_to_lds(sT, acc, lo, hi);
         __syncthreads();
@@ -861,56 +871,60 @@ __global__ __launch_bounds__(64) void layer_rows_bwd(LayerBwdArgs a, DropCfg dc)
             for (int j = 0; j < 16; ++j) dh[j] = 0.f;
         }
     }
+    CIRS_BSTAMP(21);
+    // ---- requests: everything the LayerNorms and the lin2 stage read (unconditional loads from a clamped row: they batch) -------------
+    float xh2[16], g2[16], xh1[16], g1[16], w2[4][16], ffr[4][16];
+    ep_load(xh2, a.XH2 + rr * tD + 16 * hi);
+    ep_load(g2, a.y.norm2_w + 16 * hi);
+    const float rs2 = a.RS2[rr], rs1 = a.RS1[rr];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) load_wcols_c<tH>(w2[nt], a.y.lin2_w, 16 * hi, nt * 32 + lo);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ep_load(ffr[kb], a.FF1 + rr * tH + kb * 32 + 16 * hi);    // the relu / dropout gate, row layout
+    ep_load(xh1, a.XH1 + rr * tD + 16 * hi);
+    ep_load(g1, a.y.norm1_w + 16 * hi);
     // ---- LayerNorm2 backward -------------------------------------------------------------------------------------------------------
     float dy2[16], db2[16];
-    {
-        float xh[16], gg[16];
-        ep_load(xh, a.XH2 + rr * tD + 16 * hi);
-        ep_load(gg, a.y.norm2_w + 16 * hi);
-        ln_bwd_half_row(dh, xh, gg, a.RS2[rr], dy2);
+    ln_bwd_half_row(dh, xh2, g2, rs2, dy2);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (!row_ok) dy2[j] = 0.f;
-            db2[j] = kDrop ? drop_apply(dc, dy2[j], env, pos, a.layer, CIRS_DROP_RES2, 16 * hi + j) : dy2[j];
-        }
-        if (row_ok) ep_store(a.dB2 + rr * tD + 16 * hi, db2, 1.0f);
+    for (int j = 0; j < 16; ++j) {
+        if (!row_ok) dy2[j] = 0.f;
+        db2[j] = kDrop ? drop_apply(dc, dy2[j], env, pos, a.layer, CIRS_DROP_RES2, 16 * hi + j) : dy2[j];
     }
-    // ---- lin2 backward: dFF1 = (dB2 W2) gated by relu (and the feed-forward dropout) ----------------------------------------------------
+    if (row_ok) ep_store(a.dB2 + rr * tD + 16 * hi, db2, 1.0f);
+    CIRS_BSTAMP(22);
+    // ---- lin2 backward: dB2 W2 into LDS (4 column tiles), gated by relu / the feed-forward dropout in the row layout -----------------------
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int n = nt * 32 + lo;
-        float bv[16], ff[16];
-        load_wcols(bv, a.y.lin2_w, tH, 16 * hi, n);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int r = row0 + acc_row(s, hi);
-            ff[s] = r < a.R ? a.FF1[(size_t)r * tH + n] : 0.f;
-            acc[s] = 0.f;
-        }
-        mm_regs(acc, db2, bv);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc[s] = ff[s] > 0.f ? acc[s] * dinv : 0.f;
-        acc_to_lds(sT, acc, n, hi);
+        for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+        mm_regs(acc, db2, w2[nt]);
+        acc_to_lds(sT, acc, nt * 32 + lo, hi);
     }
+    float w1[4][16], wo[16];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) load_wcols_c<tD>(w1[kb], a.y.lin1_w, kb * 32 + 16 * hi, lo);
+    load_wcols_c<tD>(wo, a.y.out_proj_w, 16 * hi, lo);
     __syncthreads();
+    CIRS_BSTAMP(23);
     float f[4][16];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         ep_load(f[kb], sT + lo * kRowT + kb * 32 + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[kb][j] = (row_ok && ffr[kb][j] > 0.f) ? f[kb][j] * dinv : 0.f;
         if (row_ok) ep_store(a.dFF1 + rr * tH + kb * 32 + 16 * hi, f[kb], 1.0f);
     }
+    CIRS_BSTAMP(24);
     // ---- lin1 backward + residual ----------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        float bv[16];
-        load_wcols(bv, a.y.lin1_w, tD, kb * 32 + 16 * hi, lo);
-        mm_regs(acc, f[kb], bv);
-    }
+    for (int kb = 0; kb < 4; ++kb) mm_regs(acc, f[kb], w1[kb]);
     __syncthreads();
     acc_to_lds(sT, acc, lo, hi);
     __syncthreads();
+    CIRS_BSTAMP(25);
     float dh1n[16];
     {
         float t[16];
@@ -919,36 +933,33 @@ __global__ __launch_bounds__(64) void layer_rows_bwd(LayerBwdArgs a, DropCfg dc)
         for (int j = 0; j < 16; ++j) dh1n[j] = row_ok ? dy2[j] + t[j] : 0.f;
         if (row_ok) ep_store(a.dH1N + rr * tD + 16 * hi, dh1n, 1.0f);
     }
+    CIRS_BSTAMP(26);
     // ---- LayerNorm1 backward -------------------------------------------------------------------------------------------------------
     float dy1[16], db1[16];
-    {
-        float xh[16], gg[16];
-        ep_load(xh, a.XH1 + rr * tD + 16 * hi);
-        ep_load(gg, a.y.norm1_w + 16 * hi);
-        ln_bwd_half_row(dh1n, xh, gg, a.RS1[rr], dy1);
+    ln_bwd_half_row(dh1n, xh1, g1, rs1, dy1);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (!row_ok) dy1[j] = 0.f;
-            db1[j] = kDrop ? drop_apply(dc, dy1[j], env, pos, a.layer, CIRS_DROP_RES1, 16 * hi + j) : dy1[j];
-        }
-        if (row_ok) {
-            ep_store(a.dY1 + rr * tD + 16 * hi, dy1, 1.0f);
-            if (kDrop) ep_store(a.dB1 + rr * tD + 16 * hi, db1, 1.0f);
-        }
+    for (int j = 0; j < 16; ++j) {
+        if (!row_ok) dy1[j] = 0.f;
+        db1[j] = kDrop ? drop_apply(dc, dy1[j], env, pos, a.layer, CIRS_DROP_RES1, 16 * hi + j) : dy1[j];
     }
-    // ---- out_proj backward ---------------------------------------------------------------------------------------------------------
-    {
-        float bv[16];
-        load_wcols(bv, a.y.out_proj_w, tD, 16 * hi, lo);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc[s] = 0.f;
-        mm_regs(acc, db1, bv);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int r = row0 + acc_row(s, hi);
-            if (r < a.R) a.dATT[(size_t)r * tD + lo] = acc[s];
-        }
+    if (row_ok) {
+        ep_store(a.dY1 + rr * tD + 16 * hi, dy1, 1.0f);
+        if (kDrop) ep_store(a.dB1 + rr * tD + 16 * hi, db1, 1.0f);
     }
+    CIRS_BSTAMP(27);
+    // ---- out_proj backward (dATT leaves in the row layout, through LDS) -------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.f;
+    mm_regs(acc, db1, wo);
+    __syncthreads();
+    acc_to_lds(sT, acc, lo, hi);
+    __syncthreads();
+    {
+        float t[16];
+        ep_load(t, sT + lo * kRowT + 16 * hi);
+        if (row_ok) ep_store(a.dATT + rr * tD + 16 * hi, t, 1.0f);
+    }
+    CIRS_BSTAMP(28);
 }
 
 // every weight-gradient problem of a layer in one launch: grid = (sum of the problems' 32 x 32 output tiles, row slabs), the slab
@@ -1351,6 +1362,9 @@ static inline void launch_ln_bwd_dw(DwList& list, const float* dOut, const float
 }  // namespace cirs
 
 #ifdef CIRS_TBWD_PROF
+extern "C" int cirs_debug_tbwd_wg(unsigned long long* out_host) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(cirs::g_tbwd_wg), 2048 * 3 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
 extern "C" int cirs_debug_tbwd_prof(unsigned long long* out_host64) {
     return hipMemcpyFromSymbol(out_host64, HIP_SYMBOL(cirs::g_tbwd_prof), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }

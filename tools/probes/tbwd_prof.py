@@ -26,9 +26,14 @@ for rep in range(8):
     if rep >= 2:
         acc = t if acc is None else acc + t
 t = acc / 6
-names = {k: v for k, v in enumerate(sys.argv[1].split("|"))} if len(sys.argv) > 1 else {k: f"stamp {k}" for k in range(12)}
-print("raw s_memtime ticks (100 MHz), workgroup 300, thread 0 (the LAST launch of the kernel in the update):")
-prev = t[0]
-for k in sorted(names):
-    print(f"  {k:2d} {names[k]:40s} {t[k] - prev:9.0f}   (cum {t[k] - t[0]:9.0f})")
-    prev = t[k]
+FWD = ["entry", "loads arrived", "out_proj MFMAs (16)", "LDS transpose, residual", "LayerNorm1", "stores, barrier", "lin1 (64 MFMAs) + FF1 stores",
+       "lin2 (64 MFMAs)", "transpose, residual", "LayerNorm2", "stores", "next in_proj (48 MFMAs) + stores"]
+BWD = ["entry", "pre stage: in_proj backward (48 MFMAs), dH", "LayerNorm2 backward, dB2", "lin2 backward (64 MFMAs), relu gate", "dFF1 rows: LDS -> regs, stores",
+       "lin1 backward (64 MFMAs)", "transpose, residual, dH1N", "LayerNorm1 backward, dY1", "out_proj backward (16 MFMAs), dATT"]
+print("raw s_memtime ticks, workgroup 300, thread 0 (stamps of the LAST launch of each kernel in the update)")
+for title, names, base in (("layer_rows_fwd", FWD, 0), ("layer_rows_bwd (the pre-stage-only launch for layer 0 overwrites stamps 20-21)", BWD, 20)):
+    print(title)
+    prev = t[base]
+    for k, nm in enumerate(names):
+        print(f"  {k:2d} {nm:52s} {t[base + k] - prev:9.0f}   (cum {t[base + k] - t[base]:9.0f})")
+        prev = t[base + k]
