@@ -45,10 +45,16 @@ def rows_of(lens):
     return offsets, row_env, row_t
 
 
+# kernels: "fused" = the round-3 default (row-chain kernels; per-episode attention when max_len <= 64 and its LDS image fits 64 KB: T = 100 and
+# T = 55 take the per-row attention kernels), "rows" = one launch per op (the path of long episodes / A-B runs), selected per call
+@pytest.mark.parametrize("kernels", ["fused", "rows"])
 @pytest.mark.parametrize("U,I,B,T,nhead,hot", [(50, 80, 9, 12, 4, 0.0), (300, 500, 70, 30, 4, 0.0), (40, 60, 5, 100, 8, 0.0),
-                                                (30, 40, 6, 7, 1, 0.0), (8, 90, 48, 30, 4, 0.6)])
-def test_tracker_backward_matches_autograd(U, I, B, T, nhead, hot):
+                                                (30, 40, 6, 7, 1, 0.0), (8, 90, 48, 30, 4, 0.6), (30, 40, 6, 20, 2, 0.0),
+                                                (30, 40, 6, 14, 8, 0.0), (20, 30, 4, 40, 4, 0.0), (20, 30, 4, 55, 4, 0.0)])
+def test_tracker_backward_matches_autograd(U, I, B, T, nhead, hot, kernels, monkeypatch):
     from cirs_hip.rollout import Trajectory
+    if kernels == "rows":
+        monkeypatch.setenv("CIRS_TRACKER_ROWS_UNFUSED", "1"); monkeypatch.setenv("CIRS_TRACKER_ATTN_ROWS", "1")
     rng = np.random.RandomState(B * T)
     tp = rolloutcase.tracker_param_dict(U, I, T, seed=3)
     lens = rng.randint(2, T + 1, size=B)
