@@ -17,9 +17,9 @@ wl = bench.WORKLOADS["c3"]
 eng, _ = bench.build_engine(wl, 0, 1, torch.device("cuda:0"))
 eng.collect(); eng.update(1024, 1)
 lib = C.CDLL(abi.LIB_PATH)
-names = {0: "tile start", 1: "LDS operand reads (za, cb, bias)", 2: "logits MFMAs (24)", 3: "dZ (exp, coefficients, mask)", 4: "dZ^T -> LDS (+ clamp corr.)",
-         5: "split + dH2 MFMAs (24)", 6: "fence + dZ^T read back", 7: "split + dWa MFMAs (24)", 8: "barrier 1", 9: "sR writes + plane commit", 10: "barrier 2",
-         11: "4-wave dWa sum + slab stores"}
+names = {0: "tile start", 1: "LDS operand reads (za, bias)", 2: "logits MFMAs (24) + dWa sum of the previous tile", 3: "dZ (exp2, coefficients, mask)",
+         4: "dZ^T -> LDS (+ branch-free clamp correction)", 5: "cb planes, split + dH2 MFMAs (24)", 6: "fence + dZ^T read back", 7: "split + dWa MFMAs (24)",
+         9: "partial-tile writes + plane commit", 10: "the tile's one barrier"}
 acc = None
 for rep in range(8):
     bench.hip_event_kernel_time(eng, wl, reps=2)

@@ -27,4 +27,8 @@ python $root/tools/kstats.py $db $out/${tag}_k1k2_sweep_kernel_stats.csv 40 > $o
 cd $root
 python tools/pmc_traffic.py collect $tag > $out/pmc.txt 2>&1
 cp gpurun_out/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.md $out/ 2>/dev/null
+# stage stamps (probe build: bash tools/probes/build_prof_lib.sh before the GPU call)
+if [ -f tools/probes/libcirs_prof.so ]; then
+  { python tools/probes/head_prof.py; python tools/probes/tbwd_prof.py; } > $out/${tag}_stage_stamps.txt 2> $out/stamps.err
+fi
 tail -3 $out/kstats_eval.txt; head -c 600 $out/${tag}_bench_c3.json
