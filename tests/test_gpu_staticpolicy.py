@@ -47,6 +47,34 @@ def test_recommend_k_item_matches_reference(golden_dir):
             assert model.n_each[int(t_id[0])] == z[f"r{ci}_n_each"][int(t_id[0])] + 1 and model.n_rec == float(z[f"r{ci}_n_rec"]) + 1
 
 
+def test_recommend_k_item_more_than_one(golden_dir):
+    """k > 1 (reference core/user_model.py:316-332): arg-max mode = torch.topk of the predicted values among the items left, sampling
+    mode with harness noise = the Gumbel top-k of log-softmax + noise (one sample without replacement), picks distinct, removed ids avoided."""
+    z = np.load(os.path.join(golden_dir, "staticpolicy.npz"))
+    model, ds = _model(golden_dir), _dataset(z)
+    user, k = int(z["r0_user"]), 5
+    removed = [3, 17, 40]
+    item_index = ds.df_photo_env.index.to_numpy()
+    pred, _ = model.device_model().sweep(np.asarray([user]), item_index, ds.df_photo_env[["feat0", "feat1", "feat2", "feat3"]].to_numpy(),
+                                         ds.df_photo_env["photo_duration"].to_numpy())
+    u = pred[0].cpu()
+    keep = np.ones(len(item_index), bool); keep[removed] = False
+    t_id, raw_id, val = model.recommend_k_item(user, ds, k=k, is_softmax=False, recommended_ids=removed)
+    want = np.arange(len(item_index))[keep][torch.topk(u[torch.as_tensor(keep)], k).indices.numpy()]
+    assert t_id.tolist() == want.tolist() and raw_id.tolist() == item_index[want].tolist()
+    np.testing.assert_allclose(val, u.numpy()[want], rtol=1e-6)
+    g = torch.as_tensor(z["r0_gumbel"][None, :])
+    t_id, _, _ = model.recommend_k_item(user, ds, k=k, is_softmax=True, recommended_ids=removed, gumbel=g)
+    noisy = torch.log_softmax(u, 0) + g[0]          # the selection kernel's softmax draw = arg-max of logit + noise
+    want = np.arange(len(item_index))[keep][torch.topk(noisy[torch.as_tensor(keep)], k).indices.numpy()]
+    assert t_id.tolist() == want.tolist()
+    t_id, _, _ = model.recommend_k_item(user, ds, k=k, is_softmax=True, recommended_ids=removed, seed=5)   # device noise: fresh per pick
+    assert len(set(t_id.tolist())) == k and not set(t_id.tolist()) & set(removed)
+    model.compile_UCB(len(item_index))
+    t_id, _, _ = model.recommend_k_item(user, ds, k=k, is_softmax=False, is_ucb=True)
+    assert model.n_rec == len(item_index) + k and all(model.n_each[t_id] == 2)
+
+
 @pytest.mark.parametrize("n,I", [(64, 10728), (5, 33), (3, 1 << 20)])
 def test_select_items_bit_exact_vs_oracle(n, I):
     from cirs_hip.static_policy import select_items
