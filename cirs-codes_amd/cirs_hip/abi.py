@@ -72,7 +72,7 @@ class PpoCfg(C.Structure):
     _fields_ = [("n_items", C.c_int32), ("dim_state", C.c_int32), ("hidden", C.c_int32), ("norm_adv", C.c_int32),
                 ("value_clip", C.c_int32), ("rew_norm", C.c_int32), ("gamma", C.c_float), ("gae_lambda", C.c_float),
                 ("eps_clip", C.c_float), ("vf_coef", C.c_float), ("ent_coef", C.c_float), ("max_grad_norm", C.c_float),
-                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float)]
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float), ("dual_clip", C.c_float)]
 
 
 class PpoBatch(C.Structure):
@@ -118,6 +118,7 @@ SIGNATURES = {
     "cirs_policy_workspace_bytes": (C.c_int64, [C.POINTER(PolicyCfg), C.c_int32]),
     "cirs_actor_sample": (C.c_int, [C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), _P, C.c_int64, C.c_int32, _P,
                                     C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "cirs_critic_values": (C.c_int, [C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
     "cirs_rollout_steps": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState),
                                      C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
                                      C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,

@@ -54,13 +54,18 @@ def minibatch_slices(n, batch_size):
 class DeviceLearner:
     def __init__(self, flat_params: torch.Tensor, n_items, n_env, max_turn, *, dim_state=20, hidden=64, gamma=0.99,
                  gae_lambda=0.95, eps_clip=0.2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=None, lr=1e-3, norm_adv=True,
-                 value_clip=False, rew_norm=False, betas=(0.9, 0.999), adam_eps=1e-8, world=1):
+                 value_clip=False, rew_norm=False, betas=(0.9, 0.999), adam_eps=1e-8, world=1, dual_clip=None):
         self.device = flat_params.device
         self.cfg = abi.PpoCfg(n_items=n_items, dim_state=dim_state, hidden=hidden, norm_adv=int(bool(norm_adv)),
                               value_clip=int(bool(value_clip)), rew_norm=int(bool(rew_norm)), gamma=gamma,
                               gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
                               max_grad_norm=float(max_grad_norm or 0.0), lr=lr, beta1=betas[0], beta2=betas[1],
-                              adam_eps=adam_eps)
+                              adam_eps=adam_eps, dual_clip=float(dual_clip or 0.0))
+        assert dual_clip is None or dual_clip > 1.0, "Dual-clip PPO parameter should greater than 1.0."   # core/policy/ppo.py:79-80
+        # recompute_advantage (core/policy/ppo.py:176-177): value_fn(traj) refreshes traj.value with the CURRENT critic; learn() then
+        # re-runs prepare() (GAE, returns, a second RunningMeanStd update -- a2c.py:80-109) before every repeat but the first
+        self.value_fn = None
+        self._prep = None
         self._lib = abi.lib()
         assert flat_params.numel() == self._lib.cirs_ppo_param_count(C.byref(self.cfg))
         self.params = flat_params
@@ -126,6 +131,7 @@ class DeviceLearner:
             lens_d = torch.as_tensor(lens_host).to(self.device)
             off_d = torch.as_tensor(offsets).to(self.device)
         self.lens_dev, self.offsets_dev = lens_d, off_d
+        self._prep = (traj, lens_host, lens_dev)
         abi.check(self._lib.cirs_ppo_prepare(C.byref(self.cfg), C.byref(traj.struct), lens_d.data_ptr(), off_d.data_ptr(),
                                              self.n_env, self.max_turn, n, self.rms_state.data_ptr(), C.byref(self.batch),
                                              self._stream()), "cirs_ppo_prepare")
@@ -296,10 +302,11 @@ class DeviceLearner:
                 k += 1
         return losses
 
-    def learn(self, batch_size, repeat, perms: Optional[List[np.ndarray]] = None, want_tracker_grad=True):
+    def learn(self, batch_size, repeat, perms: Optional[List[np.ndarray]] = None, want_tracker_grad=True, recompute_adv=False):
         """learn(): `repeat` passes of shuffled minibatches.  Returns loss arrays + leaves d loss / d obs of the LAST
         repeat in self.dobs ([T+1, B, S]) for the tracker backward.  perms: recorded permutations (parity tests);
-        default: draws of the seeded device generator (_perms_on_device)."""
+        default: draws of the seeded device generator (_perms_on_device).  recompute_adv: before every repeat but the first the
+        stored states are valued again with the current critic and process_fn's return computation is redone (ppo.py:176-177)."""
         n = self.n_rows
         slices = minibatch_slices(n, batch_size)
         max_mb = max(e - s for s, e in slices)
@@ -315,6 +322,10 @@ class DeviceLearner:
             last = rep == repeat - 1
             if last and want_tracker_grad:
                 self.dobs.zero_()  # optim_state.zero_grad() at the top of each repeat (ppo.py:174)
+            if recompute_adv and rep > 0:
+                assert self.value_fn is not None and self._prep is not None, "recompute_adv needs value_fn (critic over the stored states)"
+                self.value_fn(self._prep[0])
+                assert self.prepare(*self._prep) == n
             for s0, e0 in slices:
                 mb = e0 - s0
                 abi.check(self._lib.cirs_ppo_minibatch(

@@ -43,6 +43,16 @@ class DevicePolicy:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def values(self, state, *, state_stride=None, n=None, value_out=None):
+        """critic(state) for n rows with the current parameters (the value pass of A2CPolicy._compute_returns, a2c.py:80-86)."""
+        n = state.shape[0] if n is None else n
+        state_stride = state.stride(0) if state_stride is None else state_stride
+        value = value_out if value_out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        ws = self.workspace(n)
+        abi.check(self._lib.cirs_critic_values(C.byref(self.cfg), C.byref(self.w), state.data_ptr(), state_stride, n, value.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), self._stream()), "cirs_critic_values")
+        return value
+
     def sample(self, state, *, state_stride=None, n=None, gumbel=None, seed=0, rng_step=0, env_ids=None, visited=None,
                skip=None, act_out=None, logp_out=None, value_out=None):
         if n is None:

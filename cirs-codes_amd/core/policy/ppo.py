@@ -31,8 +31,7 @@ class PPOPolicy(nn.Module):
                  max_grad_norm=None, gae_lambda=0.95, max_batchsize=256, reward_normalization=False, action_scaling=True,
                  action_bound_method="clip", action_space=None, lr_scheduler=None, deterministic_eval=False, **kwargs):
         super().__init__()
-        assert dual_clip is None, "dual-clip PPO is not used by CIRS (CIRS-RL-kuaishou.py:279-280) and not built"
-        assert not recompute_advantage, "recompute_advantage=0 in the reference's runs; not built"
+        assert dual_clip is None or dual_clip > 1.0, "Dual-clip PPO parameter should greater than 1.0."   # reference ppo.py:79-80
         assert not deterministic_eval, "the reference never enables deterministic_eval for KuaishouEnv (SURVEY Q10)"
         if not reward_normalization:
             assert not value_clip, "value clip is available only when `reward_normalization` is True"
@@ -43,7 +42,8 @@ class PPOPolicy(nn.Module):
         self.lr_scheduler = lr_scheduler
         self._hyper = dict(gamma=discount_factor, gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
                            max_grad_norm=max_grad_norm, norm_adv=advantage_normalization, value_clip=value_clip,
-                           rew_norm=reward_normalization)
+                           rew_norm=reward_normalization, dual_clip=dual_clip)
+        self._recompute_adv = bool(recompute_advantage)
         optim_RL = optim[0] if isinstance(optim, (list, tuple)) else optim
         self._read_optim_hyper()
         # bind the modules' parameters into one flat device buffer (layout of include/cirs_hip.h)
@@ -180,7 +180,10 @@ class PPOPolicy(nn.Module):
             self._learner = DeviceLearner(self.flat, self.n_items, n_env, max_turn, dim_state=self.dim_state, hidden=self.hidden,
                                           gamma=h["gamma"], gae_lambda=h["gae_lambda"], eps_clip=h["eps_clip"], vf_coef=h["vf_coef"],
                                           ent_coef=h["ent_coef"], max_grad_norm=h["max_grad_norm"], lr=h["lr"], norm_adv=h["norm_adv"],
-                                          value_clip=h["value_clip"], rew_norm=h["rew_norm"], betas=h["betas"], adam_eps=h["adam_eps"])
+                                          value_clip=h["value_clip"], rew_norm=h["rew_norm"], betas=h["betas"], adam_eps=h["adam_eps"],
+                                          dual_clip=h["dual_clip"])
+            T1, S = max_turn, self.dim_state     # critic over every stored state obs[t, b], t < T (recompute_advantage, ppo.py:176-177)
+            self._learner.value_fn = lambda traj: self._dev_policy.values(traj.obs.view(-1, S), n=T1 * n_env, value_out=traj.value.view(-1))
             if rms is not None:
                 self._learner.rms_state.copy_(rms)
             if self._restored_RL is not None:  # optimiser state restored from a checkpoint before the first update
@@ -203,7 +206,7 @@ class PPOPolicy(nn.Module):
         ln.cfg.lr, (ln.cfg.beta1, ln.cfg.beta2), ln.cfg.adam_eps = self._hyper["lr"], self._hyper["betas"], self._hyper["adam_eps"]
         ln.perm_seed = (self.seed * 7919 + 20230) & 0x7FFFFFFF
         n = ln.prepare(ro.traj, lens)
-        losses = ln.learn(batch_size, repeat, perms=perms, want_tracker_grad=self._tracker is not None)
+        losses = ln.learn(batch_size, repeat, perms=perms, want_tracker_grad=self._tracker is not None, recompute_adv=self._recompute_adv)
         if self._tracker is not None:
             eng = ro.tracker      # the slots / caches of THIS buffer's rollout (each Collector owns its engine)
             eng.lr, eng.betas, eng.adam_eps = self._tracker_lr, self._tracker_betas, self._tracker_eps

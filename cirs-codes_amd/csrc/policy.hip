@@ -190,6 +190,20 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
     return CIRS_OK;
 }
 
+extern "C" int cirs_critic_values(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state, int64_t state_stride, int32_t n,
+                                  float* value_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_policy(cfg, w)) return rc;
+    if (n <= 0) return CIRS_OK;
+    CIRS_REQUIRE(state && value_out && workspace, "null state/value/workspace");
+    CIRS_REQUIRE(state_stride >= cfg->dim_state, "state_stride < dim_state");
+    CIRS_REQUIRE(workspace_bytes >= cirs_policy_workspace_bytes(cfg, n), "workspace too small");
+    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, *cfg, *w, state, (long)state_stride, n,
+                       (const uint8_t*)nullptr, (float*)workspace, value_out, nullptr);
+    CIRS_CHECK_LAUNCH("trunk_kernel (values)");
+    return CIRS_OK;
+}
+
 extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const cirs_policy_weights* w_shard, const float* state,
                                          int64_t state_stride, int32_t n, uint64_t seed, uint32_t rng_step, const int32_t* env_ids,
                                          const uint32_t* visited, const uint8_t* skip, int32_t item_base, int32_t n_items_total,

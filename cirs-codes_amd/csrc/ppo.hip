@@ -351,9 +351,16 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(cirs_ppo_cfg cfg,
     const float A = (b.adv[src] - v.red[0]) / v.red[1];    // per-minibatch advantage normalisation (ppo.py:184-186)
     const float s1 = ratio * A;
     const float s2 = fminf(fmaxf(ratio, 1.0f - cfg.eps_clip), 1.0f + cfg.eps_clip) * A;
-    v.clip_row[j] = -fminf(s1, s2);
+    float surr = fminf(s1, s2);
     // d(-min(s1,s2))/d logp: s1 path when s1 <= s2 (a tie passes the full gradient), else clamp blocks it
-    v.c_logp[j] = (s1 <= s2 && !clamped) ? -inv_mb * A * ratio : 0.f;
+    float c_logp = (s1 <= s2 && !clamped) ? -inv_mb * A * ratio : 0.f;
+    if (cfg.dual_clip > 0.f) {   // -max(min(s1, s2), dual_clip * A) (core/policy/ppo.py:190-193): the constant branch has no gradient
+        const float dcl = cfg.dual_clip * A;
+        if (dcl > surr) { surr = dcl; c_logp = 0.f; }
+        else if (dcl == surr) c_logp *= 0.5f;                // torch.max splits the gradient of a tie
+    }
+    v.clip_row[j] = -surr;
+    v.c_logp[j] = c_logp;
     const float val = v.value[j], vs = b.v_s[src], ret = b.ret[src];
     const float d1 = ret - val;
     float vf = d1 * d1, dv = -2.0f * d1;

@@ -214,6 +214,12 @@ int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, 
  * the full kernel computes for its items.  tuples_out [5, n] f32: {noisy score, candidate id (int32 bits), candidate logit,
  * running max, running sum-exp}.  cirs_actor_merge_shards: tuples [n_shards, 5, n] folded in shard order -> act (argmax of the
  * noisy score, ties -> lowest id: identical to the single-device action) and logp (Categorical clamp). */
+/* critic(obs) for n stored states with the current parameters: the value pass of A2CPolicy._compute_returns
+   (tianshou/tianshou/policy/modelfree/a2c.py:80-86) when PPOPolicy(recompute_advantage=True) recomputes the advantages at every repeat
+   (core/policy/ppo.py:176-177).  workspace: cirs_policy_workspace_bytes(cfg, n). */
+int cirs_critic_values(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state, int64_t state_stride, int32_t n,
+                       float* value_out, void* workspace, int64_t workspace_bytes, void* stream);
+
 int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const cirs_policy_weights* w_shard, const float* state,
                               int64_t state_stride, int32_t n, uint64_t seed, uint32_t rng_step, const int32_t* env_ids,
                               const uint32_t* visited, const uint8_t* skip, int32_t item_base, int32_t n_items_total,
@@ -310,6 +316,8 @@ typedef struct cirs_ppo_cfg {
     int32_t norm_adv, value_clip, rew_norm;
     float gamma, gae_lambda, eps_clip, vf_coef, ent_coef, max_grad_norm;
     float lr, beta1, beta2, adam_eps;
+    float dual_clip;   /* 0: off; > 1: dual-clip PPO as the reference computes it, -max(min(surr1, surr2), dual_clip * adv) for EVERY sign of
+                          adv (core/policy/ppo.py:190-193) */
 } cirs_ppo_cfg;
 
 typedef struct cirs_ppo_batch { /* N rows, buffer order */

@@ -281,7 +281,9 @@ def gen_policy():
 # --------------------------------------------------------------------------------------------------
 # learn family: reference Collector.collect + PPOPolicy.update (process_fn + learn) on a tiny problem
 # --------------------------------------------------------------------------------------------------
-def gen_learn():
+def gen_learn(name="learn", dual_clip=None, recompute=0, rounds=2):
+    """name="learn": the reference's configuration; "learn_opts": dual-clip PPO + recompute_advantage, the two PPOPolicy options the
+    CIRS scripts leave off (core/policy/ppo.py:73-99,176-177,190-193), one round."""
     import gym
     from core.collector import Collector
     from core.policy.ppo import PPOPolicy
@@ -309,7 +311,7 @@ def gen_learn():
     sim_env = gym.make("SimulatedEnv-v0")
     policy = PPOPolicy(actor, critic, [optim_RL, optim_state], torch.distributions.Categorical, discount_factor=0.95,
                        max_grad_norm=0.5, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, reward_normalization=1,
-                       advantage_normalization=1, recompute_advantage=0, value_clip=1, gae_lambda=0.95,
+                       advantage_normalization=1, recompute_advantage=recompute, value_clip=1, gae_lambda=0.95, dual_clip=dual_clip,
                        action_space=sim_env.action_space, action_bound_method="", action_scaling=False)
     random.seed(123); np.random.seed(123); torch.manual_seed(123)
     train_envs = DummyVectorEnv([lambda: gym.make("SimulatedEnv-v0") for _ in range(B)])
@@ -325,6 +327,8 @@ def gen_learn():
     orig_learn = policy.learn
 
     def learn_wrap(batch, **kw):
+        if stash.get("locked"):
+            return orig_learn(batch, **kw)
         stash.update(returns=batch.returns.detach().numpy().copy(), adv=batch.adv.detach().numpy().copy(),
                      v_s=batch.v_s.detach().numpy().copy(), logp_old=batch.logp_old.detach().numpy().copy(),
                      act=batch.act.detach().numpy().copy())
@@ -367,14 +371,20 @@ def gen_learn():
         return out, lens, losses, perms
 
     out, lens, losses, perms = one_round(321, 77)
-    out.update(hyper=np.array([0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, 16, 2]), dims=np.array([U, I, B, T]))
+    out.update(hyper=np.array([0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, 16, 2]), dims=np.array([U, I, B, T]),
+               opts=np.array([dual_clip or 0.0, float(recompute)]))
+    if rounds < 2:
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+        print(name + ".npz: N =", int(lens.sum()), "minibatches", len(losses["loss"]), "losses", np.round(losses["loss"], 4),
+              "clip", np.round(losses["loss/clip"], 4))
+        return
     # SECOND consecutive collect + update on the same policy / optimisers / ret_rms: the tracker's second Adam step pins
     # gradient MAGNITUDES (the first one is +-lr whatever the magnitude) and ret_rms / Adam-moment carry-over
     out2, lens2, losses2, perms2 = one_round(654, 78)
     out.update({"r2_" + k: v for k, v in out2.items() if not (k.startswith("pol_") or k.startswith("trk_"))})
     print("learn.npz round 2: N =", int(lens2.sum()), "lens", lens2.tolist(), "minibatches", len(losses2["loss"]))
-    np.savez_compressed(os.path.join(GOLDEN, "learn.npz"), **out)
-    print("learn.npz: N =", int(lens.sum()), "lens", lens.tolist(), "minibatches", len(losses["loss"]), "losses", np.round(losses["loss"], 4),
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+    print(name + ".npz: N =", int(lens.sum()), "lens", lens.tolist(), "minibatches", len(losses["loss"]), "losses", np.round(losses["loss"], 4),
           "perms", [len(p_) for p_ in perms])
 
 
@@ -1142,7 +1152,7 @@ def gen_c1rl():
 
 
 
-FAMILIES = {"c1rl": gen_c1rl, "virtualtb": gen_virtualtb, "collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+FAMILIES = {"c1rl": gen_c1rl, "virtualtb": gen_virtualtb, "collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "learn_opts": lambda: gen_learn("learn_opts", dual_clip=1.01, recompute=1, rounds=1), "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

@@ -222,7 +222,7 @@ def adam_substeps(p, g, state, lr, n_sub, b1=0.9, b2=0.999, eps=1e-8):
 
 def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam=0.95, eps_clip=0.2, vf_coef=0.25,
                ent_coef=0.0, max_grad_norm=0.5, lr=1e-3, batch_size=16, repeat=2, ret_rms=None, nhead=4, opt_state=None,
-               snapshot_steps=()):
+               snapshot_steps=(), dual_clip=None, recompute_adv=False):
     """Runs one policy.update on teacher-forced episodes.  tp/pp are dicts of torch fp32 tensors and are updated
     IN PLACE.  Returns dict(losses..., returns, adv, v_s, logp_old, ret_rms, opt_state).  Pass the previous call's
     `ret_rms` and `opt_state` (Adam moments + step counters of optim_RL / optim_state) to continue a run: the reference keeps
@@ -243,19 +243,27 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
     done = flatten_episodes(_t(dones), lens).bool().numpy()
     N = len(act)
     with torch.no_grad():
-        _, v_s_t = policy_forward(pp, obs.detach())
-        _, v_ns_t = policy_forward(pp, obs_next)
         logits_old, _ = policy_forward(pp, obs.detach())
         _, logp_old, _ = categorical_logp_entropy(logits_old, act)
-    scale = np.sqrt(ret_rms.var + 1e-8)
-    v_s = v_s_t.numpy().astype(np.float64) * scale
-    v_ns = v_ns_t.numpy().astype(np.float64) * scale * (~done)
-    end_flag = done.copy()  # every episode in the buffer is finished (n_episode == env_num)
-    adv = gae_numpy(v_s, v_ns, rew, end_flag.astype(np.float64), gamma, lam)
-    unnorm_returns = adv + v_s
-    returns = torch.as_tensor(unnorm_returns / scale).float()
-    ret_rms.update(unnorm_returns)
-    adv_t = torch.as_tensor(adv).float()
+
+    def compute_returns():
+        """A2CPolicy._compute_returns (a2c.py:80-109): critic over obs / obs_next with the CURRENT parameters, GAE, returns normalised by
+        the CURRENT running variance, which is then updated.  Runs once in process_fn and, with recompute_advantage, again before every
+        repeat but the first (ppo.py:176-177)."""
+        with torch.no_grad():
+            _, v_s_t = policy_forward(pp, obs.detach())
+            _, v_ns_t = policy_forward(pp, obs_next)
+        scale = np.sqrt(ret_rms.var + 1e-8)
+        v_s = v_s_t.numpy().astype(np.float64) * scale
+        v_ns = v_ns_t.numpy().astype(np.float64) * scale * (~done)
+        end_flag = done.copy()  # every episode in the buffer is finished (n_episode == env_num)
+        adv = gae_numpy(v_s, v_ns, rew, end_flag.astype(np.float64), gamma, lam)
+        unnorm_returns = adv + v_s
+        returns = torch.as_tensor(unnorm_returns / scale).float()
+        ret_rms.update(unnorm_returns)
+        return v_s_t, returns, torch.as_tensor(adv).float()
+    v_s_t, returns, adv_t = compute_returns()
+    first = dict(returns=returns.numpy().copy(), adv=adv_t.numpy().copy(), v_s=v_s_t.numpy().copy())
 
     names_trunk = ["w1", "b1", "w2", "b2"]
     names_head = ["wa", "ba", "wc", "bc"]
@@ -269,6 +277,8 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
     trk_grads = None
     for rep in range(repeat):
         trk_grads = {k: torch.zeros_like(v) for k, v in tparams.items()}  # optim_state.zero_grad()
+        if recompute_adv and rep > 0:
+            v_s_t, returns, adv_t = compute_returns()
         dobs_rows = torch.zeros(N, obs.shape[1])
         perm = np.asarray(perms[pi]); pi += 1
         starts = list(range(0, N, batch_size))
@@ -293,7 +303,10 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
             a = (a - a.mean()) / a.std()
             ratio = (logp - logp_old[idx_t]).exp()
             surr1, surr2 = ratio * a, ratio.clamp(1 - eps_clip, 1 + eps_clip) * a
-            clip_loss = -torch.min(surr1, surr2).mean()
+            if dual_clip:
+                clip_loss = -torch.max(torch.min(surr1, surr2), dual_clip * a).mean()    # ppo.py:190-193 (for every sign of a)
+            else:
+                clip_loss = -torch.min(surr1, surr2).mean()
             vs = v_s_t[idx_t]
             v_clip = vs + (value - vs).clamp(-eps_clip, eps_clip)
             vf_loss = torch.max((returns[idx_t] - value).pow(2), (returns[idx_t] - v_clip).pow(2)).mean()
@@ -326,7 +339,7 @@ def ppo_update(tp, pp, users, acts, rews, dones, lens, perms, *, gamma=0.95, lam
         for k, v in tparams.items():
             v.requires_grad_(False)
             adam_substeps(v, trk_grads[k], st_trk[k], lr, 1)
-    out.update(returns=returns.numpy(), adv=adv_t.numpy(), v_s=v_s_t.numpy(), logp_old=logp_old.numpy(), ret_rms=ret_rms,
+    out.update(returns=first["returns"], adv=first["adv"], v_s=first["v_s"], logp_old=logp_old.numpy(), ret_rms=ret_rms,
                trk_grads={k: g.clone() for k, g in trk_grads.items()}, obs=obs.detach().numpy(),
                dobs_rows=dobs_rows.numpy(), logits_old=None, opt_state=opt_state)
     return out

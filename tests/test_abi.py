@@ -42,5 +42,5 @@ def test_struct_sizes_match_header_layout():
     import ctypes as C
     assert C.sizeof(abi.EnvCfg) == 10 * 4 + 3 * 8
     assert C.sizeof(abi.TrackerWeights) == 8 * (7 + 12 * abi.MAX_TRACKER_LAYERS + 2)
-    assert C.sizeof(abi.PpoCfg) == 16 * 4
+    assert C.sizeof(abi.PpoCfg) == 17 * 4
     assert C.sizeof(abi.Traj) == 7 * 8

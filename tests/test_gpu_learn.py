@@ -36,13 +36,44 @@ def rollout_time_value_logp(pp, obs_bts, acts, lens):
     return value, logp
 
 
-def make_learner(pp, I, B, T, hyper):
+def make_learner(pp, I, B, T, hyper, dual_clip=None):
     from cirs_hip.learner import DeviceLearner, flat_policy_params
     gamma, lam, eps_clip, vf_coef, ent_coef, mgn, lr, bs, rep = hyper
     flat, views = flat_policy_params(I, init={POL[k]: v for k, v in pp.items()})
     ln = DeviceLearner(flat, I, B, T, gamma=gamma, gae_lambda=lam, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
-                       max_grad_norm=mgn, lr=lr, norm_adv=True, value_clip=True, rew_norm=True)
+                       max_grad_norm=mgn, lr=lr, norm_adv=True, value_clip=True, rew_norm=True, dual_clip=dual_clip)
     return ln, views
+
+
+def test_learner_dual_clip_and_recomputed_advantages_match_reference(golden_dir):
+    """PPOPolicy(dual_clip=1.01, recompute_advantage=1) recorded from the reference (learn_opts.npz): the device learner with
+    cfg.dual_clip and learn(recompute_adv=True) -- cirs_critic_values over the stored states + cirs_ppo_prepare before the second repeat."""
+    from cirs_hip.policy import DevicePolicy
+    from cirs_hip.rollout import Trajectory
+    z, tp, pp, perms = load_learn(golden_dir, "learn_opts")
+    U, I, B, T = [int(v) for v in z["dims"]]
+    lens, obs_bts = z["lens"], z["obs"]
+    value, logp = rollout_time_value_logp(pp, obs_bts, np.maximum(z["acts"], 0), lens)
+    traj = Trajectory(B, T, 20, "cuda")
+    upload_traj(traj, z["acts"], z["rews"], z["dones"], lens, obs_bts, value, logp)
+    ln, views = make_learner(pp, I, B, T, z["hyper"], dual_clip=float(z["opts"][0]))
+    pol = DevicePolicy(views, I)
+    # critic values of the stored states through the entry point == the rollout-time values (same parameters)
+    got = pol.values(traj.obs.view(-1, 20), n=T * B).view(T, B).cpu().numpy()
+    live = np.arange(T)[:, None] < lens[None, :]
+    np.testing.assert_allclose(got[live], value.T[live], rtol=1e-5, atol=1e-6)
+    ln.value_fn = lambda tr: pol.values(tr.obs.view(-1, 20), n=T * B, value_out=tr.value.view(-1))
+    n = ln.prepare(traj, lens)
+    np.testing.assert_allclose(ln.b_adv[:n].cpu().numpy(), z["b_adv"], rtol=1e-4, atol=1e-5)
+    bs, rep = int(z["hyper"][7]), int(z["hyper"][8])
+    losses = ln.learn(bs, rep, perms=perms, recompute_adv=True).cpu().numpy()
+    np.testing.assert_allclose(losses[:, 0], z["loss"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(losses[:, 1], z["loss_clip"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(losses[:, 2], z["loss_vf"], rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(ln.rms_state.cpu().numpy(), z["ret_rms"], rtol=1e-5)
+    for k, name in POL.items():   # (atol: see test_oracle_learn -- near-zero gradients under dual clip)
+        post = z["post_pol_" + name]
+        np.testing.assert_allclose(views[name].cpu().numpy().reshape(post.shape), post, rtol=1e-4, atol=1e-5, err_msg=name)
 
 
 def test_learner_matches_reference_golden(golden_dir):

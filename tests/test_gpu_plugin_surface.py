@@ -61,6 +61,25 @@ def test_script_wiring_runs_and_matches_engine():
     assert torch.equal(eng.tracker_flat, st.flat)
 
 
+def test_ppo_options_through_the_plugin_surface():
+    """PPOPolicy(dual_clip=..., recompute_advantage=True) (reference core/policy/ppo.py:73-99): accepted by the mirror and routed to the device
+    learner (numbers pinned in tests/test_gpu_learn.py against the reference-recorded learn_opts.npz)."""
+    from core.policy.ppo import PPOPolicy
+    ex = load_example()
+    args = ex.get_args(["--n-users", "100", "--n-items", "300", "--training-num", "16", "--episode-per-collect", "16",
+                        "--batch-size", "64", "--max_turn", "12", "--tau", "10", "--dropout", "0"])
+    tab, train_envs, st, policy, coll = ex.build(args)
+    with pytest.raises(AssertionError):
+        PPOPolicy(policy.actor, policy.critic, policy.optim, torch.distributions.Categorical, dual_clip=0.9)
+    policy._hyper["dual_clip"], policy._recompute_adv = 1.5, True      # what PPOPolicy(dual_clip=1.5, recompute_advantage=True) stores
+    res = coll.collect(n_episode=16)
+    losses = policy.update(0, coll.buffer, batch_size=64, repeat=3)
+    n = res["n/st"]
+    assert np.isfinite(losses["loss"]).all() and len(losses["loss"]) == 3 * max(n // 64, 1)
+    assert policy._learner.cfg.dual_clip == 1.5
+    assert int(policy._learner.rms_state.cpu()[2]) == 3 * n      # RunningMeanStd updated by process_fn and before repeats 2 and 3
+
+
 def test_vector_env_protocol_and_test_envs():
     """env.reset/step with numpy in/out (venvs.py:153-252) and the bare KuaishouEnv used by the test collectors."""
     ex = load_example()

@@ -13,8 +13,8 @@ POL = dict(w1="actor.preprocess.model.model.0.weight", b1="actor.preprocess.mode
            wc="critic.last.model.0.weight", bc="critic.last.model.0.bias")
 
 
-def load_learn(golden_dir):
-    z = np.load(os.path.join(golden_dir, "learn.npz"))
+def load_learn(golden_dir, name="learn"):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
     tp = {k[len("trk_"):]: torch.as_tensor(z[k]).float().clone() for k in z.files if k.startswith("trk_")}
     pp = {k: torch.as_tensor(z["pol_" + v]).float().clone() for k, v in POL.items()}
     perms = [z[f"perm{i}"] for i in range(int(z["n_perm"]))]
@@ -58,6 +58,33 @@ def test_ppo_update_matches_reference(golden_dir):
             got, post = np.delete(got, slice(32, 64)), np.delete(post, slice(32, 64))
         np.testing.assert_allclose(got, post, rtol=1e-4, atol=2e-6, err_msg=k)
     assert moved >= 20  # every tracker tensor received gradient through the stored obs
+
+
+def test_ppo_update_with_dual_clip_and_recomputed_advantages_matches_reference(golden_dir):
+    """The two PPOPolicy options the CIRS scripts leave off (core/policy/ppo.py:73-99): dual_clip (-max(min(s1, s2), c * adv) for every
+    sign of adv, :190-193) and recompute_advantage (critic + GAE + RunningMeanStd update again before the second repeat, :176-177),
+    recorded from the reference with both switched on (tests/golden/learn_opts.npz)."""
+    z, tp, pp, perms = load_learn(golden_dir, "learn_opts")
+    gamma, lam, eps_clip, vf_coef, ent_coef, mgn, lr, bs, rep = z["hyper"]
+    dual_clip, recompute = float(z["opts"][0]), bool(z["opts"][1])
+    assert dual_clip > 1.0 and recompute
+    out = nn_oracle.ppo_update(tp, pp, z["users"], z["acts"], z["rews"], z["dones"], z["lens"], perms, gamma=gamma, lam=lam,
+                               eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef, max_grad_norm=mgn, lr=lr,
+                               batch_size=int(bs), repeat=int(rep), dual_clip=dual_clip, recompute_adv=recompute)
+    np.testing.assert_allclose(out["adv"], z["b_adv"], rtol=1e-4, atol=1e-5)
+    rms = out["ret_rms"]
+    np.testing.assert_allclose([rms.mean, rms.var, rms.count], z["ret_rms"], rtol=1e-5)      # count = 2 N: updated by both passes
+    assert int(z["ret_rms"][2]) == 2 * int(z["lens"].sum())
+    np.testing.assert_allclose(out["loss"], z["loss"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out["clip"], z["loss_clip"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out["vf"], z["loss_vf"], rtol=2e-4, atol=2e-5)
+    for k, name in POL.items():   # (dual clip zeroes most rows' gradients: a few head entries have |g| ~ 1e-9, where Adam turns round-off into 5e-6)
+        np.testing.assert_allclose(pp[k].numpy(), z["post_pol_" + name], rtol=1e-4, atol=1e-5, err_msg=name)
+    # the options matter on this fixture: the plain configuration gives other losses
+    z0, tp0, pp0, perms0 = load_learn(golden_dir, "learn_opts")
+    plain = nn_oracle.ppo_update(tp0, pp0, z["users"], z["acts"], z["rews"], z["dones"], z["lens"], perms0, gamma=gamma, lam=lam,
+                                 eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef, max_grad_norm=mgn, lr=lr, batch_size=int(bs), repeat=int(rep))
+    assert np.abs(np.array(plain["clip"]) - z["loss_clip"]).max() > 1e-3 and np.abs(np.array(plain["vf"][3:]) - z["loss_vf"][3:]).max() > 1e-3
 
 
 def load_round2(z):
