@@ -268,22 +268,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(const float* __restrict__ QKV
     dQKV[(size_t)r * 96 + tD + lane] = acc;   // columns [32, 64) = dK, [64, 96) = dV
 }
 
-// ---- per-episode attention (round 3): one workgroup per env, the episode's Q / K / V rows staged in LDS ONCE --------------------------
+// ---- per-episode attention (round 3): one wavefront per env, the episode's Q / K / V rows staged in LDS ONCE ---------------------------
 // The per-row kernels above give every query row its own wavefront: <= max_turn of the 64 lanes hold a key, and every wavefront re-reads
 // the keys / values of its episode from L2 (3 launches x 30 k wavefronts x ~40 dependent global loads at C3: 34 + 48 + 28 us per
-// layer).  Here a wavefront owns a head group of one env and a lane owns a QUERY (its keys are walked out of LDS: soft-max statistics,
-// dQ and the output need no cross-lane reduction) and, in the second phase of the backward, a KEY (dK / dV accumulated over the later
-// queries in order).  The probabilities are not kept between the forward and the backward pass: the backward recomputes them from
-// Q, K (cheaper than 15 MB of P through HBM).  Used when max_len <= 64 and the LDS image fits 64 KB (max_len <= 50 at 4 heads); longer
-// episodes take the per-row kernels.
+// layer).  Here a lane owns a head group of TWO queries, p and len-1-p (the causal triangle folded: every lane walks ~len keys), its keys
+// come out of LDS -- one read serves both queries and, the head groups sharing the instruction, all heads: what bounds these kernels is the
+// LDS pipe, a ds_read costs its issue cycles whether or not lanes share an address -- and soft-max statistics, dQ and the output need no
+// cross-lane reduction.  In the second phase of the backward the lane owns two KEYS the same way (dK / dV accumulated over the later queries
+// in order).  The probabilities are not kept between the forward and the backward pass: the backward recomputes them from Q, K (cheaper
+// than 15 MB of P through HBM).  Used when max_len <= 64 and the LDS image fits 64 KB (max_len <= 50 at 4 heads); longer episodes take the
+// per-row kernels.
 template <int NH> struct EpGeo {
-    static constexpr int NW = NH < 4 ? NH : 4;      // wavefronts per env = head groups
+    static constexpr int NW = NH < 4 ? NH : 4;      // head groups (lane / SL)
+    static constexpr int SL = 64 / NW;              // query-pair slots per head group and pass
     static constexpr int HPL = NH / NW;             // heads per lane
     static constexpr int HD = tD / NH;
     static constexpr int DPL = HPL * HD;            // dims per lane
     __host__ __device__ static constexpr int strip(int Lp) { return (HPL * Lp) | 1; }   // odd stride between queries: conflict-free both ways
-    __host__ __device__ static constexpr size_t fwd_floats(int Lp) { return (size_t)Lp * 64 + (size_t)NW * Lp * strip(Lp); }
-    __host__ __device__ static constexpr size_t bwd_floats(int Lp) { return (size_t)Lp * 128 + (size_t)NW * Lp * strip(Lp) + 2 * (size_t)NH * Lp; }
+    __host__ __device__ static constexpr size_t fwd_floats(int Lp) { return (size_t)Lp * 64 + (size_t)NW * (Lp + 1) * strip(Lp); }
+    __host__ __device__ static constexpr size_t bwd_floats(int Lp) { return (size_t)Lp * 128 + (size_t)NW * (Lp + 1) * strip(Lp) + 2 * (size_t)NH * Lp; }
 };
 
 // stage `cols` floats (multiple of 4) per row of an episode, rows `src_stride` apart, into LDS rows of `cols` floats
@@ -317,186 +320,275 @@ template <int HD> __device__ __forceinline__ float ep_dot(const float* a, const 
 #define EP_KEEP(POS, ELEM) dropout_keep(dc.seed, (uint32_t)(dc.env_base + b), (uint32_t)(POS), (uint32_t)layer, (uint32_t)CIRS_DROP_ATTN, (uint32_t)(ELEM), dc.thr)
 
 template <int NH, bool kDrop>
-__global__ __launch_bounds__(64 * EpGeo<NH>::NW) void attn_fwd_ep(const float* __restrict__ QKV, const int32_t* __restrict__ offsets,
-                                                                  const int32_t* __restrict__ lens, int Lp, float* __restrict__ ATT,
-                                                                  DropCfg dc, int layer) {
+__global__ __launch_bounds__(64) void attn_fwd_ep(const float* __restrict__ QKV, const int32_t* __restrict__ offsets,
+                                                  const int32_t* __restrict__ lens, int Lp, float* __restrict__ ATT, DropCfg dc, int layer) {
     using G = EpGeo<NH>;
-    constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD;
+    constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD, SL = G::SL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, len = lens[b];
     if (len <= 0) return;
-    const int lane = threadIdx.x & 63, hg = threadIdx.x >> 6, p = lane;
+    const int lane = threadIdx.x, hg = lane / SL, slot = lane - hg * SL;
     const int base = offsets[b], STR = G::strip(Lp);
     float* sKV = smem;                          // [len][K 32 | V 32]
-    float* sS = smem + (size_t)Lp * 64;         // [head group][query][HPL][Lp] (query stride STR)
-    ep_stage(sKV, QKV + (size_t)base * 96 + tD, len, 96, 64, threadIdx.x, 64 * G::NW);
+    float* sS = smem + (size_t)Lp * 64;         // [head group][query | dummy row Lp][HPL][Lp] (query stride STR)
+    ep_stage(sKV, QKV + (size_t)base * 96 + tD, len, 96, 64, lane, 64);
     __syncthreads();
-    if (p >= len) return;
     const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;   // q * scale * log2(e): scores in log2 units
-    float* my = sS + ((size_t)hg * Lp + p) * STR;
-    float q[DPL];
-    ep_load(q, QKV + (size_t)(base + p) * 96 + hg * DPL);
+    for (int s0 = 0; 2 * s0 < len; s0 += SL) {
+        const int pA = s0 + slot, pB = len - 1 - pA;
+        const bool actA = pA <= pB, actB = pA < pB;        // the middle query of an odd episode sits in the A half only
+        const int rA = actA ? pA : 0, rB = actB ? pB : 0;
+        const int jn = len - s0;                           // the pass's longest key walk (slot 0's query B)
+        // branch-free loops: every lane stores every step; lanes without a query write the dummy row, columns beyond a query's causal limit are never read
+        float* myA = sS + ((size_t)hg * (Lp + 1) + (actA ? pA : Lp)) * STR;
+        float* myB = sS + ((size_t)hg * (Lp + 1) + (actB ? pB : Lp)) * STR;
+        float qA[DPL], qB[DPL];
+        ep_load(qA, QKV + (size_t)(base + rA) * 96 + hg * DPL);
+        ep_load(qB, QKV + (size_t)(base + rB) * 96 + hg * DPL);
 #pragma unroll
-    for (int d = 0; d < DPL; ++d) q[d] *= qs;
-    float mx[HPL], sm[HPL];
+        for (int d = 0; d < DPL; ++d) { qA[d] *= qs; qB[d] *= qs; }
+        float mxA[HPL], mxB[HPL], smA[HPL], smB[HPL];
 #pragma unroll
-    for (int h = 0; h < HPL; ++h) { mx[h] = -INFINITY; sm[h] = 0.f; }
+        for (int h = 0; h < HPL; ++h) { mxA[h] = mxB[h] = -INFINITY; smA[h] = smB[h] = 0.f; }
+        float kq[DPL];
+        ep_load(kq, sKV + hg * DPL);
 #pragma unroll 4
-    for (int j = 0; j <= p; ++j) {
-        float k[DPL];
-        ep_load(k, sKV + (size_t)j * 64 + hg * DPL);
+        for (int j = 0; j < jn; ++j) {
+            float k[DPL];      // software pipeline: key j + 1 is requested before key j is used (the strip stores below would otherwise order the loads)
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) k[d] = kq[d];
+            ep_load(kq, sKV + (size_t)(j + 1 < jn ? j + 1 : j) * 64 + hg * DPL);
+            const bool inA = actA && j <= pA, inB = actB && j <= pB;
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                const float sa = ep_dot<HD>(qA + h * HD, k + h * HD), sb = ep_dot<HD>(qB + h * HD, k + h * HD);
+                myA[h * Lp + j] = sa; myB[h * Lp + j] = sb;
+                mxA[h] = inA ? fmaxf(mxA[h], sa) : mxA[h];
+                mxB[h] = inB ? fmaxf(mxB[h], sb) : mxB[h];
+            }
+        }
+        float accA[DPL], accB[DPL];
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) accA[d] = accB[d] = 0.f;
+        float vq[DPL];
+        ep_load(vq, sKV + 32 + hg * DPL);
+#pragma unroll 4
+        for (int j = 0; j < jn; ++j) {
+            float v[DPL];
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) v[d] = vq[d];
+            ep_load(vq, sKV + (size_t)(j + 1 < jn ? j + 1 : j) * 64 + 32 + hg * DPL);
+            const bool inA = actA && j <= pA, inB = actB && j <= pB;
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                float ea = ep_exp2(myA[h * Lp + j] - mxA[h]), eb = ep_exp2(myB[h * Lp + j] - mxB[h]);
+                ea = inA ? ea : 0.f; eb = inB ? eb : 0.f;
+                smA[h] += ea; smB[h] += eb;
+                if (kDrop) {
+                    if (inA && !EP_KEEP(pA, j * NH + hg * HPL + h)) ea = 0.f;
+                    if (inB && !EP_KEEP(pB, j * NH + hg * HPL + h)) eb = 0.f;
+                }
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    accA[h * HD + d] = __builtin_fmaf(ea, v[h * HD + d], accA[h * HD + d]);
+                    accB[h * HD + d] = __builtin_fmaf(eb, v[h * HD + d], accB[h * HD + d]);
+                }
+            }
+        }
 #pragma unroll
         for (int h = 0; h < HPL; ++h) {
-            const float sc = ep_dot<HD>(q + h * HD, k + h * HD);
-            my[h * Lp + j] = sc;
-            mx[h] = fmaxf(mx[h], sc);
+            const float ia = (kDrop ? dc.inv : 1.0f) / smA[h], ib = (kDrop ? dc.inv : 1.0f) / smB[h];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) { accA[h * HD + d] *= ia; accB[h * HD + d] *= ib; }
         }
+        if (actA) ep_store(ATT + (size_t)(base + pA) * tD + hg * DPL, accA, 1.0f);
+        if (actB) ep_store(ATT + (size_t)(base + pB) * tD + hg * DPL, accB, 1.0f);
     }
-    float acc[DPL];
-#pragma unroll
-    for (int d = 0; d < DPL; ++d) acc[d] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j <= p; ++j) {
-        float v[DPL];
-        ep_load(v, sKV + (size_t)j * 64 + 32 + hg * DPL);
-#pragma unroll
-        for (int h = 0; h < HPL; ++h) {
-            float e = ep_exp2(my[h * Lp + j] - mx[h]);
-            sm[h] += e;
-            if (kDrop && !EP_KEEP(p, j * NH + hg * HPL + h)) e = 0.f;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) acc[h * HD + d] = __builtin_fmaf(e, v[h * HD + d], acc[h * HD + d]);
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < HPL; ++h) {
-        const float inv = (kDrop ? dc.inv : 1.0f) / sm[h];
-#pragma unroll
-        for (int d = 0; d < HD; ++d) acc[h * HD + d] *= inv;
-    }
-    ep_store(ATT + (size_t)(base + p) * tD + hg * DPL, acc, 1.0f);
 }
 
 // backward of the same attention: dQKV[r] = [dQ | dK | dV] for every row of the episode.
-//   phase A (lane = query p):  scores -> soft-max statistics (m, 1/sum) -> dot = sum_j P dP -> dS = P (dP - dot) into the strip, dQ
-//   phase B (lane = key j):    dK[j] = sum_{p >= j} dS[p, j] q[p] scale,  dV[j] = sum_{p >= j} PM[p, j] dATT[p], queries in order; P is
-//                              recomputed from the statistics of phase A (one strip instead of two keeps four episodes per CU)
+//   phase A (lane = two queries):  scores -> soft-max statistics (m, 1/sum) -> dot = sum_j P dP -> dS = P (dP - dot) into the strip, dQ
+//   phase B (lane = two keys):     dK[j] = sum_{p >= j} dS[p, j] q[p] scale,  dV[j] = sum_{p >= j} PM[p, j] dATT[p], queries in order; P is
+//                                  recomputed from the statistics of phase A (one strip instead of two keeps four episodes per CU)
 template <int NH, bool kDrop>
-__global__ __launch_bounds__(64 * EpGeo<NH>::NW) void attn_bwd_ep(const float* __restrict__ QKV, const float* __restrict__ dATT,
-                                                                  const int32_t* __restrict__ offsets, const int32_t* __restrict__ lens,
-                                                                  int Lp, float* __restrict__ dQKV, DropCfg dc, int layer) {
+__global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV, const float* __restrict__ dATT,
+                                                  const int32_t* __restrict__ offsets, const int32_t* __restrict__ lens, int Lp,
+                                                  float* __restrict__ dQKV, DropCfg dc, int layer) {
     using G = EpGeo<NH>;
-    constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD;
+    constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD, SL = G::SL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, len = lens[b];
     if (len <= 0) return;
-    const int lane = threadIdx.x & 63, hg = threadIdx.x >> 6;
+    const int lane = threadIdx.x, hg = lane / SL, slot = lane - hg * SL;
     const int base = offsets[b], STR = G::strip(Lp);
     float* sQKV = smem;                                  // [len][96]
     float* sdA = smem + (size_t)Lp * 96;                 // [len][32]
     float* sS = sdA + (size_t)Lp * 32;                   // [head group][query][HPL][Lp] (query stride STR): scores -> e -> dS
-    float* sM = sS + (size_t)G::NW * Lp * STR;           // [head group][query][HPL]: row max
+    float* sM = sS + (size_t)G::NW * (Lp + 1) * STR;     // [head group][query][HPL]: row max
     float* sI = sM + (size_t)NH * Lp;                    //                           1 / sum
-    ep_stage(sQKV, QKV + (size_t)base * 96, len, 96, 96, threadIdx.x, 64 * G::NW);
-    ep_stage(sdA, dATT + (size_t)base * tD, len, tD, tD, threadIdx.x, 64 * G::NW);
+    CIRS_BWG(layer == 1, 0);
+    ep_stage(sQKV, QKV + (size_t)base * 96, len, 96, 96, lane, 64);
+    ep_stage(sdA, dATT + (size_t)base * tD, len, tD, tD, lane, 64);
     __syncthreads();
-    const bool act = lane < len;
-    const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;   // q * scale * log2(e): scores in log2 units
+    CIRS_BSTAMP(40);
+    const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;
     const float dinv = kDrop ? dc.inv : 1.0f;
-    if (act) {   // ---------------- phase A: lane = query p ----------------
-        const int p = lane;
-        float* my = sS + ((size_t)hg * Lp + p) * STR;
-        float q[DPL], da[DPL];
-        ep_load(q, sQKV + (size_t)p * 96 + hg * DPL);
-        ep_load(da, sdA + (size_t)p * tD + hg * DPL);
+    // ---------------- phase A: lane = queries pA, pB ----------------
+    for (int s0 = 0; 2 * s0 < len; s0 += SL) {
+        const int pA = s0 + slot, pB = len - 1 - pA;
+        const bool actA = pA <= pB, actB = pA < pB;
+        const int rA = actA ? pA : 0, rB = actB ? pB : 0;
+        const int jn = len - s0;
+        // branch-free loops: every lane stores every step; lanes without a query write the dummy row, columns beyond a query's causal limit are never read
+        float* myA = sS + ((size_t)hg * (Lp + 1) + (actA ? pA : Lp)) * STR;
+        float* myB = sS + ((size_t)hg * (Lp + 1) + (actB ? pB : Lp)) * STR;
+        float qA[DPL], qB[DPL], daA[DPL], daB[DPL];
+        ep_load(qA, sQKV + (size_t)rA * 96 + hg * DPL);
+        ep_load(qB, sQKV + (size_t)rB * 96 + hg * DPL);
+        ep_load(daA, sdA + (size_t)rA * tD + hg * DPL);
+        ep_load(daB, sdA + (size_t)rB * tD + hg * DPL);
 #pragma unroll
-        for (int d = 0; d < DPL; ++d) q[d] *= qs;
-        float mx[HPL], sm[HPL], dot[HPL];
+        for (int d = 0; d < DPL; ++d) { qA[d] *= qs; qB[d] *= qs; }
+        float mxA[HPL], mxB[HPL], smA[HPL], smB[HPL], dotA[HPL], dotB[HPL];
 #pragma unroll
-        for (int h = 0; h < HPL; ++h) { mx[h] = -INFINITY; sm[h] = 0.f; dot[h] = 0.f; }
+        for (int h = 0; h < HPL; ++h) { mxA[h] = mxB[h] = -INFINITY; smA[h] = smB[h] = 0.f; dotA[h] = dotB[h] = 0.f; }
+        float kq[DPL], vq[DPL];
+        ep_load(kq, sQKV + 32 + hg * DPL);
 #pragma unroll 4
-        for (int j = 0; j <= p; ++j) {
-            float k[DPL];
-            ep_load(k, sQKV + (size_t)j * 96 + 32 + hg * DPL);
+        for (int j = 0; j < jn; ++j) {
+            float k[DPL];      // software pipeline: row j + 1 is requested before row j is used (the strip stores would otherwise order the loads)
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) k[d] = kq[d];
+            ep_load(kq, sQKV + (size_t)(j + 1 < jn ? j + 1 : j) * 96 + 32 + hg * DPL);
+            const bool inA = actA && j <= pA, inB = actB && j <= pB;
 #pragma unroll
             for (int h = 0; h < HPL; ++h) {
-                const float sc = ep_dot<HD>(q + h * HD, k + h * HD);
-                my[h * Lp + j] = sc;
-                mx[h] = fmaxf(mx[h], sc);
+                const float sa = ep_dot<HD>(qA + h * HD, k + h * HD), sb = ep_dot<HD>(qB + h * HD, k + h * HD);
+                myA[h * Lp + j] = sa; myB[h * Lp + j] = sb;
+                mxA[h] = inA ? fmaxf(mxA[h], sa) : mxA[h];
+                mxB[h] = inB ? fmaxf(mxB[h], sb) : mxB[h];
             }
         }
+        ep_load(vq, sQKV + 64 + hg * DPL);
 #pragma unroll 4
-        for (int j = 0; j <= p; ++j) {
+        for (int j = 0; j < jn; ++j) {
             float v[DPL];
-            ep_load(v, sQKV + (size_t)j * 96 + 64 + hg * DPL);
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) v[d] = vq[d];
+            ep_load(vq, sQKV + (size_t)(j + 1 < jn ? j + 1 : j) * 96 + 64 + hg * DPL);
+            const bool inA = actA && j <= pA, inB = actB && j <= pB;
 #pragma unroll
             for (int h = 0; h < HPL; ++h) {
-                const float e = ep_exp2(my[h * Lp + j] - mx[h]);
-                my[h * Lp + j] = e;
-                sm[h] += e;
-                float dp = ep_dot<HD>(da + h * HD, v + h * HD);
-                if (kDrop) dp = EP_KEEP(p, j * NH + hg * HPL + h) ? dp * dinv : 0.f;
-                dot[h] = __builtin_fmaf(e, dp, dot[h]);       // sum_j e dP; normalised below
+                float ea = ep_exp2(myA[h * Lp + j] - mxA[h]), eb = ep_exp2(myB[h * Lp + j] - mxB[h]);
+                ea = inA ? ea : 0.f; eb = inB ? eb : 0.f;
+                myA[h * Lp + j] = ea; myB[h * Lp + j] = eb;
+                smA[h] += ea; smB[h] += eb;
+                float dpa = ep_dot<HD>(daA + h * HD, v + h * HD), dpb = ep_dot<HD>(daB + h * HD, v + h * HD);
+                if (kDrop) {
+                    dpa = (inA && EP_KEEP(pA, j * NH + hg * HPL + h)) ? dpa * dinv : 0.f;
+                    dpb = (inB && EP_KEEP(pB, j * NH + hg * HPL + h)) ? dpb * dinv : 0.f;
+                }
+                dotA[h] = __builtin_fmaf(ea, dpa, dotA[h]);       // sum_j e dP; normalised below
+                dotB[h] = __builtin_fmaf(eb, dpb, dotB[h]);
             }
         }
-        float inv[HPL];
+        float invA[HPL], invB[HPL];
 #pragma unroll
         for (int h = 0; h < HPL; ++h) {
-            inv[h] = 1.0f / sm[h];
-            dot[h] *= inv[h];
-            sM[((size_t)hg * Lp + p) * HPL + h] = mx[h];
-            sI[((size_t)hg * Lp + p) * HPL + h] = inv[h];
+            invA[h] = 1.0f / smA[h]; invB[h] = 1.0f / smB[h];
+            dotA[h] *= invA[h]; dotB[h] *= invB[h];
+            if (actA) { sM[((size_t)hg * Lp + pA) * HPL + h] = mxA[h]; sI[((size_t)hg * Lp + pA) * HPL + h] = invA[h]; }
+            if (actB) { sM[((size_t)hg * Lp + pB) * HPL + h] = mxB[h]; sI[((size_t)hg * Lp + pB) * HPL + h] = invB[h]; }
         }
-        float dq[DPL];
+        float dqA[DPL], dqB[DPL];
 #pragma unroll
-        for (int d = 0; d < DPL; ++d) dq[d] = 0.f;
+        for (int d = 0; d < DPL; ++d) dqA[d] = dqB[d] = 0.f;
+        ep_load(kq, sQKV + 32 + hg * DPL);
+        ep_load(vq, sQKV + 64 + hg * DPL);
 #pragma unroll 4
-        for (int j = 0; j <= p; ++j) {
+        for (int j = 0; j < jn; ++j) {
             float k[DPL], v[DPL];
-            ep_load(k, sQKV + (size_t)j * 96 + 32 + hg * DPL);
-            ep_load(v, sQKV + (size_t)j * 96 + 64 + hg * DPL);
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) { k[d] = kq[d]; v[d] = vq[d]; }
+            ep_load(kq, sQKV + (size_t)(j + 1 < jn ? j + 1 : j) * 96 + 32 + hg * DPL);
+            ep_load(vq, sQKV + (size_t)(j + 1 < jn ? j + 1 : j) * 96 + 64 + hg * DPL);
+            const bool inA = actA && j <= pA, inB = actB && j <= pB;
 #pragma unroll
             for (int h = 0; h < HPL; ++h) {
-                float dp = ep_dot<HD>(da + h * HD, v + h * HD);
-                if (kDrop) dp = EP_KEEP(p, j * NH + hg * HPL + h) ? dp * dinv : 0.f;
-                const float ds = my[h * Lp + j] * inv[h] * (dp - dot[h]);
-                my[h * Lp + j] = ds;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) dq[h * HD + d] = __builtin_fmaf(ds, k[h * HD + d], dq[h * HD + d]);
-            }
-        }
-        ep_store(dQKV + (size_t)(base + p) * 96 + hg * DPL, dq, scale);
-    }
-    __syncthreads();
-    if (act) {   // ---------------- phase B: lane = key j ----------------
-        const int j = lane;
-        float kk[DPL], dK[DPL], dV[DPL];
-        ep_load(kk, sQKV + (size_t)j * 96 + 32 + hg * DPL);
-#pragma unroll
-        for (int d = 0; d < DPL; ++d) { kk[d] *= qs; dK[d] = 0.f; dV[d] = 0.f; }     // scores in log2 units, like phase A's statistics
-#pragma unroll 2
-        for (int pq = j; pq < len; ++pq) {
-            float q[DPL], da[DPL];
-            ep_load(q, sQKV + (size_t)pq * 96 + hg * DPL);
-            ep_load(da, sdA + (size_t)pq * tD + hg * DPL);
-            const size_t st = ((size_t)hg * Lp + pq);
-#pragma unroll
-            for (int h = 0; h < HPL; ++h) {
-                const float sc = ep_dot<HD>(q + h * HD, kk + h * HD);
-                float pm = ep_exp2(sc - sM[st * HPL + h]) * sI[st * HPL + h];
-                if (kDrop) pm = EP_KEEP(pq, j * NH + hg * HPL + h) ? pm * dinv : 0.f;
-                const float ds = sS[st * STR + h * Lp + j];
+                float dpa = ep_dot<HD>(daA + h * HD, v + h * HD), dpb = ep_dot<HD>(daB + h * HD, v + h * HD);
+                if (kDrop) {
+                    dpa = (inA && EP_KEEP(pA, j * NH + hg * HPL + h)) ? dpa * dinv : 0.f;
+                    dpb = (inB && EP_KEEP(pB, j * NH + hg * HPL + h)) ? dpb * dinv : 0.f;
+                }
+                float dsa = myA[h * Lp + j] * invA[h] * (dpa - dotA[h]), dsb = myB[h * Lp + j] * invB[h] * (dpb - dotB[h]);
+                dsa = inA ? dsa : 0.f; dsb = inB ? dsb : 0.f;
+                myA[h * Lp + j] = dsa; myB[h * Lp + j] = dsb;
 #pragma unroll
                 for (int d = 0; d < HD; ++d) {
-                    dK[h * HD + d] = __builtin_fmaf(ds, q[h * HD + d], dK[h * HD + d]);
-                    dV[h * HD + d] = __builtin_fmaf(pm, da[h * HD + d], dV[h * HD + d]);
+                    dqA[h * HD + d] = __builtin_fmaf(dsa, k[h * HD + d], dqA[h * HD + d]);
+                    dqB[h * HD + d] = __builtin_fmaf(dsb, k[h * HD + d], dqB[h * HD + d]);
                 }
             }
         }
-        float* o = dQKV + (size_t)(base + j) * 96 + 32 + hg * DPL;
-        ep_store(o, dK, scale);
-        ep_store(o + 32, dV, 1.0f);
+        if (actA) ep_store(dQKV + (size_t)(base + pA) * 96 + hg * DPL, dqA, scale);
+        if (actB) ep_store(dQKV + (size_t)(base + pB) * 96 + hg * DPL, dqB, scale);
     }
+    __syncthreads();
+    CIRS_BSTAMP(41);
+    // ---------------- phase B: lane = keys jA, jB ----------------
+    for (int s0 = 0; 2 * s0 < len; s0 += SL) {
+        const int jA = s0 + slot, jB = len - 1 - jA;
+        const bool actA = jA <= jB, actB = jA < jB;
+        const int rA = actA ? jA : 0, rB = actB ? jB : 0;
+        float kA[DPL], kB[DPL], dKA[DPL], dVA[DPL], dKB[DPL], dVB[DPL];
+        ep_load(kA, sQKV + (size_t)rA * 96 + 32 + hg * DPL);
+        ep_load(kB, sQKV + (size_t)rB * 96 + 32 + hg * DPL);
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) { kA[d] *= qs; kB[d] *= qs; dKA[d] = dVA[d] = dKB[d] = dVB[d] = 0.f; }   // scores in log2 units, like phase A
+        float qn[DPL], dn[DPL];
+        ep_load(qn, sQKV + (size_t)s0 * 96 + hg * DPL);
+        ep_load(dn, sdA + (size_t)s0 * tD + hg * DPL);
+#pragma unroll 4
+        for (int pq = s0; pq < len; ++pq) {          // the pass's earliest key is s0 (slot 0's key A)
+            float q[DPL], da[DPL];
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) { q[d] = qn[d]; da[d] = dn[d]; }
+            ep_load(qn, sQKV + (size_t)(pq + 1 < len ? pq + 1 : pq) * 96 + hg * DPL);
+            ep_load(dn, sdA + (size_t)(pq + 1 < len ? pq + 1 : pq) * tD + hg * DPL);
+            const size_t st = ((size_t)hg * Lp + pq), ss = ((size_t)hg * (Lp + 1) + pq) * STR;
+            const bool inA = actA && pq >= jA, inB = actB && pq >= jB;
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                const float m = sM[st * HPL + h], iv = sI[st * HPL + h];
+                float pa = ep_exp2(fminf(ep_dot<HD>(q + h * HD, kA + h * HD) - m, 0.f)) * iv;    // (beyond the causal limit the difference may be > 0: discarded below)
+                float pb = ep_exp2(fminf(ep_dot<HD>(q + h * HD, kB + h * HD) - m, 0.f)) * iv;
+                pa = inA ? pa : 0.f; pb = inB ? pb : 0.f;
+                if (kDrop) {
+                    pa = (inA && EP_KEEP(pq, jA * NH + hg * HPL + h)) ? pa * dinv : 0.f;
+                    pb = (inB && EP_KEEP(pq, jB * NH + hg * HPL + h)) ? pb * dinv : 0.f;
+                }
+                float dsa = sS[ss + h * Lp + rA], dsb = sS[ss + h * Lp + rB];
+                dsa = inA ? dsa : 0.f; dsb = inB ? dsb : 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    dKA[h * HD + d] = __builtin_fmaf(dsa, q[h * HD + d], dKA[h * HD + d]);
+                    dVA[h * HD + d] = __builtin_fmaf(pa, da[h * HD + d], dVA[h * HD + d]);
+                    dKB[h * HD + d] = __builtin_fmaf(dsb, q[h * HD + d], dKB[h * HD + d]);
+                    dVB[h * HD + d] = __builtin_fmaf(pb, da[h * HD + d], dVB[h * HD + d]);
+                }
+            }
+        }
+        if (actA) {
+            float* o = dQKV + (size_t)(base + jA) * 96 + 32 + hg * DPL;
+            ep_store(o, dKA, scale); ep_store(o + 32, dVA, 1.0f);
+        }
+        if (actB) {
+            float* o = dQKV + (size_t)(base + jB) * 96 + 32 + hg * DPL;
+            ep_store(o, dKB, scale); ep_store(o + 32, dVB, 1.0f);
+        }
+    }
+    CIRS_BSTAMP(42);
+    CIRS_BWG(layer == 1, 1);
 }
 #undef EP_KEEP
 
@@ -604,7 +696,6 @@ __global__ __launch_bounds__(64) void layer_rows_fwd(LayerFwdArgs a, DropCfg dc)
     // otherwise stacks up to nine on a CU while other CUs idle, and the slowest CU is the kernel)
     __shared__ __attribute__((aligned(16))) float sT[10 * 1024];
     CIRS_BSTAMP(0);
-    CIRS_BWG(a.layer == 1, 0);
     const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
     const int row0 = blockIdx.x * 32, row = row0 + lo;
     const bool row_ok = row < a.R;
@@ -746,7 +837,6 @@ __global__ __launch_bounds__(64) void layer_rows_fwd(LayerFwdArgs a, DropCfg dc)
         }
     }
     CIRS_BSTAMP(11);
-    CIRS_BWG(a.layer == 1, 1);
 }
 
 // slot gather + scale + positional encoding (embed_rows) + the first layer's in_proj, one wavefront per 32 rows
@@ -1415,8 +1505,8 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     const bool ep = L <= 64 && ep_bytes(true) <= 64 * 1024 && !getenv("CIRS_TRACKER_ATTN_ROWS");
 #define ATT_EP1(KERNEL, N, BWD, ...)                                                                                            \
     do {                                                                                                                        \
-        if (dc.on) hipLaunchKernelGGL((KERNEL<N, true>), dim3(B), dim3(64 * EpGeo<N>::NW), ep_bytes(BWD), s, __VA_ARGS__);       \
-        else hipLaunchKernelGGL((KERNEL<N, false>), dim3(B), dim3(64 * EpGeo<N>::NW), ep_bytes(BWD), s, __VA_ARGS__);           \
+        if (dc.on) hipLaunchKernelGGL((KERNEL<N, true>), dim3(B), dim3(64), ep_bytes(BWD), s, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((KERNEL<N, false>), dim3(B), dim3(64), ep_bytes(BWD), s, __VA_ARGS__);           \
     } while (0)
 #define ATT_EP(KERNEL, BWD, ...)                                  \
     do {                                                          \
