@@ -272,8 +272,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv(const float* __restrict__ QKV
 // The per-row kernels above give every query row its own wavefront: <= max_turn of the 64 lanes hold a key, and every wavefront re-reads
 // the keys / values of its episode from L2 (3 launches x 30 k wavefronts x ~40 dependent global loads at C3: 34 + 48 + 28 us per
 // layer).  Here a lane owns a head group of TWO queries, p and len-1-p (the causal triangle folded: every lane walks ~len keys), its keys
-// come out of LDS -- one read serves both queries and, the head groups sharing the instruction, all heads: what bounds these kernels is the
-// LDS pipe, a ds_read costs its issue cycles whether or not lanes share an address -- and soft-max statistics, dQ and the output need no
+// come out of LDS -- one read serves both queries and, the head groups sharing the instruction, all heads -- and soft-max statistics, dQ and
+// the output need no cross-lane reduction.  One wavefront per SIMD runs at ~3.7 cycles per instruction, so the loop bodies are branch-free
+// (a conditional store per query compiled to eight s_cbranch_execz blocks per iteration): every lane stores every step, lanes without a
+// query write a dummy strip row, columns beyond a query's causal limit are never read, selects do the masking.
 // cross-lane reduction.  In the second phase of the backward the lane owns two KEYS the same way (dK / dV accumulated over the later queries
 // in order).  The probabilities are not kept between the forward and the backward pass: the backward recomputes them from Q, K (cheaper
 // than 15 MB of P through HBM).  Used when max_len <= 64 and the LDS image fits 64 KB (max_len <= 50 at 4 heads); longer episodes take the
