@@ -61,7 +61,7 @@ def pmc_traffic(workload):
     return {k: int(v["bytes_per_launch"]) for k, v in z["kernels"].items()}, f"profiles/pmc_traffic.json ({z.get('taken', '?')}; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
-def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_backward=None):
+def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_backward=None, coll=None):
     from cirs_hip.engine import CirsEngine
     from cirs_hip.env import DeviceEnvTables
     from cirs_hip.synthetic import make_tables
@@ -73,7 +73,7 @@ def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_bac
                          build_dist_on_device=True)
     eng = CirsEngine(dt, wl["B"], max_turn=wl["T"], num_leave_compute=wl["N"], leave_threshold=wl["thr"], tau=wl["tau"],
                      gamma_exposure=wl["gamma_exposure"], seed=2023, world_size=world, rank=rank,
-                     dist_group=None, learner_mode=learner, dropout=dropout, tracker_backward=tracker_backward)
+                     dist_group=None, learner_mode=learner, dropout=dropout, tracker_backward=tracker_backward, coll=coll)
     return eng, tab
 
 

@@ -52,7 +52,7 @@ def unpack_records(buf: torch.Tensor, world: int, T: int, B_local: int, S: int, 
 def all_gather_records(fields: Dict[str, torch.Tensor], T: int, B_local: int, S: int, D: int, group=None, coll=None) -> Dict[str, torch.Tensor]:
     """The single collective of the data path: all-gather of the packed per-rank trajectory records (through `coll`, a
     Collectives, when given: same explicit stream ordering as the learner's collectives)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    world = getattr(coll, "world", None) or (dist.get_world_size(group) if dist.is_initialized() else 1)
     local = pack_records(fields)
     if world == 1:
         return unpack_records(local.unsqueeze(0), 1, T, B_local, S, D)
@@ -127,3 +127,31 @@ class Collectives:
             self._ordered("reduce_scatter", inp, issue)
             return
         self._ordered("reduce_scatter", inp, lambda: dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+
+class EmulatedPeers:
+    """Collectives of ONE real rank whose W - 1 peers are copies of itself (tools/emulate_world.py): all_gather tiles the local message W
+    times, all_reduce / reduce_scatter leave the local contribution in place.  Shapes, launch sequence and the per-rank kernel work of a
+    W-rank job are the real ones; the wire time of the collectives is NOT in the measurement (calls and bytes are counted like
+    Collectives does, so that it can be added from a link model)."""
+
+    def __init__(self, world: int, rank: int = 0):
+        self.world, self.rank = int(world), int(rank)
+        self.calls = {"all_reduce": 0, "reduce_scatter": 0, "all_gather": 0}
+        self.bytes = {"all_reduce": 0, "reduce_scatter": 0, "all_gather": 0}
+
+    def _count(self, kind, t):
+        self.calls[kind] += 1
+        self.bytes[kind] += t.numel() * t.element_size()
+
+    def all_reduce(self, t):
+        self._count("all_reduce", t)
+
+    def all_gather(self, out, inp):
+        self._count("all_gather", out)
+        out.view(self.world, -1).copy_(inp.reshape(1, -1).expand(self.world, -1))
+
+    def reduce_scatter(self, out, inp):
+        self._count("reduce_scatter", inp)
+        n = out.numel()
+        out.copy_(inp.reshape(-1)[self.rank * n:(self.rank + 1) * n])

@@ -70,7 +70,7 @@ class CirsEngine:
                  hidden=64, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
                  lr=1e-3, rew_norm=True, value_clip=True, norm_adv=True, seed=2023, tracker_params=None,
                  policy_params=None, dist_group=None, world_size=1, rank=0, force_gather=False, learner_mode="dp",
-                 online_reward=None, batch_size_hint=1024, dropout=0.0, tracker_backward=None, dropout_redraw=False):
+                 online_reward=None, batch_size_hint=1024, dropout=0.0, tracker_backward=None, dropout_redraw=False, coll=None):
         """dropout: probability of the tracker's five dropout sites.  0.0 (default) is the mode of every parity fixture and of
         the benchmark; 0.1 reproduces the reference's training procedure, whose tracker is never put in eval()."""
         self.device = tables.device
@@ -100,7 +100,7 @@ class CirsEngine:
         # "replicated" = every rank over all envs, no communication (default of learner "replicated": results identical to one device)
         self.tracker_backward = tracker_backward or ("replicated" if learner_mode == "replicated" else "sharded")
         assert self.tracker_backward in ("sharded", "replicated") and (learner_mode == "replicated" or self.tracker_backward == "sharded")
-        self.coll = distributed.Collectives(group=dist_group, device=self.device)
+        self.coll = coll or distributed.Collectives(group=dist_group, device=self.device)   # (coll: e.g. distributed.EmulatedPeers)
         self.env = DeviceEnv(tables, n_env, num_leave_compute=num_leave_compute, leave_threshold=leave_threshold,
                              max_turn=max_turn, tau=tau, gamma_exposure=gamma_exposure, version=version, r_decay=r_decay)
         tp = tracker_params or init_tracker_params(U, I, max_turn, seed=seed, dim_model=dim_model, dim_state=dim_state, nhead=nhead)
