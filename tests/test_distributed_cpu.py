@@ -63,3 +63,28 @@ def test_pack_unpack_single_rank_roundtrip():
     g = distributed.unpack_records(distributed.pack_records(f).unsqueeze(0), 1, T, B, S, D)
     for k, v in f.items():
         assert torch.equal(g[k], v), k
+
+
+def test_emulated_peers_tile_the_local_message_and_count_traffic():
+    """tools/emulate_world.py's stand-in for W - 1 peers: all-gather tiles the local message, reductions keep the local contribution,
+    calls and bytes are counted like Collectives does; all_gather_records takes its world size from it."""
+    import torch
+    from cirs_hip import distributed
+    from cirs_hip.distributed import EmulatedPeers
+    W = 4
+    coll = EmulatedPeers(W)
+    inp = torch.arange(6, dtype=torch.float32)
+    out = torch.zeros(W * 6)
+    coll.all_gather(out, inp)
+    assert torch.equal(out.view(W, 6), inp.expand(W, 6))
+    t = torch.ones(5); coll.all_reduce(t)
+    assert torch.equal(t, torch.ones(5))
+    shard = torch.zeros(3); coll.reduce_scatter(shard, torch.arange(12, dtype=torch.float32))
+    assert torch.equal(shard, torch.arange(3, dtype=torch.float32))
+    assert coll.calls == {"all_reduce": 1, "reduce_scatter": 1, "all_gather": 1} and coll.bytes["all_gather"] == W * 6 * 4
+    T, B, S, D = 3, 2, 20, 32
+    f = dict(obs=torch.randn(T + 1, B, S), act=torch.randint(0, 9, (T, B)), rew=torch.rand(T, B, dtype=torch.float64),
+             done=torch.zeros(T, B, dtype=torch.uint8), logp=torch.randn(T, B), value=torch.randn(T, B), ctr=torch.rand(T, B, dtype=torch.float64),
+             x_hist=torch.randn(B, T + 1, D), lens=torch.tensor([3, 2], dtype=torch.int32), users=torch.tensor([5, 7], dtype=torch.int32))
+    g = distributed.all_gather_records(f, T, B, S, D, coll=coll)
+    assert g["obs"].shape == (T + 1, W * B, S) and torch.equal(g["obs"][:, B:2 * B], f["obs"]) and g["lens"].tolist() == [3, 2] * W
