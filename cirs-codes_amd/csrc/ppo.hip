@@ -186,6 +186,8 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     float *normp;                             // [256] sum-of-squares partials
     float *dwp;                               // weight-gradient slab partials
     uint4 *wa_planes;                         // bf16 planes of Wa per item tile (wa_planes_kernel)
+    uint4 *h2z, *h2b;                         // bf16 planes of H2 in the head kernels' register order (written by trunk_adv_kernel):
+                                              // [32-row tile][12][lane] uint4, unit q of a lane = its q-th operand register quad
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
 };
 
@@ -204,6 +206,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
     f += (size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64;  // dW row slabs (one per 32 rows)
     f += (size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4;   // wa_planes
+    f += 2 * (size_t)n_pad * 96;                       // h2z, h2b: 24 uint4 per row each
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
     return f;
 }
@@ -227,6 +230,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.normp = take(1024);
     v.dwp = take((size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64);
     v.wa_planes = (uint4*)take((size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4);
+    v.h2z = (uint4*)take((size_t)n_pad * 96); v.h2b = (uint4*)take((size_t)n_pad * 96);
     v.head_ws = (void*)p;
     return v;
 }
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
                                                         const int32_t* __restrict__ idx, int mb, float* __restrict__ obs_copy,
                                                         const float* __restrict__ adv_flat, const int32_t* __restrict__ sidx,
                                                         int m_stats, int enable, float* __restrict__ red, int n_row_wgs,
-                                                        uint4* __restrict__ planes) {
+                                                        uint4* __restrict__ planes, uint4* __restrict__ h2z, uint4* __restrict__ h2b) {
     __shared__ float lds_raw[kTileN * 65];
     static_assert(kTileN * 65 >= 4 * 2 * kH, "the trunk rows use 4 x 2 x 64 floats of the same buffer");
     if ((int)blockIdx.x > n_row_wgs) {
@@ -478,6 +482,26 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
     }
     __syncthreads();
     trunk_compute(cfg, w, rows[wv][0], rows[wv][1], lane, j, h2_out, value_out, h1_out, sW1, ld1, sW2, sWc);
+    // The head kernels want H2 as bf16 planes in THEIR register order (hz: the lane's row, 8 consecutive columns per register quad; hb: 8
+    // rows of one column per quad).  Splitting here, once per row, replaces an LDS round trip + 8 split8 per wavefront in the prologue of every
+    // head workgroup (31 chunks x 8 row blocks re-split the same rows); each lane owns one element and drops its three 2-byte pieces
+    // into both layouts (same arithmetic as split_pair: same bits).
+    {
+        const float a = rows[wv][0][lane];                 // h2[j][lane] (left there by trunk_compute)
+        const uint32_t hp = cvt_pk_bf16(a, 0.f) & 0xffffu;
+        const float r1 = a - __uint_as_float(hp << 16);
+        const uint32_t mp = cvt_pk_bf16(r1, 0.f) & 0xffffu;
+        const float r2 = r1 - __uint_as_float(mp << 16);
+        const uint32_t lp = cvt_pk_bf16(r2, 0.f) & 0xffffu;
+        const int tile = j >> 5, rr = j & 31, c = lane;
+        // hz: k-step s = c / 16, lane half hi = (c / 8) & 1, element c & 7; the consumer's lane is (hi, lo = row)
+        unsigned short* z = reinterpret_cast<unsigned short*>(h2z + ((size_t)(tile * 12 + (c >> 4) * 3) * 64 + ((c >> 3) & 1) * 32 + rr)) + (c & 7);
+        z[0] = (unsigned short)hp; z[64 * 8] = (unsigned short)mp; z[2 * 64 * 8] = (unsigned short)lp;
+        // hb[c / 32][t]: element jb of the consumer lane (hi_b, lo = c % 32), accumulator row rr = acc_row(8 t + jb, hi_b)
+        const int hi_b = (rr >> 2) & 1, sb = (rr & 3) + 4 * (rr >> 3);
+        unsigned short* bq = reinterpret_cast<unsigned short*>(h2b + ((size_t)(tile * 12 + ((c >> 5) * 2 + (sb >> 3)) * 3) * 64 + hi_b * 32 + (c & 31))) + (sb & 7);
+        bq[0] = (unsigned short)hp; bq[64 * 8] = (unsigned short)mp; bq[2 * 64 * 8] = (unsigned short)lp;
+    }
 }
 
 constexpr int kTStride = 36;                 // transpose buffer row stride (floats): 16 B aligned, conflict-free b128 reads
@@ -503,7 +527,7 @@ __device__ unsigned long long g_head_prof[64];
 #endif
 __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                             const uint4* __restrict__ planes, const float* __restrict__ ba,
-                                                            const float* __restrict__ h2, ActorPartialView pv) {
+                                                            const uint4* __restrict__ h2z, ActorPartialView pv) {
     __shared__ __attribute__((aligned(16))) unsigned char sW[2][3 * kRPlaneB];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
@@ -516,25 +540,13 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
     const bool wave_ok = row0 < n_pad && row0 < mb;   // some row of this tile belongs to the minibatch
     const bool active = jr < mb;
     Planes hz[4];  // B operand: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
-    {
-        // the wave's 32 x 64 tile of H2 is 8 KB of consecutive memory: read coalesced (8 x 1 KB) and handed to the lanes through LDS
-        // (a lane reading its own 256-byte row costs 64 cache lines per load instruction, eight wavefronts per CU at once)
-        __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];
-        f32x4* st4 = reinterpret_cast<f32x4*>(sH[wv]);
-        f32x4 t8[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = row0 + 4 * q + (lane >> 4);
-            t8[q] = *reinterpret_cast<const f32x4*>(h2 + (size_t)(r < mb ? r : 0) * kH + (lane & 15) * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) st4[(4 * q + (lane >> 4)) * (kLdsStride / 4) + (lane & 15)] = t8[q];
-        __builtin_amdgcn_wave_barrier();
-        const f32x4* src = reinterpret_cast<const f32x4*>(&sH[wv][lo * kLdsStride + 8 * hi]);
+    {   // pre-split by trunk_adv_kernel in exactly this order: 12 coalesced 16-byte loads per lane, no LDS, no splits
+        const uint4* zp = h2z + (size_t)((wave_ok ? row0 : 0) >> 5) * 12 * 64 + lane;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const f32x4 p = src[4 * s4], q = src[4 * s4 + 1];
-            hz[s4] = split8(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
+            hz[s4].h = __builtin_bit_cast(bf16x8, zp[(3 * s4) * 64]);
+            hz[s4].m = __builtin_bit_cast(bf16x8, zp[(3 * s4 + 1) * 64]);
+            hz[s4].l = __builtin_bit_cast(bf16x8, zp[(3 * s4 + 2) * 64]);
         }
     }
     float run_m = -INFINITY, run_s = 0.f, run_t = 0.f;
@@ -707,41 +719,25 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     const int act = v.act[jr];
     Planes hz[4];      // B operand of ZT: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
     Planes hb[2][2];   // B operand of the dWa product: element j of k-step t = H2[row acc_row(8 t + j, hi)][32 c + lo]
-    {
-        constexpr int kHS = kH + 1;                      // odd row stride: both read patterns below are conflict-free
-        static_assert(kTileM * kHS <= kRSize, "the H2 tile borrows the wave's dWa partial-tile buffer before the first tile");
-        float* sh = sR[0][wv];
-        f32x4 t8[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = row0 + 4 * q + (lane >> 4);
-            t8[q] = *reinterpret_cast<const f32x4*>(v.h2 + (size_t)(wave_ok ? r : 0) * kH + (lane & 15) * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float* d = sh + (4 * q + (lane >> 4)) * kHS + (lane & 15) * 4;
-            d[0] = t8[q].x; d[1] = t8[q].y; d[2] = t8[q].z; d[3] = t8[q].w;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {   // both pre-split by trunk_adv_kernel in register order: 24 coalesced 16-byte loads per lane (the LDS round trip + 8 split8 of
+        // the round-2 prologue were 4.4 k of the kernel's 78 k ticks)
+        const size_t tb = (size_t)((wave_ok ? row0 : 0) >> 5) * 12 * 64 + lane;
+        const uint4* zp = v.h2z + tb;
+        const uint4* bp = v.h2b + tb;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const float* r = sh + lo * kHS + 16 * s4 + 8 * hi;
-            hz[s4] = split8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+            hz[s4].h = __builtin_bit_cast(bf16x8, zp[(3 * s4) * 64]);
+            hz[s4].m = __builtin_bit_cast(bf16x8, zp[(3 * s4 + 1) * 64]);
+            hz[s4].l = __builtin_bit_cast(bf16x8, zp[(3 * s4 + 2) * 64]);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float x0[8], x1[8];
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float* hp = sh + acc_row(8 * t + j, hi) * kHS;
-                x0[j] = hp[lo]; x1[j] = hp[32 + lo];
+            for (int t = 0; t < 2; ++t) {
+                hb[c][t].h = __builtin_bit_cast(bf16x8, bp[(3 * (2 * c + t)) * 64]);
+                hb[c][t].m = __builtin_bit_cast(bf16x8, bp[(3 * (2 * c + t) + 1) * 64]);
+                hb[c][t].l = __builtin_bit_cast(bf16x8, bp[(3 * (2 * c + t) + 2) * 64]);
             }
-            hb[0][t] = split8(x0[0], x0[1], x0[2], x0[3], x0[4], x0[5], x0[6], x0[7]);
-            hb[1][t] = split8(x1[0], x1[1], x1[2], x1[3], x1[4], x1[5], x1[6], x1[7]);
-        }
-        __builtin_amdgcn_wave_barrier();    // the buffer is first written as a partial tile at the end of iteration 0
     }
     const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
     const bool row_ok = wave_ok && jr < mb;
@@ -1689,7 +1685,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         //    batch through idx inside the kernel (v.obs keeps the copy for d W1)
         hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
                            v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, sidx, (int)(idx_global ? mb_global : mb),
-                           (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes);
+                           (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b);
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores from the bf16 planes of Wa written by launch 1;
         //    all workgroups co-resident (2 per CU) with equal tile counts
@@ -1698,7 +1694,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);   // measured: 1 / 2 / 3 workgroups per CU = 17.4 / 14.5 / 16.7 us
         const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
         CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s,
-                                                  (const uint4*)v.wa_planes, w.ba, (const float*)v.h2, pv));
+                                                  (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, pv));
         CIRS_CHECK_LAUNCH("head_stats_kernel");
         // 4. merge + row losses + backward coefficients (means over the global minibatch)
         hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
@@ -1827,13 +1823,13 @@ extern "C" int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, flo
         CIRS_REQUIRE(stats4, "stats4 is null");
         hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
                            v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, idx, (int)mb, (int)cfg->norm_adv, v.red,
-                           (int)cdiv(n_pad, 4), v.wa_planes);
+                           (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b);
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);
         const int n_schunks = cdiv(n_item_tiles, tpc_s);
         hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s, (const uint4*)v.wa_planes, w.ba,
-                           (const float*)v.h2, pv);
+                           (const uint4*)v.h2z, pv);
         CIRS_CHECK_LAUNCH("head_stats_kernel");
         hipLaunchKernelGGL(head_tp_fold_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *batch, idx, (int)mb, n_pad, n_schunks, pv, (const float*)w.wa,
                            (const float*)w.ba, (int)item_base, I, (const float*)v.h2, stats4);
