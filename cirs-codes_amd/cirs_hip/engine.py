@@ -158,6 +158,7 @@ class CirsEngine:
         self.lengths = None
         self._gtraj = None
         self._users_pinned = None
+        self._lens_pinned = None
         # user draws: the reference uses Python's (unseeded) random.randint per env reset (kuaishouEnv.py:155-159);
         # here a seeded generator per rank
         self._user_rng = np.random.RandomState(seed * 1000003 + rank)
@@ -218,10 +219,23 @@ class CirsEngine:
     def update(self, batch_size=1024, repeat=2, perms=None):
         """policy.update(0, buffer, batch_size, repeat): process_fn + learn + tracker step (base.py:219-244)."""
         traj, x_hist, lens_d, users = self._gather()
-        lens = lens_d.cpu().numpy().astype(np.int32)   # host needs N to schedule minibatches (the only sync)
         ln = self.tp_learner if self.tp_learner is not None else self.learner
+        # The host needs N to schedule the minibatches: the only read-back of an update.  The copy is enqueued FIRST and process_fn (GAE, returns,
+        # compaction, with the row count left on the device) right behind it on the same stream; the host then waits for the copy alone, and
+        # while it computes N and enqueues the permutations and the first minibatch the GPU is already running process_fn -- instead of
+        # idling behind a synchronous copy until the host has enqueued those kernels.  (A side stream for the copy was measured too: the
+        # cross-queue waits of this runtime cost more than the bubble, 7.25 vs 6.93 ms per step.)
+        cur = torch.cuda.current_stream(self.device)
+        if self._lens_pinned is None:
+            self._lens_pinned = torch.empty(self.B_total, dtype=torch.int32).pin_memory()
+        lens_i32 = lens_d if lens_d.dtype == torch.int32 else lens_d.to(torch.int32)
+        self._lens_pinned.copy_(lens_i32, non_blocking=True)
+        done = torch.cuda.Event(); done.record(cur)
+        ln.prepare_async(traj, lens_i32)
+        done.synchronize()
+        lens = self._lens_pinned.numpy().copy()
         self._last_prepared = (traj, lens, lens_d)      # bench.py's kernel probe re-prepares the full-catalogue learner from it in tp mode
-        n = ln.prepare(traj, lens, lens_dev=lens_d)
+        n = ln.finish_prepare(lens)
         if perms is None and self.world > 1:
             # identical permutations on every rank (same key): learners stay bit-identical
             ln.perm_seed, ln.perm_tag = self.seed * 7919 + 1, self.collect_count * 64

@@ -137,6 +137,28 @@ class DeviceLearner:
                                              self._stream()), "cirs_ppo_prepare")
         return n
 
+    def prepare_async(self, traj, lens_dev: torch.Tensor):
+        """prepare() enqueued WITHOUT the host knowing the row count (cirs_ppo_prepare_async: offsets and N are formed on the device from
+        lens_dev).  The caller reads the lengths back meanwhile and completes the call with finish_prepare(lens_host)."""
+        B, T = self.n_env, self.max_turn
+        self._alloc_batch(B * T)
+        if getattr(self, "_prep_scratch", None) is None:
+            self._prep_scratch = torch.empty(B * T, dtype=torch.float64, device=self.device)
+            self._off_buf = torch.empty(B, dtype=torch.int32, device=self.device)
+            self._n_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        lens_d = lens_dev if (lens_dev.dtype == torch.int32 and lens_dev.is_contiguous()) else lens_dev.to(self.device, torch.int32).contiguous()
+        self.lens_dev, self.offsets_dev = lens_d, self._off_buf
+        abi.check(self._lib.cirs_ppo_prepare_async(C.byref(self.cfg), C.byref(traj.struct), lens_d.data_ptr(), B, T, self._off_buf.data_ptr(),
+                                                   self._n_dev.data_ptr(), self.rms_state.data_ptr(), C.byref(self.batch),
+                                                   self._prep_scratch.data_ptr(), self._stream()), "cirs_ppo_prepare_async")
+        self._prep = (traj, None, lens_dev)
+
+    def finish_prepare(self, lens_host: np.ndarray):
+        lens_host = np.asarray(lens_host, dtype=np.int32)
+        self.n_rows = int(lens_host.sum())
+        self._prep = (self._prep[0], lens_host, self._prep[2])
+        return self.n_rows
+
     def workspace(self, mb):
         need = self._lib.cirs_ppo_workspace_bytes(C.byref(self.cfg), mb)
         if self._ws is None or self._ws.numel() < need:

@@ -97,16 +97,38 @@ __global__ __launch_bounds__(256) void gae_kernel(cirs_ppo_cfg cfg, cirs_traj tr
     }
 }
 
-__global__ __launch_bounds__(256) void compact_obs_kernel(cirs_traj traj, cirs_ppo_batch out, int N, int B, int S) {
+// exclusive prefix sum of the episode lengths (the buffer offsets of the envs) + the row count, one workgroup (n_env <= 2^20)
+__global__ __launch_bounds__(1024) void offsets_kernel(const int32_t* __restrict__ lens, int B, int32_t* __restrict__ offsets, int32_t* __restrict__ n_out) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, per = (B + 1023) / 1024, b0 = tid * per, b1 = min(B, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += lens[b];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {     // inclusive scan of the per-thread sums
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int b = b0; b < b1; ++b) { offsets[b] = run; run += lens[b]; }
+    if (tid == 1023) *n_out = part[1023];
+}
+
+__global__ __launch_bounds__(256) void compact_obs_kernel(cirs_traj traj, cirs_ppo_batch out, int N_arg, int B, int S, const int32_t* __restrict__ n_dev = nullptr) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int N = n_dev ? *n_dev : N_arg;     // n_dev: the row count lives on the device (cirs_ppo_prepare_async: the host does not know it yet)
     if (i >= (long)N * S) return;
     const int row = (int)(i / S), k = (int)(i % S);
     out.obs[i] = traj.obs[((size_t)out.row_t[row] * B + out.row_env[row]) * S + k];
 }
 
 // single workgroup, fixed-order float64 reductions
-__global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const double* __restrict__ unnorm_ret, int N,
-                                                       double* __restrict__ rms_state, float* __restrict__ ret_out) {
+__global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const double* __restrict__ unnorm_ret, int N_arg,
+                                                       double* __restrict__ rms_state, float* __restrict__ ret_out,
+                                                       const int32_t* __restrict__ n_dev = nullptr) {
+    const int N = n_dev ? *n_dev : N_arg;
     __shared__ double red[1024];
     __shared__ double s_mean;
     const int tid = threadIdx.x;
@@ -1643,6 +1665,30 @@ extern "C" int cirs_ppo_prepare(const cirs_ppo_cfg* cfg, const cirs_traj* traj, 
     hipLaunchKernelGGL(returns_kernel, dim3(1), dim3(1024), 0, s, *cfg, unnorm, n_rows, rms_state, out->ret);
     CIRS_CHECK_LAUNCH("returns_kernel");
     CIRS_HIP(hipFreeAsync(unnorm, s));
+    return CIRS_OK;
+}
+
+// process_fn without a host-side row count: the offsets and N are formed on the device from the episode lengths, so the whole
+// preparation can be enqueued right behind the rollout while the host is still waiting for the lengths (the one read-back of an update
+// then overlaps with these kernels instead of leaving the GPU idle behind it).  offsets_out [n_env], n_rows_out [1]: device outputs;
+// scratch: n_env * max_turn doubles; the batch arrays must hold n_env * max_turn rows.  Same kernels as cirs_ppo_prepare: same bits.
+extern "C" int cirs_ppo_prepare_async(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, int32_t n_env, int32_t max_turn,
+                                      int32_t* offsets_out, int32_t* n_rows_out, double* rms_state, const cirs_ppo_batch* out,
+                                      double* scratch, void* stream) {
+    using namespace cirs;
+    if (int rc = validate_ppo(cfg)) return rc;
+    CIRS_REQUIRE(traj && lens && offsets_out && n_rows_out && rms_state && out && scratch, "null argument");
+    CIRS_REQUIRE(out->obs && out->act && out->adv && out->ret && out->v_s && out->logp_old && out->row_env && out->row_t, "batch pointer null");
+    CIRS_REQUIRE(n_env > 0 && n_env <= (1 << 20) && max_turn > 0, "bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, s, lens, n_env, offsets_out, n_rows_out);
+    hipLaunchKernelGGL(gae_kernel, dim3(cdiv(n_env, 64)), dim3(64), 0, s, *cfg, *traj, lens, (const int32_t*)offsets_out, n_env, cfg->dim_state,
+                       rms_state, *out, scratch);
+    const long upper = (long)n_env * max_turn;
+    hipLaunchKernelGGL(compact_obs_kernel, dim3(cdiv(upper * cfg->dim_state, 256)), dim3(256), 0, s, *traj, *out, 0, n_env, cfg->dim_state,
+                       (const int32_t*)n_rows_out);
+    hipLaunchKernelGGL(returns_kernel, dim3(1), dim3(1024), 0, s, *cfg, (const double*)scratch, 0, rms_state, out->ret, (const int32_t*)n_rows_out);
+    CIRS_CHECK_LAUNCH("cirs_ppo_prepare_async");
     return CIRS_OK;
 }
 

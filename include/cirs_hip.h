@@ -340,6 +340,12 @@ int64_t cirs_ppo_workspace_bytes(const cirs_ppo_cfg* cfg, int32_t max_minibatch)
 int cirs_ppo_prepare(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, const int32_t* offsets,
                      int32_t n_env, int32_t max_turn, int32_t n_rows, double* rms_state, const cirs_ppo_batch* out,
                      void* stream);
+/* The same preparation with the row count left on the device: offsets_out [n_env] and n_rows_out [1] are formed from `lens` by the
+   first kernel, so the call can be enqueued behind the rollout before the host has read the episode lengths (the read-back then
+   overlaps with these kernels).  scratch: n_env * max_turn doubles; `out` sized for n_env * max_turn rows.  Same results, bit for bit. */
+int cirs_ppo_prepare_async(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, int32_t n_env, int32_t max_turn,
+                           int32_t* offsets_out, int32_t* n_rows_out, double* rms_state, const cirs_ppo_batch* out, double* scratch,
+                           void* stream);
 
 /* one minibatch gradient step of learn(): forward, clipped surrogate + clipped value loss + entropy, backward,
  * clip_grad_norm_, Adam.  idx[mb] are buffer-order row ids.  opt_step = optimiser steps taken so far.

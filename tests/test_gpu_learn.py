@@ -45,6 +45,25 @@ def make_learner(pp, I, B, T, hyper, dual_clip=None):
     return ln, views
 
 
+def test_prepare_with_the_row_count_left_on_the_device_is_bit_identical(golden_dir):
+    """cirs_ppo_prepare_async (offsets and N formed on the device, enqueued before the host has the episode lengths) == cirs_ppo_prepare."""
+    from cirs_hip.rollout import Trajectory
+    z, tp, pp, perms = load_learn(golden_dir)
+    U, I, B, T = [int(v) for v in z["dims"]]
+    lens, obs_bts = z["lens"], z["obs"]
+    value, logp = rollout_time_value_logp(pp, obs_bts, np.maximum(z["acts"], 0), lens)
+    traj = Trajectory(B, T, 20, "cuda")
+    upload_traj(traj, z["acts"], z["rews"], z["dones"], lens, obs_bts, value, logp)
+    a, _ = make_learner(pp, I, B, T, z["hyper"])
+    b, _ = make_learner(pp, I, B, T, z["hyper"])
+    n = a.prepare(traj, lens)
+    b.prepare_async(traj, torch.as_tensor(lens.astype(np.int32)).cuda())
+    assert b.finish_prepare(lens) == n and int(b._n_dev.cpu()) == n
+    for name in ("b_obs", "b_act", "b_adv", "b_ret", "b_vs", "b_logp", "b_env", "b_t"):
+        assert torch.equal(getattr(a, name)[:n], getattr(b, name)[:n]), name
+    assert torch.equal(a.rms_state, b.rms_state) and torch.equal(a.offsets_dev, b.offsets_dev)
+
+
 def test_learner_dual_clip_and_recomputed_advantages_match_reference(golden_dir):
     """PPOPolicy(dual_clip=1.01, recompute_advantage=1) recorded from the reference (learn_opts.npz): the device learner with
     cfg.dual_clip and learn(recompute_adv=True) -- cirs_critic_values over the stored states + cirs_ppo_prepare before the second repeat."""
