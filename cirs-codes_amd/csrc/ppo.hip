@@ -294,6 +294,49 @@ __device__ __forceinline__ void adv_stats_block(const float* __restrict__ adv_fl
     if (tid == 0) { red[0] = mean; red[1] = sqrtf(sh[0] / (float)(m - 1)); }
 }
 
+// One minibatch row's loss terms and backward coefficients (ppo.py:183-212) from its logit statistics: z = logit of the taken action,
+// lse = log-sum-exp, ez = E_p[z].  Shared by head_stats_merge_kernel (item-sharded learner) and the prologue of head_bwd_fused_kernel.
+struct RowTerms { float clip_row, c_logp, vf_row, dvalue, c_ent, h_ent; };
+__device__ __forceinline__ RowTerms ppo_row_terms(const cirs_ppo_cfg& cfg, float z, float lse, float ez, float logp_old, float adv, float adv_mean,
+                                                  float adv_std, float val, float vs, float ret, float inv_mb) {
+    RowTerms o;
+    const float eps = 1.1920928955078125e-7f;
+    const float praw = __expf(z - lse);
+    const bool clamped = praw < eps || praw > 1.0f - eps;  // probs_to_logits clamp blocks the gradient
+    const float logp = __logf(fminf(fmaxf(praw, eps), 1.0f - eps));
+    const float ratio = __expf(logp - logp_old);
+    const float A = (adv - adv_mean) / adv_std;            // per-minibatch advantage normalisation (ppo.py:184-186)
+    const float s1 = ratio * A;
+    const float s2 = fminf(fmaxf(ratio, 1.0f - cfg.eps_clip), 1.0f + cfg.eps_clip) * A;
+    float surr = fminf(s1, s2);
+    // d(-min(s1,s2))/d logp: s1 path when s1 <= s2 (a tie passes the full gradient), else clamp blocks it
+    float c_logp = (s1 <= s2 && !clamped) ? -inv_mb * A * ratio : 0.f;
+    if (cfg.dual_clip > 0.f) {   // -max(min(s1, s2), dual_clip * A) (core/policy/ppo.py:190-193): the constant branch has no gradient
+        const float dcl = cfg.dual_clip * A;
+        if (dcl > surr) { surr = dcl; c_logp = 0.f; }
+        else if (dcl == surr) c_logp *= 0.5f;                // torch.max splits the gradient of a tie
+    }
+    o.clip_row = -surr;
+    o.c_logp = c_logp;
+    const float d1 = ret - val;
+    float vf = d1 * d1, dv = -2.0f * d1;
+    if (cfg.value_clip) {
+        const float dlt = val - vs;
+        const float vclip = vs + fminf(fmaxf(dlt, -cfg.eps_clip), cfg.eps_clip);
+        const float d2 = ret - vclip;
+        const float vf2 = d2 * d2;
+        const float dv2 = (dlt >= -cfg.eps_clip && dlt <= cfg.eps_clip) ? -2.0f * d2 : 0.f;
+        if (vf2 > vf) { vf = vf2; dv = dv2; }
+        else if (vf2 == vf) dv = 0.5f * (dv + dv2);  // torch.max splits ties
+    }
+    o.vf_row = vf;
+    o.dvalue = cfg.vf_coef * inv_mb * dv;
+    // entropy gradient coefficient: dL/dz_i += c_ent * p_i * (z_i - lse + H), H = lse - E_p[z]
+    o.c_ent = cfg.ent_coef * inv_mb;
+    o.h_ent = lse - ez;
+    return o;
+}
+
 // One wavefront per minibatch row: merge the head-stats partials (lse, E_p[z]), recompute the taken action's logit
 // with the MFMA k-order, then (lane 0) the row's loss terms and backward coefficients (ppo.py:183-212).  Rows are read
 // from the buffer-order batch through idx (no separate gather pass); padded rows get neutral coefficients.
@@ -368,42 +411,10 @@ __global__ __launch_bounds__(256) void head_stats_merge_kernel(cirs_ppo_cfg cfg,
     v.act[j] = a - item_base;
     v.dst_row[j] = (long)b.row_t[src] * n_env + b.row_env[src];
     // ---- row losses + backward coefficients; every mean is over the (global) minibatch of mb_norm rows --------------
-    const float inv_mb = 1.0f / (float)mb_norm;
-    const float eps = 1.1920928955078125e-7f;
-    const float praw = __expf(z - lse);
-    const bool clamped = praw < eps || praw > 1.0f - eps;  // probs_to_logits clamp blocks the gradient
-    const float logp = __logf(fminf(fmaxf(praw, eps), 1.0f - eps));
-    const float ratio = __expf(logp - b.logp_old[src]);
-    const float A = (b.adv[src] - v.red[0]) / v.red[1];    // per-minibatch advantage normalisation (ppo.py:184-186)
-    const float s1 = ratio * A;
-    const float s2 = fminf(fmaxf(ratio, 1.0f - cfg.eps_clip), 1.0f + cfg.eps_clip) * A;
-    float surr = fminf(s1, s2);
-    // d(-min(s1,s2))/d logp: s1 path when s1 <= s2 (a tie passes the full gradient), else clamp blocks it
-    float c_logp = (s1 <= s2 && !clamped) ? -inv_mb * A * ratio : 0.f;
-    if (cfg.dual_clip > 0.f) {   // -max(min(s1, s2), dual_clip * A) (core/policy/ppo.py:190-193): the constant branch has no gradient
-        const float dcl = cfg.dual_clip * A;
-        if (dcl > surr) { surr = dcl; c_logp = 0.f; }
-        else if (dcl == surr) c_logp *= 0.5f;                // torch.max splits the gradient of a tie
-    }
-    v.clip_row[j] = -surr;
-    v.c_logp[j] = c_logp;
-    const float val = v.value[j], vs = b.v_s[src], ret = b.ret[src];
-    const float d1 = ret - val;
-    float vf = d1 * d1, dv = -2.0f * d1;
-    if (cfg.value_clip) {
-        const float dlt = val - vs;
-        const float vclip = vs + fminf(fmaxf(dlt, -cfg.eps_clip), cfg.eps_clip);
-        const float d2 = ret - vclip;
-        const float vf2 = d2 * d2;
-        const float dv2 = (dlt >= -cfg.eps_clip && dlt <= cfg.eps_clip) ? -2.0f * d2 : 0.f;
-        if (vf2 > vf) { vf = vf2; dv = dv2; }
-        else if (vf2 == vf) dv = 0.5f * (dv + dv2);  // torch.max splits ties
-    }
-    v.vf_row[j] = vf;
-    v.dvalue[j] = cfg.vf_coef * inv_mb * dv;
-    // entropy gradient coefficient: dL/dz_i += c_ent * p_i * (z_i - lse + H), H = lse - E_p[z]
-    v.c_ent[j] = cfg.ent_coef * inv_mb;
-    v.h_ent[j] = lse - t / s;
+    const RowTerms rt = ppo_row_terms(cfg, z, lse, t / s, b.logp_old[src], b.adv[src], v.red[0], v.red[1], v.value[j], b.v_s[src], b.ret[src],
+                                      1.0f / (float)mb_norm);
+    v.clip_row[j] = rt.clip_row; v.c_logp[j] = rt.c_logp; v.vf_row[j] = rt.vf_row; v.dvalue[j] = rt.dvalue;
+    v.c_ent[j] = rt.c_ent; v.h_ent[j] = rt.h_ent;
 }
 
 __device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c_ent, float h_ent, bool is_act, float& p_out) {
@@ -454,7 +465,9 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
                                                         const int32_t* __restrict__ idx, int mb, float* __restrict__ obs_copy,
                                                         const float* __restrict__ adv_flat, const int32_t* __restrict__ sidx,
                                                         int m_stats, int enable, float* __restrict__ red, int n_row_wgs,
-                                                        uint4* __restrict__ planes, uint4* __restrict__ h2z, uint4* __restrict__ h2b) {
+                                                        uint4* __restrict__ planes, uint4* __restrict__ h2z, uint4* __restrict__ h2b,
+                                                        cirs_ppo_batch bt, int n_env, int32_t* __restrict__ act_out, long* __restrict__ dst_out,
+                                                        float* __restrict__ row4 /* [4][n_pad]: adv, logp_old, ret, v_s of the minibatch rows */) {
     __shared__ float lds_raw[kTileN * 65];
     static_assert(kTileN * 65 >= 4 * 2 * kH, "the trunk rows use 4 x 2 x 64 floats of the same buffer");
     if ((int)blockIdx.x > n_row_wgs) {
@@ -501,6 +514,16 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
     if (lane < S) {
         rows[wv][0][lane] = x;
         obs_copy[(size_t)j * S + lane] = x;
+    }
+    if (act_out) {   // the row's action, its row of the [T+1, B] tracker-gradient tensor and its four scalars in minibatch order (what the merge
+                     // kernel used to gather through idx: the backward kernel's prologue reads them coalesced, without a dependent round trip)
+        if (lane == 0) {
+            act_out[j] = j < mb ? bt.act[ri] : 0;
+            dst_out[j] = j < mb ? (long)bt.row_t[ri] * n_env + bt.row_env[ri] : 0;
+        } else if (lane <= 4) {
+            const float* srcp = lane == 1 ? bt.adv : lane == 2 ? bt.logp_old : lane == 3 ? bt.ret : bt.v_s;
+            row4[(size_t)(lane - 1) * n_pad + j] = j < mb ? srcp[ri] : 0.f;
+        }
     }
     __syncthreads();
     trunk_compute(cfg, w, rows[wv][0], rows[wv][1], lane, j, h2_out, value_out, h1_out, sW1, ld1, sW2, sWc);
@@ -549,7 +572,8 @@ __device__ unsigned long long g_head_prof[64];
 #endif
 __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                             const uint4* __restrict__ planes, const float* __restrict__ ba,
-                                                            const uint4* __restrict__ h2z, ActorPartialView pv) {
+                                                            const uint4* __restrict__ h2z, ActorPartialView pv,
+                                                            const int32_t* __restrict__ act_rows, float* __restrict__ za_out) {
     __shared__ __attribute__((aligned(16))) unsigned char sW[2][3 * kRPlaneB];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
@@ -572,6 +596,11 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
         }
     }
     float run_m = -INFINITY, run_s = 0.f, run_t = 0.f;
+    // the logit of the row's taken action is one of this kernel's accumulator values (in exactly one chunk, tile, lane half): it is kept
+    // for the backward kernel's prologue, which then needs neither the head row of the action nor a 64-term chain
+    const int act_r = (act_rows && active) ? act_rows[jr] : -1;
+    float za_val = 0.f;
+    bool za_have = false;
     const int first_tile = chunk * tiles_per_chunk * kTileN;
     const int n_tiles = max(0, min(tiles_per_chunk, (I - first_tile + kTileN - 1) / kTileN));
     const int dst_r = (tid >> 3) * kRowB + (tid & 7) * 16;
@@ -617,6 +646,17 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc = mfma_bf16x6(za[s4], hz[s4], acc);
             if (it == 2) CIRS_SSTAMP(45);
+            {
+                const int arel = act_r - tile0;
+                const bool mine = act_r >= 0 && arel >= 0 && arel < kTileN && ((arel >> 2) & 1) == hi;
+                if (__any(mine)) {       // (wave-uniform: most tiles hold no action of the wave's rows)
+                    const int rsel = (arel & 3) + 4 * (arel >> 3);
+                    float zsel = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) zsel = rsel == r ? acc[r] : zsel;
+                    if (mine) { za_val = zsel; za_have = true; }
+                }
+            }
             // log-sum-exp per tile: the lane's maximum first, then ONE rescale of the running sums and one exp per element;
             // items beyond I (last tile only) carry -inf and add exp(-inf) = 0
             f32x16 zt = acc;
@@ -667,6 +707,7 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
         const size_t po = (size_t)chunk * n_pad + jr;
         pv.score[po] = run_t; pv.m[po] = run_m; pv.s[po] = run_s;
     }
+    if (za_have) za_out[jr] = za_val;
 }
 
 // ---- head backward (fused): dWa, dba, d h2, entropy correction ------------------------------------------------
@@ -711,11 +752,16 @@ __device__ __forceinline__ void mfma_bf16x6_two(const Planes& a0, const Planes& 
 
 // kEnt: the entropy term of dZ is compiled in (ent_coef != 0); the reference's scripts train with ent_coef = 0 (CIRS-RL-kuaishou.py:97),
 // where dZ = c_logp (delta - p) and the entropy is only reported.
-template <bool kEnt>
+// kMerge: the merge of the head-statistics partials and the row's loss terms / backward coefficients run in THIS kernel's prologue (every
+// workgroup for its own rows, the workgroups of chunk 0 store what later kernels read) instead of a launch of their own between the two head
+// kernels: a 6.5 us launch on the critical path of every minibatch step becomes ~1.5 us of prologue.  The item-sharded learner keeps the
+// merge kernel (its statistics cross the ranks first).
+struct HeadMergeArgs { cirs_ppo_cfg cfg; cirs_ppo_batch b; const int32_t* idx; int mb_norm, n_schunks; ActorPartialView pv; };
+template <bool kEnt, bool kMerge>
 __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                                          const uint4* __restrict__ planes,
                                                                          const float* __restrict__ ba, MbView v,
-                                                                         float* __restrict__ dwap) {
+                                                                         float* __restrict__ dwap, HeadMergeArgs ma) {
     constexpr int kThreads = kBwdWaves * 64;
     static_assert(kThreads == 256, "the plane staging maps one 16-byte unit per thread and plane");
     __shared__ __attribute__((aligned(16))) unsigned char sW[2][kWBufB];
@@ -737,7 +783,6 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     // LDS -- a lane reading its own 256-byte row costs 64 cache lines per load instruction (the prologue was 6.1 k of the kernel's
     // 77 k ticks).  The row scalars are requested first; they travel while the tile does.
     const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-    const float lse = v.lse[jr], c_logp = v.c_logp[jr], c_ent = kEnt ? v.c_ent[jr] : 0.f, h_ent = kEnt ? v.h_ent[jr] : 0.f;
     const int act = v.act[jr];
     Planes hz[4];      // B operand of ZT: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
     Planes hb[2][2];   // B operand of the dWa product: element j of k-step t = H2[row acc_row(8 t + j, hi)][32 c + lo]
@@ -761,7 +806,6 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 hb[c][t].l = __builtin_bit_cast(bf16x8, bp[(3 * (2 * c + t) + 2) * 64]);
             }
     }
-    const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
     const bool row_ok = wave_ok && jr < mb;
     f32x16 dh0, dh1;
 #pragma unroll
@@ -797,8 +841,69 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         *reinterpret_cast<uint4*>(base_ + 2 * kCPlaneB + dst_c) = gc2;                                     \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
+    // the first tile's planes and the H2 planes above are on their way while the row statistics are merged
+    if (n_tiles > 0) CIRS_ISSUE(first_tile);
+    float lse, c_logp, c_ent, h_ent;
+    if (!kMerge) {
+        lse = v.lse[jr]; c_logp = v.c_logp[jr]; c_ent = kEnt ? v.c_ent[jr] : 0.f; h_ent = kEnt ? v.h_ent[jr] : 0.f;
+    } else {
+        // lane (row lo, half hi) folds every second chunk partial of its row -- first the maxima, then the sums against the row maximum: two
+        // batches of independent, unconditional, coalesced loads -- and the halves meet by one shuffle
+        const bool real = wave_ok && jr < mb;
+        const int jc = real ? jr : 0;
+        // v.adv / v.ret / v.v_s / v.logp_old are consecutive [n_pad] arrays filled by trunk_adv_kernel in minibatch order
+        const float za = v.za[jc], adv = v.adv[jc], lpo = v.adv[n_pad + jc], ret = v.adv[2 * (size_t)n_pad + jc], vs = v.adv[3 * (size_t)n_pad + jc],
+                    val = v.value[jc];
+        const float red0 = v.red[0], red1 = v.red[1];
+        // the chunk partials (m, s, t) of the row, 32 per lane half and batch, ALL requested before the first is used (a plain loop waits for
+        // every load: 56 dependent round trips were 13 us of prologue); indices beyond the last chunk are clamped and weighted 0
+        const int nsc = ma.n_schunks;
+        const float* __restrict__ pm_ = ma.pv.m + jc;
+        const float* __restrict__ ps_ = ma.pv.s + jc;
+        const float* __restrict__ pt_ = ma.pv.score + jc;
+        float M = -INFINITY, ssum = 0.f, tsum = 0.f;
+        for (int cb = 0; cb < nsc; cb += 64) {          // (wave-uniform trip count: the two halves meet in a shuffle inside)
+            const int c0 = cb + hi;
+            float m32[32], s32[32], u32[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int c = c0 + 2 * q;
+                const size_t o = (size_t)(c < nsc ? c : nsc - 1) * n_pad;
+                m32[q] = pm_[o]; s32[q] = ps_[o]; u32[q] = pt_[o];
+            }
+            float mb_ = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) mb_ = fmaxf(mb_, m32[q]);
+            mb_ = fmaxf(mb_, __shfl_xor(mb_, 32, CIRS_WAVE));      // both halves rescale to the same maximum
+            const float Mn = fmaxf(M, mb_);
+            const float keep = __expf(M - Mn);                     // first batch: exp(-inf) = 0
+            ssum *= keep; tsum *= keep;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const float f = c0 + 2 * q < nsc ? __expf(m32[q] - Mn) : 0.f;     // (-inf, 0, 0) partials of chunks beyond the catalogue: f = 0
+                ssum = __builtin_fmaf(s32[q], f, ssum);
+                tsum = __builtin_fmaf(u32[q], f, tsum);
+            }
+            M = Mn;
+        }
+        ssum += __shfl_xor(ssum, 32, CIRS_WAVE);
+        tsum += __shfl_xor(tsum, 32, CIRS_WAVE);
+        const float lse_r = M + __logf(ssum);
+        const RowTerms rt = ppo_row_terms(ma.cfg, za, lse_r, tsum / ssum, lpo, adv, red0, red1, val, vs, ret, 1.0f / (float)ma.mb_norm);
+        lse = real ? lse_r : 1e30f;          // rows beyond the minibatch: p = exp(z - lse) = 0, neutral coefficients (as the merge kernel writes)
+        c_logp = real ? rt.c_logp : 0.f;
+        c_ent = (kEnt && real) ? rt.c_ent : 0.f;
+        h_ent = (kEnt && real) ? rt.h_ent : 0.f;
+        if (blockIdx.x == 0 && hi == 0 && wave_ok) {      // one writer per row: what trunk_bwd_kernel and the loss sums read
+            v.dvalue[jr] = real ? rt.dvalue : 0.f;
+            v.clip_row[jr] = real ? rt.clip_row : 0.f;
+            v.vf_row[jr] = real ? rt.vf_row : 0.f;
+            v.h_ent[jr] = real ? rt.h_ent : 0.f;       // the reported entropy (dh2_sum_kernel: ent_row = h_ent + clamp correction)
+        }
+    }
+    const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
     CIRS_SSTAMP(31);
-    if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
+    if (n_tiles > 0) CIRS_COMMIT(0);
     __syncthreads();
     CIRS_SSTAMP(32);
     float* slab = dwap + (size_t)blockIdx.y * dwa_slab_stride(I);
@@ -1731,7 +1836,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         //    batch through idx inside the kernel (v.obs keeps the copy for d W1)
         hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
                            v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, sidx, (int)(idx_global ? mb_global : mb),
-                           (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b);
+                           (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b, *batch, (int)n_env, v.act, v.dst_row, v.adv);
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores from the bf16 planes of Wa written by launch 1;
         //    all workgroups co-resident (2 per CU) with equal tile counts
@@ -1740,22 +1845,27 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);   // measured: 1 / 2 / 3 workgroups per CU = 17.4 / 14.5 / 16.7 us
         const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
         CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s,
-                                                  (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, pv));
+                                                  (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, pv, (const int32_t*)v.act, v.za));
         CIRS_CHECK_LAUNCH("head_stats_kernel");
-        // 4. merge + row losses + backward coefficients (means over the global minibatch)
-        hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
-                           (int)(idx_global ? mb_global : mb), n_pad, n_schunks, (int)n_env, pv, w.wa, w.ba, v, (const float*)nullptr, 0);
-        CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
-        // 5. head backward
+        // 4+5. head backward; the merge of the statistics partials + row losses + backward coefficients (means over the global minibatch) run in
+        // its prologue (CIRS_PPO_MERGE_KERNEL=1: as a launch of their own, the round-2 sequence, for A/B runs)
+        static const bool merge_launch = getenv("CIRS_PPO_MERGE_KERNEL") && atoi(getenv("CIRS_PPO_MERGE_KERNEL")) != 0;
+        const HeadMergeArgs hma{*cfg, *batch, idx, (int)(idx_global ? mb_global : mb), n_schunks, pv};
+        if (merge_launch) {
+            hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
+                               (int)(idx_global ? mb_global : mb), n_pad, n_schunks, (int)n_env, pv, w.wa, w.ba, v, (const float*)nullptr, 0);
+            CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
+        }
         // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
         const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
         const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
+        const dim3 bgrid((n_bchunks + 7) & ~7, n_slabs), bblock(kBwdWaves * 64);
         if (cfg->ent_coef != 0.f) {
-            CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel<true>, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
-                                                      (const uint4*)v.wa_planes, w.ba, v, v.dwap));
+            if (merge_launch) CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, false>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
+            else CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, true>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
         } else {
-            CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_bwd_fused_kernel<false>, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
-                                                      (const uint4*)v.wa_planes, w.ba, v, v.dwap));
+            if (merge_launch) CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, false>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
+            else CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, true>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
         }
         CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
         // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
@@ -1869,13 +1979,13 @@ extern "C" int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, flo
         CIRS_REQUIRE(stats4, "stats4 is null");
         hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
                            v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, idx, (int)mb, (int)cfg->norm_adv, v.red,
-                           (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b);
+                           (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b, *batch, (int)n_env, (int32_t*)nullptr, (long*)nullptr, (float*)nullptr);
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);
         const int n_schunks = cdiv(n_item_tiles, tpc_s);
         hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s, (const uint4*)v.wa_planes, w.ba,
-                           (const uint4*)v.h2z, pv);
+                           (const uint4*)v.h2z, pv, (const int32_t*)nullptr, (float*)nullptr);
         CIRS_CHECK_LAUNCH("head_stats_kernel");
         hipLaunchKernelGGL(head_tp_fold_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *batch, idx, (int)mb, n_pad, n_schunks, pv, (const float*)w.wa,
                            (const float*)w.ba, (int)item_base, I, (const float*)v.h2, stats4);
@@ -1895,12 +2005,13 @@ extern "C" int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, flo
         CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
         const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
         const int n_bchunks = cdiv(n_item_tiles, tpc);
+        const HeadMergeArgs no_merge{};    // the row coefficients come from head_stats_merge_kernel above (statistics of every shard)
         if (cfg->ent_coef != 0.f) {
-            hipLaunchKernelGGL(head_bwd_fused_kernel<true>, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
-                               (const uint4*)v.wa_planes, w.ba, v, v.dwap);
+            hipLaunchKernelGGL((head_bwd_fused_kernel<true, false>), dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
+                               (const uint4*)v.wa_planes, w.ba, v, v.dwap, no_merge);
         } else {
-            hipLaunchKernelGGL(head_bwd_fused_kernel<false>, dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
-                               (const uint4*)v.wa_planes, w.ba, v, v.dwap);
+            hipLaunchKernelGGL((head_bwd_fused_kernel<false, false>), dim3((n_bchunks + 7) & ~7, n_slabs), dim3(kBwdWaves * 64), 0, s, I, mb, n_pad, tpc,
+                               (const uint4*)v.wa_planes, w.ba, v, v.dwap, no_merge);
         }
         CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
         CIRS_HIP(hipMemsetAsync(red_slots, 0, sizeof(float) * (size_t)world * kWaSumBlocks, s));

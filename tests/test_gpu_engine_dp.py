@@ -136,7 +136,9 @@ def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs, mod
     ref_losses, ref_n = ref.update(bs, 2, perms=perms)
     assert ref_n == n_total
     np.testing.assert_allclose(results[0][0].cpu().numpy(), ref_losses.cpu().numpy(), rtol=3e-4, atol=3e-5)
-    np.testing.assert_allclose(engines[0].policy_flat.cpu().numpy(), ref.policy_flat.cpu().numpy(), rtol=3e-4, atol=3e-6)
+    # (tp: the item-sharded learner takes the action's logit from a scalar fp32 chain on the owning shard, the single-device step from the
+    #  bf16x6 accumulator of its statistics kernel -- 1e-7 apart, which Adam turns into a few 1e-6 on near-zero gradients)
+    np.testing.assert_allclose(engines[0].policy_flat.cpu().numpy(), ref.policy_flat.cpu().numpy(), rtol=3e-4, atol=8e-6 if mode == "tp" else 3e-6)
     got_t, want_t = engines[0].tracker_flat.cpu().numpy(), ref.tracker_flat.cpu().numpy()
     # Adam turns tiny gradient differences into +-lr steps where the gradient is ~0 (cf. the key-bias note in DESIGN.md):
     # compare where the reference actually moved a parameter by a clear margin
