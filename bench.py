@@ -520,7 +520,7 @@ def main():
         t_bwd = t_k["head_bwd_fused_kernel"]
         flop_bwd = 4.0 * mb * I * H
         exec_bwd = 6.0 * mb * I * H
-        # whole minibatch step (8 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
+        # whole minibatch step (7 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
         flop_step = 6.0 * mb * (S * H + H * H + H * I)
         exec_step = 8.0 * mb * I * H + 6.0 * mb * (S * H + H * H)
         out = {
@@ -550,13 +550,14 @@ def main():
                          "achieved_executed": exec_bwd / t_bwd / 1e12, "frac_executed": exec_bwd / t_bwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          "algorithmic_flop_per_launch": flop_bwd, "traffic": None, "seconds_per_launch": t_bwd, "rows": mb,
                          "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (cirs_prof_start/stop)",
+                         "kernel_note": "since round 3 the kernel's prologue also merges the head-statistics partials of its rows and forms their loss terms / backward coefficients (~2.5 us that replace a 6.5 us launch): its duration includes that work, the algorithmic flop count does not",
                          "peak_note": "fp32 MFMA dense peak: the kernel's results are fp32-accurate (DESIGN.md section 4); its 6x expanded bf16 flops are exec_bf16_flop_per_launch",
                          "exec_bf16_flop_per_launch": 6.0 * exec_bwd},
-            "minibatch_step": {"seconds": t_mb, "launches": 8, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
+            "minibatch_step": {"seconds": t_mb, "launches": 7, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
                                "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "traffic": None,
                                "head_stats_kernel_seconds": t_k["head_stats_kernel"],
-                               "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel + 6 small kernels"},
+                               "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel (whose prologue also merges the statistics partials and forms the row loss terms: a launch of its own until round 3) + 5 small kernels"},
         }
         # HBM traffic per launch from the committed PMC passes -- only when they were taken on exactly these kernel sources
         traffic, src = pmc_traffic(args.workload)
