@@ -59,6 +59,12 @@ def main():
                     src = eng.policy_views[k]
                     v.copy_(src[eng.tp_base:eng.tp_base + eng.tp_Il] if k.startswith("actor.last") else src)
                 eng._publish_tp = lambda: None   # (its all-gather would tile rank 0's shard over the whole head)
+            # the emulated reductions only carry rank 0's share, which would let the dp / tp policies drift (shorter episodes, other row counts):
+            # the timing runs keep the trained policy (learning rate 0: same kernels, same launches)
+            for ln in (eng.learner, eng.tp_learner):
+                if ln is not None:
+                    ln.cfg.lr = 0.0
+            eng.tracker.lr = 0.0
             t, rows = timed(eng, args.steps, args.warmup)
             c0 = {k: v for k, v in coll.calls.items()}; b0 = {k: v for k, v in coll.bytes.items()}
             n_upd = args.steps + args.warmup
