@@ -1849,7 +1849,8 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         CIRS_CHECK_LAUNCH("head_stats_kernel");
         // 4+5. head backward; the merge of the statistics partials + row losses + backward coefficients (means over the global minibatch) run in
         // its prologue (CIRS_PPO_MERGE_KERNEL=1: as a launch of their own, the round-2 sequence, for A/B runs)
-        static const bool merge_launch = getenv("CIRS_PPO_MERGE_KERNEL") && atoi(getenv("CIRS_PPO_MERGE_KERNEL")) != 0;
+        const char* mk_ = getenv("CIRS_PPO_MERGE_KERNEL");      // (read per call: tests toggle it)
+        const bool merge_launch = mk_ && atoi(mk_) != 0;
         const HeadMergeArgs hma{*cfg, *batch, idx, (int)(idx_global ? mb_global : mb), n_schunks, pv};
         if (merge_launch) {
             hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,

@@ -64,6 +64,43 @@ def test_prepare_with_the_row_count_left_on_the_device_is_bit_identical(golden_d
     assert torch.equal(a.rms_state, b.rms_state) and torch.equal(a.offsets_dev, b.offsets_dev)
 
 
+def test_merge_in_the_backward_prologue_equals_the_merge_launch(golden_dir, monkeypatch):
+    """The 7-launch minibatch step (statistics partials merged in head_bwd_fused_kernel's prologue, the action's logit from head_stats_kernel's
+    accumulator) against the round-2 sequence with head_stats_merge_kernel as a launch of its own (CIRS_PPO_MERGE_KERNEL=1: scalar fp32 chain for
+    the action's logit): same losses and parameters to fp32 round-off, on the reference-recorded case and at the benchmark's catalogue size."""
+    from cirs_hip.rollout import Trajectory
+    import policycase
+    z, tp, pp, perms = load_learn(golden_dir)
+    U, I, B, T = [int(v) for v in z["dims"]]
+    cases = [(pp, I, B, T, z["lens"], z["obs"], np.maximum(z["acts"], 0), z["acts"], z["rews"], z["dones"], z["hyper"], perms)]
+    rng = np.random.RandomState(5)
+    I2, B2, T2 = 10728, 96, 30
+    arrs = policycase.random_weights(rng, I2, head_scale=1.5)
+    pp2 = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)) for k, v in arrs.items()}
+    lens2 = rng.randint(10, T2 + 1, size=B2)
+    acts2 = rng.randint(0, I2, (B2, T2)); rews2 = rng.uniform(0, 1, (B2, T2))
+    dones2 = np.zeros((B2, T2), bool); dones2[np.arange(B2), lens2 - 1] = True
+    obs2 = rng.normal(size=(B2, T2 + 1, 20)).astype(np.float32)
+    n2 = int(lens2.sum())
+    cases.append((pp2, I2, B2, T2, lens2, obs2, acts2, acts2, rews2, dones2, [0.95, 0.95, 0.2, 0.25, 0.01, 0.5, 1e-3, 1024, 2],
+                  [rng.permutation(n2) for _ in range(2)]))
+    for pp_, I_, B_, T_, lens_, obs_, acts_pos, acts_raw, rews_, dones_, hyper, perms_ in cases:
+        value, logp = rollout_time_value_logp(pp_, obs_, acts_pos, lens_)
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("CIRS_PPO_MERGE_KERNEL", flag)
+            traj = Trajectory(B_, T_, 20, "cuda")
+            upload_traj(traj, acts_raw, rews_, dones_, lens_, obs_, value, logp)
+            ln, views = make_learner(pp_, I_, B_, T_, hyper)
+            ln.prepare(traj, lens_)
+            losses = ln.learn(int(hyper[7]), int(hyper[8]), perms=perms_).cpu().numpy()
+            outs.append((losses, ln.params.cpu().numpy().copy(), ln.dobs.cpu().numpy().copy()))
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=2e-5)      # (Adam on near-zero gradients amplifies the 1e-7 of the logit)
+        assert np.mean(np.abs(outs[0][1] - outs[1][1]) < 2e-6) > 0.99
+        np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-6)
+
+
 def test_learner_dual_clip_and_recomputed_advantages_match_reference(golden_dir):
     """PPOPolicy(dual_clip=1.01, recompute_advantage=1) recorded from the reference (learn_opts.npz): the device learner with
     cfg.dual_clip and learn(recompute_adv=True) -- cirs_critic_values over the stored states + cirs_ppo_prepare before the second repeat."""
