@@ -33,8 +33,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-MINIBATCH_KERNELS = ("trunk_adv_kernel", "head_stats_kernel", "head_stats_merge_kernel", "head_bwd_fused_kernel", "dh2_sum_kernel",
-                     "trunk_bwd_kernel", "sumsq_partial_kernel", "adam2_kernel")
+MINIBATCH_KERNELS = ("trunk_adv_kernel", "head_stats_kernel", "head_bwd_fused_kernel", "dh2_sum_kernel",
+                     "trunk_bwd_kernel", "sumsq_partial_kernel", "adam2_kernel")     # the 7 launches of a minibatch step
 
 
 def kernel_source_hash():
@@ -58,7 +58,11 @@ def pmc_traffic(workload):
         return None, f"profiles/pmc_traffic.json is stale (taken on kernel sources {z.get('source_hash')}, this build is {kernel_source_hash()})"
     if z.get("workload") != workload:
         return None, f"profiles/pmc_traffic.json was taken on workload {z.get('workload')}"
-    return {k: int(v["bytes_per_launch"]) for k, v in z["kernels"].items()}, f"profiles/pmc_traffic.json ({z.get('taken', '?')}; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
+    out = {}
+    for k, v in z["kernels"].items():      # template instantiations ("head_bwd_fused_kernel<false, true>") are looked up by the kernel's name
+        out[k] = int(v["bytes_per_launch"])
+        out.setdefault(k.split("<")[0], int(v["bytes_per_launch"]))
+    return out, f"profiles/pmc_traffic.json ({z.get('taken', '?')}; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
 def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_backward=None, coll=None):
