@@ -6,12 +6,14 @@ None of it is on the MI355X hot path; the mirror's device-backed classes dispatc
 
   HostStateTracker    core/state_tracker.py:89-115 (dense branch: features pass through), :129-250 (causal transformer re-run over
                       the whole prefix at every build_state, retained autograd graph, nn.Dropout live in training mode)
-  HostPPOPolicy       core/policy/ppo.py:96-246 + tianshou/policy/base.py:179-313,380-396 (map_action, update, GAE) +
-                      modelfree/a2c.py:80-109 (_compute_returns, RunningMeanStd) for any torch distribution
+  HostPPOPolicy       behaviour of core/policy/ppo.py:96-246 + tianshou/policy/base.py:179-313,380-396 (map_action, update, GAE) +
+                      modelfree/a2c.py:80-109 (returns, running return statistics) for any torch distribution, written in this repo's
+                      own three-stage form (ReturnScale / lambda_returns -> ppo_objective -> optimiser schedule in learn())
   HostCollector       core/collector.py:147-367 (per-step loop, finished envs dropped, result dict)
 
 Plain PyTorch on the host, in the reference's order of operations and of random draws: with the same seeds the collect and the update
 reproduce the reference's (tests/test_c1_rl_cpu.py, fixture recorded from the reference by oracle/gen_golden.py gen_c1rl)."""
+import dataclasses
 import math
 import time
 from typing import Any, Callable, Dict, List, Optional
@@ -101,28 +103,85 @@ class HostStateTracker(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-# PPO
+# PPO (written as three explicit stages, the way csrc/ppo.hip is organised: returns stage -> row objective -> optimiser schedule)
 # ------------------------------------------------------------------------------------------------------------------------------
-class _RunningMeanStd:
+class ReturnScale:
+    """Running mean / variance / weight of the un-normalised returns (parallel-variance merge of one block per update); the stored
+    variance of the PREVIOUS updates scales the critic's outputs and the regression targets of the current one."""
+
     def __init__(self):
-        self.mean, self.var, self.count = 0.0, 1.0, np.finfo(np.float32).eps.item()
+        self.mean, self.var, self.count = 0.0, 1.0, float(np.finfo(np.float32).eps)
 
-    def update(self, x):
-        b_mean, b_var, b_count = np.mean(x, axis=0), np.var(x, axis=0), len(x)
-        delta, total = b_mean - self.mean, self.count + b_count
-        m2 = self.var * self.count + b_var * b_count + delta ** 2 * self.count * b_count / total
-        self.mean, self.var, self.count = self.mean + delta * b_count / total, m2 / total, total
+    def scale(self, floor):
+        return float(np.sqrt(self.var + floor))
+
+    def update(self, block):
+        block = np.asarray(block, dtype=np.float64)
+        n, mu, s2 = block.shape[0], block.mean(axis=0), block.var(axis=0)
+        w_old, w_all = self.count, self.count + n
+        shift = mu - self.mean
+        self.var = (self.var * w_old + s2 * n + shift * shift * (w_old * n / w_all)) / w_all
+        self.mean = self.mean + shift * (n / w_all)
+        self.count = w_all
 
 
-def _gae(v_s, v_s_, rew, end_flag, gamma, gae_lambda):
-    out = np.zeros(rew.shape)
-    delta = rew + v_s_ * gamma - v_s
-    m = (1.0 - end_flag) * (gamma * gae_lambda)
-    gae = 0.0
-    for i in range(len(rew) - 1, -1, -1):
-        gae = delta[i] + m[i] * gae
-        out[i] = gae
+@dataclasses.dataclass
+class PpoHyper:
+    """The knobs of one PPO update (constructor keywords of the policy class on the left of each field's comment)."""
+    clip: float = 0.2                  # eps_clip
+    dual: Optional[float] = None       # dual_clip (> 1)
+    clip_value: bool = False           # value_clip
+    whiten_adv: bool = True            # advantage_normalization
+    refresh_adv: bool = False          # recompute_advantage
+    c_value: float = 0.5               # vf_coef
+    c_entropy: float = 0.01            # ent_coef
+    max_norm: Optional[float] = None   # max_grad_norm
+    lam: float = 0.95                  # gae_lambda
+    discount: float = 0.99             # discount_factor
+    chunk: int = 256                   # max_batchsize: rows per no-grad network pass
+    scale_returns: bool = False        # reward_normalization
+    floor: float = 1e-8
+
+
+def row_ranges(n, size):
+    """[0, n) cut into consecutive ranges of `size` rows; a short tail joins the range before it."""
+    cuts = list(range(0, n, size)) + [n]
+    if len(cuts) > 2 and n % size:
+        del cuts[-2]
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+def lambda_returns(value, value_next, reward, boundary, discount, lam):
+    """Generalised advantage estimates of a buffer-ordered slice, float64.  boundary[i]: row i closes its episode segment (terminal, or
+    the newest row of an unfinished episode), so nothing is carried across it; value_next is already zero behind a terminal row."""
+    td = reward + discount * value_next - value
+    carry = np.where(boundary, 0.0, discount * lam)
+    out = np.empty_like(td)
+    run = 0.0
+    for i in reversed(range(td.shape[0])):
+        run = td[i] + carry[i] * run
+        out[i] = run
     return out
+
+
+def ppo_objective(logp, logp_old, adv, value, value_old, target, entropy, h: PpoHyper):
+    """Scalar PPO objective of a minibatch and its three reported terms (all means over the rows).
+    policy: pessimistic (clipped) importance-weighted advantage, optionally floored by dual * adv; value: squared error against the
+    regression target, optionally the worse of the free and the trust-region-clipped prediction; entropy bonus."""
+    if h.whiten_adv:
+        adv = (adv - adv.mean()) / adv.std()
+    w = torch.exp(logp - logp_old).float().reshape(-1)
+    gain = torch.minimum(w * adv, torch.clamp(w, 1.0 - h.clip, 1.0 + h.clip) * adv)
+    if h.dual:
+        gain = torch.maximum(gain, h.dual * adv)
+    policy_term = -gain.mean()
+    err = (target - value) ** 2
+    if h.clip_value:
+        bounded = value_old + torch.clamp(value - value_old, -h.clip, h.clip)
+        err = torch.maximum(err, (target - bounded) ** 2)
+    value_term = err.mean()
+    entropy_term = entropy.mean()
+    return policy_term + h.c_value * value_term - h.c_entropy * entropy_term, policy_term, value_term, entropy_term
 
 
 class HostPPOPolicy(nn.Module):
@@ -137,132 +196,125 @@ class HostPPOPolicy(nn.Module):
         self.action_type = "continuous" if hasattr(action_space, "low") and np.asarray(action_space.low).dtype.kind == "f" else "discrete"
         self.action_scaling = action_scaling and self.action_type == "continuous"
         self.action_bound_method = action_bound_method if self.action_type == "continuous" else ""
-        self._eps_clip, self._dual_clip, self._value_clip = eps_clip, dual_clip, bool(value_clip)
-        self._norm_adv, self._recompute_adv = bool(advantage_normalization), bool(recompute_advantage)
-        self._weight_vf, self._weight_ent, self._grad_norm = vf_coef, ent_coef, max_grad_norm
-        self._lambda, self._gamma, self._batch = gae_lambda, discount_factor, max_batchsize
-        self._rew_norm, self._deterministic_eval = bool(reward_normalization), deterministic_eval
-        self.ret_rms, self._eps = _RunningMeanStd(), 1e-8
+        self.hyper = PpoHyper(clip=eps_clip, dual=dual_clip, clip_value=bool(value_clip), whiten_adv=bool(advantage_normalization),
+                              refresh_adv=bool(recompute_advantage), c_value=vf_coef, c_entropy=ent_coef, max_norm=max_grad_norm,
+                              lam=gae_lambda, discount=discount_factor, chunk=max_batchsize, scale_returns=bool(reward_normalization))
+        self.ret_rms = ReturnScale()
+        self._deterministic_eval = deterministic_eval
         self.lr_scheduler = lr_scheduler
         self.updating = False
         self.callbacks: List[Any] = []
 
     # ---- acting -----------------------------------------------------------------------------------------------------------
+    def _distribution(self, obs, state=None):
+        head, hidden = self.actor(obs, state=state)
+        return (self.dist_fn(*head) if isinstance(head, tuple) else self.dist_fn(head)), head, hidden
+
     def forward(self, batch, buffer=None, remove_recommended_ids=False, state=None, **kwargs):
         assert not remove_recommended_ids, "id masking is a discrete-catalogue feature (KuaishouEnv)"
-        logits, h = self.actor(batch.obs, state=state)
-        dist = self.dist_fn(*logits) if isinstance(logits, tuple) else self.dist_fn(logits)
-        if self._deterministic_eval and not self.training:
-            act = logits.argmax(-1) if self.action_type == "discrete" else logits[0]
-        else:
-            act = dist.sample()
-        return Batch(logits=logits, act=act, state=h, dist=dist)
+        dist, head, hidden = self._distribution(batch.obs, state)
+        greedy = self._deterministic_eval and not self.training
+        if not greedy:
+            chosen = dist.sample()
+        else:       # mode of the distribution: arg-max logit / the mean of (mu, sigma)
+            chosen = head.argmax(-1) if self.action_type == "discrete" else head[0]
+        return Batch(logits=head, act=chosen, state=hidden, dist=dist)
+
+    _SQUASH = {"clip": lambda a: np.minimum(np.maximum(a, -1.0), 1.0), "tanh": np.tanh}
 
     def map_action(self, act):
-        """Bound the raw action to [-1, 1], then scale to the action space (tianshou/policy/base.py:179-210)."""
-        if self.action_type == "continuous" and isinstance(act, np.ndarray):
-            if self.action_bound_method == "clip":
-                act = np.clip(act, -1.0, 1.0)
-            elif self.action_bound_method == "tanh":
-                act = np.tanh(act)
-            if self.action_scaling:
-                low, high = self.action_space.low, self.action_space.high
-                act = low + (high - low) * (act + 1.0) / 2.0
-        return act
+        """Raw network action -> [-1, 1] (clip or tanh) -> the env's box [low, high]; discrete actions pass through."""
+        if self.action_type != "continuous" or not isinstance(act, np.ndarray):
+            return act
+        squash = self._SQUASH.get(self.action_bound_method)
+        unit = squash(act) if squash else act
+        if not self.action_scaling:
+            return unit
+        box = self.action_space
+        return box.low + (box.high - box.low) * (unit + 1.0) / 2.0
 
     def exploration_noise(self, act, batch):
         return act
 
-    # ---- learning ---------------------------------------------------------------------------------------------------------
-    def _compute_returns(self, batch, buffer, indice):
-        v_s, v_s_ = [], []
+    # ---- learning: stage 1, returns -----------------------------------------------------------------------------------------
+    def _critic_rows(self, rows):
+        """critic(rows) without a graph, `chunk` rows per pass, as one flat tensor."""
         with torch.no_grad():
-            for b in batch.split(self._batch, shuffle=False, merge_last=True):
-                v_s.append(self.critic(b.obs))
-                v_s_.append(self.critic(b.obs_next))
-        batch.v_s = torch.cat(v_s, dim=0).flatten()
-        v_s = batch.v_s.cpu().numpy()
-        v_s_ = torch.cat(v_s_, dim=0).flatten().cpu().numpy()
-        if self._rew_norm:       # values are learned on the normalised scale
-            scale = np.sqrt(self.ret_rms.var + self._eps)
-            v_s, v_s_ = v_s * scale, v_s_ * scale
-        rew = np.asarray(batch.rew, dtype=float)
-        done = np.asarray(batch.done).astype(bool)
-        v_s_ = v_s_ * ~np.asarray(buffer.done)[indice]                       # value mask: no bootstrap across an episode end
-        end_flag = done.copy()
-        end_flag[np.isin(indice, buffer.unfinished_index())] = True
-        adv = _gae(v_s, v_s_, rew, end_flag.astype(float), self._gamma, self._lambda)
-        unnormalized_returns = adv + v_s
-        if self._rew_norm:
-            batch.returns = unnormalized_returns / np.sqrt(self.ret_rms.var + self._eps)
-            self.ret_rms.update(unnormalized_returns)
-        else:
-            batch.returns = unnormalized_returns
-        batch.returns = to_torch_as(batch.returns, batch.v_s)
+            parts = [self.critic(rows[a:b]) for a, b in row_ranges(len(rows), self.hyper.chunk)]
+        return torch.cat(parts, dim=0).flatten()
+
+    def _returns_stage(self, batch, buffer, rows):
+        """Fills batch.v_s (critic of the stored states, network scale), batch.adv and batch.returns for the sampled buffer rows.
+        Values live on the normalised-return scale: they are multiplied by the running scale before the recurrence, and the targets
+        are divided by the SAME (pre-update) scale afterwards; then this update's returns enter the running statistics."""
+        h = self.hyper
+        batch.v_s = self._critic_rows(batch.obs)
+        now = batch.v_s.cpu().numpy().astype(np.float64)
+        nxt = self._critic_rows(batch.obs_next).cpu().numpy().astype(np.float64)
+        unit = self.ret_rms.scale(h.floor) if h.scale_returns else 1.0
+        terminal = np.asarray(buffer.done)[rows].astype(bool)
+        nxt = np.where(terminal, 0.0, nxt * unit)
+        boundary = np.asarray(batch.done).astype(bool) | np.isin(rows, buffer.unfinished_index())
+        adv = lambda_returns(now * unit, nxt, np.asarray(batch.rew, dtype=np.float64), boundary, h.discount, h.lam)
+        total = adv + now * unit
+        if h.scale_returns:
+            self.ret_rms.update(total)
+        batch.returns = to_torch_as(total / unit, batch.v_s)
         batch.adv = to_torch_as(adv, batch.v_s)
         return batch
 
     def process_fn(self, batch, buffer, indice):
-        if self._recompute_adv:
-            self._buffer, self._indice = buffer, indice
-        batch = self._compute_returns(batch, buffer, indice)
-        batch.act = to_torch_as(batch.act, batch.v_s)
-        old = []
-        with torch.no_grad():
-            for b in batch.split(self._batch, shuffle=False, merge_last=True):
-                old.append(self(b).dist.log_prob(b.act))
-        batch.logp_old = torch.cat(old, dim=0)
+        """Protocol hook of the trainer: returns stage + the behaviour policy's log-probabilities of the stored actions."""
+        self._sampled = (buffer, indice)
+        batch = self._returns_stage(batch, buffer, indice)
+        batch.act = to_torch_as(batch.act, batch.v_s)      # stored actions as a tensor of the critic's dtype / device
+        with torch.no_grad():                                # behaviour log-probabilities carry no graph
+            parts = [self._distribution(batch.obs[a:b])[0].log_prob(batch.act[a:b]) for a, b in row_ranges(len(batch), self.hyper.chunk)]
+        batch.logp_old = torch.cat(parts, dim=0)
         return batch
 
+    # ---- learning: stages 2 + 3, objective and optimiser schedule -------------------------------------------------------------
     def learn(self, batch, batch_size, repeat, **kwargs) -> Dict[str, List[float]]:
-        losses, clip_losses, vf_losses, ent_losses = [], [], [], []
-        optim_RL, optim_state = self.optim
-        params = list(self.actor.parameters()) + list(self.critic.parameters())
-        for step in range(repeat):
-            optim_state.zero_grad()
-            if self._recompute_adv and step > 0:
-                batch = self._compute_returns(batch, self._buffer, self._indice)
-            for b in batch.split(batch_size, merge_last=True):
-                dist = self(b).dist
-                if self._norm_adv:
-                    b.adv = (b.adv - b.adv.mean()) / b.adv.std()
-                ratio = (dist.log_prob(b.act) - b.logp_old).exp().float()
-                ratio = ratio.reshape(ratio.size(0), -1).transpose(0, 1)
-                surr1 = ratio * b.adv
-                surr2 = ratio.clamp(1.0 - self._eps_clip, 1.0 + self._eps_clip) * b.adv
-                if self._dual_clip:
-                    clip_loss = -torch.max(torch.min(surr1, surr2), self._dual_clip * b.adv).mean()
-                else:
-                    clip_loss = -torch.min(surr1, surr2).mean()
-                value = self.critic(b.obs).flatten()
-                if self._value_clip:
-                    v_clip = b.v_s + (value - b.v_s).clamp(-self._eps_clip, self._eps_clip)
-                    vf_loss = torch.max((b.returns - value).pow(2), (b.returns - v_clip).pow(2)).mean()
-                else:
-                    vf_loss = (b.returns - value).pow(2).mean()
-                ent_loss = dist.entropy().mean()
-                loss = clip_loss + self._weight_vf * vf_loss - self._weight_ent * ent_loss
-                optim_RL.zero_grad()
-                loss.backward(retain_graph=True)      # the graph of the stored states reaches back into the tracker
-                if self._grad_norm:
-                    nn.utils.clip_grad_norm_(params, max_norm=self._grad_norm)
-                optim_RL.step()
-                clip_losses.append(clip_loss.item()); vf_losses.append(vf_loss.item())
-                ent_losses.append(ent_loss.item()); losses.append(loss.item())
-        optim_state.step()        # the tracker moves once per update, on the gradient accumulated over the last repeat
-        if self.lr_scheduler is not None:
+        """`repeat` passes over the batch in shuffled minibatches of `batch_size` rows (a short tail joins the last one).  Two optimisers
+        with two clocks: the policy optimiser (actor + critic) steps on every minibatch with the clipped gradient; the tracker optimiser
+        is cleared at the start of every pass and steps ONCE at the end of the update, i.e. on what the last pass accumulated through the
+        stored states' graph (which is why every backward keeps that graph)."""
+        h = self.hyper
+        opt_policy, opt_tracker = self.optim
+        clipped = [p for m in (self.actor, self.critic) for p in m.parameters()]
+        report = {"loss": [], "loss/clip": [], "loss/vf": [], "loss/ent": []}
+        n = len(batch)
+        for sweep in range(repeat):
+            opt_tracker.zero_grad()
+            if h.refresh_adv and sweep:
+                batch = self._returns_stage(batch, *self._sampled)
+            order = np.random.permutation(n)
+            for a, b in row_ranges(n, batch_size):
+                mb = batch[order[a:b]]
+                dist = self._distribution(mb.obs)[0]
+                total, p_term, v_term, e_term = ppo_objective(dist.log_prob(mb.act), mb.logp_old, mb.adv, self.critic(mb.obs).flatten(),
+                                                              mb.v_s, mb.returns, dist.entropy(), h)
+                opt_policy.zero_grad()
+                total.backward(retain_graph=True)
+                if h.max_norm:
+                    nn.utils.clip_grad_norm_(clipped, max_norm=h.max_norm)
+                opt_policy.step()
+                for key, val in zip(report, (total, p_term, v_term, e_term)):
+                    report[key].append(val.item())
+        opt_tracker.step()
+        if self.lr_scheduler:
             self.lr_scheduler.step()
-        return {"loss": losses, "loss/clip": clip_losses, "loss/vf": vf_losses, "loss/ent": ent_losses}
+        return report
 
     def update(self, sample_size, buffer, **kwargs):
         if buffer is None:
-            return {}
-        batch, indice = buffer.sample(sample_size)
-        self.updating = True
-        batch = self.process_fn(batch, buffer, indice)
-        result = self.learn(batch, **kwargs)
-        self.updating = False
-        return result
+            return dict()
+        batch, rows = buffer.sample(sample_size)
+        self.updating = True       # (flag read by exploration wrappers)
+        try:
+            return self.learn(self.process_fn(batch, buffer, rows), **kwargs)
+        finally:
+            self.updating = False  # also when the learner raises
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
