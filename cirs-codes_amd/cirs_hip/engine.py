@@ -114,6 +114,7 @@ class CirsEngine:
         self.policy_flat, pviews = flat_policy_params(I, dim_state, hidden, device=self.device, init=pp, world=world_size)
         self.policy_views = pviews
         self.tracker_views = tviews
+        self.hidden = hidden
         self.policy = DevicePolicy(pviews, I, dim_state=dim_state, hidden=hidden, device=self.device)
         # dropout_redraw: the reference's exact procedure (fresh masks over the whole prefix at every build_state call,
         # core/state_tracker.py:170-186,243-246) as a study option: O(T^2) tracker launches per collect (cirs_hip/redraw.py)
@@ -262,7 +263,7 @@ class CirsEngine:
 
     def _publish_tp(self):
         """The updated head shards -> the replicated rollout policy (one all-gather per update); trunk / critic are replicated."""
-        H, Is, Il, W, I = 64, self.tp_Is, self.tp_Il, self.world, self.n_items
+        H, Is, Il, W, I = self.hidden, self.tp_Is, self.tp_Il, self.world, self.n_items
         v, pv = self.tp_views, self.policy_views
         self._tp_send[:Il * H].copy_(v["actor.last.model.0.weight"].reshape(-1))
         self._tp_send[Is * H:Is * H + Il].copy_(v["actor.last.model.0.bias"])

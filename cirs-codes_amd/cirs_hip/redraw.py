@@ -23,7 +23,10 @@ from .rollout import DeviceRollout
 
 def call_tag(rng_base: int, call: int) -> int:
     """Mask-key tag of build_state call `call` of the collect whose sampler counters start at rng_base."""
-    return ((int(rng_base) & 0xFFFFFF) << 8) + int(call) + 1
+    # 16 bits for the call index (max_turn <= 65534), the collect's counter base above them: the tag space of set_dropout_key is 64 bits wide,
+    # so neither a long episode nor a long run wraps one collect's tags into another's
+    assert 0 <= int(call) < 0xFFFF, "more build_state calls per collect than the mask tag has room for"
+    return ((int(rng_base) & 0xFFFFFFFFFF) << 16) + int(call) + 1
 
 
 class RedrawRollout(DeviceRollout):

@@ -218,6 +218,10 @@ class ShardedTable:
         start = torch.cumsum(counts, 0) - counts
         pos_s = torch.arange(n, device=dev) - start[owner_s]
         keep = (owner_s < W) & (pos_s < cap)
+        if cap < n:      # a reduced capacity may drop gradient rows: counted like lookup()'s dropped requests, never silent
+            if self.overflow is None:
+                self.overflow = torch.zeros((), dtype=torch.int64, device=dev)
+            self.overflow += ((owner_s < W) & ~(pos_s < cap)).sum()
         send_id = torch.full((W + 1, cap + 1), -1, dtype=torch.int64, device=dev)
         send_id[owner_s, torch.clamp(pos_s, max=cap)] = torch.where(keep, ids[order] // W, torch.full_like(pos_s, -1))
         send_rows = torch.zeros((W + 1, cap + 1, rows.shape[1]), dtype=torch.float32, device=dev)
@@ -247,7 +251,7 @@ class ShardedTable:
     def check_overflow(self):
         """Host check of the dropped-request counter (one synchronisation): raises if any lookup exceeded its `cap`."""
         if self.overflow is not None and int(self.overflow) > 0:
-            raise RuntimeError(f"ShardedTable.lookup: {int(self.overflow)} requests exceeded the per-destination capacity (cap too small)")
+            raise RuntimeError(f"ShardedTable: {int(self.overflow)} lookup requests / gradient rows exceeded the per-destination capacity (cap too small)")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -440,6 +444,11 @@ class ShardedTrainer:
         ro, ln, W, r, Bl, T = self.ro, self.learner, self.W, self.rank, self.Bl, self.T
         lens_d = self._gather(lens_local)
         lens = lens_d.cpu().numpy().astype(np.int32)
+        # (the read-back above is the update's one synchronisation: the dropped-message counters of the sharded tables -- lookups of the
+        # rollout just finished, gradient pushes of the previous update -- are read here, where it costs no extra stall)
+        for tab in (ro.trk_user, ro.trk_item, getattr(ro, "fm_user", None), getattr(ro, "fm_item", None)):
+            if tab is not None:
+                tab.check_overflow()
         n = ln.prepare(self.gtraj, lens, lens_dev=lens_d)
         if perms is None:
             ln.perm_seed, ln.perm_tag = perm_key          # the same key on every rank: identical shuffles
