@@ -81,6 +81,31 @@ def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_bac
     return eng, tab
 
 
+def timed_pass(wl, device, dropout, warmup, steps, batch=1024):
+    """One more workload through the protocol of the headline (fresh engine, `warmup` untimed steps, `steps` timed steps = collect + update
+    between synchronisations, single GPU) -> the numbers the driver's one default run would otherwise never witness: the C3 step with
+    the tracker in training mode (Dropout(0.1) live in rollout and BPTT, the way the reference trains) and BASELINE
+    configs[1] (C2: 1411 x 3327, 64 envs)."""
+    eng, _ = build_engine(wl, 0, 1, device, dropout=dropout)
+    for _ in range(warmup):
+        eng.collect(); eng.update(batch_size=batch, repeat=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_steps = mb_steps = 0
+    for _ in range(steps):
+        eng.collect()
+        losses, n = eng.update(batch_size=batch, repeat=2)
+        n_steps += n; mb_steps += losses.shape[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": wl["name"], "tracker_dropout": dropout, "value": n_steps / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / steps,
+           "steps": steps, "warmup": warmup, "envs": wl["B"], "mean_episode_len": n_steps / steps / wl["B"],
+           "minibatch_steps_per_update": mb_steps / steps}
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def hip_event_kernel_time(eng, wl, reps=100):
     """HIP-event timing on the launch stream, PPO minibatch step of mb rows launched exactly as inside the timed region:
     -> (seconds per whole cirs_ppo_minibatch call, mb, {kernel name: average seconds per launch}) where the per-kernel numbers
@@ -379,9 +404,13 @@ def cpu_baseline(wl, eng):
         ref = json.load(open(ref_json))
     return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["cores"], "host_cores": host, "kind": "port",
             "envs_gpu_leg": wl["B"], "envs_cpu_leg": best["envs"], "envs_cpu_single_thread_leg": legs[0]["envs"],
-            "sample": f"1 step (collect + update, same tables / policy / tracker weights as the GPU leg) with {best['envs']} envs on the {wl['U']}x{wl['I']} tables: "
+            "sample": f"1 step (collect + update, same tables / policy / tracker weights as the GPU leg) with {best['envs']} envs (the GPU leg runs {wl['B']}) "
+                      f"on {best['cores']} of {host} host cores, {wl['U']}x{wl['I']} tables: "
                       f"{best['env_steps']} env-steps, {best['minibatches']} PPO minibatch steps in {best['seconds']:.1f}s "
-                      "(C oracle env/actor via OpenMP, torch-fp32 tracker/PPO restatement)",
+                      "(C oracle env/actor via OpenMP, torch-fp32 tracker/PPO restatement); legs: "
+                      + "; ".join(f"{l['cores']} threads x {l['envs']} envs = {l['env_steps_per_s']:.0f} env-steps/s" for l in legs)
+                      + (" -- the widest leg is slower than the 16-thread one: the port's per-step tensors are tiny, OpenMP / torch threading does not scale past ~16 threads"
+                         if len(legs) > 2 and legs[2]["env_steps_per_s"] < legs[1]["env_steps_per_s"] else ""),
             "single_thread": legs[0], "legs": legs,
             "reference_python": ref or {"note": "profiles/reference_python_cpu.json absent", "survey_section_6": {
                 "c2_rollout_env_steps_per_s": 940, "c3_rollout_env_steps_per_s": 520, "c2_ppo_minibatch_steps_per_s": 1.9,
@@ -576,6 +605,11 @@ def main():
             out["collectives_per_rank"] = {"calls": dict(eng.coll.calls), "bytes": dict(eng.coll.bytes),
                                            "note": "totals over warm-up, timed and extra steps of this process"}
         if world == 1 and not args.no_probes:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
+            # the same warm-up / step protocol on two more workloads, so that the driver's one default run carries them (never `value`)
+            if args.workload == "c3" and args.dropout == 0.0:
+                out["dropout_on"] = timed_pass(WORKLOADS["c3"], device, 0.1, args.warmup, args.steps, G)
+            if args.workload != "c2":
+                out["c2"] = timed_pass(WORKLOADS["c2"], device, args.dropout, args.warmup, args.steps, G)
             out["gather_fm"] = gather_fm_probe(device)
             out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
             out["sweep_mode"] = sweep_mode_probe(wl, eng, device)

@@ -48,3 +48,15 @@ def test_bench_dropout_mode_line():
     d = run_bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "c2", "--dropout", "0.1", "--no-probes")
     assert d["dropout"] == 0.1 and d["config"]["tracker_dropout"] == 0.1 and d["value"] > 0
 
+
+
+def test_bench_default_workload_carries_dropout_and_c2_passes():
+    """the default (C3) single-GPU line also carries a timed pass with the tracker in training mode (Dropout(0.1),
+    the mode the reference trains in) and a timed pass of BASELINE configs[1] (C2), both with the headline's warm-up / step protocol."""
+    d = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert "7176x10728" in d["config"]["workload"] and d["dropout"] == 0.0
+    for key, envs, p in (("dropout_on", 1024, 0.1), ("c2", 64, 0.0)):
+        e = d[key]
+        assert e["value"] > 0 and e["unit"] == "env-steps/s" and e["ms_per_step"] > 0 and e["steps"] == 2 and e["warmup"] == 1
+        assert e["envs"] == envs and e["tracker_dropout"] == p
+    assert "7176x10728" in d["dropout_on"]["workload"] and "1411x3327" in d["c2"]["workload"]
