@@ -29,6 +29,13 @@ constexpr int kBwdWaves = 4;  // row tiles per workgroup of the fused head backw
 __host__ __device__ inline int n_row_blocks_of(int n_pad) { return (n_pad / kTileM + kBwdWaves - 1) / kBwdWaves; }
 // floats between consecutive dWa|dba partial slabs (16 B aligned for the float4 stores)
 __host__ __device__ inline size_t dwa_slab_stride(int I) { return (((size_t)I * 64 + I) + 3) & ~(size_t)3; }
+// dWa slabs the workspace holds: one per row block of the fused backward kernel, or one per row range of head_dwa_kernel (<= 8)
+__host__ __device__ inline int n_dwa_slabs_of(int n_pad) {
+    const int a = n_row_blocks_of(n_pad), b = n_pad / kTileM < 8 ? n_pad / kTileM : 8;
+    return a > b ? a : b;
+}
+// workgroups of head_dwa_kernel at most: groups of 4 item tiles x 8 row ranges
+__host__ __device__ inline int n_entw_max_of(int I) { return ((I + kTileN - 1) / kTileN + 3) / 4 * 8; }
 
 struct PpoLayout {  // offsets (floats) into the flat parameter buffer
     long w1, b1, w2, b2, wa, ba, wc, bc, total, trunk;
@@ -210,6 +217,8 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     uint4 *wa_planes;                         // bf16 planes of Wa per item tile (wa_planes_kernel)
     uint4 *h2z, *h2b;                         // bf16 planes of H2 in the head kernels' register order (written by trunk_adv_kernel):
                                               // [32-row tile][12][lane] uint4, unit q of a lane = its q-th operand register quad
+    float *entw;                              // split head path: the entropy's clamp correction, one scalar per head_dwa_kernel workgroup
+    int n_entw;                               // (0 on the round-3 path: the correction is in ent_row)
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
 };
 
@@ -224,7 +233,8 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 2 * (size_t)n_pad + 2 * (size_t)n_pad + 8;    // clip_row, vf_row, dst_row (int64)
     f += 2 * (size_t)n_pad * kH;                       // da2, da1
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
-    f += (size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I);    // dwap
+    f += (size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I);     // dwap
+    f += (size_t)n_entw_max_of(I) + 4;                           // entw
     f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
     f += (size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64;  // dW row slabs (one per 32 rows)
     f += (size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4;   // wa_planes
@@ -247,7 +257,8 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dst_row = (long*)take(2 * (size_t)n_pad + 4);
     v.da2 = take((size_t)n_pad * kH); v.da1 = take((size_t)n_pad * kH);
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
-    v.dwap = take((size_t)n_row_blocks_of(n_pad) * dwa_slab_stride(I));
+    v.dwap = take((size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I));
+    v.entw = take((size_t)n_entw_max_of(I)); v.n_entw = 0;
     v.red = take(64);
     v.normp = take(1024);
     v.dwp = take((size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64);
@@ -1110,6 +1121,10 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     CIRS_SSTAMP(35);
 }
 
+}  // namespace cirs
+#include "ppo_head_split.h"
+namespace cirs {
+
 // ---- slab sums of the wa|ba gradient (one of kWaSumBlocks workgroups of 512 threads) ------------------------------------
 // The n_slabs row-block partials written by head_bwd_fused_kernel are summed in slab order into the flat gradient, one
 // float4 per thread and slab (16-byte aligned: wa_beg and slab_stride are multiples of 4), 8 independent loads in flight;
@@ -1545,6 +1560,7 @@ __device__ __forceinline__ void loss_partials_block(int mb, int mb_norm, const M
     const int tid = threadIdx.x;  // blockDim.x == 256, sh3 = float[3][256]
     float e = 0.f, c = 0.f, f = 0.f;
     for (int r = tid; r < mb; r += 256) { e += v.ent_row[r]; c += v.clip_row[r]; f += v.vf_row[r]; }
+    for (int q = tid; q < v.n_entw; q += 256) e += v.entw[q];      // split head path: per-workgroup clamp corrections (fixed order)
     sh3[tid] = c; sh3[256 + tid] = f; sh3[512 + tid] = e;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -1825,6 +1841,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
                           params + L.wa, params + L.ba, params + L.wc, params + L.bc};
     const long seg = (long)I * kH + I;
     const int n_slabs = n_row_blocks_of(n_pad);
+    int n_wa_slabs = n_slabs;      // dWa slabs the trunk-backward launch sums: row blocks (fused backward) or row ranges (split head)
     DwJobs dw_jobs{};
     int n_dw_slabs = 0;
     float* tail = grads + L.total;  // {clip, vf, ent, 0} partials of this rank
@@ -1838,37 +1855,58 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
                            v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, sidx, (int)(idx_global ? mb_global : mb),
                            (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b, *batch, (int)n_env, v.act, v.dst_row, v.adv);
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
-        // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores from the bf16 planes of Wa written by launch 1;
-        //    all workgroups co-resident (2 per CU) with equal tile counts
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         const int n_item_tiles = cdiv(I, kTileN);
-        const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);   // measured: 1 / 2 / 3 workgroups per CU = 17.4 / 14.5 / 16.7 us
-        const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
-        CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s,
-                                                  (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, pv, (const int32_t*)v.act, v.za));
-        CIRS_CHECK_LAUNCH("head_stats_kernel");
-        // 4+5. head backward; the merge of the statistics partials + row losses + backward coefficients (means over the global minibatch) run in
-        // its prologue (CIRS_PPO_MERGE_KERNEL=1: as a launch of their own, the round-2 sequence, for A/B runs)
         const char* mk_ = getenv("CIRS_PPO_MERGE_KERNEL");      // (read per call: tests toggle it)
         const bool merge_launch = mk_ && atoi(mk_) != 0;
-        const HeadMergeArgs hma{*cfg, *batch, idx, (int)(idx_global ? mb_global : mb), n_schunks, pv};
-        if (merge_launch) {
-            hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
-                               (int)(idx_global ? mb_global : mb), n_pad, n_schunks, (int)n_env, pv, w.wa, w.ba, v, (const float*)nullptr, 0);
-            CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
-        }
-        // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
-        const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
-        const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
-        const dim3 bgrid((n_bchunks + 7) & ~7, n_slabs), bblock(kBwdWaves * 64);
-        if (cfg->ent_coef != 0.f) {
-            if (merge_launch) CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, false>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
-            else CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, true>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
+        const char* fk_ = getenv("CIRS_PPO_HEAD_FUSED");        // 1: the round-3 head kernels (statistics + fused backward + chunk-slab sums), for A/B runs
+        const HeadSplitGeom hg = head_split_geom(I, n_pad);
+        const bool split_head = cfg->ent_coef == 0.f && !merge_launch && !(fk_ && atoi(fk_) != 0) && hg.tiles_per_range * kTileM <= kDwaMaxRows;
+        int n_bchunks = 0;
+        if (split_head) {
+            // 3. head forward: statistics partials + O' = P Wa per (row block, item chunk): all workgroups co-resident (1 per CU), equal tile counts
+            const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
+            const int n_fch = cdiv(n_item_tiles, tpc);          // <= n_chunks: the partial arrays and the O' slabs fit
+            CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_fwd_kernel, dim3((n_fch + 7) & ~7, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc,
+                                                      (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, (const int32_t*)v.act, pv, v.dh2p, v.za, v.ez));
+            CIRS_CHECK_LAUNCH("head_fwd_kernel");
+            // 4. head backward: row merge (lse, loss terms, coefficients) + d h2 fold + dWa / dba, one dWa slab per row range
+            const HeadDwaArgs da{*cfg, (int)(idx_global ? mb_global : mb), n_fch, tpc, hg.n_groups, hg.n_ranges, hg.tiles_per_range, pv, v.dh2p,
+                                 (const float*)w.wa, v.entw};
+            v.n_entw = hg.n_groups * hg.n_ranges;
+            CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_dwa_kernel, dim3(hg.n_groups, hg.n_ranges), dim3(256), 0, s, I, (int)mb, n_pad,
+                                                      (const uint4*)v.wa_planes, w.ba, v, v.dwap, da));
+            CIRS_CHECK_LAUNCH("head_dwa_kernel");
+            n_wa_slabs = hg.n_ranges;
         } else {
-            if (merge_launch) CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, false>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
-            else CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, true>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
+            // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores from the bf16 planes of Wa written by launch 1;
+            //    all workgroups co-resident (2 per CU) with equal tile counts
+            const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);   // measured: 1 / 2 / 3 workgroups per CU = 17.4 / 14.5 / 16.7 us
+            const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
+            CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s,
+                                                      (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, pv, (const int32_t*)v.act, v.za));
+            CIRS_CHECK_LAUNCH("head_stats_kernel");
+            // 4+5. head backward; the merge of the statistics partials + row losses + backward coefficients (means over the global minibatch) run in
+            // its prologue (CIRS_PPO_MERGE_KERNEL=1: as a launch of their own, the round-2 sequence, for A/B runs)
+            const HeadMergeArgs hma{*cfg, *batch, idx, (int)(idx_global ? mb_global : mb), n_schunks, pv};
+            if (merge_launch) {
+                hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
+                                   (int)(idx_global ? mb_global : mb), n_pad, n_schunks, (int)n_env, pv, w.wa, w.ba, v, (const float*)nullptr, 0);
+                CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
+            }
+            // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
+            const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
+            n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
+            const dim3 bgrid((n_bchunks + 7) & ~7, n_slabs), bblock(kBwdWaves * 64);
+            if (cfg->ent_coef != 0.f) {
+                if (merge_launch) CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, false>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
+                else CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, true>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
+            } else {
+                if (merge_launch) CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, false>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
+                else CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, true>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
+            }
+            CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
         }
-        CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
         // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
         static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");
         CIRS_REQUIRE(S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
@@ -1892,10 +1930,12 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         dw_jobs = jobs;
         // (+ the slab sums of the wa|ba gradient as extra workgroups of the same launch: the flat gradient's wa|ba segment is
         // complete after this launch)
-        hipLaunchKernelGGL(dh2_sum_kernel, dim3(n_pad * (kH / 4) / 64 + cdiv(n_pad, 64)), dim3(64), 0, s, (int)mb, n_pad, n_bchunks, v);
-        CIRS_CHECK_LAUNCH("dh2_sum_kernel");
+        if (!split_head) {      // (the split path's head_dwa_kernel leaves d h2 folded in slab 0 and the entropy correction in entw)
+            hipLaunchKernelGGL(dh2_sum_kernel, dim3(n_pad * (kH / 4) / 64 + cdiv(n_pad, 64)), dim3(64), 0, s, (int)mb, n_pad, n_bchunks, v);
+            CIRS_CHECK_LAUNCH("dh2_sum_kernel");
+        }
         hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM + kWaSumBlocks), dim3(512), 0, s, (int)mb, n_pad, n_bchunks, S,
-                           w.w1, w.w2, w.wc, v, dobs_accum, grads, (long)L.wa, seg, (long)dwa_slab_stride(I), n_slabs, jobs, v.dwp);
+                           w.w1, w.w2, w.wc, v, dobs_accum, grads, (long)L.wa, seg, (long)dwa_slab_stride(I), n_wa_slabs, jobs, v.dwp);
         CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
         if (phase == 1) {  // gradients + loss partials must be complete in `grads` before the caller's all-reduce
             hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(jobs.total_out, 256)), dim3(256), 0, s, jobs, n_dw_slabs, (const float*)v.dwp);

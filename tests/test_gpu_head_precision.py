@@ -29,13 +29,18 @@ def ppo_loss(p, obs, act, adv, ret, v_s, logp_old, eps_clip, vf_coef, ent_coef):
     return clip + vf_coef * vf - ent_coef * ent
 
 
-@pytest.mark.parametrize("I,mb,ent_coef", [(3000, 512, 0.0), (10728, 1024, 0.01)])
-def test_minibatch_gradient_is_fp32_accurate(I, mb, ent_coef):
+@pytest.mark.parametrize("I,mb,ent_coef,sharp", [(3000, 512, 0.0, 1.0), (10728, 1024, 0.01, 1.0), (10728, 1024, 0.0, 1.0), (10728, 1024, 0.0, 6.0),
+                                                  (10728, 992, 0.0, 3.0), (777, 96, 0.0, 2.0)])
+def test_minibatch_gradient_is_fp32_accurate(I, mb, ent_coef, sharp):
+    """ent_coef == 0 runs the split head kernels (head_fwd_kernel / head_dwa_kernel: d h2 from the soft-max-weighted head row of the forward
+    pass), ent_coef != 0 the fused backward kernel.  sharp > 1 scales the head weights and draws the actions FROM the policy, so that taken
+    actions carry most of their row's probability (the trained regime: 1 - p_a small, where a formulation that subtracts the action's own
+    term from a full sum would lose digits)."""
     from cirs_hip.learner import DeviceLearner, flat_policy_params, FLAT_ORDER
     rng = np.random.RandomState(5)
     S, H = 20, 64
     shapes = dict(w1=(H, S), b1=(H,), w2=(H, H), b2=(H,), wa=(I, H), ba=(I,), wc=(1, H), bc=(1,))
-    scale = dict(w1=0.3, b1=0.1, w2=0.2, b2=0.1, wa=0.25, ba=0.1, wc=0.2, bc=0.1)   # logits spread over several units
+    scale = dict(w1=0.3, b1=0.1, w2=0.2, b2=0.1, wa=0.25 * sharp, ba=0.1, wc=0.2, bc=0.1)   # logits spread over several units
     p64 = {k: torch.as_tensor(rng.standard_normal(shapes[k]) * scale[k]).float().double() for k in FLAT_ORDER}
     obs = torch.as_tensor(rng.standard_normal((mb, S))).float().double()
     act = torch.as_tensor(rng.randint(0, I, mb))
@@ -53,6 +58,8 @@ def test_minibatch_gradient_is_fp32_accurate(I, mb, ent_coef):
     # logp_old: the current policy's log-probabilities perturbed a little, so that some ratios leave the clip range
     with torch.no_grad():
         _, z0 = grads_in(torch.float64)
+        if sharp > 1.0:      # on-policy actions: most rows take (one of) their most probable items
+            act = torch.multinomial(torch.softmax(z0, -1), 1, generator=torch.Generator().manual_seed(3)).squeeze(1)
         lp0 = torch.log_softmax(z0, -1).gather(1, act.view(-1, 1)).squeeze(1)
     logp_old = (lp0 + torch.as_tensor(rng.standard_normal(mb) * 0.15)).float().double()
 
