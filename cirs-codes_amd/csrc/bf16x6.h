@@ -75,6 +75,19 @@ __device__ __forceinline__ f32x16_b mfma_bf16x6(const Planes& a, const Planes& b
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
     return c;
 }
+// The same product with the accumulation split BY MAGNITUDE: `big` takes the h*h term of every k-step, `small` the five cross terms (<= 2^-8 of
+// the big ones).  Every MFMA rounds its result into the fp32 accumulator; in one chain that is 6 roundings per 16 k at the magnitude of the
+// running sum, here one (the cross terms round at their own, 2^-8 smaller, magnitude): over K = 64 the logits carry ~2 instead of ~5 ulp of
+// |z| -- what separates a float32 soft-max of a sharp policy from a worse one (tests/test_gpu_head_precision.py, sharp = 6).  The caller adds
+// big + small once at the end.
+__device__ __forceinline__ void mfma_bf16x6_split(const Planes& a, const Planes& b, f32x16_b& big, f32x16_b& small) {
+    big = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, big, 0, 0, 0);
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, small, 0, 0, 0);
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, small, 0, 0, 0);
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, small, 0, 0, 0);
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, small, 0, 0, 0);
+    small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, small, 0, 0, 0);
+}
 // two independent accumulators sharing the A operand, issued alternately: a dependent bf16 MFMA waits ~40 cycles for its
 // predecessor, an independent one issues after 32
 __device__ __forceinline__ void mfma_bf16x6_pair(const Planes& a, const Planes& b0, const Planes& b1, f32x16_b& c0, f32x16_b& c1) {

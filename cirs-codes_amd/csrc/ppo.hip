@@ -25,6 +25,7 @@ namespace cirs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: a float4 struct array goes through memcpy / scratch
 
 
+constexpr bool kHeadSplitDefault = false;   // see CIRS_PPO_HEAD in ppo_minibatch_impl
 constexpr int kBwdWaves = 4;  // row tiles per workgroup of the fused head backward kernel (= rows/32 per dWa slab)
 __host__ __device__ inline int n_row_blocks_of(int n_pad) { return (n_pad / kTileM + kBwdWaves - 1) / kBwdWaves; }
 // floats between consecutive dWa|dba partial slabs (16 B aligned for the float4 stores)
@@ -217,6 +218,8 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     uint4 *wa_planes;                         // bf16 planes of Wa per item tile (wa_planes_kernel)
     uint4 *h2z, *h2b;                         // bf16 planes of H2 in the head kernels' register order (written by trunk_adv_kernel):
                                               // [32-row tile][12][lane] uint4, unit q of a lane = its q-th operand register quad
+    float *row_m;                             // split head path: the rows' reference maxima (row stage of head_fwd_kernel -> d h2 fold)
+    int *arrive;                              // split head path: arrival counters of head_fwd_kernel's row blocks (zeroed by trunk_adv_kernel)
     float *entw;                              // split head path: the entropy's clamp correction, one scalar per head_dwa_kernel workgroup
     int n_entw;                               // (0 on the round-3 path: the correction is in ent_row)
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
@@ -235,6 +238,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I);     // dwap
     f += (size_t)n_entw_max_of(I) + 4;                           // entw
+    f += (size_t)n_pad + 4 + 1024;                               // row_m, arrive
     f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
     f += (size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64;  // dW row slabs (one per 32 rows)
     f += (size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4;   // wa_planes
@@ -259,6 +263,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
     v.dwap = take((size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I));
     v.entw = take((size_t)n_entw_max_of(I)); v.n_entw = 0;
+    v.row_m = take(n_pad); v.arrive = (int*)take(1024);
     v.red = take(64);
     v.normp = take(1024);
     v.dwp = take((size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64);
@@ -478,7 +483,8 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
                                                         int m_stats, int enable, float* __restrict__ red, int n_row_wgs,
                                                         uint4* __restrict__ planes, uint4* __restrict__ h2z, uint4* __restrict__ h2b,
                                                         cirs_ppo_batch bt, int n_env, int32_t* __restrict__ act_out, long* __restrict__ dst_out,
-                                                        float* __restrict__ row4 /* [4][n_pad]: adv, logp_old, ret, v_s of the minibatch rows */) {
+                                                        float* __restrict__ row4 /* [4][n_pad]: adv, logp_old, ret, v_s of the minibatch rows */,
+                                                        int* __restrict__ arrive = nullptr, int n_arrive = 0 /* arrival counters of head_fwd_kernel, cleared here */) {
     __shared__ float lds_raw[kTileN * 65];
     static_assert(kTileN * 65 >= 4 * 2 * kH, "the trunk rows use 4 x 2 x 64 floats of the same buffer");
     if ((int)blockIdx.x > n_row_wgs) {
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
         return;
     }
     if ((int)blockIdx.x == n_row_wgs) {
+        for (int q = threadIdx.x; q < n_arrive; q += 256) arrive[q] = 0;
         adv_stats_block(adv_flat, sidx, m_stats, enable, red, lds_raw);
         return;
     }
@@ -1853,28 +1860,35 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         //    batch through idx inside the kernel (v.obs keeps the copy for d W1)
         hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
                            v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, sidx, (int)(idx_global ? mb_global : mb),
-                           (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b, *batch, (int)n_env, v.act, v.dst_row, v.adv);
+                           (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b, *batch, (int)n_env, v.act, v.dst_row, v.adv, v.arrive, n_slabs);
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         const int n_item_tiles = cdiv(I, kTileN);
         const char* mk_ = getenv("CIRS_PPO_MERGE_KERNEL");      // (read per call: tests toggle it)
         const bool merge_launch = mk_ && atoi(mk_) != 0;
-        const char* fk_ = getenv("CIRS_PPO_HEAD_FUSED");        // 1: the round-3 head kernels (statistics + fused backward + chunk-slab sums), for A/B runs
+        // CIRS_PPO_HEAD=split: the slab-free head kernels of ppo_head_split.h; =fused: the round-3 kernels (statistics + fused backward + chunk-slab
+        // sums).  Default: whichever the A/B runs of the round measured faster on the benchmark workload (tests run both).
+        const char* hk_ = getenv("CIRS_PPO_HEAD");
+        const bool want_split = hk_ ? (hk_[0] == 's') : kHeadSplitDefault;
         const HeadSplitGeom hg = head_split_geom(I, n_pad);
-        const bool split_head = cfg->ent_coef == 0.f && !merge_launch && !(fk_ && atoi(fk_) != 0) && hg.tiles_per_range * kTileM <= kDwaMaxRows;
+        const bool split_head = want_split && cfg->ent_coef == 0.f && !merge_launch && hg.tiles_per_range * kTileM <= kDwaMaxRows;
         int n_bchunks = 0;
         if (split_head) {
             // 3. head forward: statistics partials + O' = P Wa per (row block, item chunk): all workgroups co-resident (1 per CU), equal tile counts
             const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
             const int n_fch = cdiv(n_item_tiles, tpc);          // <= n_chunks: the partial arrays and the O' slabs fit
+            // the four SoA arrays of the statistics view, used as two [chunk][row] float2 arrays
+            float2* part_ms = reinterpret_cast<float2*>(pv.score);
+            float2* part_tz = reinterpret_cast<float2*>(pv.m);
+            const HeadRowArgs hra{*cfg, (int)(idx_global ? mb_global : mb), n_fch, v.arrive, v, v.row_m};
             CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_fwd_kernel, dim3((n_fch + 7) & ~7, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc,
-                                                      (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, (const int32_t*)v.act, pv, v.dh2p, v.za, v.ez));
+                                                      (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, (const int32_t*)v.act, part_ms, part_tz, v.dh2p, v.za, v.ez, hra));
             CIRS_CHECK_LAUNCH("head_fwd_kernel");
             // 4. head backward: row merge (lse, loss terms, coefficients) + d h2 fold + dWa / dba, one dWa slab per row range
-            const HeadDwaArgs da{*cfg, (int)(idx_global ? mb_global : mb), n_fch, tpc, hg.n_groups, hg.n_ranges, hg.tiles_per_range, pv, v.dh2p,
+            const HeadDwaArgs da{n_fch, tpc, hg.n_groups, hg.n_ranges, hg.tiles_per_range, (const float2*)part_ms, (const float*)v.row_m, v.dh2p,
                                  (const float*)w.wa, v.entw};
             v.n_entw = hg.n_groups * hg.n_ranges;
-            CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_dwa_kernel, dim3(hg.n_groups, hg.n_ranges), dim3(256), 0, s, I, (int)mb, n_pad,
+            CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_dwa_kernel, dim3(hg.n_groups, hg.n_ranges), dim3(kDwaThreads), 0, s, I, (int)mb, n_pad,
                                                       (const uint4*)v.wa_planes, w.ba, v, v.dwap, da));
             CIRS_CHECK_LAUNCH("head_dwa_kernel");
             n_wa_slabs = hg.n_ranges;

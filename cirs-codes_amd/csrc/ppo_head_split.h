@@ -35,8 +35,15 @@ namespace cirs {
 #define CIRS_XTSTAMP(IT, K) do { } while (0)
 #endif
 
+// global -> LDS copy of 16 bytes per lane without staging registers (global_load_lds_dwordx4): lane l of the wave writes lds + 16 l
+typedef __attribute__((address_space(1))) const void* glds_src_t;
+typedef __attribute__((address_space(3))) void* glds_dst_t;
+__device__ __forceinline__ void glds16(const void* g_lane, void* lds_wave) {
+    __builtin_amdgcn_global_load_lds((glds_src_t)g_lane, (glds_dst_t)lds_wave, 16, 0, 0);
+}
+
 constexpr int kDwaMaxSlabs = 8;      // row ranges of head_dwa_kernel = dWa slabs (wa_slab_sum_block keeps 8 in flight)
-constexpr int kDwaMaxRows = 2048;    // rows of one row range (LDS arrays of the row scalars)
+constexpr int kDwaMaxRows = 1024;    // rows of one row range (LDS arrays of the row scalars; one 32-bit mask of row tiles per item tile)
 constexpr int kH2TileU4 = 1536;      // uint4 per 32-row tile of the H2 planes: h2z (768) + h2b (768)
 
 struct HeadSplitGeom { int n_groups, n_ranges, tiles_per_range; };
@@ -46,15 +53,42 @@ inline HeadSplitGeom head_split_geom(int I, int n_pad) {
     R = R < 1 ? 1 : R;
     R = R > kDwaMaxSlabs ? kDwaMaxSlabs : R;
     R = R > n_row_tiles ? n_row_tiles : R;
+    const int r_min = cdiv(n_row_tiles, kDwaMaxRows / kTileM);    // rows of a range must fit the LDS arrays
+    R = R < r_min ? r_min : R;
     const int tpr = cdiv(n_row_tiles, R);
     return HeadSplitGeom{n_groups, cdiv(n_row_tiles, tpr), tpr};
 }
 
 // ---- forward: statistics partials + O' = P Wa ---------------------------------------------------------------------------------
+// Row stage of the head (what round 3 ran in the prologue of its backward kernel, and the first version of this file in the prologue of
+// EVERY head_dwa_kernel workgroup -- 84 redundant merges of each row, 175 KB per workgroup pulled at the ~11 B/cycle a CU gets when
+// all 256 start at once: 20 k of that kernel's 70 k cycles).  Here the LAST workgroup of a row block to finish (arrival counter) folds the
+// chunk partials of the block's 128 rows once: lse, loss terms, backward coefficients.  The partials cross workgroups inside one launch, so
+// they are written through (sc1 stores, completed before the arrival) and read around L1 (sc1 loads): the write-through form of
+// MI355X_MICROARCH.md's inter-workgroup visibility rules -- no L2 write-back fence (that cost 6 us per workgroup in round 1).
+struct HeadRowArgs {
+    cirs_ppo_cfg cfg;
+    int mb_norm;            // rows of the (global) minibatch every mean is taken over
+    int n_chunks;           // chunks that arrive per row block
+    int* counters;          // [n_row_blocks] arrival counters, zeroed by trunk_adv_kernel
+    MbView v;
+    float* row_m;           // [n_pad] out: the row's reference maximum M (d h2 fold); lse -> v.lse, c_logp -> v.c_logp, 1/S -> v.h_ent, 1 - p_a -> v.c_ent
+};
+__device__ __forceinline__ void st_sc1(float2* p, float a, float b) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float* p, float a) { __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float2 ld_sc1(const float2* p) {
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return float2{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))};
+}
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_pad, int tiles_per_chunk, const uint4* __restrict__ planes,
                                                           const float* __restrict__ ba, const uint4* __restrict__ h2z,
-                                                          const int32_t* __restrict__ act_rows, ActorPartialView pv,
-                                                          float* __restrict__ oslab, float* __restrict__ za_out, float* __restrict__ ea_out) {
+                                                          const int32_t* __restrict__ act_rows, float2* __restrict__ part_ms, float2* __restrict__ part_tz,
+                                                          float* __restrict__ oslab, float* __restrict__ za_out, float* __restrict__ ea_out, HeadRowArgs ra) {
     __shared__ __attribute__((aligned(16))) unsigned char sW[2][kWBufB];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];
     const int tid = threadIdx.x;
@@ -84,6 +118,7 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
     for (int r = 0; r < 16; ++r) { dh0[r] = 0.f; dh1[r] = 0.f; }
     float s_acc = 0.f, t_acc = 0.f;      // sum P, sum P z over this half-wave's items (the row's action excluded)
     float nm2 = 0.f;                     // -(m_ref log2 e): P = exp2(z log2 e + nm2)
+    float zmx = -INFINITY;               // largest (z - m_ref) log2 e seen by this half-wave (the action's own logit included)
     float za_val = 0.f, ea_val = 0.f;
     bool za_have = false;
 
@@ -133,8 +168,9 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = sB[buf][acc_row(r, hi)]; acc1[r] = 0.f; }
             CIRS_XTSTAMP(it, 45);
-            mfma_bf16x6_two(za[0], hz[0], acc, za[2], hz[2], acc1);
-            mfma_bf16x6_two(za[1], hz[1], acc, za[3], hz[3], acc1);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) mfma_bf16x6_split(za[s4], hz[s4], acc, acc1);      // acc: bias + the h*h terms, acc1: the cross terms
+
             CIRS_XTSTAMP(it, 46);
             // the B planes of the O' product are requested now (the A planes of the logits are dead); the exponentials cover their latency
 #pragma unroll
@@ -168,10 +204,11 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
                         dh0[r] *= fr; dh1[r] *= fr;
                     }
                 }
-                nm2 -= sh;
+                nm2 -= sh; zmx -= sh; tmax -= sh;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tk[r] -= sh;
             }
+            zmx = __builtin_fmaxf(zmx, tmax);
             CIRS_XTSTAMP(it, 47);
             f32x16 p;
 #pragma unroll
@@ -213,60 +250,174 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
     CIRS_XSTAMP(42);
 #undef CIRS_ISSUE
 #undef CIRS_COMMIT
-    if (!wave_ok) return;
-    float* hslab = oslab + (size_t)chunk * n_pad * kH;
+    if (wave_ok) {
+        s_acc += __shfl_xor(s_acc, 32, CIRS_WAVE);      // the two half-waves: same row, same reference, disjoint items
+        t_acc += __shfl_xor(t_acc, 32, CIRS_WAVE);
+        zmx = __builtin_fmaxf(zmx, __shfl_xor(zmx, 32, CIRS_WAVE));
+        if (hi == 0) {
+            const size_t po = (size_t)chunk * n_pad + jr;
+            st_sc1(&part_ms[po], -nm2 * kLn2, s_acc);               // {m_ref, s'}
+            st_sc1(&part_tz[po], t_acc, (zmx - nm2) * kLn2);        // {t', the chunk's largest logit} (the reported entropy)
+        }
+        if (za_have) { st_sc1(&za_out[jr], za_val); st_sc1(&ea_out[jr], ea_val); }
+    }
+    // ---- arrival: this workgroup's partials are complete in memory (the O' slab, which the row stage does not read, is stored AFTER the
+    // arrival: its 128 KB would otherwise sit in front of the wait); the last of the row block's chunks merges the rows ----
+    __shared__ int sLast;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) sLast = __hip_atomic_fetch_add(&ra.counters[blockIdx.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ra.n_chunks - 1;
+    __syncthreads();
+    if (wave_ok) {
+        float* hslab = oslab + (size_t)chunk * n_pad * kH;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + acc_row(r, hi);
-        hslab[(size_t)row * kH + lo] = dh0[r];
-        hslab[(size_t)row * kH + 32 + lo] = dh1[r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + acc_row(r, hi);
+            hslab[(size_t)row * kH + lo] = dh0[r];
+            hslab[(size_t)row * kH + 32 + lo] = dh1[r];
+        }
     }
-    s_acc += __shfl_xor(s_acc, 32, CIRS_WAVE);      // the two half-waves: same row, same reference, disjoint items
-    t_acc += __shfl_xor(t_acc, 32, CIRS_WAVE);
-    if (hi == 0) {
-        const size_t po = (size_t)chunk * n_pad + jr;
-        pv.m[po] = -nm2 * kLn2; pv.s[po] = s_acc; pv.score[po] = t_acc;
-    }
-    if (za_have) { za_out[jr] = za_val; ea_out[jr] = ea_val; }
     CIRS_XSTAMP(43);
+    if (!sLast) return;
+    {
+        const MbView& v = ra.v;
+        const int nsc = ra.n_chunks;
+        const float red0 = v.red[0], red1 = v.red[1];
+        const float inv_mb = 1.0f / (float)ra.mb_norm;
+        const int jr2 = blockIdx.y * 128 + (tid & 127);           // two threads per row: the chunks split in halves, combined through LDS
+        const int half = tid >> 7;
+        __shared__ float sMrg[128][4];
+        const bool in = jr2 < n_pad;
+        const bool real = in && jr2 < mb;
+        const int jc = real ? jr2 : 0;
+        const int act = act_rows[jc];
+        const float za = ld_sc1(&za_out[jc]), ea = ld_sc1(&ea_out[jc]);
+        const float adv = v.adv[jc], lpo = v.adv[n_pad + jc], ret = v.adv[2 * (size_t)n_pad + jc], vs = v.adv[3 * (size_t)n_pad + jc], val = v.value[jc];
+        const int ca = (act / kTileN) / tiles_per_chunk;
+        float m_ca = -INFINITY;       // reference maximum of the chunk that saw the action (picked from the batch below: no dependent load)
+        float M = -INFINITY, ssum = 0.f, tsum = 0.f, ztop = -INFINITY;
+        const int c_lo = half * ((nsc + 1) >> 1), c_hi = half ? nsc : ((nsc + 1) >> 1);
+        for (int cb = c_lo; cb < c_hi; cb += 16) {      // 2 x 16 partials of a batch requested before the first is used
+            float2 p16[16], q16[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int c = cb + q < c_hi ? cb + q : c_hi - 1;
+                p16[q] = ld_sc1(&part_ms[(size_t)c * n_pad + jc]);
+                q16[q] = ld_sc1(&part_tz[(size_t)c * n_pad + jc]);
+            }
+            float mb_ = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { mb_ = fmaxf(mb_, p16[q].x); m_ca = (cb + q == ca && cb + q < c_hi) ? p16[q].x : m_ca; ztop = fmaxf(ztop, q16[q].y); }
+            const float Mn = fmaxf(M, mb_);
+            const float keep = __expf(M - Mn);      // first batch: exp(-inf) = 0
+            ssum *= keep; tsum *= keep;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float f = cb + q < c_hi ? __expf(p16[q].x - Mn) : 0.f;
+                ssum = __builtin_fmaf(p16[q].y, f, ssum);
+                tsum = __builtin_fmaf(q16[q].x, f, tsum);
+            }
+            M = Mn;
+        }
+        if (half == 1) { sMrg[tid & 127][0] = M; sMrg[tid & 127][1] = ssum; sMrg[tid & 127][2] = tsum; sMrg[tid & 127][3] = ztop; }
+        __shared__ float sMca[128];
+        if (half == 1) sMca[tid & 127] = m_ca;
+        __syncthreads();
+        if (half == 0 && in) {
+            const float M1 = sMrg[tid][0], s1 = sMrg[tid][1], t1 = sMrg[tid][2];
+            ztop = fmaxf(ztop, sMrg[tid][3]);
+            m_ca = fmaxf(m_ca, sMca[tid]);                       // exactly one half saw the action's chunk (the other holds -inf)
+            const float Mn = fmaxf(M, M1);
+            const float f0 = __expf(M - Mn), f1 = __expf(M1 - Mn);   // (lower half first: fixed order)
+            ssum = ssum * f0 + s1 * f1; tsum = tsum * f0 + t1 * f1; M = Mn;
+            const float ea_s = ea * __expf(m_ca - M);
+            const float S = ssum + ea_s;
+            const float lse_r = M + __logf(S);
+            const RowTerms rt = ppo_row_terms(ra.cfg, za, lse_r, __builtin_fmaf(ea_s, za, tsum) / S, lpo, adv, red0, red1, val, vs, ret, inv_mb);
+            // Categorical.entropy takes log(clamp(p, eps, 1 - eps)).  High side (one item holds the whole row, p > 1 - eps): at most one item per row,
+            // the row's largest logit; its term p (log(1 - eps) - log p) equals -(p - (1 - eps)) for the two floats above 1 - eps.  (The low
+            // side is a sum over the whole catalogue: head_dwa_kernel's loop, per workgroup.)
+            const float p_top = __expf(ztop - lse_r);
+            const float ent_hi = -fmaxf(p_top - (1.0f - 1.1920928955078125e-7f), 0.f);
+            v.lse[jr2] = real ? lse_r : 1e30f;            // rows beyond the minibatch: p = exp(z - lse) = 0
+            v.c_logp[jr2] = real ? rt.c_logp : 0.f;
+            v.h_ent[jr2] = 1.0f / S; v.c_ent[jr2] = ssum / S; ra.row_m[jr2] = M;
+            v.dvalue[jr2] = real ? rt.dvalue : 0.f;
+            v.clip_row[jr2] = real ? rt.clip_row : 0.f;
+            v.vf_row[jr2] = real ? rt.vf_row : 0.f;
+            v.ent_row[jr2] = real ? rt.h_ent + ent_hi : 0.f;       // lse - E_p[z] + the high-side clamp term; the low side travels per workgroup (entw)
+        }
+    }
 }
 
 // ---- backward: row merge + d h2 fold + dWa / dba -------------------------------------------------------------------------------
 struct HeadDwaArgs {
-    cirs_ppo_cfg cfg;
-    int mb_norm;          // rows of the (global) minibatch every mean is taken over
     int n_schunks;        // chunks of head_fwd_kernel
     int tiles_per_chunk;  // its tiles per chunk (locates the chunk that saw a row's action)
     int n_groups, n_ranges, tiles_per_range;
-    ActorPartialView pv;
+    const float2* part_ms;  // [n_schunks][n_pad] {m_ref, s'} partials of head_fwd_kernel (the chunk references of the d h2 fold)
+    const float* row_m;     // [n_pad] the rows' reference maxima (head_fwd_kernel's row stage; lse, c_logp, 1/S, 1 - p_a: v.lse, v.c_logp, v.h_ent, v.c_ent)
     float* oslab;         // [n_schunks][n_pad][64] O' slabs; slab 0 receives d h2
     const float* wa;      // fp32 head weights (the action's row in the d h2 fold)
     float* entw;          // [n_groups * n_ranges] clamp correction of the entropy, one scalar per workgroup
 };
 
-__global__ __launch_bounds__(256, 1) void head_dwa_kernel(int I, int mb, int n_pad, const uint4* __restrict__ planes,
-                                                          const float* __restrict__ ba, MbView v, float* __restrict__ dwap, HeadDwaArgs a) {
-    __shared__ __attribute__((aligned(16))) uint4 sH[2][kH2TileU4];
-    __shared__ __attribute__((aligned(16))) float sNl[kDwaMaxRows];     // -(lse log2 e)   (rows beyond the minibatch: -1e30 log2 e -> p = 0)
+constexpr int kDwaThreads = 256;       // 4 waves = the 4 item tiles of the group, ONE wave per SIMD (512 registers: two row tiles in flight per wave)
+constexpr int kXStride = 68;           // floats per item row of the exchange tile (conflict-free b128 accesses)
+
+// d h2 of one (row, 4 columns): sum over the chunks of f_c O'_c with f_c = exp(m_c - M), then c_logp (Wa[a] (1 - p_a) - O' / S)
+__device__ __forceinline__ void fold_store(float* __restrict__ op, f32x4 acc, int act, const float* __restrict__ wa, int c4, float cl, float qa, float is) {
+    f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+    if (act >= 0) w4 = *reinterpret_cast<const f32x4*>(wa + (size_t)act * kH + c4);
+    f32x4 out = (w4 * qa - acc * is) * cl;
+    if (act < 0) out = f32x4{0.f, 0.f, 0.f, 0.f};       // rows beyond the minibatch
+    *reinterpret_cast<f32x4*>(op) = out;
+}
+
+// Main loop of head_dwa_kernel.  A wave's row tile is three segments: L (logits, 24 MFMAs) -> V (dZ, clamp correction, splits: ~250 VALU
+// + 32 LDS reads) -> D (dWa^T, 24 MFMAs), each depending on the one before, and on this part a dependent chain leaves the matrix pipe idle
+// while the vector pipe works (measured: 3.9 k cycles per tile for 1.5 k cycles of MFMAs; running two waves per SIMD in opposite phases
+// did not help: a wave issuing VALU beside its partner's MFMA stream gets ~5 issue slots per MFMA, the same as inside one wave).  So the
+// loop is software-pipelined inside the wave: iteration j holds L of tile j + 1 and V of tile j in ONE block -- independent, so the
+// scheduler fills the MFMA gaps of one with the VALU of the other -- followed by D of tile j, with the LDS reads of the next iteration
+// behind its MFMAs.  The H2 tiles arrive by LDS-DMA three buffers deep (tile j + 2 is requested at the top of iteration j).
+__global__ __launch_bounds__(kDwaThreads, 1) void head_dwa_kernel(int I, int mb, int n_pad, const uint4* __restrict__ planes,
+                                                                  const float* __restrict__ ba, MbView v, float* __restrict__ dwap, HeadDwaArgs a) {
+    __shared__ __attribute__((aligned(16))) uint4 sH[3][kH2TileU4];     // the H2 planes of one 32-row tile (h2z | h2b), three tiles deep
+    __shared__ __attribute__((aligned(16))) float sNl[kDwaMaxRows];     // lse   (rows beyond the minibatch: 1e30 -> p = 0)
     __shared__ __attribute__((aligned(16))) float sNc[kDwaMaxRows];     // -c_logp
     __shared__ __attribute__((aligned(16))) int sAct[kDwaMaxRows];      // taken action (-1: none)
-    __shared__ float sM[kDwaMaxRows], sInvS[kDwaMaxRows], sQa[kDwaMaxRows];   // row maximum, 1 / sum exp, 1 - p_a (d h2 fold)
-    __shared__ unsigned int sMask[4][kDwaMaxRows / kTileM / 32];        // per wave: row tiles that hold an action inside the wave's item tile
+    __shared__ unsigned int sMask[4];                                   // per item tile: row tiles of the range that hold an action inside it
     __shared__ float sEnt[4];
+    static_assert(kDwaMaxRows / kTileM <= 32, "one mask word per item tile");
+    static_assert(4 * kTileN * kXStride * 4 <= (int)sizeof(uint4) * 2 * kH2TileU4, "the exchange tiles reuse two staging buffers");
     const int tid = threadIdx.x;
     CIRS_XSTAMP(30);
-    const int lane = tid & 63, wv = tid >> 6;
+    kernarg_warm<448>();      // (the two by-value views are ~0.5 KB of kernel arguments: one round trip instead of one per first use)
+    const int lane = tid & 63, iw = tid >> 6;     // iw: item tile of the group
     const int hi = lane >> 5, lo = lane & 31;
     const int g = blockIdx.x, rr = blockIdx.y;
     const int rt0 = rr * a.tiles_per_range, rt1 = min(n_pad / kTileM, rt0 + a.tiles_per_range);
     const int n_rt = rt1 - rt0, r_begin = rt0 * kTileM, n_rows = n_rt * kTileM;
-    const int tile0 = (g * 4 + wv) * kTileN;
+    const int tile0 = (g * 4 + iw) * kTileN;
     const bool wave_ok = tile0 < I;
     const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-    // ---- this wave's item tile: the Wa planes (B operand of Z = H2 Wa^T: lane = item, 8 consecutive columns) and the bias ----
+    // the range's row scalars (head_fwd_kernel's row stage) are requested FIRST: memory returns in order, and they are what the loop waits for
+    float rs_lse[kDwaMaxRows / kDwaThreads], rs_cl[kDwaMaxRows / kDwaThreads];
+    int rs_act[kDwaMaxRows / kDwaThreads];
+#pragma unroll
+    for (int q = 0; q < kDwaMaxRows / kDwaThreads; ++q) {
+        const int rl = tid + kDwaThreads * q;
+        const int jr = r_begin + (rl < n_rows ? rl : 0);
+        rs_lse[q] = v.lse[jr]; rs_cl[q] = v.c_logp[jr];
+        rs_act[q] = (rl < n_rows && jr < mb) ? v.act[jr] : -1;
+    }
+    const int my_item = tile0 + lo;
+    const float bias = (wave_ok && my_item < I) ? ba[my_item] : -1e30f;      // beyond the catalogue: z = -1e30 -> p = 0, dZ = 0, no masks
+    // ---- this wave's item tile: the Wa planes (B operand of Z = H2 Wa^T: lane = item, 8 consecutive columns); they stay in registers ----
     Planes zb[4];
     {
-        const uint4* rp = planes + (size_t)(wave_ok ? g * 4 + wv : 0) * kPlaneTileU4 + lo * 8 + hi;
+        const uint4* rp = planes + (size_t)(wave_ok ? g * 4 + iw : 0) * kPlaneTileU4 + lo * 8 + hi;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             zb[s4].h = __builtin_bit_cast(bf16x8, rp[2 * s4]);
@@ -274,253 +425,242 @@ __global__ __launch_bounds__(256, 1) void head_dwa_kernel(int I, int mb, int n_p
             zb[s4].l = __builtin_bit_cast(bf16x8, rp[512 + 2 * s4]);
         }
     }
-    const int my_item = tile0 + lo;
-    const float bias = (wave_ok && my_item < I) ? ba[my_item] : -1e30f;      // beyond the catalogue: z = -1e30 -> p = 0, dZ = 0, no masks
-    // first H2 tile on its way while the rows are merged
-    uint4 st0, st1, st2, st3, st4, st5;
-#define CIRS_ISSUE(RT)                                                                                     \
+    // staging: straight from global memory into LDS (global_load_lds: the planes already are in register order, so the image is lane-linear:
+    // no staging registers, no ds_write pass).  Wave iw copies units [64 iw, 64 iw + 64) of each of the six 256-unit plane blocks.
+#define CIRS_STAGE(KT, BUF)                                                                                \
     do {                                                                                                   \
-        const uint4* z_ = v.h2z + (size_t)(RT) * 768 + tid;                                                \
-        const uint4* b_ = v.h2b + (size_t)(RT) * 768 + tid;                                                \
-        st0 = z_[0]; st1 = z_[256]; st2 = z_[512]; st3 = b_[0]; st4 = b_[256]; st5 = b_[512];              \
+        const uint4* z_ = v.h2z + (size_t)(rt0 + (KT)) * 768 + 64 * iw + lane;                             \
+        const uint4* b_ = v.h2b + (size_t)(rt0 + (KT)) * 768 + 64 * iw + lane;                             \
+        uint4* d_ = sH[BUF] + 64 * iw;                                                                     \
+        glds16(z_, d_); glds16(z_ + 256, d_ + 256); glds16(z_ + 512, d_ + 512);                            \
+        glds16(b_, d_ + 768); glds16(b_ + 256, d_ + 1024); glds16(b_ + 512, d_ + 1280);                    \
     } while (0)
-#define CIRS_COMMIT(BUF)                                                                                   \
-    do {                                                                                                   \
-        uint4* d_ = sH[BUF] + tid;                                                                         \
-        d_[0] = st0; d_[256] = st1; d_[512] = st2; d_[768] = st3; d_[1024] = st4; d_[1280] = st5;          \
-    } while (0)
-    if (n_rt > 0) CIRS_ISSUE(rt0);
-    if (tid < 4 * (kDwaMaxRows / kTileM / 32)) (&sMask[0][0])[tid] = 0u;
-    __syncthreads();
+    if (n_rt > 0) CIRS_STAGE(0, 0);
+    if (n_rt > 1) CIRS_STAGE(1, 1);
+    if (tid < 4) sMask[tid] = 0u;
+    const int nsc = a.n_schunks;
+    // ---- d h2 fold, first half: this workgroup's slice of the range's rows.  One (row, 4 columns) item per thread and third of the chunks:
+    // its O' slab pieces and chunk references are requested here and travel while the rows are merged ----
+    const int fold_k = (n_rows + a.n_groups - 1) / a.n_groups, fold_s0 = g * fold_k;
+    const int f_per = (nsc + 2) / 3;                     // chunks per third
+    const bool fold_fast = fold_k * 16 * 3 <= kDwaThreads && f_per <= 12;
+    const int f_item = tid % (fold_k * 16 > 0 ? fold_k * 16 : 1), f_third = tid / (fold_k * 16 > 0 ? fold_k * 16 : 1);
+    const int f_rl = fold_s0 + (f_item >> 4), f_c4 = (f_item & 15) * 4;
+    const bool f_on = fold_fast && f_third < 3 && f_rl < n_rows;
+    f32x4 fo[12];
+    float fm[12];
+    if (f_on) {
+        const int jr = r_begin + f_rl;
+        const float* __restrict__ pm_ = reinterpret_cast<const float*>(a.part_ms + jr);
+        const float* __restrict__ op_ = a.oslab + (size_t)jr * kH + f_c4;
+        const size_t cstride = (size_t)n_pad * kH;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int c0 = f_third * f_per + q;
+            const int c = c0 < nsc ? c0 : nsc - 1;
+            fm[q] = pm_[(size_t)c * n_pad * 2];
+            fo[q] = *reinterpret_cast<const f32x4*>(op_ + (size_t)c * cstride);
+        }
+    }
+    lds_barrier();      // (the mask words are cleared; NOT __syncthreads: the requests above stay in flight)
     CIRS_XSTAMP(31);
-    // ---- row merge: chunk partials of the range's rows -> lse, loss terms, backward coefficients (one thread per row) ----
-    {
-        const int nsc = a.n_schunks;
-        const float red0 = v.red[0], red1 = v.red[1];
-        const float inv_mb = 1.0f / (float)a.mb_norm;
-        for (int rb = 0; rb < n_rows; rb += 256) {
-            const int rl = rb + tid;
-            const bool in = rl < n_rows;
-            const int jr = r_begin + (in ? rl : 0);
-            const bool real = in && jr < mb;
-            const int jc = real ? jr : 0;
-            const int act = v.act[jc];
-            const float za = v.za[jc], ea = v.ez[jc], adv = v.adv[jc], lpo = v.adv[n_pad + jc], ret = v.adv[2 * (size_t)n_pad + jc],
-                        vs = v.adv[3 * (size_t)n_pad + jc], val = v.value[jc];
-            const int ca = (act / kTileN) / a.tiles_per_chunk;
-            const float* __restrict__ pm_ = a.pv.m + jc;
-            const float* __restrict__ ps_ = a.pv.s + jc;
-            const float* __restrict__ pt_ = a.pv.score + jc;
-            const float m_ca = pm_[(size_t)ca * n_pad];
-            float M = -INFINITY, ssum = 0.f, tsum = 0.f;
-            for (int cb = 0; cb < nsc; cb += 32) {      // all 3 x 32 partials of a batch requested before the first is used
-                float m32[32], s32[32], u32[32];
+    // ---- the range's row scalars (head_fwd_kernel's row stage): lse, -c_logp, action -> LDS; the row tiles that hold an action of each item tile ----
+    float f_M = 0.f, f_is = 0.f, f_qa = 0.f;
+    if (f_on) { const int jr = r_begin + f_rl; f_M = a.row_m[jr]; f_is = v.h_ent[jr]; f_qa = v.c_ent[jr]; }
 #pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    const int c = cb + q;
-                    const size_t o = (size_t)(c < nsc ? c : nsc - 1) * n_pad;
-                    m32[q] = pm_[o]; s32[q] = ps_[o]; u32[q] = pt_[o];
-                }
-                float mb_ = -INFINITY;
-#pragma unroll
-                for (int q = 0; q < 32; ++q) mb_ = fmaxf(mb_, m32[q]);
-                const float Mn = fmaxf(M, mb_);
-                const float keep = __expf(M - Mn);      // first batch: exp(-inf) = 0
-                ssum *= keep; tsum *= keep;
-#pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    const float f = cb + q < nsc ? __expf(m32[q] - Mn) : 0.f;
-                    ssum = __builtin_fmaf(s32[q], f, ssum);
-                    tsum = __builtin_fmaf(u32[q], f, tsum);
-                }
-                M = Mn;
-            }
-            const float ea_s = ea * __expf(m_ca - M);
-            const float S = ssum + ea_s;
-            const float lse_r = M + __logf(S);
-            const RowTerms rt = ppo_row_terms(a.cfg, za, lse_r, __builtin_fmaf(ea_s, za, tsum) / S, lpo, adv, red0, red1, val, vs, ret, inv_mb);
-            if (in) {
-                sNl[rl] = real ? -(lse_r * kLog2e) : -1.4426950408889634e30f;
-                sNc[rl] = real ? -rt.c_logp : 0.f;
-                sAct[rl] = real ? act : -1;
-                sM[rl] = M; sInvS[rl] = 1.0f / S; sQa[rl] = ssum / S;
-                if (real) {
-                    const int ita = act / kTileN;
-                    if ((ita >> 2) == g) atomicOr(&sMask[ita & 3][(rl >> 5) >> 5], 1u << ((rl >> 5) & 31));
-                }
-                if (g == 0) {      // one writer per row: what trunk_bwd_kernel and the loss sums read
-                    v.dvalue[jr] = real ? rt.dvalue : 0.f;
-                    v.clip_row[jr] = real ? rt.clip_row : 0.f;
-                    v.vf_row[jr] = real ? rt.vf_row : 0.f;
-                    v.ent_row[jr] = real ? rt.h_ent : 0.f;       // un-clamped entropy lse - E_p[z]; the clamp correction travels per workgroup (entw)
-                }
-            }
+    for (int q = 0; q < kDwaMaxRows / kDwaThreads; ++q) {
+        const int rl = tid + kDwaThreads * q;
+        if (rl < n_rows) {
+            sNl[rl] = rs_lse[q];
+            sNc[rl] = -rs_cl[q];
+            sAct[rl] = rs_act[q];
+            if (rs_act[q] >= 0 && ((rs_act[q] / kTileN) >> 2) == g) atomicOr(&sMask[(rs_act[q] / kTileN) & 3], 1u << (rl >> 5));
         }
     }
     CIRS_XSTAMP(32);
-    if (n_rt > 0) CIRS_COMMIT(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CIRS_XSTAMP(33);
-    // ---- side job: this workgroup's slice of the range's rows, O' slabs -> d h2 (slab 0) ----
-    {
-        const int nsc = a.n_schunks;
-        const int k = (n_rows + a.n_groups - 1) / a.n_groups;
-        const int s0 = g * k;
-        for (int w = tid; w < k * 16; w += 256) {
-            const int rl = s0 + (w >> 4), c4 = (w & 15) * 4;
+    // ---- d h2 fold, second half: scale by f_c = exp(m_c - M), the three thirds meet in LDS (fixed order), c_logp (Wa[a] (1 - p_a) - O' / S) -> slab 0 ----
+    float* xf = reinterpret_cast<float*>(&sH[2][0]);      // (tile 2 is staged at the top of iteration 0, after the barrier below)
+    if (fold_fast) {
+        if (f_on) {
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 12; ++q) acc4 += fo[q] * ((q < f_per && f_third * f_per + q < nsc) ? __expf(fm[q] - f_M) : 0.f);
+            *reinterpret_cast<f32x4*>(xf + (size_t)(f_third * fold_k * 16 + f_item) * 4) = acc4;
+        }
+        __syncthreads();
+        if (f_on && f_third == 0) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(xf + (size_t)f_item * 4), t1 = *reinterpret_cast<const f32x4*>(xf + (size_t)(fold_k * 16 + f_item) * 4),
+                        t2 = *reinterpret_cast<const f32x4*>(xf + (size_t)(2 * fold_k * 16 + f_item) * 4);
+            fold_store(a.oslab + (size_t)(r_begin + f_rl) * kH + f_c4, (t0 + t1) + t2, sAct[f_rl], a.wa, f_c4, -sNc[f_rl], f_qa, f_is);
+        }
+        __syncthreads();
+    } else {        // (large slices / many chunks: plain loop)
+        for (int w = tid; w < fold_k * 16; w += kDwaThreads) {
+            const int rl = fold_s0 + (w >> 4), c4 = (w & 15) * 4;
             if (rl >= n_rows) break;
             const int jr = r_begin + rl;
-            const float M = sM[rl];
-            const float* __restrict__ pm_ = a.pv.m + jr;
+            const float M = a.row_m[jr];
+            const float* __restrict__ pm_ = reinterpret_cast<const float*>(a.part_ms + jr);
             float* __restrict__ op_ = a.oslab + (size_t)jr * kH + c4;
             const size_t cstride = (size_t)n_pad * kH;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int cb = 0; cb < nsc; cb += 32) {
-                f32x4 o32[32];
-                float m32[32];
-#pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    const int c = cb + q < nsc ? cb + q : nsc - 1;
-                    m32[q] = pm_[(size_t)c * n_pad];
-                    o32[q] = *reinterpret_cast<const f32x4*>(op_ + (size_t)c * cstride);
-                }
-#pragma unroll
-                for (int q = 0; q < 32; ++q) {
-                    const float f = cb + q < nsc ? __expf(m32[q] - M) : 0.f;
-                    acc += o32[q] * f;
-                }
-            }
-            const int act = sAct[rl];
-            f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
-            if (act >= 0) w4 = *reinterpret_cast<const f32x4*>(a.wa + (size_t)act * kH + c4);
-            const float cl = -sNc[rl], qa = sQa[rl], is = sInvS[rl];
-            f32x4 out = (w4 * qa - acc * is) * cl;
-            if (act < 0) out = f32x4{0.f, 0.f, 0.f, 0.f};       // rows beyond the minibatch
-            *reinterpret_cast<f32x4*>(op_) = out;
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < nsc; ++c) acc4 += *reinterpret_cast<const f32x4*>(op_ + (size_t)c * cstride) * __expf(pm_[(size_t)c * n_pad * 2] - M);
+            fold_store(op_, acc4, sAct[rl], a.wa, c4, -sNc[rl], v.c_ent[jr], v.h_ent[jr]);
         }
     }
     CIRS_XSTAMP(34);
-    // ---- main loop over the row tiles of the range ----
-    static_assert(kDwaMaxRows / kTileM / 32 == 2, "two mask words per wave");
-    const unsigned long long amask = (unsigned long long)__builtin_amdgcn_readfirstlane(sMask[wv][0]) |
-                                     ((unsigned long long)__builtin_amdgcn_readfirstlane(sMask[wv][1]) << 32);
+    const unsigned int amask = __builtin_amdgcn_readfirstlane(sMask[iw]);
     f32x16 dw0, dw1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; }
-    float db = 0.f, ent = 0.f;
-    f32x2_b elo2 = {0.f, 0.f};
-    const float eps = 1.1920928955078125e-7f, kLog1mEps = -1.1920929665620834e-7f, kTEps = -23.0f;
-    for (int kt = 0; kt < n_rt; ++kt) {
-        const int buf = kt & 1;
-        CIRS_XTSTAMP(kt, 0);
-        if (kt + 1 < n_rt) CIRS_ISSUE(rt0 + kt + 1);
-        if (wave_ok) {
-            const uint4* th = sH[buf] + lane;
-            Planes hz[4], hb[2][2];
+    f32x16 acc, acs;       // logits of the CURRENT tile: bias + the h*h terms | the cross terms (mfma_bf16x6_split)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                hz[s4].h = __builtin_bit_cast(bf16x8, th[(3 * s4) * 64]);
-                hz[s4].m = __builtin_bit_cast(bf16x8, th[(3 * s4 + 1) * 64]);
-                hz[s4].l = __builtin_bit_cast(bf16x8, th[(3 * s4 + 2) * 64]);
-            }
-            f32x16 acc, acc1;
+    for (int r = 0; r < 16; ++r) { acc[r] = bias; acs[r] = 0.f; }
+    Planes hz[4];
+    {   // L_0
+        const uint4* th = sH[0] + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = bias; acc1[r] = 0.f; }
-            CIRS_XTSTAMP(kt, 1);
-            // Z[row][item]: A = the H2 rows (lane = row), B = this wave's Wa tile (lane = item) -> the lane owns item lo, registers are rows
-            mfma_bf16x6_two(hz[0], zb[0], acc, hz[2], zb[2], acc1);
-            mfma_bf16x6_two(hz[1], zb[1], acc, hz[3], zb[3], acc1);
-            CIRS_XTSTAMP(kt, 2);
-            // A operand of the dWa^T product (H2^T: lane = column, 8 rows in accumulator order) + the rows' scalars
+        for (int s4 = 0; s4 < 4; ++s4) {
+            hz[s4].h = __builtin_bit_cast(bf16x8, th[(3 * s4) * 64]);
+            hz[s4].m = __builtin_bit_cast(bf16x8, th[(3 * s4 + 1) * 64]);
+            hz[s4].l = __builtin_bit_cast(bf16x8, th[(3 * s4 + 2) * 64]);
+        }
+        // Z[row][item]: A = the H2 rows (lane = row), B = this wave's Wa tile (lane = item) -> the lane owns item lo, registers are rows
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+        for (int s4 = 0; s4 < 4; ++s4) mfma_bf16x6_split(hz[s4], zb[s4], acc, acs);
+    }
+    float db = 0.f;
+    float elo = 0.f;
+    const float kLogEps = -15.942385152878742f;
+    // operands of the D product of the PREVIOUS tile (zeros before the first: D_-1 adds nothing)
+    Planes hbP[2][2], plP[2];
+    {
+        const pk4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    hb[c][t].h = __builtin_bit_cast(bf16x8, th[(12 + 3 * (2 * c + t)) * 64]);
-                    hb[c][t].m = __builtin_bit_cast(bf16x8, th[(12 + 3 * (2 * c + t) + 1) * 64]);
-                    hb[c][t].l = __builtin_bit_cast(bf16x8, th[(12 + 3 * (2 * c + t) + 2) * 64]);
-                }
-            const int base = kt * kTileM + 4 * hi;       // register r of the lane is row base + 8 (r >> 2) + (r & 3) of the range
-            f32x4 nl4[4], nc4[4];
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { hbP[c][t].h = __builtin_bit_cast(bf16x8, z4); hbP[c][t].m = hbP[c][t].h; hbP[c][t].l = hbP[c][t].h; }
+        plP[0].h = plP[0].m = plP[0].l = plP[1].h = plP[1].m = plP[1].l = __builtin_bit_cast(bf16x8, z4);
+    }
+    int buf = 0;       // buffer of tile j
+    for (int j = 0; j < n_rt; ++j) {
+        const int bn = buf == 2 ? 0 : buf + 1;       // buffer of tile j + 1; tile j + 2 goes where tile j - 1 was
+        const bool more = j + 1 < n_rt;
+        CIRS_XTSTAMP(j, 0);
+        if (j + 2 < n_rt) CIRS_STAGE(j + 2, bn == 2 ? 0 : bn + 1);
+        const uint4* th = sH[buf] + lane;
+        const uint4* tn = sH[more ? bn : buf] + lane;     // (after the last tile: a harmless re-read, those logits are not used)
+        const int base = j * kTileM + 4 * hi;       // register r of the lane is row base + 8 (r >> 2) + (r & 3) of the range
+        // ---- one branch-free block per iteration:  [D_j-1 beside dZ_j]  then  [L_j+1 beside split_j] ----
+        f32x4 nl4[4], nc4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            nl4[g4] = *reinterpret_cast<const f32x4*>(&sNl[base + 8 * g4]);
+            nc4[g4] = *reinterpret_cast<const f32x4*>(&sNc[base + 8 * g4]);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            hz[s4].h = __builtin_bit_cast(bf16x8, tn[(3 * s4) * 64]);
+            hz[s4].m = __builtin_bit_cast(bf16x8, tn[(3 * s4 + 1) * 64]);
+            hz[s4].l = __builtin_bit_cast(bf16x8, tn[(3 * s4 + 2) * 64]);
+        }
+        // D_j-1: dWa^T += H2^T dZ of the previous tile (operands in registers since the previous iteration)
+        mfma_bf16x6_pair_b(hbP[0][0], hbP[1][0], plP[0], dw0, dw1);
+        mfma_bf16x6_pair_b(hbP[0][1], hbP[1][1], plP[1], dw0, dw1);
+        // dZ_j in place: d = z - lse FIRST (exact where it matters: the items that carry the row's probability have z ~ lse; one fma against
+        // -lse log2 e loses |lse| 2^-24 there, 3x the error of a float32 soft-max on a sharp policy), p = exp2(d log2 e), dZ = -c_logp p.
+        // Entropy clamp correction, low side (p < eps <=> d < log eps): p (log eps - d), branch-free (the high side is one item per row: the
+        // merge handles it).  Plain (not packed) operations: a packed fp32 op costs several issue slots beside MFMAs on this part.
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = (acc[r] + acs[r]) - nl4[r >> 2][r & 3];
+            const float p = __builtin_amdgcn_exp2f(d * kLog2e);
+            elo = __builtin_fmaf(p, __builtin_fmaxf(kLogEps - d, 0.f), elo);
+            acc[r] = nc4[r >> 2][r & 3] * p;
+        }
+        // (the schedule of the block above: every MFMA of D with its share of the dZ work behind it)
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x402, 6, 0);
+        }
+        // The taken action's own term (+ c_logp on item a_r of row r) is applied to dZ itself, before the split: c (1 - p) is formed in one fp32
+        // subtraction per element (a rank-one fp32 update of the accumulators instead was measured: the accumulator then carries the large
+        // c H2[r] until the -c p H2[r] terms cancel it, and a sharp policy loses a digit).  Scalar test per tile (~9 % of the tiles enter).
+        if ((amask >> j) & 1u) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                nl4[g4] = *reinterpret_cast<const f32x4*>(&sNl[base + 8 * g4]);
-                nc4[g4] = *reinterpret_cast<const f32x4*>(&sNc[base + 8 * g4]);
+                const int4 a4 = *reinterpret_cast<const int4*>(&sAct[base + 8 * g4]);
+                const float f0 = a4.x == my_item ? nc4[g4][0] : 0.f, f1 = a4.y == my_item ? nc4[g4][1] : 0.f,
+                            f2 = a4.z == my_item ? nc4[g4][2] : 0.f, f3 = a4.w == my_item ? nc4[g4][3] : 0.f;
+                acc[4 * g4] -= f0; acc[4 * g4 + 1] -= f1; acc[4 * g4 + 2] -= f2; acc[4 * g4 + 3] -= f3;
             }
-            // dZ in place: t = (z - lse) log2 e as one fma, p = exp2(t), dZ = -c_logp p (+ c_logp on the row's action, below).  Entropy clamp
-            // correction, low side (p < eps = 2^-23 <=> t < -23): ln2 p (-23 - t), branch-free; high side (p > 1 - eps) a rare branch.
-            CIRS_XTSTAMP(kt, 3);
-            f32x16 tk;
-            float pmax = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float t0 = __builtin_fmaf(acc[r] + acc1[r], kLog2e, nl4[r >> 2][r & 3]);
-                const float t1 = __builtin_fmaf(acc[r + 1] + acc1[r + 1], kLog2e, nl4[r >> 2][(r & 3) + 1]);
-                const float p0 = __builtin_amdgcn_exp2f(t0), p1 = __builtin_amdgcn_exp2f(t1);
-                tk[r] = t0; tk[r + 1] = t1;
-                pmax = __builtin_fmaxf(__builtin_fmaxf(pmax, p0), p1);
-                const f32x2_b d2 = f32x2_b{kTEps, kTEps} - f32x2_b{t0, t1};
-                const f32x2_b w2 = {__builtin_fmaxf(d2.x, 0.f), __builtin_fmaxf(d2.y, 0.f)};
-                elo2 = f32x2_b{p0, p1} * w2 + elo2;
-                acc[r] = nc4[r >> 2][r & 3] * p0; acc[r + 1] = nc4[r >> 2][(r & 3) + 1] * p1;
-            }
-            CIRS_XTSTAMP(kt, 4);
-            if ((amask >> kt) & 1ull) {      // scalar test: some row of this tile took an item of this wave's tile
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int4 a4 = *reinterpret_cast<const int4*>(&sAct[base + 8 * g4]);
-                    acc[4 * g4] -= a4.x == my_item ? nc4[g4][0] : 0.f;
-                    acc[4 * g4 + 1] -= a4.y == my_item ? nc4[g4][1] : 0.f;
-                    acc[4 * g4 + 2] -= a4.z == my_item ? nc4[g4][2] : 0.f;
-                    acc[4 * g4 + 3] -= a4.w == my_item ? nc4[g4][3] : 0.f;
-                }
-            }
-            if (__any(pmax > 1.0f - eps)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(tk[r]);
-                    ent -= p > 1.0f - eps ? p * (kLog1mEps - tk[r] * kLn2) : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) db += acc[r];
-            CIRS_XTSTAMP(kt, 5);
-            if (kt + 1 < n_rt) CIRS_COMMIT(buf ^ 1);
-            CIRS_XTSTAMP(kt, 6);
-            {
-                const Planes b0 = split8(acc, 0), b1 = split8(acc, 8);   // element j of k-step t: dZ[row acc_row(8 t + j, hi)][item lo]
-                mfma_bf16x6_pair_b(hb[0][0], hb[1][0], b0, dw0, dw1);
-                mfma_bf16x6_pair_b(hb[0][1], hb[1][1], b1, dw0, dw1);
-            }
-            CIRS_XTSTAMP(kt, 7);
-        } else {
-            if (kt + 1 < n_rt) CIRS_COMMIT(buf ^ 1);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) db += acc[r];      // (after the action's term: the sum never carries the large -c p of a row's own item alone)
+        // split_j -> the B operand of D_j; the A operand (H2^T: lane = column, 8 rows in accumulator order) for the next iteration
+        plP[0] = split8(acc, 0); plP[1] = split8(acc, 8);   // element j of k-step t: dZ[row acc_row(8 t + j, hi)][item lo]
+        // L_j+1 (needs the rows read above)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = bias; acs[r] = 0.f; }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) mfma_bf16x6_split(hz[s4], zb[s4], acc, acs);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                hbP[c][t].h = __builtin_bit_cast(bf16x8, th[(12 + 3 * (2 * c + t)) * 64]);
+                hbP[c][t].m = __builtin_bit_cast(bf16x8, th[(12 + 3 * (2 * c + t) + 1) * 64]);
+                hbP[c][t].l = __builtin_bit_cast(bf16x8, th[(12 + 3 * (2 * c + t) + 2) * 64]);
+            }
+        // the schedule of this block: every MFMA with its share of the vector work behind it
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);
+        }
+        CIRS_XTSTAMP(j, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile j + 2 has landed (requested a whole iteration ago)
         lds_barrier();
-        CIRS_XTSTAMP(kt, 8);
+        CIRS_XTSTAMP(j, 2);
+        buf = bn;
     }
+    // D of the last tile
+    mfma_bf16x6_pair_b(hbP[0][0], hbP[1][0], plP[0], dw0, dw1);
+    mfma_bf16x6_pair_b(hbP[0][1], hbP[1][1], plP[1], dw0, dw1);
+    float ent = -elo;
     CIRS_XSTAMP(35);
-#undef CIRS_ISSUE
-#undef CIRS_COMMIT
-    // ---- results: the wave's dWa tile (lane = item, registers = 4 consecutive columns x 8), dba, the workgroup's entropy correction ----
-    ent -= kLn2 * (elo2.x + elo2.y);
+#undef CIRS_STAGE
+    // ---- results: the wave's dWa tile leaves through LDS as whole 256-byte item rows; dba; the workgroup's entropy correction ----
     if (!wave_ok) ent = 0.f;
     ent = wave_sum_f32_dpp(ent);
-    if (lane == 0) sEnt[wv] = ent;
+    if (lane == 0) sEnt[iw] = ent;
+    db += __shfl_xor(db, 32, CIRS_WAVE);
+    float* xt = reinterpret_cast<float*>(&sH[0][0]) + iw * (kTileN * kXStride);     // (every wave is past the last barrier: the staging buffers are free)
+    float* xrow = xt + lo * kXStride + 4 * hi;        // lane = item lo; its registers are columns 32 c + 8 g4 + 4 hi + (0..3)
     if (wave_ok) {
-        float* slab = dwap + (size_t)rr * dwa_slab_stride(I);
-        if (my_item < I) {
-            float* orow = slab + (size_t)my_item * kH + 4 * hi;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                *reinterpret_cast<f32x4*>(orow + 8 * g4) = f32x4{dw0[4 * g4], dw0[4 * g4 + 1], dw0[4 * g4 + 2], dw0[4 * g4 + 3]};
-                *reinterpret_cast<f32x4*>(orow + 32 + 8 * g4) = f32x4{dw1[4 * g4], dw1[4 * g4 + 1], dw1[4 * g4 + 2], dw1[4 * g4 + 3]};
-            }
+        for (int g4 = 0; g4 < 4; ++g4) {
+            *reinterpret_cast<f32x4*>(xrow + 8 * g4) = f32x4{dw0[4 * g4], dw0[4 * g4 + 1], dw0[4 * g4 + 2], dw0[4 * g4 + 3]};
+            *reinterpret_cast<f32x4*>(xrow + 32 + 8 * g4) = f32x4{dw1[4 * g4], dw1[4 * g4 + 1], dw1[4 * g4 + 2], dw1[4 * g4 + 3]};
         }
-        db += __shfl_xor(db, 32, CIRS_WAVE);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* slab = dwap + (size_t)rr * dwa_slab_stride(I);
+        const bool full = tile0 + kTileN <= I;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {      // 4 item rows (1 KB of consecutive memory) per store instruction
+            const int il = 4 * q + (lane >> 4), c4 = (lane & 15) * 4;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(xt + il * kXStride + c4);
+            if (full || tile0 + il < I) *reinterpret_cast<f32x4*>(slab + (size_t)(tile0 + il) * kH + c4) = t;
+        }
         if (hi == 0 && my_item < I) slab[(size_t)I * kH + my_item] = db;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) a.entw[rr * a.n_groups + g] = (sEnt[0] + sEnt[1]) + (sEnt[2] + sEnt[3]);
     CIRS_XSTAMP(36);
 }

@@ -39,13 +39,12 @@ def show(title, names, base):
 
 
 show("head_fwd_kernel, workgroup (0,0) thread 0 (raw s_memtime ticks):",
-     {40: "entry", 41: "H2 planes requested, first Wa tile staged, barrier", 42: "all tiles", 43: "O' slab + partial stores"}, 40)
+     {40: "entry", 41: "H2 planes requested, first Wa tile staged, barrier", 42: "all tiles", 43: "O' slab + partial stores (write-through)"}, 40)
 show("head_fwd_kernel, third tile:",
      {44: "tile start", 45: "next tile requested, za reads, bias init", 46: "logits MFMAs (24)", 47: "cb reads, z sums, t, max, reference test", 48: "16 exp2, action test, sums",
       49: "plane commit", 50: "split + O' MFMAs (24)", 51: "barrier"}, 44)
 show("head_dwa_kernel, workgroup (0,0) thread 0:",
-     {30: "entry", 31: "Wa tile planes + bias + first H2 tile requested, mask cleared, barrier", 32: "row merge (2 passes of 256 rows)", 33: "first H2 tile committed, barrier",
-      34: "d h2 fold of the workgroup's slice", 35: "all row tiles", 36: "dWa tile / dba / entropy stores"}, 30)
-show("head_dwa_kernel, third row tile:",
-     {0: "tile start", 1: "next tile requested, hz reads", 2: "logits MFMAs (24)", 3: "hb + row scalar reads", 4: "dZ (exp2, coefficients, clamp correction)", 5: "action / clamp branches, dba",
-      6: "plane commit", 7: "split + dWa MFMAs (24)", 8: "barrier"}, 0)
+     {30: "entry", 31: "Wa tile planes + bias + first H2 tile requested, mask cleared, barrier", 32: "row scalars -> LDS, action masks", 33: "wait for the first H2 tile, barrier",
+      34: "d h2 fold of the slice, Wa planes of the item tile", 35: "all row tiles", 36: "dWa tile / dba / entropy stores"}, 30)
+show("head_dwa_kernel, third iteration:",
+     {0: "iteration start", 1: "[D_j-1 | dZ_j] [L_j+1 | split_j] (one block)", 2: "wait for the LDS-DMA, barrier"}, 0)
