@@ -88,6 +88,23 @@ __device__ __forceinline__ void mfma_bf16x6_split(const Planes& a, const Planes&
     small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, small, 0, 0, 0);
     small = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, small, 0, 0, 0);
 }
+// Two k-steps at once with TWO cross-term accumulators, issued so that no MFMA follows one it depends on (a dependent bf16 MFMA waits ~8 cycles
+// longer for its predecessor): for kernels whose MFMA groups run back to back without vector work in between.  z = big + (sm0 + sm1).
+__device__ __forceinline__ void mfma_bf16x6_split2(const Planes& a0, const Planes& b0, const Planes& a1, const Planes& b1, f32x16_b& big, f32x16_b& sm0,
+                                                   f32x16_b& sm1) {
+    sm0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b0.h, sm0, 0, 0, 0);
+    sm1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.l, b1.h, sm1, 0, 0, 0);
+    big = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.h, big, 0, 0, 0);
+    sm0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.l, sm0, 0, 0, 0);
+    sm1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.l, sm1, 0, 0, 0);
+    big = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.h, big, 0, 0, 0);
+    sm0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b0.m, sm0, 0, 0, 0);
+    sm1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b1.m, sm1, 0, 0, 0);
+    sm0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b0.h, sm0, 0, 0, 0);
+    sm1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b1.h, sm1, 0, 0, 0);
+    sm0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.m, sm0, 0, 0, 0);
+    sm1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.m, sm1, 0, 0, 0);
+}
 // two independent accumulators sharing the A operand, issued alternately: a dependent bf16 MFMA waits ~40 cycles for its
 // predecessor, an independent one issues after 32
 __device__ __forceinline__ void mfma_bf16x6_pair(const Planes& a, const Planes& b0, const Planes& b1, f32x16_b& c0, f32x16_b& c1) {

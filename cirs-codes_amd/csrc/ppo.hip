@@ -657,12 +657,14 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
                 za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);
                 za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);
             }
-            f32x16 acc;
+            f32x16 acc, accs, acct;      // bias + the h*h terms | the cross terms, two chains (bf16x6.h: the logits round once per k-step at their own magnitude)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = sB[buf][acc_row(r, hi)];
+            for (int r = 0; r < 16; ++r) { acc[r] = sB[buf][acc_row(r, hi)]; accs[r] = 0.f; acct[r] = 0.f; }
             if (it == 2) CIRS_SSTAMP(44);
+            mfma_bf16x6_split2(za[0], hz[0], za[1], hz[1], acc, accs, acct);
+            mfma_bf16x6_split2(za[2], hz[2], za[3], hz[3], acc, accs, acct);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = mfma_bf16x6(za[s4], hz[s4], acc);
+            for (int r = 0; r < 16; ++r) acc[r] += accs[r] + acct[r];
             if (it == 2) CIRS_SSTAMP(45);
             {
                 const int arel = act_r - tile0;
@@ -981,14 +983,17 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
                 za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);
                 za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);
             }
-            f32x16 acc, acc1;
+            f32x16 acc, acc1, acc2;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = sB[buf][acc_row(r, hi)]; acc1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { acc[r] = sB[buf][acc_row(r, hi)]; acc1[r] = 0.f; acc2[r] = 0.f; }
             CIRS_HSTAMP(1);
-            mfma_bf16x6_two(za[0], hz[0], acc, za[2], hz[2], acc1);
+            // (acc: bias + the h*h terms, acc1 / acc2: the cross terms -- same split as head_stats_kernel, so that p = exp(z - lse) sums to one)
+            mfma_bf16x6_split2(za[0], hz[0], za[1], hz[1], acc, acc1, acc2);
             RedRegs rg;
             if (CIRS_BWD_REDUCE_POS == 0 && it > 0) reduce_load(buf ^ 1, rg);
-            mfma_bf16x6_two(za[1], hz[1], acc, za[3], hz[3], acc1);
+            mfma_bf16x6_split2(za[2], hz[2], za[3], hz[3], acc, acc1, acc2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] += acc2[r];
             if (CIRS_BWD_REDUCE_POS == 0 && it > 0) reduce_store(rg, tile0 - kTileN);
             // the B planes of the dH2 product are requested only now: the A planes of the logits are dead (the two sets never coexist:
             // the kernel runs at the 256-VGPR limit and every value beyond it costs an AGPR copy per use) and the dZ arithmetic below

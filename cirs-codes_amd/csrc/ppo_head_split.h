@@ -89,14 +89,14 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
                                                           const float* __restrict__ ba, const uint4* __restrict__ h2z,
                                                           const int32_t* __restrict__ act_rows, float2* __restrict__ part_ms, float2* __restrict__ part_tz,
                                                           float* __restrict__ oslab, float* __restrict__ za_out, float* __restrict__ ea_out, HeadRowArgs ra) {
-    __shared__ __attribute__((aligned(16))) unsigned char sW[2][kWBufB];
-    __shared__ __attribute__((aligned(16))) float sB[2][kTileN];
+    __shared__ __attribute__((aligned(16))) unsigned char sW[3][kWBufB];      // the planes of three consecutive item tiles
+    __shared__ __attribute__((aligned(16))) float sB[3][kTileN];
     const int tid = threadIdx.x;
     CIRS_XSTAMP(40);
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * 4 + wv) * kTileM;
-    const bool wave_ok = row0 < n_pad;          // idle row tiles (padding of the last row block) still stage and meet the barriers
+    const bool wave_ok = row0 < n_pad;          // (idle row tiles -- padding of the last row block -- compute on row tile 0 and store nothing)
     const int chunk = blockIdx.x;
     // gridDim.x is padded to a multiple of 8: workgroups are dealt round-robin to the 8 XCDs, so the row blocks of one chunk share an L2
     if (chunk * tiles_per_chunk * kTileN >= I) return;
@@ -146,107 +146,140 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
         *reinterpret_cast<uint4*>(base_ + 2 * kCPlaneB + dst_c) = gc2;                                     \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
+#define CIRS_READ_ZA(BUF)                                                                                  \
+    do {                                                                                                   \
+        const unsigned char* tw_ = sW[BUF];                                                                \
+        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                 \
+            const unsigned char* ap = tw_ + lo * kRowB + (16 * s4 + 8 * hi) * 2;                           \
+            za[s4].h = *reinterpret_cast<const bf16x8*>(ap);                                               \
+            za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);                                    \
+            za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);                                \
+        }                                                                                                  \
+    } while (0)
     if (n_tiles > 0) { CIRS_ISSUE(first_tile); CIRS_COMMIT(0); }
+    if (n_tiles > 1) { CIRS_ISSUE(first_tile + kTileN); CIRS_COMMIT(1); }
     __syncthreads();
     CIRS_XSTAMP(41);
+    // The loop is software-pipelined inside the wave like head_dwa_kernel's: iteration k holds  [O'_k-1 beside the exponentials of tile k]  and
+    // [the logits of tile k + 1 beside the sums and splits of tile k]  -- a dependent chain L -> P -> O' per tile left the matrix pipe idle 60 %
+    // of the time (3.9 k cycles per tile for 1.5 k cycles of MFMAs).
+    Planes za[4];
+    f32x16 acc, acc1;      // logits of the CURRENT tile: bias + the h*h terms | the cross terms
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = n_tiles > 0 ? sB[0][acc_row(r, hi)] : 0.f; acc1[r] = 0.f; }
+    CIRS_READ_ZA(0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) mfma_bf16x6_split(za[s4], hz[s4], acc, acc1);
+    Planes cbP[2][2], plP[2];      // operands of the O' product of the PREVIOUS tile (zeros before the first)
+    {
+        const pk4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { cbP[c][t].h = __builtin_bit_cast(bf16x8, z4); cbP[c][t].m = cbP[c][t].h; cbP[c][t].l = cbP[c][t].h; }
+        plP[0].h = plP[0].m = plP[0].l = plP[1].h = plP[1].m = plP[1].l = __builtin_bit_cast(bf16x8, z4);
+    }
+    int buf = 0;
     for (int it = 0; it < n_tiles; ++it) {
-        const int buf = it & 1;
+        const int bn = buf == 2 ? 0 : buf + 1, b2 = bn == 2 ? 0 : bn + 1;
+        const bool more = it + 1 < n_tiles;
         const int tile0 = first_tile + it * kTileN;
         CIRS_XTSTAMP(it, 44);
-        if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);
-        if (wave_ok) {
-            const unsigned char* tw = sW[buf];
-            Planes za[4], cb[2][2];
+        if (it + 2 < n_tiles) CIRS_ISSUE(tile0 + 2 * kTileN);
+        // ---- block 1: O'_it-1 (operands in registers since the previous iteration) beside z, t, max, exp of tile it ----
+        CIRS_READ_ZA(more ? bn : buf);        // (the next tile's A planes; after the last tile a harmless re-read)
+        f32x16 an, an1;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const unsigned char* ap = tw + lo * kRowB + (16 * s4 + 8 * hi) * 2;
-                za[s4].h = *reinterpret_cast<const bf16x8*>(ap);
-                za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);
-                za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);
+        for (int r = 0; r < 16; ++r) { an[r] = sB[more ? bn : buf][acc_row(r, hi)]; an1[r] = 0.f; }
+        mfma_bf16x6_pair(plP[0], cbP[0][0], cbP[1][0], dh0, dh1);
+        mfma_bf16x6_pair(plP[1], cbP[0][1], cbP[1][1], dh0, dh1);
+        f32x16 zs, tk;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            zs[r] = acc[r] + acc1[r]; zs[r + 1] = acc[r + 1] + acc1[r + 1];
+            tk[r] = __builtin_fmaf(zs[r], kLog2e, nm2); tk[r + 1] = __builtin_fmaf(zs[r + 1], kLog2e, nm2);
+            tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, tk[r]), tk[r + 1]);
+        }
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);
+        }
+        // Reference maximum of the (row, chunk): the row's maximum over the chunk's FIRST tile (both half-waves agree: they feed one
+        // MFMA row).  Later tiles re-base only when a logit exceeds the reference by 2^64 (never in practice; any lane -> the wave).
+        if (it == 0 || __any(tmax > 64.0f)) {
+            const float mrow = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, CIRS_WAVE));
+            const float sh = it == 0 ? mrow : __builtin_fmaxf(mrow, 0.f);      // shift of the reference in log2 units (it only grows)
+            const float fac = it == 0 ? 0.f : __builtin_amdgcn_exp2f(-sh);      // (nothing accumulated yet at it == 0)
+            s_acc *= fac; t_acc *= fac; ea_val *= fac;
+            if (it != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {      // the O' accumulators hold 16 different ROWS of one column: that row's factor
+                    const float fr = __shfl(fac, acc_row(r, hi), CIRS_WAVE);
+                    dh0[r] *= fr; dh1[r] *= fr;
+                }
             }
-            f32x16 acc, acc1;
+            nm2 -= sh; zmx -= sh; tmax -= sh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = sB[buf][acc_row(r, hi)]; acc1[r] = 0.f; }
-            CIRS_XTSTAMP(it, 45);
+            for (int r = 0; r < 16; ++r) tk[r] -= sh;
+        }
+        zmx = __builtin_fmaxf(zmx, tmax);
+        f32x16 p;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) mfma_bf16x6_split(za[s4], hz[s4], acc, acc1);      // acc: bias + the h*h terms, acc1: the cross terms
-
-            CIRS_XTSTAMP(it, 46);
-            // the B planes of the O' product are requested now (the A planes of the logits are dead); the exponentials cover their latency
+        for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(tk[r]);
+        {   // the row's taken action: its logit and its P leave through za / ea, and it is excluded from every sum of this kernel
+            const int arel = act_r - tile0;
+            const bool mine = act_r >= 0 && arel >= 0 && arel < kTileN && ((arel >> 2) & 1) == hi;
+            if (__any(mine)) {       // (wave-uniform: ~9 % of the tiles hold an action of the wave's rows)
+                const int rsel = (arel & 3) + 4 * (arel >> 3);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool hit = mine && rsel == r;
+                    za_val = hit ? zs[r] : za_val;
+                    ea_val = hit ? p[r] : ea_val;
+                    p[r] = hit ? 0.f : p[r];
+                }
+                za_have = za_have || mine;
+            }
+        }
+        // ---- block 2: the logits of tile it + 1 beside the sums and the splits of tile it; this tile's C planes for the next iteration ----
+        CIRS_XTSTAMP(it, 45);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) mfma_bf16x6_split(za[s4], hz[s4], an, an1);
+        float ss = 0.f, tt = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ss += p[r]; tt = __builtin_fmaf(p[r], zs[r], tt); }
+        s_acc += ss; t_acc += tt;
+        plP[0] = split8(p, 0); plP[1] = split8(p, 8);   // element j: P[row lo][item acc_row(8 t + j, hi)]
+        {
+            const unsigned char* tw = sW[buf];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const unsigned char* bp = tw + 3 * kRPlaneB + (32 * c + lo) * kColB + (16 * t + 8 * hi) * 2;
-                    cb[c][t].h = *reinterpret_cast<const bf16x8*>(bp);
-                    cb[c][t].m = *reinterpret_cast<const bf16x8*>(bp + kCPlaneB);
-                    cb[c][t].l = *reinterpret_cast<const bf16x8*>(bp + 2 * kCPlaneB);
+                    cbP[c][t].h = *reinterpret_cast<const bf16x8*>(bp);
+                    cbP[c][t].m = *reinterpret_cast<const bf16x8*>(bp + kCPlaneB);
+                    cbP[c][t].l = *reinterpret_cast<const bf16x8*>(bp + 2 * kCPlaneB);
                 }
-            f32x16 zs, tk;
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                zs[r] = acc[r] + acc1[r]; zs[r + 1] = acc[r + 1] + acc1[r + 1];
-                tk[r] = __builtin_fmaf(zs[r], kLog2e, nm2); tk[r + 1] = __builtin_fmaf(zs[r + 1], kLog2e, nm2);
-                tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, tk[r]), tk[r + 1]);
-            }
-            // Reference maximum of the (row, chunk): the row's maximum over the chunk's FIRST tile (both half-waves agree: they feed one
-            // MFMA row).  Later tiles re-base only when a logit exceeds the reference by 2^64 (never in practice; any lane -> the wave).
-            if (it == 0 || __any(tmax > 64.0f)) {
-                const float mrow = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, CIRS_WAVE));
-                const float sh = it == 0 ? mrow : __builtin_fmaxf(mrow, 0.f);      // shift of the reference in log2 units (it only grows)
-                const float fac = it == 0 ? 0.f : __builtin_amdgcn_exp2f(-sh);      // (nothing accumulated yet at it == 0)
-                s_acc *= fac; t_acc *= fac; ea_val *= fac;
-                if (it != 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {      // the O' accumulators hold 16 different ROWS of one column: that row's factor
-                        const float fr = __shfl(fac, acc_row(r, hi), CIRS_WAVE);
-                        dh0[r] *= fr; dh1[r] *= fr;
-                    }
-                }
-                nm2 -= sh; zmx -= sh; tmax -= sh;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tk[r] -= sh;
-            }
-            zmx = __builtin_fmaxf(zmx, tmax);
-            CIRS_XTSTAMP(it, 47);
-            f32x16 p;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(tk[r]);
-            {   // the row's taken action: its logit and its P leave through za / ea, and it is excluded from every sum of this kernel
-                const int arel = act_r - tile0;
-                const bool mine = act_r >= 0 && arel >= 0 && arel < kTileN && ((arel >> 2) & 1) == hi;
-                if (__any(mine)) {       // (wave-uniform: ~9 % of the tiles hold an action of the wave's rows)
-                    const int rsel = (arel & 3) + 4 * (arel >> 3);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool hit = mine && rsel == r;
-                        za_val = hit ? zs[r] : za_val;
-                        ea_val = hit ? p[r] : ea_val;
-                        p[r] = hit ? 0.f : p[r];
-                    }
-                    za_have = za_have || mine;
-                }
-            }
-            float ss = 0.f, tt = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { ss += p[r]; tt = __builtin_fmaf(p[r], zs[r], tt); }
-            s_acc += ss; t_acc += tt;
-            CIRS_XTSTAMP(it, 48);
-            if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);     // the other buffer was last read one barrier ago
-            CIRS_XTSTAMP(it, 49);
-            {
-                const Planes a0 = split8(p, 0), a1 = split8(p, 8);   // element j: P[row lo][item acc_row(8 t + j, hi)]
-                mfma_bf16x6_pair(a0, cb[0][0], cb[1][0], dh0, dh1);
-                mfma_bf16x6_pair(a1, cb[0][1], cb[1][1], dh0, dh1);
-            }
-            CIRS_XTSTAMP(it, 50);
-        } else {
-            if (it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);
         }
+        if (it + 2 < n_tiles) CIRS_COMMIT(b2);     // (that buffer held tile it - 1: last read one barrier ago)
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+        }
+        acc = an; acc1 = an1;
+        CIRS_XTSTAMP(it, 46);
         lds_barrier();
-        CIRS_XTSTAMP(it, 51);
+        CIRS_XTSTAMP(it, 47);
+        buf = bn;
     }
+    // O' of the last tile
+    mfma_bf16x6_pair(plP[0], cbP[0][0], cbP[1][0], dh0, dh1);
+    mfma_bf16x6_pair(plP[1], cbP[0][1], cbP[1][1], dh0, dh1);
+#undef CIRS_READ_ZA
     CIRS_XSTAMP(42);
 #undef CIRS_ISSUE
 #undef CIRS_COMMIT
@@ -507,7 +540,18 @@ __global__ __launch_bounds__(kDwaThreads, 1) void head_dwa_kernel(int I, int mb,
             float* __restrict__ op_ = a.oslab + (size_t)jr * kH + c4;
             const size_t cstride = (size_t)n_pad * kH;
             f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < nsc; ++c) acc4 += *reinterpret_cast<const f32x4*>(op_ + (size_t)c * cstride) * __expf(pm_[(size_t)c * n_pad * 2] - M);
+            for (int cb = 0; cb < nsc; cb += 16) {      // 16 slabs in flight per batch (a load-use loop is one memory round trip per chunk)
+                f32x4 o16[16];
+                float m16[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int c = cb + q < nsc ? cb + q : nsc - 1;
+                    m16[q] = pm_[(size_t)c * n_pad * 2];
+                    o16[q] = *reinterpret_cast<const f32x4*>(op_ + (size_t)c * cstride);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc4 += o16[q] * (cb + q < nsc ? __expf(m16[q] - M) : 0.f);
+            }
             fold_store(op_, acc4, sAct[rl], a.wa, c4, -sNc[rl], v.c_ent[jr], v.h_ent[jr]);
         }
     }

@@ -12,6 +12,14 @@ from test_oracle_learn import POL, load_learn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["fused", "split"], autouse=True)
+def head_path(request, monkeypatch):
+    """Every test of this file runs on both actor-head paths of the minibatch step (csrc/ppo.hip: CIRS_PPO_HEAD): the fused backward kernel of
+    round 3 and the slab-free pair head_fwd_kernel / head_dwa_kernel (csrc/ppo_head_split.h)."""
+    monkeypatch.setenv("CIRS_PPO_HEAD", request.param)
+    return request.param
+
+
 def upload_traj(traj, acts, rews, dones, lens, obs_bts, value_bt, logp_bt):
     """Fill a device Trajectory (time-major) from env-major host arrays."""
     B, T = acts.shape

@@ -40,9 +40,8 @@ def show(title, names, base):
 
 show("head_fwd_kernel, workgroup (0,0) thread 0 (raw s_memtime ticks):",
      {40: "entry", 41: "H2 planes requested, first Wa tile staged, barrier", 42: "all tiles", 43: "O' slab + partial stores (write-through)"}, 40)
-show("head_fwd_kernel, third tile:",
-     {44: "tile start", 45: "next tile requested, za reads, bias init", 46: "logits MFMAs (24)", 47: "cb reads, z sums, t, max, reference test", 48: "16 exp2, action test, sums",
-      49: "plane commit", 50: "split + O' MFMAs (24)", 51: "barrier"}, 44)
+show("head_fwd_kernel, third iteration:",
+     {44: "iteration start", 45: "next tile requested; [O'_k-1 | z, t, max], reference test, exp, action test", 46: "[L_k+1 | sums, splits], C planes read, plane commit", 47: "barrier"}, 44)
 show("head_dwa_kernel, workgroup (0,0) thread 0:",
      {30: "entry", 31: "Wa tile planes + bias + first H2 tile requested, mask cleared, barrier", 32: "row scalars -> LDS, action masks", 33: "wait for the first H2 tile, barrier",
       34: "d h2 fold of the slice, Wa planes of the item tile", 35: "all row tiles", 36: "dWa tile / dba / entropy stores"}, 30)
