@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
     __syncthreads();
     if (tid == 0) sLast = __hip_atomic_fetch_add(&ra.counters[blockIdx.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ra.n_chunks - 1;
     __syncthreads();
-    if (wave_ok) {
+    auto store_slab = [&]() {
+        if (!wave_ok) return;
         float* hslab = oslab + (size_t)chunk * n_pad * kH;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -309,9 +310,9 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
             hslab[(size_t)row * kH + lo] = dh0[r];
             hslab[(size_t)row * kH + 32 + lo] = dh1[r];
         }
-    }
+    };
     CIRS_XSTAMP(43);
-    if (!sLast) return;
+    if (!sLast) { store_slab(); return; }
     {
         const MbView& v = ra.v;
         const int nsc = ra.n_chunks;
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(256, 1) void head_fwd_kernel(int I, int mb, int n_p
             v.ent_row[jr2] = real ? rt.h_ent + ent_hi : 0.f;       // lse - E_p[z] + the high-side clamp term; the low side travels per workgroup (entw)
         }
     }
+    store_slab();      // (the last workgroup's own O' slab goes out behind the row stage: its 128 KB of stores would sit in front of the partial loads)
 }
 
 // ---- backward: row merge + d h2 fold + dWa / dba -------------------------------------------------------------------------------
