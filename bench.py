@@ -34,7 +34,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 MINIBATCH_KERNELS = ("trunk_adv_kernel", "head_stats_kernel", "head_bwd_fused_kernel", "dh2_sum_kernel",
-                     "trunk_bwd_kernel", "sumsq_partial_kernel", "adam2_kernel")     # the 7 launches of a minibatch step
+                     "trunk_bwd_kernel", "sumsq_partial_kernel", "adam2_kernel")     # the 7 launches of a minibatch step (fused head path)
+MINIBATCH_KERNELS_SPLIT = ("trunk_adv_kernel", "head_fwd_kernel", "head_dwa_kernel", "trunk_bwd_kernel", "sumsq_partial_kernel",
+                           "adam2_kernel")                                           # the 6 launches with CIRS_PPO_HEAD=split
 
 
 def kernel_source_hash():
@@ -63,6 +65,14 @@ def pmc_traffic(workload):
         out[k] = int(v["bytes_per_launch"])
         out.setdefault(k.split("<")[0], int(v["bytes_per_launch"]))
     return out, f"profiles/pmc_traffic.json ({z.get('taken', '?')}; 2 x FETCH_SIZE + WRITE_SIZE, separate passes)"
+
+
+def pmc_json(workload):
+    """The committed PMC summary (profiles/pmc_traffic.json) if it was taken on THIS kernel source and workload, else None."""
+    if not os.path.exists(PMC_TRAFFIC_JSON):
+        return None
+    z = json.load(open(PMC_TRAFFIC_JSON))
+    return z if z.get("source_hash") == kernel_source_hash() and z.get("workload") == workload else None
 
 
 def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_backward=None, coll=None):
@@ -141,7 +151,8 @@ def hip_event_kernel_time(eng, wl, reps=100):
     torch.cuda.synchronize()
     t_step = start.elapsed_time(stop) / reps * 1e-3
     per_kernel = {}
-    for kid, name in ((1, "head_bwd_fused_kernel"), (2, "head_stats_kernel")):
+    split = os.environ.get("CIRS_PPO_HEAD", "fused").startswith("s")
+    for kid, name in ((1, "head_dwa_kernel" if split else "head_bwd_fused_kernel"), (2, "head_fwd_kernel" if split else "head_stats_kernel")):
         run(10)    # the event pairs are taken in steady state, like the kernel's average in a rocprofv3 trace of the timed loop
         abi.check(lib.cirs_prof_start(kid, reps), "cirs_prof_start")
         run(reps)
@@ -250,6 +261,8 @@ def gather_fm_probe(device, reps=10):
     from cirs_hip.deepfm import DeviceDeepFM
     out = []
     traffic, src = pmc_traffic("c3")
+    pz = pmc_json("c3") or {}
+    cases = pz.get("gather_fm_cases") or {}
     # mid_E64: 2 x 2^17 rows x 260 B = 68 MB -- past the 8 x 4 MiB L2s, inside the 256 MiB Infinity Cache: where the logical rate of the
     # C3 shape turns into the physical rate of the C5 shape
     for name, U, I, E, n in (("c3_E32", 7176, 10728, 32, 1 << 24), ("c3_E16", 7176, 10728, 16, 1 << 24), ("mid_E64", 1 << 17, 1 << 17, 64, 1 << 23),
@@ -281,7 +294,12 @@ def gather_fm_probe(device, reps=10):
         rec = {"case": name, "users": U, "items": I, "emb_dim": E, "pairs": n, "seconds_per_launch": t, "pairs_per_s": n / t,
                "algorithmic_bytes_per_pair": 8 * E + 40,
                "roofline": {"bound": "hbm", "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
-                            "traffic": (traffic or {}).get(f"gather_fm_kernel<{E}, true>"),
+                            # per CASE (dispatch group of the PMC workload), FETCH_SIZE doubled per the guide's streaming correction
+                            "traffic": (cases.get(name) or {}).get("bytes_doubled_fetch", (traffic or {}).get(f"gather_fm_kernel<{E}, true>")),
+                            # the same counters with the factors of the known-bytes calibration launches (random rows of this width + streams)
+                            "traffic_calibrated": (cases.get(name) or {}).get("bytes_calibrated"),
+                            "physical_GBps": ((cases.get(name) or {}).get("bytes_calibrated") or 0) / t / 1e9 or None,
+                            "calibration": (cases.get(name) or {}).get("calibration"),
                             "compulsory_stream_bytes_per_pair": 32,
                             "note": "tables L2-resident: achieved is a logical gather rate, physical HBM traffic ~ 32 B/pair" if U < 100000 else
                                     ("tables past L2, inside the Infinity Cache (MALL): rows come from MALL, HBM sees the X / out streams" if U < (1 << 19) else
@@ -543,7 +561,24 @@ def main():
     l2, n2 = eng.update(G, 2); torch.cuda.synchronize(); tc = time.perf_counter()
 
     if rank == 0:
+        head_mode = "split" if os.environ.get("CIRS_PPO_HEAD", "fused").startswith("s") else "fused"      # the path the timed region ran
         t_mb, mb, t_k = hip_event_kernel_time(eng, wl)
+        # both actor-head paths of the minibatch step on this box, same state (csrc/ppo.hip CIRS_PPO_HEAD; the default is the faster one)
+        head_paths = {}
+        for hm in ("fused", "split"):
+            if hm == head_mode:
+                tm_, tk_ = t_mb, t_k
+            else:
+                prev = os.environ.get("CIRS_PPO_HEAD")
+                os.environ["CIRS_PPO_HEAD"] = hm
+                tm_, _, tk_ = hip_event_kernel_time(eng, wl, reps=50)
+                if prev is None:
+                    os.environ.pop("CIRS_PPO_HEAD")
+                else:
+                    os.environ["CIRS_PPO_HEAD"] = prev
+            head_paths[hm] = {"minibatch_step_seconds": tm_, "launches": 7 if hm == "fused" else 6, "kernel_seconds": tk_}
+        if head_mode == "split":      # same keys downstream: the backward-side kernel / the forward-side kernel of the path
+            t_k = {"head_bwd_fused_kernel": t_k["head_dwa_kernel"], "head_stats_kernel": t_k["head_fwd_kernel"]}
         I = wl["I"]
         S, H = 20, 64
         # Dominant kernel of the timed step (profiles/*_kernel_stats.csv): head_bwd_fused_kernel, the fused actor-head backward
@@ -586,7 +621,11 @@ def main():
                          "kernel_note": "since round 3 the kernel's prologue also merges the head-statistics partials of its rows and forms their loss terms / backward coefficients (~2.5 us that replace a 6.5 us launch): its duration includes that work, the algorithmic flop count does not",
                          "peak_note": "fp32 MFMA dense peak: the kernel's results are fp32-accurate (DESIGN.md section 4); its 6x expanded bf16 flops are exec_bf16_flop_per_launch",
                          "exec_bf16_flop_per_launch": 6.0 * exec_bwd},
-            "minibatch_step": {"seconds": t_mb, "launches": 7, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
+            "head_paths": {"default": head_mode, **head_paths,
+                           "note": "fused = head_stats_kernel + head_bwd_fused_kernel + dh2_sum_kernel (8 dWa row-block slabs + 31 dH2 chunk slabs per step); "
+                                   "split = head_fwd_kernel (statistics + O' = P Wa, row stage in its last workgroup) + head_dwa_kernel (dWa with the item tile "
+                                   "stationary, 3 slabs): see DESIGN.md section 8 for the traffic / time trade measured this round"},
+            "minibatch_step": {"seconds": t_mb, "launches": 7 if head_mode == "fused" else 6, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
                                "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "traffic": None,
                                "head_stats_kernel_seconds": t_k["head_stats_kernel"],
