@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import sys
 
+os.environ["CIRS_PPO_HEAD"] = "split"      # the kernels this probe stamps
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cirs-codes_amd"))
 import numpy as np
