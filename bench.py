@@ -298,7 +298,10 @@ def gather_fm_probe(device, reps=10):
                             "traffic": (cases.get(name) or {}).get("bytes_doubled_fetch", (traffic or {}).get(f"gather_fm_kernel<{E}, true>")),
                             # the same counters with the factors of the known-bytes calibration launches (random rows of this width + streams)
                             "traffic_calibrated": (cases.get(name) or {}).get("bytes_calibrated"),
-                            "physical_GBps": ((cases.get(name) or {}).get("bytes_calibrated") or 0) / t / 1e9 or None,
+                            # requests at the L2's memory-side port per second: Infinity-Cache hits are counted too (MI355X_MICROARCH.md, HBM section),
+                            # so this is an UPPER bound of the HBM rate and may exceed what HBM alone delivers (6.3 TB/s streaming) for
+                            # tables of which a part stays in the 256 MiB Infinity Cache
+                            "pmc_fabric_GBps": ((cases.get(name) or {}).get("bytes_calibrated") or 0) / t / 1e9 or None,
                             "calibration": (cases.get(name) or {}).get("calibration"),
                             "compulsory_stream_bytes_per_pair": 32,
                             "note": "tables L2-resident: achieved is a logical gather rate, physical HBM traffic ~ 32 B/pair" if U < 100000 else
