@@ -295,6 +295,7 @@ class DeviceLearner:
             self._tp_stats = torch.zeros(4 * pad(max_mb), dtype=torch.float32, device=self.device)
             self._tp_all = torch.zeros(world * 4 * pad(max_mb), dtype=torch.float32, device=self.device)
             self._tp_red = torch.zeros(nred_max, dtype=torch.float32, device=self.device)
+            self._tp_fm = torch.zeros(world * 4 * pad(max_mb), dtype=torch.float32, device=self.device)
 
         def call(phase, idx_ptr, mb, stats4, stats_all, red, want_dobs, loss_ptr):
             abi.check(self._lib.cirs_ppo_minibatch_tp(
@@ -316,7 +317,8 @@ class DeviceLearner:
                 red = self._tp_red[:int(self._lib.cirs_ppo_tp_exchange_floats(mb, world))]
                 call(1, idx_ptr, mb, stats4.data_ptr(), None, red.data_ptr(), False, None)
                 coll.all_gather(gathered, stats4)
-                stats_all = gathered.view(world, 4, npad).permute(1, 0, 2).contiguous()     # field-major: [4][world][n_pad]
+                stats_all = self._tp_fm[:world * 4 * npad].view(4, world, npad)             # field-major: [4][world][n_pad]
+                stats_all.copy_(gathered.view(world, 4, npad).permute(1, 0, 2))            # (preallocated: no allocation per minibatch)
                 call(2, idx_ptr, mb, None, stats_all.data_ptr(), red.data_ptr(), False, None)
                 coll.all_reduce(red)
                 call(3, idx_ptr, mb, None, None, red.data_ptr(), last and want_tracker_grad, losses.data_ptr() + 16 * k)

@@ -191,7 +191,8 @@ def test_sharded_training_step_equals_single_device(W, U, I, Bl, T):
             ln = sr.collect(users[r * Bl:(r + 1) * Bl], seed=seed << 8, rng_base=0)
             losses, n = trainer.update(ln, bs, 2, perms=perms)
             torch.cuda.synchronize()
-            out[r] = dict(lens=ln.cpu().numpy(), losses=losses, n=n, pviews=pviews, tviews=tviews, user=sr.trk_user.local, item=sr.trk_item.local)
+            out[r] = dict(lens=ln.cpu().numpy(), losses=losses, n=n, pviews=pviews, tviews=tviews, user=sr.trk_user.local, item=sr.trk_item.local,
+                          gviews=trkl.grad_views, guser=sr.trk_user.grad, gitem=sr.trk_item.grad)
         except Exception as e:  # noqa: BLE001
             err[r] = e
             comms[r].s.barrier.abort()
@@ -212,6 +213,24 @@ def test_sharded_training_step_equals_single_device(W, U, I, Bl, T):
     for k in ("w1", "b1", "w2", "b2", "wc", "bc", "ba"):
         got = (torch.cat([out[r]["pviews"][names[k]] for r in range(W)]) if k == "ba" else out[0]["pviews"][names[k]]).cpu().numpy()
         np.testing.assert_allclose(got, eng.policy_views[names[k]].cpu().numpy(), rtol=3e-4, atol=3e-6, err_msg=k)
+    # the GRADIENTS before Adam: the all-reduced dense tracker gradient and every owner's embedding-gradient shard against
+    # the single-device BPTT's, relative to the tensor's largest entry (summation order over ranks / rows differs, nothing else)
+    def grad_close(got, want, what, tol=2e-4):
+        scale = float(np.abs(want).max())
+        assert scale > 0 or float(np.abs(got).max()) == 0, what
+        assert float(np.abs(got - want).max()) <= tol * scale + 1e-12, (what, float(np.abs(got - want).max()), scale)
+    for k, v in out[0]["gviews"].items():
+        if k.startswith("embedding_dict"):
+            continue
+        got, want = v.cpu().numpy(), eng.tracker.grad_views[k].cpu().numpy()
+        if k.endswith("in_proj_bias"):
+            got, want = np.r_[got[:32], got[64:]], np.r_[want[:32], want[64:]]
+        grad_close(got, want, "grad " + k)
+    for key, name in (("guser", "embedding_dict.feat_user.weight"), ("gitem", "embedding_dict.feat_item.weight")):
+        full = eng.tracker.grad_views[name]
+        for r in range(W):
+            grad_close(out[r][key].cpu().numpy(), full[r::W].cpu().numpy(), f"grad {name} shard {r}")
+    # after Adam: a smoke test only (a first step moves a parameter by lr * sign(g), so near-zero gradients may differ by a whole step)
     close = []
     for k, v in out[0]["tviews"].items():
         if k.startswith("embedding_dict"):
