@@ -35,3 +35,33 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ---- how much of each tolerance the golden comparisons use --------------------------------------------------------------------------
+# close(...) is numpy's assert_allclose plus a record of the observed error: largest |got - want|, largest relative error where
+# |want| > atol / rtol, and the largest fraction of the bar (atol + rtol |want|) any element used.  The session writes the records to
+# gpurun_out/parity_margins.json (profiles/ keeps the copy the DESIGN table quotes).
+_MARGINS = []
+
+
+def close(got, want, rtol, atol, what):
+    import numpy as np
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=what)
+    if got.size:
+        err = np.abs(got - want)
+        bar = atol + rtol * np.abs(want)
+        big = np.abs(want) > (atol / rtol if rtol > 0 else np.inf)
+        _MARGINS.append({"what": what, "n": int(got.size), "rtol": rtol, "atol": atol, "max_abs_err": float(err.max()),
+                         "max_rel_err": float((err[big] / np.abs(want[big])).max()) if big.any() else None,
+                         "bar_used": float((err / bar).max())})
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_margins.json"), "w") as f:
+        json.dump(_MARGINS, f, indent=1)

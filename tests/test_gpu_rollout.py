@@ -8,6 +8,7 @@ import torch
 
 import envcase
 import nn_oracle
+from conftest import close
 import policycase
 import rolloutcase
 
@@ -46,13 +47,13 @@ def check_rollout(U, I, B, T, seed, *, sync_every=None, **kw):
         oa, ol, ov, _ = policycase.oracle_sample(arrs, obs[t], seed=seed, rng_step=100 + t, skip=(~live).astype(np.uint8))
         mism += int((oa[live] != act[t][live]).sum())
         assert np.array_equal(ov[live], value[t][live])
-        np.testing.assert_allclose(logp[t][live], ol[live], rtol=1e-4, atol=1e-4)
+        close(logp[t][live], ol[live], 1e-4, 1e-4, "rollout: log-prob of the sampled action vs oracle")
     assert mism == 0, f"{mism} action ids differ from the oracle"
     # --- tracker: restatement over the recorded episodes ---
     states = nn_oracle.tracker_states(tp, users, np.maximum(act.T, 0), rew.T).numpy()  # [B, T+1, S]
     for b in range(B):
         L = lengths[b]
-        np.testing.assert_allclose(obs[:L + 1, b], states[b, :L + 1], atol=1e-4, rtol=1e-4)
+        close(obs[:L + 1, b], states[b, :L + 1], 1e-4, 1e-4, "rollout: tracker states vs restatement")
     # --- the fused step reads its weights from the packed image ([k/4][O][4], coalesced), the stand-alone tracker step from the
     #     row-major matrices: same fma order, so a teacher-forced replay through cirs_tracker_init / cirs_tracker_step must
     #     reproduce the states BIT FOR BIT

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import nn_oracle
+from conftest import close
 
 pytestmark = pytest.mark.gpu
 
@@ -42,12 +43,12 @@ def test_tracker_matches_reference_golden(golden_dir):
     m = np.isfinite(want)
     assert np.array_equal(np.isfinite(got), m)
     # s_t <= 1e-5 abs with dropout disabled, every step of the episode
-    print(f"[tracker vs reference golden] max |err| = {np.abs(got[m] - want[m]).max():.3e} over {int(m.sum())} state entries (bar 2e-5)")
-    np.testing.assert_allclose(got[m], want[m], atol=2e-5, rtol=1e-5)
+    print(f"[tracker vs reference golden] max |err| = {np.abs(got[m] - want[m]).max():.3e} over {int(m.sum())} state entries (bar 1e-5)")
+    close(got[m], want[m], 1e-5, 1e-5, "tracker states vs reference golden")
     # x_hist (the reference's self.data) matches too
     x = nn_oracle.tracker_inputs(p, z["users"], z["acts"], z["rews"]).numpy()
     live = np.where(z["last_turn"] == T)[0]
-    np.testing.assert_allclose(trk.x_hist.cpu().numpy()[live], x[live], atol=1e-6, rtol=1e-5)
+    close(trk.x_hist.cpu().numpy()[live], x[live], 1e-5, 1e-6, "tracker input slots vs restatement")
 
 
 @pytest.mark.parametrize("U,I,B,T,nhead", [(1411, 3327, 64, 30, 4), (7176, 10728, 1024, 30, 4), (100, 200, 33, 100, 8), (50, 60, 7, 5, 1)])
@@ -78,5 +79,5 @@ def test_tracker_vs_restatement_at_baseline_sizes(U, I, B, T, nhead):
     trk = dev_tracker(p, U, I, B, T, nhead=nhead)
     got = run_device(trk, users, acts, rews, np.full(B, T))
     print(f"[tracker vs restatement U={U} I={I} B={B} T={T} nhead={nhead}] max |err| = {np.abs(got - want).max():.3e}, max |state| = {np.abs(want).max():.2f}")
-    np.testing.assert_allclose(got, want, atol=5e-5, rtol=1e-4)
+    close(got, want, 1e-4, 5e-5, f"tracker states vs restatement (nhead={nhead}, T={T})")
     assert int(trk.len.min()) == T + 1

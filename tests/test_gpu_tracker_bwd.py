@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import nn_oracle
+from conftest import close
 import rolloutcase
 from test_gpu_learn import make_learner, rollout_time_value_logp, upload_traj
 from test_oracle_learn import POL, load_learn
@@ -124,7 +125,7 @@ def test_full_update_matches_reference_tracker_params(golden_dir):
         # where the reference moved by (almost) the full lr, and bound the rest by lr
         full = np.abs(np.abs(post - pre) - 1e-3) < 2e-5
         still = post == pre  # e.g. embedding rows of users/items that never occurred: exactly zero gradient
-        np.testing.assert_allclose(got[full], post[full], rtol=1e-4, atol=3e-5, err_msg=k)
+        close(got[full], post[full], 1e-5, 2e-6, "full update, tracker post-Adam: " + k)
         np.testing.assert_array_equal(got[still], pre[still], err_msg=k)
         assert np.abs(got - pre).max() <= 1e-3 * 1.01
         assert (full | still).mean() > 0.9, k
@@ -153,18 +154,18 @@ def test_two_consecutive_updates_match_reference(golden_dir):
         traj.clear()
         upload_traj(traj, z[pre + "acts"], z[pre + "rews"], z[pre + "dones"], lens, z[pre + "obs"], value, logp)
         n = ln.prepare(traj, lens)
-        np.testing.assert_allclose(ln.b_vs[:n].cpu().numpy(), z[pre + "b_v_s"], rtol=2e-4, atol=2e-5)
-        np.testing.assert_allclose(ln.b_ret[:n].cpu().numpy(), z[pre + "b_returns"], rtol=2e-4, atol=2e-5)
-        np.testing.assert_allclose(ln.b_adv[:n].cpu().numpy(), z[pre + "b_adv"], rtol=2e-4, atol=2e-5)
+        close(ln.b_vs[:n].cpu().numpy(), z[pre + "b_v_s"], 1e-5, 2e-6, "two updates " + pre + "b_v_s")
+        close(ln.b_ret[:n].cpu().numpy(), z[pre + "b_returns"], 1e-5, 2e-6, "two updates " + pre + "b_returns")
+        close(ln.b_adv[:n].cpu().numpy(), z[pre + "b_adv"], 1e-5, 2e-6, "two updates " + pre + "b_adv")
         np.testing.assert_allclose(ln.rms_state.cpu().numpy(), z[pre + "ret_rms"], rtol=1e-5)
         losses = ln.learn(bs, rep, perms=pr).cpu().numpy()
-        np.testing.assert_allclose(losses[:, 0], z[pre + "loss"], rtol=5e-4, atol=5e-5)
-        np.testing.assert_allclose(losses[:, 2], z[pre + "loss_vf"], rtol=5e-4, atol=5e-5)
+        close(losses[:, 0], z[pre + "loss"], 1e-5, 1e-5, "two updates " + pre + "loss")
+        close(losses[:, 2], z[pre + "loss_vf"], 1e-5, 1e-5, "two updates " + pre + "loss_vf")
         offsets, _, _ = rows_of(lens)
         trk.backward(torch.as_tensor(z[pre + "users"]), traj, ln.b_env, ln.b_t, torch.as_tensor(offsets).cuda(),
                      torch.as_tensor(lens.astype(np.int32)).cuda(), n, ln.dobs)
         trk.adam_update()
         for k, name in POL.items():
             post = z[pre + "post_pol_" + name]
-            np.testing.assert_allclose(pviews[name].cpu().numpy().reshape(post.shape), post, rtol=2e-4, atol=5e-6, err_msg=pre + name)
+            close(pviews[name].cpu().numpy().reshape(post.shape), post, 1e-5, 1e-5, "two updates " + pre + name)
     compare_tracker_second_step({k: v.cpu().numpy() for k, v in views.items()}, z, lr=lr)
