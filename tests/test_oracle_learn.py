@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 import nn_oracle
+from conftest import close
 
 POL = dict(w1="actor.preprocess.model.model.0.weight", b1="actor.preprocess.model.model.0.bias",
            w2="actor.preprocess.model.model.2.weight", b2="actor.preprocess.model.model.2.bias",
@@ -28,23 +29,23 @@ def test_ppo_update_matches_reference(golden_dir):
                                eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef, max_grad_norm=mgn, lr=lr,
                                batch_size=int(bs), repeat=int(rep))
     # processed batch
-    np.testing.assert_allclose(out["obs"], nn_oracle.flatten_episodes(torch.as_tensor(z["obs"]), z["lens"]).numpy(), atol=2e-5)
-    np.testing.assert_allclose(out["v_s"], z["b_v_s"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(out["returns"], z["b_returns"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(out["adv"], z["b_adv"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(out["logp_old"], z["b_logp_old"], rtol=1e-4, atol=1e-5)
+    close(out["obs"], nn_oracle.flatten_episodes(torch.as_tensor(z["obs"]), z["lens"]).numpy(), 0.0, 1e-5, 'oracle: tracker states of the stored graph')
+    close(out["v_s"], z["b_v_s"], 1e-5, 2e-6, 'oracle: b_v_s')
+    close(out["returns"], z["b_returns"], 1e-5, 2e-6, 'oracle: b_returns')
+    close(out["adv"], z["b_adv"], 1e-5, 2e-6, 'oracle: b_adv')
+    close(out["logp_old"], z["b_logp_old"], 1e-5, 2e-6, 'oracle: b_logp_old')
     rms = out["ret_rms"]
-    np.testing.assert_allclose([rms.mean, rms.var, rms.count], z["ret_rms"], rtol=1e-5)
+    close([rms.mean, rms.var, rms.count], z["ret_rms"], 1e-5, 0.0, 'oracle: ret_rms')
     # per-minibatch losses (<= 1e-5 rel; fp32 summation order gives a little slack)
-    np.testing.assert_allclose(out["loss"], z["loss"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(out["clip"], z["loss_clip"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(out["vf"], z["loss_vf"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(out["ent"], z["loss_ent"], rtol=2e-4, atol=2e-5)
+    close(out["loss"], z["loss"], 1e-5, 1e-5, 'oracle: loss')
+    close(out["clip"], z["loss_clip"], 1e-5, 1e-5, 'oracle: loss_clip')
+    close(out["vf"], z["loss_vf"], 1e-5, 1e-5, 'oracle: loss_vf')
+    close(out["ent"], z["loss_ent"], 1e-5, 1e-5, 'oracle: loss_ent')
     # post-update parameters: policy (duplicate-param Adam/clip quirk) and tracker (BPTT through the rollout)
     for k, name in POL.items():
         pre, post = z["pol_" + name], z["post_pol_" + name]
         assert np.abs(post - pre).max() > 0
-        np.testing.assert_allclose(pp[k].numpy(), post, rtol=1e-4, atol=2e-6, err_msg=name)
+        close(pp[k].numpy(), post, 1e-5, 1e-5, 'oracle: ' + name)
     moved = 0
     for k, v in tp.items():
         if k == "pos_encoder.pe":
@@ -56,7 +57,7 @@ def test_ppo_update_matches_reference(golden_dir):
             # d loss / d key-bias == 0 analytically (softmax is invariant to a per-query constant); the reference's
             # Adam normalises the fp32 round-off it gets instead into +-lr steps -> noise, not a parity target.
             got, post = np.delete(got, slice(32, 64)), np.delete(post, slice(32, 64))
-        np.testing.assert_allclose(got, post, rtol=1e-4, atol=2e-6, err_msg=k)
+        close(got, post, 1e-5, 1e-5, 'oracle: ' + k)
     assert moved >= 20  # every tracker tensor received gradient through the stored obs
 
 
@@ -71,15 +72,15 @@ def test_ppo_update_with_dual_clip_and_recomputed_advantages_matches_reference(g
     out = nn_oracle.ppo_update(tp, pp, z["users"], z["acts"], z["rews"], z["dones"], z["lens"], perms, gamma=gamma, lam=lam,
                                eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef, max_grad_norm=mgn, lr=lr,
                                batch_size=int(bs), repeat=int(rep), dual_clip=dual_clip, recompute_adv=recompute)
-    np.testing.assert_allclose(out["adv"], z["b_adv"], rtol=1e-4, atol=1e-5)
+    close(out["adv"], z["b_adv"], 1e-5, 2e-6, 'oracle: b_adv')
     rms = out["ret_rms"]
-    np.testing.assert_allclose([rms.mean, rms.var, rms.count], z["ret_rms"], rtol=1e-5)      # count = 2 N: updated by both passes
+    close([rms.mean, rms.var, rms.count], z["ret_rms"], 1e-5, 0.0, 'oracle: ret_rms')      # count = 2 N: updated by both passes
     assert int(z["ret_rms"][2]) == 2 * int(z["lens"].sum())
-    np.testing.assert_allclose(out["loss"], z["loss"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(out["clip"], z["loss_clip"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(out["vf"], z["loss_vf"], rtol=2e-4, atol=2e-5)
+    close(out["loss"], z["loss"], 1e-5, 1e-5, 'oracle: loss')
+    close(out["clip"], z["loss_clip"], 1e-5, 1e-5, 'oracle: loss_clip')
+    close(out["vf"], z["loss_vf"], 1e-5, 1e-5, 'oracle: loss_vf')
     for k, name in POL.items():   # (dual clip zeroes most rows' gradients: a few head entries have |g| ~ 1e-9, where Adam turns round-off into 5e-6)
-        np.testing.assert_allclose(pp[k].numpy(), z["post_pol_" + name], rtol=1e-4, atol=1e-5, err_msg=name)
+        close(pp[k].numpy(), z["post_pol_" + name], 1e-5, 1e-5, 'oracle: ' + name)
     # the options matter on this fixture: the plain configuration gives other losses
     z0, tp0, pp0, perms0 = load_learn(golden_dir, "learn_opts")
     plain = nn_oracle.ppo_update(tp0, pp0, z["users"], z["acts"], z["rews"], z["dones"], z["lens"], perms0, gamma=gamma, lam=lam,
@@ -129,14 +130,14 @@ def test_two_consecutive_updates_match_reference(golden_dir):
     o1 = nn_oracle.ppo_update(tp, pp, z["users"], z["acts"], z["rews"], z["dones"], z["lens"], perms, **kw)
     o2 = nn_oracle.ppo_update(tp, pp, z["r2_users"], z["r2_acts"], z["r2_rews"], z["r2_dones"], z["r2_lens"], load_round2(z),
                               ret_rms=o1["ret_rms"], opt_state=o1["opt_state"], **kw)
-    np.testing.assert_allclose(o2["obs"], nn_oracle.flatten_episodes(torch.as_tensor(z["r2_obs"]), z["r2_lens"]).numpy(), atol=3e-5)
-    np.testing.assert_allclose(o2["v_s"], z["r2_b_v_s"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(o2["returns"], z["r2_b_returns"], rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(o2["adv"], z["r2_b_adv"], rtol=2e-4, atol=2e-5)
+    close(o2["obs"], nn_oracle.flatten_episodes(torch.as_tensor(z["r2_obs"]), z["r2_lens"]).numpy(), 0.0, 1e-5, 'oracle: tracker states of the stored graph (second update)')
+    close(o2["v_s"], z["r2_b_v_s"], 1e-5, 2e-6, 'oracle: r2_b_v_s')
+    close(o2["returns"], z["r2_b_returns"], 1e-5, 2e-6, 'oracle: r2_b_returns')
+    close(o2["adv"], z["r2_b_adv"], 1e-5, 2e-6, 'oracle: r2_b_adv')
     rms = o2["ret_rms"]
-    np.testing.assert_allclose([rms.mean, rms.var, rms.count], z["r2_ret_rms"], rtol=1e-5)
-    np.testing.assert_allclose(o2["loss"], z["r2_loss"], rtol=5e-4, atol=5e-5)
-    np.testing.assert_allclose(o2["vf"], z["r2_loss_vf"], rtol=5e-4, atol=5e-5)
+    close([rms.mean, rms.var, rms.count], z["r2_ret_rms"], 1e-5, 0.0, 'oracle: r2_ret_rms')
+    close(o2["loss"], z["r2_loss"], 1e-5, 1e-5, 'oracle: r2_loss')
+    close(o2["vf"], z["r2_loss_vf"], 1e-5, 1e-5, 'oracle: r2_loss_vf')
     for k, name in POL.items():
-        np.testing.assert_allclose(pp[k].numpy(), z["r2_post_pol_" + name], rtol=2e-4, atol=5e-6, err_msg=name)
+        close(pp[k].numpy(), z["r2_post_pol_" + name], 1e-5, 1e-5, 'oracle: ' + name)
     compare_tracker_second_step({k: v.detach().numpy() for k, v in tp.items()}, z, lr=lr)
