@@ -75,7 +75,7 @@ def pmc_json(workload):
     return z if z.get("source_hash") == kernel_source_hash() and z.get("workload") == workload else None
 
 
-def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_backward=None, coll=None):
+def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_backward=None, coll=None, dropout_redraw=False):
     from cirs_hip.engine import CirsEngine
     from cirs_hip.env import DeviceEnvTables
     from cirs_hip.synthetic import make_tables
@@ -87,7 +87,8 @@ def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_bac
                          build_dist_on_device=True)
     eng = CirsEngine(dt, wl["B"], max_turn=wl["T"], num_leave_compute=wl["N"], leave_threshold=wl["thr"], tau=wl["tau"],
                      gamma_exposure=wl["gamma_exposure"], seed=2023, world_size=world, rank=rank,
-                     dist_group=None, learner_mode=learner, dropout=dropout, tracker_backward=tracker_backward, coll=coll)
+                     dist_group=None, learner_mode=learner, dropout=dropout, tracker_backward=tracker_backward, coll=coll,
+                     dropout_redraw=dropout_redraw)
     return eng, tab
 
 
@@ -455,6 +456,9 @@ def main():
     ap.add_argument("--global-batch", type=int, default=1024, help="PPO minibatch size over ALL ranks (reference batch_size, CIRS-RL-kuaishou.py:89)")
     ap.add_argument("--dropout", type=float, default=0.0, help="tracker dropout probability (0 = eval-mode tracker of the parity fixtures; "
                                                                "0.1 = the mode the reference trains in, SURVEY Q7)")
+    ap.add_argument("--dropout-redraw", action="store_true",
+                    help="with --dropout > 0: the reference's own procedure (fresh masks over the whole prefix at every build_state call, "
+                         "core/state_tracker.py:170-186,243-246; cirs_hip/redraw.py) instead of position-keyed masks.  Single GPU; O(T^2) row-passes by definition")
     ap.add_argument("--scaled-batch-steps", type=int, default=-1,
                     help="N > 1: extra steps timed with the global minibatch scaled to --global-batch x N (constant optimiser steps per update; "
                          "reported under scaled_batch_variant, never as value).  -1 = min(steps, 5), 0 = skip")
@@ -487,7 +491,8 @@ def main():
 
     G = int(args.global_batch)
     eng, tab = build_engine(wl, rank, world, device, learner=args.learner, dropout=args.dropout,
-                            tracker_backward=args.tracker_backward if args.learner == "replicated" else None)
+                            tracker_backward=args.tracker_backward if args.learner == "replicated" else None,
+                            dropout_redraw=bool(args.dropout_redraw and args.dropout > 0))
 
     def barrier():
         if world > 1:
@@ -611,7 +616,7 @@ def main():
                                           "tp": f"every rank runs all {G} rows of a minibatch against its 1/{world} of the catalogue (item-sharded head), "
                                                 "all-gather of 16 B/row + all-reduce of the d h2 partials per minibatch, head shards all-gathered per update"}[args.learner])
                        if world > 1 else "single GPU"},
-            "dropout": args.dropout,
+            "dropout": args.dropout, "dropout_redraw": bool(args.dropout_redraw and args.dropout > 0),
             "ppo_minibatch_steps_per_s": mb_steps / elapsed, "rank_parameters_bit_identical": ranks_identical,
             "rollout_only_env_steps_per_s": n_ro / t_ro, "rollout_only_ms_per_collect": 1e3 * t_ro,
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),

@@ -253,7 +253,7 @@ class CirsEngine:
             return losses, n
         if self.dropout_redraw:
             from .redraw import redraw_tracker_backward
-            redraw_tracker_backward(self.rollout, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs)
+            redraw_tracker_backward(self.rollout, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs, lens_host=lens)
             self.tracker.adam_update()
             return losses, n
         self.tracker.backward(users, traj, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs,

@@ -7,11 +7,12 @@ keyed by position, K/V-cached decode) keeps a position's masks for the rest of t
 every state, different joint distribution over an episode.  This module is the reference's procedure as a tested OPTION, so that the
 two can be compared (tools/compare_dropout_modes.py):
 
-  RedrawRollout.collect     per vector step t: the mask key becomes (seed, collect tag, CALL t), the K/V caches are rebuilt by replaying
-                            positions 0..t through cirs_tracker_init / cirs_tracker_step (O(T^2) launches per collect instead of O(T):
-                            an option for studies, not the benchmark path), then cirs_actor_sample and cirs_env_step as separate launches
-  redraw_tracker_backward   d loss / d s_t flows through call t only: one cirs_tracker_backward per call with the call's key and a
-                            d-state tensor that is zero except at position t, gradients summed over the calls."""
+  RedrawRollout.collect     per vector step t: the mask key becomes (seed, collect tag, CALL t) and ONE batched causal pass over positions 0..t of
+                            every env (cirs_tracker_prefix_states: the forward half of the BPTT, 6 launches) gives s_t; the cached decode only
+                            keeps writing the input slots.  O(T) launches and O(T^2) row-passes per collect -- the procedure's own arithmetic --,
+                            then cirs_actor_sample and cirs_env_step as separate launches
+  redraw_tracker_backward   d loss / d s_t flows through call t only: ONE cirs_tracker_backward over pseudo-envs (call c, env e) = episodes of c + 1
+                            rows with the d-state at their last row; a call's masks are keyed by its pseudo-env id, so the pass regenerates them."""
 import ctypes as C
 from typing import Optional
 
@@ -21,29 +22,35 @@ from . import abi
 from .rollout import DeviceRollout
 
 
-def call_tag(rng_base: int, call: int) -> int:
-    """Mask-key tag of build_state call `call` of the collect whose sampler counters start at rng_base."""
-    # 16 bits for the call index (max_turn <= 65534), the collect's counter base above them: the tag space of set_dropout_key is 64 bits wide,
-    # so neither a long episode nor a long run wraps one collect's tags into another's
-    assert 0 <= int(call) < 0xFFFF, "more build_state calls per collect than the mask tag has room for"
+def call_tag(rng_base: int, call: int = 0) -> int:
+    """Mask-key tag of the collect whose sampler counters start at rng_base.  The build_state calls of one collect share the tag and differ in
+    the env field of the mask counter: call t of env e draws the masks of pseudo-env t * B + e (RedrawRollout._call_state).  (`call` is kept for
+    callers that want one tag per call; the rollout passes 0.)"""
+    assert 0 <= int(call) < 0xFFFF
     return ((int(rng_base) & 0xFFFFFFFFFF) << 16) + int(call) + 1
 
 
 class RedrawRollout(DeviceRollout):
-    def _replay(self, t, users, key_seed, rng_base, out):
-        """Rebuild the tracker state of call t (prefix 0..t) with that call's masks; s_t -> out [B, S]."""
-        trk, tr = self.tracker, self.traj
-        trk.set_dropout_key(key_seed, call_tag(rng_base, t), self.dropout_env_base)
-        trk.reset()
-        S = trk.dim_state
-        if t == 0:
-            trk.init(users, out=out, out_stride=S)
-            return
-        trk.init(users, out=self._scratch, out_stride=S)
-        for k in range(t):
-            skip = (tr.act[k] < 0).to(torch.uint8)
-            trk.step(tr.act[k].clamp(min=0), tr.rew[k], skip=skip, out=out if k == t - 1 else self._scratch, out_stride=S)
-        self._keep = skip
+    def _prefix_rows(self, t, B):
+        """Row description of call t: every env, positions 0..t (device tensors, built once per (t, B))."""
+        cache = self.__dict__.setdefault("_rows_cache", {})
+        if (t, B) not in cache:
+            dev = self.device
+            ar = torch.arange(B, dtype=torch.int32, device=dev)
+            cache[(t, B)] = (ar.repeat_interleave(t + 1).contiguous(), torch.arange(t + 1, dtype=torch.int32, device=dev).repeat(B).contiguous(),
+                             (ar * (t + 1)).contiguous(), torch.full((B,), t + 1, dtype=torch.int32, device=dev))
+        return cache[(t, B)]
+
+    def _call_state(self, t, key_seed, rng_base, out):
+        """s_t of build_state call t: ONE batched causal pass over positions 0..t of every env from the stored input slots with call t's masks
+        (cirs_tracker_prefix_states).  Envs that finished before call t get a state nobody reads (the sampler skips them)."""
+        trk = self.tracker
+        B = self.env.n_env
+        row_env, row_t, offsets, lens = self._prefix_rows(t, B)
+        # call t's masks: the collect's key with the pseudo-env id t * B + e in place of the env id (a fresh set per call; the batched backward
+        # regenerates them from the same ids)
+        trk.set_dropout_key(key_seed, call_tag(rng_base, 0), self.dropout_env_base + t * B)
+        trk.prefix_states(row_env, row_t, offsets, lens, B * (t + 1), out)
 
     def collect(self, users: torch.Tensor, *, seed=0, rng_base=0, sync_every: Optional[int] = None, gumbel=None):
         assert gumbel is None and self.online is None and self.visited is None and self.force_length == 0, \
@@ -56,8 +63,12 @@ class RedrawRollout(DeviceRollout):
         tr.clear()
         env.reset(users)
         self._users, self._key = users, (key_seed, rng_base)
+        # the cached decode keeps writing the INPUT slots (user slot, then one slot per action: they do not depend on any mask); its own states,
+        # which belong to the position-keyed masks of the production mode, are discarded
+        trk.reset()
+        trk.init(users, out=self._scratch, out_stride=S)
         for t in range(T):
-            self._replay(t, users, key_seed, rng_base, tr.obs[t])
+            self._call_state(t, key_seed, rng_base, tr.obs[t])
             done = env.done.clone()
             self.policy.sample(tr.obs[t], seed=seed, rng_step=(rng_base + t) & 0xFFFFFFFF, skip=done, act_out=tr.act[t], logp_out=tr.logp[t],
                                value_out=tr.value[t])
@@ -66,22 +77,48 @@ class RedrawRollout(DeviceRollout):
             tr.rew[t].copy_(torch.where(live, rew, torch.zeros_like(rew)))
             tr.done[t].copy_(torch.where(live, dn, torch.zeros_like(dn)))
             tr.ctr[t].copy_(ctr)
-        self._replay(T, users, key_seed, rng_base, tr.obs[T]) if T < trk.cfg.max_len else None
+            if t + 1 < trk.cfg.max_len:
+                trk.step(tr.act[t].clamp(min=0), tr.rew[t], skip=(tr.act[t] < 0).to(torch.uint8), out=self._scratch, out_stride=S)
+        if T < trk.cfg.max_len:
+            self._call_state(T, key_seed, rng_base, tr.obs[T])
         return env.turn.clone()
 
 
-def redraw_tracker_backward(rollout: RedrawRollout, row_env, row_t, offsets, lens, n_rows, dstate):
-    """Gradients of the tracker parameters under the exact-redraw procedure: sum over the calls t of the backward pass with call t's
-    masks and d-state restricted to position t.  Leaves the sum in tracker.flat_grad."""
+class _CallBatch:
+    """act / rew of the rollout's trajectory seen by T_calls x B pseudo-envs (pseudo-env c * B + e = env e in the graph of call c)."""
+    def __init__(self, tr, n_calls):
+        self.act = tr.act.repeat(1, n_calls).contiguous()
+        self.rew = tr.rew.repeat(1, n_calls).contiguous()
+
+
+def redraw_tracker_backward(rollout: RedrawRollout, row_env, row_t, offsets, lens, n_rows, dstate, lens_host=None):
+    """Gradients of the tracker parameters under the exact-redraw procedure: d loss / d s_t flows through the graph of call t alone (call t's
+    masks, positions 0..t of the envs alive at t).  All calls run as ONE backward pass: call c of env e is the pseudo-env c * B + e -- an episode
+    of c + 1 rows over env e's input slots whose only d-state sits at its last row --, and because a call's masks are keyed by exactly that
+    pseudo-env id (RedrawRollout._call_state), the pass regenerates every call's masks by itself.  sum_c (c + 1) live(c) rows instead of one pass
+    per call: the same row-passes, 27 launches instead of 27 per call, one ordered embedding scatter.  Leaves the sum in tracker.flat_grad.
+    (row_env / row_t / offsets / n_rows describe the whole buffer and are not needed; the lengths on the host -- lens_host, or one read-back -- only give the row count; the row lists are built on the device.)"""
+    import numpy as np
     trk, tr = rollout.tracker, rollout.traj
     key_seed, rng_base = rollout._key
-    T = rollout.env.max_turn
-    total = torch.zeros_like(trk.flat_grad)
-    t_max = int(lens.max())
-    for t in range(t_max):
-        trk.set_dropout_key(key_seed, call_tag(rng_base, t), rollout.dropout_env_base)
-        d_t = torch.zeros_like(dstate)
-        d_t[t] = dstate[t]
-        trk.backward(rollout._users, tr, row_env, row_t, offsets, lens, n_rows, d_t)
-        total += trk.flat_grad
-    trk.flat_grad.copy_(total)
+    dev = dstate.device
+    lens_h = (lens.detach().cpu().numpy() if lens_host is None else np.asarray(lens_host)).astype(np.int64)
+    B = lens_h.shape[0]
+    C_ = int(lens_h.max())                                          # calls 0 .. C_-1 carry a gradient (s_t with t < len)
+    n_q = int(sum((c + 1) * int((lens_h > c).sum()) for c in range(C_)))
+    T = tr.act.shape[0]
+    trk.reserve_backward(B * T * (T + 1) // 2)                      # the largest call batch (every env alive at every call): one allocation per run
+    lens_d = lens.to(dev, torch.int32)
+    call = torch.arange(C_, dtype=torch.int32, device=dev).repeat_interleave(B)
+    lens_q = torch.where(lens_d.repeat(C_) > call, call + 1, torch.zeros_like(call))          # [C_ * B]
+    offs_q = (torch.cumsum(lens_q, 0, dtype=torch.int32) - lens_q).contiguous()
+    env_q = torch.repeat_interleave(torch.arange(C_ * B, dtype=torch.int32, device=dev), lens_q.long(), output_size=n_q)
+    pos_q = torch.arange(n_q, dtype=torch.int32, device=dev) - torch.repeat_interleave(offs_q, lens_q.long(), output_size=n_q)
+    up = lambda a: a.to(torch.int32).contiguous()      # noqa: E731
+    d_q = torch.zeros((dstate.shape[0], C_, B, dstate.shape[2]), dtype=dstate.dtype, device=dev)
+    ar = torch.arange(C_, device=dev)
+    d_q[ar, ar] = dstate[:C_]                                       # d s_c of env e -> position c of pseudo-env (c, e)
+    trk.set_dropout_key(key_seed, call_tag(rng_base, 0), rollout.dropout_env_base)
+    trk.backward(rollout._users.repeat(C_), _CallBatch(tr, C_), up(env_q), up(pos_q), up(offs_q), up(lens_q), n_q,
+                 d_q.view(dstate.shape[0], C_ * B, dstate.shape[2]), x_hist=trk.x_hist.repeat(C_, 1, 1).contiguous(),
+                 drop_env_base=rollout.dropout_env_base)

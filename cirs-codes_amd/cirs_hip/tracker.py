@@ -134,7 +134,7 @@ class DeviceTracker:
         self.lr, self.betas, self.adam_eps = lr, betas, eps
         self._bws = None
 
-    def backward(self, users, traj, row_env, row_t, offsets, lens, n_rows, dstate, x_hist=None):
+    def backward(self, users, traj, row_env, row_t, offsets, lens, n_rows, dstate, x_hist=None, drop_env_base=0):
         """d loss / d tracker params from d loss / d obs (dstate [T+1,B,S]); fills self.flat_grad.
         x_hist: stored input slots [B', max_len, D] when the rows come from a gathered (multi-rank) buffer whose
         env count B' = traj.B differs from this tracker's own n_env."""
@@ -143,7 +143,7 @@ class DeviceTracker:
         if x_hist is not None:
             cfg = abi.TrackerCfg.from_buffer_copy(self.cfg)
             cfg.n_env = x_hist.shape[0]
-            cfg.drop_env_base = 0      # rows of a gathered buffer carry GLOBAL env ids already
+            cfg.drop_env_base = int(drop_env_base)      # rows of a gathered buffer carry GLOBAL env ids already (0); redraw.py: the rollout's base
             st = abi.TrackerState(x_hist=x_hist.data_ptr(), kcache=self.kcache.data_ptr(), vcache=self.vcache.data_ptr(),
                                   len=self.len.data_ptr())
         need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(cfg), n_rows)
@@ -154,6 +154,17 @@ class DeviceTracker:
             traj.rew.data_ptr(), row_env.data_ptr(), row_t.data_ptr(), offsets.data_ptr(), lens.data_ptr(), n_rows,
             dstate.data_ptr(), C.byref(self.g), self._bws.data_ptr(), self._bws.numel(), self._stream()),
             "cirs_tracker_backward")
+
+    def prefix_states(self, row_env, row_t, offsets, lens, n_rows, out, out_stride=None):
+        """One causal pass over the rows (env b, positions 0 .. lens[b]-1) from the stored input slots under the CURRENT dropout key; the state
+        of every env's last row -> out [B, S] (cirs_tracker_prefix_states: the forward half of backward())."""
+        need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(self.cfg), n_rows)
+        if self._bws is None or self._bws.numel() < need:
+            self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        abi.check(self._lib.cirs_tracker_prefix_states(
+            C.byref(self.cfg), C.byref(self.w), C.byref(self.st), row_env.data_ptr(), row_t.data_ptr(), offsets.data_ptr(), lens.data_ptr(),
+            n_rows, out.data_ptr(), self.dim_state if out_stride is None else out_stride, self._bws.data_ptr(), self._bws.numel(), self._stream()),
+            "cirs_tracker_prefix_states")
 
     def reserve_backward(self, max_rows):
         need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(self.cfg), max_rows)

@@ -1462,18 +1462,39 @@ extern "C" int cirs_debug_tbwd_prof(unsigned long long* out_host64) {
 }
 #endif
 
+namespace cirs {
+// cirs_tracker_prefix_states: state of the LAST row of every env that has rows = decoder(H_last[row]); one wavefront per env, lane j < S owns
+// output j (fma chain over the 32 features in ascending order)
+__global__ __launch_bounds__(256) void prefix_decoder_kernel(const float* __restrict__ H, const int32_t* __restrict__ offsets, const int32_t* __restrict__ lens,
+                                                             int B, int S, const float* __restrict__ dec_w, const float* __restrict__ dec_b,
+                                                             float* __restrict__ out, long out_stride) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), j = threadIdx.x & 63;
+    if (e >= B || j >= S) return;
+    const int n = lens[e];
+    if (n <= 0) return;
+    const float* h = H + (size_t)(offsets[e] + n - 1) * tD;
+    float acc = dec_b[j];
+#pragma unroll
+    for (int k = 0; k < tD; ++k) acc = __builtin_fmaf(h[k], dec_w[(size_t)j * tD + k], acc);
+    out[(size_t)e * out_stride + j] = acc;
+}
+}  // namespace cirs
+
 extern "C" int64_t cirs_tracker_backward_workspace_bytes(const cirs_tracker_cfg* cfg, int32_t n_rows) {
     if (!cfg || n_rows <= 0) return 0;
     return (int64_t)cirs::bwd_floats(cfg, n_rows) * 4;
 }
 
-extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
-                                     const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
-                                     const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
-                                     const float* dstate, const cirs_tracker_grads* grads, void* workspace,
-                                     int64_t workspace_bytes, void* stream) {
+// forward recompute over the buffer rows (+ backward unless state_out is set: then the decoder runs on the last row of every env and the call
+// returns -- cirs_tracker_prefix_states)
+static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
+                             const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
+                             const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
+                             const float* dstate, const cirs_tracker_grads* grads, void* workspace,
+                             int64_t workspace_bytes, void* stream, float* state_out, int64_t state_stride) {
     using namespace cirs;
-    CIRS_REQUIRE(cfg && w && st && users && act && rew && row_env && row_t && offsets && lens && dstate && grads && workspace, "null argument");
+    CIRS_REQUIRE(cfg && w && st && row_env && row_t && offsets && lens && workspace, "null argument");
+    CIRS_REQUIRE(state_out || (users && act && rew && dstate && grads), "null argument");
     if (cfg->dim_model != tD || cfg->d_hid != tH) return fail(CIRS_E_UNSUPPORTED, "dim_model == 32 and d_hid == 128 only");
     CIRS_REQUIRE(cfg->nhead == 1 || cfg->nhead == 2 || cfg->nhead == 4 || cfg->nhead == 8, "nhead must be 1,2,4,8");
     CIRS_REQUIRE(n_rows > 0, "n_rows must be positive");
@@ -1563,6 +1584,12 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
                            dc, row_env, row_t, l, (int)CIRS_DROP_RES2);
     }
     CIRS_CHECK_LAUNCH("tracker forward recompute");
+    if (state_out) {
+        hipLaunchKernelGGL(prefix_decoder_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, (const float*)sc.H[nl], offsets, lens, B, S, w->dec_w, w->dec_b,
+                           state_out, (long)state_stride);
+        CIRS_CHECK_LAUNCH("prefix_decoder_kernel");
+        return CIRS_OK;
+    }
     // ---------------- backward ----------------
     hipLaunchKernelGGL(gather_dstate, g1((long)R * S), dim3(256), 0, s, dstate, row_env, row_t, R, S, B, sc.G);
     float* dH = sc.T0;  // gradient w.r.t. the current layer output
@@ -1694,6 +1721,25 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
 #undef ATT_EP1
 #undef ATT_DISPATCH_SH
     return CIRS_OK;
+}
+
+extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
+                                     const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
+                                     const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
+                                     const float* dstate, const cirs_tracker_grads* grads, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    CIRS_REQUIRE(users && act && rew && dstate && grads, "null argument");
+    return tracker_rows_impl(cfg, w, st, users, act, rew, row_env, row_t, offsets, lens, n_rows, dstate, grads, workspace, workspace_bytes, stream,
+                             nullptr, 0);
+}
+
+extern "C" int cirs_tracker_prefix_states(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
+                                          const int32_t* row_env, const int32_t* row_t, const int32_t* offsets, const int32_t* lens,
+                                          int32_t n_rows, float* state_out, int64_t state_stride, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+    CIRS_REQUIRE(state_out && state_stride >= (cfg ? cfg->dim_state : 0), "bad state_out");
+    return tracker_rows_impl(cfg, w, st, nullptr, nullptr, nullptr, row_env, row_t, offsets, lens, n_rows, nullptr, nullptr, workspace, workspace_bytes,
+                             stream, state_out, state_stride);
 }
 
 // ---- row-sharded embedding tables (BASELINE configs[4]): the owner rank's ordered scatter of received gradient rows ----------------

@@ -447,6 +447,16 @@ int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
                           const float* dstate, const cirs_tracker_grads* grads, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* The forward half of cirs_tracker_backward as an entry point: ONE causal pass over the buffer rows (env b, positions 0 .. lens[b]-1) from the
+ * stored input slots, with the dropout masks of the key currently set in cfg (dropout_seed / drop_env_base), and the state of every env's LAST row
+ * -> state_out[b * state_stride + 0 .. dim_state) (envs with lens[b] == 0 are left untouched).  This is the reference's build_state under live
+ * dropout -- the encoder re-run over the WHOLE prefix with fresh masks at every call (core/state_tracker.py:170-186, 243-246) -- as one batched
+ * pass per call instead of a replay of the cached decode (cirs_hip/redraw.py).  Workspace: cirs_tracker_backward_workspace_bytes(cfg, n_rows). */
+int cirs_tracker_prefix_states(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
+                               const int32_t* row_env, const int32_t* row_t, const int32_t* offsets, const int32_t* lens,
+                               int32_t n_rows, float* state_out, int64_t state_stride, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+
 /* Ordered scatter of embedding-gradient rows (dim_model == 32) into a table: grad_table [n_table_rows, 32] is OVERWRITTEN with, per row k,
  * the sum of contrib[r] over the rows r with keys[r] == k, added in ascending r (stable radix sort + ordered segment sums: no float
  * atomics, cost O(n_rows) whatever the table size); keys outside [0, n_table_rows) contribute nothing.  It is the scatter of

@@ -165,13 +165,13 @@ def test_exact_redraw_mode_matches_the_reference_procedure():
     # (a) call by call against the restatement
     sticky_like = None
     for t in range(int(lens.max()) + 1):
-        d = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, t)), envs=np.arange(B))
+        d = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, 0)), envs=t * B + np.arange(B))      # call t's masks: pseudo-env ids t * B + e
         with torch.no_grad():
             want = nn_oracle.tracker_states(tp, users.numpy(), acts0, rew, dropout=d).numpy()
         live = lens >= t
         np.testing.assert_allclose(obs[t][live], want[live, t], atol=5e-5, rtol=1e-4, err_msg=f"call {t}")
         if t == 2:
-            d1 = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, 1)), envs=np.arange(B))
+            d1 = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, 0)), envs=1 * B + np.arange(B))
             with torch.no_grad():
                 other = nn_oracle.tracker_states(tp, users.numpy(), acts0, rew, dropout=d1).numpy()
             assert np.abs(other[live, 2] - want[live, 2]).max() > 1e-3, "a call's masks must differ from the previous call's"
@@ -183,7 +183,7 @@ def test_exact_redraw_mode_matches_the_reference_procedure():
             v.requires_grad_(True)
     total = 0.0
     for t in range(int(lens.max())):
-        d = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, t)), envs=np.arange(B))
+        d = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, 0)), envs=t * B + np.arange(B))      # call t's masks: pseudo-env ids t * B + e
         st = nn_oracle.tracker_forward_all(tpo, nn_oracle.tracker_inputs(tpo, users.numpy(), acts0, rew), 4, dropout=d)
         w = torch.zeros(B, 20)
         sel = torch.as_tensor(lens > t)

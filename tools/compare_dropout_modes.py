@@ -7,6 +7,7 @@ exit rule punishes repeated categories), CirsEngine on one MI355X:
   redraw   dropout 0.1, the reference's procedure: fresh masks over the whole prefix at every build_state call (cirs_hip/redraw.py)
 
     python tools/compare_dropout_modes.py [epochs] [seeds]      -> markdown table on stdout (mean trajectory length / reward per epoch)
+    CMP_SHAPE=c2 ...                                            -> the same at BASELINE configs[1]'s shape (1411 x 3327, 64 envs)
 """
 import os
 import sys
@@ -24,6 +25,8 @@ from cirs_hip.synthetic import make_tables
 EPOCHS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 SEEDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 U, I, B, T, STEPS_PER_EPOCH = 300, 800, 128, 30, 6000
+if os.environ.get("CMP_SHAPE") == "c2":          # BASELINE configs[1]'s shape: 1411 users x 3327 items, 64 envs
+    U, I, B = 1411, 3327, 64
 tab = make_tables(U, I, seed=0, build_dist=True)
 a_env = tab.alpha_u[tab.raw_uid, 0].astype(np.float64); b_env = tab.beta_i[tab.raw_pid, 0].astype(np.float64)
 dt = DeviceEnvTables(tab.mat, tab.normed_mat, tab.item_cats, dist=tab.dist, alpha_env=a_env, beta_env=b_env)
