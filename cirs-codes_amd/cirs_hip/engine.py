@@ -117,17 +117,19 @@ class CirsEngine:
         self.hidden = hidden
         self.policy = DevicePolicy(pviews, I, dim_state=dim_state, hidden=hidden, device=self.device)
         # dropout_redraw: the reference's exact procedure (fresh masks over the whole prefix at every build_state call,
-        # core/state_tracker.py:170-186,243-246) as a study option: O(T^2) tracker launches per collect (cirs_hip/redraw.py)
+        # core/state_tracker.py:170-186,243-246): one batched prefix pass per call, one batched backward over all calls (cirs_hip/redraw.py)
         self.dropout_redraw = bool(dropout_redraw)
         if self.dropout_redraw:
             from .redraw import RedrawRollout
-            assert world_size == 1 and online_reward is None, "the exact-redraw option is a single-device study mode"
+            assert online_reward is None and (world_size == 1 or (learner_mode == "replicated" and self.tracker_backward == "replicated")), \
+                "the exact-redraw option runs on one device or with the replicated learner (every rank over the gathered buffer)"
             self.rollout = RedrawRollout(self.env, self.tracker, self.policy)
         else:
             self.rollout = DeviceRollout(self.env, self.tracker, self.policy, online=online_reward)
         self.rollout.dropout_env_base = rank * n_env
         self.rollout.dropout_key_from_high_bits = True
         self.B_total = n_env * world_size
+        self.rollout.B_total = self.B_total
         self.learner = DeviceLearner(self.policy_flat, I, self.B_total, max_turn, dim_state=dim_state, hidden=hidden, gamma=gamma,
                                      gae_lambda=gae_lambda, eps_clip=eps_clip, vf_coef=vf_coef, ent_coef=ent_coef,
                                      max_grad_norm=max_grad_norm, lr=lr, norm_adv=norm_adv, value_clip=value_clip, rew_norm=rew_norm,
@@ -253,7 +255,8 @@ class CirsEngine:
             return losses, n
         if self.dropout_redraw:
             from .redraw import redraw_tracker_backward
-            redraw_tracker_backward(self.rollout, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs, lens_host=lens)
+            redraw_tracker_backward(self.rollout, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs, lens_host=lens, users=users, traj=traj,
+                                    x_hist=x_hist)
             self.tracker.adam_update()
             return losses, n
         self.tracker.backward(users, traj, ln.b_env, ln.b_t, ln.offsets_dev, ln.lens_dev, n, ln.dobs,

@@ -49,7 +49,7 @@ class RedrawRollout(DeviceRollout):
         row_env, row_t, offsets, lens = self._prefix_rows(t, B)
         # call t's masks: the collect's key with the pseudo-env id t * B + e in place of the env id (a fresh set per call; the batched backward
         # regenerates them from the same ids)
-        trk.set_dropout_key(key_seed, call_tag(rng_base, 0), self.dropout_env_base + t * B)
+        trk.set_dropout_key(key_seed, call_tag(rng_base, 0), self.dropout_env_base + t * getattr(self, "B_total", B))     # (B_total: envs of ALL ranks)
         trk.prefix_states(row_env, row_t, offsets, lens, B * (t + 1), out)
 
     def collect(self, users: torch.Tensor, *, seed=0, rng_base=0, sync_every: Optional[int] = None, gumbel=None):
@@ -91,7 +91,7 @@ class _CallBatch:
         self.rew = tr.rew.repeat(1, n_calls).contiguous()
 
 
-def redraw_tracker_backward(rollout: RedrawRollout, row_env, row_t, offsets, lens, n_rows, dstate, lens_host=None):
+def redraw_tracker_backward(rollout: RedrawRollout, row_env, row_t, offsets, lens, n_rows, dstate, lens_host=None, users=None, traj=None, x_hist=None):
     """Gradients of the tracker parameters under the exact-redraw procedure: d loss / d s_t flows through the graph of call t alone (call t's
     masks, positions 0..t of the envs alive at t).  All calls run as ONE backward pass: call c of env e is the pseudo-env c * B + e -- an episode
     of c + 1 rows over env e's input slots whose only d-state sits at its last row --, and because a call's masks are keyed by exactly that
@@ -99,7 +99,11 @@ def redraw_tracker_backward(rollout: RedrawRollout, row_env, row_t, offsets, len
     per call: the same row-passes, 27 launches instead of 27 per call, one ordered embedding scatter.  Leaves the sum in tracker.flat_grad.
     (row_env / row_t / offsets / n_rows describe the whole buffer and are not needed; the lengths on the host -- lens_host, or one read-back -- only give the row count; the row lists are built on the device.)"""
     import numpy as np
-    trk, tr = rollout.tracker, rollout.traj
+    # several ranks (replicated learner): `lens`, `dstate`, `users`, `traj`, `x_hist` describe the GATHERED buffer of all B_total envs; env ids are
+    # global (rank * n_env + e), which is what the rollouts keyed their masks with
+    trk, tr = rollout.tracker, (rollout.traj if traj is None else traj)
+    users = rollout._users if users is None else users.to(dstate.device, torch.int32)
+    x_hist = trk.x_hist if x_hist is None else x_hist
     key_seed, rng_base = rollout._key
     dev = dstate.device
     lens_h = (lens.detach().cpu().numpy() if lens_host is None else np.asarray(lens_host)).astype(np.int64)
@@ -118,7 +122,7 @@ def redraw_tracker_backward(rollout: RedrawRollout, row_env, row_t, offsets, len
     d_q = torch.zeros((dstate.shape[0], C_, B, dstate.shape[2]), dtype=dstate.dtype, device=dev)
     ar = torch.arange(C_, device=dev)
     d_q[ar, ar] = dstate[:C_]                                       # d s_c of env e -> position c of pseudo-env (c, e)
-    trk.set_dropout_key(key_seed, call_tag(rng_base, 0), rollout.dropout_env_base)
-    trk.backward(rollout._users.repeat(C_), _CallBatch(tr, C_), up(env_q), up(pos_q), up(offs_q), up(lens_q), n_q,
-                 d_q.view(dstate.shape[0], C_ * B, dstate.shape[2]), x_hist=trk.x_hist.repeat(C_, 1, 1).contiguous(),
-                 drop_env_base=rollout.dropout_env_base)
+    base = rollout.dropout_env_base if B == rollout.env.n_env else 0          # (gathered buffer: the ids are global already)
+    trk.set_dropout_key(key_seed, call_tag(rng_base, 0), base)
+    trk.backward(users.repeat(C_), _CallBatch(tr, C_), up(env_q), up(pos_q), up(offs_q), up(lens_q), n_q,
+                 d_q.view(dstate.shape[0], C_ * B, dstate.shape[2]), x_hist=x_hist.repeat(C_, 1, 1).contiguous(), drop_env_base=base)

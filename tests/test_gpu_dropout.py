@@ -209,3 +209,81 @@ def test_exact_redraw_mode_matches_the_reference_procedure():
     live = (e1.rollout.traj.act >= 0)
     torch.testing.assert_close(e0.rollout.traj.obs[:-1][live], e1.rollout.traj.obs[:-1][live], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(e0.rollout.traj.rew[live], e1.rollout.traj.rew[live], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("W,B,I,U,T", [(2, 12, 300, 90, 10), (4, 8, 500, 90, 8)])
+def test_exact_redraw_with_replicated_ranks(monkeypatch, W, B, I, U, T):
+    """The exact-redraw procedure under world_size > 1: W virtual ranks (threads + the thread-synchronised collectives of
+    test_gpu_engine_dp), learner "replicated" -- every rank rolls out its own envs with call t's masks keyed by the GLOBAL pseudo-env id
+    t * B_total + rank * B + e, gathers all trajectories, and runs the identical update incl. the one batched backward over all calls of all
+    envs.  Checks: a rank's states are the restatement's under exactly those ids; ranks stay bit-identical; the result equals one device
+    holding all W * B envs and running the same procedure on the gathered buffer."""
+    import threading
+    import torch.distributed as dist
+    from test_gpu_engine_dp import FakeCollectives
+    from cirs_hip.engine import CirsEngine
+    from cirs_hip.env import DeviceEnvTables
+    from cirs_hip.redraw import call_tag
+    from cirs_hip.synthetic import make_tables
+    tab = make_tables(U, I, seed=0, build_dist=False)
+    a_env = tab.alpha_u[tab.raw_uid, 0].astype(np.float64); b_env = tab.beta_i[tab.raw_pid, 0].astype(np.float64)
+    dt = DeviceEnvTables(tab.mat, tab.normed_mat, tab.item_cats, alpha_env=a_env, beta_env=b_env)
+    fake = FakeCollectives(W)
+    monkeypatch.setattr(dist, "all_reduce", fake.all_reduce)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake.all_gather_into_tensor)
+    monkeypatch.setattr(dist, "reduce_scatter_tensor", fake.reduce_scatter_tensor)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: W)
+    p, seed, bs = 0.1, 5, 32
+    kw = dict(max_turn=T, num_leave_compute=3, leave_threshold=1, tau=10.0, gamma_exposure=10.0, seed=seed, batch_size_hint=bs, dropout=p, dropout_redraw=True)
+    engines = [CirsEngine(dt, B, world_size=W, rank=r, learner_mode="replicated", tracker_backward="replicated", **kw) for r in range(W)]
+    rng = np.random.RandomState(2)
+    users = [torch.as_tensor(rng.randint(0, U, B)) for _ in range(W)]
+    for r, eng in enumerate(engines):
+        eng.collect(users[r])
+    torch.cuda.synchronize()
+    # a rank's states against the restatement with the global pseudo-env ids
+    r = W - 1
+    tr = engines[r].rollout.traj
+    lens = engines[r].lengths.cpu().numpy()
+    act = np.maximum(tr.act.cpu().numpy().T, 0); rew = tr.rew.cpu().numpy().T; obs = tr.obs.cpu().numpy()
+    tp = {k: v.detach().cpu().clone() for k, v in engines[r].tracker.params.items()}
+    for t in range(int(lens.max()) + 1):
+        d = dict(p=p, key=nn_oracle.dropout_key(seed, call_tag(0, 0)), envs=t * (W * B) + r * B + np.arange(B))
+        with torch.no_grad():
+            want = nn_oracle.tracker_states(tp, users[r].numpy(), act, rew, dropout=d).numpy()
+        live = lens >= t
+        np.testing.assert_allclose(obs[t][live], want[live, t], atol=5e-5, rtol=1e-4, err_msg=f"rank {r} call {t}")
+    n_total = int(sum(int(e.lengths.sum()) for e in engines))
+    perms = [rng.permutation(n_total) for _ in range(2)]
+    gathered, results = {}, [None] * W
+
+    def run(q):
+        try:
+            fake.local.rank = q
+            g = engines[q]._gather()
+            if q == 0:
+                gathered["traj"] = {k: getattr(g[0], k).clone() for k in ("obs", "act", "rew", "done", "logp", "value", "ctr")}
+                gathered["x_hist"], gathered["lens"], gathered["users"] = g[1].clone(), g[2].clone(), g[3].clone()
+            results[q] = engines[q].update(bs, 2, perms=perms)
+        except Exception as exc:  # noqa: BLE001
+            fake.errors.append(exc)
+            fake.bar.abort()
+
+    threads = [threading.Thread(target=run, args=(q,)) for q in range(W)]
+    [t.start() for t in threads]; [t.join(timeout=120) for t in threads]
+    assert not fake.errors, fake.errors
+    for q in range(1, W):
+        assert torch.equal(engines[0].policy_flat, engines[q].policy_flat) and torch.equal(engines[0].tracker_flat, engines[q].tracker_flat)
+    monkeypatch.undo()
+    ref = CirsEngine(dt, B * W, world_size=1, rank=0, **kw)
+    for k, v in gathered["traj"].items():
+        getattr(ref.rollout.traj, k).copy_(v)
+    ref.tracker.x_hist.copy_(gathered["x_hist"])
+    ref.lengths, ref.users = gathered["lens"].to(torch.int32), gathered["users"].to(torch.int32)
+    ref.rollout._users, ref.rollout._key = ref.users, engines[0].rollout._key
+    ref.update(bs, 2, perms=perms)
+    assert torch.equal(ref.policy_flat, engines[0].policy_flat)
+    assert torch.equal(ref.tracker_flat, engines[0].tracker_flat)
+    assert not torch.equal(ref.tracker_flat, CirsEngine(dt, B * W, world_size=1, rank=0, **kw).tracker_flat), "the update must have moved the tracker"

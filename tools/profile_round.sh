@@ -2,7 +2,7 @@
 # All measurements of a round in one GPU call:  bash tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
 #   bench JSON lines (c3, c2, c3 with --dropout 0.1), rocprofv3 kernel-trace summaries of the timed step (eval-mode and dropout-mode)
 #   and of the K1-K2 / sweep workload (tools/pmc_workload.py), the phase timeline, the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs).
-tag=${1:-r04}
+tag=${1:-r04y}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
