@@ -11,6 +11,7 @@ Workloads (BASELINE.json configs): c3 (default) KuaishouEnv big_matrix-shaped 71
 recent-N = 10 (C4 = the same with 8 ranks: 8192 envs, weak scaling); c2 = 1411 x 3327, 64 envs.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -100,18 +101,26 @@ def timed_pass(wl, device, dropout, warmup, steps, batch=1024):
     eng, _ = build_engine(wl, 0, 1, device, dropout=dropout)
     for _ in range(warmup):
         eng.collect(); eng.update(batch_size=batch, repeat=2)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # one event per step on the launch stream: the spread of the steps
+    gc.collect()
+    gc.disable()          # (see the headline's timed region)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks[0].record()
     n_steps = mb_steps = 0
-    for _ in range(steps):
+    for k in range(steps):
         eng.collect()
         losses, n = eng.update(batch_size=batch, repeat=2)
         n_steps += n; mb_steps += losses.shape[0]
+        marks[k + 1].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
     out = {"workload": wl["name"], "tracker_dropout": dropout, "value": n_steps / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / steps,
            "steps": steps, "warmup": warmup, "envs": wl["B"], "mean_episode_len": n_steps / steps / wl["B"],
-           "minibatch_steps_per_update": mb_steps / steps}
+           "minibatch_steps_per_update": mb_steps / steps,
+           "gpu_ms_per_step_median_max": [per_step[len(per_step) // 2], per_step[-1]]}
     del eng
     torch.cuda.empty_cache()
     return out
@@ -506,6 +515,10 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    # Python's cyclic collector stays out of the timed region (as timeit does): a generation-2 pass over the tables / engines built above costs
+    # 3-80 ms when it happens to fire inside 20 timed steps (seen as single-step spikes: tools/probes/pass_jitter.py)
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     steps_local = 0
@@ -518,6 +531,7 @@ def main():
         mb_steps += losses.shape[0]
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
