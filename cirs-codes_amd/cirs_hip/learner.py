@@ -215,8 +215,7 @@ class DeviceLearner:
                 self.dobs.zero_()
             for s0, e0 in slices:
                 g_idx = perm_d[s0:e0]
-                l_idx = g_idx[rank::world].contiguous()
-                assert l_idx.numel() >= 1, "global minibatch smaller than the world size"
+                l_idx = self._local_rows(g_idx, rank, world)
                 self.mb_phase1(l_idx, g_idx, last and want_tracker_grad, losses[k])
                 all_reduce(self.grads)
                 self.mb_phase2(int(l_idx.numel()), int(g_idx.numel()), losses[k])
@@ -257,8 +256,7 @@ class DeviceLearner:
                 self.dobs.zero_()
             for s0, e0 in slices:
                 g_idx = perm_d[s0:e0]
-                l_idx = g_idx[rank::world].contiguous()
-                assert l_idx.numel() >= 1, "global minibatch smaller than the world size"
+                l_idx = self._local_rows(g_idx, rank, world)
                 self.mb_phase1(l_idx, g_idx, last and want_tracker_grad, losses[k])
                 coll.reduce_scatter(self._gshard, self.grads)
                 abi.check(self._lib.cirs_ppo_shard_norm(C.byref(self.cfg), self._gshard.data_ptr(), b0, sl, self._stats.data_ptr(),
@@ -274,6 +272,16 @@ class DeviceLearner:
                 self.opt_step += 1
                 k += 1
         return losses
+
+    def _local_rows(self, g_idx, rank, world):
+        """Rows rank::world of a global minibatch in a preallocated buffer (stream-ordered reuse: no allocation per minibatch)."""
+        m = len(range(rank, g_idx.numel(), world))
+        assert m >= 1, "global minibatch smaller than the world size"
+        if getattr(self, "_lidx_buf", None) is None or self._lidx_buf.numel() < m:
+            self._lidx_buf = torch.empty(max(m, 2048), dtype=g_idx.dtype, device=self.device)
+        l_idx = self._lidx_buf[:m]
+        l_idx.copy_(g_idx[rank::world])
+        return l_idx
 
     def learn_tp(self, batch_size, repeat, perms, rank, world, item_base, coll, want_tracker_grad=True):
         """learn() for an ITEM-SHARDED actor head (tensor-parallel; BASELINE configs[4]): this learner was built over the shard
@@ -297,6 +305,8 @@ class DeviceLearner:
             self._tp_red = torch.zeros(nred_max, dtype=torch.float32, device=self.device)
             self._tp_fm = torch.zeros(world * 4 * pad(max_mb), dtype=torch.float32, device=self.device)
 
+        nred_of = {e - s: int(self._lib.cirs_ppo_tp_exchange_floats(e - s, world)) for s, e in slices}      # (one ABI call per distinct size, not per minibatch)
+
         def call(phase, idx_ptr, mb, stats4, stats_all, red, want_dobs, loss_ptr):
             abi.check(self._lib.cirs_ppo_minibatch_tp(
                 C.byref(self.cfg), self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
@@ -314,7 +324,7 @@ class DeviceLearner:
                 mb, npad = e0 - s0, pad(e0 - s0)
                 idx_ptr = perm_d.data_ptr() + 4 * s0
                 stats4, gathered = self._tp_stats[:4 * npad], self._tp_all[:world * 4 * npad]
-                red = self._tp_red[:int(self._lib.cirs_ppo_tp_exchange_floats(mb, world))]
+                red = self._tp_red[:nred_of[mb]]
                 call(1, idx_ptr, mb, stats4.data_ptr(), None, red.data_ptr(), False, None)
                 coll.all_gather(gathered, stats4)
                 stats_all = self._tp_fm[:world * 4 * npad].view(4, world, npad)             # field-major: [4][world][n_pad]
