@@ -448,6 +448,27 @@ def cpu_baseline(wl, eng):
                 "c3_ppo_minibatch_steps_per_s": 0.75, "deepfm_pairs_per_s": 1.78e6, "cores": 8}}}
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): re-run this command line under torch.distributed.run, one rank
+    per GPU, and hand back its exit code.  Rank 0 of the child job prints the JSON line on the inherited stdout.  On a box with fewer
+    than N GPUs the job only starts with CIRS_BENCH_SHARE_GPU=1 (test hook: every rank on device 0, collectives over gloo)."""
+    import socket
+    import subprocess
+    share = os.environ.get("CIRS_BENCH_SHARE_GPU", "0") == "1"
+    have = torch.cuda.device_count()
+    if have < n_gpus and not share:
+        raise SystemExit(f"bench.py --gpus {n_gpus}: this node exposes {have} GPU(s) (set CIRS_BENCH_SHARE_GPU=1 to run every rank on device 0 over gloo)")
+    with socket.socket() as sk:      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -463,8 +484,9 @@ def main():
                     help="N > 1, learner replicated only: tracker BPTT over the rank's own envs + one gradient all-reduce (sharded) or over all "
                          "envs on every rank (replicated: no communication, results identical to one device).  Other learners always shard it")
     ap.add_argument("--global-batch", type=int, default=1024, help="PPO minibatch size over ALL ranks (reference batch_size, CIRS-RL-kuaishou.py:89)")
-    ap.add_argument("--dropout", type=float, default=0.0, help="tracker dropout probability (0 = eval-mode tracker of the parity fixtures; "
-                                                               "0.1 = the mode the reference trains in, SURVEY Q7)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="tracker dropout probability.  Default 0.1 = the mode the reference trains in (its tracker is "
+                                                               "never put in eval(), SURVEY Q7), with position-keyed masks unless --dropout-redraw; "
+                                                               "0 = the eval-mode tracker of the parity fixtures (reported as config.also_measured.dropout_off)")
     ap.add_argument("--dropout-redraw", action="store_true",
                     help="with --dropout > 0: the reference's own procedure (fresh masks over the whole prefix at every build_state call, "
                          "core/state_tracker.py:170-186,243-246; cirs_hip/redraw.py) instead of position-keyed masks.  Single GPU; O(T^2) row-passes by definition")
@@ -479,8 +501,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))       # the driver's command shape: `python3 bench.py --gpus N ...` with no launcher around it
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} under a launcher needs WORLD_SIZE={args.gpus} (found {world})")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     # test hook (tests/test_gpu_distributed.py on a 1-GPU box): every rank on device 0, collectives through gloo -- the same
     # multi-process engine path (env sharding, packed all-gather, per-minibatch all-reduce) without a second GPU
@@ -623,6 +647,11 @@ def main():
                        "global_minibatch": G, "minibatch_steps_per_update": mb_steps / args.steps,
                        "rows_per_rank_per_minibatch": G if (world == 1 or args.learner in ("replicated", "tp")) else G / world,
                        "ppo_repeat": 2, "tracker_dropout": args.dropout,
+                       "dropout_mode": ("off (eval-mode tracker)" if args.dropout == 0 else
+                                        "exact redraw (the reference's procedure: fresh masks over the whole prefix at every build_state call)" if args.dropout_redraw
+                                        else "position-keyed masks (every state has the reference's marginal distribution; a position keeps its masks for the rest of the episode)"),
+                       "mean_episode_len": total_steps / args.steps / (wl["B"] * world), "env_steps_per_step": total_steps / args.steps,
+                       "max_turn": wl["T"], "timed_region": f"{args.warmup} warm-up + {args.steps} timed collect+update steps from a freshly initialised policy (gc disabled inside the timed region)",
                        "parallelism": (f"env-sharded x{world}; one all-gather of trajectory records per update; learner '{args.learner}': "
                                        + {"dp": f"global minibatch of {G} rows sharded by rows over the ranks, one flat-gradient all-reduce per minibatch",
                                           "dp_sharded": f"global minibatch of {G} rows sharded by rows, reduce-scatter + sharded Adam + parameter all-gather per minibatch",
@@ -666,9 +695,10 @@ def main():
             out["collectives_per_rank"] = {"calls": dict(eng.coll.calls), "bytes": dict(eng.coll.bytes),
                                            "note": "totals over warm-up, timed and extra steps of this process"}
         if world == 1 and not args.no_probes:  # secondary probes and the host baseline belong to the single-GPU run (task contract: rank 0 at N=1 only)
-            # the same warm-up / step protocol on two more workloads, so that the driver's one default run carries them (never `value`)
-            if args.workload == "c3" and args.dropout == 0.0:
-                out["dropout_on"] = timed_pass(WORKLOADS["c3"], device, 0.1, args.warmup, args.steps, G)
+            # the same warm-up / step protocol on more workloads, so that the driver's one default run carries them (never `value`):
+            # the C3 step in the OTHER tracker mode (headline = Dropout(0.1) live, extra = eval-mode tracker, or the reverse) and C2
+            if args.workload == "c3" and not args.dropout_redraw:
+                out["dropout_off" if args.dropout > 0 else "dropout_on"] = timed_pass(WORKLOADS["c3"], device, 0.0 if args.dropout > 0 else 0.1, args.warmup, args.steps, G)
             if args.workload != "c2":
                 out["c2"] = timed_pass(WORKLOADS["c2"], device, args.dropout, args.warmup, args.steps, G)
             out["gather_fm"] = gather_fm_probe(device)
@@ -677,7 +707,25 @@ def main():
             out["c5_split"] = c5_split_probe(device)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl, eng)
-        print(json.dumps(out), flush=True)
+        # what else this run measured, in `config` (the driver's record keeps config / roofline / cpu_baseline whole and everything else by name only)
+        brief = lambda e: {k: e[k] for k in ("value", "ms_per_step", "mean_episode_len", "tracker_dropout", "envs", "minibatch_steps_per_update")}  # noqa: E731
+        also = {"rollout_only_env_steps_per_s": out["rollout_only_env_steps_per_s"], "rollout_only_ms_per_collect": out["rollout_only_ms_per_collect"],
+                "update_only_ms": out["update_only_ms"], "minibatch_step_us": 1e6 * t_mb, "minibatch_step_launches": out["minibatch_step"]["launches"],
+                "ppo_minibatch_steps_per_s": out["ppo_minibatch_steps_per_s"]}
+        for key in ("dropout_off", "dropout_on", "c2"):
+            if key in out:
+                also[key] = brief(out[key])
+        out["config"]["also_measured"] = also
+        # print order: the bulky probe objects first, the numbers a reader wants last (a log tail keeps the end of the line)
+        tail_keys = ("roofline", "minibatch_step", "head_paths", "dropout_off", "dropout_on", "c2", "rollout_only_env_steps_per_s", "rollout_only_ms_per_collect",
+                     "update_only_ms", "ppo_minibatch_steps_per_s")
+        bulky = ("cpu_baseline", "gather_fm", "deepfm_sweep", "sweep_mode", "c5_split", "hbm_traffic_per_launch")
+        ordered = {k: out[k] for k in bulky if k in out}
+        ordered.update({k: v for k, v in out.items() if k not in bulky and k not in tail_keys})
+        ordered.update({k: out[k] for k in tail_keys if k in out})
+        ordered["summary"] = {"value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"], "n_gpus": world,
+                              "mean_episode_len": out["config"]["mean_episode_len"], "tracker_dropout": args.dropout, **also}
+        print(json.dumps(ordered), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
