@@ -210,6 +210,15 @@ class HostPPOPolicy(nn.Module):
         head, hidden = self.actor(obs, state=state)
         return (self.dist_fn(*head) if isinstance(head, tuple) else self.dist_fn(head)), head, hidden
 
+    def _distribution_as_forward(self, obs):
+        """The action distribution of `obs`, leaving torch's generator where a whole forward() call leaves it.  forward() draws an action even
+        when only its distribution is wanted, and the reference's process_fn / learn go through forward (core/policy/ppo.py:107,183): a run that
+        seeds once must find the generator in the same place after an update, or every later collect samples other actions and other masks."""
+        dist = self._distribution(obs)[0]
+        if not (self._deterministic_eval and not self.training):
+            dist.sample()
+        return dist
+
     def forward(self, batch, buffer=None, remove_recommended_ids=False, state=None, **kwargs):
         assert not remove_recommended_ids, "id masking is a discrete-catalogue feature (KuaishouEnv)"
         dist, head, hidden = self._distribution(batch.obs, state)
@@ -269,7 +278,7 @@ class HostPPOPolicy(nn.Module):
         batch = self._returns_stage(batch, buffer, indice)
         batch.act = to_torch_as(batch.act, batch.v_s)      # stored actions as a tensor of the critic's dtype / device
         with torch.no_grad():                                # behaviour log-probabilities carry no graph
-            parts = [self._distribution(batch.obs[a:b])[0].log_prob(batch.act[a:b]) for a, b in row_ranges(len(batch), self.hyper.chunk)]
+            parts = [self._distribution_as_forward(batch.obs[a:b]).log_prob(batch.act[a:b]) for a, b in row_ranges(len(batch), self.hyper.chunk)]
         batch.logp_old = torch.cat(parts, dim=0)
         return batch
 
@@ -291,7 +300,7 @@ class HostPPOPolicy(nn.Module):
             order = np.random.permutation(n)
             for a, b in row_ranges(n, batch_size):
                 mb = batch[order[a:b]]
-                dist = self._distribution(mb.obs)[0]
+                dist = self._distribution_as_forward(mb.obs)
                 total, p_term, v_term, e_term = ppo_objective(dist.log_prob(mb.act), mb.logp_old, mb.adv, self.critic(mb.obs).flatten(),
                                                               mb.v_s, mb.returns, dist.entropy(), h)
                 opt_policy.zero_grad()
@@ -321,84 +330,110 @@ class HostPPOPolicy(nn.Module):
 # collector
 # ------------------------------------------------------------------------------------------------------------------------------
 class HostCollector:
+    """Per-step collector over host vector envs.  Public surface = what the trainer, test_episode and the scripts touch (call shapes of
+    core/collector.py:40-147): the constructor keywords, `collect(n_episode=)`, the three reset hooks, `buffer`, the three running counters.
+    Inside, the envs of one collect() call form a `_Cohort` (below); the collector itself only keeps the states the tracker produced at reset."""
+
     def __init__(self, policy, env, buffer: Optional[VectorReplayBuffer] = None, preprocess_fn: Optional[Callable[..., Any]] = None,
                  exploration_noise: bool = False, remove_recommended_ids=False, force_length=0):
-        self.policy, self.env, self.env_num = policy, env, len(env)
-        self.preprocess_fn, self.exploration_noise = preprocess_fn, exploration_noise
-        self.remove_recommended_ids, self.force_length = remove_recommended_ids, force_length
-        self._action_space = env.action_space
-        self.buffer = buffer if buffer is not None else VectorReplayBuffer(self.env_num, self.env_num)
-        assert self.buffer.buffer_num >= self.env_num
+        self.policy, self.env, self.preprocess_fn = policy, env, preprocess_fn
+        self.env_num = len(env)
+        self.options = dict(noise=bool(exploration_noise), mask_seen=remove_recommended_ids, horizon=int(force_length))
+        self.buffer = VectorReplayBuffer(self.env_num, self.env_num) if buffer is None else buffer
+        assert self.buffer.buffer_num >= self.env_num, "one sub-buffer per env"
         self.reset()
 
-    def reset(self):
-        self.data = Batch(obs=Batch(), act=Batch(), rew=Batch(), done=Batch(), obs_next=Batch(), info=Batch(), policy=Batch())
-        self.reset_env()
-        self.reset_buffer()
-        self.reset_stat()
+    # the reference's attribute names, for callers that read them back
+    exploration_noise = property(lambda self: self.options["noise"])
+    remove_recommended_ids = property(lambda self: self.options["mask_seen"])
+    force_length = property(lambda self: self.options["horizon"])
 
     def reset_stat(self):
-        self.collect_step, self.collect_episode, self.collect_time = 0, 0, 0.0
+        self.collect_step = self.collect_episode = 0
+        self.collect_time = 0.0
 
     def reset_buffer(self, keep_statistics=False):
-        self.buffer = VectorReplayBuffer(self.buffer.maxsize, self.buffer.buffer_num)      # a brand-new buffer per collect
+        self.buffer = type(self.buffer)(self.buffer.maxsize, self.buffer.buffer_num)      # every collect fills a brand-new buffer
 
     def reset_env(self):
-        if self.preprocess_fn:
-            self.preprocess_fn(dim_batch=self.env_num, reset=True)
-        obs = self.env.reset()
-        if self.preprocess_fn:
-            obs = self.preprocess_fn(obs=obs, env_id=np.arange(self.env_num)).get("obs", obs)
-        self.data.obs = obs
+        """Fresh episodes everywhere; with a tracker attached the stored observation is the tracker's state of the reset observation."""
+        track = self.preprocess_fn
+        if track:
+            track(dim_batch=self.env_num, reset=True)
+        first = self.env.reset()
+        if track:
+            first = track(obs=first, env_id=np.arange(self.env_num)).get("obs", first)
+        self.front = first
+
+    def reset(self):
+        for hook in (self.reset_env, self.reset_buffer, self.reset_stat):
+            hook()
 
     def collect(self, n_step=None, n_episode=None, random=False, render=None, no_grad=True) -> Dict[str, Any]:
         assert n_step is None and n_episode is not None and n_episode > 0, "the CIRS scripts collect whole episodes (n_episode)"
-        ready = np.arange(min(self.env_num, n_episode))
-        self.reset()       # fresh observations from the updated parameters (core/collector.py:200)
-        self.data = self.data[:min(self.env_num, n_episode)] if len(ready) < self.env_num else self.data
-        start = time.time()
-        step_count, episode_count, cnt_loop = 0, 0, 0
-        ep_rews, ep_lens, ep_idxs = [], [], []
-        while True:
-            assert len(self.data) == len(ready)
-            if random:
-                self.data.update(act=np.stack([self._action_space[i].sample() for i in ready]))
-            else:
-                if no_grad:
-                    with torch.no_grad():
-                        result = self.policy(self.data, self.buffer, state=None, remove_recommended_ids=self.remove_recommended_ids)
-                else:
-                    result = self.policy(self.data, self.buffer, state=None, remove_recommended_ids=self.remove_recommended_ids)
-                act = to_numpy(result.act)
-                if self.exploration_noise:
-                    act = self.policy.exploration_noise(act, self.data)
-                self.data.update(policy=result.get("policy", Batch()) or Batch(), act=act)
-            obs_next, rew, done, info = self.env.step(self.policy.map_action(self.data.act), ready)
-            cnt_loop += 1
-            if self.force_length > 0:
-                done = np.full_like(done, cnt_loop >= self.force_length, dtype=bool)
-            self.data.update(obs_next=obs_next, rew=rew, done=done, info=info)
-            if self.preprocess_fn:
-                self.data.update(self.preprocess_fn(obs_next=self.data.obs_next, rew=self.data.rew, done=self.data.done,
-                                                    info=self.data.info, policy=self.data.policy, env_id=ready))
-            ptr, e_rew, e_len, e_idx = self.buffer.add(self.data, buffer_ids=ready)
-            step_count += len(ready)
-            if np.any(done):
-                fin = np.where(done)[0]
-                episode_count += len(fin)
-                ep_lens.append(e_len[fin]); ep_rews.append(e_rew[fin]); ep_idxs.append(e_idx[fin])
-                surplus = len(ready) - (n_episode - episode_count)      # finished envs leave the ready set (they are not reset)
-                if surplus > 0:
-                    mask = np.ones_like(ready, dtype=bool)
-                    mask[fin[:surplus]] = False
-                    ready = ready[mask]
-                    self.data = self.data[mask]
-            self.data.obs = self.data.obs_next
-            if episode_count >= n_episode:
-                break
-        self.collect_step += step_count
-        self.collect_episode += episode_count
-        self.collect_time += max(time.time() - start, 1e-9)
-        rews, lens, idxs = np.concatenate(ep_rews), np.concatenate(ep_lens), np.concatenate(ep_idxs)
-        return {"n/ep": episode_count, "n/st": step_count, "rews": rews, "lens": lens, "idxs": idxs, "rew": rews.mean(), "len": lens.mean(),
-                "rew_std": rews.std(), "len_std": lens.std()}
+        self.reset()       # states rebuilt by the tracker from the updated parameters (core/collector.py:200)
+        cohort = _Cohort(self, n_episode)
+        clock = time.time()
+        while cohort.episodes < n_episode:
+            actions, extra = cohort.decide(random, no_grad)
+            cohort.advance(actions, extra)
+        elapsed = max(time.time() - clock, 1e-9)
+        self.front = cohort.obs
+        self.collect_time += elapsed
+        self.collect_step += cohort.transitions
+        self.collect_episode += cohort.episodes
+        return cohort.summary()
+
+
+class _Cohort:
+    """The envs still playing inside one HostCollector.collect() call.  Plain arrays per field (ids, current states); a Batch is only assembled
+    where a protocol asks for one (the policy call, ReplayBuffer.add).  Finished envs are never reset: they leave once the episode quota is
+    covered by the envs that remain."""
+
+    def __init__(self, host: HostCollector, quota: int):
+        n = min(host.env_num, quota)
+        self.host, self.quota = host, quota
+        self.ids, self.obs = np.arange(n), host.front[:n]
+        self.turn = self.transitions = self.episodes = 0
+        self.closed: List[tuple] = []      # (returns, lengths, first buffer rows) of the episodes each vector step closed, in completion order
+
+    def decide(self, random: bool, no_grad: bool):
+        """-> (raw actions [n, ...] as numpy, the policy's own per-step record or an empty Batch)."""
+        host = self.host
+        if random:
+            return np.stack([host.env.action_space[i].sample() for i in self.ids]), Batch()
+        view = Batch(obs=self.obs, info=Batch())
+        with torch.set_grad_enabled(not no_grad):
+            out = host.policy(view, host.buffer, state=None, remove_recommended_ids=host.options["mask_seen"])
+        raw = to_numpy(out.act)
+        if host.options["noise"]:
+            raw = host.policy.exploration_noise(raw, view)
+        return raw, (out.get("policy", Batch()) or Batch())
+
+    def advance(self, raw, extra):
+        host = self.host
+        nxt, rew, done, info = host.env.step(host.policy.map_action(raw), self.ids)
+        self.turn += 1
+        if host.options["horizon"] > 0:      # fixed-horizon evaluation: the env's own exit decision is overridden
+            done = np.full(len(self.ids), self.turn >= host.options["horizon"])
+        row = dict(obs=self.obs, act=raw, rew=rew, done=done, obs_next=nxt, info=info, policy=extra)
+        if host.preprocess_fn:               # the tracker turns (next observation, reward) into the next state
+            row.update(host.preprocess_fn(env_id=self.ids, **{k: row[k] for k in ("obs_next", "rew", "done", "info", "policy")}))
+        _, ep_return, ep_length, ep_first = host.buffer.add(Batch(**row), buffer_ids=self.ids)
+        self.transitions += len(self.ids)
+        self.obs = row["obs_next"]
+        over = np.flatnonzero(np.asarray(row["done"], dtype=bool))
+        if len(over):
+            self.episodes += len(over)
+            self.closed.append((ep_return[over], ep_length[over], ep_first[over]))
+            surplus = len(self.ids) - max(self.quota - self.episodes, 0)
+            if surplus > 0:
+                keep = np.setdiff1d(np.arange(len(self.ids)), over[:surplus])
+                self.ids, self.obs = self.ids[keep], self.obs[keep]
+
+    def summary(self) -> Dict[str, Any]:
+        returns, lengths, firsts = (np.concatenate(col) for col in zip(*self.closed))
+        stats = {"rews": returns, "lens": lengths, "idxs": firsts, "n/st": self.transitions, "n/ep": self.episodes}
+        for name, arr in (("rew", returns), ("len", lengths)):
+            stats[name], stats[name + "_std"] = arr.mean(), arr.std()
+        return stats

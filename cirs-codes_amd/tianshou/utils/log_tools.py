@@ -1,108 +1,78 @@
-"""BaseLogger / BasicLogger (reference tianshou/tianshou/utils/log_tools.py:11-189): the trainer's logging protocol
-(core/trainer/onpolicy.py: log_train_data / log_test_data / log_update_data / save_data / restore_data).
-
-`write` goes to the writer's add_scalar(key, y, global_step=x) -- a real torch.utils.tensorboard.SummaryWriter or the stand-in of
-cirs_hip.compat.  restore_data reads the last "save/*" steps back: from the tensorboard event files when the tensorboard package is
-there, from the stand-in writer's own record otherwise."""
-from abc import ABC, abstractmethod
-from typing import Any, Callable, Optional, Tuple
+"""The logging protocol of the trainer (`log_train_data`, `log_test_data`, `log_update_data`, `save_data`, `restore_data`; contract: reference
+tianshou/tianshou/utils/log_tools.py:84-189) over any writer with `add_scalar(tag, value, global_step=)`.  Written for this repository: one
+`_Every` gate per channel decides whether a step is due; resuming reads the three "save/*" tags back from the writer."""
+from typing import Callable, Optional, Tuple
 
 
-class BaseLogger(ABC):
-    def __init__(self, writer: Any) -> None:
-        super().__init__()
+class _Every:
+    """Lets a step through when at least `gap` steps passed since the last one it let through."""
+
+    def __init__(self, gap: int):
+        self.gap, self.last = gap, -1
+
+    def due(self, step: int) -> bool:
+        if step - self.last < self.gap:
+            return False
+        self.last = step
+        return True
+
+
+class BaseLogger:
+    def __init__(self, writer):
         self.writer = writer
 
-    @abstractmethod
-    def write(self, key: str, x: int, y, **kwargs: Any) -> None:
-        pass
-
-    def log_train_data(self, collect_result: dict, step: int) -> None:
-        pass
-
-    def log_update_data(self, update_result: dict, step: int) -> None:
-        pass
-
-    def log_test_data(self, collect_result: dict, step: int) -> None:
-        pass
-
-    def save_data(self, epoch: int, env_step: int, gradient_step: int,
-                  save_checkpoint_fn: Optional[Callable[[int, int, int], None]] = None) -> None:
-        pass
-
-    def restore_data(self) -> Tuple[int, int, int]:
-        pass
+    def write(self, key: str, x: int, y, **kwargs) -> None:
+        self.writer.add_scalar(key, y, global_step=x)
 
 
 class BasicLogger(BaseLogger):
-    def __init__(self, writer, train_interval: int = 1000, test_interval: int = 1, update_interval: int = 1000,
-                 save_interval: int = 1) -> None:
+    def __init__(self, writer, train_interval: int = 1000, test_interval: int = 1, update_interval: int = 1000, save_interval: int = 1):
         super().__init__(writer)
-        self.train_interval, self.test_interval = train_interval, test_interval
-        self.update_interval, self.save_interval = update_interval, save_interval
-        self.last_log_train_step = self.last_log_test_step = self.last_log_update_step = self.last_save_step = -1
+        self.gate = {"train": _Every(train_interval), "test": _Every(test_interval), "update": _Every(update_interval), "save": _Every(save_interval)}
 
-    def write(self, key: str, x: int, y, **kwargs: Any) -> None:
-        self.writer.add_scalar(key, y, global_step=x)
+    def _emit(self, channel: str, step: int, scalars: dict, prefix: str = ""):
+        if self.gate[channel].due(step):
+            for tag, value in scalars.items():
+                self.write(prefix + tag, step, value)
 
     def log_train_data(self, collect_result: dict, step: int) -> None:
-        """`collect_result` gains "rew" / "len" in place (log_tools.py:124-141)."""
-        if collect_result["n/ep"] > 0:
-            collect_result["rew"] = collect_result["rews"].mean()
-            collect_result["len"] = collect_result["lens"].mean()
-            if step - self.last_log_train_step >= self.train_interval:
-                for key in ("n/ep", "rew", "len"):
-                    self.write("train/" + key, step, collect_result[key])
-                self.last_log_train_step = step
+        if collect_result["n/ep"] > 0:       # the caller reads "rew" / "len" back from its own dict
+            collect_result.update(rew=collect_result["rews"].mean(), len=collect_result["lens"].mean())
+            self._emit("train", step, {k: collect_result[k] for k in ("n/ep", "rew", "len")}, "train/")
 
     def log_test_data(self, collect_result: dict, step: int) -> None:
-        """`collect_result` gains "rew", "rew_std", "len", "len_std" in place (log_tools.py:143-164)."""
         assert collect_result["n/ep"] > 0
-        rews, lens = collect_result["rews"], collect_result["lens"]
-        stats = dict(rew=rews.mean(), rew_std=rews.std(), len=lens.mean(), len_std=lens.std())
-        collect_result.update(stats)
-        if step - self.last_log_test_step >= self.test_interval:
-            for key in ("rew", "len", "rew_std", "len_std"):
-                self.write("test/" + key, step, stats[key])
-            self.last_log_test_step = step
+        spread = {name: fn(collect_result[src]) for name, src, fn in (("rew", "rews", lambda a: a.mean()), ("len", "lens", lambda a: a.mean()),
+                                                                      ("rew_std", "rews", lambda a: a.std()), ("len_std", "lens", lambda a: a.std()))}
+        collect_result.update(spread)
+        self._emit("test", step, spread, "test/")
 
     def log_update_data(self, update_result: dict, step: int) -> None:
-        if step - self.last_log_update_step >= self.update_interval:
-            for k, v in update_result.items():
-                self.write(k, step, v)
-            self.last_log_update_step = step
+        self._emit("update", step, update_result)
 
-    def save_data(self, epoch: int, env_step: int, gradient_step: int,
-                  save_checkpoint_fn: Optional[Callable[[int, int, int], None]] = None) -> None:
-        if save_checkpoint_fn and epoch - self.last_save_step >= self.save_interval:
-            self.last_save_step = epoch
+    def save_data(self, epoch: int, env_step: int, gradient_step: int, save_checkpoint_fn: Optional[Callable[[int, int, int], None]] = None) -> None:
+        if save_checkpoint_fn and self.gate["save"].due(epoch):
             save_checkpoint_fn(epoch, env_step, gradient_step)
-            self.write("save/epoch", epoch, epoch)
-            self.write("save/env_step", env_step, env_step)
-            self.write("save/gradient_step", gradient_step, gradient_step)
+            for tag, n in (("save/epoch", epoch), ("save/env_step", env_step), ("save/gradient_step", gradient_step)):
+                self.write(tag, n, n)
 
-    def _last_step(self, tag):
-        if hasattr(self.writer, "scalars"):          # stand-in writer (cirs_hip.compat.SummaryWriter)
-            items = self.writer.scalars(tag)
-            if not items:
-                raise KeyError(tag)
-            return items[-1][0]
+    def _recorded(self, tag: str) -> Optional[int]:
+        """Step of the last scalar written under `tag`, or None."""
+        if hasattr(self.writer, "scalars"):          # the stand-in writer (cirs_hip.compat.SummaryWriter) keeps its own record
+            rows = self.writer.scalars(tag)
+            return rows[-1][0] if rows else None
         from tensorboard.backend.event_processing import event_accumulator
-        ea = event_accumulator.EventAccumulator(self.writer.log_dir)
-        ea.Reload()
-        return ea.scalars.Items(tag)[-1].step
+        acc = event_accumulator.EventAccumulator(self.writer.log_dir)
+        acc.Reload()
+        return acc.scalars.Items(tag)[-1].step if tag in acc.Tags().get("scalars", ()) else None
 
     def restore_data(self) -> Tuple[int, int, int]:
-        try:
-            epoch = self._last_step("save/epoch")
-            self.last_save_step = self.last_log_test_step = epoch
-            gradient_step = self._last_step("save/gradient_step")
-            self.last_log_update_step = gradient_step
-        except KeyError:
-            epoch, gradient_step = 0, 0
-        try:
-            env_step = self._last_step("save/env_step")
-            self.last_log_train_step = env_step
-        except KeyError:
-            env_step = 0
-        return epoch, env_step, gradient_step
+        epoch, env_step, gradient_step = (self._recorded("save/" + t) for t in ("epoch", "env_step", "gradient_step"))
+        if epoch is None or gradient_step is None:
+            epoch = gradient_step = 0
+        else:
+            self.gate["save"].last = self.gate["test"].last = epoch
+            self.gate["update"].last = gradient_step
+        if env_step is not None:
+            self.gate["train"].last = env_step
+        return epoch, env_step or 0, gradient_step

@@ -1146,6 +1146,9 @@ def gen_c1rl():
         out.update({f"r{rnd}_loss_" + k.replace("/", "_"): np.array(v) for k, v in losses.items()})
         out[f"r{rnd}_ret_rms"] = np.array([policy.ret_rms.mean, policy.ret_rms.var, policy.ret_rms.count], np.float64)
         snap(f"r{rnd}")
+        # where the update left torch's generator (process_fn / learn go through forward(), which samples: ppo.py:107,183); the next
+        # round reseeds, so this probe draw changes nothing downstream
+        out[f"r{rnd}_rng_probe"] = torch.rand(4).numpy()
     np.savez_compressed(os.path.join(GOLDEN, "c1rl.npz"), **out)
     print("c1rl.npz: n/st", out["r0_res_n"], out["r1_res_n"], "losses", np.round(out["r0_loss_loss"][:4], 5), "lens", out["r0_res_lens"], out["r1_res_lens"],
           "act[0,:3]", out["r0_act"][0, :3])

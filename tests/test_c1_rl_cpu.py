@@ -89,6 +89,9 @@ def test_c1_rl_loop_reproduces_the_reference(golden_dir):
         for k, v in losses.items():
             np.testing.assert_allclose(np.array(v), z[f"r{rnd}_loss_" + k.replace("/", "_")], rtol=2e-4, atol=2e-5, err_msg=k)
         np.testing.assert_allclose([policy.ret_rms.mean, policy.ret_rms.var, policy.ret_rms.count], z[f"r{rnd}_ret_rms"], rtol=1e-5)
+        # the update leaves torch's generator where the reference's leaves it (its process_fn / learn sample through forward()): a run that
+        # seeds ONCE keeps drawing the reference's actions and dropout masks in every later collect
+        np.testing.assert_array_equal(torch.rand(4).numpy(), z[f"r{rnd}_rng_probe"])
         for mod, tag in ((actor, "actor"), (critic, "critic"), (tracker, "tracker")):
             for k, v in mod.state_dict().items():
                 got, want = v.detach().numpy(), z[f"r{rnd}_{tag}_{k}"]

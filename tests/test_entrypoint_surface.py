@@ -104,9 +104,9 @@ def test_basic_logger_protocol(tmp_path):
     lg = BasicLogger(w, train_interval=10, update_interval=5, save_interval=2)
     res = {"n/ep": 2, "rews": np.array([1.0, 3.0]), "lens": np.array([4, 6])}
     lg.log_train_data(res, 12)
-    assert res["rew"] == 2.0 and res["len"] == 5.0 and lg.last_log_train_step == 12
+    assert res["rew"] == 2.0 and res["len"] == 5.0 and lg.gate["train"].last == 12
     lg.log_train_data(dict(res), 15)
-    assert lg.last_log_train_step == 12           # inside the interval: not written
+    assert lg.gate["train"].last == 12           # inside the interval: not written
     t = {"n/ep": 2, "rews": np.array([1.0, 3.0]), "lens": np.array([4, 6])}
     lg.log_test_data(t, 1)
     assert t["rew_std"] == 1.0 and t["len_std"] == 1.0
