@@ -69,7 +69,8 @@ def test_engine_dp_update_with_virtual_ranks(monkeypatch, W, B, I, U, T, bs, mod
 @pytest.mark.parametrize("mode", ["replicated", "dp"])
 def test_engine_c4_size_update_with_8_virtual_ranks(monkeypatch, mode):
     """BASELINE configs[3] at its own size: 8 ranks x 1024 envs on the 7176 x 10728 tables, one update of the gathered
-    buffer (8192 episodes, ~245 k rows, ~480 optimiser steps of 1024 rows).  Ranks bit-identical; `replicated` = the single-device update of the
+    buffer (8192 episodes; a fresh policy plays ~12-turn episodes: ~100 k rows, ~190 optimiser steps of 1024 rows; 245 k rows / ~480 steps once
+    episodes run to max_turn).  Ranks bit-identical; `replicated` = the single-device update of the
     gathered buffer; `dp` tracks it for as long as two fp32 evaluations of this update can (~19 free-running steps), then
     stays on the same trajectory statistically."""
     _virtual_rank_update(monkeypatch, 8, 1024, 10728, 7176, 30, 1024, mode, c4=True)
@@ -150,7 +151,7 @@ def _virtual_rank_update(monkeypatch, W, B, I, U, T, bs, mode, c4=False):
     ref_losses, ref_n = ref.update(bs, 2, perms=perms)
     assert ref_n == n_total
     if c4:
-        assert n_total > 150000 and n_mb >= 2 * (n_total // bs)      # the C4 buffer: 8192 episodes, hundreds of optimiser steps per update
+        assert n_total >= 8 * 8192 and n_mb >= 2 * (n_total // bs)      # the C4 buffer: 8192 episodes, >= 128 optimiser steps per update
         got_l, want_l = results[0][0].cpu().numpy(), ref_losses.cpu().numpy()
         got_p, want_p = engines[0].policy_flat.cpu().numpy(), ref.policy_flat.cpu().numpy()
         np.testing.assert_allclose(got_l[:16], want_l[:16], rtol=3e-4, atol=3e-5)       # free-running, while it means something
