@@ -34,10 +34,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-MINIBATCH_KERNELS = ("trunk_adv_kernel", "head_stats_kernel", "head_bwd_fused_kernel", "dh2_sum_kernel",
-                     "trunk_bwd_kernel", "sumsq_partial_kernel", "adam2_kernel")     # the 7 launches of a minibatch step (fused head path)
-MINIBATCH_KERNELS_SPLIT = ("trunk_adv_kernel", "head_fwd_kernel", "head_dwa_kernel", "trunk_bwd_kernel", "sumsq_partial_kernel",
-                           "adam2_kernel")                                           # the 6 launches with CIRS_PPO_HEAD=split
+MINIBATCH_KERNELS = ("head_stats_kernel", "head_bwd_fused_kernel", "trunk_rows_kernel", "adam_next_kernel")
+# the 4 launches of a minibatch step inside cirs_ppo_learn's loop (round 5; rounds 3-4: 7).  The head of step k + 1 -- trunk forward, advantage
+# statistics, Wa planes -- runs in step k's optimiser launch; the chunk-slab sums of d h2, the trunk backward, the weight-gradient sums and the
+# squared-norm partials are one launch; trunk_adv_kernel runs once per update
 
 
 def kernel_source_hash():
@@ -127,8 +127,8 @@ def timed_pass(wl, device, dropout, warmup, steps, batch=1024):
 
 
 def hip_event_kernel_time(eng, wl, reps=100):
-    """HIP-event timing on the launch stream, PPO minibatch step of mb rows launched exactly as inside the timed region:
-    -> (seconds per whole cirs_ppo_minibatch call, mb, {kernel name: average seconds per launch}) where the per-kernel numbers
+    """HIP-event timing on the launch stream, PPO minibatch steps of mb rows launched exactly as inside the timed region (cirs_ppo_learn's loop):
+    -> (seconds per minibatch step, mb, {kernel name: average seconds per launch}) where the per-kernel numbers
     come from event pairs the library records around each launch of that kernel (cirs_prof_start / cirs_prof_stop): the same
     quantity as the kernel's average duration in the rocprofv3 --kernel-trace --stats summary under profiles/."""
     from cirs_hip import abi
@@ -139,18 +139,21 @@ def hip_event_kernel_time(eng, wl, reps=100):
         ln.prepare(traj, lens, lens_dev=lens_d)
     n = ln.n_rows
     mb = min(1024, n)
-    ws = ln.workspace(mb)
-    idx = torch.arange(mb, dtype=torch.int32, device=eng.device)
-    losses = torch.zeros(4, dtype=torch.float32, device=eng.device)
+    n_use = n // mb * mb                    # whole minibatches of mb rows: every step of the probe is a step of the timed region's size
+    spc = n_use // mb                       # steps per cirs_ppo_learn call
+    ws = ln.workspace(2 * mb)
+    perm = torch.arange(n_use, dtype=torch.int32, device=eng.device)
+    losses = torch.zeros((spc, 4), dtype=torch.float32, device=eng.device)
     # snapshot optimiser state so the probe does not advance training
     snap = [t.clone() for t in (ln.params, ln.adam_m, ln.adam_v)]
     lib = ln._lib
+    reps = max(1, reps // spc)              # calls; reps * spc steps
 
     def run(k):
         for _ in range(k):
-            abi.check(lib.cirs_ppo_minibatch(C.byref(ln.cfg), ln.params.data_ptr(), ln.grads.data_ptr(), ln.adam_m.data_ptr(),
-                                             ln.adam_v.data_ptr(), ln.opt_step, C.byref(ln.batch), idx.data_ptr(), mb, None,
-                                             ln.n_env, losses.data_ptr(), ws.data_ptr(), ws.numel(), ln._stream()), "probe")
+            abi.check(lib.cirs_ppo_learn(C.byref(ln.cfg), ln.params.data_ptr(), ln.grads.data_ptr(), ln.adam_m.data_ptr(), ln.adam_v.data_ptr(),
+                                         ln.opt_step, C.byref(ln.batch), perm.data_ptr(), n_use, mb, 1, None, 0, ln.n_env, losses.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), ln._stream()), "probe")
 
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     run(3)
@@ -159,12 +162,11 @@ def hip_event_kernel_time(eng, wl, reps=100):
     run(reps)
     stop.record()
     torch.cuda.synchronize()
-    t_step = start.elapsed_time(stop) / reps * 1e-3
+    t_step = start.elapsed_time(stop) / (reps * spc) * 1e-3
     per_kernel = {}
-    split = os.environ.get("CIRS_PPO_HEAD", "fused").startswith("s")
-    for kid, name in ((1, "head_dwa_kernel" if split else "head_bwd_fused_kernel"), (2, "head_fwd_kernel" if split else "head_stats_kernel")):
-        run(10)    # the event pairs are taken in steady state, like the kernel's average in a rocprofv3 trace of the timed loop
-        abi.check(lib.cirs_prof_start(kid, reps), "cirs_prof_start")
+    for kid, name in ((1, "head_bwd_fused_kernel"), (2, "head_stats_kernel")):
+        run(1)    # the event pairs are taken in steady state, like the kernel's average in a rocprofv3 trace of the timed loop
+        abi.check(lib.cirs_prof_start(kid, reps * spc), "cirs_prof_start")
         run(reps)
         tot, cnt = C.c_double(0.0), C.c_int32(0)
         abi.check(lib.cirs_prof_stop(C.byref(tot), C.byref(cnt)), "cirs_prof_stop")
@@ -607,24 +609,7 @@ def main():
     l2, n2 = eng.update(G, 2); torch.cuda.synchronize(); tc = time.perf_counter()
 
     if rank == 0:
-        head_mode = "split" if os.environ.get("CIRS_PPO_HEAD", "fused").startswith("s") else "fused"      # the path the timed region ran
         t_mb, mb, t_k = hip_event_kernel_time(eng, wl)
-        # both actor-head paths of the minibatch step on this box, same state (csrc/ppo.hip CIRS_PPO_HEAD; the default is the faster one)
-        head_paths = {}
-        for hm in ("fused", "split"):
-            if hm == head_mode:
-                tm_, tk_ = t_mb, t_k
-            else:
-                prev = os.environ.get("CIRS_PPO_HEAD")
-                os.environ["CIRS_PPO_HEAD"] = hm
-                tm_, _, tk_ = hip_event_kernel_time(eng, wl, reps=50)
-                if prev is None:
-                    os.environ.pop("CIRS_PPO_HEAD")
-                else:
-                    os.environ["CIRS_PPO_HEAD"] = prev
-            head_paths[hm] = {"minibatch_step_seconds": tm_, "launches": 7 if hm == "fused" else 6, "kernel_seconds": tk_}
-        if head_mode == "split":      # same keys downstream: the backward-side kernel / the forward-side kernel of the path
-            t_k = {"head_bwd_fused_kernel": t_k["head_dwa_kernel"], "head_stats_kernel": t_k["head_fwd_kernel"]}
         I = wl["I"]
         S, H = 20, 64
         # Dominant kernel of the timed step (profiles/*_kernel_stats.csv): head_bwd_fused_kernel, the fused actor-head backward
@@ -634,7 +619,7 @@ def main():
         t_bwd = t_k["head_bwd_fused_kernel"]
         flop_bwd = 4.0 * mb * I * H
         exec_bwd = 6.0 * mb * I * H
-        # whole minibatch step (7 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
+        # whole minibatch step (4 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
         flop_step = 6.0 * mb * (S * H + H * H + H * I)
         exec_step = 8.0 * mb * I * H + 6.0 * mb * (S * H + H * H)
         out = {
@@ -672,15 +657,11 @@ def main():
                          "kernel_note": "since round 3 the kernel's prologue also merges the head-statistics partials of its rows and forms their loss terms / backward coefficients (~2.5 us that replace a 6.5 us launch): its duration includes that work, the algorithmic flop count does not",
                          "peak_note": "fp32 MFMA dense peak: the kernel's results are fp32-accurate (DESIGN.md section 4); its 6x expanded bf16 flops are exec_bf16_flop_per_launch",
                          "exec_bf16_flop_per_launch": 6.0 * exec_bwd},
-            "head_paths": {"default": head_mode, **head_paths,
-                           "note": "fused = head_stats_kernel + head_bwd_fused_kernel + dh2_sum_kernel (8 dWa row-block slabs + 31 dH2 chunk slabs per step); "
-                                   "split = head_fwd_kernel (statistics + O' = P Wa, row stage in its last workgroup) + head_dwa_kernel (dWa with the item tile "
-                                   "stationary, 3 slabs): see DESIGN.md section 8 for the traffic / time trade measured this round"},
-            "minibatch_step": {"seconds": t_mb, "launches": 7 if head_mode == "fused" else 6, "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
+            "minibatch_step": {"seconds": t_mb, "launches": len(MINIBATCH_KERNELS), "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
                                "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "traffic": None,
                                "head_stats_kernel_seconds": t_k["head_stats_kernel"],
-                               "note": "one whole cirs_ppo_minibatch call: head_stats_kernel + head_bwd_fused_kernel (whose prologue also merges the statistics partials and forms the row loss terms: a launch of its own until round 3) + 5 small kernels"},
+                               "note": "one step of cirs_ppo_learn's loop: head_stats_kernel + head_bwd_fused_kernel (whose prologue also merges the statistics partials and forms the row loss terms) + trunk_rows_kernel (chunk-slab sums of d h2, trunk backward, dWa slab sums, trunk-gradient sums, squared-norm partials) + adam_next_kernel (Adam + the trunk forward / advantage statistics / Wa planes of the NEXT step)"},
         }
         # HBM traffic per launch from the committed PMC passes -- only when they were taken on exactly these kernel sources
         traffic, src = pmc_traffic(args.workload)
@@ -717,7 +698,7 @@ def main():
                 also[key] = brief(out[key])
         out["config"]["also_measured"] = also
         # print order: the bulky probe objects first, the numbers a reader wants last (a log tail keeps the end of the line)
-        tail_keys = ("roofline", "minibatch_step", "head_paths", "dropout_off", "dropout_on", "c2", "rollout_only_env_steps_per_s", "rollout_only_ms_per_collect",
+        tail_keys = ("roofline", "minibatch_step", "dropout_off", "dropout_on", "c2", "rollout_only_env_steps_per_s", "rollout_only_ms_per_collect",
                      "update_only_ms", "ppo_minibatch_steps_per_s")
         bulky = ("cpu_baseline", "gather_fm", "deepfm_sweep", "sweep_mode", "c5_split", "hbm_traffic_per_launch")
         ordered = {k: out[k] for k in bulky if k in out}

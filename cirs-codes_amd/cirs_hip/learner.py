@@ -336,11 +336,12 @@ class DeviceLearner:
                 k += 1
         return losses
 
-    def learn(self, batch_size, repeat, perms: Optional[List[np.ndarray]] = None, want_tracker_grad=True, recompute_adv=False):
+    def learn(self, batch_size, repeat, perms: Optional[List[np.ndarray]] = None, want_tracker_grad=True, recompute_adv=False, step_calls=False):
         """learn(): `repeat` passes of shuffled minibatches.  Returns loss arrays + leaves d loss / d obs of the LAST
         repeat in self.dobs ([T+1, B, S]) for the tracker backward.  perms: recorded permutations (parity tests);
         default: draws of the seeded device generator (_perms_on_device).  recompute_adv: before every repeat but the first the
-        stored states are valued again with the current critic and process_fn's return computation is redone (ppo.py:176-177)."""
+        stored states are valued again with the current critic and process_fn's return computation is redone (ppo.py:176-177).
+        step_calls: one cirs_ppo_minibatch call per step from this loop (what recompute_adv needs; also the tests' reference for cirs_ppo_learn)."""
         n = self.n_rows
         slices = minibatch_slices(n, batch_size)
         max_mb = max(e - s for s, e in slices)
@@ -350,6 +351,15 @@ class DeviceLearner:
         # all permutations of this update at once, before the first minibatch: the launches of the following repeats then
         # queue back to back
         perm_all_d = self._perms_on_device(n, repeat, perms)
+        if not recompute_adv and not step_calls:
+            # the whole loop from one call (cirs_ppo_learn: the same step kernels; the optimiser launch of a step also runs the head of the next)
+            assert int(self._lib.cirs_ppo_learn_steps(n, batch_size, repeat)) == n_steps
+            abi.check(self._lib.cirs_ppo_learn(
+                C.byref(self.cfg), self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.opt_step,
+                C.byref(self.batch), perm_all_d.data_ptr(), n, batch_size, repeat, self.dobs.data_ptr() if want_tracker_grad else None,
+                self.dobs.numel(), self.n_env, losses.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()), "cirs_ppo_learn")
+            self.opt_step += n_steps
+            return losses
         k = 0
         for rep in range(repeat):
             perm_d = perm_all_d[rep]

@@ -25,18 +25,12 @@ namespace cirs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: a float4 struct array goes through memcpy / scratch
 
 
-constexpr bool kHeadSplitDefault = false;   // see CIRS_PPO_HEAD in ppo_minibatch_impl
 constexpr int kBwdWaves = 4;  // row tiles per workgroup of the fused head backward kernel (= rows/32 per dWa slab)
 __host__ __device__ inline int n_row_blocks_of(int n_pad) { return (n_pad / kTileM + kBwdWaves - 1) / kBwdWaves; }
 // floats between consecutive dWa|dba partial slabs (16 B aligned for the float4 stores)
 __host__ __device__ inline size_t dwa_slab_stride(int I) { return (((size_t)I * 64 + I) + 3) & ~(size_t)3; }
-// dWa slabs the workspace holds: one per row block of the fused backward kernel, or one per row range of head_dwa_kernel (<= 8)
-__host__ __device__ inline int n_dwa_slabs_of(int n_pad) {
-    const int a = n_row_blocks_of(n_pad), b = n_pad / kTileM < 8 ? n_pad / kTileM : 8;
-    return a > b ? a : b;
-}
-// workgroups of head_dwa_kernel at most: groups of 4 item tiles x 8 row ranges
-__host__ __device__ inline int n_entw_max_of(int I) { return ((I + kTileN - 1) / kTileN + 3) / 4 * 8; }
+// dWa slabs the workspace holds: one per row block of the fused backward kernel
+__host__ __device__ inline int n_dwa_slabs_of(int n_pad) { return n_row_blocks_of(n_pad); }
 
 struct PpoLayout {  // offsets (floats) into the flat parameter buffer
     long w1, b1, w2, b2, wa, ba, wc, bc, total, trunk;
@@ -218,13 +212,19 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     uint4 *wa_planes;                         // bf16 planes of Wa per item tile (wa_planes_kernel)
     uint4 *h2z, *h2b;                         // bf16 planes of H2 in the head kernels' register order (written by trunk_adv_kernel):
                                               // [32-row tile][12][lane] uint4, unit q of a lane = its q-th operand register quad
-    float *row_m;                             // split head path: the rows' reference maxima (row stage of head_fwd_kernel -> d h2 fold)
-    int *arrive;                              // split head path: arrival counters of head_fwd_kernel's row blocks (zeroed by trunk_adv_kernel)
-    float *entw;                              // split head path: the entropy's clamp correction, one scalar per head_dwa_kernel workgroup
-    int n_entw;                               // (0 on the round-3 path: the correction is in ent_row)
+    int *sync;                                // [4] arrival counter of trunk_bwd_kernel's row workgroups (zeroed by dh2_sum_kernel)
+    float *snap;                              // [2][3][snap_stride]: p | m | v of [trunk | wc | bc] as of before optimiser step k in buffer k & 1 (written by
+                                              // trunk_adv_kernel for a call's first step, by the A workgroups of adam_next_kernel for the step after theirs):
+                                              // what the T workgroups of step k's optimiser launch read while its A workgroups overwrite the live values
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
 };
 
+__host__ __device__ inline int snap_floats(int S) { return kH * (S + 66) + kH + 1; }      // trunk (w1 | b1 | w2 | b2) + wc | bc
+__host__ __device__ inline int snap_stride(int S) { return (snap_floats(S) + 3) & ~3; }       // (16-byte aligned arrays)
+__host__ inline size_t dwp_floats(int n_pad, int S) {
+    const size_t a = (size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64, b = (size_t)(n_pad / 8) * snap_stride(S) + 64;
+    return a > b ? a : b;
+}
 __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     const size_t nch = n_chunks_of(I);
     size_t f = 0;
@@ -237,10 +237,9 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 2 * (size_t)n_pad * kH;                       // da2, da1
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I);     // dwap
-    f += (size_t)n_entw_max_of(I) + 4;                           // entw
-    f += (size_t)n_pad + 4 + 1024;                               // row_m, arrive
+    f += 4 + 6 * (size_t)snap_stride(S) + 4;                     // sync, snap
     f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
-    f += (size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64;  // dW row slabs (one per 32 rows)
+    f += dwp_floats(n_pad, S);                         // dW row slabs (one per 32 rows: trunk_bwd_kernel; one per 8 rows in flat order: trunk_rows_kernel)
     f += (size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4;   // wa_planes
     f += 2 * (size_t)n_pad * 96;                       // h2z, h2b: 24 uint4 per row each
     f += (size_t)n_pad * kH + 4 * nch * (size_t)n_pad; // head workspace
@@ -262,11 +261,10 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.da2 = take((size_t)n_pad * kH); v.da1 = take((size_t)n_pad * kH);
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
     v.dwap = take((size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I));
-    v.entw = take((size_t)n_entw_max_of(I)); v.n_entw = 0;
-    v.row_m = take(n_pad); v.arrive = (int*)take(1024);
+    v.sync = (int*)take(4); v.snap = take(6 * (size_t)snap_stride(S));
     v.red = take(64);
     v.normp = take(1024);
-    v.dwp = take((size_t)(n_pad / kTileM) * (kH * (kH + 1) + kH * (S + 1) + (kH + 1)) + 64);
+    v.dwp = take(dwp_floats(n_pad, S));
     v.wa_planes = (uint4*)take((size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4);
     v.h2z = (uint4*)take((size_t)n_pad * 96); v.h2b = (uint4*)take((size_t)n_pad * 96);
     v.head_ws = (void*)p;
@@ -444,6 +442,7 @@ __device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c
 //   [12288, 24576)  col-major  C[p][col 64][slot 32]    : B operand of dH2 = dZ Wa  (lane = col, 8 consecutive slots);
 //                   slot 16 t + 8 hi + j holds item acc_row(8 t + j, hi): the order in which the logit accumulators
 //                   of a lane enumerate the items, so the dZ registers are the A operand as they are.
+__device__ __forceinline__ void wa_planes_from_lds(int tile, uint4* __restrict__ planes, const float* sw);
 __device__ __forceinline__ void wa_planes_block(int tile, int I, const float* __restrict__ wa, uint4* __restrict__ planes, float* sw) {
     const int tid = threadIdx.x, tile0 = tile * kTileN;
 #pragma unroll
@@ -455,6 +454,11 @@ __device__ __forceinline__ void wa_planes_block(int tile, int I, const float* __
         d[0] = t4.x; d[1] = t4.y; d[2] = t4.z; d[3] = t4.w;
     }
     __syncthreads();
+    wa_planes_from_lds(tile, planes, sw);
+}
+// the six planes of item tile `tile` from its fp32 image sw[item][65] (all 256 threads; the caller has synchronised the image)
+__device__ __forceinline__ void wa_planes_from_lds(int tile, uint4* __restrict__ planes, const float* sw) {
+    const int tid = threadIdx.x;
     uint4* out = planes + (size_t)tile * kPlaneTileU4;
     {
         const float* r = &sw[(tid >> 3) * 65 + 8 * (tid & 7)];
@@ -471,28 +475,99 @@ __device__ __forceinline__ void wa_planes_block(int tile, int I, const float* __
     }
 }
 
-// First launch of a minibatch step, three independent jobs by workgroup index:
+// ---- trunk forward of minibatch rows (first launch of a stand-alone minibatch step; inside a learn() loop: the Adam launch of the step before) ----
+// What a row leaves behind for the later kernels of its step.
+struct TrunkRowOut {
+    float *h2, *value, *h1, *obs_copy;     // [n_pad, 64], [n_pad], [n_pad, 64], [n_pad, S]
+    int32_t* act; long* dst;               // the row's action / its row of the [T+1, B] tracker-gradient tensor, in minibatch order
+    float* row4;                           // [4][n_pad]: adv, logp_old, ret, v_s of the minibatch rows
+    uint4 *h2z, *h2b;                      // bf16 planes of H2 in the head kernels' register order
+};
+// The weights as the row job reads them: the three matrices from LDS copies, the biases through `w` (global memory in trunk_adv_kernel, LDS in
+// adam_next_kernel, whose workgroups form the updated values themselves).
+struct TrunkLds { const float* w1; int ld1; const float* w2; const float* wc; };
+
+// row j's gathers, requested by the whole wavefront before anything waits
+struct TrunkRowIn { int ri; float x; };
+__device__ __forceinline__ TrunkRowIn trunk_row_gather(int j, int mb, const int32_t* __restrict__ idx, const float* __restrict__ obs_flat, long stride, int S,
+                                                       int lane) {
+    TrunkRowIn in;
+    in.ri = idx[j];                                       // (idx holds n_pad entries or the tail is never dereferenced: see the callers)
+    in.x = (j < mb && lane < S) ? obs_flat[(size_t)in.ri * stride + lane] : 0.f;    // rows >= mb: zeros (as trunk_rows)
+    return in;
+}
+// a row's input into LDS + what the row leaves for the later kernels besides the trunk's own outputs
+__device__ __forceinline__ void trunk_row_pre(int S, const TrunkRowIn& in, int j, int mb, int n_pad, int lane, float* xs, const cirs_ppo_batch& bt, int n_env,
+                                              const TrunkRowOut& o) {
+    if (lane < S) {
+        xs[lane] = in.x;
+        o.obs_copy[(size_t)j * S + lane] = in.x;
+    }
+    if (o.act) {   // the row's action, its row of the [T+1, B] tracker-gradient tensor and its four scalars in minibatch order (what the merge
+                   // kernel used to gather through idx: the backward kernel's prologue reads them coalesced, without a dependent round trip)
+        if (lane == 0) {
+            o.act[j] = j < mb ? bt.act[in.ri] : 0;
+            o.dst[j] = j < mb ? (long)bt.row_t[in.ri] * n_env + bt.row_env[in.ri] : 0;
+        } else if (lane <= 4) {
+            const float* srcp = lane == 1 ? bt.adv : lane == 2 ? bt.logp_old : lane == 3 ? bt.ret : bt.v_s;
+            o.row4[(size_t)(lane - 1) * n_pad + j] = j < mb ? srcp[in.ri] : 0.f;
+        }
+    }
+}
+// The head kernels want H2 as bf16 planes in THEIR register order (hz: the lane's row, 8 consecutive columns per register quad; hb: 8
+// rows of one column per quad).  Splitting here, once per row, replaces an LDS round trip + 8 split8 per wavefront in the prologue of every
+// head workgroup (31 chunks x 8 row blocks re-split the same rows); each lane owns one element and drops its three 2-byte pieces
+// into both layouts (same arithmetic as split_pair: same bits).  a = h2[j][lane].
+__device__ __forceinline__ void trunk_row_planes(float a, int j, int lane, const TrunkRowOut& o) {
+    const uint32_t hp = cvt_pk_bf16(a, 0.f) & 0xffffu;
+    const float r1 = a - __uint_as_float(hp << 16);
+    const uint32_t mp = cvt_pk_bf16(r1, 0.f) & 0xffffu;
+    const float r2 = r1 - __uint_as_float(mp << 16);
+    const uint32_t lp = cvt_pk_bf16(r2, 0.f) & 0xffffu;
+    const int tile = j >> 5, rr = j & 31, c = lane;
+    // hz: k-step s = c / 16, lane half hi = (c / 8) & 1, element c & 7; the consumer's lane is (hi, lo = row)
+    unsigned short* z = reinterpret_cast<unsigned short*>(o.h2z + ((size_t)(tile * 12 + (c >> 4) * 3) * 64 + ((c >> 3) & 1) * 32 + rr)) + (c & 7);
+    z[0] = (unsigned short)hp; z[64 * 8] = (unsigned short)mp; z[2 * 64 * 8] = (unsigned short)lp;
+    // hb[c / 32][t]: element jb of the consumer lane (hi_b, lo = c % 32), accumulator row rr = acc_row(8 t + jb, hi_b)
+    const int hi_b = (rr >> 2) & 1, sb = (rr & 3) + 4 * (rr >> 3);
+    unsigned short* bq = reinterpret_cast<unsigned short*>(o.h2b + ((size_t)(tile * 12 + ((c >> 5) * 2 + (sb >> 3)) * 3) * 64 + hi_b * 32 + (c & 31))) + (sb & 7);
+    bq[0] = (unsigned short)hp; bq[64 * 8] = (unsigned short)mp; bq[2 * 64 * 8] = (unsigned short)lp;
+}
+// one minibatch row by one wavefront: trunk (the rollout's fma chains), the gathered row scalars, H2 as bf16 planes
+__device__ __forceinline__ void trunk_row_job(const cirs_policy_cfg& cfg, const cirs_policy_weights& w, const TrunkLds& L, const TrunkRowIn& in, int j, int mb,
+                                              int n_pad, int lane, float* xs, float* hs, const cirs_ppo_batch& bt, int n_env, const TrunkRowOut& o) {
+    trunk_row_pre(cfg.dim_state, in, j, mb, n_pad, lane, xs, bt, n_env, o);
+    trunk_compute(cfg, w, xs, hs, lane, j, o.h2, o.value, o.h1, L.w1, L.ld1, L.w2, L.wc);
+    trunk_row_planes(xs[lane], j, lane, o);        // (h2[j][lane]: left in xs by trunk_compute)
+}
+struct SnapJob { const float *p, *m, *v; float* dst; int n_tr; long wc; };      // dst null: no snapshot (item-sharded step)
+// First launch of a stand-alone minibatch step, independent jobs by workgroup index (+ the snapshot workgroups behind the planes):
 //   [0, n_row_wgs)                trunk forward of the minibatch rows (same fma chains as the rollout)
 //   n_row_wgs                     advantage statistics of the (global) minibatch
 //   (n_row_wgs, n_row_wgs + tiles] bf16 planes of one Wa item tile (operands of the two head kernels)
+// Inside cirs_ppo_learn's loop only the first step of an update needs it: adam_next_kernel does the same three jobs for the step after it.
 __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cirs_policy_weights w, const float* __restrict__ obs_flat,
-                                                        long stride, int n_pad, float* __restrict__ h2_out,
-                                                        float* __restrict__ value_out, float* __restrict__ h1_out,
-                                                        const int32_t* __restrict__ idx, int mb, float* __restrict__ obs_copy,
+                                                        long stride, int n_pad, const int32_t* __restrict__ idx, int mb,
                                                         const float* __restrict__ adv_flat, const int32_t* __restrict__ sidx,
                                                         int m_stats, int enable, float* __restrict__ red, int n_row_wgs,
-                                                        uint4* __restrict__ planes, uint4* __restrict__ h2z, uint4* __restrict__ h2b,
-                                                        cirs_ppo_batch bt, int n_env, int32_t* __restrict__ act_out, long* __restrict__ dst_out,
-                                                        float* __restrict__ row4 /* [4][n_pad]: adv, logp_old, ret, v_s of the minibatch rows */,
-                                                        int* __restrict__ arrive = nullptr, int n_arrive = 0 /* arrival counters of head_fwd_kernel, cleared here */) {
+                                                        uint4* __restrict__ planes, cirs_ppo_batch bt, int n_env, TrunkRowOut out, SnapJob sj) {
     __shared__ float lds_raw[kTileN * 65];
     static_assert(kTileN * 65 >= 4 * 2 * kH, "the trunk rows use 4 x 2 x 64 floats of the same buffer");
+    const int n_tiles = (cfg.n_items + kTileN - 1) / kTileN;
+    if ((int)blockIdx.x > n_row_wgs + n_tiles) {      // p | m | v of [trunk | wc | bc] as of before this step's optimiser launch (its T workgroups)
+        const int e = ((int)blockIdx.x - n_row_wgs - n_tiles - 1) * 256 + threadIdx.x;
+        const int n_sn = sj.n_tr + kH + 1, st = (n_sn + 3) & ~3;
+        if (e < n_sn) {
+            const long i = e < sj.n_tr ? e : sj.wc + (e - sj.n_tr);
+            sj.dst[e] = sj.p[i]; sj.dst[st + e] = sj.m[i]; sj.dst[2 * st + e] = sj.v[i];
+        }
+        return;
+    }
     if ((int)blockIdx.x > n_row_wgs) {
         wa_planes_block((int)blockIdx.x - n_row_wgs - 1, cfg.n_items, w.wa, planes, lds_raw);
         return;
     }
     if ((int)blockIdx.x == n_row_wgs) {
-        for (int q = threadIdx.x; q < n_arrive; q += 256) arrive[q] = 0;
         adv_stats_block(adv_flat, sidx, m_stats, enable, red, lds_raw);
         return;
     }
@@ -503,7 +578,6 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
     __shared__ float sWc[kH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, S = cfg.dim_state;
     const int j = blockIdx.x * 4 + wv;                     // < n_pad: the grid has n_pad / 4 row workgroups
-    const int ri = idx[j];
     const int ld1 = S | 1;     // odd row stride: lane o reads sW1[o * ld1 + k] without bank conflicts
     const bool al16 = (reinterpret_cast<uintptr_t>(w.w2) & 15) == 0;
     f32x4 t2[4];
@@ -516,7 +590,7 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
 #pragma unroll
     for (int q = 0; q < 8; ++q) t1[q] = tid + 256 * q < kH * S ? w.w1[tid + 256 * q] : 0.f;
     const float tc = tid < kH ? w.wc[tid] : 0.f;
-    const float x = (j < mb && lane < S) ? obs_flat[(size_t)ri * stride + lane] : 0.f;    // rows >= mb: zeros (as trunk_rows)
+    const TrunkRowIn in = trunk_row_gather(j, mb, idx, obs_flat, stride, S, lane);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i4 = tid + 256 * q;
@@ -529,42 +603,8 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
     }
     if (tid < kH) sWc[tid] = tc;
     float (*rows)[2][kH] = reinterpret_cast<float (*)[2][kH]>(lds_raw);
-    if (lane < S) {
-        rows[wv][0][lane] = x;
-        obs_copy[(size_t)j * S + lane] = x;
-    }
-    if (act_out) {   // the row's action, its row of the [T+1, B] tracker-gradient tensor and its four scalars in minibatch order (what the merge
-                     // kernel used to gather through idx: the backward kernel's prologue reads them coalesced, without a dependent round trip)
-        if (lane == 0) {
-            act_out[j] = j < mb ? bt.act[ri] : 0;
-            dst_out[j] = j < mb ? (long)bt.row_t[ri] * n_env + bt.row_env[ri] : 0;
-        } else if (lane <= 4) {
-            const float* srcp = lane == 1 ? bt.adv : lane == 2 ? bt.logp_old : lane == 3 ? bt.ret : bt.v_s;
-            row4[(size_t)(lane - 1) * n_pad + j] = j < mb ? srcp[ri] : 0.f;
-        }
-    }
     __syncthreads();
-    trunk_compute(cfg, w, rows[wv][0], rows[wv][1], lane, j, h2_out, value_out, h1_out, sW1, ld1, sW2, sWc);
-    // The head kernels want H2 as bf16 planes in THEIR register order (hz: the lane's row, 8 consecutive columns per register quad; hb: 8
-    // rows of one column per quad).  Splitting here, once per row, replaces an LDS round trip + 8 split8 per wavefront in the prologue of every
-    // head workgroup (31 chunks x 8 row blocks re-split the same rows); each lane owns one element and drops its three 2-byte pieces
-    // into both layouts (same arithmetic as split_pair: same bits).
-    {
-        const float a = rows[wv][0][lane];                 // h2[j][lane] (left there by trunk_compute)
-        const uint32_t hp = cvt_pk_bf16(a, 0.f) & 0xffffu;
-        const float r1 = a - __uint_as_float(hp << 16);
-        const uint32_t mp = cvt_pk_bf16(r1, 0.f) & 0xffffu;
-        const float r2 = r1 - __uint_as_float(mp << 16);
-        const uint32_t lp = cvt_pk_bf16(r2, 0.f) & 0xffffu;
-        const int tile = j >> 5, rr = j & 31, c = lane;
-        // hz: k-step s = c / 16, lane half hi = (c / 8) & 1, element c & 7; the consumer's lane is (hi, lo = row)
-        unsigned short* z = reinterpret_cast<unsigned short*>(h2z + ((size_t)(tile * 12 + (c >> 4) * 3) * 64 + ((c >> 3) & 1) * 32 + rr)) + (c & 7);
-        z[0] = (unsigned short)hp; z[64 * 8] = (unsigned short)mp; z[2 * 64 * 8] = (unsigned short)lp;
-        // hb[c / 32][t]: element jb of the consumer lane (hi_b, lo = c % 32), accumulator row rr = acc_row(8 t + jb, hi_b)
-        const int hi_b = (rr >> 2) & 1, sb = (rr & 3) + 4 * (rr >> 3);
-        unsigned short* bq = reinterpret_cast<unsigned short*>(h2b + ((size_t)(tile * 12 + ((c >> 5) * 2 + (sb >> 3)) * 3) * 64 + hi_b * 32 + (c & 31))) + (sb & 7);
-        bq[0] = (unsigned short)hp; bq[64 * 8] = (unsigned short)mp; bq[2 * 64 * 8] = (unsigned short)lp;
-    }
+    trunk_row_job(cfg, w, TrunkLds{sW1, ld1, sW2, sWc}, in, j, mb, n_pad, lane, rows[wv][0], rows[wv][1], bt, n_env, out);
 }
 
 constexpr int kTStride = 36;                 // transpose buffer row stride (floats): 16 B aligned, conflict-free b128 reads
@@ -577,6 +617,13 @@ constexpr int kWBufB = 3 * kRPlaneB + 3 * kCPlaneB;
 // grid = (n_chunks, ceil(n_pad/32/4)); workgroup = 4 waves = 4 row tiles walking the item tiles of one chunk; the R planes
 // of a Wa tile (12 KB) are staged once per workgroup, double-buffered.  Output: the per-chunk partials (m, s, t) of each
 // row in the ActorPartialView arrays (score = t), merged by head_stats_merge_kernel.
+#ifdef CIRS_HEAD_PROF
+// stage timestamps of chosen workgroups of the small kernels of a minibatch step (probe builds only: tools/probes/step_prof.py)
+__device__ unsigned long long g_step_prof[64];
+#define CIRS_PSTAMP(COND, K) do { if ((COND) && threadIdx.x == 0) g_step_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CIRS_PSTAMP(COND, K) do { } while (0)
+#endif
 #ifdef CIRS_HEAD_PROF
 // per-tile stage timestamps of workgroup (0, 0) / wave 0 at its third tile (probe builds only: tools/probes/head_prof.py)
 __device__ unsigned long long g_head_prof[64];
@@ -790,6 +837,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     __shared__ __attribute__((aligned(16))) float sR[2][kBwdWaves][kRSize];   // double-buffered: the sum of tile t runs inside iteration t + 1
     const int tid = threadIdx.x;
     CIRS_SSTAMP(30);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) v.sync[0] = 0;      // arrival counter of the trunk-backward launch of this step
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * kBwdWaves + wv) * kTileM;
@@ -1133,10 +1181,6 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     CIRS_SSTAMP(35);
 }
 
-}  // namespace cirs
-#include "ppo_head_split.h"
-namespace cirs {
-
 // ---- slab sums of the wa|ba gradient (one of kWaSumBlocks workgroups of 512 threads) ------------------------------------
 // The n_slabs row-block partials written by head_bwd_fused_kernel are summed in slab order into the flat gradient, one
 // float4 per thread and slab (16-byte aligned: wa_beg and slab_stride are multiples of 4), 8 independent loads in flight;
@@ -1208,6 +1252,11 @@ __device__ __forceinline__ void dw_tile_x_lds(const float* sX, int ldx, int K, i
 #pragma unroll
     for (int j = 0; j < 16; ++j) b[j] = (k_ok && row0 + 2 * j + hi < n_rows) ? sX[(2 * j + hi) * ldx + k] : 0.f;
 }
+// Values that cross workgroups INSIDE one launch are written through (sc1 stores, completed before the arrival is counted) and read around
+// the non-coherent caches (sc1 loads): the write-through form of MI355X_MICROARCH.md's inter-workgroup visibility rules -- no L2 write-back fence.
+__device__ __forceinline__ void st_sc1(float* p, float a) { __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool kSc1 = false>
 __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)[16], int K, int o0, int k0, float* __restrict__ out, int lane) {
     const int hi = lane >> 5, lo = lane & 31;
     const int o = o0 + lo, k = k0 + lo;
@@ -1226,11 +1275,14 @@ __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)
     }
     if (k_ok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(size_t)(o0 + acc_row(r, hi)) * (K + 1) + k] = acc[r];
+        for (int r = 0; r < 16; ++r) {
+            float* d = out + (size_t)(o0 + acc_row(r, hi)) * (K + 1) + k;
+            if (kSc1) st_sc1(d, acc[r]); else *d = acc[r];
+        }
     }
     if (k0 == 0) {
         bsum += __shfl_xor(bsum, 32, CIRS_WAVE);
-        if (hi == 0) out[(size_t)o * (K + 1) + K] = bsum;
+        if (hi == 0) { float* d = out + (size_t)o * (K + 1) + K; if (kSc1) st_sc1(d, bsum); else *d = bsum; }
     }
 }
 
@@ -1251,6 +1303,7 @@ __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)
 __global__ __launch_bounds__(64) void dh2_sum_kernel(int mb, int n_pad, int n_chunks, MbView v, float* __restrict__ tp_dh2 = nullptr,
                                                      float* __restrict__ tp_ent = nullptr) {
     const int n_f4_wgs = n_pad * (kH / 4) / 64;
+    if (blockIdx.x == 0 && threadIdx.x == 0) v.sync[0] = 0;       // arrival counter of a folding trunk-backward launch that follows
     if ((int)blockIdx.x < n_f4_wgs) {
         const size_t q4 = (size_t)blockIdx.x * 64 + threadIdx.x;
         float* p = v.dh2p + q4 * 4;
@@ -1336,6 +1389,12 @@ __global__ __launch_bounds__(256) void head_tp_fold_kernel(cirs_ppo_batch b, con
     out4[j] = m; out4[n_pad + j] = s; out4[2 * n_pad + j] = t; out4[3 * n_pad + j] = z;
 }
 
+// kFold (single-rank step): the launch also finishes the trunk / critic weight gradients and their share of the squared norm -- what a launch of
+// its own (sumsq_partial_kernel: 5 us for 5.6 k outputs) did.  The row workgroups write their dW row slabs through and count their arrival; 11 more
+// workgroups (F, the LAST of the grid: the row workgroups are dispatched before anything that waits for them) wait for the count and sum 512
+// outputs each over the slabs in slab order (the assignment output -> thread is fixed, so is every order of summation).  The hand-off (write-through
+// drain + atomic + a round trip to memory, ~4 us) runs beside the wa|ba slab-sum workgroups, which take as long as rows + hand-off together.
+template <bool kFold>
 __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n_chunks, int S, const float* __restrict__ w1,
                                                         const float* __restrict__ w2, const float* __restrict__ wc, MbView v,
                                                         float* __restrict__ dobs_accum, float* __restrict__ g, long wa_beg, long wa_len,
@@ -1352,13 +1411,65 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
     CIRS_TSTAMP(n_pad / kTileM, 24);
     if ((int)blockIdx.x >= n_pad / kTileM) {   // extra workgroups (single-rank path): slab sums of the wa|ba gradient
         const int b = (int)blockIdx.x - n_pad / kTileM;
+        if (kFold && b >= kWaSumBlocks) {      // F workgroups: 512 outputs of [trunk | wc | bc] each, one per thread
+            const int f = b - kWaSumBlocks;
+            const int n_row_wgs = n_pad / kTileM;
+            const int tid = threadIdx.x;
+            CIRS_PSTAMP(f == 0, 30);
+            if (tid == 0) {     // (bounded: a lost arrival must not hang the device; the parity tests would see the wrong sums)
+                int spins = 0;
+                while (__hip_atomic_load(v.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_row_wgs && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            CIRS_PSTAMP(f == 0, 31);
+            // element e of [trunk | wc | bc]: job 2 = W1|b1, 1 = W2|b2, 0 = wc|bc (the mapping sumsq_partial_kernel uses)
+            const long n_trunk = (long)kH * S + kH + (long)kH * kH + kH, n_dw = n_trunk + kH + 1;
+            const long e = f * 512L + tid;
+            float sq = 0.f;
+            if (e < n_dw) {
+                const long i = e < n_trunk ? e : wa_beg + wa_len + (e - n_trunk);
+                int ji, q;
+                if (e < (long)kH * S) { ji = 2; q = (int)(e / S) * (S + 1) + (int)(e % S); }
+                else if (e < (long)kH * S + kH) { ji = 2; q = (int)(e - (long)kH * S) * (S + 1) + S; }
+                else if (e < (long)kH * S + kH + (long)kH * kH) { const int r = (int)(e - ((long)kH * S + kH)); ji = 1; q = (r / kH) * (kH + 1) + (r % kH); }
+                else if (e < n_trunk) { ji = 1; q = (int)(e - ((long)kH * S + kH + (long)kH * kH)) * (kH + 1) + kH; }
+                else { ji = 0; q = (int)(e - n_trunk); }
+                const int n_out = ji == 2 ? jobs.j[2].O * (jobs.j[2].K + 1) : ji == 1 ? jobs.j[1].O * (jobs.j[1].K + 1) : jobs.j[0].O * (jobs.j[0].K + 1);
+                const int p_off = ji == 2 ? jobs.j[2].part_off : ji == 1 ? jobs.j[1].part_off : jobs.j[0].part_off;
+                float x = 0.f;
+                for (int c0 = 0; c0 < n_row_wgs; c0 += 32) {     // all loads of a batch in flight, added in slab order
+                    float t32[32];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_row_wgs) ? ld_sc1(dwp + p_off + (size_t)(c0 + u) * n_out + q) : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) x += t32[u];
+                }
+                g[i] = x;
+                sq = (e < n_trunk ? 2.0f : 1.0f) * x * x;       // trunk parameters appear twice in the reference's list
+            }
+            CIRS_PSTAMP(f == 0, 32);
+            sA[tid] = sq;
+            __syncthreads();
+            for (int st = 256; st > 0; st >>= 1) {
+                if (tid < st) sA[tid] += sA[tid + st];
+                __syncthreads();
+            }
+            if (tid == 0) v.normp[f] = sA[0];
+            const int n_f = (int)((n_dw + 511) / 512);
+            if (f == 0 && tid >= n_f && tid < kNormBlocks) v.normp[tid] = 0.f;      // the slots no workgroup owns
+            CIRS_PSTAMP(f == 0, 33);
+            return;
+        }
+        CIRS_PSTAMP(b == 0, 26); CIRS_PSTAMP(b == kWaSumBlocks - 1, 28);
         wa_slab_sum_block(g, wa_beg, wa_len, v.dwap, slab_stride, n_slabs, b, v.normp + kNormBlocks + b, sA);
+        CIRS_PSTAMP(b == 0, 27); CIRS_PSTAMP(b == kWaSumBlocks - 1, 29);
         CIRS_TSTAMP(n_pad / kTileM, 25);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = blockIdx.x * kTileM;
+    CIRS_PSTAMP(kFold && blockIdx.x == 0, 20);
     // Everything the later stages read besides stage 1's own result -- W2, W1, the h1 / h2 / obs rows of the tile, dvalue -- depends on
     // nothing computed here.  A wavefront's memory instruction costs the CU's address unit ~16 cycles whatever its width, and eight
     // wavefronts share that unit: per-lane operand loads (32 + 16 dwords per lane, 64 more for the critic row) took longer to ISSUE
@@ -1412,6 +1523,7 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
     CIRS_TSTAMP(0, 17);
     __syncthreads();
     CIRS_TSTAMP(0, 18);
+    CIRS_PSTAMP(kFold && blockIdx.x == 0, 21);
     if (wv < 2) {  // d a1 tile: columns wv*32 .. +32
         const int n = wv * 32 + lo;
         float arow[32];
@@ -1442,7 +1554,7 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
         const int t = wv - 2;
         float xrow[16];
         dw_tile_x_lds(sH1, kLdsStride, kH, row0, mb, (t & 1) * 32, lane, xrow);
-        dw_tile_32rows(sA, xrow, kH, (t >> 1) * 32, (t & 1) * 32, dwp + jobs.j[1].part_off + (size_t)blockIdx.x * (kH * (kH + 1)), lane);
+        dw_tile_32rows<kFold>(sA, xrow, kH, (t >> 1) * 32, (t & 1) * 32, dwp + jobs.j[1].part_off + (size_t)blockIdx.x * (kH * (kH + 1)), lane);
     } else if (dwp && wv == 6) {  // d wc | d bc row slab: lane = column of h2
         float acc = 0.f, bs = 0.f;
         float dv32[kTileM], h32[kTileM];    // from the LDS tiles (dvalue is 0 there for rows beyond the minibatch)
@@ -1456,18 +1568,27 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
             }
         }
         float* out = dwp + jobs.j[0].part_off + (size_t)blockIdx.x * (kH + 1);
-        out[lane] = acc;
-        if (lane == 0) out[kH] = bs;
+        if (kFold) { st_sc1(out + lane, acc); if (lane == 0) st_sc1(out + kH, bs); }
+        else { out[lane] = acc; if (lane == 0) out[kH] = bs; }
     }
     CIRS_TSTAMP(0, 19);
     __syncthreads();
     CIRS_TSTAMP(0, 20);
+    CIRS_PSTAMP(kFold && blockIdx.x == 0, 22);
     if (dwp && wv < 2) {  // d W1 | d b1 row slab: two 32 x 32 tiles (S <= 32 columns), waves 0, 1
         float xrow[16];
         dw_tile_x_lds(sObs, S, S, row0, mb, 0, lane, xrow);
-        dw_tile_32rows(sD, xrow, S, wv * 32, 0, dwp + jobs.j[2].part_off + (size_t)blockIdx.x * (kH * (S + 1)), lane);
+        dw_tile_32rows<kFold>(sD, xrow, S, wv * 32, 0, dwp + jobs.j[2].part_off + (size_t)blockIdx.x * (kH * (S + 1)), lane);
     }
     CIRS_TSTAMP(0, 21);
+    if (kFold) {      // every slab store of this workgroup has left before its arrival is counted
+        CIRS_PSTAMP(blockIdx.x == 0, 23);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CIRS_PSTAMP(blockIdx.x == 0, 24);
+        if (tid == 0) __hip_atomic_fetch_add(v.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CIRS_PSTAMP(blockIdx.x == 0, 25);
+    }
     if (!dobs_accum) return;
     if (wv == 2) {
         float arow[32];
@@ -1492,6 +1613,216 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
             }
         }
     }
+}
+
+// ---- trunk backward of the single-rank step (round 5): chunk-slab sums of d h2 + trunk backward + weight-gradient sums + squared norm, ONE launch ----
+// Until round 5 this was three launches (dh2_sum_kernel, trunk_bwd_kernel, sumsq_partial_kernel: 4.9 + 8.5 + 5.2 us, each within 1-3 us of the
+// floor of a dependent launch).  What forced the first boundary was bytes per workgroup: a 32-row MFMA tile needs the 31 chunk slabs of its rows,
+// 254 KB through ONE CU.  Here a row workgroup owns 8 rows (64 KB of slabs) and does its small products on the vector ALUs in the matrix cores'
+// order (k = kk, 32 + kk: same bits as trunk_bwd_kernel); 128 workgroups instead of 32 pull the same bytes.  Roles by workgroup index:
+//   R [0, n_r)            8 rows each: d a2 (chunk slabs summed in chunk order + the critic's term), entropy per row, d a1, d obs scatter, and the
+//                         rows' share of every trunk / critic weight gradient as ONE slab in the flat gradient's own order [w1|b1|w2|b2|wc|bc],
+//                         written through (sc1) before the workgroup counts its arrival
+//   W next kWaSumBlocks   slab sums of the wa|ba gradient + their squared-norm partials (depend on the head backward kernel only)
+//   F last n_f            wait for the R arrivals, then 128 outputs each: four threads per output sum a quarter of the slabs in slab order and
+//                         meet in quarter order; flat gradient + squared-norm partial.  The hand-off runs beside the W workgroups.
+// R has the lowest indices: everything it needs is dispatched before anything that waits for it.
+constexpr int kRR = 8;                       // rows of an R workgroup
+constexpr int kFOut = 128;                   // outputs of an F workgroup
+struct RowsLds {
+    __attribute__((aligned(16))) float w2[kH * kLdsStride];      // W2 [k][n]
+    __attribute__((aligned(16))) float a2[kRR * kH];             // d a2
+    __attribute__((aligned(16))) float a1[kRR * kH];             // d a1
+    __attribute__((aligned(16))) float h1[kRR * kH];
+    __attribute__((aligned(16))) float h2[kRR * kH];
+    __attribute__((aligned(16))) float obs[kRR * 32];
+    float w1[kH * 32];                                           // W1 [k][S]
+    float dv[kRR];
+};
+__device__ __forceinline__ void st_sc1x2(float* p, float a, float b) {      // 8-byte write-through store (p 8-byte aligned)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int n_chunks, int S, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                         const float* __restrict__ wc, MbView v, float* __restrict__ dobs_accum, float* __restrict__ g,
+                                                         long wa_beg, long wa_len, long slab_stride, int n_slabs, int n_r, int rslab /* floats per R slab */,
+                                                         int w_delay /* W workgroups start this many x 1024 cycles late: the R workgroups' requests go first */) {
+    __shared__ RowsLds L;
+    __shared__ float sRed[512];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int n_tr = kH * S + kH + kH * kH + kH, n_dw = n_tr + kH + 1;      // [w1 | b1 | w2 | b2] + [wc | bc]
+    if (b >= n_r + kWaSumBlocks) {
+        // ---- F ----------------------------------------------------------------------------------------------------------------
+        const int f = b - n_r - kWaSumBlocks;
+        CIRS_PSTAMP(f == 0, 30);
+        if (tid == 0) {     // (bounded: a lost arrival must not hang the device; the parity tests would see the wrong sums)
+            int spins = 0;
+            while (__hip_atomic_load(v.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_r && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        CIRS_PSTAMP(f == 0, 31);
+        const int o = tid & (kFOut - 1), q = tid >> 7;          // output of this workgroup, slab quarter
+        const int e = f * kFOut + o;
+        const int per = (n_r + 3) >> 2, s_lo = q * per, s_hi = min(n_r, s_lo + per);
+        float x = 0.f;
+        if (e < n_dw) {
+            const float* src = v.dwp + e;
+            for (int c0 = s_lo; c0 < s_hi; c0 += 32) {          // all loads of a batch in flight, added in slab order
+                float t32[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < s_hi) ? ld_sc1(src + (size_t)(c0 + u) * rslab) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) x += t32[u];
+            }
+        }
+        sRed[tid] = x;
+        __syncthreads();
+        CIRS_PSTAMP(f == 0, 32);
+        float sq = 0.f;
+        if (tid < kFOut && e < n_dw) {
+            const float tot = ((sRed[tid] + sRed[kFOut + tid]) + sRed[2 * kFOut + tid]) + sRed[3 * kFOut + tid];
+            g[e < n_tr ? e : wa_beg + wa_len + (e - n_tr)] = tot;
+            sq = (e < n_tr ? 2.0f : 1.0f) * tot * tot;          // trunk parameters appear twice in the reference's list
+        }
+        __syncthreads();
+        sRed[tid] = sq;
+        __syncthreads();
+        for (int st = 64; st > 0; st >>= 1) {
+            if (tid < st) sRed[tid] += sRed[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) v.normp[f] = sRed[0];
+        const int n_f = (n_dw + kFOut - 1) / kFOut;
+        if (f == 0 && tid >= n_f && tid < kNormBlocks) v.normp[tid] = 0.f;      // the slots no workgroup owns
+        CIRS_PSTAMP(f == 0, 33);
+        return;
+    }
+    if (b >= n_r) {
+        CIRS_PSTAMP(b == n_r, 26);
+        for (int q = 0; q < w_delay; ++q) __builtin_amdgcn_s_sleep(16);
+        wa_slab_sum_block(g, wa_beg, wa_len, v.dwap, slab_stride, n_slabs, b - n_r, v.normp + kNormBlocks + (b - n_r), sRed);
+        CIRS_PSTAMP(b == n_r, 27);
+        return;
+    }
+    // ---- R: thread (row r = tid / 64, column n = tid % 64) ----------------------------------------------------------------------
+    CIRS_PSTAMP(b == 0, 20);
+    const int r = tid >> 6, n = tid & 63, row = b * kRR + r;      // row < n_pad (n_pad is a multiple of 32)
+    // requests: the slab column of this thread's element first (31 loads, chunk order), then the operands every later stage reads from LDS
+    float acc = 0.f;
+    {
+        const float* src = v.dh2p + (size_t)row * kH + n;
+        const size_t cstride = (size_t)n_pad * kH;
+        for (int c0 = 0; c0 < n_chunks; c0 += 32) {
+            float t32[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_chunks) ? src[(size_t)(c0 + u) * cstride] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += t32[u];
+        }
+    }
+    const f32x4 w2a = *reinterpret_cast<const f32x4*>(w2 + (size_t)tid * 4), w2b = *reinterpret_cast<const f32x4*>(w2 + (size_t)(tid + 512) * 4);
+    float w1t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w1t[q] = tid + 512 * q < kH * S ? w1[tid + 512 * q] : 0.f;   // W1 [64][S], S <= 32
+    const float h1v = v.h1[(size_t)row * kH + n], h2v = v.h2[(size_t)row * kH + n], wcn = wc[n], dvr = v.dvalue[row];
+    const float obv = tid < kRR * S ? v.obs[(size_t)b * kRR * S + tid] : 0.f;
+    float ent = 0.f, hent = 0.f;
+    if (tid < kRR) {            // entropy per row = (lse - E_p[z]) + the chunks' clamp corrections, chunk order
+        const int rr = b * kRR + tid;
+        for (int c0 = 0; c0 < n_chunks; c0 += 32) {
+            float t32[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_chunks) ? v.entp[(size_t)(c0 + u) * n_pad + rr] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) ent += t32[u];
+        }
+        hent = v.h_ent[rr];
+    }
+    const bool ok = row < mb;
+    const float da2 = (ok && h2v > 0.f) ? __builtin_fmaf(dvr, wcn, acc) : 0.f;
+    L.a2[r * kH + n] = da2; L.h1[r * kH + n] = h1v; L.h2[r * kH + n] = h2v;
+    *reinterpret_cast<f32x4*>(&L.w2[(tid >> 4) * kLdsStride + (tid & 15) * 4]) = w2a;
+    *reinterpret_cast<f32x4*>(&L.w2[((tid + 512) >> 4) * kLdsStride + (tid & 15) * 4]) = w2b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (tid + 512 * q < kH * S) L.w1[tid + 512 * q] = w1t[q];
+    if (tid < kRR * S) L.obs[(tid / S) * 32 + tid % S] = obv;
+    if (n == 0) L.dv[r] = ok ? dvr : 0.f;
+    if (tid < kRR) v.ent_row[b * kRR + tid] = (b * kRR + tid) < mb ? hent + ent : 0.f;
+    __syncthreads();
+    CIRS_PSTAMP(b == 0, 21);
+    // d a1 = (d a2 W2) relu'(h1): the matrix cores' order k = kk, 32 + kk
+    {
+        float t = 0.f;
+        const float* ar = L.a2 + r * kH;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            t = __builtin_fmaf(ar[kk], L.w2[kk * kLdsStride + n], t);
+            t = __builtin_fmaf(ar[32 + kk], L.w2[(32 + kk) * kLdsStride + n], t);
+        }
+        L.a1[r * kH + n] = h1v > 0.f ? t : 0.f;
+    }
+    __syncthreads();
+    CIRS_PSTAMP(b == 0, 22);
+    float* slab = v.dwp + (size_t)b * rslab;
+    const int o_b1 = kH * S, o_w2 = o_b1 + kH, o_b2 = o_w2 + kH * kH;
+    {   // d W2 [o][k]: thread (o = tid / 8, k = 8 (tid % 8) .. + 8), rows in order
+        const int o = tid >> 3, kb = (tid & 7) * 8;
+        float w[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < kRR; ++rr) {
+            const float a = L.a2[rr * kH + o];
+            const f32x4 ha = *reinterpret_cast<const f32x4*>(&L.h1[rr * kH + kb]), hb = *reinterpret_cast<const f32x4*>(&L.h1[rr * kH + kb + 4]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { w[u] = __builtin_fmaf(a, ha[u], w[u]); w[4 + u] = __builtin_fmaf(a, hb[u], w[4 + u]); }
+        }
+        float* d = slab + o_w2 + o * kH + kb;       // (o_w2 = 64 (S + 1): 8-byte aligned)
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) st_sc1x2(d + u, w[u], w[u + 1]);
+    }
+    {   // d W1 [o][s]: thread (o = tid / 8, s = 4 (tid % 8) .. + 4)
+        const int o = tid >> 3, sb = (tid & 7) * 4;
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < kRR; ++rr) {
+            const float a = L.a1[rr * kH + o];
+            const f32x4 x4 = *reinterpret_cast<const f32x4*>(&L.obs[rr * 32 + sb]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = __builtin_fmaf(a, x4[u], w[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (sb + u < S) st_sc1(slab + o * S + sb + u, w[u]);
+    }
+    if (tid < kH) {             // bias columns and the critic's row
+        float s2 = 0.f, s1 = 0.f, wcg = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < kRR; ++rr) { s2 += L.a2[rr * kH + tid]; s1 += L.a1[rr * kH + tid]; wcg = __builtin_fmaf(L.dv[rr], L.h2[rr * kH + tid], wcg); }
+        st_sc1(slab + o_b2 + tid, s2); st_sc1(slab + o_b1 + tid, s1); st_sc1(slab + n_tr + tid, wcg);
+    } else if (tid == kH) {
+        float s0 = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < kRR; ++rr) s0 += L.dv[rr];
+        st_sc1(slab + n_tr + kH, s0);
+    }
+    CIRS_PSTAMP(b == 0, 23);
+    if (dobs_accum && tid < kRR * 32) {         // d obs = d a1 W1, scattered to the [T+1, B, S] tracker-gradient tensor; thread (row tid / 32, s = tid % 32)
+        const int rr = tid >> 5, sc = tid & 31, rw = b * kRR + rr;
+        if (sc < S && rw < mb) {
+            float t = 0.f;
+            const float* ar = L.a1 + rr * kH;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                t = __builtin_fmaf(ar[kk], L.w1[kk * S + sc], t);
+                t = __builtin_fmaf(ar[32 + kk], L.w1[(32 + kk) * S + sc], t);
+            }
+            dobs_accum[(size_t)v.dst_row[rw] * S + sc] = t;
+        }
+    }
+    // every slab store of this workgroup has left before its arrival is counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CIRS_PSTAMP(b == 0, 24);
+    if (tid == 0) __hip_atomic_fetch_add(v.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    CIRS_PSTAMP(b == 0, 25);
 }
 
 // ---- item-sharded head: pieces around the all-reduce of the d h2 partials ------------------------------------------------------
@@ -1572,7 +1903,6 @@ __device__ __forceinline__ void loss_partials_block(int mb, int mb_norm, const M
     const int tid = threadIdx.x;  // blockDim.x == 256, sh3 = float[3][256]
     float e = 0.f, c = 0.f, f = 0.f;
     for (int r = tid; r < mb; r += 256) { e += v.ent_row[r]; c += v.clip_row[r]; f += v.vf_row[r]; }
-    for (int q = tid; q < v.n_entw; q += 256) e += v.entw[q];      // split head path: per-workgroup clamp corrections (fixed order)
     sh3[tid] = c; sh3[256 + tid] = f; sh3[512 + tid] = e;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -1591,8 +1921,26 @@ __global__ __launch_bounds__(256) void loss_partials_kernel(int mb, int mb_norm,
 }
 
 // torch.optim.Adam (_single_tensor_adam): lerp_, mul_/addcmul_, bias corrections from the step count
-struct AdamSeg { int n_sub; int scale_pow; float step_size0, bc2s0, step_size1, bc2s1; };
+struct AdamSeg { int n_sub; int scale_pow; float step_size0, bc2s0, step_size1, bc2s1; float rbc2s0, rbc2s1; /* 1 / bc2s (adam_next_kernel) */ };
 
+// torch's update p -= step_size * m / (sqrt(v) / sqrt(1 - beta2^t) + eps) with the hardware's 1-ulp square root and reciprocal (v_sqrt_f32,
+// v_rcp_f32) instead of the correctly rounded expansions (2 divisions + 1 square root = ~45 instructions per sub-step, which made the trunk's
+// 5.6 k redundant updates per T workgroup a 5 us chain): relative error 2e-7 of a step of size lr, i.e. 1e-10 of a parameter.  The
+// denominator is >= eps, never denormal; a denormal v (|g| < 1e-19) is below eps^2 by 22 orders of magnitude either way.
+// <kSub, kPow> = (2, 2) for the trunk (the reference's parameter list holds it twice: coefficient squared, two sub-steps), (1, 1) for the heads
+template <int kSub, int kPow>
+__device__ __forceinline__ void adam_elem(float& pi, float& mi, float& vi, float gi, const AdamSeg& sg, float c, float beta1, float beta2, float eps) {
+#pragma unroll
+    for (int q = 0; q < kPow; ++q) gi *= c;
+#pragma unroll
+    for (int sub = 0; sub < kSub; ++sub) {
+        mi = mi + (1.0f - beta1) * (gi - mi);
+        vi = vi * beta2 + (1.0f - beta2) * gi * gi;
+        const float ss = sub == 0 ? sg.step_size0 : sg.step_size1;
+        const float rb2 = sub == 0 ? sg.rbc2s0 : sg.rbc2s1;
+        pi = pi - ss * (mi * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vi) * rb2 + eps));
+    }
+}
 // one launch over the whole flat buffer: elements [0, n_first) use segment a (trunk), the rest segment b (heads).
 // clip_grad_norm_ stage 2 rides along: EVERY workgroup sums the kNormBlocks partial sums of squares in the same fixed
 // tree order (identical coefficient everywhere); workgroup 0 also forms the loss terms (mb > 0: single-rank path, the
@@ -1626,16 +1974,335 @@ __global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const
     if (i >= n) return;
     const AdamSeg sg = i < n_first ? sa : sb;
     float gi = g[i];
-    for (int q = 0; q < sg.scale_pow; ++q) gi *= c;
     float pi = p[i], mi = m[i], vi = v[i];
-    for (int sub = 0; sub < sg.n_sub; ++sub) {
-        mi = mi + (1.0f - beta1) * (gi - mi);
-        vi = vi * beta2 + (1.0f - beta2) * gi * gi;
-        const float ss = sub == 0 ? sg.step_size0 : sg.step_size1;
-        const float b2 = sub == 0 ? sg.bc2s0 : sg.bc2s1;
-        pi = pi - ss * (mi / (sqrtf(vi) / b2 + eps));
-    }
+    if (sg.n_sub == 2) adam_elem<2, 2>(pi, mi, vi, gi, sg, c, beta1, beta2, eps);      // (the arithmetic of adam_next_kernel: every learner mode takes the same step)
+    else adam_elem<1, 1>(pi, mi, vi, gi, sg, c, beta1, beta2, eps);
     p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+// ---- the optimiser launch of a single-rank minibatch step (round 5) ---------------------------------------------------------------
+// adam2_kernel's arithmetic (adam_elem / norm_coef_block are the same statements, so the same bits), re-tiled so that the launch can also do
+// the three jobs trunk_adv_kernel did at the head of the NEXT step -- that launch (8 us, all of it latency on the critical path of every
+// minibatch step) disappears from cirs_ppo_learn's loop:
+//   [0, n_t)            T: trunk forward of 8 rows of the next minibatch.  The trunk has 5.6 k parameters: every T workgroup forms their
+//                          updated values itself (gradient, moments, clip coefficient -> Adam, into LDS; nothing is written) and runs the
+//                          rollout's fma chains on them, while the A / P workgroups beside it write the same values to memory.
+//   [n_t, n_t + n_s)    S: advantage statistics of the next minibatch (no dependency on the update)
+//   next n_p            P: Adam on one 32-item tile of Wa (8 consecutive elements of a head row per thread) + the tile's bf16 planes from
+//                          the updated registers (what wa_planes_block re-read from memory)
+//   rest                A: Adam on everything else ([trunk | ba | wc | bc]); the first A workgroup reduces the loss terms and publishes them
+// Without a next step (n_t = n_s = 0) it is the step's Adam launch and nothing else.
+struct AdamNext {
+    int n_t, n_s, n_p;
+    cirs_policy_cfg pcfg;
+    const float* obs_flat; const int32_t* idx; int mb, n_pad;      // next minibatch: rows idx[0 .. mb) of the buffer-order batch
+    const float* adv_flat; const int32_t* sidx; int m_stats, enable; float* red;
+    uint4* planes;
+    const float* snap;                                             // [3][snap_stride(S)]: p | m | v of [trunk | wc | bc] as of before this launch
+    float* snap_next;                                              // the same for the step after this one, written by the A workgroups
+    int s_magic;                                                   // ceil(65536 / S): i / S = (i * s_magic) >> 16 for i < 2048
+    int pa_delay;                                                  // P / A workgroups start this many x 1024 cycles late (the T workgroups' requests go first)
+    cirs_ppo_batch bt; int n_env;
+    TrunkRowOut out;
+};
+// clip_grad_norm_ stage 2 in every workgroup (256 threads): the same fixed tree over the same slots -> the same coefficient everywhere
+__device__ __forceinline__ float norm_coef_block(float part_a, float part_b, const cirs_ppo_cfg& cfg, float* sh, float& total_norm) {
+    const int tid = threadIdx.x;
+    static_assert(kNormBlocks == 256 && kWaSumBlocks <= 256, "each thread folds one slot of each kind");
+    sh[tid] = part_a + part_b;      // slot tid of sumsq_partial_kernel / the F workgroups + slot tid of the wa|ba slab-sum workgroups
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    total_norm = sqrtf(sh[0]);
+    float c = 1.0f;
+    if (cfg.max_grad_norm > 0.f) c = fminf(cfg.max_grad_norm / (total_norm + 1e-6f), 1.0f);
+    return c;
+}
+__device__ __forceinline__ float norm_coef_block(const float* __restrict__ partial, const cirs_ppo_cfg& cfg, float* sh, float& total_norm) {
+    const int tid = threadIdx.x;
+    return norm_coef_block(partial[tid], tid < kWaSumBlocks ? partial[kNormBlocks + tid] : 0.f, cfg, sh, total_norm);
+}
+constexpr int kTrunkQ4 = 7;          // 256 x 7 float4 >= 64 (S + 66) floats, S <= 32: the trunk's parameters, four elements per thread and pass
+constexpr int kTrunkRowsPerWg = kTileM;   // rows of a T workgroup: one MFMA row tile
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    PpoLayout L; AdamSeg sa, sb; float beta1, beta2, eps; cirs_ppo_cfg cfg;
+    const float* partial; float* tail; float* loss_out; int mb, mb_norm;
+};
+struct AdamLds {
+    float sh[256];
+    float sh3[768];
+    __attribute__((aligned(16))) float lt[12288];               // T: TrunkTileLds (weights + the tiles of its 32 rows);  P: the item tile's fp32 image [32][65]
+};
+// T: the trunk forward of 32 rows of the NEXT minibatch on the weights this launch forms.
+//   requests first: the rows' gathers (idx -> obs row, row scalars) and the trunk's gradient / parameters / moments (float4s; the parameters and
+//   moments from the SNAPSHOT dh2_sum_kernel took earlier in this step -- the A workgroups of this very launch overwrite the live values in place);
+//   then the clip coefficient, Adam of the 5.6 k trunk parameters into LDS (nothing is written to memory: the A workgroups do that), and the two
+//   layers on the fp32 matrix cores: D[feature][row] = W X^T as v_mfma_f32_32x32x2_f32 k-steps in ascending k from the bias -- bit for bit the
+//   sequential fma chain of trunk_compute (MI355X_MICROARCH.md: the fp32 MFMA is an fma chain; the lane with hi = 0 supplies k = 2 s, hi = 1
+//   k = 2 s + 1), so the rows equal what trunk_adv_kernel / the rollout compute.  Waves 0, 1 own one 32-feature tile each; the critic chains run
+//   one row per lane; the outputs leave as whole tiles (coalesced float4 rows, H2's bf16 planes as 16-byte units of the head kernels' layout).
+constexpr int kTS = kH + 1;          // LDS row stride of the T role's tiles (odd: lane = row reads are conflict-free)
+struct TrunkTileLds {                // overlays AdamLds::lt
+    float w2[kH * kTS];
+    float w1[kH * 33];
+    float vec[4 * kH];               // b1 | b2 | wc | bc
+    float x[kTileM * 33];
+    float h1[kTileM * kTS];
+    float h2[kTileM * kTS];
+    int ri[kTileM];
+    float dump[32];
+};
+constexpr int kTW1 = kH * kTS, kTVec = kTW1 + kH * 33, kTDump = kTVec + 4 * kH + kTileM * 33 + 2 * kTileM * kTS + kTileM;
+__device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNext& nx, AdamLds& l, int b) {
+    const int tid = threadIdx.x, S = a.cfg.dim_state;
+    const int lane = tid & 63, wv = tid >> 6, hi = lane >> 5, lo = lane & 31;
+    const int j0 = b * kTileM;
+    TrunkTileLds& t = *reinterpret_cast<TrunkTileLds*>(l.lt);
+    const int ldx = S | 1;
+    // ---- requests, the long ones first (memory returns in order: a dependent gather issued early would hold the parameter loads back) -------
+    const int n_tr = (int)a.L.trunk, n4 = n_tr >> 2;          // (n_tr = 64 (S + 66): a multiple of 4)
+    const int n_sn = snap_stride(S);
+    const float* sp = nx.snap; const float* sm = nx.snap + n_sn; const float* sv = nx.snap + 2 * n_sn;
+    f32x4 g4[kTrunkQ4], p4[kTrunkQ4], m4[kTrunkQ4], v4[kTrunkQ4];
+#pragma unroll
+    for (int q = 0; q < kTrunkQ4; ++q) {
+        const int e4 = tid + 256 * q;
+        const int ec = (e4 < n4 ? e4 : 0) * 4;
+        g4[q] = *reinterpret_cast<const f32x4*>(a.g + ec); p4[q] = *reinterpret_cast<const f32x4*>(sp + ec);
+        m4[q] = *reinterpret_cast<const f32x4*>(sm + ec); v4[q] = *reinterpret_cast<const f32x4*>(sv + ec);
+    }
+    const int tc = tid < kH + 1 ? tid : 0;                     // wc | bc: 65 elements of the head segment
+    float gc = a.g[a.L.wc + tc], pc = sp[n_tr + tc], mc = sm[n_tr + tc], vc = sv[n_tr + tc];
+    const float part_a = a.partial[tid], part_b = tid < kWaSumBlocks ? a.partial[kNormBlocks + tid] : 0.f;      // (norm_coef_block's two loads)
+    // obs elements of the 32 rows: element i = row * S + k, three passes of 256 threads cover S <= 24; the rest (S <= 32) in a fourth
+    int xrow[4], xk[4], xri[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + 256 * q;
+        const int row = (i * nx.s_magic) >> 16;                 // i / S (s_magic = ceil(65536 / S), exact for i < 2048)
+        const bool ok = i < kTileM * S;
+        xrow[q] = ok ? row : 0; xk[q] = ok ? i - row * S : -1;
+        xri[q] = nx.idx[j0 + xrow[q]];
+    }
+    // row scalars: thread (field = tid / 32, row = tid % 32): act, row_t, row_env, adv, logp_old, ret, v_s
+    const int fr = tid & 31, ff = tid >> 5;
+    const bool frow_ok = j0 + fr < nx.mb;
+    const int fri = nx.idx[j0 + fr];
+    float tn;
+    const float c = norm_coef_block(part_a, part_b, a.cfg, l.sh, tn);
+    CIRS_PSTAMP(b == 0, 1);
+    // the dependent gathers (idx -> obs row / row scalars) are requested only now: they travel while the Adam arithmetic below runs
+    float xq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xq[q] = (xk[q] >= 0 && j0 + xrow[q] < nx.mb) ? nx.obs_flat[(size_t)xri[q] * S + xk[q]] : 0.f;      // rows >= mb: zeros (as trunk_rows)
+    int fi = 0; float fv = 0.f;
+    {
+        const void* srcp = ff == 0 ? (const void*)nx.bt.act : ff == 1 ? (const void*)nx.bt.row_t : ff == 2 ? (const void*)nx.bt.row_env
+                         : ff == 3 ? (const void*)nx.bt.adv : ff == 4 ? (const void*)nx.bt.logp_old : ff == 5 ? (const void*)nx.bt.ret : (const void*)nx.bt.v_s;
+        const int w32 = (frow_ok && ff < 7) ? reinterpret_cast<const int*>(srcp)[fri] : 0;       // (all seven fields are 4-byte arrays)
+        fi = w32; fv = __int_as_float(w32);
+    }
+    // ---- Adam of the trunk -> LDS (flat order [w1 | b1 | w2 | b2]) ------------------------------------------------------------
+    const int ld1 = S | 1, o_b1 = kH * S, o_w2 = o_b1 + kH, o_b2 = o_w2 + kH * kH;
+#pragma unroll
+    for (int q = 0; q < kTrunkQ4; ++q) {
+        const int e4 = tid + 256 * q;
+        if ((S & 3) == 0) {      // four consecutive elements never straddle a row or a region: one destination per float4
+            float pn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float pi = p4[q][u], mi = m4[q][u], vi = v4[q][u];
+                adam_elem<2, 2>(pi, mi, vi, g4[q][u], a.sa, c, a.beta1, a.beta2, a.eps);
+                pn[u] = pi;
+            }
+            const int e = 4 * e4;
+            const int r1 = (e * nx.s_magic) >> 16, r2 = e - o_w2;
+            const int d_w1 = kTW1 + r1 * ld1 + (e - r1 * S), d_b1 = kTVec + (e - o_b1), d_w2 = (r2 >> 6) * kTS + (r2 & 63), d_b2 = kTVec + kH + (e - o_b2);
+            int d = e < o_b2 ? d_w2 : d_b2;
+            d = e < o_w2 ? d_b1 : d;
+            d = e < o_b1 ? d_w1 : d;
+            d = e4 < n4 ? d : kTDump + (tid & 15);
+            l.lt[d] = pn[0]; l.lt[d + 1] = pn[1]; l.lt[d + 2] = pn[2]; l.lt[d + 3] = pn[3];
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float pi = p4[q][u], mi = m4[q][u], vi = v4[q][u];
+            adam_elem<2, 2>(pi, mi, vi, g4[q][u], a.sa, c, a.beta1, a.beta2, a.eps);
+            const int e = 4 * e4 + u;
+            const int r1 = (e * nx.s_magic) >> 16, r2 = e - o_w2;          // row of a W1 element (e < 64 S <= 2048: exact)
+            // offset inside TrunkTileLds as integer selects (a select between pointers compiled to a branch per region and element)
+            const int d_w1 = kTW1 + r1 * ld1 + (e - r1 * S), d_b1 = kTVec + (e - o_b1), d_w2 = (r2 >> 6) * kTS + (r2 & 63), d_b2 = kTVec + kH + (e - o_b2);
+            int d = e < o_b2 ? d_w2 : d_b2;
+            d = e < o_w2 ? d_b1 : d;
+            d = e < o_b1 ? d_w1 : d;
+            d = e4 < n4 ? d : kTDump + (tid & 31);                         // (threads beyond the trunk store to a dump row)
+            l.lt[d] = pi;
+        }
+    }
+    adam_elem<1, 1>(pc, mc, vc, gc, a.sb, c, a.beta1, a.beta2, a.eps);
+    if (tid < kH + 1) t.vec[2 * kH + tid] = pc;               // wc[0..63], bc at [3 * kH]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (xk[q] >= 0) { t.x[xrow[q] * ldx + xk[q]] = xq[q]; nx.out.obs_copy[(size_t)(j0 + xrow[q]) * S + xk[q]] = xq[q]; }
+    if (nx.out.act) {
+        if (ff == 0) nx.out.act[j0 + fr] = fi;
+        else if (ff == 1) t.ri[fr] = fi;                      // row_t; combined with row_env below
+        else if (ff >= 3 && ff < 7) nx.out.row4[(size_t)(ff - 3) * nx.n_pad + j0 + fr] = fv;
+    }
+    __syncthreads();
+    if (nx.out.act && ff == 2) nx.out.dst[j0 + fr] = frow_ok ? (long)t.ri[fr] * nx.n_env + fi : 0;
+    CIRS_PSTAMP(b == 0, 2);
+    // ---- layer 1: waves 0, 1 (feature tile wv) --------------------------------------------------------------------------------
+    if (wv < 2) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = t.vec[32 * wv + acc_row(r, hi)];              // b1
+        const float* wr = t.w1 + (32 * wv + lo) * ld1 + hi;
+        const float* xr = t.x + lo * ldx + hi;
+        const int ks = (S + 1) >> 1;
+        float av[16], bv[16];                                  // S <= 32: at most 16 k-steps, operands requested up front
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const bool kin = 2 * s2 + hi < S;                  // (odd S: the last k-step's upper half multiplies zeros)
+            av[s2] = kin ? wr[2 * s2] : 0.f; bv[s2] = kin ? xr[2 * s2] : 0.f;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2)
+            if (s2 < ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);      // (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t.h1[lo * kTS + 32 * wv + acc_row(r, hi)] = fmaxf(acc[r], 0.f);
+    }
+    __syncthreads();
+    // ---- layer 2 ----------------------------------------------------------------------------------------------------------------
+    if (wv < 2) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = t.vec[kH + 32 * wv + acc_row(r, hi)];         // b2
+        float av[32], bv[32];
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) { av[s2] = t.w2[(32 * wv + lo) * kTS + 2 * s2 + hi]; bv[s2] = t.h1[lo * kTS + 2 * s2 + hi]; }
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t.h2[lo * kTS + 32 * wv + acc_row(r, hi)] = fmaxf(acc[r], 0.f);
+    }
+    __syncthreads();
+    CIRS_PSTAMP(b == 0, 18);
+    // ---- outputs ----------------------------------------------------------------------------------------------------------------
+    if (wv == 3 && lane < kTileM) {      // critic: one row per lane, sequential chain (bit-reproducible)
+        float v = t.vec[3 * kH];
+        const float* hr = t.h2 + lane * kTS;
+#pragma unroll
+        for (int k = 0; k < kH; ++k) v = __builtin_fmaf(t.vec[2 * kH + k], hr[k], v);
+        nx.out.value[j0 + lane] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {        // h1 / h2 tiles as float4 rows
+        const int f = tid + 256 * q, row = f >> 4, c4 = (f & 15) * 4;
+        const float* s1 = t.h1 + row * kTS + c4; const float* s2 = t.h2 + row * kTS + c4;
+        *reinterpret_cast<f32x4*>(nx.out.h1 + (size_t)(j0 + row) * kH + c4) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4*>(nx.out.h2 + (size_t)(j0 + row) * kH + c4) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+    }
+    {   // H2 planes, 16-byte units of the head kernels' register order (trunk_row_planes: the same pieces, element by element)
+        const int tile = j0 >> 5;
+        // hz: unit (k-step s = tid / 64, lane' = (hi', row)) = columns 16 s + 8 hi' .. + 8 of the row
+        const int s4 = tid >> 6, hz_hi = (tid >> 5) & 1, hz_row = tid & 31;
+        const float* r = t.h2 + hz_row * kTS + 16 * s4 + 8 * hz_hi;
+        const Planes pz = split8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        uint4* z = nx.out.h2z + (size_t)(tile * 12 + s4 * 3) * 64 + (tid & 63);
+        z[0] = __builtin_bit_cast(uint4, pz.h); z[64] = __builtin_bit_cast(uint4, pz.m); z[128] = __builtin_bit_cast(uint4, pz.l);
+        // hb: unit (column half ch = tid / 128, t = (tid / 64) % 2, lane'' = (hi_b, column % 32)) = rows acc_row(8 t + jb, hi_b), jb < 8, of one column
+        const int ch = tid >> 7, tt = (tid >> 6) & 1, hb_hi = (tid >> 5) & 1, col = 32 * ch + (tid & 31);
+        float xb[8];
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) xb[jb] = t.h2[acc_row(8 * tt + jb, hb_hi) * kTS + col];
+        const Planes pb = split8(xb[0], xb[1], xb[2], xb[3], xb[4], xb[5], xb[6], xb[7]);
+        uint4* bq = nx.out.h2b + (size_t)(tile * 12 + (ch * 2 + tt) * 3) * 64 + (tid & 63);
+        bq[0] = __builtin_bit_cast(uint4, pb.h); bq[64] = __builtin_bit_cast(uint4, pb.m); bq[128] = __builtin_bit_cast(uint4, pb.l);
+    }
+}
+// P: thread = 8 consecutive elements of one head row (two float4: f = tid, tid + 256 of the tile's 512)
+__device__ __forceinline__ void adam_next_planes(const AdamArgs& a, const AdamNext& nx, AdamLds& l, int bp) {
+    const int tid = threadIdx.x, I = a.cfg.n_items;
+    const int tile0 = bp * kTileN;
+    f32x4 g4[2], p4[2], m4[2], v4[2];
+    size_t off[2];
+    bool ok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int f = tid + 256 * q, item = f >> 4, col = (f & 15) * 4;
+        ok[q] = tile0 + item < I;
+        off[q] = (size_t)a.L.wa + (size_t)(ok[q] ? tile0 + item : 0) * kH + col;
+        g4[q] = *reinterpret_cast<const f32x4*>(a.g + off[q]); p4[q] = *reinterpret_cast<const f32x4*>(a.p + off[q]);
+        m4[q] = *reinterpret_cast<const f32x4*>(a.m + off[q]); v4[q] = *reinterpret_cast<const f32x4*>(a.v + off[q]);
+    }
+    float tn;
+    const float c = norm_coef_block(a.partial, a.cfg, l.sh, tn);
+    CIRS_PSTAMP(nx.n_t > 0 && bp == 0, 9);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int f = tid + 256 * q, item = f >> 4, col = (f & 15) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float pi = p4[q][u], mi = m4[q][u], vi = v4[q][u];
+            adam_elem<1, 1>(pi, mi, vi, g4[q][u], a.sb, c, a.beta1, a.beta2, a.eps);
+            p4[q][u] = ok[q] ? pi : 0.f; m4[q][u] = mi; v4[q][u] = vi;          // (items beyond the catalogue: zero rows in the planes)
+        }
+        if (ok[q]) {
+            *reinterpret_cast<f32x4*>(a.p + off[q]) = p4[q]; *reinterpret_cast<f32x4*>(a.m + off[q]) = m4[q]; *reinterpret_cast<f32x4*>(a.v + off[q]) = v4[q];
+        }
+        float* d = &l.lt[item * 65 + col];
+        d[0] = p4[q][0]; d[1] = p4[q][1]; d[2] = p4[q][2]; d[3] = p4[q][3];
+    }
+    __syncthreads();
+    CIRS_PSTAMP(nx.n_t > 0 && bp == 0, 10);
+    wa_planes_from_lds(bp, nx.planes, l.lt);
+}
+// A: element e of [trunk | ba | wc | bc] -> flat index (the Wa matrix between them belongs to the P workgroups)
+__device__ __forceinline__ void adam_next_rest(const AdamArgs& a, const MbView& mv, AdamLds& l, int ba_, float* snap_next) {
+    const int tid = threadIdx.x;
+    if (ba_ == 0 && a.mb > 0) loss_partials_block(a.mb, a.mb_norm, mv, a.tail, l.sh3);
+    float total_norm;
+    const float c = norm_coef_block(a.partial, a.cfg, l.sh, total_norm);
+    if (ba_ == 0 && tid == 0) {
+        mv.red[4] = c;
+        mv.red[5] = total_norm;
+        const float clip = a.tail[0], vf = a.tail[1], ent = a.tail[2];
+        a.loss_out[0] = clip + a.cfg.vf_coef * vf - a.cfg.ent_coef * ent;
+        a.loss_out[1] = clip; a.loss_out[2] = vf; a.loss_out[3] = ent;
+    }
+    const long e = ba_ * 256L + tid;
+    const long i = e < a.L.trunk ? e : e + (long)a.cfg.n_items * kH;
+    if (i < a.L.total) {
+        float gi = a.g[i], pi = a.p[i], mi = a.m[i], vi = a.v[i];
+        if (i < a.L.trunk) adam_elem<2, 2>(pi, mi, vi, gi, a.sa, c, a.beta1, a.beta2, a.eps);
+        else adam_elem<1, 1>(pi, mi, vi, gi, a.sb, c, a.beta1, a.beta2, a.eps);
+        a.p[i] = pi; a.m[i] = mi; a.v[i] = vi;
+        if (snap_next && (i < a.L.trunk || i >= a.L.wc)) {      // [trunk | wc | bc] also into the next step's snapshot
+            const int es = i < a.L.trunk ? (int)i : (int)(a.L.trunk + (i - a.L.wc)), st = snap_stride(a.cfg.dim_state);
+            snap_next[es] = pi; snap_next[st + es] = mi; snap_next[2 * st + es] = vi;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void adam_next_kernel(AdamArgs a, MbView mv, AdamNext nx) {
+    __shared__ AdamLds l;
+    const int b = blockIdx.x;
+    const int nb = gridDim.x;
+    const bool pn = nx.n_t > 0;      // (probe builds stamp the launches that have a next step)
+    CIRS_PSTAMP(pn && b == 0, 0); CIRS_PSTAMP(pn && b == nx.n_t - 1, 4); CIRS_PSTAMP(pn && b == nx.n_t, 6); CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s, 8);
+    CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s + nx.n_p - 1, 12); CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s + nx.n_p, 14); CIRS_PSTAMP(pn && b == nb - 1, 16);
+    if (b >= nx.n_t + nx.n_s) for (int q = 0; q < nx.pa_delay; ++q) __builtin_amdgcn_s_sleep(16);
+    if (b < nx.n_t) adam_next_trunk(a, nx, l, b);
+    else if (b < nx.n_t + nx.n_s) adv_stats_block(nx.adv_flat, nx.sidx, nx.m_stats, nx.enable, nx.red, l.sh);
+    else if (b < nx.n_t + nx.n_s + nx.n_p) adam_next_planes(a, nx, l, b - nx.n_t - nx.n_s);
+    else adam_next_rest(a, mv, l, b - nx.n_t - nx.n_s - nx.n_p, nx.snap_next);
+    CIRS_PSTAMP(pn && b == 0, 3); CIRS_PSTAMP(pn && b == nx.n_t - 1, 5); CIRS_PSTAMP(pn && b == nx.n_t, 7); CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s, 11);
+    CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s + nx.n_p - 1, 13); CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s + nx.n_p, 15); CIRS_PSTAMP(pn && b == nb - 1, 17);
+    (void)pn; (void)nb;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -1724,15 +2391,9 @@ __global__ __launch_bounds__(256) void shard_adam_kernel(float* __restrict__ p, 
     if (i >= len || begin + i >= P) return;
     const AdamSeg sg = begin + i < n_first ? sa : sb;
     float gi = g[i];
-    for (int q = 0; q < sg.scale_pow; ++q) gi *= c;
     float pi = p[i], mi = m[i], vi = v[i];
-    for (int sub = 0; sub < sg.n_sub; ++sub) {
-        mi = mi + (1.0f - beta1) * (gi - mi);
-        vi = vi * beta2 + (1.0f - beta2) * gi * gi;
-        const float ss = sub == 0 ? sg.step_size0 : sg.step_size1;
-        const float b2 = sub == 0 ? sg.bc2s0 : sg.bc2s1;
-        pi = pi - ss * (mi / (sqrtf(vi) / b2 + eps));
-    }
+    if (sg.n_sub == 2) adam_elem<2, 2>(pi, mi, vi, gi, sg, c, beta1, beta2, eps);      // (the arithmetic of adam_next_kernel: every learner mode takes the same step)
+    else adam_elem<1, 1>(pi, mi, vi, gi, sg, c, beta1, beta2, eps);
     p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
@@ -1752,6 +2413,9 @@ static int launch_adam(float* p, const float* g, float* m, float* v, long n, lon
 }
 
 #ifdef CIRS_HEAD_PROF
+extern "C" int cirs_debug_step_prof(unsigned long long* out_host64) {
+    return hipMemcpyFromSymbol(out_host64, HIP_SYMBOL(cirs::g_step_prof), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
 extern "C" int cirs_debug_head_prof(unsigned long long* out_host32) {
     return hipMemcpyFromSymbol(out_host32, HIP_SYMBOL(cirs::g_head_prof), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }
@@ -1833,6 +2497,210 @@ extern "C" int cirs_adam_step(float* params, const float* grads, float* m, float
     return launch_adam(params, grads, m, v, n, step_before, n_sub, lr, beta1, beta2, eps, grad_scale, scale_pow, (hipStream_t)stream);
 }
 
+// ---- the launches of a minibatch step as separate pieces, so that cirs_ppo_minibatch (one step), cirs_ppo_minibatch_dp (the step cut at the
+// gradient all-reduce) and cirs_ppo_learn (all steps of an update from one call) issue the SAME kernels on the same data ---------------
+struct PpoRun {     // what does not change between the steps of a call
+    const cirs_ppo_cfg* cfg;
+    float *params, *grads, *adam_m, *adam_v;
+    const cirs_ppo_batch* batch;
+    int n_env;
+    void* workspace;
+    int n_pad_carve;        // the workspace is carved for this many rows (>= every step's n_pad), so consecutive steps of different size do not overlap
+    hipStream_t s;
+    int I, S;
+    cirs::PpoLayout L;
+    cirs_policy_cfg pcfg;
+    cirs_policy_weights w;
+    cirs::MbView v;
+    float* tail;            // {clip, vf, ent, 0} partials of this rank (behind the flat gradient)
+    bool merge_launch;      // CIRS_PPO_MERGE_KERNEL=1: the round-2 sequence with the merge of the statistics partials as a launch of its own (A/B runs)
+};
+struct PpoStep { const int32_t* idx; int mb; const int32_t* sidx; int mb_norm; float* dobs; float* loss_out; long opt_step; };
+
+static PpoRun ppo_run(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, const cirs_ppo_batch* batch, int n_env,
+                      void* workspace, int max_mb, hipStream_t s) {
+    using namespace cirs;
+    PpoRun r;
+    r.cfg = cfg; r.params = params; r.grads = grads; r.adam_m = adam_m; r.adam_v = adam_v; r.batch = batch; r.n_env = n_env; r.workspace = workspace;
+    r.n_pad_carve = n_pad_of(max_mb); r.s = s; r.I = cfg->n_items; r.S = cfg->dim_state;
+    r.L = ppo_layout(r.I, r.S);
+    r.pcfg = cirs_policy_cfg{r.I, r.S, kH};
+    r.w = cirs_policy_weights{params + r.L.w1, params + r.L.b1, params + r.L.w2, params + r.L.b2, params + r.L.wa, params + r.L.ba, params + r.L.wc,
+                              params + r.L.bc};
+    r.v = carve(workspace, r.n_pad_carve, r.I, r.S);
+    r.tail = grads + r.L.total;
+    const char* mk_ = getenv("CIRS_PPO_MERGE_KERNEL");      // (read per call: tests toggle it)
+    r.merge_launch = mk_ && atoi(mk_) != 0;
+    return r;
+}
+static cirs::TrunkRowOut trunk_out_of(const cirs::MbView& v) { return cirs::TrunkRowOut{v.h2, v.value, v.h1, v.obs, v.act, v.dst_row, v.adv, v.h2z, v.h2b}; }
+
+// 1+2. advantage statistics of the (global) minibatch, the trunk forward (same fma chains as the rollout -> ratio == 1 exactly while the
+//      weights are unchanged; rows gathered from the buffer-order batch through idx, v.obs keeps the copy for d W1) and the bf16 planes of Wa
+static int launch_trunk_adv(const PpoRun& r, const PpoStep& st) {
+    using namespace cirs;
+    const int n_pad = n_pad_of(st.mb);
+    const SnapJob sj{r.params, r.adam_m, r.adam_v, r.v.snap + (st.opt_step & 1) * 3 * (size_t)snap_stride(r.S), (int)r.L.trunk, r.L.wc};
+    hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(r.I, kTileN) + cdiv(snap_floats(r.S), 256)), dim3(256), 0, r.s, r.pcfg, r.w,
+                       (const float*)r.batch->obs, (long)r.S, n_pad, st.idx, st.mb, (const float*)r.batch->adv, st.sidx, st.mb_norm, (int)r.cfg->norm_adv,
+                       r.v.red, (int)cdiv(n_pad, 4), r.v.wa_planes, *r.batch, r.n_env, trunk_out_of(r.v), sj);
+    CIRS_CHECK_LAUNCH("trunk_adv_kernel");
+    return CIRS_OK;
+}
+// 3-5. head statistics, head backward (+ the merge of the statistics partials in its prologue), chunk-slab sums of d h2 (unless the trunk-backward
+//      launch of the single-rank step sums them itself)
+static int launch_head(const PpoRun& r, const PpoStep& st, int* n_bchunks_out, bool with_dh2_sum) {
+    using namespace cirs;
+    const int I = r.I, mb = st.mb, n_pad = n_pad_of(mb), n_slabs = n_row_blocks_of(n_pad);
+    const MbView& v = r.v;
+    ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
+    const int n_item_tiles = cdiv(I, kTileN);
+    // head statistics (log-sum-exp, E_p[z]) on the matrix cores from the bf16 planes of Wa; all workgroups co-resident (2 per CU) with equal tile counts
+    const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);   // measured: 1 / 2 / 3 workgroups per CU = 17.4 / 14.5 / 16.7 us
+    const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
+    CIRS_PROF_LAUNCH(2, r.s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, r.s, I, mb, n_pad, tpc_s,
+                                                (const uint4*)v.wa_planes, r.w.ba, (const uint4*)v.h2z, pv, (const int32_t*)v.act, v.za));
+    CIRS_CHECK_LAUNCH("head_stats_kernel");
+    // head backward; the merge of the statistics partials + row losses + backward coefficients (means over the global minibatch) run in
+    // its prologue (CIRS_PPO_MERGE_KERNEL=1: as a launch of their own, the round-2 sequence, for A/B runs)
+    const HeadMergeArgs hma{*r.cfg, *r.batch, st.idx, st.mb_norm, n_schunks, pv};
+    if (r.merge_launch) {
+        hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, r.s, *r.cfg, *r.batch, st.idx, mb, st.mb_norm, n_pad, n_schunks,
+                           r.n_env, pv, r.w.wa, r.w.ba, v, (const float*)nullptr, 0);
+        CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
+    }
+    // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
+    const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
+    const int n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
+    const dim3 bgrid((n_bchunks + 7) & ~7, n_slabs), bblock(kBwdWaves * 64);
+    if (r.cfg->ent_coef != 0.f) {
+        if (r.merge_launch) CIRS_PROF_LAUNCH(1, r.s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, false>), bgrid, bblock, 0, r.s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, r.w.ba, v, v.dwap, hma));
+        else CIRS_PROF_LAUNCH(1, r.s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, true>), bgrid, bblock, 0, r.s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, r.w.ba, v, v.dwap, hma));
+    } else {
+        if (r.merge_launch) CIRS_PROF_LAUNCH(1, r.s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, false>), bgrid, bblock, 0, r.s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, r.w.ba, v, v.dwap, hma));
+        else CIRS_PROF_LAUNCH(1, r.s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, true>), bgrid, bblock, 0, r.s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, r.w.ba, v, v.dwap, hma));
+    }
+    CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
+    if (with_dh2_sum) {
+        hipLaunchKernelGGL(dh2_sum_kernel, dim3(n_pad * (kH / 4) / 64 + cdiv(n_pad, 64)), dim3(64), 0, r.s, mb, n_pad, n_bchunks, v);
+        CIRS_CHECK_LAUNCH("dh2_sum_kernel");
+    }
+    *n_bchunks_out = n_bchunks;
+    return CIRS_OK;
+}
+// d wc/d bc, d W2/d b2, d W1/d b1 as one row slab per trunk-backward workgroup (32 rows)
+static cirs::DwJobs trunk_dw_jobs(const PpoRun& r, int n_pad) {
+    using namespace cirs;
+    const MbView& v = r.v;
+    DwJobs jobs{};
+    jobs.n = 3;
+    jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, r.grads + r.L.wc, r.grads + r.L.bc, 0, 0};
+    jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, r.grads + r.L.w2, r.grads + r.L.b2, 0, 0};
+    jobs.j[2] = DwJob{v.da1, kH, v.obs, r.S, kH, r.S, r.grads + r.L.w1, r.grads + r.L.b1, 0, 0};
+    const int n_dw_slabs = n_pad / kTileM;
+    int off = 0, out = 0;
+    for (int q = 0; q < 3; ++q) {
+        jobs.j[q].part_off = off;
+        off += n_dw_slabs * jobs.j[q].O * (jobs.j[q].K + 1);
+        out += jobs.j[q].O * (jobs.j[q].K + 1);
+    }
+    jobs.total_out = out;
+    return jobs;
+}
+// 6. trunk backward: d a2, d a1, d obs (scattered to the tracker-gradient tensor) + the slab sums of the wa|ba gradient as extra workgroups of
+//    the same launch.  fold: the launch also finishes the trunk / critic gradients and their squared-norm partials (single-rank step): no
+//    sumsq_partial_kernel launch.  Returns whether it folded.
+static int launch_trunk_bwd(const PpoRun& r, const PpoStep& st, int n_bchunks, bool want_fold, bool* folded) {
+    using namespace cirs;
+    static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");
+    CIRS_REQUIRE(r.S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
+    const int n_pad = n_pad_of(st.mb), n_slabs = n_row_blocks_of(n_pad);
+    const long seg = (long)r.I * kH + r.I;
+    const DwJobs jobs = trunk_dw_jobs(r, n_pad);
+    const char* nf_ = getenv("CIRS_PPO_NO_FOLD");
+    const bool fold = want_fold && !(nf_ && atoi(nf_) != 0);
+    const int n_f = cdiv(snap_floats(r.S), 512);       // F workgroups: 512 outputs of [trunk | wc | bc] each
+    const dim3 grid(n_pad / kTileM + kWaSumBlocks + (fold ? n_f : 0));
+    if (fold)
+        hipLaunchKernelGGL(trunk_bwd_kernel<true>, grid, dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1, r.w.w2, r.w.wc, r.v, st.dobs, r.grads,
+                           (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, jobs, r.v.dwp);
+    else
+        hipLaunchKernelGGL(trunk_bwd_kernel<false>, grid, dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1, r.w.w2, r.w.wc, r.v, st.dobs, r.grads,
+                           (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, jobs, r.v.dwp);
+    CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
+    *folded = fold;
+    return CIRS_OK;
+}
+// 6'. the single-rank step: chunk-slab sums + trunk backward + weight-gradient sums + squared-norm partials in one launch (trunk_rows_kernel)
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static bool rows_kernel_wanted() {
+    const char* e = getenv("CIRS_PPO_ROWS_KERNEL");       // =0: the round-4 sequence dh2_sum_kernel + trunk_bwd_kernel (+ fold), for A/B runs
+    return !(e && atoi(e) == 0);
+}
+static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks) {
+    using namespace cirs;
+    CIRS_REQUIRE(r.S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
+    const int n_pad = n_pad_of(st.mb), n_slabs = n_row_blocks_of(n_pad);
+    const long seg = (long)r.I * kH + r.I;
+    const int n_r = n_pad / kRR, n_f = cdiv(snap_floats(r.S), kFOut);
+    hipLaunchKernelGGL(trunk_rows_kernel, dim3(n_r + kWaSumBlocks + n_f), dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1, r.w.w2, r.w.wc, r.v, st.dobs,
+                       r.grads, (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, n_r, snap_stride(r.S), env_int("CIRS_PPO_W_DELAY", 0));
+    CIRS_CHECK_LAUNCH("trunk_rows_kernel");
+    return CIRS_OK;
+}
+static cirs::AdamSeg adam_seg_of(const cirs_ppo_cfg* cfg, long step_before, int n_sub, int scale_pow) {
+    cirs::AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f, 1.f, 1.f};
+    for (int q = 0; q < n_sub; ++q) {
+        const double t = (double)(step_before + 1 + q);
+        const float ss = (float)((double)cfg->lr / (1.0 - pow((double)cfg->beta1, t)));
+        const float bs = (float)sqrt(1.0 - pow((double)cfg->beta2, t));
+        const float rbs = (float)(1.0 / sqrt(1.0 - pow((double)cfg->beta2, t)));
+        if (q == 0) { sg.step_size0 = ss; sg.bc2s0 = bs; sg.rbc2s0 = rbs; } else { sg.step_size1 = ss; sg.bc2s1 = bs; sg.rbc2s1 = rbs; }
+    }
+    return sg;
+}
+// 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps 2k+1, 2k+2; heads: one step, coefficient once).
+//    single (phase 0): adam_next_kernel -- with `next` it also runs the head of the next step (trunk forward, advantage statistics, Wa planes);
+//    data-parallel phase 2: sumsq over the all-reduced flat gradient + adam2_kernel.
+static int launch_norm_adam(const PpoRun& r, const PpoStep& st, int phase, bool folded, const PpoStep* next) {
+    using namespace cirs;
+    const int n_pad = n_pad_of(st.mb);
+    const long seg = (long)r.I * kH + r.I;
+    const MbView& v = r.v;
+    if (!(phase == 0 && folded)) {
+        const DwJobs jobs = phase == 0 ? trunk_dw_jobs(r, n_pad) : DwJobs{};
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, r.s, r.grads, r.L.trunk, r.L.total, r.L.wa, seg, (int)(phase == 0), jobs,
+                           phase == 0 ? n_pad / kTileM : 0, phase == 0 ? (const float*)v.dwp : (const float*)nullptr, r.S, v.normp);
+        CIRS_CHECK_LAUNCH("sumsq_partial_kernel");
+    }
+    const AdamSeg sa = adam_seg_of(r.cfg, 2 * st.opt_step, 2, 2), sb = adam_seg_of(r.cfg, st.opt_step, 1, 1);
+    if (phase != 0) {
+        hipLaunchKernelGGL(adam2_kernel, dim3(cdiv(r.L.total, 256)), dim3(256), 0, r.s, r.params, r.grads, r.adam_m, r.adam_v, r.L.total, r.L.trunk, sa, sb,
+                           r.cfg->beta1, r.cfg->beta2, r.cfg->adam_eps, *r.cfg, v.normp, r.tail, v, st.loss_out, 0, st.mb_norm);
+        CIRS_CHECK_LAUNCH("adam2_kernel");
+        return CIRS_OK;
+    }
+    AdamNext nx{};
+    nx.n_p = cdiv(r.I, kTileN);
+    nx.planes = v.wa_planes;
+    if (next) {
+        const int np = n_pad_of(next->mb);
+        nx.n_t = np / kTrunkRowsPerWg; nx.n_s = 1;
+        nx.pcfg = r.pcfg; nx.obs_flat = r.batch->obs; nx.idx = next->idx; nx.mb = next->mb; nx.n_pad = np;
+        nx.adv_flat = r.batch->adv; nx.sidx = next->sidx; nx.m_stats = next->mb_norm; nx.enable = (int)r.cfg->norm_adv; nx.red = v.red;
+        nx.bt = *r.batch; nx.n_env = r.n_env; nx.out = trunk_out_of(v); nx.s_magic = (65536 + r.S - 1) / r.S;
+        nx.snap = v.snap + (st.opt_step & 1) * 3 * (size_t)snap_stride(r.S);
+        nx.snap_next = v.snap + ((st.opt_step + 1) & 1) * 3 * (size_t)snap_stride(r.S);
+        nx.pa_delay = env_int("CIRS_PPO_PA_DELAY", 4);      // (A/B on one box: 0 / 4 / 8 -> 77.3 / 76.7 / 77.2 us per step)
+    }
+    const int n_a = cdiv(r.L.trunk + r.I + kH + 1, 256);
+    const AdamArgs aa{r.params, r.grads, r.adam_m, r.adam_v, r.L, sa, sb, r.cfg->beta1, r.cfg->beta2, r.cfg->adam_eps, *r.cfg, v.normp, r.tail, st.loss_out, st.mb,
+                      st.mb_norm};
+    hipLaunchKernelGGL(adam_next_kernel, dim3(nx.n_t + nx.n_s + nx.n_p + n_a), dim3(256), 0, r.s, aa, v, nx);
+    CIRS_CHECK_LAUNCH("adam_next_kernel");
+    return CIRS_OK;
+}
+
 static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
                               const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb, const int32_t* idx_global,
                               int32_t mb_global, float* dobs_accum, int32_t n_env, float* loss_out, void* workspace,
@@ -1843,148 +2711,27 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
     CIRS_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0, 1 or 2");
     CIRS_REQUIRE(mb >= 1 && mb_global >= 2 && mb <= mb_global, "bad minibatch sizes (need mb_global >= 2 for the unbiased std)");
     CIRS_REQUIRE(workspace_bytes >= cirs_ppo_workspace_bytes(cfg, mb), "workspace too small");
-    hipStream_t s = (hipStream_t)stream;
-    const int I = cfg->n_items, S = cfg->dim_state;
-    const int n_pad = n_pad_of(mb), n_chunks = n_chunks_of(I);
-    const PpoLayout L = ppo_layout(I, S);
-    MbView v = carve(workspace, n_pad, I, S);
-    cirs_policy_cfg pcfg{I, S, kH};
-    cirs_policy_weights w{params + L.w1, params + L.b1, params + L.w2, params + L.b2,
-                          params + L.wa, params + L.ba, params + L.wc, params + L.bc};
-    const long seg = (long)I * kH + I;
-    const int n_slabs = n_row_blocks_of(n_pad);
-    int n_wa_slabs = n_slabs;      // dWa slabs the trunk-backward launch sums: row blocks (fused backward) or row ranges (split head)
-    DwJobs dw_jobs{};
-    int n_dw_slabs = 0;
-    float* tail = grads + L.total;  // {clip, vf, ent, 0} partials of this rank
+    const PpoRun r = ppo_run(cfg, params, grads, adam_m, adam_v, batch, n_env, workspace, mb, (hipStream_t)stream);
+    const PpoStep st{idx, (int)mb, idx_global ? idx_global : idx, (int)(idx_global ? mb_global : mb), dobs_accum, loss_out, (long)opt_step};
+    bool folded = false;
     if (phase == 0 || phase == 1) {
         CIRS_REQUIRE(idx != nullptr, "idx is null");
-        const int32_t* sidx = idx_global ? idx_global : idx;
-        // 1+2. advantage statistics of the (global) minibatch (last workgroup) and the trunk forward (same fma chains as
-        //    the rollout -> ratio == 1 exactly while the weights are unchanged); rows are gathered from the buffer-order
-        //    batch through idx inside the kernel (v.obs keeps the copy for d W1)
-        hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
-                           v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, sidx, (int)(idx_global ? mb_global : mb),
-                           (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b, *batch, (int)n_env, v.act, v.dst_row, v.adv, v.arrive, n_slabs);
-        CIRS_CHECK_LAUNCH("trunk_adv_kernel");
-        ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
-        const int n_item_tiles = cdiv(I, kTileN);
-        const char* mk_ = getenv("CIRS_PPO_MERGE_KERNEL");      // (read per call: tests toggle it)
-        const bool merge_launch = mk_ && atoi(mk_) != 0;
-        // CIRS_PPO_HEAD=split: the slab-free head kernels of ppo_head_split.h; =fused: the round-3 kernels (statistics + fused backward + chunk-slab
-        // sums).  Default: whichever the A/B runs of the round measured faster on the benchmark workload (tests run both).
-        const char* hk_ = getenv("CIRS_PPO_HEAD");
-        const bool want_split = hk_ ? (hk_[0] == 's') : kHeadSplitDefault;
-        const HeadSplitGeom hg = head_split_geom(I, n_pad);
-        const bool split_head = want_split && cfg->ent_coef == 0.f && !merge_launch && hg.tiles_per_range * kTileM <= kDwaMaxRows;
         int n_bchunks = 0;
-        if (split_head) {
-            // 3. head forward: statistics partials + O' = P Wa per (row block, item chunk): all workgroups co-resident (1 per CU), equal tile counts
-            const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
-            const int n_fch = cdiv(n_item_tiles, tpc);          // <= n_chunks: the partial arrays and the O' slabs fit
-            // the four SoA arrays of the statistics view, used as two [chunk][row] float2 arrays
-            float2* part_ms = reinterpret_cast<float2*>(pv.score);
-            float2* part_tz = reinterpret_cast<float2*>(pv.m);
-            const HeadRowArgs hra{*cfg, (int)(idx_global ? mb_global : mb), n_fch, v.arrive, v, v.row_m};
-            CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_fwd_kernel, dim3((n_fch + 7) & ~7, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc,
-                                                      (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, (const int32_t*)v.act, part_ms, part_tz, v.dh2p, v.za, v.ez, hra));
-            CIRS_CHECK_LAUNCH("head_fwd_kernel");
-            // 4. head backward: row merge (lse, loss terms, coefficients) + d h2 fold + dWa / dba, one dWa slab per row range
-            const HeadDwaArgs da{n_fch, tpc, hg.n_groups, hg.n_ranges, hg.tiles_per_range, (const float2*)part_ms, (const float*)v.row_m, v.dh2p,
-                                 (const float*)w.wa, v.entw};
-            v.n_entw = hg.n_groups * hg.n_ranges;
-            CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL(head_dwa_kernel, dim3(hg.n_groups, hg.n_ranges), dim3(kDwaThreads), 0, s, I, (int)mb, n_pad,
-                                                      (const uint4*)v.wa_planes, w.ba, v, v.dwap, da));
-            CIRS_CHECK_LAUNCH("head_dwa_kernel");
-            n_wa_slabs = hg.n_ranges;
-        } else {
-            // 3. head statistics (log-sum-exp, E_p[z]) on the matrix cores from the bf16 planes of Wa written by launch 1;
-            //    all workgroups co-resident (2 per CU) with equal tile counts
-            const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);   // measured: 1 / 2 / 3 workgroups per CU = 17.4 / 14.5 / 16.7 us
-            const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
-            CIRS_PROF_LAUNCH(2, s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, s, I, (int)mb, n_pad, tpc_s,
-                                                      (const uint4*)v.wa_planes, w.ba, (const uint4*)v.h2z, pv, (const int32_t*)v.act, v.za));
-            CIRS_CHECK_LAUNCH("head_stats_kernel");
-            // 4+5. head backward; the merge of the statistics partials + row losses + backward coefficients (means over the global minibatch) run in
-            // its prologue (CIRS_PPO_MERGE_KERNEL=1: as a launch of their own, the round-2 sequence, for A/B runs)
-            const HeadMergeArgs hma{*cfg, *batch, idx, (int)(idx_global ? mb_global : mb), n_schunks, pv};
-            if (merge_launch) {
-                hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, s, *cfg, *batch, idx, (int)mb,
-                                   (int)(idx_global ? mb_global : mb), n_pad, n_schunks, (int)n_env, pv, w.wa, w.ba, v, (const float*)nullptr, 0);
-                CIRS_CHECK_LAUNCH("head_stats_merge_kernel");
-            }
-            // chunking of the backward kernel: all workgroups co-resident (1 per CU) with equal tile counts -> no tail round
-            const int tpc = head_tiles_per_chunk(n_item_tiles, n_slabs, 1);
-            n_bchunks = cdiv(n_item_tiles, tpc);  // <= n_chunks: the d h2 / entropy partial slabs fit
-            const dim3 bgrid((n_bchunks + 7) & ~7, n_slabs), bblock(kBwdWaves * 64);
-            if (cfg->ent_coef != 0.f) {
-                if (merge_launch) CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, false>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
-                else CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<true, true>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
-            } else {
-                if (merge_launch) CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, false>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
-                else CIRS_PROF_LAUNCH(1, s, hipLaunchKernelGGL((head_bwd_fused_kernel<false, true>), bgrid, bblock, 0, s, I, mb, n_pad, tpc, (const uint4*)v.wa_planes, w.ba, v, v.dwap, hma));
-            }
-            CIRS_CHECK_LAUNCH("head_bwd_fused_kernel");
-        }
-        // 6. trunk backward: d a2 (sum of the chunk partials), d a1, d obs (scattered to the tracker-gradient tensor)
-        static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");
-        CIRS_REQUIRE(S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
-        // d wc/d bc, d W2/d b2, d W1/d b1: single-rank path = one row slab per trunk-backward workgroup (32 rows), summed in slab
-        // order by sumsq_partial_kernel; data-parallel phase 1 = dw_multi launch pair with the final sums
-        DwJobs jobs;
-        jobs.n = 3;
-        jobs.j[0] = DwJob{v.dvalue, 1, v.h2, kH, 1, kH, grads + L.wc, grads + L.bc, 0, 0};
-        jobs.j[1] = DwJob{v.da2, kH, v.h1, kH, kH, kH, grads + L.w2, grads + L.b2, 0, 0};
-        jobs.j[2] = DwJob{v.da1, kH, v.obs, S, kH, S, grads + L.w1, grads + L.b1, 0, 0};
-        n_dw_slabs = n_pad / kTileM;
-        {
-            int off = 0, out = 0;
-            for (int q = 0; q < 3; ++q) {
-                jobs.j[q].part_off = off;
-                off += n_dw_slabs * jobs.j[q].O * (jobs.j[q].K + 1);
-                out += jobs.j[q].O * (jobs.j[q].K + 1);
-            }
-            jobs.total_out = out;
-        }
-        dw_jobs = jobs;
-        // (+ the slab sums of the wa|ba gradient as extra workgroups of the same launch: the flat gradient's wa|ba segment is
-        // complete after this launch)
-        if (!split_head) {      // (the split path's head_dwa_kernel leaves d h2 folded in slab 0 and the entropy correction in entw)
-            hipLaunchKernelGGL(dh2_sum_kernel, dim3(n_pad * (kH / 4) / 64 + cdiv(n_pad, 64)), dim3(64), 0, s, (int)mb, n_pad, n_bchunks, v);
-            CIRS_CHECK_LAUNCH("dh2_sum_kernel");
-        }
-        hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM + kWaSumBlocks), dim3(512), 0, s, (int)mb, n_pad, n_bchunks, S,
-                           w.w1, w.w2, w.wc, v, dobs_accum, grads, (long)L.wa, seg, (long)dwa_slab_stride(I), n_wa_slabs, jobs, v.dwp);
-        CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
+        const bool rows = phase == 0 && rows_kernel_wanted();
+        if (int rc = launch_trunk_adv(r, st)) return rc;
+        if (int rc = launch_head(r, st, &n_bchunks, !rows)) return rc;
+        if (rows) { if (int rc = launch_trunk_rows(r, st, n_bchunks)) return rc; folded = true; }
+        else if (int rc = launch_trunk_bwd(r, st, n_bchunks, phase == 0, &folded)) return rc;
         if (phase == 1) {  // gradients + loss partials must be complete in `grads` before the caller's all-reduce
-            hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(jobs.total_out, 256)), dim3(256), 0, s, jobs, n_dw_slabs, (const float*)v.dwp);
+            const DwJobs jobs = trunk_dw_jobs(r, n_pad_of(mb));
+            hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(jobs.total_out, 256)), dim3(256), 0, r.s, jobs, n_pad_of(mb) / kTileM, (const float*)r.v.dwp);
             CIRS_CHECK_LAUNCH("dw_multi_final");
-            hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, s, mb, mb_global, v, tail);
+            hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, r.s, (int)mb, st.mb_norm, r.v, r.tail);
             CIRS_CHECK_LAUNCH("loss_partials_kernel");
             return CIRS_OK;
         }
     }
-    // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps; heads: once)
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg,
-                       (int)(phase == 0), dw_jobs, n_dw_slabs,
-                       phase == 0 ? (const float*)v.dwp : (const float*)nullptr, S, v.normp);
-    CIRS_CHECK_LAUNCH("sumsq_partial_kernel");
-    auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
-        AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};
-        for (int q = 0; q < n_sub; ++q) {
-            const double t = (double)(step_before + 1 + q);
-            const float ss = (float)((double)cfg->lr / (1.0 - pow((double)cfg->beta1, t)));
-            const float bs = (float)sqrt(1.0 - pow((double)cfg->beta2, t));
-            if (q == 0) { sg.step_size0 = ss; sg.bc2s0 = bs; } else { sg.step_size1 = ss; sg.bc2s1 = bs; }
-        }
-        return sg;
-    };
-    // trunk: two sequential sub-steps (steps 2k+1, 2k+2), clip coefficient squared; heads: one step, coefficient once
-    hipLaunchKernelGGL(adam2_kernel, dim3(cdiv(L.total, 256)), dim3(256), 0, s, params, grads, adam_m, adam_v, L.total, L.trunk,
-                       seg_of(2 * opt_step, 2, 2), seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, *cfg, v.normp, tail, v,
-                       loss_out, phase == 0 ? (int)mb : 0, (int)(idx_global ? mb_global : mb));
-    CIRS_CHECK_LAUNCH("adam2_kernel");
-    return CIRS_OK;
+    return launch_norm_adam(r, st, phase, folded, nullptr);
 }
 
 extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
@@ -1994,6 +2741,67 @@ extern "C" int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float*
     if (mb < 2) return cirs::fail(CIRS_E_INVALID, "minibatch needs >= 2 rows (unbiased std)");
     return ppo_minibatch_impl(cfg, params, grads, adam_m, adam_v, opt_step, batch, idx, mb, nullptr, mb, dobs_accum, n_env, loss_out,
                               workspace, workspace_bytes, 0, stream);
+}
+
+// Batch.split(size, merge_last=True) (tianshou/data/batch.py:734-744): minibatch k of n rows -> [begin, end)
+static int ppo_slice_count(int n, int bs) {
+    int k = 0;
+    const bool merge_last = n % bs > 0;
+    for (int s0 = 0; s0 < n; s0 += bs) { ++k; if (merge_last && s0 + 2 * bs >= n) break; }
+    return k;
+}
+static void ppo_slice(int n, int bs, int k, int* b, int* e) {
+    const bool merge_last = n % bs > 0;
+    const int s0 = k * bs;
+    *b = s0;
+    *e = (merge_last && s0 + 2 * bs >= n) ? n : (s0 + bs < n ? s0 + bs : n);
+}
+extern "C" int32_t cirs_ppo_learn_steps(int32_t n_rows, int32_t batch_size, int32_t n_repeat) {
+    if (n_rows < 1 || batch_size < 1 || n_repeat < 1) return 0;
+    return n_repeat * ppo_slice_count(n_rows, batch_size);
+}
+extern "C" int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
+                              const cirs_ppo_batch* batch, const int32_t* perms, int32_t n_rows, int32_t batch_size, int32_t n_repeat,
+                              float* dobs_accum, int64_t dobs_floats, int32_t n_env, float* losses, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+    using namespace cirs;
+    if (int rc = validate_ppo(cfg)) return rc;
+    CIRS_REQUIRE(params && grads && adam_m && adam_v && batch && perms && losses && workspace, "null argument");
+    CIRS_REQUIRE(n_rows >= 2 && batch_size >= 2 && n_repeat >= 1, "need n_rows >= 2, batch_size >= 2, n_repeat >= 1");
+    CIRS_REQUIRE(!dobs_accum || dobs_floats > 0, "dobs_floats must be the size of dobs_accum");
+    const int n_sl = ppo_slice_count(n_rows, batch_size);
+    int max_mb = 0;
+    for (int k = 0; k < n_sl; ++k) { int b, e; ppo_slice(n_rows, batch_size, k, &b, &e); CIRS_REQUIRE(e - b >= 2, "a minibatch of one row has no unbiased std"); max_mb = e - b > max_mb ? e - b : max_mb; }
+    CIRS_REQUIRE(workspace_bytes >= cirs_ppo_workspace_bytes(cfg, max_mb), "workspace too small");
+    const PpoRun r = ppo_run(cfg, params, grads, adam_m, adam_v, batch, n_env, workspace, max_mb, (hipStream_t)stream);
+    const char* pf_ = getenv("CIRS_PPO_LEARN_PREFETCH");      // =0: every step starts with its own trunk_adv_kernel launch (A/B runs, tests)
+    const bool prefetch = !(pf_ && atoi(pf_) == 0) && !r.merge_launch;
+    const int n_steps = n_repeat * n_sl;
+    auto step_of = [&](int k) {
+        const int rep = k / n_sl;
+        int b, e; ppo_slice(n_rows, batch_size, k % n_sl, &b, &e);
+        const int32_t* idx = perms + (size_t)rep * n_rows + b;
+        return PpoStep{idx, e - b, idx, e - b, (dobs_accum && rep == n_repeat - 1) ? dobs_accum : nullptr, losses + 4 * (size_t)k, (long)(opt_step + k)};
+    };
+    const bool rows = rows_kernel_wanted();
+    bool have_head = false;     // the head of step k (trunk forward, statistics, planes) already ran inside step k - 1's Adam launch
+    for (int k = 0; k < n_steps; ++k) {
+        const PpoStep st = step_of(k);
+        if (dobs_accum && k == (n_repeat - 1) * n_sl) {      // optim.zero_grad() at the top of the last repeat: only its d loss / d obs reaches the tracker
+            if (hipMemsetAsync(dobs_accum, 0, sizeof(float) * (size_t)dobs_floats, r.s) != hipSuccess) return fail(CIRS_E_LAUNCH, "hipMemsetAsync(dobs_accum)");
+        }
+        int n_bchunks = 0;
+        bool folded = false;
+        if (!have_head) { if (int rc = launch_trunk_adv(r, st)) return rc; }
+        if (int rc = launch_head(r, st, &n_bchunks, !rows)) return rc;
+        if (rows) { if (int rc = launch_trunk_rows(r, st, n_bchunks)) return rc; folded = true; }
+        else if (int rc = launch_trunk_bwd(r, st, n_bchunks, true, &folded)) return rc;
+        const bool has_next = prefetch && k + 1 < n_steps;
+        const PpoStep nxt = has_next ? step_of(k + 1) : PpoStep{};
+        if (int rc = launch_norm_adam(r, st, 0, folded, has_next ? &nxt : nullptr)) return rc;
+        have_head = has_next;
+    }
+    return CIRS_OK;
 }
 
 extern "C" int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v,
@@ -2038,8 +2846,8 @@ extern "C" int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, flo
     if (phase == 1) {
         CIRS_REQUIRE(stats4, "stats4 is null");
         hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
-                           v.h2, v.value, v.h1, idx, (int)mb, v.obs, (const float*)batch->adv, idx, (int)mb, (int)cfg->norm_adv, v.red,
-                           (int)cdiv(n_pad, 4), v.wa_planes, v.h2z, v.h2b, *batch, (int)n_env, (int32_t*)nullptr, (long*)nullptr, (float*)nullptr);
+                           idx, (int)mb, (const float*)batch->adv, idx, (int)mb, (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, *batch, (int)n_env,
+                           TrunkRowOut{v.h2, v.value, v.h1, v.obs, nullptr, nullptr, nullptr, v.h2z, v.h2b}, SnapJob{});
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);
@@ -2104,22 +2912,13 @@ extern "C" int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, flo
     }
     MbView v3 = v;
     v3.dh2p = red_dh2;      // the trunk backward reads the summed d h2 (slab 0 position) from the exchange buffer
-    hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM), dim3(512), 0, s, (int)mb, n_pad, 1, S, w.w1, w.w2, w.wc, v3, dobs_accum, grads,
+    hipLaunchKernelGGL(trunk_bwd_kernel<false>, dim3(n_pad / kTileM), dim3(512), 0, s, (int)mb, n_pad, 1, S, w.w1, w.w2, w.wc, v3, dobs_accum, grads,
                        (long)L.wa, seg, (long)dwa_slab_stride(I), n_slabs, jobs, v.dwp);
     CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg, 1, jobs, n_dw_slabs,
                        (const float*)v.dwp, S, v.normp);
     CIRS_CHECK_LAUNCH("sumsq_partial_kernel");
-    auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
-        AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};
-        for (int q = 0; q < n_sub; ++q) {
-            const double t = (double)(step_before + 1 + q);
-            const float ss = (float)((double)cfg->lr / (1.0 - pow((double)cfg->beta1, t)));
-            const float bs = (float)sqrt(1.0 - pow((double)cfg->beta2, t));
-            if (q == 0) { sg.step_size0 = ss; sg.bc2s0 = bs; } else { sg.step_size1 = ss; sg.bc2s1 = bs; }
-        }
-        return sg;
-    };
+    auto seg_of = [&](long step_before, int n_sub, int scale_pow) { return adam_seg_of(cfg, step_before, n_sub, scale_pow); };
     hipLaunchKernelGGL(adam2_kernel, dim3(cdiv(L.total, 256)), dim3(256), 0, s, params, grads, adam_m, adam_v, L.total, L.trunk,
                        seg_of(2 * opt_step, 2, 2), seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, *cfg, v.normp, tail, v3, loss_out,
                        (int)mb, (int)mb);
@@ -2150,16 +2949,7 @@ extern "C" int cirs_ppo_shard_adam(const cirs_ppo_cfg* cfg, float* params_shard,
     CIRS_REQUIRE(params_shard && grads_shard && adam_m_shard && adam_v_shard && stats_all, "null argument");
     CIRS_REQUIRE(shard_begin >= 0 && shard_len > 0 && world >= 1, "bad shard arguments");
     const PpoLayout L = ppo_layout(cfg->n_items, cfg->dim_state);
-    auto seg_of = [&](long step_before, int n_sub, int scale_pow) {
-        AdamSeg sg{n_sub, scale_pow, 0.f, 1.f, 0.f, 1.f};
-        for (int q = 0; q < n_sub; ++q) {
-            const double t = (double)(step_before + 1 + q);
-            const float ss = (float)((double)cfg->lr / (1.0 - pow((double)cfg->beta1, t)));
-            const float bs = (float)sqrt(1.0 - pow((double)cfg->beta2, t));
-            if (q == 0) { sg.step_size0 = ss; sg.bc2s0 = bs; } else { sg.step_size1 = ss; sg.bc2s1 = bs; }
-        }
-        return sg;
-    };
+    auto seg_of = [&](long step_before, int n_sub, int scale_pow) { return adam_seg_of(cfg, step_before, n_sub, scale_pow); };
     hipLaunchKernelGGL(shard_adam_kernel, dim3(cdiv(shard_len, 256)), dim3(256), 0, (hipStream_t)stream, params_shard, grads_shard,
                        adam_m_shard, adam_v_shard, (long)shard_begin, (long)shard_len, L.trunk, L.total, seg_of(2 * opt_step, 2, 2),
                        seg_of(opt_step, 1, 1), cfg->beta1, cfg->beta2, cfg->adam_eps, *cfg, stats_all, (int)world, loss_out);

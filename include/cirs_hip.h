@@ -356,6 +356,22 @@ int cirs_ppo_minibatch(const cirs_ppo_cfg* cfg, float* params, float* grads, flo
                        float* dobs_accum, int32_t n_env, float* loss_out, void* workspace, int64_t workspace_bytes,
                        void* stream);
 
+/* PPOPolicy.learn's loop (core/policy/ppo.py:173-233: `for step in range(repeat): for minibatch in batch.split(batch_size, merge_last=True)`) from
+ * ONE call: n_repeat passes over the n_rows buffer rows, pass r in the order perms[r * n_rows .. (r + 1) * n_rows) (device; the host's
+ * np.random.permutation of Batch.split, tianshou/data/batch.py:721-752), cut into minibatches of batch_size rows with the remainder merged into the
+ * last one (batch.py:734-744).  Every minibatch is exactly one cirs_ppo_minibatch step -- same kernels, same bits -- with optimiser step
+ * opt_step + k; what the call adds is that step k's optimiser launch also runs the head of step k + 1 (trunk forward of its rows on the updated
+ * weights, its advantage statistics, the bf16 planes of the updated Wa), so the loop has one launch less per step and the host leaves the loop's
+ * critical path (one ctypes call per update instead of one per step).  dobs_accum (nullable, dobs_floats floats): zeroed before the LAST pass and
+ * filled by it (ppo.py:174 zero_grad at the top of every repeat: only the last pass's d loss / d obs reaches the state tracker).
+ * losses [cirs_ppo_learn_steps(n_rows, batch_size, n_repeat)][4] = {loss, clip, vf, ent} per step.  workspace: cirs_ppo_workspace_bytes(cfg, m)
+ * for the largest minibatch m (< 2 * batch_size). */
+int32_t cirs_ppo_learn_steps(int32_t n_rows, int32_t batch_size, int32_t n_repeat);
+int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
+                   const cirs_ppo_batch* batch, const int32_t* perms, int32_t n_rows, int32_t batch_size, int32_t n_repeat,
+                   float* dobs_accum, int64_t dobs_floats, int32_t n_env, float* losses, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+
 /* Data-parallel form of cirs_ppo_minibatch for a learner sharded over ranks.  A GLOBAL minibatch of mb_global rows
  * (idx_global) is split by rows; this rank owns idx_local[mb_local].  Advantage normalisation uses the statistics of
  * the global minibatch (every rank holds the gathered buffer) and every mean is over mb_global rows, so the SUM over

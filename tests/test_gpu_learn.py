@@ -13,11 +13,11 @@ from test_oracle_learn import POL, load_learn
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fused", "split"], autouse=True)
-def head_path(request, monkeypatch):
-    """Every test of this file runs on both actor-head paths of the minibatch step (csrc/ppo.hip: CIRS_PPO_HEAD): the fused backward kernel of
-    round 3 and the slab-free pair head_fwd_kernel / head_dwa_kernel (csrc/ppo_head_split.h)."""
-    monkeypatch.setenv("CIRS_PPO_HEAD", request.param)
+@pytest.fixture(params=["prefetch", "head_launch"], autouse=True)
+def loop_mode(request, monkeypatch):
+    """Every test of this file runs cirs_ppo_learn both ways: with the head of step k + 1 (trunk forward, advantage statistics, Wa planes) inside
+    step k's optimiser launch (the default), and with a trunk_adv_kernel launch at the top of every step (CIRS_PPO_LEARN_PREFETCH=0)."""
+    monkeypatch.setenv("CIRS_PPO_LEARN_PREFETCH", "1" if request.param == "prefetch" else "0")
     return request.param
 
 
@@ -108,6 +108,72 @@ def test_merge_in_the_backward_prologue_equals_the_merge_launch(golden_dir, monk
         np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=2e-5)      # (Adam on near-zero gradients amplifies the 1e-7 of the logit)
         assert np.mean(np.abs(outs[0][1] - outs[1][1]) < 2e-6) > 0.99
         np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-6)
+
+
+def _random_case(I, B, T, seed, ent_coef=0.0, head_scale=1.5):
+    import policycase
+    rng = np.random.RandomState(seed)
+    arrs = policycase.random_weights(rng, I, head_scale=head_scale)
+    pp = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)) for k, v in arrs.items()}
+    lens = rng.randint(max(2, T // 3), T + 1, size=B)
+    acts = rng.randint(0, I, (B, T)); rews = rng.uniform(0, 1, (B, T))
+    dones = np.zeros((B, T), bool); dones[np.arange(B), lens - 1] = True
+    obs = rng.normal(size=(B, T + 1, 20)).astype(np.float32)
+    n = int(lens.sum())
+    return pp, lens, acts, rews, dones, obs, n, rng
+
+
+@pytest.mark.parametrize("I,B,T,bs,rep,ent_coef", [(500, 24, 10, 32, 2, 0.0), (3327, 64, 30, 1024, 2, 0.01), (10728, 160, 30, 1024, 2, 0.0),
+                                                   (10728, 100, 30, 512, 3, 0.0)])
+def test_learn_loop_equals_one_call_per_step(I, B, T, bs, rep, ent_coef, loop_mode):
+    """cirs_ppo_learn (all steps of an update from one call; step k's optimiser launch runs the head of step k + 1 on the weights it has just
+    formed) against one cirs_ppo_minibatch call per step: the same kernels on the same data, so losses, parameters, Adam moments and the
+    gradient towards the tracker are BIT-identical -- incl. a merged last minibatch of another size and the zeroing of d obs before the last pass."""
+    from cirs_hip.rollout import Trajectory
+    pp, lens, acts, rews, dones, obs, n, rng = _random_case(I, B, T, seed=I + bs, ent_coef=ent_coef)
+    value, logp = rollout_time_value_logp(pp, obs, acts, lens)
+    perms = [rng.permutation(n) for _ in range(rep)]
+    hyper = [0.95, 0.95, 0.2, 0.25, ent_coef, 0.5, 1e-3, bs, rep]
+    outs = []
+    for step_calls in (True, False):
+        traj = Trajectory(B, T, 20, "cuda")
+        upload_traj(traj, acts, rews, dones, lens, obs, value, logp)
+        ln, _ = make_learner(pp, I, B, T, hyper)
+        assert ln.prepare(traj, lens) == n
+        ln.dobs.fill_(7.0)          # (the last pass starts from zero either way)
+        losses = ln.learn(bs, rep, perms=perms, step_calls=step_calls)
+        torch.cuda.synchronize()
+        outs.append((losses.clone(), ln.params.clone(), ln.adam_m.clone(), ln.adam_v.clone(), ln.dobs.clone(), ln.opt_step))
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b)
+    assert outs[0][5] == outs[1][5] == rep * len(__import__("cirs_hip.learner", fromlist=["minibatch_slices"]).minibatch_slices(n, bs))
+
+
+def test_trunk_backward_in_one_launch_equals_the_three_launch_sequence(monkeypatch, loop_mode):
+    """The single-rank step's trunk backward is ONE launch (trunk_rows_kernel: chunk-slab sums of d h2, d a2 / d a1 / d obs, the trunk / critic weight
+    gradients summed over 8-row slabs behind an arrival counter, squared-norm partials) where rounds 3-4 had three (dh2_sum_kernel, trunk_bwd_kernel
+    over 32-row MFMA tiles, sumsq_partial_kernel; CIRS_PPO_ROWS_KERNEL=0 CIRS_PPO_NO_FOLD=1 keeps them).  Same d a2 / d a1 / d obs chains (bit-identical
+    first-step loss terms incl. the entropy); the weight gradients are summed over another slab partition, so gradients and parameters agree to fp32
+    round-off."""
+    from cirs_hip.rollout import Trajectory
+    I, B, T, bs = 10728, 96, 30, 1024
+    pp, lens, acts, rews, dones, obs, n, rng = _random_case(I, B, T, seed=11)
+    value, logp = rollout_time_value_logp(pp, obs, acts, lens)
+    perms = [rng.permutation(n) for _ in range(2)]
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CIRS_PPO_ROWS_KERNEL", flag)
+        monkeypatch.setenv("CIRS_PPO_NO_FOLD", "0" if flag == "1" else "1")
+        traj = Trajectory(B, T, 20, "cuda")
+        upload_traj(traj, acts, rews, dones, lens, obs, value, logp)
+        ln, _ = make_learner(pp, I, B, T, [0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, bs, 2])
+        ln.prepare(traj, lens)
+        l1 = ln.learn(bs, 1, perms=perms[:1], want_tracker_grad=False)[:1].clone()      # (the first step starts from identical parameters)
+        outs.append((ln.grads.clone(), l1, ln.params.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    g0, g1 = outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy()      # gradient of the LAST step: taken at parameters 1e-7 apart
+    np.testing.assert_allclose(g0, g1, rtol=1e-3, atol=1e-6 * np.abs(g1).max())
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy(), rtol=1e-4, atol=2e-5)
 
 
 def test_learner_dual_clip_and_recomputed_advantages_match_reference(golden_dir):

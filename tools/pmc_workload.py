@@ -1,5 +1,4 @@
-"""Workload of the PMC passes (tools/pmc_traffic.py): a few C3 bench steps (rollout + PPO update) on BOTH actor-head paths of the minibatch
-step, the K1-K2 gather+FM kernel at the micro-benchmark's shapes (one dispatch group per case, in the order of bench.gather_fm_probe), the
+"""Workload of the PMC passes (tools/pmc_traffic.py): a few C3 bench steps (rollout + PPO update), the K1-K2 gather+FM kernel at the micro-benchmark's shapes (one dispatch group per case, in the order of bench.gather_fm_probe), the
 DeepFM catalogue sweep / sweep-mode step -- every kernel whose HBM traffic bench.py quotes -- and three KNOWN-BYTES calibration launches
 of cirs_gather_rows over a 512 MiB table (far past L2 and the 256 MiB Infinity Cache): a streaming read of 256-byte rows, random 256-byte
 rows and random 128-byte rows.  Their counter values fix, per access pattern, the factor between FETCH_SIZE and bytes on this box."""
@@ -18,12 +17,9 @@ CAL_ROWS = 1 << 21      # launches per calibration case: 1; rows gathered per la
 wl = bench.WORKLOADS[os.environ.get("CIRS_PMC_WORKLOAD", "c3")]
 dev = torch.device("cuda:0")
 eng, _ = bench.build_engine(wl, 0, 1, dev)
-for mode in ("fused", "split"):
-    os.environ["CIRS_PPO_HEAD"] = mode
-    for _ in range(3):
-        eng.collect()
-        eng.update(1024, 2)
-os.environ.pop("CIRS_PPO_HEAD")
+for _ in range(3):
+    eng.collect()
+    eng.update(1024, 2)
 torch.cuda.synchronize()
 bench.gather_fm_probe(dev, reps=3)
 bench.deepfm_sweep_probe(wl, dev, reps=2)

@@ -2,7 +2,7 @@
 # All measurements of a round in one GPU call:  bash tools/profile_round.sh <tag>     -> gpurun_out/<tag>/
 #   bench JSON lines (c3, c2, c3 with --dropout 0.1), rocprofv3 kernel-trace summaries of the timed step (eval-mode and dropout-mode)
 #   and of the K1-K2 / sweep workload (tools/pmc_workload.py), the phase timeline, the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs).
-tag=${1:-r04y}
+tag=${1:-r05}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
@@ -11,20 +11,15 @@ python bench.py > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
 python bench.py --workload c2 --no-cpu-baseline --no-probes > $out/${tag}_bench_c2.json 2>> $out/bench_c3.err
 python bench.py --dropout 0.1 --no-cpu-baseline --no-probes > $out/${tag}_bench_c3_dropout.json 2>> $out/bench_c3.err
 cd /tmp
-for mode in eval dropout split; do
+for mode in eval dropout; do
   flags="--no-probes --no-cpu-baseline --steps 50 --warmup 15"; [ $mode = dropout ] && flags="$flags --dropout 0.1"
   rm -rf /tmp/prof_$mode
-  # (split: the same step with the slab-free head kernels, CIRS_PPO_HEAD=split)
-  if [ $mode = split ]; then export CIRS_PPO_HEAD=split; else unset CIRS_PPO_HEAD; fi
   timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_$mode -o p -- python $root/bench.py $flags > $out/${tag}_bench_c3_prof_$mode.json 2> $out/prof_$mode.err
-  unset CIRS_PPO_HEAD
   db=$(find /tmp/prof_$mode -name "*.db" | head -1)
-  sfx=""; [ $mode = dropout ] && sfx="_dropout"; [ $mode = split ] && sfx="_split_head"
+  sfx=""; [ $mode = dropout ] && sfx="_dropout"
   python $root/tools/kstats.py $db $out/${tag}_bench_c3${sfx}_kernel_stats.csv 40 > $out/kstats_$mode.txt
   [ $mode = eval ] && python $root/tools/step_timeline.py $db $out/${tag}_step_timeline.md > /dev/null
-  [ $mode = split ] && python $root/tools/step_timeline.py $db $out/${tag}_step_timeline_split_head.md > /dev/null
 done
-python $root/tools/ab_head_paths.py 20 200 > $out/${tag}_head_paths_ab.txt 2>> $out/bench_c3.err
 rm -rf /tmp/prof_k12
 timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_k12 -o p -- python $root/tools/pmc_workload.py > /dev/null 2> $out/prof_k12.err
 db=$(find /tmp/prof_k12 -name "*.db" | head -1)
@@ -34,6 +29,6 @@ python tools/pmc_traffic.py collect $tag > $out/pmc.txt 2>&1
 cp gpurun_out/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.md $out/ 2>/dev/null
 # stage stamps (probe build: bash tools/probes/build_prof_lib.sh before the GPU call)
 if [ -f tools/probes/libcirs_prof.so ]; then
-  { python tools/probes/head_prof.py; CIRS_PPO_HEAD=split python tools/probes/head_split_prof.py; python tools/probes/tbwd_prof.py; } > $out/${tag}_stage_stamps.txt 2> $out/stamps.err
+  { python tools/probes/head_prof.py; python tools/probes/tbwd_prof.py; } > $out/${tag}_stage_stamps.txt 2> $out/stamps.err
 fi
 tail -3 $out/kstats_eval.txt; head -c 600 $out/${tag}_bench_c3.json
