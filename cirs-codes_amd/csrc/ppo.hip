@@ -1256,7 +1256,6 @@ __device__ __forceinline__ void dw_tile_x_lds(const float* sX, int ldx, int K, i
 // the non-coherent caches (sc1 loads): the write-through form of MI355X_MICROARCH.md's inter-workgroup visibility rules -- no L2 write-back fence.
 __device__ __forceinline__ void st_sc1(float* p, float a) { __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool kSc1 = false>
 __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)[16], int K, int o0, int k0, float* __restrict__ out, int lane) {
     const int hi = lane >> 5, lo = lane & 31;
     const int o = o0 + lo, k = k0 + lo;
@@ -1275,14 +1274,11 @@ __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)
     }
     if (k_ok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float* d = out + (size_t)(o0 + acc_row(r, hi)) * (K + 1) + k;
-            if (kSc1) st_sc1(d, acc[r]); else *d = acc[r];
-        }
+        for (int r = 0; r < 16; ++r) out[(size_t)(o0 + acc_row(r, hi)) * (K + 1) + k] = acc[r];
     }
     if (k0 == 0) {
         bsum += __shfl_xor(bsum, 32, CIRS_WAVE);
-        if (hi == 0) { float* d = out + (size_t)o * (K + 1) + K; if (kSc1) st_sc1(d, bsum); else *d = bsum; }
+        if (hi == 0) out[(size_t)o * (K + 1) + K] = bsum;
     }
 }
 
@@ -1303,7 +1299,6 @@ __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)
 __global__ __launch_bounds__(64) void dh2_sum_kernel(int mb, int n_pad, int n_chunks, MbView v, float* __restrict__ tp_dh2 = nullptr,
                                                      float* __restrict__ tp_ent = nullptr) {
     const int n_f4_wgs = n_pad * (kH / 4) / 64;
-    if (blockIdx.x == 0 && threadIdx.x == 0) v.sync[0] = 0;       // arrival counter of a folding trunk-backward launch that follows
     if ((int)blockIdx.x < n_f4_wgs) {
         const size_t q4 = (size_t)blockIdx.x * 64 + threadIdx.x;
         float* p = v.dh2p + q4 * 4;
@@ -1389,12 +1384,6 @@ __global__ __launch_bounds__(256) void head_tp_fold_kernel(cirs_ppo_batch b, con
     out4[j] = m; out4[n_pad + j] = s; out4[2 * n_pad + j] = t; out4[3 * n_pad + j] = z;
 }
 
-// kFold (single-rank step): the launch also finishes the trunk / critic weight gradients and their share of the squared norm -- what a launch of
-// its own (sumsq_partial_kernel: 5 us for 5.6 k outputs) did.  The row workgroups write their dW row slabs through and count their arrival; 11 more
-// workgroups (F, the LAST of the grid: the row workgroups are dispatched before anything that waits for them) wait for the count and sum 512
-// outputs each over the slabs in slab order (the assignment output -> thread is fixed, so is every order of summation).  The hand-off (write-through
-// drain + atomic + a round trip to memory, ~4 us) runs beside the wa|ba slab-sum workgroups, which take as long as rows + hand-off together.
-template <bool kFold>
 __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n_chunks, int S, const float* __restrict__ w1,
                                                         const float* __restrict__ w2, const float* __restrict__ wc, MbView v,
                                                         float* __restrict__ dobs_accum, float* __restrict__ g, long wa_beg, long wa_len,
@@ -1411,65 +1400,13 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
     CIRS_TSTAMP(n_pad / kTileM, 24);
     if ((int)blockIdx.x >= n_pad / kTileM) {   // extra workgroups (single-rank path): slab sums of the wa|ba gradient
         const int b = (int)blockIdx.x - n_pad / kTileM;
-        if (kFold && b >= kWaSumBlocks) {      // F workgroups: 512 outputs of [trunk | wc | bc] each, one per thread
-            const int f = b - kWaSumBlocks;
-            const int n_row_wgs = n_pad / kTileM;
-            const int tid = threadIdx.x;
-            CIRS_PSTAMP(f == 0, 30);
-            if (tid == 0) {     // (bounded: a lost arrival must not hang the device; the parity tests would see the wrong sums)
-                int spins = 0;
-                while (__hip_atomic_load(v.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_row_wgs && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-            }
-            __syncthreads();
-            CIRS_PSTAMP(f == 0, 31);
-            // element e of [trunk | wc | bc]: job 2 = W1|b1, 1 = W2|b2, 0 = wc|bc (the mapping sumsq_partial_kernel uses)
-            const long n_trunk = (long)kH * S + kH + (long)kH * kH + kH, n_dw = n_trunk + kH + 1;
-            const long e = f * 512L + tid;
-            float sq = 0.f;
-            if (e < n_dw) {
-                const long i = e < n_trunk ? e : wa_beg + wa_len + (e - n_trunk);
-                int ji, q;
-                if (e < (long)kH * S) { ji = 2; q = (int)(e / S) * (S + 1) + (int)(e % S); }
-                else if (e < (long)kH * S + kH) { ji = 2; q = (int)(e - (long)kH * S) * (S + 1) + S; }
-                else if (e < (long)kH * S + kH + (long)kH * kH) { const int r = (int)(e - ((long)kH * S + kH)); ji = 1; q = (r / kH) * (kH + 1) + (r % kH); }
-                else if (e < n_trunk) { ji = 1; q = (int)(e - ((long)kH * S + kH + (long)kH * kH)) * (kH + 1) + kH; }
-                else { ji = 0; q = (int)(e - n_trunk); }
-                const int n_out = ji == 2 ? jobs.j[2].O * (jobs.j[2].K + 1) : ji == 1 ? jobs.j[1].O * (jobs.j[1].K + 1) : jobs.j[0].O * (jobs.j[0].K + 1);
-                const int p_off = ji == 2 ? jobs.j[2].part_off : ji == 1 ? jobs.j[1].part_off : jobs.j[0].part_off;
-                float x = 0.f;
-                for (int c0 = 0; c0 < n_row_wgs; c0 += 32) {     // all loads of a batch in flight, added in slab order
-                    float t32[32];
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_row_wgs) ? ld_sc1(dwp + p_off + (size_t)(c0 + u) * n_out + q) : 0.f;
-#pragma unroll
-                    for (int u = 0; u < 32; ++u) x += t32[u];
-                }
-                g[i] = x;
-                sq = (e < n_trunk ? 2.0f : 1.0f) * x * x;       // trunk parameters appear twice in the reference's list
-            }
-            CIRS_PSTAMP(f == 0, 32);
-            sA[tid] = sq;
-            __syncthreads();
-            for (int st = 256; st > 0; st >>= 1) {
-                if (tid < st) sA[tid] += sA[tid + st];
-                __syncthreads();
-            }
-            if (tid == 0) v.normp[f] = sA[0];
-            const int n_f = (int)((n_dw + 511) / 512);
-            if (f == 0 && tid >= n_f && tid < kNormBlocks) v.normp[tid] = 0.f;      // the slots no workgroup owns
-            CIRS_PSTAMP(f == 0, 33);
-            return;
-        }
-        CIRS_PSTAMP(b == 0, 26); CIRS_PSTAMP(b == kWaSumBlocks - 1, 28);
         wa_slab_sum_block(g, wa_beg, wa_len, v.dwap, slab_stride, n_slabs, b, v.normp + kNormBlocks + b, sA);
-        CIRS_PSTAMP(b == 0, 27); CIRS_PSTAMP(b == kWaSumBlocks - 1, 29);
         CIRS_TSTAMP(n_pad / kTileM, 25);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = blockIdx.x * kTileM;
-    CIRS_PSTAMP(kFold && blockIdx.x == 0, 20);
     // Everything the later stages read besides stage 1's own result -- W2, W1, the h1 / h2 / obs rows of the tile, dvalue -- depends on
     // nothing computed here.  A wavefront's memory instruction costs the CU's address unit ~16 cycles whatever its width, and eight
     // wavefronts share that unit: per-lane operand loads (32 + 16 dwords per lane, 64 more for the critic row) took longer to ISSUE
@@ -1523,7 +1460,6 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
     CIRS_TSTAMP(0, 17);
     __syncthreads();
     CIRS_TSTAMP(0, 18);
-    CIRS_PSTAMP(kFold && blockIdx.x == 0, 21);
     if (wv < 2) {  // d a1 tile: columns wv*32 .. +32
         const int n = wv * 32 + lo;
         float arow[32];
@@ -1554,7 +1490,7 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
         const int t = wv - 2;
         float xrow[16];
         dw_tile_x_lds(sH1, kLdsStride, kH, row0, mb, (t & 1) * 32, lane, xrow);
-        dw_tile_32rows<kFold>(sA, xrow, kH, (t >> 1) * 32, (t & 1) * 32, dwp + jobs.j[1].part_off + (size_t)blockIdx.x * (kH * (kH + 1)), lane);
+        dw_tile_32rows(sA, xrow, kH, (t >> 1) * 32, (t & 1) * 32, dwp + jobs.j[1].part_off + (size_t)blockIdx.x * (kH * (kH + 1)), lane);
     } else if (dwp && wv == 6) {  // d wc | d bc row slab: lane = column of h2
         float acc = 0.f, bs = 0.f;
         float dv32[kTileM], h32[kTileM];    // from the LDS tiles (dvalue is 0 there for rows beyond the minibatch)
@@ -1568,27 +1504,18 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
             }
         }
         float* out = dwp + jobs.j[0].part_off + (size_t)blockIdx.x * (kH + 1);
-        if (kFold) { st_sc1(out + lane, acc); if (lane == 0) st_sc1(out + kH, bs); }
-        else { out[lane] = acc; if (lane == 0) out[kH] = bs; }
+        out[lane] = acc;
+        if (lane == 0) out[kH] = bs;
     }
     CIRS_TSTAMP(0, 19);
     __syncthreads();
     CIRS_TSTAMP(0, 20);
-    CIRS_PSTAMP(kFold && blockIdx.x == 0, 22);
     if (dwp && wv < 2) {  // d W1 | d b1 row slab: two 32 x 32 tiles (S <= 32 columns), waves 0, 1
         float xrow[16];
         dw_tile_x_lds(sObs, S, S, row0, mb, 0, lane, xrow);
-        dw_tile_32rows<kFold>(sD, xrow, S, wv * 32, 0, dwp + jobs.j[2].part_off + (size_t)blockIdx.x * (kH * (S + 1)), lane);
+        dw_tile_32rows(sD, xrow, S, wv * 32, 0, dwp + jobs.j[2].part_off + (size_t)blockIdx.x * (kH * (S + 1)), lane);
     }
     CIRS_TSTAMP(0, 21);
-    if (kFold) {      // every slab store of this workgroup has left before its arrival is counted
-        CIRS_PSTAMP(blockIdx.x == 0, 23);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        CIRS_PSTAMP(blockIdx.x == 0, 24);
-        if (tid == 0) __hip_atomic_fetch_add(v.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        CIRS_PSTAMP(blockIdx.x == 0, 25);
-    }
     if (!dobs_accum) return;
     if (wv == 2) {
         float arow[32];
@@ -2607,34 +2534,23 @@ static cirs::DwJobs trunk_dw_jobs(const PpoRun& r, int n_pad) {
     jobs.total_out = out;
     return jobs;
 }
-// 6. trunk backward: d a2, d a1, d obs (scattered to the tracker-gradient tensor) + the slab sums of the wa|ba gradient as extra workgroups of
-//    the same launch.  fold: the launch also finishes the trunk / critic gradients and their squared-norm partials (single-rank step): no
-//    sumsq_partial_kernel launch.  Returns whether it folded.
-static int launch_trunk_bwd(const PpoRun& r, const PpoStep& st, int n_bchunks, bool want_fold, bool* folded) {
+// 6. trunk backward of the data-parallel step (and of CIRS_PPO_ROWS_KERNEL=0): d a2, d a1, d obs (scattered to the tracker-gradient tensor) over 32-row
+//    MFMA tiles + the slab sums of the wa|ba gradient as extra workgroups of the same launch; the weight gradients stay in row slabs
+static int launch_trunk_bwd(const PpoRun& r, const PpoStep& st, int n_bchunks) {
     using namespace cirs;
     static_assert(kH == 64, "trunk_bwd_kernel tiles assume hidden == 64");
     CIRS_REQUIRE(r.S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
     const int n_pad = n_pad_of(st.mb), n_slabs = n_row_blocks_of(n_pad);
     const long seg = (long)r.I * kH + r.I;
     const DwJobs jobs = trunk_dw_jobs(r, n_pad);
-    const char* nf_ = getenv("CIRS_PPO_NO_FOLD");
-    const bool fold = want_fold && !(nf_ && atoi(nf_) != 0);
-    const int n_f = cdiv(snap_floats(r.S), 512);       // F workgroups: 512 outputs of [trunk | wc | bc] each
-    const dim3 grid(n_pad / kTileM + kWaSumBlocks + (fold ? n_f : 0));
-    if (fold)
-        hipLaunchKernelGGL(trunk_bwd_kernel<true>, grid, dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1, r.w.w2, r.w.wc, r.v, st.dobs, r.grads,
-                           (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, jobs, r.v.dwp);
-    else
-        hipLaunchKernelGGL(trunk_bwd_kernel<false>, grid, dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1, r.w.w2, r.w.wc, r.v, st.dobs, r.grads,
-                           (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, jobs, r.v.dwp);
+    hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM + kWaSumBlocks), dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1, r.w.w2, r.w.wc, r.v, st.dobs,
+                       r.grads, (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, jobs, r.v.dwp);
     CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
-    *folded = fold;
     return CIRS_OK;
 }
-// 6'. the single-rank step: chunk-slab sums + trunk backward + weight-gradient sums + squared-norm partials in one launch (trunk_rows_kernel)
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static bool rows_kernel_wanted() {
-    const char* e = getenv("CIRS_PPO_ROWS_KERNEL");       // =0: the round-4 sequence dh2_sum_kernel + trunk_bwd_kernel (+ fold), for A/B runs
+    const char* e = getenv("CIRS_PPO_ROWS_KERNEL");       // =0: the round-4 sequence dh2_sum_kernel + trunk_bwd_kernel + sumsq_partial_kernel (A/B runs, tests)
     return !(e && atoi(e) == 0);
 }
 static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks) {
@@ -2721,7 +2637,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
         if (int rc = launch_trunk_adv(r, st)) return rc;
         if (int rc = launch_head(r, st, &n_bchunks, !rows)) return rc;
         if (rows) { if (int rc = launch_trunk_rows(r, st, n_bchunks)) return rc; folded = true; }
-        else if (int rc = launch_trunk_bwd(r, st, n_bchunks, phase == 0, &folded)) return rc;
+        else if (int rc = launch_trunk_bwd(r, st, n_bchunks)) return rc;
         if (phase == 1) {  // gradients + loss partials must be complete in `grads` before the caller's all-reduce
             const DwJobs jobs = trunk_dw_jobs(r, n_pad_of(mb));
             hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(jobs.total_out, 256)), dim3(256), 0, r.s, jobs, n_pad_of(mb) / kTileM, (const float*)r.v.dwp);
@@ -2795,7 +2711,7 @@ extern "C" int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* gra
         if (!have_head) { if (int rc = launch_trunk_adv(r, st)) return rc; }
         if (int rc = launch_head(r, st, &n_bchunks, !rows)) return rc;
         if (rows) { if (int rc = launch_trunk_rows(r, st, n_bchunks)) return rc; folded = true; }
-        else if (int rc = launch_trunk_bwd(r, st, n_bchunks, true, &folded)) return rc;
+        else if (int rc = launch_trunk_bwd(r, st, n_bchunks)) return rc;
         const bool has_next = prefetch && k + 1 < n_steps;
         const PpoStep nxt = has_next ? step_of(k + 1) : PpoStep{};
         if (int rc = launch_norm_adam(r, st, 0, folded, has_next ? &nxt : nullptr)) return rc;
@@ -2912,7 +2828,7 @@ extern "C" int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, flo
     }
     MbView v3 = v;
     v3.dh2p = red_dh2;      // the trunk backward reads the summed d h2 (slab 0 position) from the exchange buffer
-    hipLaunchKernelGGL(trunk_bwd_kernel<false>, dim3(n_pad / kTileM), dim3(512), 0, s, (int)mb, n_pad, 1, S, w.w1, w.w2, w.wc, v3, dobs_accum, grads,
+    hipLaunchKernelGGL(trunk_bwd_kernel, dim3(n_pad / kTileM), dim3(512), 0, s, (int)mb, n_pad, 1, S, w.w1, w.w2, w.wc, v3, dobs_accum, grads,
                        (long)L.wa, seg, (long)dwa_slab_stride(I), n_slabs, jobs, v.dwp);
     CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kNormBlocks), dim3(256), 0, s, grads, L.trunk, L.total, L.wa, seg, 1, jobs, n_dw_slabs,

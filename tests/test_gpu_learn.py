@@ -152,7 +152,7 @@ def test_learn_loop_equals_one_call_per_step(I, B, T, bs, rep, ent_coef, loop_mo
 def test_trunk_backward_in_one_launch_equals_the_three_launch_sequence(monkeypatch, loop_mode):
     """The single-rank step's trunk backward is ONE launch (trunk_rows_kernel: chunk-slab sums of d h2, d a2 / d a1 / d obs, the trunk / critic weight
     gradients summed over 8-row slabs behind an arrival counter, squared-norm partials) where rounds 3-4 had three (dh2_sum_kernel, trunk_bwd_kernel
-    over 32-row MFMA tiles, sumsq_partial_kernel; CIRS_PPO_ROWS_KERNEL=0 CIRS_PPO_NO_FOLD=1 keeps them).  Same d a2 / d a1 / d obs chains (bit-identical
+    over 32-row MFMA tiles, sumsq_partial_kernel; CIRS_PPO_ROWS_KERNEL=0 keeps them).  Same d a2 / d a1 / d obs chains (bit-identical
     first-step loss terms incl. the entropy); the weight gradients are summed over another slab partition, so gradients and parameters agree to fp32
     round-off."""
     from cirs_hip.rollout import Trajectory
@@ -163,7 +163,6 @@ def test_trunk_backward_in_one_launch_equals_the_three_launch_sequence(monkeypat
     outs = []
     for flag in ("1", "0"):
         monkeypatch.setenv("CIRS_PPO_ROWS_KERNEL", flag)
-        monkeypatch.setenv("CIRS_PPO_NO_FOLD", "0" if flag == "1" else "1")
         traj = Trajectory(B, T, 20, "cuda")
         upload_traj(traj, acts, rews, dones, lens, obs, value, logp)
         ln, _ = make_learner(pp, I, B, T, [0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, bs, 2])

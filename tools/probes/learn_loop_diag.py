@@ -30,7 +30,7 @@ def cmp(name, a, b):
     print(f"{name}: steps {a[0].shape[0]}, first differing step {bad[0] if len(bad) else None}, n differing {len(bad)}, max |dp| {np.abs(a[1] - b[1]).max():.3e}, "
           f"max |ddobs| {np.abs(a[2] - b[2]).max():.3e}", flush=True)
 
-OLD = {"CIRS_PPO_ROWS_KERNEL": "0", "CIRS_PPO_NO_FOLD": "1"}        # dh2_sum_kernel + trunk_bwd_kernel + sumsq_partial_kernel
+OLD = {"CIRS_PPO_ROWS_KERNEL": "0"}        # dh2_sum_kernel + trunk_bwd_kernel + sumsq_partial_kernel
 s_rows = run(True, {})
 cmp("steps/rows twice", s_rows, run(True, {}))
 s_old = run(True, OLD)
@@ -38,4 +38,3 @@ cmp("old sequence: steps vs loop(prefetch)", s_old, run(False, OLD))
 cmp("rows: steps vs loop(no prefetch)", s_rows, run(False, {"CIRS_PPO_LEARN_PREFETCH": "0"}))
 cmp("rows: steps vs loop(prefetch)", s_rows, run(False, {}))
 cmp("rows vs old sequence (steps)", s_rows, s_old)
-cmp("rows vs fold in trunk_bwd_kernel (steps)", s_rows, run(True, {"CIRS_PPO_ROWS_KERNEL": "0"}))

@@ -6,7 +6,7 @@ over the steps of the trace (the first `SKIP` steps are dropped as warm-up).
 
 phases:  rollout      first tracker_step_kernel of a collect  -> last rollout kernel
          prepare      end of rollout -> first trunk_adv_kernel (GAE, returns, permutations, tracker forward over the buffer)
-         minibatches  first trunk_adv_kernel -> last adam2_kernel of the update
+         minibatches  first trunk_adv_kernel -> last adam_next_kernel / adam2_kernel of the update
          tracker_bwd  after the last minibatch Adam -> next collect's first kernel (BPTT through the tracker, its Adam)
 """
 import sqlite3
@@ -42,12 +42,13 @@ def main():
         print("no steady-state steps found"); return
     agg = defaultdict(lambda: defaultdict(float))
     kern = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    gaps = defaultdict(lambda: [0, 0.0])
     for seg in steps:
         names = [k[0] for k in seg]
         r_end = max(i for i, n in enumerate(names) if is_roll(n))
         mb0 = min(i for i, n in enumerate(names) if n.startswith("trunk_adv_kernel"))
-        mb1 = max(i for i, n in enumerate(names) if n.startswith("adam2_kernel") and i > mb0 and
-                  any(m.startswith("trunk_adv_kernel") for m in names[max(0, i - 8):i]))
+        is_adam = lambda n: n.startswith("adam2_kernel") or n.startswith("adam_next_kernel")
+        mb1 = max(i for i, n in enumerate(names) if is_adam(n) and i > mb0)
         bounds = {"rollout": (0, r_end + 1), "prepare": (r_end + 1, mb0), "minibatches": (mb0, mb1 + 1), "tracker_bwd": (mb1 + 1, len(seg))}
         t_next = seg[-1][2]
         for ph, (a, b) in bounds.items():
@@ -62,6 +63,10 @@ def main():
             agg[ph]["launches"] += len(part)
             for n, s, e in part:
                 kern[ph][n][0] += 1; kern[ph][n][1] += e - s
+        for i in range(1, len(seg)):       # the largest gaps between consecutive kernels, keyed by (previous kernel -> next kernel)
+            gap = seg[i][1] - seg[i - 1][2]
+            if gap > 3000:
+                gaps[(seg[i - 1][0], seg[i][0])][0] += 1; gaps[(seg[i - 1][0], seg[i][0])][1] += gap
         agg["step"]["span"] += seg[-1][2] - seg[0][1]
         agg["step"]["busy"] += sum(e - s for _, s, e in seg)
         agg["step"]["launches"] += len(seg)
@@ -75,6 +80,9 @@ def main():
         out += ["", f"kernels of `{ph}` (per step):", "", "| kernel | launches | busy us |", "|---|---|---|"]
         for n, (c, t) in sorted(kern[ph].items(), key=lambda kv: -kv[1][1])[:14]:
             out.append(f"| {n} | {c/ns:.1f} | {t/ns/1e3:.1f} |")
+    out += ["", "gaps > 3 us between consecutive kernels (per step):", "", "| previous kernel -> next kernel | count | idle us |", "|---|---|---|"]
+    for (pa, pb), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:12]:
+        out.append(f"| {pa} -> {pb} | {c/ns:.2f} | {t/ns/1e3:.1f} |")
     txt = "\n".join(out)
     print(txt)
     if len(sys.argv) > 2:
