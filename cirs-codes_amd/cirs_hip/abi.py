@@ -139,6 +139,8 @@ SIGNATURES = {
                                    C.POINTER(PpoBatch), _P]),
     "cirs_ppo_minibatch": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32,
                                      _P, C.c_int32, _P, _P, C.c_int64, _P]),
+    "cirs_ppo_minibatch_dp_chain": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P,
+                                              _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P]),
     "cirs_ppo_learn_steps": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "cirs_ppo_learn": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, C.c_int32, C.c_int32,
                                  _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),

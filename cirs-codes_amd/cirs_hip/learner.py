@@ -202,24 +202,49 @@ class DeviceLearner:
     def learn_dp(self, global_batch, repeat, perms, rank, world, all_reduce, want_tracker_grad=True):
         """Data-parallel learn(): GLOBAL minibatches of `global_batch` rows (the reference's batch_size, CIRS-RL-kuaishou.py:89 /
         core/policy/ppo.py:180-181: the PPO configuration does not change with the number of ranks), rows rank::world of each
-        belong to this rank; `all_reduce(tensor)` sums a flat tensor over the ranks in place (torch.distributed.all_reduce)."""
+        belong to this rank; `all_reduce(tensor)` sums a flat tensor over the ranks in place (torch.distributed.all_reduce).
+        The steps run as a chain (cirs_ppo_minibatch_dp_chain): phase 2 of a step also runs the head of the next one (this rank's rows of the
+        next global minibatch on the weights it has just formed), so a step is 3 launches + all-reduce + 2 launches (7 + 2 before round 5)."""
         n = self.n_rows
         slices = minibatch_slices(n, global_batch)
-        losses = torch.zeros((repeat * len(slices), 4), dtype=torch.float32, device=self.device)
+        steps = [(rep, s0, e0) for rep in range(repeat) for s0, e0 in slices]
+        losses = torch.zeros((len(steps), 4), dtype=torch.float32, device=self.device)
         perm_all_d = self._perms_on_device(n, repeat, perms)
-        k = 0
-        for rep in range(repeat):
-            perm_d = perm_all_d[rep]
-            last = rep == repeat - 1
-            if last and want_tracker_grad:
+        n_local = lambda s0, e0: len(range(rank, e0 - s0, world))
+        max_ml = max(max(n_local(s0, e0) for _, s0, e0 in steps), 2)
+        assert min(n_local(s0, e0) for _, s0, e0 in steps) >= 1, "global minibatch smaller than the world size"
+        ws = self.workspace(max_ml)
+        if getattr(self, "_lidx2", None) is None or self._lidx2[0].numel() < max_ml:
+            self._lidx2 = [torch.empty(max(max_ml, 2048), dtype=torch.int32, device=self.device) for _ in range(2)]   # (step k's rows in buffer k & 1)
+
+        def rows_of(k):
+            rep, s0, e0 = steps[k]
+            g = perm_all_d[rep][s0:e0]
+            l = self._lidx2[k & 1][:n_local(s0, e0)]
+            l.copy_(g[rank::world])
+            return g, l
+
+        def call(phase, k, g, l, head_done, nxt):
+            rep = steps[k][0]
+            want = want_tracker_grad and rep == repeat - 1
+            ng, nl = nxt if nxt is not None else (None, None)
+            abi.check(self._lib.cirs_ppo_minibatch_dp_chain(
+                C.byref(self.cfg), self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.opt_step,
+                C.byref(self.batch), l.data_ptr(), int(l.numel()), g.data_ptr(), int(g.numel()), self.dobs.data_ptr() if (want and phase == 1) else None,
+                self.n_env, losses[k].data_ptr(), ws.data_ptr(), ws.numel(), phase, max_ml, int(head_done),
+                nl.data_ptr() if nl is not None else None, int(nl.numel()) if nl is not None else 0,
+                ng.data_ptr() if ng is not None else None, int(ng.numel()) if ng is not None else 0, self._stream()), f"cirs_ppo_minibatch_dp_chain(phase {phase})")
+
+        cur, head_done = rows_of(0), False
+        for k in range(len(steps)):
+            if want_tracker_grad and steps[k][0] == repeat - 1 and steps[k][1] == 0:
                 self.dobs.zero_()
-            for s0, e0 in slices:
-                g_idx = perm_d[s0:e0]
-                l_idx = self._local_rows(g_idx, rank, world)
-                self.mb_phase1(l_idx, g_idx, last and want_tracker_grad, losses[k])
-                all_reduce(self.grads)
-                self.mb_phase2(int(l_idx.numel()), int(g_idx.numel()), losses[k])
-                k += 1
+            call(1, k, cur[0], cur[1], head_done, None)
+            all_reduce(self.grads)
+            nxt = rows_of(k + 1) if k + 1 < len(steps) else None
+            call(2, k, cur[0], cur[1], False, nxt)
+            self.opt_step += 1
+            cur, head_done = nxt, nxt is not None
         return losses
 
     def learn_dp_sharded(self, global_batch, repeat, perms, rank, world, coll, want_tracker_grad=True):

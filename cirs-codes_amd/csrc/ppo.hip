@@ -1573,11 +1573,35 @@ __device__ __forceinline__ void st_sc1x2(float* p, float a, float b) {      // 8
 __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int n_chunks, int S, const float* __restrict__ w1, const float* __restrict__ w2,
                                                          const float* __restrict__ wc, MbView v, float* __restrict__ dobs_accum, float* __restrict__ g,
                                                          long wa_beg, long wa_len, long slab_stride, int n_slabs, int n_r, int rslab /* floats per R slab */,
-                                                         int w_delay /* W workgroups start this many x 1024 cycles late: the R workgroups' requests go first */) {
+                                                         int w_delay /* W workgroups start this many x 1024 cycles late: the R workgroups' requests go first */,
+                                                         float* __restrict__ tail_out /* data-parallel phase 1: {clip, vf, ent, 0} partials of this rank */, int mb_norm) {
     __shared__ RowsLds L;
     __shared__ float sRed[512];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int n_tr = kH * S + kH + kH * kH + kH, n_dw = n_tr + kH + 1;      // [w1 | b1 | w2 | b2] + [wc | bc]
+    const int n_f_wgs = (n_dw + kFOut - 1) / kFOut;
+    if (b >= n_r + kWaSumBlocks + n_f_wgs) {
+        // ---- loss partials of this rank (data-parallel step; the single-rank step forms them in its optimiser launch): needs the rows' entropies
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(v.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_r && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        __shared__ float sL[3][512];
+        float e = 0.f, c = 0.f, f = 0.f;
+        for (int r = tid; r < mb; r += 512) { e += ld_sc1(v.ent_row + r); c += v.clip_row[r]; f += v.vf_row[r]; }
+        sL[0][tid] = c; sL[1][tid] = f; sL[2][tid] = e;
+        __syncthreads();
+        for (int st = 256; st > 0; st >>= 1) {
+            if (tid < st) { sL[0][tid] += sL[0][tid + st]; sL[1][tid] += sL[1][tid + st]; sL[2][tid] += sL[2][tid + st]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const float inv = 1.0f / (float)mb_norm;
+            tail_out[0] = sL[0][0] * inv; tail_out[1] = sL[1][0] * inv; tail_out[2] = sL[2][0] * inv; tail_out[3] = 0.f;
+        }
+        return;
+    }
     if (b >= n_r + kWaSumBlocks) {
         // ---- F ----------------------------------------------------------------------------------------------------------------
         const int f = b - n_r - kWaSumBlocks;
@@ -1674,7 +1698,7 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
     for (int q = 0; q < 4; ++q) if (tid + 512 * q < kH * S) L.w1[tid + 512 * q] = w1t[q];
     if (tid < kRR * S) L.obs[(tid / S) * 32 + tid % S] = obv;
     if (n == 0) L.dv[r] = ok ? dvr : 0.f;
-    if (tid < kRR) v.ent_row[b * kRR + tid] = (b * kRR + tid) < mb ? hent + ent : 0.f;
+    if (tid < kRR) st_sc1(v.ent_row + b * kRR + tid, (b * kRR + tid) < mb ? hent + ent : 0.f);      // (written through: the loss workgroup of a data-parallel step reads it inside this launch)
     __syncthreads();
     CIRS_PSTAMP(b == 0, 21);
     // d a1 = (d a2 W2) relu'(h1): the matrix cores' order k = kk, 32 + kk
@@ -2553,14 +2577,15 @@ static bool rows_kernel_wanted() {
     const char* e = getenv("CIRS_PPO_ROWS_KERNEL");       // =0: the round-4 sequence dh2_sum_kernel + trunk_bwd_kernel + sumsq_partial_kernel (A/B runs, tests)
     return !(e && atoi(e) == 0);
 }
-static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks) {
+static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks, bool with_loss_partials) {
     using namespace cirs;
     CIRS_REQUIRE(r.S <= 32, "dim_state > 32 is not supported by the trunk backward kernel");
     const int n_pad = n_pad_of(st.mb), n_slabs = n_row_blocks_of(n_pad);
     const long seg = (long)r.I * kH + r.I;
     const int n_r = n_pad / kRR, n_f = cdiv(snap_floats(r.S), kFOut);
-    hipLaunchKernelGGL(trunk_rows_kernel, dim3(n_r + kWaSumBlocks + n_f), dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1, r.w.w2, r.w.wc, r.v, st.dobs,
-                       r.grads, (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, n_r, snap_stride(r.S), env_int("CIRS_PPO_W_DELAY", 0));
+    hipLaunchKernelGGL(trunk_rows_kernel, dim3(n_r + kWaSumBlocks + n_f + (with_loss_partials ? 1 : 0)), dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1,
+                       r.w.w2, r.w.wc, r.v, st.dobs, r.grads, (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, n_r, snap_stride(r.S),
+                       env_int("CIRS_PPO_W_DELAY", 0), with_loss_partials ? r.tail : (float*)nullptr, st.mb_norm);
     CIRS_CHECK_LAUNCH("trunk_rows_kernel");
     return CIRS_OK;
 }
@@ -2576,8 +2601,8 @@ static cirs::AdamSeg adam_seg_of(const cirs_ppo_cfg* cfg, long step_before, int 
     return sg;
 }
 // 7. clip_grad_norm_ + Adam (trunk: coefficient squared, two sub-steps 2k+1, 2k+2; heads: one step, coefficient once).
-//    single (phase 0): adam_next_kernel -- with `next` it also runs the head of the next step (trunk forward, advantage statistics, Wa planes);
-//    data-parallel phase 2: sumsq over the all-reduced flat gradient + adam2_kernel.
+//    adam_next_kernel -- with `next` it also runs the head of the next step (trunk forward, advantage statistics, Wa planes); data-parallel
+//    phase 2: the squared norm of the all-reduced flat gradient first (sumsq_partial_kernel).
 static int launch_norm_adam(const PpoRun& r, const PpoStep& st, int phase, bool folded, const PpoStep* next) {
     using namespace cirs;
     const int n_pad = n_pad_of(st.mb);
@@ -2590,12 +2615,6 @@ static int launch_norm_adam(const PpoRun& r, const PpoStep& st, int phase, bool 
         CIRS_CHECK_LAUNCH("sumsq_partial_kernel");
     }
     const AdamSeg sa = adam_seg_of(r.cfg, 2 * st.opt_step, 2, 2), sb = adam_seg_of(r.cfg, st.opt_step, 1, 1);
-    if (phase != 0) {
-        hipLaunchKernelGGL(adam2_kernel, dim3(cdiv(r.L.total, 256)), dim3(256), 0, r.s, r.params, r.grads, r.adam_m, r.adam_v, r.L.total, r.L.trunk, sa, sb,
-                           r.cfg->beta1, r.cfg->beta2, r.cfg->adam_eps, *r.cfg, v.normp, r.tail, v, st.loss_out, 0, st.mb_norm);
-        CIRS_CHECK_LAUNCH("adam2_kernel");
-        return CIRS_OK;
-    }
     AdamNext nx{};
     nx.n_p = cdiv(r.I, kTileN);
     nx.planes = v.wa_planes;
@@ -2610,42 +2629,58 @@ static int launch_norm_adam(const PpoRun& r, const PpoStep& st, int phase, bool 
         nx.pa_delay = env_int("CIRS_PPO_PA_DELAY", 4);      // (A/B on one box: 0 / 4 / 8 -> 77.3 / 76.7 / 77.2 us per step)
     }
     const int n_a = cdiv(r.L.trunk + r.I + kH + 1, 256);
-    const AdamArgs aa{r.params, r.grads, r.adam_m, r.adam_v, r.L, sa, sb, r.cfg->beta1, r.cfg->beta2, r.cfg->adam_eps, *r.cfg, v.normp, r.tail, st.loss_out, st.mb,
-                      st.mb_norm};
+    // (phase 2: the loss partials were all-reduced with the gradient: mb = 0 leaves `tail` as it is)
+    const AdamArgs aa{r.params, r.grads, r.adam_m, r.adam_v, r.L, sa, sb, r.cfg->beta1, r.cfg->beta2, r.cfg->adam_eps, *r.cfg, v.normp, r.tail, st.loss_out,
+                      phase == 0 ? st.mb : 0, st.mb_norm};
     hipLaunchKernelGGL(adam_next_kernel, dim3(nx.n_t + nx.n_s + nx.n_p + n_a), dim3(256), 0, r.s, aa, v, nx);
     CIRS_CHECK_LAUNCH("adam_next_kernel");
     return CIRS_OK;
 }
 
+// options of a data-parallel step that is part of a chain of steps (cirs_ppo_minibatch_dp_chain): the workspace is carved for the update's largest
+// local minibatch, phase 1 skips the head launch when the previous step's phase 2 already ran it, phase 2 runs the head of the next step
+struct DpChain { int max_mb; int head_done; const int32_t* next_idx; int next_mb; const int32_t* next_idx_global; int next_mb_global; };
 static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
                               const cirs_ppo_batch* batch, const int32_t* idx, int32_t mb, const int32_t* idx_global,
                               int32_t mb_global, float* dobs_accum, int32_t n_env, float* loss_out, void* workspace,
-                              int64_t workspace_bytes, int phase, void* stream) {
+                              int64_t workspace_bytes, int phase, void* stream, const DpChain* ch = nullptr) {
     using namespace cirs;
     if (int rc = validate_ppo(cfg)) return rc;
     CIRS_REQUIRE(params && grads && adam_m && adam_v && batch && loss_out && workspace, "null argument");
     CIRS_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0, 1 or 2");
     CIRS_REQUIRE(mb >= 1 && mb_global >= 2 && mb <= mb_global, "bad minibatch sizes (need mb_global >= 2 for the unbiased std)");
-    CIRS_REQUIRE(workspace_bytes >= cirs_ppo_workspace_bytes(cfg, mb), "workspace too small");
-    const PpoRun r = ppo_run(cfg, params, grads, adam_m, adam_v, batch, n_env, workspace, mb, (hipStream_t)stream);
+    const int carve_mb = ch ? (ch->max_mb > mb ? ch->max_mb : mb) : mb;
+    CIRS_REQUIRE(!ch || !ch->next_idx || ch->next_mb <= carve_mb, "next minibatch larger than max_mb");
+    CIRS_REQUIRE(workspace_bytes >= cirs_ppo_workspace_bytes(cfg, carve_mb), "workspace too small");
+    const PpoRun r = ppo_run(cfg, params, grads, adam_m, adam_v, batch, n_env, workspace, carve_mb, (hipStream_t)stream);
     const PpoStep st{idx, (int)mb, idx_global ? idx_global : idx, (int)(idx_global ? mb_global : mb), dobs_accum, loss_out, (long)opt_step};
     bool folded = false;
+    const bool rows = rows_kernel_wanted();
     if (phase == 0 || phase == 1) {
-        CIRS_REQUIRE(idx != nullptr, "idx is null");
+        CIRS_REQUIRE(idx != nullptr || (ch && ch->head_done), "idx is null");
         int n_bchunks = 0;
-        const bool rows = phase == 0 && rows_kernel_wanted();
-        if (int rc = launch_trunk_adv(r, st)) return rc;
+        if (!(ch && ch->head_done)) { if (int rc = launch_trunk_adv(r, st)) return rc; }
         if (int rc = launch_head(r, st, &n_bchunks, !rows)) return rc;
-        if (rows) { if (int rc = launch_trunk_rows(r, st, n_bchunks)) return rc; folded = true; }
-        else if (int rc = launch_trunk_bwd(r, st, n_bchunks)) return rc;
-        if (phase == 1) {  // gradients + loss partials must be complete in `grads` before the caller's all-reduce
-            const DwJobs jobs = trunk_dw_jobs(r, n_pad_of(mb));
-            hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(jobs.total_out, 256)), dim3(256), 0, r.s, jobs, n_pad_of(mb) / kTileM, (const float*)r.v.dwp);
-            CIRS_CHECK_LAUNCH("dw_multi_final");
-            hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, r.s, (int)mb, st.mb_norm, r.v, r.tail);
-            CIRS_CHECK_LAUNCH("loss_partials_kernel");
-            return CIRS_OK;
+        if (rows) {     // phase 1: the flat gradient and this rank's loss partials are complete in `grads` after this launch (the caller's all-reduce follows)
+            if (int rc = launch_trunk_rows(r, st, n_bchunks, phase == 1)) return rc;
+            folded = true;
+            if (phase == 1) return CIRS_OK;
+        } else {
+            if (int rc = launch_trunk_bwd(r, st, n_bchunks)) return rc;
+            if (phase == 1) {
+                const DwJobs jobs = trunk_dw_jobs(r, n_pad_of(mb));
+                hipLaunchKernelGGL(dw_multi_final, dim3(cdiv(jobs.total_out, 256)), dim3(256), 0, r.s, jobs, n_pad_of(mb) / kTileM, (const float*)r.v.dwp);
+                CIRS_CHECK_LAUNCH("dw_multi_final");
+                hipLaunchKernelGGL(loss_partials_kernel, dim3(1), dim3(256), 0, r.s, (int)mb, st.mb_norm, r.v, r.tail);
+                CIRS_CHECK_LAUNCH("loss_partials_kernel");
+                return CIRS_OK;
+            }
         }
+    }
+    if (ch && ch->next_idx && phase == 2) {
+        const PpoStep nxt{ch->next_idx, ch->next_mb, ch->next_idx_global ? ch->next_idx_global : ch->next_idx,
+                          ch->next_idx_global ? ch->next_mb_global : ch->next_mb, nullptr, nullptr, (long)opt_step + 1};
+        return launch_norm_adam(r, st, phase, folded, &nxt);
     }
     return launch_norm_adam(r, st, phase, folded, nullptr);
 }
@@ -2710,7 +2745,7 @@ extern "C" int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* gra
         bool folded = false;
         if (!have_head) { if (int rc = launch_trunk_adv(r, st)) return rc; }
         if (int rc = launch_head(r, st, &n_bchunks, !rows)) return rc;
-        if (rows) { if (int rc = launch_trunk_rows(r, st, n_bchunks)) return rc; folded = true; }
+        if (rows) { if (int rc = launch_trunk_rows(r, st, n_bchunks, false)) return rc; folded = true; }
         else if (int rc = launch_trunk_bwd(r, st, n_bchunks)) return rc;
         const bool has_next = prefetch && k + 1 < n_steps;
         const PpoStep nxt = has_next ? step_of(k + 1) : PpoStep{};
@@ -2727,6 +2762,20 @@ extern "C" int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, flo
     if (phase != 2 && !idx_global) return cirs::fail(CIRS_E_INVALID, "idx_global is null");
     return ppo_minibatch_impl(cfg, params, grads, adam_m, adam_v, opt_step, batch, idx_local, mb_local, idx_global, mb_global,
                               dobs_accum, n_env, loss_out, workspace, workspace_bytes, phase, stream);
+}
+
+extern "C" int cirs_ppo_minibatch_dp_chain(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
+                                           const cirs_ppo_batch* batch, const int32_t* idx_local, int32_t mb_local, const int32_t* idx_global,
+                                           int32_t mb_global, float* dobs_accum, int32_t n_env, float* loss_out, void* workspace,
+                                           int64_t workspace_bytes, int32_t phase, int32_t max_mb_local, int32_t head_done,
+                                           const int32_t* next_idx_local, int32_t next_mb_local, const int32_t* next_idx_global,
+                                           int32_t next_mb_global, void* stream) {
+    if (phase != 1 && phase != 2) return cirs::fail(CIRS_E_INVALID, "phase must be 1 or 2");
+    if (phase == 1 && !idx_global) return cirs::fail(CIRS_E_INVALID, "idx_global is null");
+    if (next_idx_local && (!next_idx_global || next_mb_local < 1 || next_mb_global < 2)) return cirs::fail(CIRS_E_INVALID, "bad next minibatch");
+    const DpChain ch{(int)max_mb_local, (int)head_done, next_idx_local, (int)next_mb_local, next_idx_global, (int)next_mb_global};
+    return ppo_minibatch_impl(cfg, params, grads, adam_m, adam_v, opt_step, batch, idx_local, mb_local, idx_global, mb_global, dobs_accum, n_env,
+                              loss_out, workspace, workspace_bytes, phase, stream, &ch);
 }
 
 // ---- tensor-parallel (item-sharded head) minibatch step ------------------------------------------------------------------------

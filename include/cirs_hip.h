@@ -386,6 +386,20 @@ int cirs_ppo_minibatch_dp(const cirs_ppo_cfg* cfg, float* params, float* grads, 
                           const int32_t* idx_global, int32_t mb_global, float* dobs_accum, int32_t n_env,
                           float* loss_out, void* workspace, int64_t workspace_bytes, int32_t phase, void* stream);
 
+/* cirs_ppo_minibatch_dp for a CHAIN of data-parallel steps (one update's minibatches; no reference counterpart, same semantics and bits as
+ * cirs_ppo_minibatch_dp step by step): the workspace is laid out for max_mb_local rows (the update's largest local minibatch), so that consecutive
+ * steps of different size share it;
+ *   phase 1, head_done != 0: the head of this step (trunk forward of its rows, advantage statistics of the global minibatch, Wa planes) already ran
+ *            inside the previous step's phase 2 -- three launches (head statistics, head backward, trunk backward incl. every gradient sum and this
+ *            rank's loss partials) instead of seven;
+ *   phase 2, next_idx_local != NULL: the optimiser launch also runs the head of the next step on the weights it forms (rows next_idx_local
+ *            [next_mb_local] of this rank, statistics over next_idx_global [next_mb_global]); the caller passes head_done = 1 to that step's phase 1. */
+int cirs_ppo_minibatch_dp_chain(const cirs_ppo_cfg* cfg, float* params, float* grads, float* adam_m, float* adam_v, int64_t opt_step,
+                                const cirs_ppo_batch* batch, const int32_t* idx_local, int32_t mb_local, const int32_t* idx_global,
+                                int32_t mb_global, float* dobs_accum, int32_t n_env, float* loss_out, void* workspace, int64_t workspace_bytes,
+                                int32_t phase, int32_t max_mb_local, int32_t head_done, const int32_t* next_idx_local, int32_t next_mb_local,
+                                const int32_t* next_idx_global, int32_t next_mb_global, void* stream);
+
 /* Tensor-parallel form of cirs_ppo_minibatch for an ITEM-SHARDED actor head (BASELINE configs[4]: the catalogue does not fit / is not
  * replicated; SURVEY 8(e): "actor head column-sharded over items with a cross-rank (max, sum-exp, ...) reduction").  No reference
  * counterpart (the reference is single-process); semantics = cirs_ppo_minibatch on one device with the whole catalogue.
