@@ -7,18 +7,20 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 cd $root
+# (the default line is the reference's training mode: tracker Dropout 0.1, position-keyed masks; --dropout 0 = eval-mode tracker)
 python bench.py > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
 python bench.py --workload c2 --no-cpu-baseline --no-probes > $out/${tag}_bench_c2.json 2>> $out/bench_c3.err
-python bench.py --dropout 0.1 --no-cpu-baseline --no-probes > $out/${tag}_bench_c3_dropout.json 2>> $out/bench_c3.err
+python bench.py --dropout 0 --no-cpu-baseline --no-probes > $out/${tag}_bench_c3_dropout_off.json 2>> $out/bench_c3.err
+python bench.py --dropout 0.1 --dropout-redraw --steps 20 --warmup 5 --no-cpu-baseline --no-probes > $out/${tag}_bench_c3_dropout_redraw.json 2>> $out/bench_c3.err
 cd /tmp
-for mode in eval dropout; do
-  flags="--no-probes --no-cpu-baseline --steps 50 --warmup 15"; [ $mode = dropout ] && flags="$flags --dropout 0.1"
+for mode in train eval; do
+  flags="--no-probes --no-cpu-baseline --steps 50 --warmup 15"; [ $mode = eval ] && flags="$flags --dropout 0"
   rm -rf /tmp/prof_$mode
   timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_$mode -o p -- python $root/bench.py $flags > $out/${tag}_bench_c3_prof_$mode.json 2> $out/prof_$mode.err
   db=$(find /tmp/prof_$mode -name "*.db" | head -1)
-  sfx=""; [ $mode = dropout ] && sfx="_dropout"
+  sfx=""; [ $mode = eval ] && sfx="_dropout_off"
   python $root/tools/kstats.py $db $out/${tag}_bench_c3${sfx}_kernel_stats.csv 40 > $out/kstats_$mode.txt
-  [ $mode = eval ] && python $root/tools/step_timeline.py $db $out/${tag}_step_timeline.md > /dev/null
+  [ $mode = train ] && python $root/tools/step_timeline.py $db $out/${tag}_step_timeline.md > /dev/null
 done
 rm -rf /tmp/prof_k12
 timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_k12 -o p -- python $root/tools/pmc_workload.py > /dev/null 2> $out/prof_k12.err
@@ -29,6 +31,6 @@ python tools/pmc_traffic.py collect $tag > $out/pmc.txt 2>&1
 cp gpurun_out/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.md $out/ 2>/dev/null
 # stage stamps (probe build: bash tools/probes/build_prof_lib.sh before the GPU call)
 if [ -f tools/probes/libcirs_prof.so ]; then
-  { python tools/probes/head_prof.py; python tools/probes/tbwd_prof.py; } > $out/${tag}_stage_stamps.txt 2> $out/stamps.err
+  { python tools/probes/head_prof.py; python tools/probes/step_prof.py; python tools/probes/tbwd_prof.py; } > $out/${tag}_stage_stamps.txt 2> $out/stamps.err
 fi
-tail -3 $out/kstats_eval.txt; head -c 600 $out/${tag}_bench_c3.json
+tail -3 $out/kstats_train.txt; head -c 600 $out/${tag}_bench_c3.json
