@@ -1657,25 +1657,32 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
     }
     // ---- R: thread (row r = tid / 64, column n = tid % 64) ----------------------------------------------------------------------
     CIRS_PSTAMP(b == 0, 20);
-    const int r = tid >> 6, n = tid & 63, row = b * kRR + r;      // row < n_pad (n_pad is a multiple of 32)
-    // requests: the slab column of this thread's element first (31 loads, chunk order), then the operands every later stage reads from LDS
-    float acc = 0.f;
-    {
-        const float* src = v.dh2p + (size_t)row * kH + n;
+    const int r = tid >> 6, n = tid & 63;
+    // requests: the chunk slabs of the rows first -- as float4 by the first 128 threads (thread = 4 columns of a row; 31 loads of 16 bytes, chunk
+    // order): a quarter of the load instructions of one column per thread, and the CU's address unit takes ~16 cycles per instruction whatever
+    // its width --, then the operands every later stage reads from LDS
+    const int r4 = (tid >> 4) & (kRR - 1), c4 = (tid & 15) * 4, row4 = b * kRR + r4;      // row4 < n_pad (n_pad is a multiple of 32)
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f}, h1q = acc4, h2q = acc4, wcq = acc4;
+    float dvr = 0.f;
+    if (tid < kRR * 16) {
+        const float* src = v.dh2p + (size_t)row4 * kH + c4;
         const size_t cstride = (size_t)n_pad * kH;
-        for (int c0 = 0; c0 < n_chunks; c0 += 32) {
-            float t32[32];
+        for (int c0 = 0; c0 < n_chunks; c0 += 16) {      // (16 x 16 bytes in flight per thread: 64 registers; 32 would leave one workgroup per CU)
+            f32x4 t16[16];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) t32[u] = (c0 + u < n_chunks) ? src[(size_t)(c0 + u) * cstride] : 0.f;
+            for (int u = 0; u < 16; ++u) t16[u] = (c0 + u < n_chunks) ? *reinterpret_cast<const f32x4*>(src + (size_t)(c0 + u) * cstride) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 32; ++u) acc += t32[u];
+            for (int u = 0; u < 16; ++u) acc4 += t16[u];
         }
+        h1q = *reinterpret_cast<const f32x4*>(v.h1 + (size_t)row4 * kH + c4);
+        h2q = *reinterpret_cast<const f32x4*>(v.h2 + (size_t)row4 * kH + c4);
+        wcq = *reinterpret_cast<const f32x4*>(wc + c4);
+        dvr = v.dvalue[row4];
     }
     const f32x4 w2a = *reinterpret_cast<const f32x4*>(w2 + (size_t)tid * 4), w2b = *reinterpret_cast<const f32x4*>(w2 + (size_t)(tid + 512) * 4);
     float w1t[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) w1t[q] = tid + 512 * q < kH * S ? w1[tid + 512 * q] : 0.f;   // W1 [64][S], S <= 32
-    const float h1v = v.h1[(size_t)row * kH + n], h2v = v.h2[(size_t)row * kH + n], wcn = wc[n], dvr = v.dvalue[row];
     const float obv = tid < kRR * S ? v.obs[(size_t)b * kRR * S + tid] : 0.f;
     float ent = 0.f, hent = 0.f;
     if (tid < kRR) {            // entropy per row = (lse - E_p[z]) + the chunks' clamp corrections, chunk order
@@ -1689,15 +1696,21 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
         }
         hent = v.h_ent[rr];
     }
-    const bool ok = row < mb;
-    const float da2 = (ok && h2v > 0.f) ? __builtin_fmaf(dvr, wcn, acc) : 0.f;
-    L.a2[r * kH + n] = da2; L.h1[r * kH + n] = h1v; L.h2[r * kH + n] = h2v;
+    if (tid < kRR * 16) {
+        const bool ok = row4 < mb;
+        f32x4 d4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d4[u] = (ok && h2q[u] > 0.f) ? __builtin_fmaf(dvr, wcq[u], acc4[u]) : 0.f;
+        *reinterpret_cast<f32x4*>(&L.a2[r4 * kH + c4]) = d4;
+        *reinterpret_cast<f32x4*>(&L.h1[r4 * kH + c4]) = h1q;
+        *reinterpret_cast<f32x4*>(&L.h2[r4 * kH + c4]) = h2q;
+        if ((tid & 15) == 0) L.dv[r4] = ok ? dvr : 0.f;
+    }
     *reinterpret_cast<f32x4*>(&L.w2[(tid >> 4) * kLdsStride + (tid & 15) * 4]) = w2a;
     *reinterpret_cast<f32x4*>(&L.w2[((tid + 512) >> 4) * kLdsStride + (tid & 15) * 4]) = w2b;
 #pragma unroll
     for (int q = 0; q < 4; ++q) if (tid + 512 * q < kH * S) L.w1[tid + 512 * q] = w1t[q];
     if (tid < kRR * S) L.obs[(tid / S) * 32 + tid % S] = obv;
-    if (n == 0) L.dv[r] = ok ? dvr : 0.f;
     if (tid < kRR) st_sc1(v.ent_row + b * kRR + tid, (b * kRR + tid) < mb ? hent + ent : 0.f);      // (written through: the loss workgroup of a data-parallel step reads it inside this launch)
     __syncthreads();
     CIRS_PSTAMP(b == 0, 21);
@@ -1710,7 +1723,7 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
             t = __builtin_fmaf(ar[kk], L.w2[kk * kLdsStride + n], t);
             t = __builtin_fmaf(ar[32 + kk], L.w2[(32 + kk) * kLdsStride + n], t);
         }
-        L.a1[r * kH + n] = h1v > 0.f ? t : 0.f;
+        L.a1[r * kH + n] = L.h1[r * kH + n] > 0.f ? t : 0.f;
     }
     __syncthreads();
     CIRS_PSTAMP(b == 0, 22);
@@ -2573,9 +2586,17 @@ static int launch_trunk_bwd(const PpoRun& r, const PpoStep& st, int n_bchunks) {
     return CIRS_OK;
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static bool rows_kernel_wanted() {
-    const char* e = getenv("CIRS_PPO_ROWS_KERNEL");       // =0: the round-4 sequence dh2_sum_kernel + trunk_bwd_kernel + sumsq_partial_kernel (A/B runs, tests)
-    return !(e && atoi(e) == 0);
+// Which trunk backward a step runs.  trunk_rows_kernel (one launch: chunk-slab sums, trunk backward, every gradient sum, squared-norm / loss
+// partials) or the round-4 sequence dh2_sum_kernel + trunk_bwd_kernel (+ sumsq_partial_kernel / dw_multi_final + loss_partials_kernel).  Measured on
+// one box at C3, 1024 rows (tools/ab_step.py, round 5): 78.5 us per step with trunk_rows_kernel against 77.2 us with the sequence -- its row workgroups
+// wait ~6 us for their 90 KB of operands and ~5 us for the write-through drain of their 22 KB gradient slab while the wa|ba slab sums load the
+// fabric, which costs more than the two launch boundaries it removes -- so the single-rank step keeps the sequence; a data-parallel rank's share of a
+// minibatch (128 rows at 8 ranks: 16 row workgroups) runs trunk_rows_kernel, where four launches of ~5 us each become one.  CIRS_PPO_ROWS_KERNEL=0/1
+// forces either (A/B runs, tests).
+static bool rows_kernel_wanted(int phase) {
+    const char* e = getenv("CIRS_PPO_ROWS_KERNEL");
+    if (e) return atoi(e) != 0;
+    return phase == 1;
 }
 static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks, bool with_loss_partials) {
     using namespace cirs;
@@ -2655,7 +2676,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
     const PpoRun r = ppo_run(cfg, params, grads, adam_m, adam_v, batch, n_env, workspace, carve_mb, (hipStream_t)stream);
     const PpoStep st{idx, (int)mb, idx_global ? idx_global : idx, (int)(idx_global ? mb_global : mb), dobs_accum, loss_out, (long)opt_step};
     bool folded = false;
-    const bool rows = rows_kernel_wanted();
+    const bool rows = rows_kernel_wanted(phase);
     if (phase == 0 || phase == 1) {
         CIRS_REQUIRE(idx != nullptr || (ch && ch->head_done), "idx is null");
         int n_bchunks = 0;
@@ -2734,7 +2755,7 @@ extern "C" int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* gra
         const int32_t* idx = perms + (size_t)rep * n_rows + b;
         return PpoStep{idx, e - b, idx, e - b, (dobs_accum && rep == n_repeat - 1) ? dobs_accum : nullptr, losses + 4 * (size_t)k, (long)(opt_step + k)};
     };
-    const bool rows = rows_kernel_wanted();
+    const bool rows = rows_kernel_wanted(0);
     bool have_head = false;     // the head of step k (trunk forward, statistics, planes) already ran inside step k - 1's Adam launch
     for (int k = 0; k < n_steps; ++k) {
         const PpoStep st = step_of(k);
