@@ -212,10 +212,7 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     uint4 *wa_planes;                         // bf16 planes of Wa per item tile (wa_planes_kernel)
     uint4 *h2z, *h2b;                         // bf16 planes of H2 in the head kernels' register order (written by trunk_adv_kernel):
                                               // [32-row tile][12][lane] uint4, unit q of a lane = its q-th operand register quad
-    int *sync;                                // [4] arrival counter of trunk_bwd_kernel's row workgroups (zeroed by dh2_sum_kernel)
-    float *snap;                              // [2][3][snap_stride]: p | m | v of [trunk | wc | bc] as of before optimiser step k in buffer k & 1 (written by
-                                              // trunk_adv_kernel for a call's first step, by the A workgroups of adam_next_kernel for the step after theirs):
-                                              // what the T workgroups of step k's optimiser launch read while its A workgroups overwrite the live values
+    int *sync;                                // [4] arrival counters (zeroed by head_bwd_fused_kernel): [0] the R workgroups of trunk_rows_kernel, [1] the A0 workgroups of adam_next_kernel
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
 };
 
@@ -237,7 +234,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 2 * (size_t)n_pad * kH;                       // da2, da1
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I);     // dwap
-    f += 4 + 6 * (size_t)snap_stride(S) + 4;                     // sync, snap
+    f += 8;                     // sync, snap
     f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
     f += dwp_floats(n_pad, S);                         // dW row slabs (one per 32 rows: trunk_bwd_kernel; one per 8 rows in flat order: trunk_rows_kernel)
     f += (size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4;   // wa_planes
@@ -261,7 +258,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.da2 = take((size_t)n_pad * kH); v.da1 = take((size_t)n_pad * kH);
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
     v.dwap = take((size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I));
-    v.sync = (int*)take(4); v.snap = take(6 * (size_t)snap_stride(S));
+    v.sync = (int*)take(4);
     v.red = take(64);
     v.normp = take(1024);
     v.dwp = take(dwp_floats(n_pad, S));
@@ -540,8 +537,7 @@ __device__ __forceinline__ void trunk_row_job(const cirs_policy_cfg& cfg, const 
     trunk_compute(cfg, w, xs, hs, lane, j, o.h2, o.value, o.h1, L.w1, L.ld1, L.w2, L.wc);
     trunk_row_planes(xs[lane], j, lane, o);        // (h2[j][lane]: left in xs by trunk_compute)
 }
-struct SnapJob { const float *p, *m, *v; float* dst; int n_tr; long wc; };      // dst null: no snapshot (item-sharded step)
-// First launch of a stand-alone minibatch step, independent jobs by workgroup index (+ the snapshot workgroups behind the planes):
+// First launch of a stand-alone minibatch step, three independent jobs by workgroup index:
 //   [0, n_row_wgs)                trunk forward of the minibatch rows (same fma chains as the rollout)
 //   n_row_wgs                     advantage statistics of the (global) minibatch
 //   (n_row_wgs, n_row_wgs + tiles] bf16 planes of one Wa item tile (operands of the two head kernels)
@@ -550,19 +546,9 @@ __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cir
                                                         long stride, int n_pad, const int32_t* __restrict__ idx, int mb,
                                                         const float* __restrict__ adv_flat, const int32_t* __restrict__ sidx,
                                                         int m_stats, int enable, float* __restrict__ red, int n_row_wgs,
-                                                        uint4* __restrict__ planes, cirs_ppo_batch bt, int n_env, TrunkRowOut out, SnapJob sj) {
+                                                        uint4* __restrict__ planes, cirs_ppo_batch bt, int n_env, TrunkRowOut out) {
     __shared__ float lds_raw[kTileN * 65];
     static_assert(kTileN * 65 >= 4 * 2 * kH, "the trunk rows use 4 x 2 x 64 floats of the same buffer");
-    const int n_tiles = (cfg.n_items + kTileN - 1) / kTileN;
-    if ((int)blockIdx.x > n_row_wgs + n_tiles) {      // p | m | v of [trunk | wc | bc] as of before this step's optimiser launch (its T workgroups)
-        const int e = ((int)blockIdx.x - n_row_wgs - n_tiles - 1) * 256 + threadIdx.x;
-        const int n_sn = sj.n_tr + kH + 1, st = (n_sn + 3) & ~3;
-        if (e < n_sn) {
-            const long i = e < sj.n_tr ? e : sj.wc + (e - sj.n_tr);
-            sj.dst[e] = sj.p[i]; sj.dst[st + e] = sj.m[i]; sj.dst[2 * st + e] = sj.v[i];
-        }
-        return;
-    }
     if ((int)blockIdx.x > n_row_wgs) {
         wa_planes_block((int)blockIdx.x - n_row_wgs - 1, cfg.n_items, w.wa, planes, lds_raw);
         return;
@@ -837,7 +823,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     __shared__ __attribute__((aligned(16))) float sR[2][kBwdWaves][kRSize];   // double-buffered: the sum of tile t runs inside iteration t + 1
     const int tid = threadIdx.x;
     CIRS_SSTAMP(30);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) v.sync[0] = 0;      // arrival counter of the trunk-backward launch of this step
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { v.sync[0] = 0; v.sync[1] = 0; }      // arrival counters of this step's trunk-backward / optimiser launches
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * kBwdWaves + wv) * kTileM;
@@ -1256,6 +1242,10 @@ __device__ __forceinline__ void dw_tile_x_lds(const float* sX, int ldx, int K, i
 // the non-coherent caches (sc1 loads): the write-through form of MI355X_MICROARCH.md's inter-workgroup visibility rules -- no L2 write-back fence.
 __device__ __forceinline__ void st_sc1(float* p, float a) { __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float2 ld_sc1x2(const float* p) {      // (p 8-byte aligned)
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
 __device__ __forceinline__ void dw_tile_32rows(const float* sY, const float (&b)[16], int K, int o0, int k0, float* __restrict__ out, int lane) {
     const int hi = lane >> 5, lo = lane & 31;
     const int o = o0 + lo, k = k0 + lo;
@@ -1948,13 +1938,12 @@ __global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const
 // adam2_kernel's arithmetic (adam_elem / norm_coef_block are the same statements, so the same bits), re-tiled so that the launch can also do
 // the three jobs trunk_adv_kernel did at the head of the NEXT step -- that launch (8 us, all of it latency on the critical path of every
 // minibatch step) disappears from cirs_ppo_learn's loop:
-//   [0, n_t)            T: trunk forward of 8 rows of the next minibatch.  The trunk has 5.6 k parameters: every T workgroup forms their
-//                          updated values itself (gradient, moments, clip coefficient -> Adam, into LDS; nothing is written) and runs the
-//                          rollout's fma chains on them, while the A / P workgroups beside it write the same values to memory.
-//   [n_t, n_t + n_s)    S: advantage statistics of the next minibatch (no dependency on the update)
+//   [0, n_a0)           A0: Adam on [trunk | wc | bc], one element per thread, the parameters written through + an arrival count (what T waits for)
+//   next n_t            T: trunk forward of 32 rows of the next minibatch on the updated trunk (waits for A0, reads 22 KB)
+//   next n_s            S: advantage statistics of the next minibatch (no dependency on the update)
 //   next n_p            P: Adam on one 32-item tile of Wa (8 consecutive elements of a head row per thread) + the tile's bf16 planes from
 //                          the updated registers (what wa_planes_block re-read from memory)
-//   rest                A: Adam on everything else ([trunk | ba | wc | bc]); the first A workgroup reduces the loss terms and publishes them
+//   rest                A: Adam on ba; the first one reduces the loss terms and publishes them
 // Without a next step (n_t = n_s = 0) it is the step's Adam launch and nothing else.
 struct AdamNext {
     int n_t, n_s, n_p;
@@ -1962,8 +1951,7 @@ struct AdamNext {
     const float* obs_flat; const int32_t* idx; int mb, n_pad;      // next minibatch: rows idx[0 .. mb) of the buffer-order batch
     const float* adv_flat; const int32_t* sidx; int m_stats, enable; float* red;
     uint4* planes;
-    const float* snap;                                             // [3][snap_stride(S)]: p | m | v of [trunk | wc | bc] as of before this launch
-    float* snap_next;                                              // the same for the step after this one, written by the A workgroups
+    int n_a0;                                                      // A0 workgroups (set with or without a next step)
     int s_magic;                                                   // ceil(65536 / S): i / S = (i * s_magic) >> 16 for i < 2048
     int pa_delay;                                                  // P / A workgroups start this many x 1024 cycles late (the T workgroups' requests go first)
     cirs_ppo_batch bt; int n_env;
@@ -1988,7 +1976,7 @@ __device__ __forceinline__ float norm_coef_block(const float* __restrict__ parti
     const int tid = threadIdx.x;
     return norm_coef_block(partial[tid], tid < kWaSumBlocks ? partial[kNormBlocks + tid] : 0.f, cfg, sh, total_norm);
 }
-constexpr int kTrunkQ4 = 7;          // 256 x 7 float4 >= 64 (S + 66) floats, S <= 32: the trunk's parameters, four elements per thread and pass
+constexpr int kTrunkQ2 = 13;         // 256 x 13 float2 >= 64 (S + 66) floats, S <= 32: the trunk's parameters, two elements per thread and pass
 constexpr int kTrunkRowsPerWg = kTileM;   // rows of a T workgroup: one MFMA row tile
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
@@ -2001,10 +1989,11 @@ struct AdamLds {
     __attribute__((aligned(16))) float lt[12288];               // T: TrunkTileLds (weights + the tiles of its 32 rows);  P: the item tile's fp32 image [32][65]
 };
 // T: the trunk forward of 32 rows of the NEXT minibatch on the weights this launch forms.
-//   requests first: the rows' gathers (idx -> obs row, row scalars) and the trunk's gradient / parameters / moments (float4s; the parameters and
-//   moments from the SNAPSHOT dh2_sum_kernel took earlier in this step -- the A workgroups of this very launch overwrite the live values in place);
-//   then the clip coefficient, Adam of the 5.6 k trunk parameters into LDS (nothing is written to memory: the A workgroups do that), and the two
-//   layers on the fp32 matrix cores: D[feature][row] = W X^T as v_mfma_f32_32x32x2_f32 k-steps in ascending k from the bias -- bit for bit the
+//   The rows' gathers (idx -> obs row, row scalars) are requested first; then the workgroup waits for the A0 workgroups of the same launch -- the 22
+//   lowest block ids, one trunk / critic parameter per thread: their Adam update is a few hundred cycles behind one memory round trip, their stores are
+//   written through and counted in sync[1] -- and reads the 5.6 k updated parameters (22 KB, sc1) into LDS.  (The first version formed the update in every T
+//   workgroup from gradient + a snapshot of p / m / v: 89 KB of operands and 1.3 k instructions of Adam per workgroup were 20 k of its 27 k cycles.)
+//   Both layers run on the fp32 matrix cores: D[feature][row] = W X^T as v_mfma_f32_32x32x2_f32 k-steps in ascending k from the bias -- bit for bit the
 //   sequential fma chain of trunk_compute (MI355X_MICROARCH.md: the fp32 MFMA is an fma chain; the lane with hi = 0 supplies k = 2 s, hi = 1
 //   k = 2 s + 1), so the rows equal what trunk_adv_kernel / the rollout compute.  Waves 0, 1 own one 32-feature tile each; the critic chains run
 //   one row per lane; the outputs leave as whole tiles (coalesced float4 rows, H2's bf16 planes as 16-byte units of the head kernels' layout).
@@ -2020,27 +2009,14 @@ struct TrunkTileLds {                // overlays AdamLds::lt
     float dump[32];
 };
 constexpr int kTW1 = kH * kTS, kTVec = kTW1 + kH * 33, kTDump = kTVec + 4 * kH + kTileM * 33 + 2 * kTileM * kTS + kTileM;
-__device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNext& nx, AdamLds& l, int b) {
+__device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNext& nx, AdamLds& l, int b, const int* mv_sync) {
     const int tid = threadIdx.x, S = a.cfg.dim_state;
     const int lane = tid & 63, wv = tid >> 6, hi = lane >> 5, lo = lane & 31;
     const int j0 = b * kTileM;
     TrunkTileLds& t = *reinterpret_cast<TrunkTileLds*>(l.lt);
     const int ldx = S | 1;
-    // ---- requests, the long ones first (memory returns in order: a dependent gather issued early would hold the parameter loads back) -------
-    const int n_tr = (int)a.L.trunk, n4 = n_tr >> 2;          // (n_tr = 64 (S + 66): a multiple of 4)
-    const int n_sn = snap_stride(S);
-    const float* sp = nx.snap; const float* sm = nx.snap + n_sn; const float* sv = nx.snap + 2 * n_sn;
-    f32x4 g4[kTrunkQ4], p4[kTrunkQ4], m4[kTrunkQ4], v4[kTrunkQ4];
-#pragma unroll
-    for (int q = 0; q < kTrunkQ4; ++q) {
-        const int e4 = tid + 256 * q;
-        const int ec = (e4 < n4 ? e4 : 0) * 4;
-        g4[q] = *reinterpret_cast<const f32x4*>(a.g + ec); p4[q] = *reinterpret_cast<const f32x4*>(sp + ec);
-        m4[q] = *reinterpret_cast<const f32x4*>(sm + ec); v4[q] = *reinterpret_cast<const f32x4*>(sv + ec);
-    }
-    const int tc = tid < kH + 1 ? tid : 0;                     // wc | bc: 65 elements of the head segment
-    float gc = a.g[a.L.wc + tc], pc = sp[n_tr + tc], mc = sm[n_tr + tc], vc = sv[n_tr + tc];
-    const float part_a = a.partial[tid], part_b = tid < kWaSumBlocks ? a.partial[kNormBlocks + tid] : 0.f;      // (norm_coef_block's two loads)
+    // ---- requests: the rows' gathers (idx -> obs row / row scalars) travel while this workgroup waits for the trunk's updated parameters ------
+    const int n_tr = (int)a.L.trunk;
     // obs elements of the 32 rows: element i = row * S + k, three passes of 256 threads cover S <= 24; the rest (S <= 32) in a fourth
     int xrow[4], xk[4], xri[4];
 #pragma unroll
@@ -2055,10 +2031,6 @@ __device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNex
     const int fr = tid & 31, ff = tid >> 5;
     const bool frow_ok = j0 + fr < nx.mb;
     const int fri = nx.idx[j0 + fr];
-    float tn;
-    const float c = norm_coef_block(part_a, part_b, a.cfg, l.sh, tn);
-    CIRS_PSTAMP(b == 0, 1);
-    // the dependent gathers (idx -> obs row / row scalars) are requested only now: they travel while the Adam arithmetic below runs
     float xq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) xq[q] = (xk[q] >= 0 && j0 + xrow[q] < nx.mb) ? nx.obs_flat[(size_t)xri[q] * S + xk[q]] : 0.f;      // rows >= mb: zeros (as trunk_rows)
@@ -2069,45 +2041,38 @@ __device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNex
         const int w32 = (frow_ok && ff < 7) ? reinterpret_cast<const int*>(srcp)[fri] : 0;       // (all seven fields are 4-byte arrays)
         fi = w32; fv = __int_as_float(w32);
     }
-    // ---- Adam of the trunk -> LDS (flat order [w1 | b1 | w2 | b2]) ------------------------------------------------------------
+    // ---- the trunk's updated parameters: written through by the A0 workgroups of this launch (22 workgroups, one element per thread, the lowest
+    // block ids: dispatched first), counted in sync[1]; read around the caches as 8-byte units -> LDS ---------------------------------------------------
+    if (tid == 0) {     // (bounded: a lost arrival must not hang the device; the bit-identity tests would see stale weights)
+        int spins = 0;
+        while (__hip_atomic_load(mv_sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nx.n_a0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    CIRS_PSTAMP(b == 0, 1);
     const int ld1 = S | 1, o_b1 = kH * S, o_w2 = o_b1 + kH, o_b2 = o_w2 + kH * kH;
+    float2 pw[kTrunkQ2];
 #pragma unroll
-    for (int q = 0; q < kTrunkQ4; ++q) {
-        const int e4 = tid + 256 * q;
-        if ((S & 3) == 0) {      // four consecutive elements never straddle a row or a region: one destination per float4
-            float pn[4];
+    for (int q = 0; q < kTrunkQ2; ++q) {
+        const int e2 = tid + 256 * q;
+        pw[q] = ld_sc1x2(a.p + 2 * (e2 < (n_tr >> 1) ? e2 : 0));
+    }
+    const float pc = ld_sc1(a.p + a.L.wc + (tid < kH + 1 ? tid : 0));                     // wc | bc
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float pi = p4[q][u], mi = m4[q][u], vi = v4[q][u];
-                adam_elem<2, 2>(pi, mi, vi, g4[q][u], a.sa, c, a.beta1, a.beta2, a.eps);
-                pn[u] = pi;
-            }
-            const int e = 4 * e4;
-            const int r1 = (e * nx.s_magic) >> 16, r2 = e - o_w2;
-            const int d_w1 = kTW1 + r1 * ld1 + (e - r1 * S), d_b1 = kTVec + (e - o_b1), d_w2 = (r2 >> 6) * kTS + (r2 & 63), d_b2 = kTVec + kH + (e - o_b2);
-            int d = e < o_b2 ? d_w2 : d_b2;
-            d = e < o_w2 ? d_b1 : d;
-            d = e < o_b1 ? d_w1 : d;
-            d = e4 < n4 ? d : kTDump + (tid & 15);
-            l.lt[d] = pn[0]; l.lt[d + 1] = pn[1]; l.lt[d + 2] = pn[2]; l.lt[d + 3] = pn[3];
-            continue;
-        }
+    for (int q = 0; q < kTrunkQ2; ++q) {
+        const int e2 = tid + 256 * q;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float pi = p4[q][u], mi = m4[q][u], vi = v4[q][u];
-            adam_elem<2, 2>(pi, mi, vi, g4[q][u], a.sa, c, a.beta1, a.beta2, a.eps);
-            const int e = 4 * e4 + u;
+        for (int u = 0; u < 2; ++u) {
+            const int e = 2 * e2 + u;
             const int r1 = (e * nx.s_magic) >> 16, r2 = e - o_w2;          // row of a W1 element (e < 64 S <= 2048: exact)
             // offset inside TrunkTileLds as integer selects (a select between pointers compiled to a branch per region and element)
             const int d_w1 = kTW1 + r1 * ld1 + (e - r1 * S), d_b1 = kTVec + (e - o_b1), d_w2 = (r2 >> 6) * kTS + (r2 & 63), d_b2 = kTVec + kH + (e - o_b2);
             int d = e < o_b2 ? d_w2 : d_b2;
             d = e < o_w2 ? d_b1 : d;
             d = e < o_b1 ? d_w1 : d;
-            d = e4 < n4 ? d : kTDump + (tid & 31);                         // (threads beyond the trunk store to a dump row)
-            l.lt[d] = pi;
+            d = e2 < (n_tr >> 1) ? d : kTDump + (tid & 31);                // (threads beyond the trunk store to a dump row)
+            l.lt[d] = u ? pw[q].y : pw[q].x;
         }
     }
-    adam_elem<1, 1>(pc, mc, vc, gc, a.sb, c, a.beta1, a.beta2, a.eps);
     if (tid < kH + 1) t.vec[2 * kH + tid] = pc;               // wc[0..63], bc at [3 * kH]
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -2226,10 +2191,28 @@ __device__ __forceinline__ void adam_next_planes(const AdamArgs& a, const AdamNe
     CIRS_PSTAMP(nx.n_t > 0 && bp == 0, 10);
     wa_planes_from_lds(bp, nx.planes, l.lt);
 }
-// A: element e of [trunk | ba | wc | bc] -> flat index (the Wa matrix between them belongs to the P workgroups)
-__device__ __forceinline__ void adam_next_rest(const AdamArgs& a, const MbView& mv, AdamLds& l, int ba_, float* snap_next) {
+// A0: element e of [trunk | wc | bc] (nothing else: the T workgroups wait for these)
+__device__ __forceinline__ void adam_next_trunk_params(const AdamArgs& a, const MbView& mv, AdamLds& l, int b0) {
     const int tid = threadIdx.x;
-    if (ba_ == 0 && a.mb > 0) loss_partials_block(a.mb, a.mb_norm, mv, a.tail, l.sh3);
+    float total_norm;
+    const float c = norm_coef_block(a.partial, a.cfg, l.sh, total_norm);
+    const long e = b0 * 256L + tid;
+    const long i = e < a.L.trunk ? e : a.L.wc + (e - a.L.trunk);
+    if (i < a.L.total) {
+        float gi = a.g[i], pi = a.p[i], mi = a.m[i], vi = a.v[i];
+        if (i < a.L.trunk) adam_elem<2, 2>(pi, mi, vi, gi, a.sa, c, a.beta1, a.beta2, a.eps);
+        else adam_elem<1, 1>(pi, mi, vi, gi, a.sb, c, a.beta1, a.beta2, a.eps);
+        st_sc1(a.p + i, pi);        // (written through: the T workgroups of this launch read it)
+        a.m[i] = mi; a.v[i] = vi;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(mv.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// A: ba (the trunk / critic belong to A0, the Wa matrix to the P workgroups); its first workgroup reduces the loss terms and publishes them
+__device__ __forceinline__ void adam_next_rest(const AdamArgs& a, const MbView& mv, AdamLds& l, int ba_) {
+    const int tid = threadIdx.x;
+    if (ba_ == 0 && a.mb > 0) loss_partials_block(a.mb, a.mb_norm, mv, a.tail, l.sh3);      // (here, off the T workgroups' critical path)
     float total_norm;
     const float c = norm_coef_block(a.partial, a.cfg, l.sh, total_norm);
     if (ba_ == 0 && tid == 0) {
@@ -2239,34 +2222,29 @@ __device__ __forceinline__ void adam_next_rest(const AdamArgs& a, const MbView& 
         a.loss_out[0] = clip + a.cfg.vf_coef * vf - a.cfg.ent_coef * ent;
         a.loss_out[1] = clip; a.loss_out[2] = vf; a.loss_out[3] = ent;
     }
-    const long e = ba_ * 256L + tid;
-    const long i = e < a.L.trunk ? e : e + (long)a.cfg.n_items * kH;
-    if (i < a.L.total) {
+    const long i = a.L.ba + ba_ * 256L + tid;
+    if (i < a.L.wc) {
         float gi = a.g[i], pi = a.p[i], mi = a.m[i], vi = a.v[i];
-        if (i < a.L.trunk) adam_elem<2, 2>(pi, mi, vi, gi, a.sa, c, a.beta1, a.beta2, a.eps);
-        else adam_elem<1, 1>(pi, mi, vi, gi, a.sb, c, a.beta1, a.beta2, a.eps);
+        adam_elem<1, 1>(pi, mi, vi, gi, a.sb, c, a.beta1, a.beta2, a.eps);
         a.p[i] = pi; a.m[i] = mi; a.v[i] = vi;
-        if (snap_next && (i < a.L.trunk || i >= a.L.wc)) {      // [trunk | wc | bc] also into the next step's snapshot
-            const int es = i < a.L.trunk ? (int)i : (int)(a.L.trunk + (i - a.L.wc)), st = snap_stride(a.cfg.dim_state);
-            snap_next[es] = pi; snap_next[st + es] = mi; snap_next[2 * st + es] = vi;
-        }
     }
 }
 __global__ __launch_bounds__(256) void adam_next_kernel(AdamArgs a, MbView mv, AdamNext nx) {
     __shared__ AdamLds l;
     const int b = blockIdx.x;
-    const int nb = gridDim.x;
+    const int b_t = nx.n_a0, b_s = b_t + nx.n_t, b_p = b_s + nx.n_s, b_a = b_p + nx.n_p;
     const bool pn = nx.n_t > 0;      // (probe builds stamp the launches that have a next step)
-    CIRS_PSTAMP(pn && b == 0, 0); CIRS_PSTAMP(pn && b == nx.n_t - 1, 4); CIRS_PSTAMP(pn && b == nx.n_t, 6); CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s, 8);
-    CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s + nx.n_p - 1, 12); CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s + nx.n_p, 14); CIRS_PSTAMP(pn && b == nb - 1, 16);
-    if (b >= nx.n_t + nx.n_s) for (int q = 0; q < nx.pa_delay; ++q) __builtin_amdgcn_s_sleep(16);
-    if (b < nx.n_t) adam_next_trunk(a, nx, l, b);
-    else if (b < nx.n_t + nx.n_s) adv_stats_block(nx.adv_flat, nx.sidx, nx.m_stats, nx.enable, nx.red, l.sh);
-    else if (b < nx.n_t + nx.n_s + nx.n_p) adam_next_planes(a, nx, l, b - nx.n_t - nx.n_s);
-    else adam_next_rest(a, mv, l, b - nx.n_t - nx.n_s - nx.n_p, nx.snap_next);
-    CIRS_PSTAMP(pn && b == 0, 3); CIRS_PSTAMP(pn && b == nx.n_t - 1, 5); CIRS_PSTAMP(pn && b == nx.n_t, 7); CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s, 11);
-    CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s + nx.n_p - 1, 13); CIRS_PSTAMP(pn && b == nx.n_t + nx.n_s + nx.n_p, 15); CIRS_PSTAMP(pn && b == nb - 1, 17);
-    (void)pn; (void)nb;
+    CIRS_PSTAMP(pn && b == b_t, 0); CIRS_PSTAMP(pn && b == b_s - 1, 4); CIRS_PSTAMP(pn && b == b_s, 6); CIRS_PSTAMP(pn && b == b_p, 8);
+    CIRS_PSTAMP(pn && b == b_a - 1, 12); CIRS_PSTAMP(pn && b == 0, 14); CIRS_PSTAMP(pn && b == nx.n_a0 - 1, 16);
+    if (b >= b_p) for (int q = 0; q < nx.pa_delay; ++q) __builtin_amdgcn_s_sleep(16);
+    if (b < b_t) adam_next_trunk_params(a, mv, l, b);
+    else if (b < b_s) adam_next_trunk(a, nx, l, b - b_t, mv.sync);
+    else if (b < b_p) adv_stats_block(nx.adv_flat, nx.sidx, nx.m_stats, nx.enable, nx.red, l.sh);
+    else if (b < b_a) adam_next_planes(a, nx, l, b - b_p);
+    else adam_next_rest(a, mv, l, b - b_a);
+    CIRS_PSTAMP(pn && b == b_t, 3); CIRS_PSTAMP(pn && b == b_s - 1, 5); CIRS_PSTAMP(pn && b == b_s, 7); CIRS_PSTAMP(pn && b == b_p, 11);
+    CIRS_PSTAMP(pn && b == b_a - 1, 13); CIRS_PSTAMP(pn && b == 0, 15); CIRS_PSTAMP(pn && b == nx.n_a0 - 1, 17);
+    (void)pn;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -2504,10 +2482,9 @@ static cirs::TrunkRowOut trunk_out_of(const cirs::MbView& v) { return cirs::Trun
 static int launch_trunk_adv(const PpoRun& r, const PpoStep& st) {
     using namespace cirs;
     const int n_pad = n_pad_of(st.mb);
-    const SnapJob sj{r.params, r.adam_m, r.adam_v, r.v.snap + (st.opt_step & 1) * 3 * (size_t)snap_stride(r.S), (int)r.L.trunk, r.L.wc};
-    hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(r.I, kTileN) + cdiv(snap_floats(r.S), 256)), dim3(256), 0, r.s, r.pcfg, r.w,
-                       (const float*)r.batch->obs, (long)r.S, n_pad, st.idx, st.mb, (const float*)r.batch->adv, st.sidx, st.mb_norm, (int)r.cfg->norm_adv,
-                       r.v.red, (int)cdiv(n_pad, 4), r.v.wa_planes, *r.batch, r.n_env, trunk_out_of(r.v), sj);
+    hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(r.I, kTileN)), dim3(256), 0, r.s, r.pcfg, r.w, (const float*)r.batch->obs, (long)r.S,
+                       n_pad, st.idx, st.mb, (const float*)r.batch->adv, st.sidx, st.mb_norm, (int)r.cfg->norm_adv, r.v.red, (int)cdiv(n_pad, 4),
+                       r.v.wa_planes, *r.batch, r.n_env, trunk_out_of(r.v));
     CIRS_CHECK_LAUNCH("trunk_adv_kernel");
     return CIRS_OK;
 }
@@ -2645,11 +2622,10 @@ static int launch_norm_adam(const PpoRun& r, const PpoStep& st, int phase, bool 
         nx.pcfg = r.pcfg; nx.obs_flat = r.batch->obs; nx.idx = next->idx; nx.mb = next->mb; nx.n_pad = np;
         nx.adv_flat = r.batch->adv; nx.sidx = next->sidx; nx.m_stats = next->mb_norm; nx.enable = (int)r.cfg->norm_adv; nx.red = v.red;
         nx.bt = *r.batch; nx.n_env = r.n_env; nx.out = trunk_out_of(v); nx.s_magic = (65536 + r.S - 1) / r.S;
-        nx.snap = v.snap + (st.opt_step & 1) * 3 * (size_t)snap_stride(r.S);
-        nx.snap_next = v.snap + ((st.opt_step + 1) & 1) * 3 * (size_t)snap_stride(r.S);
-        nx.pa_delay = env_int("CIRS_PPO_PA_DELAY", 4);      // (A/B on one box: 0 / 4 / 8 -> 77.3 / 76.7 / 77.2 us per step)
+        nx.pa_delay = env_int("CIRS_PPO_PA_DELAY", 0);      // (A/B on one box: 0 / 4 -> 78.0-78.6 / 78.5-78.9 us per step)
     }
-    const int n_a = cdiv(r.L.trunk + r.I + kH + 1, 256);
+    nx.n_a0 = cdiv(r.L.trunk + kH + 1, 256);
+    const int n_a = nx.n_a0 + cdiv(r.I, 256);
     // (phase 2: the loss partials were all-reduced with the gradient: mb = 0 leaves `tail` as it is)
     const AdamArgs aa{r.params, r.grads, r.adam_m, r.adam_v, r.L, sa, sb, r.cfg->beta1, r.cfg->beta2, r.cfg->adam_eps, *r.cfg, v.normp, r.tail, st.loss_out,
                       phase == 0 ? st.mb : 0, st.mb_norm};
@@ -2833,7 +2809,7 @@ extern "C" int cirs_ppo_minibatch_tp(const cirs_ppo_cfg* cfg, float* params, flo
         CIRS_REQUIRE(stats4, "stats4 is null");
         hipLaunchKernelGGL(trunk_adv_kernel, dim3(cdiv(n_pad, 4) + 1 + cdiv(I, kTileN)), dim3(256), 0, s, pcfg, w, (const float*)batch->obs, (long)S, n_pad,
                            idx, (int)mb, (const float*)batch->adv, idx, (int)mb, (int)cfg->norm_adv, v.red, (int)cdiv(n_pad, 4), v.wa_planes, *batch, (int)n_env,
-                           TrunkRowOut{v.h2, v.value, v.h1, v.obs, nullptr, nullptr, nullptr, v.h2z, v.h2b}, SnapJob{});
+                           TrunkRowOut{v.h2, v.value, v.h1, v.obs, nullptr, nullptr, nullptr, v.h2z, v.h2b});
         CIRS_CHECK_LAUNCH("trunk_adv_kernel");
         ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
         const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);

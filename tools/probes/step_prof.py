@@ -35,9 +35,9 @@ def show(title, base, items):
 print("ticks relative to the first stamp of the launch (s_memtime: 100 MHz on this part -> 1 tick = 10 ns)")
 show("adam_next_kernel P / A roles (same launch)", 0,
      [(8, "P first: entry"), (9, "P first: loads + clip coefficient"), (10, "P first: Adam + stores + LDS image"), (11, "P first: planes written"),
-      (12, "P last: entry"), (13, "P last: end"), (14, "A first: entry"), (15, "A first: end"), (16, "A last: entry"), (17, "A last: end")])
+      (12, "P last: entry"), (13, "P last: end"), (14, "A0 first: entry"), (15, "A0 first: end (arrival counted)"), (16, "A0 last: entry"), (17, "A0 last: end")])
 show("adam_next_kernel T / S roles (the last launch of the update that had a next step)", 0,
-     [(0, "T first: entry"), (1, "T first: requests + clip coefficient"), (2, "T first: Adam of the trunk -> LDS"), (18, "T first: both layers (MFMA)"), (3, "T first: outputs written"),
+     [(0, "T first: entry"), (1, "T first: gathers requested, A0 arrived"), (2, "T first: updated trunk read -> LDS"), (18, "T first: both layers (MFMA)"), (3, "T first: outputs written"),
       (4, "T last: entry"), (5, "T last: end"), (6, "S: entry"), (7, "S: end")])
 show("trunk_rows_kernel", 20,
      [(20, "row wg 0: entry"), (21, "row wg 0: slabs summed, operands in LDS"), (22, "row wg 0: d a1"), (23, "row wg 0: weight-gradient slab stores issued"),
