@@ -102,6 +102,11 @@ class Traj(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("obs", "act", "rew", "done", "logp", "value", "ctr")]
 
 
+class Redraw(C.Structure):      # cirs_redraw
+    _fields_ = [("row_env", C.c_void_p), ("row_t", C.c_void_p), ("offsets", C.c_void_p), ("lens", C.c_void_p), ("dropout_seed", C.c_uint64),
+                ("env_base0", C.c_int64), ("env_stride", C.c_int64), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
 # name -> (restype, argtypes).  Must list every symbol include/cirs_hip.h declares (tests check this).
 _P = C.c_void_p
 SIGNATURES = {
@@ -123,6 +128,10 @@ SIGNATURES = {
                                      C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
                                      C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
                                      C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, _P, C.c_int32, _P, C.c_int64, _P]),
+    "cirs_rollout_steps_redraw": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState),
+                                            C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
+                                            C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(Redraw), _P, C.c_int64, _P]),
     "cirs_rollout_steps_noise": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(EnvTables), C.POINTER(EnvState),
                                            C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState),
                                            C.POINTER(PolicyCfg), C.POINTER(PolicyWeights), C.POINTER(Traj), C.c_int32,

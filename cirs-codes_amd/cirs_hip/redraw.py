@@ -52,9 +52,42 @@ class RedrawRollout(DeviceRollout):
         trk.set_dropout_key(key_seed, call_tag(rng_base, 0), self.dropout_env_base + t * getattr(self, "B_total", B))     # (B_total: envs of ALL ranks)
         trk.prefix_states(row_env, row_t, offsets, lens, B * (t + 1), out)
 
+    def _all_call_rows(self, T, B):
+        """Row lists of build_state calls 0 .. T, concatenated (call c: every env, positions 0 .. c; n_env * (c + 1) rows starting at n_env c (c + 1) / 2)
+        + offsets / lens [T + 1][B]: device tensors, built once per (T, B)."""
+        cache = self.__dict__.setdefault("_all_rows_cache", {})
+        if (T, B) not in cache:
+            parts = [self._prefix_rows(c, B) for c in range(T + 1)]
+            cache[(T, B)] = tuple(torch.cat([p[k] for p in parts]).contiguous() for k in range(4))
+        return cache[(T, B)]
+
     def collect(self, users: torch.Tensor, *, seed=0, rng_base=0, sync_every: Optional[int] = None, gumbel=None):
+        """The whole collect from one call (cirs_rollout_steps_redraw, round 5): per vector step the batched prefix pass of call t, the trunk, the
+        sampler's chunk masses and the fused step kernel -- the loop of collect_stepwise() without its ~18 launches and torch ops per step from Python."""
         assert gumbel is None and self.online is None and self.visited is None and self.force_length == 0, \
             "the exact-redraw option covers the plain training rollout"
+        env, tr, trk = self.env, self.traj, self.tracker
+        B, T, S = env.n_env, env.max_turn, trk.dim_state
+        assert T < trk.cfg.max_len
+        users = users.to(self.device, torch.int32)
+        key_seed = seed >> 8 if self.dropout_key_from_high_bits else seed
+        self._users, self._key = users, (key_seed, rng_base)
+        self.reset(users)                       # (traj cleared, tracker reset + user slot, env reset; obs[0] is overwritten by call 0's pass)
+        row_env, row_t, offsets, lens = self._all_call_rows(T, B)
+        trk.set_dropout_key(key_seed, call_tag(rng_base, 0), self.dropout_env_base)          # -> cfg.dropout_seed: the collect's key
+        trk.reserve_backward(B * (T + 1))
+        rd = abi.Redraw(row_env=row_env.data_ptr(), row_t=row_t.data_ptr(), offsets=offsets.data_ptr(), lens=lens.data_ptr(),
+                        dropout_seed=trk.cfg.dropout_seed, env_base0=self.dropout_env_base, env_stride=getattr(self, "B_total", B),
+                        workspace=trk._bws.data_ptr(), workspace_bytes=trk._bws.numel())
+        ws = self.policy.workspace(B)
+        abi.check(self._lib.cirs_rollout_steps_redraw(
+            C.byref(env.cfg), C.byref(env._tab), C.byref(env._st), C.byref(trk.cfg), C.byref(trk.w), C.byref(trk.st), C.byref(self.policy.cfg),
+            C.byref(self.policy.w), C.byref(tr.struct), B, 0, T, seed, rng_base, C.byref(rd), ws.data_ptr(), ws.numel(), self._stream()),
+            "cirs_rollout_steps_redraw")
+        return env.turn.clone()
+
+    def collect_stepwise(self, users: torch.Tensor, *, seed=0, rng_base=0):
+        """The same collect one library call per stage and step (round 4's form; kept as the test's reference for collect())."""
         env, tr, trk = self.env, self.traj, self.tracker
         B, T, S = env.n_env, env.max_turn, trk.dim_state
         users = users.to(self.device, torch.int32)

@@ -53,7 +53,18 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                         const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
                         const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
                         int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited, int32_t force_length,
-                        const cirs_online_reward* online, const float* gumbel, void* workspace, int64_t workspace_bytes, void* stream);
+                        const cirs_online_reward* online, const float* gumbel, void* workspace, int64_t workspace_bytes, void* stream,
+                        const cirs_redraw* redraw = nullptr);
+
+extern "C" int cirs_rollout_steps_redraw(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                                         const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                                         const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
+                                         int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, const cirs_redraw* redraw,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    CIRS_REQUIRE(redraw && redraw->row_env && redraw->row_t && redraw->offsets && redraw->lens && redraw->workspace, "cirs_rollout_steps_redraw: null field");
+    return rollout_impl(env_cfg, env_tab, env_st, trk_cfg, trk_w, trk_st, pol_cfg, pol_w, traj, n_env, t_begin, t_end, seed, rng_base, nullptr, 0,
+                        nullptr, nullptr, workspace, workspace_bytes, stream, redraw);
+}
 
 extern "C" int cirs_rollout_steps_noise(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
                                         const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
@@ -91,7 +102,8 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                         const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
                         const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
                         int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited, int32_t force_length,
-                        const cirs_online_reward* online, const float* gumbel, void* workspace, int64_t workspace_bytes, void* stream) {
+                        const cirs_online_reward* online, const float* gumbel, void* workspace, int64_t workspace_bytes, void* stream,
+                        const cirs_redraw* redraw) {
     using namespace cirs;
     cirs_env_tables tab_local;
     if (online) {
@@ -171,6 +183,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         // overlap returns, so one group is the default and CIRS_ROLLOUT_GROUPS opts in
         G = forced > 0 ? forced : 1;
         if (G > kMaxGroups) G = kMaxGroups;
+        if (redraw) G = 1;
     }
     int n_g = ((n_env + G - 1) / G + 127) / 128 * 128;       // rows per group: whole 128-row blocks of the mass kernel
     if (G > 1) {   // room for one sampler workspace per group?
@@ -221,6 +234,20 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         q.st = g == 0 ? s : gs[g];
     }
     const uint8_t* done_all = (const uint8_t*)env_st->done;
+    // Exact-redraw dropout (the reference's procedure, core/state_tracker.py:170-186,243-246): the state of vector step t is NOT the cached decode's -- it is
+    // ONE batched causal pass over positions 0 .. t of every env with the masks of build_state call t (cirs_tracker_prefix_states, key = the collect's key with
+    // pseudo-env ids env_base0 + t * env_stride + e), followed by the trunk of that state; the step kernel keeps writing the input slots and its own state is
+    // overwritten by the next call's pass.  (cirs_hip/redraw.py ran this loop from Python: ~18 launches and torch ops per step, host-bound.)
+    auto redraw_state = [&](int t) -> int {
+        cirs_tracker_cfg cfg_t = *trk_cfg;
+        cfg_t.dropout_seed = redraw->dropout_seed;
+        cfg_t.drop_env_base = (int32_t)(redraw->env_base0 + (int64_t)t * redraw->env_stride);
+        const size_t start = (size_t)B * t * (t + 1) / 2;
+        return cirs_tracker_prefix_states(&cfg_t, trk_w, trk_st, redraw->row_env + start, redraw->row_t + start, redraw->offsets + (size_t)t * B,
+                                          redraw->lens + (size_t)t * B, (int32_t)(B * (t + 1)), traj->obs + (size_t)t * B * S, S, redraw->workspace,
+                                          redraw->workspace_bytes, stream);
+    };
+    if (redraw) { if (int rc = redraw_state(t_begin)) return rc; }
     // trunk of the first step of this call (later ones ride on the tracker step)
     for (int gi = 0; gi < n_groups; ++gi) {
         const Group& q = grp[gi];
@@ -249,7 +276,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
             }
             CIRS_CHECK_LAUNCH("sampler kernel");
             TrunkFuse tf{};
-            if (t + 1 < t_end) {
+            if (t + 1 < t_end && !redraw) {
                 tf.on = 1; tf.cfg = *pol_cfg; tf.w = *pol_w; tf.skip = done_all + q.base; tf.h2 = q.h2;
                 tf.value = traj->value + (size_t)(t + 1) * B + q.base;
             }
@@ -268,6 +295,14 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
             tl.ctr_out = traj->ctr + (size_t)t * B + q.base;
             if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, q.n, obs_n, S, &tf, q.st, &tl, img))
                 return rc;
+            if (redraw && (t + 1 < t_end || t + 1 < trk_cfg->max_len)) {      // the state of call t + 1 (the last one: obs_next of the final step)
+                if (int rc = redraw_state(t + 1)) return rc;
+                if (t + 1 < t_end) {
+                    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(q.n, 4)), dim3(256), 0, q.st, *pol_cfg, *pol_w, traj->obs + (size_t)(t + 1) * B * S, (long)S, q.n,
+                                       done_all, q.h2, traj->value + (size_t)(t + 1) * B, (float*)nullptr);
+                    CIRS_CHECK_LAUNCH("trunk_kernel");
+                }
+            }
         }
     }
     if (n_groups > 1) {

@@ -1463,16 +1463,32 @@ extern "C" int cirs_debug_tbwd_prof(unsigned long long* out_host64) {
 #endif
 
 namespace cirs {
+// cirs_tracker_prefix_states only needs the LAST row of every env out of the last layer: everything behind that layer's attention is row-local, so its row
+// chain (out_proj .. LayerNorm2: 192 MFMAs per 32 rows) runs on one row per env instead of on every row of the prefix -- at call t of a collect B rows instead
+// of B (t + 1).  This kernel gathers those rows' attention outputs / layer inputs and their (env, position) (the dropout masks are keyed by them).
+__global__ __launch_bounds__(256) void prefix_last_rows_kernel(const float* __restrict__ ATT, const float* __restrict__ H, const int32_t* __restrict__ row_env,
+                                                               const int32_t* __restrict__ row_t, const int32_t* __restrict__ offsets,
+                                                               const int32_t* __restrict__ lens, int B, float* __restrict__ ATTc, float* __restrict__ Hc,
+                                                               int32_t* __restrict__ env_c, int32_t* __restrict__ t_c) {
+    const int e = blockIdx.x * 8 + (threadIdx.x >> 5), c = threadIdx.x & 31;
+    if (e >= B) return;
+    const int n = lens[e];
+    const long r = n > 0 ? (long)offsets[e] + n - 1 : -1;
+    ATTc[(size_t)e * tD + c] = r >= 0 ? ATT[r * tD + c] : 0.f;
+    Hc[(size_t)e * tD + c] = r >= 0 ? H[r * tD + c] : 0.f;
+    if (c == 0) { env_c[e] = r >= 0 ? row_env[r] : e; t_c[e] = r >= 0 ? row_t[r] : 0; }
+}
 // cirs_tracker_prefix_states: state of the LAST row of every env that has rows = decoder(H_last[row]); one wavefront per env, lane j < S owns
 // output j (fma chain over the 32 features in ascending order)
+// compact != 0: H holds one row per env (the last layer ran on the envs' last rows only, below)
 __global__ __launch_bounds__(256) void prefix_decoder_kernel(const float* __restrict__ H, const int32_t* __restrict__ offsets, const int32_t* __restrict__ lens,
                                                              int B, int S, const float* __restrict__ dec_w, const float* __restrict__ dec_b,
-                                                             float* __restrict__ out, long out_stride) {
+                                                             float* __restrict__ out, long out_stride, int compact) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6), j = threadIdx.x & 63;
     if (e >= B || j >= S) return;
     const int n = lens[e];
     if (n <= 0) return;
-    const float* h = H + (size_t)(offsets[e] + n - 1) * tD;
+    const float* h = H + (size_t)(compact ? e : offsets[e] + n - 1) * tD;
     float acc = dec_b[j];
 #pragma unroll
     for (int k = 0; k < tD; ++k) acc = __builtin_fmaf(h[k], dec_w[(size_t)j * tD + k], acc);
@@ -1560,11 +1576,25 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
     } else {
         hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0], dc);
     }
+    bool last_compact = false;
     for (int l = 0; l < nl; ++l) {
         const cirs_tracker_layer& y = w->layer[l];
         if (!fused_rows) launch_rows_gemm(true, sc.H[l], tD, y.in_proj_w, tD, y.in_proj_b, R, tD, 96, 0, nullptr, 0, sc.QKV[l], 96, s);
         if (ep) ATT_EP(attn_fwd_ep, false, (const float*)sc.QKV[l], offsets, lens, L, sc.ATT[l], dc, l);
         else ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l], dc, l, sc.PM[l]);
+        if (fused_rows && state_out && l == nl - 1 && !getenv("CIRS_TRACKER_PREFIX_FULL")) {      // prefix states: the last layer's row chain on the envs' last rows only
+            static_assert(tD == 32, "prefix_last_rows_kernel maps 32 columns to 32 threads");
+            float *ATTc = sc.T0, *Hc = sc.T1;
+            int32_t *env_c = reinterpret_cast<int32_t*>(sc.T2), *t_c = env_c + B;
+            hipLaunchKernelGGL(prefix_last_rows_kernel, dim3(cdiv(B, 8)), dim3(256), 0, s, (const float*)sc.ATT[l], (const float*)sc.H[l], row_env, row_t, offsets,
+                               lens, B, ATTc, Hc, env_c, t_c);
+            LayerFwdArgs fa{ATTc, Hc, y, nullptr, nullptr, sc.XH1[l], sc.RS1[l], sc.H1N[l], sc.FF1[l], sc.XH2[l], sc.RS2[l], sc.H[l + 1], nullptr,
+                            env_c, t_c, B, l};
+            if (dc.on) hipLaunchKernelGGL(layer_rows_fwd<true>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
+            else hipLaunchKernelGGL(layer_rows_fwd<false>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
+            last_compact = true;
+            continue;
+        }
         if (fused_rows) {
             LayerFwdArgs fa{sc.ATT[l], sc.H[l], y, l + 1 < nl ? w->layer[l + 1].in_proj_w : nullptr, l + 1 < nl ? w->layer[l + 1].in_proj_b : nullptr,
                             sc.XH1[l], sc.RS1[l], sc.H1N[l], sc.FF1[l], sc.XH2[l], sc.RS2[l], sc.H[l + 1], l + 1 < nl ? sc.QKV[l + 1] : nullptr,
@@ -1586,7 +1616,7 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
     CIRS_CHECK_LAUNCH("tracker forward recompute");
     if (state_out) {
         hipLaunchKernelGGL(prefix_decoder_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, (const float*)sc.H[nl], offsets, lens, B, S, w->dec_w, w->dec_b,
-                           state_out, (long)state_stride);
+                           state_out, (long)state_stride, last_compact ? 1 : 0);
         CIRS_CHECK_LAUNCH("prefix_decoder_kernel");
         return CIRS_OK;
     }

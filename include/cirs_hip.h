@@ -477,6 +477,28 @@ int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
                           const float* dstate, const cirs_tracker_grads* grads, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* Exact-redraw dropout inside the fused rollout (core/state_tracker.py:170-186,243-246: the reference never switches the tracker to eval(), so every
+ * build_state call re-runs the encoder over the WHOLE prefix with fresh masks).  cirs_rollout_steps_redraw = cirs_rollout_steps in which the state of
+ * vector step t comes from cirs_tracker_prefix_states over positions 0 .. t of every env under the masks of call t (pseudo-env ids env_base0 +
+ * t * env_stride + e of the key dropout_seed), instead of from the cached decode.  Row lists of all calls, concatenated: call c describes n_env * (c + 1)
+ * rows (env-major) starting at n_env * c * (c + 1) / 2 of row_env / row_t, and row c of offsets / lens [max_turn + 1][n_env].
+ * workspace: cirs_tracker_backward_workspace_bytes(cfg, n_env * (max_turn + 1)). */
+typedef struct {
+    const int32_t* row_env;
+    const int32_t* row_t;
+    const int32_t* offsets;
+    const int32_t* lens;
+    uint64_t dropout_seed;
+    int64_t env_base0, env_stride;
+    void* workspace;
+    int64_t workspace_bytes;
+} cirs_redraw;
+int cirs_rollout_steps_redraw(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                              const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                              const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
+                              int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, const cirs_redraw* redraw,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The forward half of cirs_tracker_backward as an entry point: ONE causal pass over the buffer rows (env b, positions 0 .. lens[b]-1) from the
  * stored input slots, with the dropout masks of the key currently set in cfg (dropout_seed / drop_env_base), and the state of every env's LAST row
  * -> state_out[b * state_stride + 0 .. dim_state) (envs with lens[b] == 0 are left untouched).  This is the reference's build_state under live

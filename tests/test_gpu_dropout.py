@@ -135,6 +135,41 @@ def test_stepwise_protocol_draws_fresh_masks_per_episode():
     assert np.array_equal(c, d)
 
 
+@pytest.mark.parametrize("U,I,B,T", [(60, 150, 12, 7), (300, 3327, 64, 30)])
+def test_exact_redraw_collect_from_one_call_equals_the_stepwise_collect(U, I, B, T):
+    """cirs_rollout_steps_redraw (the whole exact-redraw collect from one call: per vector step the batched prefix pass of build_state call t inside the
+    fused rollout) == the stage-by-stage loop of round 4 (RedrawRollout.collect_stepwise): actions, rewards, done flags, log-probs, values, episode
+    lengths and the tracker's input slots bit for bit, the states of the envs alive at a call bit for bit."""
+    from cirs_hip.engine import CirsEngine
+    from cirs_hip.env import DeviceEnvTables
+    from cirs_hip.synthetic import make_tables
+    tab = make_tables(U, I, seed=0, build_dist=False)
+    a_env = tab.alpha_u[tab.raw_uid, 0].astype(np.float64); b_env = tab.beta_i[tab.raw_pid, 0].astype(np.float64)
+    users = torch.as_tensor(np.random.RandomState(1).randint(0, U, B))
+    out = []
+    for stepwise in (False, True):
+        dt = DeviceEnvTables(tab.mat, tab.normed_mat, tab.item_cats, alpha_env=a_env, beta_env=b_env)
+        eng = CirsEngine(dt, B, max_turn=T, num_leave_compute=3 if T < 30 else 10, leave_threshold=1 if T < 30 else 4, tau=10.0, gamma_exposure=10.0,
+                         seed=11, dropout=0.1, dropout_redraw=True)
+        ro = eng.rollout
+        lens = (ro.collect_stepwise(users.cuda(), seed=(11 << 8), rng_base=0) if stepwise else ro.collect(users.cuda(), seed=(11 << 8), rng_base=0))
+        torch.cuda.synchronize()
+        tr = ro.traj
+        out.append(dict(lens=lens.clone(), act=tr.act.clone(), rew=tr.rew.clone(), done=tr.done.clone(), logp=tr.logp.clone(), value=tr.value.clone(),
+                        ctr=tr.ctr.clone(), obs=tr.obs.clone(), x_hist=eng.tracker.x_hist.clone()))
+    a, b = out
+    assert torch.equal(a["lens"], b["lens"]) and int(a["lens"].min()) >= 1
+    live = (a["act"] >= 0)                                   # [T, B]: env alive at step t
+    assert torch.equal(a["act"], b["act"])
+    for k in ("done", "rew", "logp", "value", "ctr"):           # (rows of finished envs are padding: the two loops fill them differently)
+        assert torch.equal(a[k][live], b[k][live]), k
+    assert torch.equal(a["obs"][:T][live], b["obs"][:T][live])
+    lens = a["lens"].long()
+    for e in range(B):                                       # the final state of every env (call len[e]) and its input slots
+        assert torch.equal(a["obs"][lens[e], e], b["obs"][lens[e], e])
+        assert torch.equal(a["x_hist"][e, :lens[e] + 1], b["x_hist"][e, :lens[e] + 1])
+
+
 def test_exact_redraw_mode_matches_the_reference_procedure():
     """the reference redraws the masks of the WHOLE prefix at every build_state call (core/state_tracker.py:170-186,
     243-246).  The exact-redraw option (cirs_hip/redraw.py, CirsEngine(dropout_redraw=True)) must (a) produce, for every call t, the
