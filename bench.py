@@ -34,10 +34,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-MINIBATCH_KERNELS = ("head_stats_kernel", "head_bwd_fused_kernel", "dh2_sum_kernel", "trunk_bwd_kernel", "sumsq_partial_kernel", "adam_next_kernel")
-# the 6 launches of a minibatch step inside cirs_ppo_learn's loop (round 5; rounds 3-4: 7): the head of step k + 1 -- trunk forward, advantage
-# statistics, Wa planes -- runs in step k's optimiser launch; trunk_adv_kernel runs once per update.  (A 4-launch form exists -- trunk_rows_kernel,
-# CIRS_PPO_ROWS_KERNEL=1 -- and is 1.3 us per step slower on this workload: DESIGN.md section 4, round 5.)
+MINIBATCH_KERNELS = ("head_stats_kernel", "head_bwd_fused_kernel", "trunk_rows_kernel", "adam_next_kernel")
+# the 4 launches of a minibatch step inside cirs_ppo_learn's loop (round 5; rounds 3-4: 7).  The head of step k + 1 -- trunk forward, advantage
+# statistics, Wa planes -- runs in step k's optimiser launch; the chunk-slab sums of d h2, the trunk backward, the weight-gradient sums and the
+# squared-norm partials are one launch; trunk_adv_kernel runs once per update
 
 
 def kernel_source_hash():
@@ -619,7 +619,7 @@ def main():
         t_bwd = t_k["head_bwd_fused_kernel"]
         flop_bwd = 4.0 * mb * I * H
         exec_bwd = 6.0 * mb * I * H
-        # whole minibatch step (6 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
+        # whole minibatch step (4 launches), SURVEY 8(d): 3 x 2*mb*(S*64 + 64*64 + 64*I) = 4.25 GFLOP at mb = 1024, I = 10728
         flop_step = 6.0 * mb * (S * H + H * H + H * I)
         exec_step = 8.0 * mb * I * H + 6.0 * mb * (S * H + H * H)
         out = {
@@ -661,7 +661,7 @@ def main():
                                "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "traffic": None,
                                "head_stats_kernel_seconds": t_k["head_stats_kernel"],
-                               "note": "one step of cirs_ppo_learn's loop: head_stats_kernel + head_bwd_fused_kernel (whose prologue also merges the statistics partials and forms the row loss terms) + dh2_sum_kernel + trunk_bwd_kernel (+ dWa slab sums) + sumsq_partial_kernel + adam_next_kernel (Adam + the trunk forward / advantage statistics / Wa planes of the NEXT step)"},
+                               "note": "one step of cirs_ppo_learn's loop: head_stats_kernel + head_bwd_fused_kernel (whose prologue also merges the statistics partials and forms the row loss terms) + trunk_rows_kernel (chunk-slab sums of d h2, trunk backward, dWa slab sums, trunk-gradient sums, squared-norm partials) + adam_next_kernel (Adam + the trunk forward / advantage statistics / Wa planes of the NEXT step)"},
         }
         # HBM traffic per launch from the committed PMC passes -- only when they were taken on exactly these kernel sources
         traffic, src = pmc_traffic(args.workload)

@@ -212,10 +212,27 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     uint4 *wa_planes;                         // bf16 planes of Wa per item tile (wa_planes_kernel)
     uint4 *h2z, *h2b;                         // bf16 planes of H2 in the head kernels' register order (written by trunk_adv_kernel):
                                               // [32-row tile][12][lane] uint4, unit q of a lane = its q-th operand register quad
-    int *sync;                                // [4] arrival counters (zeroed by head_bwd_fused_kernel): [0] the R workgroups of trunk_rows_kernel, [1] the A0 workgroups of adam_next_kernel
+    int *sync;                                // [kSyncInts] arrival flags (see kSyncInts)
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
 };
 
+// arrival FLAGS of the workgroups that other workgroups of the same launch wait for (one word per producer, zeroed by head_bwd_fused_kernel earlier in the
+// step): [0, 256) the R workgroups of trunk_rows_kernel, [256, 288) the A0 workgroups of adam_next_kernel.  A flag per producer instead of one counter:
+// 22 - 128 read-modify-writes of ONE address are serialised at the memory side (a few hundred ns each), a flag is a plain write-through store, and the
+// consumer's threads poll one flag each (one cache line per instruction).
+constexpr int kSyncInts = 288, kSyncA0 = 256;
+__device__ __forceinline__ void flag_arrive(int* flags, int b) {      // the caller has drained its stores (s_waitcnt vmcnt(0)) and synchronised the workgroup
+    if (threadIdx.x == 0) __hip_atomic_store(flags + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flags_wait(const int* flags, int n) {      // every thread of the workgroup calls it; bounded (a lost arrival must not hang the device)
+    int spins = 0;
+    for (;;) {
+        int mine = 1;
+        for (int q = threadIdx.x; q < n; q += blockDim.x) mine &= __hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (__syncthreads_and(mine) || ++spins >= (1 << 20)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 __host__ __device__ inline int snap_floats(int S) { return kH * (S + 66) + kH + 1; }      // trunk (w1 | b1 | w2 | b2) + wc | bc
 __host__ __device__ inline int snap_stride(int S) { return (snap_floats(S) + 3) & ~3; }       // (16-byte aligned arrays)
 __host__ inline size_t dwp_floats(int n_pad, int S) {
@@ -234,7 +251,7 @@ __host__ inline size_t mb_ws_floats(int n_pad, int I, int S) {
     f += 2 * (size_t)n_pad * kH;                       // da2, da1
     f += nch * (size_t)n_pad * kH + nch * (size_t)n_pad;  // dh2p, entp
     f += (size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I);     // dwap
-    f += 8;                     // sync, snap
+    f += kSyncInts + 4;         // sync
     f += 64 + 1024;                                    // red + sum-of-squares partials (kNormBlocks)
     f += dwp_floats(n_pad, S);                         // dW row slabs (one per 32 rows: trunk_bwd_kernel; one per 8 rows in flat order: trunk_rows_kernel)
     f += (size_t)cdiv(I, kTileN) * kPlaneTileU4 * 4;   // wa_planes
@@ -258,7 +275,7 @@ __host__ inline MbView carve(void* ws, int n_pad, int I, int S) {
     v.da2 = take((size_t)n_pad * kH); v.da1 = take((size_t)n_pad * kH);
     v.dh2p = take(nch * (size_t)n_pad * kH); v.entp = take(nch * (size_t)n_pad);
     v.dwap = take((size_t)n_dwa_slabs_of(n_pad) * dwa_slab_stride(I));
-    v.sync = (int*)take(4);
+    v.sync = (int*)take(kSyncInts);
     v.red = take(64);
     v.normp = take(1024);
     v.dwp = take(dwp_floats(n_pad, S));
@@ -823,7 +840,10 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     __shared__ __attribute__((aligned(16))) float sR[2][kBwdWaves][kRSize];   // double-buffered: the sum of tile t runs inside iteration t + 1
     const int tid = threadIdx.x;
     CIRS_SSTAMP(30);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { v.sync[0] = 0; v.sync[1] = 0; }      // arrival counters of this step's trunk-backward / optimiser launches
+    if (blockIdx.x == 0 && blockIdx.y == 0) {      // arrival flags of this step's trunk-backward / optimiser launches
+        v.sync[tid] = 0;
+        if (tid < kSyncInts - 256) v.sync[256 + tid] = 0;
+    }
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
     const int row0 = (blockIdx.y * kBwdWaves + wv) * kTileM;
@@ -1572,11 +1592,7 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
     const int n_f_wgs = (n_dw + kFOut - 1) / kFOut;
     if (b >= n_r + kWaSumBlocks + n_f_wgs) {
         // ---- loss partials of this rank (data-parallel step; the single-rank step forms them in its optimiser launch): needs the rows' entropies
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(v.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_r && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-        }
-        __syncthreads();
+        flags_wait(v.sync, n_r);
         __shared__ float sL[3][512];
         float e = 0.f, c = 0.f, f = 0.f;
         for (int r = tid; r < mb; r += 512) { e += ld_sc1(v.ent_row + r); c += v.clip_row[r]; f += v.vf_row[r]; }
@@ -1596,11 +1612,7 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
         // ---- F ----------------------------------------------------------------------------------------------------------------
         const int f = b - n_r - kWaSumBlocks;
         CIRS_PSTAMP(f == 0, 30);
-        if (tid == 0) {     // (bounded: a lost arrival must not hang the device; the parity tests would see the wrong sums)
-            int spins = 0;
-            while (__hip_atomic_load(v.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_r && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-        }
-        __syncthreads();
+        flags_wait(v.sync, n_r);
         CIRS_PSTAMP(f == 0, 31);
         const int o = tid & (kFOut - 1), q = tid >> 7;          // output of this workgroup, slab quarter
         const int e = f * kFOut + o;
@@ -1775,7 +1787,7 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CIRS_PSTAMP(b == 0, 24);
-    if (tid == 0) __hip_atomic_fetch_add(v.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag_arrive(v.sync, b);
     CIRS_PSTAMP(b == 0, 25);
 }
 
@@ -2043,11 +2055,7 @@ __device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNex
     }
     // ---- the trunk's updated parameters: written through by the A0 workgroups of this launch (22 workgroups, one element per thread, the lowest
     // block ids: dispatched first), counted in sync[1]; read around the caches as 8-byte units -> LDS ---------------------------------------------------
-    if (tid == 0) {     // (bounded: a lost arrival must not hang the device; the bit-identity tests would see stale weights)
-        int spins = 0;
-        while (__hip_atomic_load(mv_sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nx.n_a0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
+    flags_wait(mv_sync + kSyncA0, nx.n_a0);
     CIRS_PSTAMP(b == 0, 1);
     const int ld1 = S | 1, o_b1 = kH * S, o_w2 = o_b1 + kH, o_b2 = o_w2 + kH * kH;
     float2 pw[kTrunkQ2];
@@ -2194,12 +2202,13 @@ __device__ __forceinline__ void adam_next_planes(const AdamArgs& a, const AdamNe
 // A0: element e of [trunk | wc | bc] (nothing else: the T workgroups wait for these)
 __device__ __forceinline__ void adam_next_trunk_params(const AdamArgs& a, const MbView& mv, AdamLds& l, int b0) {
     const int tid = threadIdx.x;
-    float total_norm;
-    const float c = norm_coef_block(a.partial, a.cfg, l.sh, total_norm);
     const long e = b0 * 256L + tid;
     const long i = e < a.L.trunk ? e : a.L.wc + (e - a.L.trunk);
+    const long ic = i < a.L.total ? i : 0;
+    float gi = a.g[ic], pi = a.p[ic], mi = a.m[ic], vi = a.v[ic];      // (requested before the norm's tree: one round trip for both)
+    float total_norm;
+    const float c = norm_coef_block(a.partial, a.cfg, l.sh, total_norm);
     if (i < a.L.total) {
-        float gi = a.g[i], pi = a.p[i], mi = a.m[i], vi = a.v[i];
         if (i < a.L.trunk) adam_elem<2, 2>(pi, mi, vi, gi, a.sa, c, a.beta1, a.beta2, a.eps);
         else adam_elem<1, 1>(pi, mi, vi, gi, a.sb, c, a.beta1, a.beta2, a.eps);
         st_sc1(a.p + i, pi);        // (written through: the T workgroups of this launch read it)
@@ -2207,7 +2216,7 @@ __device__ __forceinline__ void adam_next_trunk_params(const AdamArgs& a, const 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(mv.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag_arrive(mv.sync + kSyncA0, b0);
 }
 // A: ba (the trunk / critic belong to A0, the Wa matrix to the P workgroups); its first workgroup reduces the loss terms and publishes them
 __device__ __forceinline__ void adam_next_rest(const AdamArgs& a, const MbView& mv, AdamLds& l, int ba_) {
@@ -2565,15 +2574,15 @@ static int launch_trunk_bwd(const PpoRun& r, const PpoStep& st, int n_bchunks) {
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 // Which trunk backward a step runs.  trunk_rows_kernel (one launch: chunk-slab sums, trunk backward, every gradient sum, squared-norm / loss
 // partials) or the round-4 sequence dh2_sum_kernel + trunk_bwd_kernel (+ sumsq_partial_kernel / dw_multi_final + loss_partials_kernel).  Measured on
-// one box at C3, 1024 rows (tools/ab_step.py, round 5): 78.5 us per step with trunk_rows_kernel against 77.2 us with the sequence -- its row workgroups
-// wait ~6 us for their 90 KB of operands and ~5 us for the write-through drain of their 22 KB gradient slab while the wa|ba slab sums load the
-// fabric, which costs more than the two launch boundaries it removes -- so the single-rank step keeps the sequence; a data-parallel rank's share of a
-// minibatch (128 rows at 8 ranks: 16 row workgroups) runs trunk_rows_kernel, where four launches of ~5 us each become one.  CIRS_PPO_ROWS_KERNEL=0/1
-// forces either (A/B runs, tests).
-static bool rows_kernel_wanted(int phase) {
+// one box at C3, 1024 rows (tools/ab_step.py, round 5): with ONE arrival counter 78.5 us per step against 77.2 us for the sequence; with one arrival FLAG
+// per row workgroup (128 read-modify-writes of one address were serialised at the memory side) 75.75 against 76.1 us.  CIRS_PPO_ROWS_KERNEL=0/1 forces
+// either (A/B runs, tests).
+static bool rows_kernel_wanted(int phase, int mb) {
+    if (cirs::n_pad_of(mb) / cirs::kRR > cirs::kSyncA0) return false;      // (one arrival flag per row workgroup)
     const char* e = getenv("CIRS_PPO_ROWS_KERNEL");
     if (e) return atoi(e) != 0;
-    return phase == 1;
+    (void)phase;
+    return true;
 }
 static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks, bool with_loss_partials) {
     using namespace cirs;
@@ -2581,6 +2590,7 @@ static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks, 
     const int n_pad = n_pad_of(st.mb), n_slabs = n_row_blocks_of(n_pad);
     const long seg = (long)r.I * kH + r.I;
     const int n_r = n_pad / kRR, n_f = cdiv(snap_floats(r.S), kFOut);
+    CIRS_REQUIRE(n_r <= kSyncA0, "trunk_rows_kernel: more than 2048 rows in a minibatch (one arrival flag per 8 rows)");
     hipLaunchKernelGGL(trunk_rows_kernel, dim3(n_r + kWaSumBlocks + n_f + (with_loss_partials ? 1 : 0)), dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1,
                        r.w.w2, r.w.wc, r.v, st.dobs, r.grads, (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, n_r, snap_stride(r.S),
                        env_int("CIRS_PPO_W_DELAY", 0), with_loss_partials ? r.tail : (float*)nullptr, st.mb_norm);
@@ -2652,7 +2662,7 @@ static int ppo_minibatch_impl(const cirs_ppo_cfg* cfg, float* params, float* gra
     const PpoRun r = ppo_run(cfg, params, grads, adam_m, adam_v, batch, n_env, workspace, carve_mb, (hipStream_t)stream);
     const PpoStep st{idx, (int)mb, idx_global ? idx_global : idx, (int)(idx_global ? mb_global : mb), dobs_accum, loss_out, (long)opt_step};
     bool folded = false;
-    const bool rows = rows_kernel_wanted(phase);
+    const bool rows = rows_kernel_wanted(phase, mb);
     if (phase == 0 || phase == 1) {
         CIRS_REQUIRE(idx != nullptr || (ch && ch->head_done), "idx is null");
         int n_bchunks = 0;
@@ -2731,7 +2741,6 @@ extern "C" int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* gra
         const int32_t* idx = perms + (size_t)rep * n_rows + b;
         return PpoStep{idx, e - b, idx, e - b, (dobs_accum && rep == n_repeat - 1) ? dobs_accum : nullptr, losses + 4 * (size_t)k, (long)(opt_step + k)};
     };
-    const bool rows = rows_kernel_wanted(0);
     bool have_head = false;     // the head of step k (trunk forward, statistics, planes) already ran inside step k - 1's Adam launch
     for (int k = 0; k < n_steps; ++k) {
         const PpoStep st = step_of(k);
@@ -2740,6 +2749,7 @@ extern "C" int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* gra
         }
         int n_bchunks = 0;
         bool folded = false;
+        const bool rows = rows_kernel_wanted(0, st.mb);
         if (!have_head) { if (int rc = launch_trunk_adv(r, st)) return rc; }
         if (int rc = launch_head(r, st, &n_bchunks, !rows)) return rc;
         if (rows) { if (int rc = launch_trunk_rows(r, st, n_bchunks, false)) return rc; folded = true; }
