@@ -1240,6 +1240,42 @@ __device__ __forceinline__ void wa_slab_sum_block(float* __restrict__ g, long wa
     if (tid == 0) *partial_out = sh[0];
 }
 
+// The same sums for trunk_rows_kernel: ONE float4 per thread and pass (8 slab loads, 64 KB in flight per workgroup) and as many workgroups as it takes
+// (340 at C3 instead of 176 x 128 KB): a CU pulls ~11 B/cycle at kernel start whatever is asked of it, so the slab sums take what the SLOWEST CU needs
+// for its share -- many small workgroups let the dispatcher hand the work to whichever CU is free (the row workgroups of the same launch sit on 128 of them).
+constexpr int kWaSlotsMax = 768;   // slots [kNormBlocks, kNormBlocks + 768) of the norm partials: all of them are folded, unused ones hold 0
+__device__ __forceinline__ void wa_slab_sum_block1(float* __restrict__ g, long wa_beg, long wa_len, const float* __restrict__ dwap,
+                                                   long slab_stride, int n_slabs, int b, int n_w, float* __restrict__ partial_out, float* sh) {
+    const int tid = threadIdx.x;  // blockDim.x == 512
+    float acc = 0.f;
+    const long n4 = wa_len >> 2;
+    for (long q4 = b * 512L + tid; q4 < n4; q4 += (long)n_w * 512) {
+        f32x4 ta[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ta[q] = q < n_slabs ? *reinterpret_cast<const f32x4*>(dwap + (size_t)q * slab_stride + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x += ta[q];
+        for (int s0 = 8; s0 < n_slabs; ++s0) x += *reinterpret_cast<const f32x4*>(dwap + (size_t)s0 * slab_stride + 4 * q4);   // (minibatches beyond 1024 rows)
+        *reinterpret_cast<f32x4*>(g + wa_beg + 4 * q4) = x;
+        acc += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    }
+    const long wi = (n4 << 2) + b * 512L + tid;   // the (< 4) elements after the last whole float4 (b = 0 covers them)
+    if (wi < wa_len) {
+        float x = 0.f;
+        for (int s0 = 0; s0 < n_slabs; ++s0) x += dwap[(size_t)s0 * slab_stride + wi];
+        g[wa_beg + wi] = x;
+        acc += x * x;
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int st = 256; st > 0; st >>= 1) {
+        if (tid < st) sh[tid] += sh[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) *partial_out = sh[0];
+}
+
 // one 32 x 32 tile of dW = dY^T X (+ the bias column sum of dY when k0 == 0) over the 32 rows of a trunk-backward workgroup:
 // A = dY from its LDS copy (sY[row][o]), B = X rows from global memory; written as this workgroup's row slab of the job
 // (partial layout of dw_multi_final / dw_multi_fetch: out[o * (K + 1) + k], k == K the bias column)
@@ -1560,7 +1596,7 @@ __global__ __launch_bounds__(512) void trunk_bwd_kernel(int mb, int n_pad, int n
 //   R [0, n_r)            8 rows each: d a2 (chunk slabs summed in chunk order + the critic's term), entropy per row, d a1, d obs scatter, and the
 //                         rows' share of every trunk / critic weight gradient as ONE slab in the flat gradient's own order [w1|b1|w2|b2|wc|bc],
 //                         written through (sc1) before the workgroup counts its arrival
-//   W next kWaSumBlocks   slab sums of the wa|ba gradient + their squared-norm partials (depend on the head backward kernel only)
+//   W next n_w            slab sums of the wa|ba gradient + their squared-norm partials (depend on the head backward kernel only)
 //   F last n_f            wait for the R arrivals, then 128 outputs each: four threads per output sum a quarter of the slabs in slab order and
 //                         meet in quarter order; flat gradient + squared-norm partial.  The hand-off runs beside the W workgroups.
 // R has the lowest indices: everything it needs is dispatched before anything that waits for it.
@@ -1584,13 +1620,14 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
                                                          const float* __restrict__ wc, MbView v, float* __restrict__ dobs_accum, float* __restrict__ g,
                                                          long wa_beg, long wa_len, long slab_stride, int n_slabs, int n_r, int rslab /* floats per R slab */,
                                                          int w_delay /* W workgroups start this many x 1024 cycles late: the R workgroups' requests go first */,
-                                                         float* __restrict__ tail_out /* data-parallel phase 1: {clip, vf, ent, 0} partials of this rank */, int mb_norm) {
+                                                         float* __restrict__ tail_out /* data-parallel phase 1: {clip, vf, ent, 0} partials of this rank */, int mb_norm,
+                                                         int n_w /* W workgroups */) {
     __shared__ RowsLds L;
     __shared__ float sRed[512];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int n_tr = kH * S + kH + kH * kH + kH, n_dw = n_tr + kH + 1;      // [w1 | b1 | w2 | b2] + [wc | bc]
     const int n_f_wgs = (n_dw + kFOut - 1) / kFOut;
-    if (b >= n_r + kWaSumBlocks + n_f_wgs) {
+    if (b >= n_r + n_w + n_f_wgs) {
         // ---- loss partials of this rank (data-parallel step; the single-rank step forms them in its optimiser launch): needs the rows' entropies
         flags_wait(v.sync, n_r);
         __shared__ float sL[3][512];
@@ -1608,9 +1645,9 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
         }
         return;
     }
-    if (b >= n_r + kWaSumBlocks) {
+    if (b >= n_r + n_w) {
         // ---- F ----------------------------------------------------------------------------------------------------------------
-        const int f = b - n_r - kWaSumBlocks;
+        const int f = b - n_r - n_w;
         CIRS_PSTAMP(f == 0, 30);
         flags_wait(v.sync, n_r);
         CIRS_PSTAMP(f == 0, 31);
@@ -1646,14 +1683,17 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
         }
         if (tid == 0) v.normp[f] = sRed[0];
         const int n_f = (n_dw + kFOut - 1) / kFOut;
-        if (f == 0 && tid >= n_f && tid < kNormBlocks) v.normp[tid] = 0.f;      // the slots no workgroup owns
+        if (f == 0) {      // the slots no workgroup owns
+            if (tid >= n_f && tid < kNormBlocks) v.normp[tid] = 0.f;
+            for (int q = n_w + tid; q < kWaSlotsMax; q += 512) v.normp[kNormBlocks + q] = 0.f;
+        }
         CIRS_PSTAMP(f == 0, 33);
         return;
     }
     if (b >= n_r) {
         CIRS_PSTAMP(b == n_r, 26);
         for (int q = 0; q < w_delay; ++q) __builtin_amdgcn_s_sleep(16);
-        wa_slab_sum_block(g, wa_beg, wa_len, v.dwap, slab_stride, n_slabs, b - n_r, v.normp + kNormBlocks + (b - n_r), sRed);
+        wa_slab_sum_block1(g, wa_beg, wa_len, v.dwap, slab_stride, n_slabs, b - n_r, n_w, v.normp + kNormBlocks + (b - n_r), sRed);
         CIRS_PSTAMP(b == n_r, 27);
         return;
     }
@@ -1828,7 +1868,11 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
     const long lo = blockIdx.x * per, hi = min(n_total, lo + per);
     float acc = 0.f;
     // slots of the wa|ba slab-sum workgroups (trunk-backward launch): theirs when wa_fused, zero otherwise
-    if (!wa_fused && blockIdx.x < kWaSumBlocks) { if (tid == 0) partial[kNormBlocks + blockIdx.x] = 0.f; }
+    // (adam_next_kernel folds all kWaSlotsMax slots; blocks 0..255 own slots b, b + 256, b + 512 of them)
+    if (tid < 3) {
+        const int q = blockIdx.x + 256 * tid;
+        if (!wa_fused || q >= kWaSumBlocks) partial[kNormBlocks + q] = 0.f;
+    }
     // everything else: already summed in g unless dw_partial holds it (handled below)
     for (long i = lo + tid; i < hi && !dw_partial; i += 256) {
         const float x = g[i];
@@ -1986,7 +2030,7 @@ __device__ __forceinline__ float norm_coef_block(float part_a, float part_b, con
 }
 __device__ __forceinline__ float norm_coef_block(const float* __restrict__ partial, const cirs_ppo_cfg& cfg, float* sh, float& total_norm) {
     const int tid = threadIdx.x;
-    return norm_coef_block(partial[tid], tid < kWaSumBlocks ? partial[kNormBlocks + tid] : 0.f, cfg, sh, total_norm);
+    return norm_coef_block(partial[tid], (partial[kNormBlocks + tid] + partial[2 * kNormBlocks + tid]) + partial[3 * kNormBlocks + tid], cfg, sh, total_norm);
 }
 constexpr int kTrunkQ2 = 13;         // 256 x 13 float2 >= 64 (S + 66) floats, S <= 32: the trunk's parameters, two elements per thread and pass
 constexpr int kTrunkRowsPerWg = kTileM;   // rows of a T workgroup: one MFMA row tile
@@ -2591,9 +2635,12 @@ static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks, 
     const long seg = (long)r.I * kH + r.I;
     const int n_r = n_pad / kRR, n_f = cdiv(snap_floats(r.S), kFOut);
     CIRS_REQUIRE(n_r <= kSyncA0, "trunk_rows_kernel: more than 2048 rows in a minibatch (one arrival flag per 8 rows)");
-    hipLaunchKernelGGL(trunk_rows_kernel, dim3(n_r + kWaSumBlocks + n_f + (with_loss_partials ? 1 : 0)), dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1,
+    const long n4 = seg >> 2;
+    int n_w = (int)cdiv(n4, 512L);
+    n_w = n_w > kWaSlotsMax ? kWaSlotsMax : n_w;
+    hipLaunchKernelGGL(trunk_rows_kernel, dim3(n_r + n_w + n_f + (with_loss_partials ? 1 : 0)), dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1,
                        r.w.w2, r.w.wc, r.v, st.dobs, r.grads, (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, n_r, snap_stride(r.S),
-                       env_int("CIRS_PPO_W_DELAY", 0), with_loss_partials ? r.tail : (float*)nullptr, st.mb_norm);
+                       env_int("CIRS_PPO_W_DELAY", 0), with_loss_partials ? r.tail : (float*)nullptr, st.mb_norm, n_w);
     CIRS_CHECK_LAUNCH("trunk_rows_kernel");
     return CIRS_OK;
 }
