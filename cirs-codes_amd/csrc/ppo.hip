@@ -826,7 +826,7 @@ __device__ __forceinline__ void mfma_bf16x6_two(const Planes& a0, const Planes& 
 // workgroup for its own rows, the workgroups of chunk 0 store what later kernels read) instead of a launch of their own between the two head
 // kernels: a 6.5 us launch on the critical path of every minibatch step becomes ~1.5 us of prologue.  The item-sharded learner keeps the
 // merge kernel (its statistics cross the ranks first).
-struct HeadMergeArgs { cirs_ppo_cfg cfg; cirs_ppo_batch b; const int32_t* idx; int mb_norm, n_schunks; ActorPartialView pv; };
+struct HeadMergeArgs { cirs_ppo_cfg cfg; cirs_ppo_batch b; const int32_t* idx; int mb_norm, n_schunks; ActorPartialView pv; int t_all; /* A/B switch: every workgroup loads the E_p[z] partials */ };
 template <bool kEnt, bool kMerge>
 __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I, int mb, int n_pad, int tiles_per_chunk,
                                                                          const uint4* __restrict__ planes,
@@ -936,6 +936,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         const float* __restrict__ ps_ = ma.pv.s + jc;
         const float* __restrict__ pt_ = ma.pv.score + jc;
         float M = -INFINITY, ssum = 0.f, tsum = 0.f;
+        // E_p[z]'s partials only where somebody uses them: every workgroup when the entropy term is in dZ, else the chunk-0 workgroups (they store the reported
+        // entropy) -- a third of the prologue's 86 KB per workgroup for the other 30 of 31 (a prologue costs what its bytes cost: ~11 B/cycle per CU)
+        const bool need_t = kEnt || blockIdx.x == 0 || ma.t_all;
         for (int cb = 0; cb < nsc; cb += 64) {          // (wave-uniform trip count: the two halves meet in a shuffle inside)
             const int c0 = cb + hi;
             float m32[32], s32[32], u32[32];
@@ -943,7 +946,17 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
             for (int q = 0; q < 32; ++q) {
                 const int c = c0 + 2 * q;
                 const size_t o = (size_t)(c < nsc ? c : nsc - 1) * n_pad;
-                m32[q] = pm_[o]; s32[q] = ps_[o]; u32[q] = pt_[o];
+                m32[q] = pm_[o]; s32[q] = ps_[o];
+            }
+            if (need_t) {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+                    const int c = c0 + 2 * q;
+                    u32[q] = pt_[(size_t)(c < nsc ? c : nsc - 1) * n_pad];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) u32[q] = 0.f;
             }
             float mb_ = -INFINITY;
 #pragma unroll
@@ -2494,6 +2507,7 @@ extern "C" int cirs_adam_step(float* params, const float* grads, float* m, float
 
 // ---- the launches of a minibatch step as separate pieces, so that cirs_ppo_minibatch (one step), cirs_ppo_minibatch_dp (the step cut at the
 // gradient all-reduce) and cirs_ppo_learn (all steps of an update from one call) issue the SAME kernels on the same data ---------------
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 struct PpoRun {     // what does not change between the steps of a call
     const cirs_ppo_cfg* cfg;
     float *params, *grads, *adam_m, *adam_v;
@@ -2557,7 +2571,7 @@ static int launch_head(const PpoRun& r, const PpoStep& st, int* n_bchunks_out, b
     CIRS_CHECK_LAUNCH("head_stats_kernel");
     // head backward; the merge of the statistics partials + row losses + backward coefficients (means over the global minibatch) run in
     // its prologue (CIRS_PPO_MERGE_KERNEL=1: as a launch of their own, the round-2 sequence, for A/B runs)
-    const HeadMergeArgs hma{*r.cfg, *r.batch, st.idx, st.mb_norm, n_schunks, pv};
+    const HeadMergeArgs hma{*r.cfg, *r.batch, st.idx, st.mb_norm, n_schunks, pv, env_int("CIRS_PPO_MERGE_T_ALL", 0)};
     if (r.merge_launch) {
         hipLaunchKernelGGL(head_stats_merge_kernel, dim3(cdiv(n_pad, 4)), dim3(256), 0, r.s, *r.cfg, *r.batch, st.idx, mb, st.mb_norm, n_pad, n_schunks,
                            r.n_env, pv, r.w.wa, r.w.ba, v, (const float*)nullptr, 0);
@@ -2615,7 +2629,6 @@ static int launch_trunk_bwd(const PpoRun& r, const PpoStep& st, int n_bchunks) {
     CIRS_CHECK_LAUNCH("trunk_bwd_kernel");
     return CIRS_OK;
 }
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 // Which trunk backward a step runs.  trunk_rows_kernel (one launch: chunk-slab sums, trunk backward, every gradient sum, squared-norm / loss
 // partials) or the round-4 sequence dh2_sum_kernel + trunk_bwd_kernel (+ sumsq_partial_kernel / dw_multi_final + loss_partials_kernel).  Measured on
 // one box at C3, 1024 rows (tools/ab_step.py, round 5): with ONE arrival counter 78.5 us per step against 77.2 us for the sequence; with one arrival FLAG
