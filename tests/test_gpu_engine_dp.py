@@ -168,9 +168,9 @@ def _virtual_rank_update(monkeypatch, W, B, I, U, T, bs, mode, c4=False):
     # (tp: the item-sharded learner takes the action's logit from a scalar fp32 chain on the owning shard, the single-device step from the
     #  bf16x6 accumulator of its statistics kernel -- 1e-7 apart, which Adam turns into a few 1e-6 on near-zero gradients)
     got_p, want_p = engines[0].policy_flat.cpu().numpy(), ref.policy_flat.cpu().numpy()
-    if mode == "tp":     # (a handful of near-zero gradients may land on the other side of Adam's normalisation: bounded, and rare)
-        bad = ~np.isclose(got_p, want_p, rtol=3e-4, atol=8e-6)
-        assert bad.mean() < 2e-4 and np.abs(got_p - want_p).max() < 2e-4, (int(bad.sum()), float(np.abs(got_p - want_p).max()))
+    if mode == "tp":     # a strict bar again (observed since the 1-ulp Adam arithmetic of round 5: max |error| 1.6e-6, nothing beyond the bar; gpurun_out/parity_margins.json)
+        import conftest
+        conftest.close(got_p, want_p, 3e-4, 8e-6, f"engine tp W={W}, {got_p.size} parameters after the update vs single device")
     else:
         np.testing.assert_allclose(got_p, want_p, rtol=3e-4, atol=3e-6)
     got_t, want_t = engines[0].tracker_flat.cpu().numpy(), ref.tracker_flat.cpu().numpy()
