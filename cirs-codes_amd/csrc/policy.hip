@@ -146,7 +146,8 @@ extern "C" int64_t cirs_policy_workspace_bytes(const cirs_policy_cfg* cfg, int32
     if (!cfg || n <= 0) return 0;
     // + slack: the fused rollout may carve one (256-byte aligned) workspace per env group out of this buffer
     // + the packed weight image of the fused rollout's step kernel (internal.h: TrkImg) at its end
-    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items)) * 4 + 8192 + kTrkImgBytes;
+    // + the logit store of the fused rollout's sampler while it is small (policy_kernels.h: ws_zstore_floats)
+    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items) + ws_zstore_floats(n, cfg->n_items)) * 4 + 8192 + kTrkImgBytes;
 }
 
 extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state,

@@ -27,6 +27,16 @@ __host__ __device__ inline int n_pad_of(int n) { return ((n + kTileM - 1) / kTil
 
 __host__ inline size_t ws_h2_floats(int n) { return (size_t)n_pad_of(n) * kH; }
 __host__ inline size_t ws_partial_elems(int n, int n_items) { return (size_t)n_chunks_of(n_items) * n_pad_of(n); }
+// Logit store of the two-level sampler for SMALL env counts (round 5): actor_mass_kernel keeps the 128 logits of every (chunk, env row) it has just
+// computed -- [n_chunks][n_pad][128] floats -- and the step kernel's pick reads the two logits a lane needs of the drawn chunk instead of re-reading
+// the chunk's 32 KB of head rows and redoing 128 dot products at the head of its dependent chain (~8 k of the step kernel's 58 k cycles).  The
+// values are the ones the recompute reproduces bit for bit (the MFMA accumulators).  Only while the store stays small (L2 resident): at C3 it would be
+// 44 MB per vector step.
+constexpr size_t kZStoreMaxFloats = 1u << 20;     // 4 MB
+__host__ inline size_t ws_zstore_floats(int n, int n_items) {
+    const size_t f = ws_partial_elems(n, n_items) * kChunkItems;
+    return f <= kZStoreMaxFloats ? f : 0;
+}
 
 __host__ __device__ inline ActorPartialView partial_view(void* ws, int n, int n_items) {
     float* base = (float*)ws + (size_t)n_pad_of(n) * kH;
@@ -350,7 +360,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
                                                                    const uint32_t* __restrict__ visited,
                                                                    const uint8_t* __restrict__ skip, float* __restrict__ lmass,
                                                                    int n_pad, int chunks_per_wg, int item_base = 0,
-                                                                   int n_items_total = 0, int env_base = 0) {
+                                                                   int n_items_total = 0, int env_base = 0, float* __restrict__ zstore = nullptr) {
     __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
@@ -459,6 +469,14 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
             CIRS_MSTAMP(4 + 2 * t);
         }
         if (!wave_live) continue;
+        if (zstore && active) {      // the chunk's logits of this row as computed (before masking): item t * 32 + 8 q + 4 hi + (0..3) in one 16-byte store
+            float* zr = zstore + ((size_t)c * n_pad + jr) * kChunkItems + 4 * hi;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(zr + t * kTileN + 8 * q) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        }
         // mask, chunk maximum over the lane pair, fixed-order sum of exponentials
         float mloc = -INFINITY;
         if (!visited && (c + 1) * kChunkItems <= I) {     // whole chunk inside the catalogue, nothing masked: no per-element tests
@@ -653,6 +671,7 @@ struct PickArgs {
     const float *wa, *ba, *h2;                   // head rows of this shard, hidden rows [n, 64]
     const uint32_t* visited; int n_items, item_base, n_items_total;
     uint64_t seed; uint32_t rng_step;
+    const float* zstore;                          // (nullable) logit store of actor_mass_kernel, [n_chunks][n_pad][128]: the pick reads instead of recomputing
 };
 // The 128 head rows of the drawn chunk are 32 KB of CONSECUTIVE memory: the wave reads them coalesced (32 x 1 KB, all requested at
 // once) and transposes them through `stage` (per-wave LDS, kPickStage floats: 64 rows of kH + 4 floats -- 16-byte rows whose b128
@@ -710,6 +729,30 @@ __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e,
         const int ilc = live[q] ? il : a.n_items - 1;
         bias[q] = a.ba[ilc];
         vword[q] = a.visited ? a.visited[(size_t)e * vis_words + ((a.item_base + ilc) >> 5)] : 0u;
+    }
+    if (a.zstore) {      // the drawn chunk's logits were kept by actor_mass_kernel: two coalesced loads per lane, no head rows, no dot products
+        float zq[2], gz[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) zq[q] = a.zstore[((size_t)cw.bi * a.n_pad + j) * kChunkItems + lane + 64 * q];
+        CIRS_PICK_STAMP(36);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gz[q] = actor_gumbel(a.seed, a.rng_step, (uint32_t)e, (uint32_t)(a.item_base + row0 + lane + 64 * q));
+        CIRS_PICK_STAMP(38);
+        const Mass mwz = mass_wave_reduce(ms);
+        CIRS_PICK_STAMP(22);
+        CIRS_PICK_STAMP(23);
+        CIRS_PICK_STAMP(37);
+        after_issue();
+        Best itz{-INFINITY, 0.f, 0x7FFFFFFF};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ig = a.item_base + row0 + lane + 64 * q;
+            if (live[q] && !((vword[q] >> (ig & 31)) & 1u)) best_fold(itz, zq[q] + gz[q], ig, zq[q]);
+        }
+        CIRS_PICK_STAMP(24);
+        const Best iwz = best_wave_reduce(itz);
+        CIRS_PICK_STAMP(25);
+        return Cand{cw.bs, iwz.bz, mwz.m, mwz.s, iwz.bi};
     }
     // (native vector values: a float4 struct copy becomes a memcpy through a private array that is not promoted to registers)
     typedef float pick_v4 __attribute__((ext_vector_type(4)));

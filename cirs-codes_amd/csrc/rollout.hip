@@ -233,6 +233,12 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         q.cpw = mass_chunks_per_wg(n_mass_chunks, q.hg.n_row_blocks);
         q.st = g == 0 ? s : gs[g];
     }
+    // logit store (one group, counter-based sampler, small env counts): behind the group's sampler scratch
+    float* zstore = nullptr;
+    if (n_groups == 1 && !gumbel && ws_zstore_floats(n_env, pol_cfg->n_items) > 0) {
+        static const int zs_on = [] { const char* ev = getenv("CIRS_ROLLOUT_ZSTORE"); return ev ? atoi(ev) : 1; }();
+        if (zs_on) zstore = (float*)((char*)workspace + ws_per);
+    }
     const uint8_t* done_all = (const uint8_t*)env_st->done;
     // Exact-redraw dropout (the reference's procedure, core/state_tracker.py:170-186,243-246): the state of vector step t is NOT the cached decode's -- it is
     // ONE batched causal pass over positions 0 .. t of every env with the masks of build_state call t (cirs_tracker_prefix_states, key = the collect's key with
@@ -272,7 +278,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
             } else {       // counter-based sampler: chunk log-masses now, chunk + item draws in the tail of the step kernel
                 CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(n_mass_chunks, q.cpw), q.hg.n_row_blocks), dim3(256), 0,
                                                              q.st, *pol_cfg, pol_w->wa, pol_w->ba, (const float*)q.h2, q.n, (const int32_t*)nullptr,
-                                                             (const uint32_t*)visited, done_all + q.base, q.pv.m, q.n_pad, q.cpw, 0, 0, q.base));
+                                                             (const uint32_t*)visited, done_all + q.base, q.pv.m, q.n_pad, q.cpw, 0, 0, q.base, zstore));
             }
             CIRS_CHECK_LAUNCH("sampler kernel");
             TrunkFuse tf{};
@@ -288,7 +294,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
             tl.visited = visited; tl.force_length = force_length;
             if (!gum_t) {
                 tl.pick_on = 1;
-                tl.pick = PickArgs{q.pv.m, q.n_pad, n_mass_chunks, pol_w->wa, pol_w->ba, q.h2, visited, pol_cfg->n_items, 0, 0, seed, rng_base + (uint32_t)t};
+                tl.pick = PickArgs{q.pv.m, q.n_pad, n_mass_chunks, pol_w->wa, pol_w->ba, q.h2, visited, pol_cfg->n_items, 0, 0, seed, rng_base + (uint32_t)t, zstore};
             }
             tl.force_done = (t + 1 >= force_length) ? 1 : 0;
             tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B + q.base; tl.rew_out = rew_t; tl.done_out = done_t;
