@@ -681,7 +681,9 @@ def main():
             if args.workload == "c3" and not args.dropout_redraw:
                 out["dropout_off" if args.dropout > 0 else "dropout_on"] = timed_pass(WORKLOADS["c3"], device, 0.0 if args.dropout > 0 else 0.1, args.warmup, args.steps, G)
             if args.workload != "c2":
-                out["c2"] = timed_pass(WORKLOADS["c2"], device, args.dropout, args.warmup, args.steps, G)
+                # (C2 learns from 2 minibatch steps per update: after the driver's 5 + 20 steps its episodes are still 12 steps long and the number says
+                #  nothing about the shape; a step is 1.7 ms, so this pass always runs >= 150 warm-up and >= 100 timed steps -- its own `steps` / `warmup` are reported)
+                out["c2"] = timed_pass(WORKLOADS["c2"], device, args.dropout, max(args.warmup, 150), max(args.steps, 100), G)
             out["gather_fm"] = gather_fm_probe(device)
             out["deepfm_sweep"] = deepfm_sweep_probe(wl, device)
             out["sweep_mode"] = sweep_mode_probe(wl, eng, device)
@@ -689,7 +691,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl, eng)
         # what else this run measured, in `config` (the driver's record keeps config / roofline / cpu_baseline whole and everything else by name only)
-        brief = lambda e: {k: e[k] for k in ("value", "ms_per_step", "mean_episode_len", "tracker_dropout", "envs", "minibatch_steps_per_update")}  # noqa: E731
+        brief = lambda e: {k: e[k] for k in ("value", "ms_per_step", "mean_episode_len", "tracker_dropout", "envs", "minibatch_steps_per_update", "steps", "warmup")}  # noqa: E731
         also = {"rollout_only_env_steps_per_s": out["rollout_only_env_steps_per_s"], "rollout_only_ms_per_collect": out["rollout_only_ms_per_collect"],
                 "update_only_ms": out["update_only_ms"], "minibatch_step_us": 1e6 * t_mb, "minibatch_step_launches": out["minibatch_step"]["launches"],
                 "ppo_minibatch_steps_per_s": out["ppo_minibatch_steps_per_s"]}

@@ -57,16 +57,18 @@ def test_bench_dropout_mode_line():
 
 def test_bench_default_workload_carries_dropout_and_c2_passes():
     """the default (C3) single-GPU line runs the tracker in training mode and also carries a timed pass with the
-    eval-mode tracker and a timed pass of BASELINE configs[1] (C2), all with the headline's warm-up / step protocol -- and their numbers sit in
+    eval-mode tracker (the headline's warm-up / step protocol) and a timed pass of BASELINE configs[1] (C2, at its steady state) -- and their numbers sit in
     `config.also_measured`, which the driver's record keeps whole."""
     d = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     assert "7176x10728" in d["config"]["workload"] and d["dropout"] == 0.1
     for key, envs, p in (("dropout_off", 1024, 0.0), ("c2", 64, 0.1)):
         e = d[key]
-        assert e["value"] > 0 and e["unit"] == "env-steps/s" and e["ms_per_step"] > 0 and e["steps"] == 2 and e["warmup"] == 1
+        assert e["value"] > 0 and e["unit"] == "env-steps/s" and e["ms_per_step"] > 0
+        # the C3 pass repeats the headline's protocol; the C2 pass (1.7 ms per step) always runs to its steady state: >= 150 warm-up, >= 100 timed steps
+        assert (e["steps"], e["warmup"]) == ((2, 1) if key == "dropout_off" else (100, 150))
         assert e["envs"] == envs and e["tracker_dropout"] == p
         a = d["config"]["also_measured"][key]
-        assert a["value"] == e["value"] and a["ms_per_step"] == e["ms_per_step"] and a["mean_episode_len"] == e["mean_episode_len"]
+        assert a["value"] == e["value"] and a["ms_per_step"] == e["ms_per_step"] and a["mean_episode_len"] == e["mean_episode_len"] and a["steps"] == e["steps"]
     assert "7176x10728" in d["dropout_off"]["workload"] and "1411x3327" in d["c2"]["workload"]
     am = d["config"]["also_measured"]
     assert am["rollout_only_env_steps_per_s"] > 0 and am["minibatch_step_us"] > 0 and am["minibatch_step_launches"] == 4
