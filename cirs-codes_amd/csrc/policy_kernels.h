@@ -524,6 +524,118 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
 #undef CIRS_COMMIT
 }
 
+// ---- the same chunk masses for FEW env rows (n_pad <= 128), one workgroup per chunk, one WAVE per (row tile, item tile) -----------------------
+// actor_mass_kernel walks the four item tiles of a chunk one after the other in each wave: at 64 envs (BASELINE configs[1]) that is 26 workgroups of two live
+// waves, 9.9 us of which ~4 us are the three tiles that wait their turn.  Here the chunk's four tiles run side by side in four waves per row tile
+// (2 row tiles x 4 = 8 waves at 64 envs): the whole 32 KB of the chunk's head rows are staged at once, every wave does ONE tile's 32 MFMAs and its 16
+// exponentials per lane, and only what has an order is serial -- the half-wave sums S_hi = (((0 + e(t0, r0)) + e(t0, r1)) + ... + e(t3, r15)) are handed
+// from tile wave to tile wave through LDS (16 adds and one barrier per hand-off).  Bits identical to actor_mass_kernel (max is order-free; the sum keeps
+// its order).  grid = n_chunks, block = (n_pad / 32) * 256 threads.
+static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa, const float* __restrict__ ba,
+                                                                       const float* __restrict__ h2, int n, const uint32_t* __restrict__ visited,
+                                                                       const uint8_t* __restrict__ skip, float* __restrict__ lmass, int n_pad, int env_base,
+                                                                       float* __restrict__ zstore) {
+    __shared__ __attribute__((aligned(16))) float sW[4][kTileN * kLdsStride];     // the chunk's four item tiles
+    __shared__ __attribute__((aligned(16))) float sB[4][kTileN];
+    __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];     // one hidden tile per row tile
+    __shared__ float sM[4][4][kTileM];                                             // [row tile][item tile][row]: the tile's maximum
+    __shared__ float sS[4][2][kTileM];                                             // [row tile][half][row]: the running half-wave sum
+    const int tid = threadIdx.x, n_thr = blockDim.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int hi = lane >> 5, lo = lane & 31;
+    const int rt = wv >> 2, tt = wv & 3;
+    const int I = cfg.n_items, c = blockIdx.x;
+    const int vis_words = (I + 31) / 32;
+    typedef float mass_v4 __attribute__((ext_vector_type(4)));
+    // the chunk's 128 head rows (rows beyond the catalogue: zeros) and biases, the hidden tiles: everything requested before the first wait
+    for (int f = tid; f < kChunkItems * (kH / 4); f += n_thr) {
+        const int il = f >> 4, col4 = f & 15, item = c * kChunkItems + il;
+        const mass_v4 v = item < I ? *reinterpret_cast<const mass_v4*>(wa + (size_t)item * kH + 4 * col4) : mass_v4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<mass_v4*>(&sW[il >> 5][(il & 31) * kLdsStride + 4 * col4]) = v;
+    }
+    if (tid < kChunkItems) sB[tid >> 5][tid & 31] = c * kChunkItems + tid < I ? ba[c * kChunkItems + tid] : 0.f;
+    for (int f = tid; f < n_pad * (kH / 4); f += n_thr) {
+        const int r = f >> 4, col4 = f & 15;
+        const mass_v4 v = r < n ? *reinterpret_cast<const mass_v4*>(h2 + (size_t)r * kH + 4 * col4) : mass_v4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<mass_v4*>(&sH[r >> 5][(r & 31) * kLdsStride + 4 * col4]) = v;
+    }
+    const int jr = rt * kTileM + lo;
+    const bool active = jr < n && !(skip && skip[jr]);
+    const int e = env_base + jr;
+    const int tile0 = c * kChunkItems + tt * kTileN;
+    const uint32_t vis = (visited && active && tile0 < I) ? visited[(size_t)e * vis_words + (tile0 >> 5)] : 0u;
+    __syncthreads();
+    f32x16 acc;
+    {
+        float wrow[32], hrow[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&sW[tt][lo * kLdsStride + hi * 32 + 4 * q]);
+            wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
+            const float4 h4 = *reinterpret_cast<const float4*>(&sH[rt][lo * kLdsStride + hi * 32 + 4 * q]);
+            hrow[4 * q] = h4.x; hrow[4 * q + 1] = h4.y; hrow[4 * q + 2] = h4.z; hrow[4 * q + 3] = h4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = sB[tt][(r & 3) + 8 * (r >> 2) + 4 * hi];
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
+    }
+    if (zstore && active) {
+        float* zr = zstore + ((size_t)c * n_pad + jr) * kChunkItems + tt * kTileN + 4 * hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(zr + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool valid = tile0 + il < I && !((vis >> (il & 31)) & 1u);
+        acc[r] = valid ? acc[r] : -INFINITY;
+        mloc = fmaxf(mloc, acc[r]);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, CIRS_WAVE));
+    if (hi == 0) sM[rt][tt][lo] = mloc;
+    __syncthreads();
+    const float M = fmaxf(fmaxf(sM[rt][0][lo], sM[rt][1][lo]), fmaxf(sM[rt][2][lo], sM[rt][3][lo]));
+    det_f2 ex[8];
+    if (M > -INFINITY) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 8) {
+            det_f2 x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x[i].x = acc[r + 2 * i] - M; x[i].y = acc[r + 2 * i + 1] - M; }
+            det_f2 o4[4];
+            det_expf_neg8(x, o4);                         // masked elements: e^(-inf) = 0
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[r / 2 + i] = o4[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ex[i] = det_f2{0.f, 0.f};
+    }
+    // the ordered sum, tile after tile (every wave passes every barrier)
+    float sl = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (tt == t) {
+            sl = t == 0 ? 0.f : sS[rt][hi][lo];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sl += ex[i].x; sl += ex[i].y; }
+            if (t < 3) sS[rt][hi][lo] = sl;
+        }
+        if (t < 3) __syncthreads();
+    }
+    if (tt == 3) {
+        float L = -INFINITY;
+        const float so = __shfl_xor(sl, 32, CIRS_WAVE);
+        if (M > -INFINITY) {
+            const float S = hi == 0 ? sl + so : so + sl;                          // S_hi0 + S_hi1, in that order on both lanes
+            L = M + det_logf(S);
+        }
+        if (hi == 0) lmass[(size_t)c * n_pad + jr] = active ? L : -INFINITY;
+    }
+}
+
 // ---- merge of the per-chunk partials of one env row (one wavefront) --------------------------------------------------------
 // Candidate = (noisy score, item id, its logit); the winner is the highest score, ties -> lowest id (order independent);
 // (m, s) = running max / sum-exp of the logits, folded pairwise.  Lanes first fold the chunks they own (lane, lane + 64, ...),

@@ -239,6 +239,8 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         static const int zs_on = [] { const char* ev = getenv("CIRS_ROLLOUT_ZSTORE"); return ev ? atoi(ev) : 1; }();
         if (zs_on) zstore = (float*)((char*)workspace + ws_per);
     }
+    static const int mass_small_on = [] { const char* ev = getenv("CIRS_ROLLOUT_MASS_SMALL"); return ev ? atoi(ev) : 1; }();
+    const bool mass_small = mass_small_on && n_groups == 1 && !gumbel && grp[0].n_pad <= 128;
     const uint8_t* done_all = (const uint8_t*)env_st->done;
     // Exact-redraw dropout (the reference's procedure, core/state_tracker.py:170-186,243-246): the state of vector step t is NOT the cached decode's -- it is
     // ONE batched causal pass over positions 0 .. t of every env with the masks of build_state call t (cirs_tracker_prefix_states, key = the collect's key with
@@ -275,6 +277,10 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                                                              pol_w->wa, pol_w->ba, (const float*)q.h2, q.n, gum_t, seed,
                                                              rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
                                                              done_all, q.pv, q.n_pad, q.hg.tiles_per_chunk));
+            } else if (mass_small) {   // few envs: one workgroup per chunk, one wave per (row tile, item tile)
+                CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_small_kernel, dim3(n_mass_chunks), dim3(q.n_pad / kTileM * 256), 0, q.st, *pol_cfg, pol_w->wa,
+                                                             pol_w->ba, (const float*)q.h2, q.n, (const uint32_t*)visited, done_all + q.base, q.pv.m, q.n_pad, q.base,
+                                                             zstore));
             } else {       // counter-based sampler: chunk log-masses now, chunk + item draws in the tail of the step kernel
                 CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(n_mass_chunks, q.cpw), q.hg.n_row_blocks), dim3(256), 0,
                                                              q.st, *pol_cfg, pol_w->wa, pol_w->ba, (const float*)q.h2, q.n, (const int32_t*)nullptr,
