@@ -26,7 +26,7 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     rows = list(db.execute("select name, start, end from kernels order by start"))
     ks = [(short(n), s, e) for n, s, e in rows]
-    is_roll = lambda n: n.startswith("tracker_step_kernel") or n.startswith("actor_mass_kernel") or n.startswith("actor_pick") \
+    is_roll = lambda n: n.startswith("tracker_step_kernel") or n.startswith("actor_mass_kernel") or n.startswith("actor_mass_small_kernel") or n.startswith("actor_pick") \
         or n.startswith("actor_head_kernel") or n.startswith("actor_merge")
     # step boundaries: a rollout kernel whose predecessor is not a rollout kernel
     starts = [i for i, k in enumerate(ks) if is_roll(k[0]) and (i == 0 or not is_roll(ks[i - 1][0]))]
