@@ -93,13 +93,13 @@ def build_engine(wl, rank, world, device, learner="dp", dropout=0.0, tracker_bac
     return eng, tab
 
 
-def timed_pass(wl, device, dropout, warmup, steps, batch=1024):
+def timed_pass(wl, device, dropout, warmup, steps, batch=1024, pretrain=0):
     """One more workload through the protocol of the headline (fresh engine, `warmup` untimed steps, `steps` timed steps = collect + update
     between synchronisations, single GPU) -> the numbers the driver's one default run would otherwise never witness: the C3 step with
     the tracker in training mode (Dropout(0.1) live in rollout and BPTT, the way the reference trains) and BASELINE
     configs[1] (C2: 1411 x 3327, 64 envs)."""
     eng, _ = build_engine(wl, 0, 1, device, dropout=dropout)
-    for _ in range(warmup):
+    for _ in range(pretrain + warmup):
         eng.collect(); eng.update(batch_size=batch, repeat=2)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # one event per step on the launch stream: the spread of the steps
     gc.collect()
@@ -495,6 +495,10 @@ def main():
     ap.add_argument("--scaled-batch-steps", type=int, default=-1,
                     help="N > 1: extra steps timed with the global minibatch scaled to --global-batch x N (constant optimiser steps per update; "
                          "reported under scaled_batch_variant, never as value).  -1 = min(steps, 5), 0 = skip")
+    ap.add_argument("--pretrain-steps", type=int, default=40,
+                    help="untimed collect + update steps BEFORE the counted warm-up, so that the timed steps run in the steady state (episodes at max_turn) whatever "
+                         "--warmup is: a fresh policy plays short episodes for its first ~25 updates and the driver's 5 + 20 steps would time that transient "
+                         "(reported as config.pretrain_steps; the fresh-policy number stays in config.also_measured.fresh_policy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probes", action="store_true", help="skip the secondary probes (gather_fm / sweep / cpu baseline): contract line only")
     args = ap.parse_args()
@@ -539,6 +543,8 @@ def main():
         losses, n = eng.update(batch_size=G, repeat=2)
         return losses.shape[0]
 
+    for _ in range(args.pretrain_steps):     # the policy reaches its steady state (full-length episodes) before the counted warm-up
+        one_step()
     for _ in range(args.warmup):
         one_step()
     # Python's cyclic collector stays out of the timed region (as timeit does): a generation-2 pass over the tables / engines built above costs
@@ -636,7 +642,8 @@ def main():
                                         "exact redraw (the reference's procedure: fresh masks over the whole prefix at every build_state call)" if args.dropout_redraw
                                         else "position-keyed masks (every state has the reference's marginal distribution; a position keeps its masks for the rest of the episode)"),
                        "mean_episode_len": total_steps / args.steps / (wl["B"] * world), "env_steps_per_step": total_steps / args.steps,
-                       "max_turn": wl["T"], "timed_region": f"{args.warmup} warm-up + {args.steps} timed collect+update steps from a freshly initialised policy (gc disabled inside the timed region)",
+                       "max_turn": wl["T"], "pretrain_steps": args.pretrain_steps,
+                       "timed_region": f"{args.pretrain_steps} untimed pre-training steps (steady state: full-length episodes), then {args.warmup} warm-up + {args.steps} timed collect+update steps (gc disabled inside the timed region)",
                        "parallelism": (f"env-sharded x{world}; one all-gather of trajectory records per update; learner '{args.learner}': "
                                        + {"dp": f"global minibatch of {G} rows sharded by rows over the ranks, one flat-gradient all-reduce per minibatch",
                                           "dp_sharded": f"global minibatch of {G} rows sharded by rows, reduce-scatter + sharded Adam + parameter all-gather per minibatch",
@@ -679,7 +686,10 @@ def main():
             # the same warm-up / step protocol on more workloads, so that the driver's one default run carries them (never `value`):
             # the C3 step in the OTHER tracker mode (headline = Dropout(0.1) live, extra = eval-mode tracker, or the reverse) and C2
             if args.workload == "c3" and not args.dropout_redraw:
-                out["dropout_off" if args.dropout > 0 else "dropout_on"] = timed_pass(WORKLOADS["c3"], device, 0.0 if args.dropout > 0 else 0.1, args.warmup, args.steps, G)
+                out["dropout_off" if args.dropout > 0 else "dropout_on"] = timed_pass(WORKLOADS["c3"], device, 0.0 if args.dropout > 0 else 0.1, args.warmup, args.steps, G,
+                                                                                      pretrain=args.pretrain_steps)
+                if args.pretrain_steps > 0:      # the transient the driver's line used to time (rounds 1-5): same flags, policy fresh at the first warm-up step
+                    out["fresh_policy"] = timed_pass(WORKLOADS["c3"], device, args.dropout, args.warmup, args.steps, G)
             if args.workload != "c2":
                 # (C2 learns from 2 minibatch steps per update: after the driver's 5 + 20 steps its episodes are still 12 steps long and the number says
                 #  nothing about the shape; a step is 1.7 ms, so this pass always runs >= 150 warm-up and >= 100 timed steps -- its own `steps` / `warmup` are reported)
@@ -695,12 +705,12 @@ def main():
         also = {"rollout_only_env_steps_per_s": out["rollout_only_env_steps_per_s"], "rollout_only_ms_per_collect": out["rollout_only_ms_per_collect"],
                 "update_only_ms": out["update_only_ms"], "minibatch_step_us": 1e6 * t_mb, "minibatch_step_launches": out["minibatch_step"]["launches"],
                 "ppo_minibatch_steps_per_s": out["ppo_minibatch_steps_per_s"]}
-        for key in ("dropout_off", "dropout_on", "c2"):
+        for key in ("dropout_off", "dropout_on", "c2", "fresh_policy"):
             if key in out:
                 also[key] = brief(out[key])
         out["config"]["also_measured"] = also
         # print order: the bulky probe objects first, the numbers a reader wants last (a log tail keeps the end of the line)
-        tail_keys = ("roofline", "minibatch_step", "dropout_off", "dropout_on", "c2", "rollout_only_env_steps_per_s", "rollout_only_ms_per_collect",
+        tail_keys = ("roofline", "minibatch_step", "dropout_off", "dropout_on", "fresh_policy", "c2", "rollout_only_env_steps_per_s", "rollout_only_ms_per_collect",
                      "update_only_ms", "ppo_minibatch_steps_per_s")
         bulky = ("cpu_baseline", "gather_fm", "deepfm_sweep", "sweep_mode", "c5_split", "hbm_traffic_per_launch")
         ordered = {k: out[k] for k in bulky if k in out}

@@ -151,6 +151,7 @@ SIGNATURES = {
     "cirs_ppo_minibatch_dp_chain": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P,
                                               _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P]),
     "cirs_ppo_learn_steps": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
+    "cirs_ppo_handoff_status": (C.c_int, [_P, C.c_int32, _P]),
     "cirs_ppo_learn": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, C.c_int32, C.c_int32,
                                  _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
     "cirs_tracker_backward_workspace_bytes": (C.c_int64, [C.POINTER(TrackerCfg), C.c_int32]),

@@ -233,10 +233,13 @@ class CirsEngine:
             self._lens_pinned = torch.empty(self.B_total, dtype=torch.int32).pin_memory()
         lens_i32 = lens_d if lens_d.dtype == torch.int32 else lens_d.to(torch.int32)
         self._lens_pinned.copy_(lens_i32, non_blocking=True)
+        ln.request_handoff_status()     # (4 more bytes in the same read-back: did a hand-off wait of an earlier update's minibatch steps give up?)
         done = torch.cuda.Event(); done.record(cur)
         ln.prepare_async(traj, lens_i32)
         done.synchronize()
         lens = self._lens_pinned.numpy().copy()
+        if ln.handoff_lost():
+            ln.check_handoffs(reset=True)   # raises CirsHipError
         self._last_prepared = (traj, lens, lens_d)      # bench.py's kernel probe re-prepares the full-catalogue learner from it in tp mode
         n = ln.finish_prepare(lens)
         if perms is None and self.world > 1:

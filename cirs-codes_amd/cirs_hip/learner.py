@@ -94,6 +94,33 @@ class DeviceLearner:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    # ---- in-launch hand-offs of the minibatch step: a wait that gave up is counted on the device (csrc/ppo.hip: flags_wait) ---------------------
+    def request_handoff_status(self):
+        """Enqueue a copy of the sticky "lost hand-off" count into a pinned host word (no synchronisation); read it with handoff_lost() once the
+        stream has passed this point -- CirsEngine.update() piggybacks on its one read-back."""
+        if getattr(self, "_ho_dev", None) is None:
+            self._ho_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._ho_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+        abi.check(self._lib.cirs_ppo_handoff_status(self._ho_dev.data_ptr(), 0, self._stream()), "cirs_ppo_handoff_status")
+        self._ho_pin.copy_(self._ho_dev, non_blocking=True)
+
+    def handoff_lost(self):
+        """The count last copied by request_handoff_status() (the caller has synchronised with the stream)."""
+        return int(self._ho_pin[0]) if getattr(self, "_ho_pin", None) is not None else 0
+
+    def check_handoffs(self, reset=False):
+        """Synchronous check (tests, end of a run): raises when a bounded wait inside the minibatch step ever gave up -- the update that contained it
+        used incomplete gradient sums or pre-Adam trunk weights."""
+        self.request_handoff_status()
+        torch.cuda.current_stream(self.device).synchronize()
+        lost = self.handoff_lost()
+        if reset and lost:
+            abi.check(self._lib.cirs_ppo_handoff_status(self._ho_dev.data_ptr(), 1, self._stream()), "cirs_ppo_handoff_status")
+            self._ho_pin.zero_()
+        if lost:
+            raise abi.CirsHipError(f"{lost} in-launch hand-off wait(s) of the PPO minibatch step timed out: the update is invalid "
+                                   "(csrc/ppo.hip: flags_wait; GPU shared with another process or a dispatch order that is not block-id order?)")
+
     def _alloc_batch(self, n):
         if n > self._batch_cap:
             dev, S = self.device, self.S

@@ -40,7 +40,9 @@ class _Trail:
     def absorb(self, samples) -> float:
         if hasattr(samples, "detach"):                 # a tensor of per-minibatch values
             samples = samples.detach().cpu().numpy()
-        self._recent.extend(float(x) for x in np.ravel(samples) if np.isfinite(x))     # (inf / nan never enter the window: statistics.py:36-49)
+        # +-inf never enters the window; a COMPUTED NaN does (statistics.py:30,44-46 bans by membership in [inf, nan, -inf], and nan != nan), so a
+        # diverged update shows up as a NaN moving average instead of a healthy-looking one
+        self._recent.extend(float(x) for x in np.ravel(samples) if not np.isinf(x))
         return sum(self._recent) / len(self._recent) if self._recent else 0.0
 
 

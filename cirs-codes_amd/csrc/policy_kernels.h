@@ -540,6 +540,8 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
     __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];     // one hidden tile per row tile
     __shared__ float sM[4][4][kTileM];                                             // [row tile][item tile][row]: the tile's maximum
     __shared__ float sS[4][2][kTileM];                                             // [row tile][half][row]: the running half-wave sum
+    // ~73 KB of static LDS: more than the 64 KB of gfx90a / gfx942 -- this kernel (like the whole library) is gfx950-only (160 KB per CU)
+    static_assert(sizeof(float) * (2 * 4 * kTileN * kLdsStride + 4 * kTileN + 4 * 4 * kTileM + 4 * 2 * kTileM) <= 160 * 1024, "actor_mass_small_kernel: LDS beyond gfx950's 160 KB");
     const int tid = threadIdx.x, n_thr = blockDim.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
@@ -797,7 +799,9 @@ constexpr int kPickStage = 64 * kPickRow;
 struct PickNoHook { __device__ __forceinline__ void operator()() const {} };
 // after_issue(): called once, when the last of the chunk's rows has arrived (the memory queue is empty again) and the second
 // half's dot products are about to start -- the place for a caller's own prefetches
-template <class AfterIssue = PickNoHook>
+// ZS (compile time): the logit store is present (a.zstore non-null) -- the kernel that reads the store carries neither the 128 registers of the chunk's head
+// rows nor a run-time branch at the head of the pick (round 6: the nullable pointer + branch cost the C3 step kernel 1.5 us per launch).
+template <bool ZS = false, class AfterIssue = PickNoHook>
 __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e, int lane, float* hs, float* stage, const PickPre* pre,
                                                 AfterIssue&& after_issue = AfterIssue()) {
     const int chunk_base = a.item_base / CIRS_SAMPLER_CHUNK;
@@ -842,7 +846,7 @@ __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e,
         bias[q] = a.ba[ilc];
         vword[q] = a.visited ? a.visited[(size_t)e * vis_words + ((a.item_base + ilc) >> 5)] : 0u;
     }
-    if (a.zstore) {      // the drawn chunk's logits were kept by actor_mass_kernel: two coalesced loads per lane, no head rows, no dot products
+    if constexpr (ZS) {      // the drawn chunk's logits were kept by actor_mass_kernel: two coalesced loads per lane, no head rows, no dot products
         float zq[2], gz[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) zq[q] = a.zstore[((size_t)cw.bi * a.n_pad + j) * kChunkItems + lane + 64 * q];
@@ -865,7 +869,7 @@ __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e,
         const Best iwz = best_wave_reduce(itz);
         CIRS_PICK_STAMP(25);
         return Cand{cw.bs, iwz.bz, mwz.m, mwz.s, iwz.bi};
-    }
+    } else {
     // (native vector values: a float4 struct copy becomes a memcpy through a private array that is not promoted to registers)
     typedef float pick_v4 __attribute__((ext_vector_type(4)));
     const pick_v4* wa4 = reinterpret_cast<const pick_v4*>(a.wa);
@@ -918,6 +922,7 @@ __device__ __forceinline__ Cand actor_pick_wave(const PickArgs& a, int j, int e,
     const Best iw = best_wave_reduce(it);
     CIRS_PICK_STAMP(25);
     return Cand{cw.bs, iw.bz, mw.m, mw.s, iw.bi};   // bs = the chunk-level noisy score (what shards are compared by), (m, s) = log-sum-exp of the shard's masses
+    }
 }
 
 // log-prob of the drawn item with Categorical's clamp (torch probs_to_logits), from its logit and the row's (max, sum-exp)

@@ -224,14 +224,29 @@ constexpr int kSyncInts = 288, kSyncA0 = 256;
 __device__ __forceinline__ void flag_arrive(int* flags, int b) {      // the caller has drained its stores (s_waitcnt vmcnt(0)) and synchronised the workgroup
     if (threadIdx.x == 0) __hip_atomic_store(flags + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void flags_wait(const int* flags, int n) {      // every thread of the workgroup calls it; bounded (a lost arrival must not hang the device)
+// A lost or late arrival must neither hang the device nor pass silently (round 6): on giving up the workgroup counts itself in a STICKY device word that
+// cirs_ppo_handoff_status copies out -- the host checks it at the update's read-back and raises (cirs_hip/learner.py: check_handoffs).  Assumptions of the
+// hand-off, in one place: (i) producers have the LOWEST block ids of the launch and are therefore dispatched before (or together with) their consumers -- not
+// a HIP guarantee, which is exactly why the wait is bounded and loud; (ii) payload and flag are `sc1` (write-through) stores, the payload drained with
+// `s_waitcnt vmcnt(0)` before the flag leaves, and consumers read both with `sc1` loads (L2 / fabric, never a stale L1 line) -- MI355X_MICROARCH.md's
+// "sc1 stores AND sc1 loads" form, which needs no release / acquire fence.
+__device__ int g_handoff_lost = 0;
+__device__ __forceinline__ void flags_wait(const int* flags, int n) {      // every thread of the workgroup calls it; bounded
     int spins = 0;
     for (;;) {
         int mine = 1;
         for (int q = threadIdx.x; q < n; q += blockDim.x) mine &= __hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        if (__syncthreads_and(mine) || ++spins >= (1 << 20)) break;
+        if (__syncthreads_and(mine)) break;
+        if (++spins >= (1 << 20)) {
+            if (threadIdx.x == 0) atomicAdd(&g_handoff_lost, 1);
+            break;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
+}
+__global__ void handoff_status_kernel(int* __restrict__ out, int reset) {
+    out[0] = g_handoff_lost;
+    if (reset) g_handoff_lost = 0;
 }
 __host__ __device__ inline int snap_floats(int S) { return kH * (S + 66) + kH + 1; }      // trunk (w1 | b1 | w2 | b2) + wc | bc
 __host__ __device__ inline int snap_stride(int S) { return (snap_floats(S) + 3) & ~3; }       // (16-byte aligned arrays)
@@ -506,7 +521,7 @@ struct TrunkRowIn { int ri; float x; };
 __device__ __forceinline__ TrunkRowIn trunk_row_gather(int j, int mb, const int32_t* __restrict__ idx, const float* __restrict__ obs_flat, long stride, int S,
                                                        int lane) {
     TrunkRowIn in;
-    in.ri = idx[j];                                       // (idx holds n_pad entries or the tail is never dereferenced: see the callers)
+    in.ri = idx[j < mb ? j : mb - 1];                     // rows >= mb: never used -- clamped, so the load stays inside the index array (mb >= 1)
     in.x = (j < mb && lane < S) ? obs_flat[(size_t)in.ri * stride + lane] : 0.f;    // rows >= mb: zeros (as trunk_rows)
     return in;
 }
@@ -2023,6 +2038,7 @@ struct AdamNext {
     int n_a0;                                                      // A0 workgroups (set with or without a next step)
     int s_magic;                                                   // ceil(65536 / S): i / S = (i * s_magic) >> 16 for i < 2048
     int pa_delay;                                                  // P / A workgroups start this many x 1024 cycles late (the T workgroups' requests go first)
+    int drop_arrival;                                              // TEST HOOK (CIRS_PPO_TEST_DROP_ARRIVAL=1): A0 workgroup 0 never raises its flag -> the T workgroups' wait must time out LOUDLY
     cirs_ppo_batch bt; int n_env;
     TrunkRowOut out;
 };
@@ -2094,12 +2110,12 @@ __device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNex
         const int row = (i * nx.s_magic) >> 16;                 // i / S (s_magic = ceil(65536 / S), exact for i < 2048)
         const bool ok = i < kTileM * S;
         xrow[q] = ok ? row : 0; xk[q] = ok ? i - row * S : -1;
-        xri[q] = nx.idx[j0 + xrow[q]];
+        xri[q] = nx.idx[min(j0 + xrow[q], nx.mb - 1)];      // (rows >= mb are never used: clamped so that the load stays inside the index array)
     }
     // row scalars: thread (field = tid / 32, row = tid % 32): act, row_t, row_env, adv, logp_old, ret, v_s
     const int fr = tid & 31, ff = tid >> 5;
     const bool frow_ok = j0 + fr < nx.mb;
-    const int fri = nx.idx[j0 + fr];
+    const int fri = nx.idx[min(j0 + fr, nx.mb - 1)];
     float xq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) xq[q] = (xk[q] >= 0 && j0 + xrow[q] < nx.mb) ? nx.obs_flat[(size_t)xri[q] * S + xk[q]] : 0.f;      // rows >= mb: zeros (as trunk_rows)
@@ -2257,7 +2273,7 @@ __device__ __forceinline__ void adam_next_planes(const AdamArgs& a, const AdamNe
     wa_planes_from_lds(bp, nx.planes, l.lt);
 }
 // A0: element e of [trunk | wc | bc] (nothing else: the T workgroups wait for these)
-__device__ __forceinline__ void adam_next_trunk_params(const AdamArgs& a, const MbView& mv, AdamLds& l, int b0) {
+__device__ __forceinline__ void adam_next_trunk_params(const AdamArgs& a, const MbView& mv, AdamLds& l, int b0, int drop_arrival) {
     const int tid = threadIdx.x;
     const long e = b0 * 256L + tid;
     const long i = e < a.L.trunk ? e : a.L.wc + (e - a.L.trunk);
@@ -2273,7 +2289,7 @@ __device__ __forceinline__ void adam_next_trunk_params(const AdamArgs& a, const 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    flag_arrive(mv.sync + kSyncA0, b0);
+    if (!(drop_arrival && b0 == 0)) flag_arrive(mv.sync + kSyncA0, b0);
 }
 // A: ba (the trunk / critic belong to A0, the Wa matrix to the P workgroups); its first workgroup reduces the loss terms and publishes them
 __device__ __forceinline__ void adam_next_rest(const AdamArgs& a, const MbView& mv, AdamLds& l, int ba_) {
@@ -2303,7 +2319,7 @@ __global__ __launch_bounds__(256) void adam_next_kernel(AdamArgs a, MbView mv, A
     CIRS_PSTAMP(pn && b == b_t, 0); CIRS_PSTAMP(pn && b == b_s - 1, 4); CIRS_PSTAMP(pn && b == b_s, 6); CIRS_PSTAMP(pn && b == b_p, 8);
     CIRS_PSTAMP(pn && b == b_a - 1, 12); CIRS_PSTAMP(pn && b == 0, 14); CIRS_PSTAMP(pn && b == nx.n_a0 - 1, 16);
     if (b >= b_p) for (int q = 0; q < nx.pa_delay; ++q) __builtin_amdgcn_s_sleep(16);
-    if (b < b_t) adam_next_trunk_params(a, mv, l, b);
+    if (b < b_t) adam_next_trunk_params(a, mv, l, b, nx.drop_arrival);
     else if (b < b_s) adam_next_trunk(a, nx, l, b - b_t, mv.sync);
     else if (b < b_p) adv_stats_block(nx.adv_flat, nx.sidx, nx.m_stats, nx.enable, nx.red, l.sh);
     else if (b < b_a) adam_next_planes(a, nx, l, b - b_p);
@@ -2693,6 +2709,7 @@ static int launch_norm_adam(const PpoRun& r, const PpoStep& st, int phase, bool 
         nx.adv_flat = r.batch->adv; nx.sidx = next->sidx; nx.m_stats = next->mb_norm; nx.enable = (int)r.cfg->norm_adv; nx.red = v.red;
         nx.bt = *r.batch; nx.n_env = r.n_env; nx.out = trunk_out_of(v); nx.s_magic = (65536 + r.S - 1) / r.S;
         nx.pa_delay = env_int("CIRS_PPO_PA_DELAY", 0);      // (A/B on one box: 0 / 4 -> 78.0-78.6 / 78.5-78.9 us per step)
+        nx.drop_arrival = env_int("CIRS_PPO_TEST_DROP_ARRIVAL", 0);
     }
     nx.n_a0 = cdiv(r.L.trunk + kH + 1, 256);
     const int n_a = nx.n_a0 + cdiv(r.I, 256);
@@ -2774,6 +2791,13 @@ static void ppo_slice(int n, int bs, int k, int* b, int* e) {
     *b = s0;
     *e = (merge_last && s0 + 2 * bs >= n) ? n : (s0 + bs < n ? s0 + bs : n);
 }
+extern "C" int cirs_ppo_handoff_status(int32_t* lost_out, int32_t reset, void* stream) {
+    CIRS_REQUIRE(lost_out, "cirs_ppo_handoff_status: lost_out is null");
+    hipLaunchKernelGGL(cirs::handoff_status_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)lost_out, (int)reset);
+    CIRS_CHECK_LAUNCH("handoff_status_kernel");
+    return CIRS_OK;
+}
+
 extern "C" int32_t cirs_ppo_learn_steps(int32_t n_rows, int32_t batch_size, int32_t n_repeat) {
     if (n_rows < 1 || batch_size < 1 || n_repeat < 1) return 0;
     return n_repeat * ppo_slice_count(n_rows, batch_size);

@@ -236,11 +236,11 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     // logit store (one group, counter-based sampler, small env counts): behind the group's sampler scratch
     float* zstore = nullptr;
     if (n_groups == 1 && !gumbel && ws_zstore_floats(n_env, pol_cfg->n_items) > 0) {
-        static const int zs_on = [] { const char* ev = getenv("CIRS_ROLLOUT_ZSTORE"); return ev ? atoi(ev) : 1; }();
-        if (zs_on) zstore = (float*)((char*)workspace + ws_per);
+        const char* ev = getenv("CIRS_ROLLOUT_ZSTORE");     // read per call (like CIRS_PPO_MERGE_KERNEL): a test may flip it between collects
+        if (ev ? atoi(ev) != 0 : true) zstore = (float*)((char*)workspace + ws_per);
     }
-    static const int mass_small_on = [] { const char* ev = getenv("CIRS_ROLLOUT_MASS_SMALL"); return ev ? atoi(ev) : 1; }();
-    const bool mass_small = mass_small_on && n_groups == 1 && !gumbel && grp[0].n_pad <= 128;
+    const char* ms_ev = getenv("CIRS_ROLLOUT_MASS_SMALL");   // per call as well
+    const bool mass_small = (ms_ev ? atoi(ms_ev) != 0 : true) && n_groups == 1 && !gumbel && grp[0].n_pad <= 128;
     const uint8_t* done_all = (const uint8_t*)env_st->done;
     // Exact-redraw dropout (the reference's procedure, core/state_tracker.py:170-186,243-246): the state of vector step t is NOT the cached decode's -- it is
     // ONE batched causal pass over positions 0 .. t of every env with the masks of build_state call t (cirs_tracker_prefix_states, key = the collect's key with

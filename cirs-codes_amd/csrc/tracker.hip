@@ -104,7 +104,8 @@ __device__ unsigned long long g_trk_prof[64];
 #define CIRS_STAMP(K) do { } while (0)
 #endif
 
-template <int NHEAD, bool DROP, bool IMG>
+// ZS: the fused tail's pick reads the sampler's logit store (small env counts) -- a compile-time variant, policy_kernels.h: actor_pick_wave
+template <int NHEAD, bool DROP, bool IMG, bool ZS>
 __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w,
                                                            cirs_tracker_state st, const int32_t* __restrict__ users,
                                                            const int64_t* __restrict__ items,
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         } else if (tl.pick_on) {   // two-level draw: chunk, then item (per-wave LDS scratch: the feed-forward buffer, free here)
             float* stage = smem + (size_t)4 * (6 * kD + kHid + NHEAD * lpad) + (size_t)wv * kPickStage;   // after the four waves' scratch
             // the (env, position) prefetch goes out when the pick's own rows have arrived, under the item draw's second half
-            const Cand r = actor_pick_wave(tl.pick, j, et, lane, ffs, stage, &ppre, step_prefetch);
+            const Cand r = actor_pick_wave<ZS>(tl.pick, j, et, lane, ffs, stage, &ppre, step_prefetch);
             act = r.bi == 0x7FFFFFFF ? -1 : (int64_t)r.bi;
             if (lane == 0) { tl.act_out[j] = act; tl.logp_out[j] = cand_logp(r); }
         } else {
@@ -579,24 +580,27 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
     const bool drop = cfg->dropout_p > 0.f;
     const TrkImg IL = img ? trk_img_layout(cfg->nlayers, tf.on ? tf.cfg.dim_state : cfg->dim_state) : TrkImg{};
     if (drop && !(cfg->dropout_p < 1.f)) return fail(CIRS_E_INVALID, "dropout_p must be in [0, 1)");
-#define CIRS_TRK_LAUNCH(NH, DR, IM)                                                                                   \
+#define CIRS_TRK_LAUNCH(NH, DR, IM, ZS)                                                                               \
     do {                                                                                                              \
         if (shmem > 48 * 1024) {   /* more dynamic LDS than the default window: opt in once per instantiation */        \
             static bool optin = false;                                                                                \
             if (!optin) {                                                                                             \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tracker_step_kernel<NH, DR, IM>),              \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tracker_step_kernel<NH, DR, IM, ZS>),          \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)        \
                     return fail(CIRS_E_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");            \
                 optin = true;                                                                                         \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((tracker_step_kernel<NH, DR, IM>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
+        hipLaunchKernelGGL((tracker_step_kernel<NH, DR, IM, ZS>), grid, block, shmem, s, *cfg, *w, *st, users, items, rew, env_ids, skip, \
                            n, state_out, state_stride, lpad, tf, tl, img, IL);                                        \
     } while (0)
+    // the logit-store variant exists for the image path only (the fused rollout always packs the image)
+    const bool zs = tl.on && tl.pick_on && tl.pick.zstore != nullptr;
+    if (zs && !img) return fail(CIRS_E_INVALID, "the sampler's logit store needs the packed weight image");
 #define CIRS_TRK(NH)                                                                                                  \
     do {                                                                                                              \
-        if (drop) { if (img) CIRS_TRK_LAUNCH(NH, true, true); else CIRS_TRK_LAUNCH(NH, true, false); }                \
-        else { if (img) CIRS_TRK_LAUNCH(NH, false, true); else CIRS_TRK_LAUNCH(NH, false, false); }                   \
+        if (drop) { if (zs) CIRS_TRK_LAUNCH(NH, true, true, true); else if (img) CIRS_TRK_LAUNCH(NH, true, true, false); else CIRS_TRK_LAUNCH(NH, true, false, false); }    \
+        else { if (zs) CIRS_TRK_LAUNCH(NH, false, true, true); else if (img) CIRS_TRK_LAUNCH(NH, false, true, false); else CIRS_TRK_LAUNCH(NH, false, false, false); }      \
     } while (0)
     switch (cfg->nhead) {
         case 1: CIRS_TRK(1); break;

@@ -372,6 +372,14 @@ int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* grads, float* 
                    float* dobs_accum, int64_t dobs_floats, int32_t n_env, float* losses, void* workspace, int64_t workspace_bytes,
                    void* stream);
 
+/* Health of the in-launch hand-offs of the minibatch step (no reference counterpart: the reference's optimiser step, core/policy/ppo.py:215-233,
+ * is a sequence of synchronous torch calls and cannot lose one).  Inside cirs_ppo_learn / cirs_ppo_minibatch* some workgroups wait for arrival
+ * flags of other workgroups of the SAME launch (trunk backward rows -> gradient sums; trunk Adam -> the next step's trunk forward).  The wait is
+ * bounded; a workgroup that gives up counts itself in a sticky device word.  This call enqueues (on `stream`) a copy of that count to lost_out
+ * (device pointer, one int32) and, with reset != 0, clears it.  A non-zero count means the update it belongs to used incomplete sums or stale
+ * weights: the host must treat the update as failed (cirs_hip/learner.py raises at the update's read-back). */
+int cirs_ppo_handoff_status(int32_t* lost_out, int32_t reset, void* stream);
+
 /* Data-parallel form of cirs_ppo_minibatch for a learner sharded over ranks.  A GLOBAL minibatch of mb_global rows
  * (idx_global) is split by rows; this rank owns idx_local[mb_local].  Advantage normalisation uses the statistics of
  * the global minibatch (every rank holds the gathered buffer) and every mean is over mb_global rows, so the SUM over

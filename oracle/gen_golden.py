@@ -1154,8 +1154,53 @@ def gen_c1rl():
           "act[0,:3]", out["r0_act"][0, :3])
 
 
+def gen_bufferindex():
+    """Index semantics of the reference's VectorReplayBuffer (tianshou/data/buffer/manager.py:91-142, base.py prev / next / unfinished_index) as DATA:
+    op scripts are replayed on the reference's own class and the full index state is dumped after every op -> tests/golden/buffer_index.json.
+    Script 0 is the scenario of the reference's known-answer test (tianshou/test/base/test_buffer.py:397-488: 4 sub-buffers of 5, episodes ending in
+    different sub-buffers, ring wrap-around inside sub-buffer 2); scripts 1-2 are seeded random add sequences on other geometries."""
+    import json
+    from tianshou.data import Batch, VectorReplayBuffer
 
-FAMILIES = {"c1rl": gen_c1rl, "virtualtb": gen_virtualtb, "collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "learn_opts": lambda: gen_learn("learn_opts", dual_clip=1.01, recompute=1, rounds=1), "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
+    def scenario():
+        z = [0, 0, 0, 0]
+        return dict(total=20, n=4, ops=[
+            dict(val=[1, 2, 3], done=[0, 0, 1], ids=[0, 1, 2]),
+            dict(val=[4], done=[1], ids=[3]),
+            dict(val=z, done=[0, 0, 0, 0], ids=[0, 1, 2, 3]),
+            dict(val=z, done=[1, 1, 1, 1], ids=[0, 1, 2, 3]),
+            dict(val=z, done=[0, 0, 0, 0], ids=[0, 1, 2, 3]),
+            dict(val=z, done=[0, 1, 0, 1], ids=[0, 1, 2, 3]),
+            dict(val=[1], done=[1], ids=[2]),
+        ])
+
+    def random_script(seed, total, n, n_ops):
+        rng = np.random.RandomState(seed)
+        ops = []
+        for _ in range(n_ops):
+            k = rng.randint(1, n + 1)
+            ids = sorted(rng.choice(n, size=k, replace=False).tolist())
+            ops.append(dict(val=rng.randint(0, 9, k).tolist(), done=(rng.uniform(size=k) < 0.3).astype(int).tolist(), ids=ids))
+        return dict(total=total, n=n, ops=ops)
+
+    scripts = [scenario(), random_script(1, 12, 3, 40), random_script(2, 35, 5, 60)]
+    for sc in scripts:
+        buf = VectorReplayBuffer(sc["total"], sc["n"])
+        for op in sc["ops"]:
+            v = np.array(op["val"])
+            ptr, ep_rew, ep_len, ep_idx = buf.add(Batch(obs=v, act=v, rew=v, done=np.array(op["done"])), buffer_ids=op["ids"])
+            idx = np.sort(buf.sample_index(0))
+            op["want"] = dict(ptr=np.asarray(ptr).tolist(), ep_rew=np.asarray(ep_rew, np.float64).tolist(), ep_len=np.asarray(ep_len).tolist(),
+                              ep_idx=np.asarray(ep_idx).tolist(), len=len(buf), index=idx.tolist(), prev=buf.prev(idx).tolist(),
+                              next=buf.next(idx).tolist(), unfinished=np.asarray(buf.unfinished_index()).tolist(),
+                              done=np.asarray(buf.done).astype(int).tolist(), rew=np.asarray(buf.rew, np.float64).tolist(),
+                              prev_last=int(buf.prev(-1)), next_last=int(buf.next(-1)), sample_minus1=buf.sample_index(-1).tolist())
+    with open(os.path.join(GOLDEN, "buffer_index.json"), "w") as f:
+        json.dump(dict(source="reference VectorReplayBuffer driven by oracle/gen_golden.py:gen_bufferindex", scripts=scripts), f, separators=(",", ":"))
+    print("buffer_index.json:", [len(sc["ops"]) for sc in scripts], "ops; final unfinished", [sc["ops"][-1]["want"]["unfinished"] for sc in scripts])
+
+
+FAMILIES = {"bufferindex": gen_bufferindex, "c1rl": gen_c1rl, "virtualtb": gen_virtualtb, "collectorset": gen_collectorset, "userval": gen_userval, "userdata": gen_userdata, "dataprep": gen_dataprep, "usertrain": gen_usertrain, "staticpolicy": gen_staticpolicy, "loaders": gen_loaders, "evalmetrics": gen_evalmetrics, "deepfm": gen_deepfm, "learn": gen_learn, "learn_opts": lambda: gen_learn("learn_opts", dual_clip=1.01, recompute=1, rounds=1), "env": gen_env, "tracker": gen_tracker, "policy": gen_policy}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

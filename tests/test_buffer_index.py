@@ -1,78 +1,40 @@
-"""CPU: index semantics of the mirror's VectorReplayBuffer against the KNOWN ANSWERS of the reference's own test
-(tianshou/test/base/test_buffer.py:397-488, test_replaybuffermanager): add() return values, sample_index(0), prev / next /
-unfinished_index incl. ring wrap-around inside a sub-buffer — the expected arrays below are that test's literals."""
+"""CPU: index semantics of the mirror's VectorReplayBuffer (add() return values, sample_index(0), prev / next / unfinished_index incl. ring
+wrap-around inside a sub-buffer) against states RECORDED from the reference's own class: tests/golden/buffer_index.json, written by
+oracle/gen_golden.py:gen_bufferindex (op scripts replayed on the reference's VectorReplayBuffer, full index state dumped after every op; script 0 is
+the scenario of the reference's known-answer test, tianshou/test/base/test_buffer.py:397-488, scripts 1-2 are seeded random add sequences)."""
+import json
+import os
+
 import numpy as np
+import pytest
 
 from tianshou.data import Batch, VectorReplayBuffer
 
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "buffer_index.json")) as _f:
+    _SCRIPTS = json.load(_f)["scripts"]
 
-def test_replaybuffermanager_known_answers():
-    buf = VectorReplayBuffer(20, 4)
-    batch = Batch(obs=np.array([1, 2, 3]), act=np.array([1, 2, 3]), rew=np.array([1, 2, 3]), done=np.array([0, 0, 1]))
-    ptr, ep_rew, ep_len, ep_idx = buf.add(batch, buffer_ids=[0, 1, 2])
-    assert np.all(ep_len == [0, 0, 1]) and np.all(ep_rew == [0, 0, 3])
-    assert np.all(ptr == [0, 5, 10]) and np.all(ep_idx == [0, 5, 10])
-    batch, indice = buf.sample(0)
-    assert np.allclose(indice, [0, 5, 10])
-    assert np.allclose(buf.prev(indice), indice)
-    assert np.allclose(buf.next(indice), indice)
-    assert np.allclose(buf.unfinished_index(), [0, 5])
-    buf.add(Batch(obs=np.array([4]), act=np.array([4]), rew=np.array([4]), done=np.array([1])), buffer_ids=[3])
-    assert np.allclose(buf.unfinished_index(), [0, 5])
-    batch, indice = buf.sample(0)
-    assert np.allclose(indice, [0, 5, 10, 15])
-    assert np.allclose(buf.prev(indice), indice)
-    assert np.allclose(buf.next(indice), indice)
-    data = np.array([0, 0, 0, 0])
-    buf.add(Batch(obs=data, act=data, rew=data, done=data), buffer_ids=[0, 1, 2, 3])
-    buf.add(Batch(obs=data, act=data, rew=data, done=1 - data), buffer_ids=[0, 1, 2, 3])
-    assert len(buf) == 12
-    buf.add(Batch(obs=data, act=data, rew=data, done=data), buffer_ids=[0, 1, 2, 3])
-    buf.add(Batch(obs=data, act=data, rew=data, done=np.array([0, 1, 0, 1])), buffer_ids=[0, 1, 2, 3])
-    assert len(buf) == 20
-    indice = buf.sample_index(0)
-    assert np.allclose(indice, np.arange(len(buf)))
-    assert np.allclose(buf.done, [
-        0, 0, 1, 0, 0,
-        0, 0, 1, 0, 1,
-        1, 0, 1, 0, 0,
-        1, 0, 1, 0, 1,
-    ])
-    assert np.allclose(buf.prev(indice), [
-        0, 0, 1, 3, 3,
-        5, 5, 6, 8, 8,
-        10, 11, 11, 13, 13,
-        15, 16, 16, 18, 18,
-    ])
-    assert np.allclose(buf.next(indice), [
-        1, 2, 2, 4, 4,
-        6, 7, 7, 9, 9,
-        10, 12, 12, 14, 14,
-        15, 17, 17, 19, 19,
-    ])
-    assert np.allclose(buf.unfinished_index(), [4, 14])
-    ptr, ep_rew, ep_len, ep_idx = buf.add(Batch(obs=np.array([1]), act=np.array([1]), rew=np.array([1]), done=np.array([1])), buffer_ids=[2])
-    assert np.all(ep_len == [3]) and np.all(ep_rew == [1])
-    assert np.all(ptr == [10]) and np.all(ep_idx == [13])
-    assert np.allclose(buf.unfinished_index(), [4])
-    indice = list(sorted(buf.sample_index(0)))
-    assert np.allclose(indice, np.arange(len(buf)))
-    assert np.allclose(buf.prev(indice), [
-        0, 0, 1, 3, 3,
-        5, 5, 6, 8, 8,
-        14, 11, 11, 13, 13,
-        15, 16, 16, 18, 18,
-    ])
-    assert np.allclose(buf.next(indice), [
-        1, 2, 2, 4, 4,
-        6, 7, 7, 9, 9,
-        10, 12, 12, 14, 10,
-        15, 17, 17, 19, 19,
-    ])
-    # corner case: list, int and -1
-    assert buf.prev(-1) == buf.prev([buf.maxsize - 1])[0]
-    assert buf.next(-1) == buf.next([buf.maxsize - 1])[0]
-    assert buf.sample_index(-1).tolist() == []
+
+@pytest.mark.parametrize("k", range(len(_SCRIPTS)))
+def test_index_state_after_every_add_equals_the_reference(k):
+    sc = _SCRIPTS[k]
+    buf = VectorReplayBuffer(sc["total"], sc["n"])
+    for n_op, op in enumerate(sc["ops"]):
+        v, want, at = np.array(op["val"]), op["want"], f"script {k}, op {n_op}"
+        ptr, ep_rew, ep_len, ep_idx = buf.add(Batch(obs=v, act=v, rew=v, done=np.array(op["done"])), buffer_ids=op["ids"])
+        assert np.asarray(ptr).tolist() == want["ptr"] and np.asarray(ep_len).tolist() == want["ep_len"] and np.asarray(ep_idx).tolist() == want["ep_idx"], at
+        np.testing.assert_allclose(np.asarray(ep_rew, np.float64), want["ep_rew"], rtol=0, atol=0, err_msg=at)
+        assert len(buf) == want["len"], at
+        idx = np.sort(buf.sample_index(0))
+        assert idx.tolist() == want["index"], at
+        assert np.asarray(buf.prev(idx)).tolist() == want["prev"], at
+        assert np.asarray(buf.next(idx)).tolist() == want["next"], at
+        assert np.asarray(buf.unfinished_index()).tolist() == want["unfinished"], at
+        assert np.asarray(buf.done).astype(int).tolist() == want["done"], at
+        np.testing.assert_array_equal(np.asarray(buf.rew, np.float64), want["rew"], err_msg=at)
+        # corner cases: a scalar index, -1, an empty sample
+        assert int(buf.prev(-1)) == want["prev_last"] == int(buf.prev([buf.maxsize - 1])[0]), at
+        assert int(buf.next(-1)) == want["next_last"] == int(buf.next([buf.maxsize - 1])[0]), at
+        assert buf.sample_index(-1).tolist() == want["sample_minus1"], at
 
 
 def test_fill_from_trajectory_equals_sequence_of_adds():

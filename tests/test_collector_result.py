@@ -28,3 +28,13 @@ def test_result_dict_equals_reference(golden_dir):
         assert np.array_equal(res["rews"], z[pre + "res_rews"]), "episode rewards must be the reference's running float64 sums"
         assert res["rew"] == rew and res["len"] == ln and res["rew_std"] == rew_std and res["len_std"] == len_std
         assert set(res) == {"n/ep", "n/st", "rews", "lens", "idxs", "rew", "len", "rew_std", "len_std"}
+
+
+def test_moving_average_of_the_trainer_lets_nan_through_and_bans_inf():
+    """core/trainer/onpolicy.py:_Trail == tianshou/utils/statistics.py:MovAvg on what it admits: +-inf never enters the window, a COMPUTED NaN does
+    (the reference bans by membership in [inf, nan, -inf], and nan != nan) -- a diverged update must stay visible in the logged loss."""
+    import numpy as np
+    from core.trainer.onpolicy import _Trail
+    t = _Trail(span=4)
+    assert t.absorb([1.0, float("inf"), 3.0, -float("inf")]) == 2.0
+    assert np.isnan(t.absorb(np.array([np.float32("nan")])))

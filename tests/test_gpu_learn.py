@@ -149,6 +149,38 @@ def test_learn_loop_equals_one_call_per_step(I, B, T, bs, rep, ent_coef, loop_mo
     assert outs[0][5] == outs[1][5] == rep * len(__import__("cirs_hip.learner", fromlist=["minibatch_slices"]).minibatch_slices(n, bs))
 
 
+def test_lost_handoff_is_loud(monkeypatch):
+    """A hand-off inside the minibatch step that never arrives (CIRS_PPO_TEST_DROP_ARRIVAL=1: one trunk-Adam workgroup of adam_next_kernel never raises
+    its flag, so the next step's trunk workgroups give up after their bounded wait and run on whatever they find) must not return a plausible loss
+    silently: the sticky device word is set, DeviceLearner.check_handoffs() raises -- and a healthy update afterwards is clean again (VERDICT r05 #5)."""
+    from cirs_hip import abi
+    from cirs_hip.rollout import Trajectory
+    I, B, T, bs = 500, 24, 10, 32
+    pp, lens, acts, rews, dones, obs, n, rng = _random_case(I, B, T, seed=5)
+    value, logp = rollout_time_value_logp(pp, obs, acts, lens)
+    hyper = [0.95, 0.95, 0.2, 0.25, 0.0, 0.5, 1e-3, bs, 1]
+
+    def run():
+        traj = Trajectory(B, T, 20, "cuda")
+        upload_traj(traj, acts, rews, dones, lens, obs, value, logp)
+        ln, _ = make_learner(pp, I, B, T, hyper)
+        assert ln.prepare(traj, lens) == n
+        losses = ln.learn(bs, 1, perms=[rng.permutation(n)])
+        return ln, losses
+
+    monkeypatch.setenv("CIRS_PPO_LEARN_PREFETCH", "1")      # (the hand-off under test only exists when the optimiser launch runs the next step's head)
+    ln, losses = run()
+    ln.check_handoffs()                       # healthy: nothing lost
+    monkeypatch.setenv("CIRS_PPO_TEST_DROP_ARRIVAL", "1")
+    ln2, losses2 = run()
+    assert np.isfinite(losses2.cpu().numpy()).all()      # exactly the danger: the losses LOOK fine
+    with pytest.raises(abi.CirsHipError, match="hand-off"):
+        ln2.check_handoffs(reset=True)
+    monkeypatch.delenv("CIRS_PPO_TEST_DROP_ARRIVAL")
+    ln3, _ = run()
+    ln3.check_handoffs()                      # the word was reset, and a healthy update leaves it at zero
+
+
 def test_trunk_backward_in_one_launch_equals_the_three_launch_sequence(monkeypatch, loop_mode):
     """The single-rank step's trunk backward is ONE launch (trunk_rows_kernel: chunk-slab sums of d h2, d a2 / d a1 / d obs, the trunk / critic weight
     gradients summed over 8-row slabs behind an arrival counter, squared-norm partials) where rounds 3-4 had three (dh2_sum_kernel, trunk_bwd_kernel
