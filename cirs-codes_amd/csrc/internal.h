@@ -122,6 +122,18 @@ inline TrkImg trk_img_layout(int nlayers, int S) {
     L.total = o;
     return L;
 }
+// bf16 planes of the actor head for the sampler's chunk-mass kernels (policy_kernels.h: wa_rplanes_kernel): in front of the weight image at the end of the
+// policy workspace (cirs_policy_workspace_bytes reserves both), rebuilt by every call that samples (the weights change between calls, never inside one)
+inline uint4* ws_rplanes(void* workspace, int64_t workspace_bytes, int n_items) {
+    const int64_t img_off = (workspace_bytes - kTrkImgBytes) & ~(int64_t)255;
+    return (uint4*)((char*)workspace + ((img_off - (int64_t)ws_rplanes_bytes(n_items)) & ~(int64_t)255));
+}
+inline int build_rplanes(const float* wa, int n_items, uint4* planes, hipStream_t s) {
+    hipLaunchKernelGGL(wa_rplanes_kernel, dim3(n_chunks_of(n_items) * kTilesPerChunk), dim3(256), 0, s, wa, n_items, planes);
+    CIRS_CHECK_LAUNCH("wa_rplanes_kernel");
+    return CIRS_OK;
+}
+
 // img <- the image of (w, pol); pol may be null (no trunk fusion)
 int pack_tracker_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_policy_weights* pol, int S, float* img,
                        hipStream_t s);

@@ -147,7 +147,9 @@ extern "C" int64_t cirs_policy_workspace_bytes(const cirs_policy_cfg* cfg, int32
     // + slack: the fused rollout may carve one (256-byte aligned) workspace per env group out of this buffer
     // + the packed weight image of the fused rollout's step kernel (internal.h: TrkImg) at its end
     // + the logit store of the fused rollout's sampler while it is small (policy_kernels.h: ws_zstore_floats)
-    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items) + ws_zstore_floats(n, cfg->n_items)) * 4 + 8192 + kTrkImgBytes;
+    // + the bf16 planes of the actor head for the chunk-mass kernels (policy_kernels.h: ws_rplanes_bytes), in front of the image
+    return (int64_t)(ws_h2_floats(n) + 5 * ws_partial_elems(n, cfg->n_items) + ws_zstore_floats(n, cfg->n_items)) * 4 + 8192 + kTrkImgBytes +
+           (int64_t)ws_rplanes_bytes(cfg->n_items) + 512;
 }
 
 extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_weights* w, const float* state,
@@ -174,7 +176,9 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
     if (!gumbel) {   // counter-based sampler: two-level Gumbel-max (chunk masses, then chunk + item draws)
         const int nch = n_chunks_of(cfg->n_items);
         const int cpw = mass_chunks_per_wg(nch, hg.n_row_blocks);
-        hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg, w->wa, w->ba, (const float*)h2, n,
+        uint4* planes = ws_rplanes(workspace, workspace_bytes, cfg->n_items);
+        if (int rc = build_rplanes(w->wa, cfg->n_items, planes, s)) return rc;
+        hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg, (const uint4*)planes, w->ba, (const float*)h2, n,
                            env_ids, visited, skip, pv.m, n_pad, cpw, 0, 0);
         CIRS_CHECK_LAUNCH("actor_mass_kernel");
         PickArgs pa{pv.m, n_pad, nch, w->wa, w->ba, h2, visited, cfg->n_items, 0, 0, seed, rng_step};
@@ -227,7 +231,9 @@ extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const
     CIRS_CHECK_LAUNCH("trunk_kernel");
     const int nch = n_chunks_of(cfg_shard->n_items);
     const int cpw = mass_chunks_per_wg(nch, hg.n_row_blocks);
-    hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg_shard, w_shard->wa, w_shard->ba,
+    uint4* planes = ws_rplanes(workspace, workspace_bytes, cfg_shard->n_items);
+    if (int rc = build_rplanes(w_shard->wa, cfg_shard->n_items, planes, s)) return rc;
+    hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg_shard, (const uint4*)planes, w_shard->ba,
                        (const float*)h2, n, env_ids, visited, skip, pv.m, n_pad, cpw, item_base, n_items_total);
     CIRS_CHECK_LAUNCH("actor_mass_kernel");
     PickArgs pa{pv.m, n_pad, nch, w_shard->wa, w_shard->ba, h2, visited, cfg_shard->n_items, item_base, n_items_total, seed, rng_step};

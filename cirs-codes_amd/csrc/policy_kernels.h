@@ -1,6 +1,7 @@
 // policy_kernels.h -- device code shared by policy.hip (rollout) and ppo.hip (learner): trunk MLP and the MFMA
 // actor head.  See policy.hip for the design notes.
 #pragma once
+#include "bf16x6.h"
 #include "common.h"
 #include "rng.h"
 
@@ -342,11 +343,78 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 // logit with the SAME k-order as the MFMA chain (bias, then for kk: k = kk, k = 32+kk) so logp is consistent with the
 // sampled distribution.  Lane 0 writes act / logp; the action id is returned in every lane.
 // ---- two-level sampler, stage 1: log-mass of every 128-item chunk ----------------------------------------------------------
-// Same tiling as actor_head_kernel (ZT[32 items x 32 rows] per MFMA tile, a lane owns ONE env row and 16 items of a tile; Wa tile
-// staged in LDS once per workgroup, double buffered), but no noise at all: the four tiles of a chunk stay in the accumulators,
-// M_c = max of the lane pair's valid logits, S_c = sum of det_expf_neg(z - M_c) in register order (tile, r) per half-wave,
-// S_c = S_hi0 + S_hi1, L_c = M_c + det_logf(S_c): bit-identical to oracle/cirs_oracle.c two_level_draw.  One float per (chunk,
-// env row) leaves the kernel: lmass[c][row] (-inf: no valid item).  grid = (ceil(n_chunks / chunks_per_wg), row blocks).
+// Same tiling as actor_head_kernel (ZT[32 items x 32 rows] per MFMA tile, a lane owns ONE env row and 16 items of a tile), no noise at all: the four
+// tiles of a chunk stay in the accumulators, M_c = max of the lane pair's valid logits, S_c = sum of exp(z - M_c) in register order (tile, r) per
+// half-wave, S_c = S_hi0 + S_hi1, L_c = M_c + log S_c.  One float per (chunk, env row) leaves the kernel: lmass[c][row] (-inf: no valid item).
+//
+// Round 6: the logits are fp32 products on the BF16 matrix pipe ("bf16x6", bf16x6.h) -- the arithmetic of the learner's head_stats_kernel, accumulator
+// split and all (bias + h*h terms | cross terms, met once), so the rollout's log-probabilities and the learner's come from the same numbers -- and the
+// mass uses the hardware's exp2 / log2.  Rounds 2-5 kept this stage on the fp32 MFMA with fma-only exp / log so that the C oracle could restate L_c BIT
+// FOR BIT (22.9 us per launch at C3, 39 % of the fp32 MFMA peak; no arithmetic model of v_mfma_f32_32x32x16_bf16 reproduces it exactly:
+// tools/probes/mfma_model_probe.hip).  The masses now agree with the oracle's to ~1e-6 and SURVEY 8(c)'s own protocol applies to the draw: "action
+// indices identical wherever the top-2 margin > 1e-6; report violations, expected 0" (tests/policycase.py: assert_draws_match; the oracle reports both
+// margins of its two-level draw).  Still exact and order-fixed: a logit depends on its (item, env row) alone -- not on the tile, the workgroup, the launch
+// geometry or the shard --, the sum keeps its order, and stage 3 (the item inside the drawn chunk) still runs scalar fp32 fma chains.  So every path that
+// forms chunk masses (this kernel, the small-count kernel below, item shards) gives the same bits, and ranks / replays stay bit-identical.
+//
+// Wa arrives as bf16 planes (wa_rplanes_kernel, once per cirs_rollout_steps / cirs_actor_sample call -- the weights do not change inside a call):
+// per item tile of 32, [3 planes h | m | l][32 items][64 cols] bf16 = 768 uint4 (items beyond the catalogue: zero rows; the chunk count is rounded up to
+// whole chunks).  A tile's 12 KB are staged in LDS once per workgroup (row stride 144 B: conflict-free 16-byte operand reads), double buffered.
+constexpr int kMassRowB = 144;                      // LDS row stride (bytes) of one plane of a staged tile: 64 bf16 + 16
+constexpr int kMassPlaneB = kTileN * kMassRowB;     // one plane of a tile in LDS
+constexpr int kMassTileU4 = 768;                    // uint4 per item tile in global memory
+__host__ __device__ inline size_t ws_rplanes_bytes(int n_items) { return (size_t)n_chunks_of(n_items) * kTilesPerChunk * kMassTileU4 * 16; }
+
+// grid = tiles of whole chunks (n_chunks * 4), 256 threads: thread -> (item = tid / 8, 8 consecutive columns)
+static __global__ __launch_bounds__(256) void wa_rplanes_kernel(const float* __restrict__ wa, int I, uint4* __restrict__ planes) {
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int item = tile * kTileN + (tid >> 3), col = 8 * (tid & 7);
+    typedef float rp_v4 __attribute__((ext_vector_type(4)));
+    rp_v4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (item < I) {
+        const rp_v4* src = reinterpret_cast<const rp_v4*>(wa + (size_t)item * kH + col);
+        a = src[0]; b = src[1];
+    }
+    const Planes pl = split8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+    uint4* out = planes + (size_t)tile * kMassTileU4;
+    out[tid] = __builtin_bit_cast(uint4, pl.h); out[256 + tid] = __builtin_bit_cast(uint4, pl.m); out[512 + tid] = __builtin_bit_cast(uint4, pl.l);
+}
+
+// B operand of the logits product: this lane's env row of H2 (col = lane & 31), element j of k-step s = column 16 s + 8 hi + j, split into bf16 pieces.
+// tile: the wave's 32 x 64 fp32 tile in LDS (row stride kLdsStride floats).
+__device__ __forceinline__ void mass_split_hidden(const float* tile, int lo, int hi, Planes (&hz)[4]) {
+    typedef float ms_v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const ms_v4* src = reinterpret_cast<const ms_v4*>(&tile[lo * kLdsStride + 16 * s4 + 8 * hi]);
+        const ms_v4 a = src[0], b = src[1];
+        hz[s4] = split8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+    }
+}
+// one 32 x 32 logits tile: A = the staged planes of the item tile (lane = item lo, 8 consecutive columns per k-step), B = hz, accumulator = bias + h*h terms |
+// cross terms (two chains), met once -- head_stats_kernel's sequence (ppo.hip)
+__device__ __forceinline__ f32x16 mass_logits_tile(const unsigned char* tw, const float* sb, const Planes (&hz)[4], int lo, int hi) {
+    Planes za[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const unsigned char* ap = tw + lo * kMassRowB + (16 * s4 + 8 * hi) * 2;
+        za[s4].h = *reinterpret_cast<const bf16x8*>(ap);
+        za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kMassPlaneB);
+        za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kMassPlaneB);
+    }
+    f32x16 acc, accs, acct;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = sb[acc_row(r, hi)]; accs[r] = 0.f; acct[r] = 0.f; }
+    mfma_bf16x6_split2(za[0], hz[0], za[1], hz[1], acc, accs, acct);
+    mfma_bf16x6_split2(za[2], hz[2], za[3], hz[3], acc, accs, acct);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += accs[r] + acct[r];
+    return acc;
+}
+// e^(z - M) as the hardware's exp2 of one fma (nml = -M log2 e); masked elements carry z = -inf -> 0.  ONE definition for every mass kernel: same bits.
+__device__ __forceinline__ float mass_exp(float z, float nml) { return __builtin_amdgcn_exp2f(__builtin_fmaf(z, 1.4426950408889634f, nml)); }
+__device__ __forceinline__ float mass_log(float s) { return __builtin_amdgcn_logf(s) * 0.6931471805599453f; }
+
 #ifdef CIRS_MASS_PROF
 // stage timestamps of workgroup (0, 0) / wave 0 (probe builds only: tools/probes/mass_prof.py)
 static __device__ unsigned long long g_mass_prof[32];
@@ -354,14 +422,15 @@ static __device__ unsigned long long g_mass_prof[32];
 #else
 #define CIRS_MSTAMP(K) do { } while (0)
 #endif
-static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa,
+// grid = (ceil(n_chunks / chunks_per_wg), row blocks); 4 waves = 4 env row tiles walking the same chunks (shared staged tiles).
+static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_cfg cfg, const uint4* __restrict__ planes,
                                                                    const float* __restrict__ ba, const float* __restrict__ h2, int n,
                                                                    const int32_t* __restrict__ env_ids,
                                                                    const uint32_t* __restrict__ visited,
                                                                    const uint8_t* __restrict__ skip, float* __restrict__ lmass,
                                                                    int n_pad, int chunks_per_wg, int item_base = 0,
                                                                    int n_items_total = 0, int env_base = 0, float* __restrict__ zstore = nullptr) {
-    __shared__ __attribute__((aligned(16))) float sW[2][kTileN * kLdsStride];
+    __shared__ __attribute__((aligned(16))) unsigned char sW[2][3 * kMassPlaneB];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
     CIRS_MSTAMP(0);
@@ -374,34 +443,31 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
     const int n_chunks = n_chunks_of(I);
     const int c_begin = blockIdx.x * chunks_per_wg;
     const int c_end = min(n_chunks, c_begin + chunks_per_wg);
-    const int st_item = tid >> 3, st_col = (tid & 7) * 8;
-    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    const int dst_r = (tid >> 3) * kMassRowB + (tid & 7) * 16;
+    uint4 g0 = {0u, 0u, 0u, 0u}, g1 = g0, g2 = g0;
     float gb = 0.f;
 #define CIRS_ISSUE(TILE0)                                                                                  \
     do {                                                                                                   \
-        const int item_ = (TILE0) + st_item;                                                               \
-        if (item_ < I) {                                                                                   \
-            const float4* src_ = reinterpret_cast<const float4*>(wa + (size_t)item_ * kH + st_col);        \
-            g0 = src_[0]; g1 = src_[1];                                                                    \
-        } else {                                                                                           \
-            g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0;                                                 \
-        }                                                                                                  \
+        const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kMassTileU4 + tid;                       \
+        g0 = src_[0]; g1 = src_[256]; g2 = src_[512];                                                      \
         if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
-        float4* dst_ = reinterpret_cast<float4*>(&sW[BUF][st_item * kLdsStride + st_col]);                 \
-        dst_[0] = g0; dst_[1] = g1;                                                                        \
+        unsigned char* base_ = sW[BUF];                                                                    \
+        *reinterpret_cast<uint4*>(base_ + dst_r) = g0;                                                     \
+        *reinterpret_cast<uint4*>(base_ + kMassPlaneB + dst_r) = g1;                                       \
+        *reinterpret_cast<uint4*>(base_ + 2 * kMassPlaneB + dst_r) = g2;                                   \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
-    // the first tile's rows are requested before anything that waits (the skip flags behind `active`, the vote below): one memory
+    // the first tile's planes are requested before anything that waits (the skip flags behind `active`, the vote below): one memory
     // round trip for both instead of two in a row
     if (c_begin < c_end) CIRS_ISSUE(c_begin * kChunkItems);
     const int jr = row0 + lo;
     const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
     const bool wave_live = __ballot(active) != 0ull;
     const int e = active ? (env_ids ? env_ids[jr] : env_base + jr) : 0;
-    float hrow[32];
+    Planes hz[4];
     if (wave_live) {
         // the wave's 32 x 64 tile of hidden rows is 8 KB of consecutive memory: read coalesced (8 x 1 KB), handed to the lanes through LDS
         __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];
@@ -416,15 +482,11 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
 #pragma unroll
         for (int q = 0; q < 8; ++q) st4[(4 * q + (lane >> 4)) * (kLdsStride / 4) + (lane & 15)] = t8[q];
         __builtin_amdgcn_wave_barrier();
-        const mass_v4* src = reinterpret_cast<const mass_v4*>(&sH[wv][lo * kLdsStride + hi * 32]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const mass_v4 v = src[q];
-            hrow[4 * q + 0] = v.x; hrow[4 * q + 1] = v.y; hrow[4 * q + 2] = v.z; hrow[4 * q + 3] = v.w;
-        }
+        mass_split_hidden(sH[wv], lo, hi, hz);
     } else {
+        const pk4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int q = 0; q < 32; ++q) hrow[q] = 0.f;
+        for (int q = 0; q < 4; ++q) { hz[q].h = __builtin_bit_cast(bf16x8, z4); hz[q].m = hz[q].h; hz[q].l = hz[q].h; }
     }
     __shared__ int s_any;
     if (tid == 0) s_any = 0;
@@ -450,17 +512,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
             const bool more = t < 3 || c + 1 < c_end;
             if (more) CIRS_ISSUE(tile0 + kTileN);
             if (wave_live) {
-                const float* tw = sW[buf];
-                float wrow[32];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(&tw[lo * kLdsStride + hi * 32 + 4 * q]);
-                    wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = sB[buf][(r & 3) + 8 * (r >> 2) + 4 * hi];
-#pragma unroll
-                for (int kk = 0; kk < 32; ++kk) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc[t], 0, 0, 0);
+                acc[t] = mass_logits_tile(sW[buf], sB[buf], hz, lo, hi);
                 vis[t] = (visited && active && tile0 < I) ? visited[(size_t)e * vis_words + ((item_base + tile0) >> 5)] : 0u;   // tiles beyond the catalogue: no word exists
             }
             CIRS_MSTAMP(3 + 2 * t);
@@ -500,22 +552,16 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
         CIRS_MSTAMP(11);
         float L = -INFINITY;
         if (M > -INFINITY) {        // uniform over the lane pair (M is shared), evaluated by every lane that has a partner
+            const float nml = -M * 1.4426950408889634f;
             float sl = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; r += 8) {      // 4 pairs at a time on the packed-fp32 pipe; the sum keeps its element order
-                    det_f2 x[4], ex[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { x[i].x = acc[t][r + 2 * i] - M; x[i].y = acc[t][r + 2 * i + 1] - M; }
-                    det_expf_neg8(x, ex);                 // masked elements: e^(-inf) = 0
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { sl += ex[i].x; sl += ex[i].y; }
-                }
+                for (int r = 0; r < 16; ++r) sl += mass_exp(acc[t][r], nml);      // the sum keeps its element order (tile, r)
             const float so = __shfl_xor(sl, 32, CIRS_WAVE);
             CIRS_MSTAMP(12);
             const float S = hi == 0 ? sl + so : so + sl;                          // S_hi0 + S_hi1, in that order on both lanes
-            L = M + det_logf(S);
+            L = M + mass_log(S);
         }
         if (row0 < n_pad && hi == 0) lmass[(size_t)c * n_pad + jr] = active ? L : -INFINITY;
         CIRS_MSTAMP(13);
@@ -526,22 +572,22 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
 
 // ---- the same chunk masses for FEW env rows (n_pad <= 128), one workgroup per chunk, one WAVE per (row tile, item tile) -----------------------
 // actor_mass_kernel walks the four item tiles of a chunk one after the other in each wave: at 64 envs (BASELINE configs[1]) that is 26 workgroups of two live
-// waves, 9.9 us of which ~4 us are the three tiles that wait their turn.  Here the chunk's four tiles run side by side in four waves per row tile
-// (2 row tiles x 4 = 8 waves at 64 envs): the whole 32 KB of the chunk's head rows are staged at once, every wave does ONE tile's 32 MFMAs and its 16
-// exponentials per lane, and only what has an order is serial -- the half-wave sums S_hi = (((0 + e(t0, r0)) + e(t0, r1)) + ... + e(t3, r15)) are handed
-// from tile wave to tile wave through LDS (16 adds and one barrier per hand-off).  Bits identical to actor_mass_kernel (max is order-free; the sum keeps
-// its order).  grid = n_chunks, block = (n_pad / 32) * 256 threads.
-static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_policy_cfg cfg, const float* __restrict__ wa, const float* __restrict__ ba,
+// waves.  Here the chunk's four tiles run side by side in four waves per row tile (2 row tiles x 4 = 8 waves at 64 envs): the chunk's four plane tiles (48 KB)
+// are staged at once, every wave does ONE tile's 24 MFMAs and its 16 exponentials per lane, and only what has an order is serial -- the half-wave sums
+// S_hi = (((0 + e(t0, r0)) + e(t0, r1)) + ... + e(t3, r15)) are handed from tile wave to tile wave through LDS (16 adds and one barrier per hand-off).
+// Bits identical to actor_mass_kernel (same logits and exponentials; max is order-free; the sum keeps its order).  grid = n_chunks, block = (n_pad / 32) * 256.
+static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_policy_cfg cfg, const uint4* __restrict__ planes, const float* __restrict__ ba,
                                                                        const float* __restrict__ h2, int n, const uint32_t* __restrict__ visited,
                                                                        const uint8_t* __restrict__ skip, float* __restrict__ lmass, int n_pad, int env_base,
                                                                        float* __restrict__ zstore) {
-    __shared__ __attribute__((aligned(16))) float sW[4][kTileN * kLdsStride];     // the chunk's four item tiles
+    __shared__ __attribute__((aligned(16))) unsigned char sW[4][3 * kMassPlaneB];     // the chunk's four item tiles (planes)
     __shared__ __attribute__((aligned(16))) float sB[4][kTileN];
     __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];     // one hidden tile per row tile
     __shared__ float sM[4][4][kTileM];                                             // [row tile][item tile][row]: the tile's maximum
     __shared__ float sS[4][2][kTileM];                                             // [row tile][half][row]: the running half-wave sum
-    // ~73 KB of static LDS: more than the 64 KB of gfx90a / gfx942 -- this kernel (like the whole library) is gfx950-only (160 KB per CU)
-    static_assert(sizeof(float) * (2 * 4 * kTileN * kLdsStride + 4 * kTileN + 4 * 4 * kTileM + 4 * 2 * kTileM) <= 160 * 1024, "actor_mass_small_kernel: LDS beyond gfx950's 160 KB");
+    // ~92 KB of static LDS: more than the 64 KB of gfx90a / gfx942 -- this kernel (like the whole library) is gfx950-only (160 KB per CU)
+    static_assert(4 * 3 * kMassPlaneB + sizeof(float) * (4 * kTileN + 4 * kTileM * kLdsStride + 4 * 4 * kTileM + 4 * 2 * kTileM) <= 160 * 1024,
+                  "actor_mass_small_kernel: LDS beyond gfx950's 160 KB");
     const int tid = threadIdx.x, n_thr = blockDim.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
@@ -549,11 +595,11 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
     const int I = cfg.n_items, c = blockIdx.x;
     const int vis_words = (I + 31) / 32;
     typedef float mass_v4 __attribute__((ext_vector_type(4)));
-    // the chunk's 128 head rows (rows beyond the catalogue: zeros) and biases, the hidden tiles: everything requested before the first wait
-    for (int f = tid; f < kChunkItems * (kH / 4); f += n_thr) {
-        const int il = f >> 4, col4 = f & 15, item = c * kChunkItems + il;
-        const mass_v4 v = item < I ? *reinterpret_cast<const mass_v4*>(wa + (size_t)item * kH + 4 * col4) : mass_v4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<mass_v4*>(&sW[il >> 5][(il & 31) * kLdsStride + 4 * col4]) = v;
+    // the chunk's four plane tiles (48 KB of consecutive memory) and biases, the hidden tiles: everything requested before the first wait
+    for (int f = tid; f < 4 * kMassTileU4; f += n_thr) {
+        const int t = f / kMassTileU4, u = f - t * kMassTileU4, pl = u >> 8, v = u & 255;
+        const uint4 x = planes[(size_t)(c * kTilesPerChunk + t) * kMassTileU4 + u];
+        *reinterpret_cast<uint4*>(sW[t] + pl * kMassPlaneB + (v >> 3) * kMassRowB + (v & 7) * 16) = x;
     }
     if (tid < kChunkItems) sB[tid >> 5][tid & 31] = c * kChunkItems + tid < I ? ba[c * kChunkItems + tid] : 0.f;
     for (int f = tid; f < n_pad * (kH / 4); f += n_thr) {
@@ -569,18 +615,9 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
     __syncthreads();
     f32x16 acc;
     {
-        float wrow[32], hrow[32];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 t4 = *reinterpret_cast<const float4*>(&sW[tt][lo * kLdsStride + hi * 32 + 4 * q]);
-            wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
-            const float4 h4 = *reinterpret_cast<const float4*>(&sH[rt][lo * kLdsStride + hi * 32 + 4 * q]);
-            hrow[4 * q] = h4.x; hrow[4 * q + 1] = h4.y; hrow[4 * q + 2] = h4.z; hrow[4 * q + 3] = h4.w;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = sB[tt][(r & 3) + 8 * (r >> 2) + 4 * hi];
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[kk], hrow[kk], acc, 0, 0, 0);
+        Planes hz[4];
+        mass_split_hidden(sH[rt], lo, hi, hz);
+        acc = mass_logits_tile(sW[tt], sB[tt], hz, lo, hi);
     }
     if (zstore && active) {
         float* zr = zstore + ((size_t)c * n_pad + jr) * kChunkItems + tt * kTileN + 4 * hi;
@@ -599,21 +636,14 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
     if (hi == 0) sM[rt][tt][lo] = mloc;
     __syncthreads();
     const float M = fmaxf(fmaxf(sM[rt][0][lo], sM[rt][1][lo]), fmaxf(sM[rt][2][lo], sM[rt][3][lo]));
-    det_f2 ex[8];
+    float ex[16];
     if (M > -INFINITY) {
+        const float nml = -M * 1.4426950408889634f;
 #pragma unroll
-        for (int r = 0; r < 16; r += 8) {
-            det_f2 x[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { x[i].x = acc[r + 2 * i] - M; x[i].y = acc[r + 2 * i + 1] - M; }
-            det_f2 o4[4];
-            det_expf_neg8(x, o4);                         // masked elements: e^(-inf) = 0
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ex[r / 2 + i] = o4[i];
-        }
+        for (int r = 0; r < 16; ++r) ex[r] = mass_exp(acc[r], nml);      // masked elements: e^(-inf) = 0
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ex[i] = det_f2{0.f, 0.f};
+        for (int r = 0; r < 16; ++r) ex[r] = 0.f;
     }
     // the ordered sum, tile after tile (every wave passes every barrier)
     float sl = 0.f;
@@ -622,7 +652,7 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
         if (tt == t) {
             sl = t == 0 ? 0.f : sS[rt][hi][lo];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { sl += ex[i].x; sl += ex[i].y; }
+            for (int r = 0; r < 16; ++r) sl += ex[r];
             if (t < 3) sS[rt][hi][lo] = sl;
         }
         if (t < 3) __syncthreads();
@@ -632,7 +662,7 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
         const float so = __shfl_xor(sl, 32, CIRS_WAVE);
         if (M > -INFINITY) {
             const float S = hi == 0 ? sl + so : so + sl;                          // S_hi0 + S_hi1, in that order on both lanes
-            L = M + det_logf(S);
+            L = M + mass_log(S);
         }
         if (hi == 0) lmass[(size_t)c * n_pad + jr] = active ? L : -INFINITY;
     }

@@ -188,7 +188,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     int n_g = ((n_env + G - 1) / G + 127) / 128 * 128;       // rows per group: whole 128-row blocks of the mass kernel
     if (G > 1) {   // room for one sampler workspace per group?
         const int64_t per = (group_ws_bytes(pol_cfg, n_g) + 255) & ~(int64_t)255;
-        if (per * G > workspace_bytes - kTrkImgBytes) { G = 1; n_g = n_env; }
+        if (per * G > workspace_bytes - kTrkImgBytes - (int64_t)ws_rplanes_bytes(pol_cfg->n_items) - 512) { G = 1; n_g = n_env; }
     } else {
         n_g = n_env;
     }
@@ -196,6 +196,9 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     // caller's stream, before the group streams fork from it
     float* img = (float*)((char*)workspace + ((workspace_bytes - kTrkImgBytes) & ~(int64_t)255));
     if (int rc = pack_tracker_image(trk_cfg, trk_w, pol_w, S, img, s)) return rc;
+    // bf16 planes of the actor head for the chunk-mass kernels, likewise once per call
+    uint4* rplanes = ws_rplanes(workspace, workspace_bytes, pol_cfg->n_items);
+    if (!gumbel) { if (int rc = build_rplanes(pol_w->wa, pol_cfg->n_items, rplanes, s)) return rc; }
     // group streams / events: one set per (host thread, device) -- a stream belongs to the device that was current when it was
     // created, and two host threads driving rollouts concurrently (the virtual-rank tests) must not share the event array
     constexpr int kMaxDevices = 16;
@@ -278,12 +281,12 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                                                              rng_base + (uint32_t)t, (const int32_t*)nullptr, (const uint32_t*)visited,
                                                              done_all, q.pv, q.n_pad, q.hg.tiles_per_chunk));
             } else if (mass_small) {   // few envs: one workgroup per chunk, one wave per (row tile, item tile)
-                CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_small_kernel, dim3(n_mass_chunks), dim3(q.n_pad / kTileM * 256), 0, q.st, *pol_cfg, pol_w->wa,
+                CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_small_kernel, dim3(n_mass_chunks), dim3(q.n_pad / kTileM * 256), 0, q.st, *pol_cfg, (const uint4*)rplanes,
                                                              pol_w->ba, (const float*)q.h2, q.n, (const uint32_t*)visited, done_all + q.base, q.pv.m, q.n_pad, q.base,
                                                              zstore));
             } else {       // counter-based sampler: chunk log-masses now, chunk + item draws in the tail of the step kernel
                 CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(n_mass_chunks, q.cpw), q.hg.n_row_blocks), dim3(256), 0,
-                                                             q.st, *pol_cfg, pol_w->wa, pol_w->ba, (const float*)q.h2, q.n, (const int32_t*)nullptr,
+                                                             q.st, *pol_cfg, (const uint4*)rplanes, pol_w->ba, (const float*)q.h2, q.n, (const int32_t*)nullptr,
                                                              (const uint32_t*)visited, done_all + q.base, q.pv.m, q.n_pad, q.cpw, 0, 0, q.base, zstore));
             }
             CIRS_CHECK_LAUNCH("sampler kernel");

@@ -44,6 +44,9 @@ def lib():
         h.oracle_actor_sample.restype = C.c_int
         h.oracle_actor_sample.argtypes = [C.POINTER(abi.PolicyCfg), C.POINTER(abi.PolicyWeights), _P, C.c_int64,
                                           C.c_int32, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P]
+        h.oracle_actor_sample_margins.restype = C.c_int
+        h.oracle_actor_sample_margins.argtypes = [C.POINTER(abi.PolicyCfg), C.POINTER(abi.PolicyWeights), _P, C.c_int64,
+                                                  C.c_int32, C.c_uint64, C.c_uint32, _P, _P, _P, _P, _P, _P, _P]
         h.oracle_deepfm_forward.restype = C.c_int
         h.oracle_deepfm_forward.argtypes = [C.POINTER(abi.DeepFMCfg), C.POINTER(abi.DeepFMWeights), _P, _P, _P, _P, C.c_int32, _P]
         h.oracle_dropout_keep.restype = C.c_int

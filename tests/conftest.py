@@ -58,10 +58,18 @@ def close(got, want, rtol, atol, what):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if not _MARGINS:
-        return
     import json
     out = os.path.join(ROOT, "gpurun_out")
+    try:      # the margin protocol of the sampler's draws (tests/policycase.py): draws compared with the C oracle, ids that differ inside the 1e-6 top-2 margin,
+        import policycase      # violations (ids that differ outside it; any violation also fails its test)
+        if policycase.DRAW_STATS["draws"]:
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "draw_margin_stats.json"), "w") as f:
+                json.dump(dict(policycase.DRAW_STATS, margin=policycase.DRAW_MARGIN), f)
+    except ImportError:
+        pass
+    if not _MARGINS:
+        return
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_margins.json"), "w") as f:
         json.dump(_MARGINS, f, indent=1)

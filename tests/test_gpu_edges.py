@@ -70,8 +70,8 @@ def test_rollout_and_update_odd_shapes(U, I, B, T, N, thr):
     arrs = {k: eng.policy_views[v].cpu().numpy() for k, v in names.items()}
     for t in range(int(lens.max())):
         live = act[t] >= 0
-        oa, _, ov, _ = policycase.oracle_sample(arrs, obs[t], seed=(11 << 8), rng_step=t, skip=(~live).astype(np.uint8))
-        assert np.array_equal(oa[live], act[t][live])
+        oa, _, ov, mg = policycase.oracle_sample(arrs, obs[t], seed=(11 << 8), rng_step=t, skip=(~live).astype(np.uint8), want_margins=True)
+        policycase.assert_draws_match(act[t][live], oa[live], mg[live], f"step {t}")
     host = envcase.HostEnv(envcase.env_cfg(U, I, num_leave_compute=N, leave_threshold=thr, max_turn=T, tau=10.0, gamma_exposure=10.0,
                                            version=1, r_decay=1.0, has_ab=True), tab.mat, tab.normed_mat, tab.dist, tab.item_cats, a_env, b_env, B)
     want = envcase.run_teacher_forced(host, users.numpy(), np.maximum(act.T, 0), T)

@@ -118,12 +118,15 @@ def test_sharded_rollout_bit_identical_to_single_device(W, E):
     assert int(ref["act"].max()) >= I - I // W, "the sampler must reach the last rank's item shard"
 
 
-@pytest.mark.parametrize("W,U,I,Bl,T", [(4, 4096, 4096, 16, 6), (8, 1 << 20, 1 << 20, 16, 5)])
-def test_sharded_training_step_equals_single_device(W, U, I, Bl, T):
+@pytest.mark.parametrize("W,U,I,Bl,T,pol_lr", [(4, 4096, 4096, 16, 6, 1e-3), (8, 1 << 20, 1 << 20, 16, 5, 1e-3), (4, 4096, 4096, 16, 6, 0.0)])
+def test_sharded_training_step_equals_single_device(W, U, I, Bl, T, pol_lr):
     """BASELINE configs[4] TRAINS in its split form (VERDICT r02 missing #1): ShardedRollout.collect + ShardedTrainer.update (item-sharded
     head via cirs_ppo_minibatch_tp, tracker BPTT over compact embedding tables, gradient rows pushed to their owners and scattered in
     buffer order, Adam on every shard) against the single-device engine on the same users / noise / minibatches: losses, the
-    concatenated head shards, trunk / critic, dense tracker parameters and the re-assembled embedding tables."""
+    concatenated head shards, trunk / critic, dense tracker parameters and the re-assembled embedding tables.
+    pol_lr = 0 is the TEACHER-FORCED variant: the policy does not move during the update, so both sides back-propagate the same
+    d loss / d obs function and the tracker / embedding gradients of the sharded BPTT must agree with the single-device ones to fp32 round-off
+    (2e-4 of each tensor's largest entry) -- the bar that catches a 0.1 % regression, which the free-running comparison (3e-3) cannot."""
     from cirs_hip.deepfm import DeviceDeepFM
     from cirs_hip.engine import CirsEngine
     from cirs_hip.env import DeviceEnv, DeviceEnvTables
@@ -151,6 +154,7 @@ def test_sharded_training_step_equals_single_device(W, U, I, Bl, T):
     dt = DeviceEnvTables(None, None, cats, n_users=U, n_items=I)
     eng = CirsEngine(dt, B, seed=seed, tracker_params={k: v.float() for k, v in tp.items()}, policy_params=pol_named, batch_size_hint=bs,
                      online_reward=OnlineReward(um, ident, ident, feats, dur, mm, B), **env_kw)
+    eng.learner.cfg.lr = pol_lr           # (the tracker keeps its own step size)
     lengths = eng.collect(users).cpu().numpy()
     n_total = int(lengths.sum())
     perms = [rng.permutation(n_total) for _ in range(2)]
@@ -187,7 +191,7 @@ def test_sharded_training_step_equals_single_device(W, U, I, Bl, T):
             mk = lambda full, n: ShardedTable(ShardedTable.shard_of(full, r, W).cuda(), n, comm)  # noqa: E731
             sr = ShardedRollout(comm, envl, trkl, Trajectory(Bl, T, 20, "cuda"), shard, r * Is, I, fml, mk(fm_user_full, U), mk(fm_item_full, I),
                                 mk(trk_user_full, U), mk(trk_item_full, I), ident, ident, feats, dur, mm)
-            trainer = ShardedTrainer(sr, pflat, B, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, lr=1e-3)
+            trainer = ShardedTrainer(sr, pflat, B, gamma=0.95, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, lr=pol_lr)
             ln = sr.collect(users[r * Bl:(r + 1) * Bl], seed=seed << 8, rng_base=0)
             losses, n = trainer.update(ln, bs, 2, perms=perms)
             torch.cuda.synchronize()
@@ -219,7 +223,7 @@ def test_sharded_training_step_equals_single_device(W, U, I, Bl, T):
     # to round-off moves its parameter by +-lr in either direction, and the item-sharded learner and the single-device one evaluate the step in
     # different fp32 orders.  Observed 2.0e-4 (round 4), 3.0e-4 and 1.1e-3 (two builds of round 5 that differ in summation order only); the
     # per-step losses above and the teacher-forced gradient comparison of tests/test_gpu_tp_learner.py are the round-off bars.
-    def grad_close(got, want, what, tol=3e-3):
+    def grad_close(got, want, what, tol=3e-3 if pol_lr > 0 else 2e-4):
         scale = float(np.abs(want).max())
         assert scale > 0 or float(np.abs(got).max()) == 0, what
         assert float(np.abs(got - want).max()) <= tol * scale + 1e-12, (what, float(np.abs(got - want).max()), scale)
