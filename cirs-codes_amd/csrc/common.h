@@ -93,6 +93,21 @@ __device__ __forceinline__ float wave_max_f32_dpp(float v) {
     return fmaxf(fmaxf(row_pick(v, 0), row_pick(v, 16)), fmaxf(row_pick(v, 32), row_pick(v, 48)));
 }
 
+// reductions inside a ROW of 16 lanes (four DPP steps, no cross-row traffic): afterwards every lane of the row holds the row's result
+__device__ __forceinline__ float row16_sum_f32(float v) {
+    v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v)); v = fmaxf(v, dpp_f32<0x4E>(v)); v = fmaxf(v, dpp_f32<0x141>(v)); v = fmaxf(v, dpp_f32<0x140>(v));
+    return v;
+}
+// sum over lanes 0..31 (the caller passes 0 in lanes >= 32 or ignores them): two rows
+__device__ __forceinline__ float half_sum_f32_dpp(float v) {
+    v = row16_sum_f32(v);
+    return row_pick(v, 0) + row_pick(v, 16);
+}
+
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it stalls every wave until its
 // outstanding global stores/loads have completed (~1-2 us for a store).  Use where the data exchanged is in LDS and
 // the global accesses in flight are either write-only results or prefetches consumed behind a later register dependency.

@@ -71,11 +71,12 @@ __device__ __forceinline__ float dot_pre(const RowRegs<K>& r, const float* xs, f
 // LayerNorm over the 32 values held by lanes 0..31 (lanes >= 32 pass 0 and get garbage they never use); wo / bo = this lane's
 // weight and bias, loaded by the caller well before (a load here would wait behind every weight row requested in between)
 __device__ __forceinline__ float layer_norm32(float v, int lane, float wo, float bo) {
-    const float vv = lane < kD ? v : 0.f;
-    const float mean = wave_sum_f32_dpp(vv) * (1.0f / kD);
-    const float dlt = lane < kD ? v - mean : 0.f;
-    const float var = wave_sum_f32_dpp(dlt * dlt) * (1.0f / kD);
-    const float inv = 1.0f / sqrtf(var + 1e-5f);
+    // (round 6: the 32 values live in two rows of 16 lanes -> four DPP steps + two row picks per sum instead of a full-wave reduction; v_rsq_f32 (1 ulp)
+    //  instead of a correctly rounded division by a square root: ~25 instructions less per LayerNorm on a wave whose instruction count is its time)
+    const float mean = half_sum_f32_dpp(v) * (1.0f / kD);       // lanes >= 32 hold a duplicate of lanes 0..31 or garbage: only rows 0, 1 are picked
+    const float dlt = v - mean;
+    const float var = half_sum_f32_dpp(dlt * dlt) * (1.0f / kD);
+    const float inv = __builtin_amdgcn_rsqf(var + 1e-5f);
     return dlt * inv * wo + bo;
 }
 
@@ -181,9 +182,16 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     do {                                                                                                         \
         const float* kc0_ = st.kcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
         const float* vc0_ = st.vcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
+        if constexpr (NHEAD == 4) {   /* lane = (head lane >> 4, slot lane & 15): this head's 8 key components of positions slot and slot + 16 */ \
+            const float4* kh_ = reinterpret_cast<const float4*>(kc0_) + (size_t)(2 * (lane >> 4)) * L + (lane & 15);    \
+            const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
+            kpre[0] = (lane & 15) < pos ? kh_[0] : z4_;       kpre[1] = (lane & 15) < pos ? kh_[L] : z4_;        \
+            kpre[2] = (lane & 15) + 16 < pos ? kh_[16] : z4_; kpre[3] = (lane & 15) + 16 < pos ? kh_[L + 16] : z4_; \
+        } else {                                                                                                 \
         const float4* k4_ = reinterpret_cast<const float4*>(kc0_) + lane;   /* K cache: [d/4][L][4], see below */ \
         _Pragma("unroll") for (int q4 = 0; q4 < kD / 4; ++q4)                                                    \
             kpre[q4] = lane < pos ? k4_[(size_t)q4 * L] : make_float4(0.f, 0.f, 0.f, 0.f);                       \
+        }                                                                                                        \
         _Pragma("unroll") for (int u8 = 0; u8 < 16; ++u8) {                                                      \
             const int jp_ = (lane >> 5) + 2 * u8;                                                                \
             vpre[u8] = jp_ < pos ? vc0_[(size_t)jp_ * kD + o32] : 0.f;                                           \
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         }
         __builtin_amdgcn_wave_barrier();
         const float acc = dot_pre<kD>(gp, xs, __builtin_fmaf(g_r, r, gbias));   // input order [r, a_0..a_31]
-        const float g = 1.0f / (1.0f + expf(-acc));
+        const float g = __builtin_amdgcn_rcpf(1.0f + __expf(-acc));      // hardware exp2 / rcp (1 ulp each)
         x = g * a;
     }
     __builtin_amdgcn_wave_barrier();
@@ -326,6 +334,83 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         if (lane < kD) kc[((size_t)(lane >> 2) * L + pos) * 4 + (lane & 3)] = kcur[lane];
         else vc[(size_t)pos * kD + (lane - kD)] = vcur[lane - kD];
         CIRS_STAMP(5 + 6 * l);
+        if constexpr (NHEAD == 4) {
+            // ---- attention, 4 heads x 8 (round 6): lane = (head hq = lane >> 4, slot pq = lane & 15) owns the positions pq, pq + 16, pq + 32, ...  A head is a ROW of
+            // 16 lanes, so its soft-max maximum and sum are four DPP steps each with no cross-row traffic (the lane = position layout reduced four heads one
+            // after the other over the whole wave: ~90 instructions of DPP + v_readlane), a lane forms two 8-term dots instead of four per position, and the
+            // probabilities leave NORMALISED (the V sum needs no per-head factor).  Positions < 32 -- every episode of the benchmark -- live in registers
+            // (keys prefetched a layer ahead); longer episodes park their scores in the probability buffer.  Hardware exp2 / rcp.
+            const int hq = lane >> 4, pq = lane & 15;
+            const float4 q0 = *reinterpret_cast<const float4*>(qs + 8 * hq), q1 = *reinterpret_cast<const float4*>(qs + 8 * hq + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(kcur + 8 * hq), c1 = *reinterpret_cast<const float4*>(kcur + 8 * hq + 4);   // this step's key
+            auto dot8 = [&](const float4& a, const float4& b) {
+                float sc = q0.x * a.x;
+                sc = __builtin_fmaf(q0.y, a.y, sc); sc = __builtin_fmaf(q0.z, a.z, sc); sc = __builtin_fmaf(q0.w, a.w, sc);
+                sc = __builtin_fmaf(q1.x, b.x, sc); sc = __builtin_fmaf(q1.y, b.y, sc); sc = __builtin_fmaf(q1.z, b.z, sc); sc = __builtin_fmaf(q1.w, b.w, sc);
+                return sc;
+            };
+            const float4* kh = reinterpret_cast<const float4*>(kc) + (size_t)(2 * hq) * L;
+            float sA, sB;
+            {
+                const bool curA = pq == pos, curB = pq + 16 == pos;
+                const float4 a0 = curA ? c0 : kpre[0], a1 = curA ? c1 : kpre[1], b0 = curB ? c0 : kpre[2], b1 = curB ? c1 : kpre[3];
+                sA = pq <= pos ? dot8(a0, a1) : -INFINITY;
+                sB = pq + 16 <= pos ? dot8(b0, b1) : -INFINITY;
+            }
+            float mxh = fmaxf(sA, sB);
+            for (int jp = pq + 32; jp <= pos; jp += 16) {      // (episodes longer than 31 steps only)
+                const float4 a0 = jp == pos ? c0 : kh[jp], a1 = jp == pos ? c1 : kh[L + jp];
+                const float sc = dot8(a0, a1);
+                ps[hq * lpad + jp] = sc;
+                mxh = fmaxf(mxh, sc);
+            }
+            mxh = row16_max_f32(mxh);
+            const float eA = __expf(sA - mxh), eB = __expf(sB - mxh);      // exp(-inf) = 0 beyond the prefix
+            float smh = eA + eB;
+            for (int jp = pq + 32; jp <= pos; jp += 16) {
+                const float ex = __expf(ps[hq * lpad + jp] - mxh);
+                ps[hq * lpad + jp] = ex;
+                smh += ex;
+            }
+            const float invh = __builtin_amdgcn_rcpf(row16_sum_f32(smh));
+            // attention-probability dropout acts AFTER the softmax: the normaliser sums the unmasked terms
+            if (pq <= pos) ps[hq * lpad + pq] = (DROP ? CIRS_DROP(eA, l, CIRS_DROP_ATTN, pq * NHEAD + hq) : eA) * invh;
+            if (pq + 16 <= pos) ps[hq * lpad + pq + 16] = (DROP ? CIRS_DROP(eB, l, CIRS_DROP_ATTN, (pq + 16) * NHEAD + hq) : eB) * invh;
+            for (int jp = pq + 32; jp <= pos; jp += 16) {
+                const float ex = ps[hq * lpad + jp];
+                ps[hq * lpad + jp] = (DROP ? CIRS_DROP(ex, l, CIRS_DROP_ATTN, jp * NHEAD + hq) : ex) * invh;
+            }
+            __builtin_amdgcn_wave_barrier();
+            CIRS_STAMP(6 + 6 * l);
+            // weighted sum of V: lane (half, d) walks the positions half, half + 2, ...; the first 32 positions from the prefetched registers, branch-free
+            {
+                const int half = lane >> 5, d = o32;
+                const float* pr = ps + (d >> 3) * lpad;
+                const float vnow = vcur[d];
+                float acc = 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int jp = half + 2 * u;
+                    const float pv_ = pr[jp <= pos ? jp : pos];            // (clamped: a valid address whatever max_len is)
+                    acc = __builtin_fmaf(jp <= pos ? pv_ : 0.f, jp == pos ? vnow : vpre[u], acc);
+                }
+                for (int j0 = 32 + half; j0 <= pos; j0 += 16) {            // (episodes longer than 31 steps only) 8 cached rows per batch in flight together
+                    float v8[8];
+#pragma unroll
+                    for (int u8 = 0; u8 < 8; ++u8) {
+                        const int jp = j0 + 2 * u8;
+                        v8[u8] = jp < pos ? vc[(size_t)jp * kD + d] : 0.f;
+                    }
+#pragma unroll
+                    for (int u8 = 0; u8 < 8; ++u8) {
+                        const int jp = j0 + 2 * u8;
+                        if (jp <= pos) acc = __builtin_fmaf(pr[jp], jp == pos ? vnow : v8[u8], acc);
+                    }
+                }
+                acc += __shfl_xor(acc, 32, CIRS_WAVE);
+                if (lane < kD) att[d] = acc;
+            }
+        } else {
         // scores: lanes stride over positions 0..pos
         float mx[NHEAD];
 #pragma unroll
@@ -395,6 +480,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
 #pragma unroll
             for (int q = 1; q < NHEAD; ++q) norm = hh == q ? sm[q] : norm;
             if (lane < kD) att[d] = acc * norm;
+        }
         }
         if (l + 1 < cfg.nlayers) CIRS_KV_PREFETCH(l + 1);
         CIRS_STAMP(7 + 6 * l);

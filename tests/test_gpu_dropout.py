@@ -136,10 +136,14 @@ def test_stepwise_protocol_draws_fresh_masks_per_episode():
 
 
 @pytest.mark.parametrize("U,I,B,T", [(60, 150, 12, 7), (300, 3327, 64, 30)])
-def test_exact_redraw_collect_from_one_call_equals_the_stepwise_collect(U, I, B, T):
+def test_exact_redraw_collect_from_one_call_equals_the_stepwise_collect(U, I, B, T, monkeypatch):
     """cirs_rollout_steps_redraw (the whole exact-redraw collect from one call: per vector step the batched prefix pass of build_state call t inside the
     fused rollout) == the stage-by-stage loop of round 4 (RedrawRollout.collect_stepwise): actions, rewards, done flags, log-probs, values, episode
-    lengths and the tracker's input slots bit for bit, the states of the envs alive at a call bit for bit."""
+    lengths and the tracker's input slots bit for bit, the states of the envs alive at a call bit for bit.
+    (The fused rollout's logit store is off here: at these env counts it would hand the pick the mass kernel's bf16-pipe logits, while the stage-by-stage
+    loop's stand-alone pick recomputes them as fp32 chains -- 1e-7 apart, tests/test_gpu_rollout.py::test_small_count_switches_keep_the_draws;
+    this test is about the redraw plumbing and keeps its bit-for-bit bar.)"""
+    monkeypatch.setenv("CIRS_ROLLOUT_ZSTORE", "0")
     from cirs_hip.engine import CirsEngine
     from cirs_hip.env import DeviceEnvTables
     from cirs_hip.synthetic import make_tables
