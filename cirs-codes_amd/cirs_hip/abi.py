@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcirs_hip.so")
+# CIRS_HIP_LIB: an explicit path to another build of the library (same-box A/B runs of tools/ab_step_libs.py, tests against a probe build); default: the in-tree build
+LIB_PATH = os.environ.get("CIRS_HIP_LIB") or os.path.join(_HERE, "libcirs_hip.so")
 
 c_i32p = C.POINTER(C.c_int32)
 c_i64p = C.POINTER(C.c_int64)

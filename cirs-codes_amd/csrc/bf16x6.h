@@ -136,6 +136,61 @@ __device__ __forceinline__ void mfma_bf16x6_pair_b(const Planes& a0, const Plane
     c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b.h, c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b.h, c1, 0, 0, 0);
 }
+
+// ---- fp32 products from TWO fp16 pieces per operand ("f16x3", round 6 experiment) ------------------------------------
+// x = h + l with h = fp16(x), l = fp16(x - h): round-to-nearest pieces of 11 significant bits each leave |x - h - l| <= 2^-24 |x| -- fp32's own half ulp --
+// as long as both pieces are NORMAL fp16 numbers (|piece| >= 6.1e-5; below that a piece keeps 6e-8 of ABSOLUTE resolution).  a b = ah bh + (ah bl + al bh)
+// + O(2^-24 |a b|): THREE MFMAs per 16 k instead of six, one split level instead of two.  The price is the 5-bit exponent: operands are pre-scaled by
+// exact powers of two into [2^-2, 2^15] (callers: ppo.hip kScWa / kScH2 / the per-row-block dZ scale) and results unscaled exactly.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_b __attribute__((ext_vector_type(2)));
+struct Planes2 { f16x8 h, l; };
+__device__ __forceinline__ uint32_t cvt_pk_f16(float lo_val, float hi_val) {
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo_val), "v"(hi_val));
+    return r;
+}
+__device__ __forceinline__ Planes2 split8h(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+    const f32x2_b x[4] = {{x0, x1}, {x2, x3}, {x4, x5}, {x6, x7}};
+    uint32_t hh[4], ll[4];
+    f32x2_b r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hh[i] = cvt_pk_f16(x[i].x, x[i].y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2_b hv = __builtin_bit_cast(f16x2_b, hh[i]);
+        const f32x2_b hf = {(float)hv.x, (float)hv.y};
+        r[i] = x[i] - hf;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ll[i] = cvt_pk_f16(r[i].x, r[i].y);
+    const pk4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+    Planes2 o;
+    o.h = __builtin_bit_cast(f16x8, h); o.l = __builtin_bit_cast(f16x8, l);
+    return o;
+}
+__device__ __forceinline__ Planes2 split8h(const f32x16_b& v, int base) {
+    return split8h(v[base], v[base + 1], v[base + 2], v[base + 3], v[base + 4], v[base + 5], v[base + 6], v[base + 7]);
+}
+// two k-steps, accumulation split by magnitude like mfma_bf16x6_split2: big = the h*h terms, sm0 / sm1 = the cross terms of k-step 0 / 1
+__device__ __forceinline__ void mfma_f16x3_split2(const Planes2& a0, const Planes2& b0, const Planes2& a1, const Planes2& b1, f32x16_b& big, f32x16_b& sm0,
+                                                  f32x16_b& sm1) {
+    sm0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.l, b0.h, sm0, 0, 0, 0);
+    sm1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.l, b1.h, sm1, 0, 0, 0);
+    big = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b0.h, big, 0, 0, 0);
+    sm0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b0.l, sm0, 0, 0, 0);
+    sm1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b1.l, sm1, 0, 0, 0);
+    big = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b1.h, big, 0, 0, 0);
+}
+// two independent accumulators sharing the A operand (small terms first)
+__device__ __forceinline__ void mfma_f16x3_pair(const Planes2& a, const Planes2& b0, const Planes2& b1, f32x16_b& c0, f32x16_b& c1) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b1.h, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b0.l, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b1.l, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b0.h, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b1.h, c1, 0, 0, 0);
+}
 // accumulator register r of a 32 x 32 tile, lane half hi -> row (C/D layout of the 32x32 MFMAs)
 __device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

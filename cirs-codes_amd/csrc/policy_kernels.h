@@ -347,9 +347,9 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 // tiles of a chunk stay in the accumulators, M_c = max of the lane pair's valid logits, S_c = sum of exp(z - M_c) in register order (tile, r) per
 // half-wave, S_c = S_hi0 + S_hi1, L_c = M_c + log S_c.  One float per (chunk, env row) leaves the kernel: lmass[c][row] (-inf: no valid item).
 //
-// Round 6: the logits are fp32 products on the BF16 matrix pipe ("bf16x6", bf16x6.h) -- the arithmetic of the learner's head_stats_kernel, accumulator
-// split and all (bias + h*h terms | cross terms, met once), so the rollout's log-probabilities and the learner's come from the same numbers -- and the
-// mass uses the hardware's exp2 / log2.  Rounds 2-5 kept this stage on the fp32 MFMA with fma-only exp / log so that the C oracle could restate L_c BIT
+// Round 6: the logits are fp32 products from two fp16 pieces per operand on the matrix pipe ("f16x3", bf16x6.h: three MFMAs per 16 k, operands pre-scaled by
+// exact powers of two) -- the arithmetic of the learner's head_stats_kernel, accumulator split and all (bias + h*h terms | cross terms, met once), so the
+// rollout's log-probabilities and the learner's come from the same numbers -- and the mass uses the hardware's exp2 / log2.  Rounds 2-5 kept this stage on the fp32 MFMA with fma-only exp / log so that the C oracle could restate L_c BIT
 // FOR BIT (22.9 us per launch at C3, 39 % of the fp32 MFMA peak; no arithmetic model of v_mfma_f32_32x32x16_bf16 reproduces it exactly:
 // tools/probes/mfma_model_probe.hip).  The masses now agree with the oracle's to ~1e-6 and SURVEY 8(c)'s own protocol applies to the draw: "action
 // indices identical wherever the top-2 margin > 1e-6; report violations, expected 0" (tests/policycase.py: assert_draws_match; the oracle reports both
@@ -357,12 +357,13 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 // geometry or the shard --, the sum keeps its order, and stage 3 (the item inside the drawn chunk) still runs scalar fp32 fma chains.  So every path that
 // forms chunk masses (this kernel, the small-count kernel below, item shards) gives the same bits, and ranks / replays stay bit-identical.
 //
-// Wa arrives as bf16 planes (wa_rplanes_kernel, once per cirs_rollout_steps / cirs_actor_sample call -- the weights do not change inside a call):
-// per item tile of 32, [3 planes h | m | l][32 items][64 cols] bf16 = 768 uint4 (items beyond the catalogue: zero rows; the chunk count is rounded up to
-// whole chunks).  A tile's 12 KB are staged in LDS once per workgroup (row stride 144 B: conflict-free 16-byte operand reads), double buffered.
-constexpr int kMassRowB = 144;                      // LDS row stride (bytes) of one plane of a staged tile: 64 bf16 + 16
+// Wa arrives as fp16 planes (wa_rplanes_kernel, once per cirs_rollout_steps / cirs_actor_sample call -- the weights do not change inside a call):
+// per item tile of 32, [2 planes h | l][32 items][64 cols] fp16 of kMassScWa * Wa = 512 uint4 (items beyond the catalogue: zero rows; the chunk count is
+// rounded up to whole chunks).  A tile's 8 KB are staged in LDS once per workgroup (row stride 144 B: conflict-free 16-byte operand reads), double buffered.
+constexpr int kMassRowB = 144;                      // LDS row stride (bytes) of one plane of a staged tile: 64 fp16 + 16
 constexpr int kMassPlaneB = kTileN * kMassRowB;     // one plane of a tile in LDS
-constexpr int kMassTileU4 = 768;                    // uint4 per item tile in global memory
+constexpr int kMassTileU4 = 512;                    // uint4 per item tile in global memory
+constexpr float kMassScWa = 256.f, kMassScH2 = 64.f, kMassScZ = kMassScWa * kMassScH2, kMassScZi = 1.0f / kMassScZ;   // exact power-of-two prescales (ppo.hip: kScWa / kScH2)
 __host__ __device__ inline size_t ws_rplanes_bytes(int n_items) { return (size_t)n_chunks_of(n_items) * kTilesPerChunk * kMassTileU4 * 16; }
 
 // grid = tiles of whole chunks (n_chunks * 4), 256 threads: thread -> (item = tid / 8, 8 consecutive columns)
@@ -375,40 +376,41 @@ static __global__ __launch_bounds__(256) void wa_rplanes_kernel(const float* __r
         const rp_v4* src = reinterpret_cast<const rp_v4*>(wa + (size_t)item * kH + col);
         a = src[0]; b = src[1];
     }
-    const Planes pl = split8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+    a *= kMassScWa; b *= kMassScWa;
+    const Planes2 pl = split8h(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
     uint4* out = planes + (size_t)tile * kMassTileU4;
-    out[tid] = __builtin_bit_cast(uint4, pl.h); out[256 + tid] = __builtin_bit_cast(uint4, pl.m); out[512 + tid] = __builtin_bit_cast(uint4, pl.l);
+    out[tid] = __builtin_bit_cast(uint4, pl.h); out[256 + tid] = __builtin_bit_cast(uint4, pl.l);
 }
 
-// B operand of the logits product: this lane's env row of H2 (col = lane & 31), element j of k-step s = column 16 s + 8 hi + j, split into bf16 pieces.
-// tile: the wave's 32 x 64 fp32 tile in LDS (row stride kLdsStride floats).
-__device__ __forceinline__ void mass_split_hidden(const float* tile, int lo, int hi, Planes (&hz)[4]) {
+// B operand of the logits product: this lane's env row of H2 (col = lane & 31), element j of k-step s = column 16 s + 8 hi + j, split into fp16 pieces of
+// kMassScH2 * H2.  tile: the wave's 32 x 64 fp32 tile in LDS (row stride kLdsStride floats).
+__device__ __forceinline__ void mass_split_hidden(const float* tile, int lo, int hi, Planes2 (&hz)[4]) {
     typedef float ms_v4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
         const ms_v4* src = reinterpret_cast<const ms_v4*>(&tile[lo * kLdsStride + 16 * s4 + 8 * hi]);
-        const ms_v4 a = src[0], b = src[1];
-        hz[s4] = split8(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
+        const ms_v4 a = src[0] * kMassScH2, b = src[1] * kMassScH2;
+        hz[s4] = split8h(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
     }
 }
 // one 32 x 32 logits tile: A = the staged planes of the item tile (lane = item lo, 8 consecutive columns per k-step), B = hz, accumulator = bias + h*h terms |
 // cross terms (two chains), met once -- head_stats_kernel's sequence (ppo.hip)
-__device__ __forceinline__ f32x16 mass_logits_tile(const unsigned char* tw, const float* sb, const Planes (&hz)[4], int lo, int hi) {
-    Planes za[4];
+// (sb: the tile's biases PRE-SCALED by kMassScZ -- the accumulators hold kMassScZ z until the last line)
+__device__ __forceinline__ f32x16 mass_logits_tile(const unsigned char* tw, const float* sb, const Planes2 (&hz)[4], int lo, int hi) {
+    Planes2 za[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
         const unsigned char* ap = tw + lo * kMassRowB + (16 * s4 + 8 * hi) * 2;
-        za[s4].h = *reinterpret_cast<const bf16x8*>(ap);
-        za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kMassPlaneB);
-        za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kMassPlaneB);
+        za[s4].h = *reinterpret_cast<const f16x8*>(ap);
+        za[s4].l = *reinterpret_cast<const f16x8*>(ap + kMassPlaneB);
     }
     f32x16 acc, accs, acct;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = sb[acc_row(r, hi)]; accs[r] = 0.f; acct[r] = 0.f; }
-    mfma_bf16x6_split2(za[0], hz[0], za[1], hz[1], acc, accs, acct);
-    mfma_bf16x6_split2(za[2], hz[2], za[3], hz[3], acc, accs, acct);
+    mfma_f16x3_split2(za[0], hz[0], za[1], hz[1], acc, accs, acct);
+    mfma_f16x3_split2(za[2], hz[2], za[3], hz[3], acc, accs, acct);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += accs[r] + acct[r];
+    for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + (accs[r] + acct[r])) * kMassScZi;
     return acc;
 }
 // e^(z - M) as the hardware's exp2 of one fma (nml = -M log2 e); masked elements carry z = -inf -> 0.  ONE definition for every mass kernel: same bits.
@@ -430,7 +432,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
                                                                    const uint8_t* __restrict__ skip, float* __restrict__ lmass,
                                                                    int n_pad, int chunks_per_wg, int item_base = 0,
                                                                    int n_items_total = 0, int env_base = 0, float* __restrict__ zstore = nullptr) {
-    __shared__ __attribute__((aligned(16))) unsigned char sW[2][3 * kMassPlaneB];
+    __shared__ __attribute__((aligned(16))) unsigned char sW[2][2 * kMassPlaneB];
     __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
     const int tid = threadIdx.x;
     CIRS_MSTAMP(0);
@@ -444,20 +446,19 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
     const int c_begin = blockIdx.x * chunks_per_wg;
     const int c_end = min(n_chunks, c_begin + chunks_per_wg);
     const int dst_r = (tid >> 3) * kMassRowB + (tid & 7) * 16;
-    uint4 g0 = {0u, 0u, 0u, 0u}, g1 = g0, g2 = g0;
+    uint4 g0 = {0u, 0u, 0u, 0u}, g1 = g0;
     float gb = 0.f;
 #define CIRS_ISSUE(TILE0)                                                                                  \
     do {                                                                                                   \
         const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kMassTileU4 + tid;                       \
-        g0 = src_[0]; g1 = src_[256]; g2 = src_[512];                                                      \
-        if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
+        g0 = src_[0]; g1 = src_[256];                                                                      \
+        if (tid < kTileN) gb = ((TILE0) + tid) < I ? kMassScZ * ba[(TILE0) + tid] : 0.f;                   \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
         unsigned char* base_ = sW[BUF];                                                                    \
         *reinterpret_cast<uint4*>(base_ + dst_r) = g0;                                                     \
         *reinterpret_cast<uint4*>(base_ + kMassPlaneB + dst_r) = g1;                                       \
-        *reinterpret_cast<uint4*>(base_ + 2 * kMassPlaneB + dst_r) = g2;                                   \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
     // the first tile's planes are requested before anything that waits (the skip flags behind `active`, the vote below): one memory
@@ -467,7 +468,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
     const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
     const bool wave_live = __ballot(active) != 0ull;
     const int e = active ? (env_ids ? env_ids[jr] : env_base + jr) : 0;
-    Planes hz[4];
+    Planes2 hz[4];
     if (wave_live) {
         // the wave's 32 x 64 tile of hidden rows is 8 KB of consecutive memory: read coalesced (8 x 1 KB), handed to the lanes through LDS
         __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];
@@ -486,7 +487,7 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
     } else {
         const pk4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { hz[q].h = __builtin_bit_cast(bf16x8, z4); hz[q].m = hz[q].h; hz[q].l = hz[q].h; }
+        for (int q = 0; q < 4; ++q) { hz[q].h = __builtin_bit_cast(f16x8, z4); hz[q].l = hz[q].h; }
     }
     __shared__ int s_any;
     if (tid == 0) s_any = 0;
@@ -572,21 +573,21 @@ static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_c
 
 // ---- the same chunk masses for FEW env rows (n_pad <= 128), one workgroup per chunk, one WAVE per (row tile, item tile) -----------------------
 // actor_mass_kernel walks the four item tiles of a chunk one after the other in each wave: at 64 envs (BASELINE configs[1]) that is 26 workgroups of two live
-// waves.  Here the chunk's four tiles run side by side in four waves per row tile (2 row tiles x 4 = 8 waves at 64 envs): the chunk's four plane tiles (48 KB)
-// are staged at once, every wave does ONE tile's 24 MFMAs and its 16 exponentials per lane, and only what has an order is serial -- the half-wave sums
+// waves.  Here the chunk's four tiles run side by side in four waves per row tile (2 row tiles x 4 = 8 waves at 64 envs): the chunk's four plane tiles (32 KB)
+// are staged at once, every wave does ONE tile's 12 MFMAs and its 16 exponentials per lane, and only what has an order is serial -- the half-wave sums
 // S_hi = (((0 + e(t0, r0)) + e(t0, r1)) + ... + e(t3, r15)) are handed from tile wave to tile wave through LDS (16 adds and one barrier per hand-off).
 // Bits identical to actor_mass_kernel (same logits and exponentials; max is order-free; the sum keeps its order).  grid = n_chunks, block = (n_pad / 32) * 256.
 static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_policy_cfg cfg, const uint4* __restrict__ planes, const float* __restrict__ ba,
                                                                        const float* __restrict__ h2, int n, const uint32_t* __restrict__ visited,
                                                                        const uint8_t* __restrict__ skip, float* __restrict__ lmass, int n_pad, int env_base,
                                                                        float* __restrict__ zstore) {
-    __shared__ __attribute__((aligned(16))) unsigned char sW[4][3 * kMassPlaneB];     // the chunk's four item tiles (planes)
+    __shared__ __attribute__((aligned(16))) unsigned char sW[4][2 * kMassPlaneB];     // the chunk's four item tiles (planes)
     __shared__ __attribute__((aligned(16))) float sB[4][kTileN];
     __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];     // one hidden tile per row tile
     __shared__ float sM[4][4][kTileM];                                             // [row tile][item tile][row]: the tile's maximum
     __shared__ float sS[4][2][kTileM];                                             // [row tile][half][row]: the running half-wave sum
-    // ~92 KB of static LDS: more than the 64 KB of gfx90a / gfx942 -- this kernel (like the whole library) is gfx950-only (160 KB per CU)
-    static_assert(4 * 3 * kMassPlaneB + sizeof(float) * (4 * kTileN + 4 * kTileM * kLdsStride + 4 * 4 * kTileM + 4 * 2 * kTileM) <= 160 * 1024,
+    // ~74 KB of static LDS: more than the 64 KB of gfx90a / gfx942 -- this kernel (like the whole library) is gfx950-only (160 KB per CU)
+    static_assert(4 * 2 * kMassPlaneB + sizeof(float) * (4 * kTileN + 4 * kTileM * kLdsStride + 4 * 4 * kTileM + 4 * 2 * kTileM) <= 160 * 1024,
                   "actor_mass_small_kernel: LDS beyond gfx950's 160 KB");
     const int tid = threadIdx.x, n_thr = blockDim.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -595,13 +596,13 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
     const int I = cfg.n_items, c = blockIdx.x;
     const int vis_words = (I + 31) / 32;
     typedef float mass_v4 __attribute__((ext_vector_type(4)));
-    // the chunk's four plane tiles (48 KB of consecutive memory) and biases, the hidden tiles: everything requested before the first wait
+    // the chunk's four plane tiles (32 KB of consecutive memory) and biases, the hidden tiles: everything requested before the first wait
     for (int f = tid; f < 4 * kMassTileU4; f += n_thr) {
         const int t = f / kMassTileU4, u = f - t * kMassTileU4, pl = u >> 8, v = u & 255;
         const uint4 x = planes[(size_t)(c * kTilesPerChunk + t) * kMassTileU4 + u];
         *reinterpret_cast<uint4*>(sW[t] + pl * kMassPlaneB + (v >> 3) * kMassRowB + (v & 7) * 16) = x;
     }
-    if (tid < kChunkItems) sB[tid >> 5][tid & 31] = c * kChunkItems + tid < I ? ba[c * kChunkItems + tid] : 0.f;
+    if (tid < kChunkItems) sB[tid >> 5][tid & 31] = c * kChunkItems + tid < I ? kMassScZ * ba[c * kChunkItems + tid] : 0.f;
     for (int f = tid; f < n_pad * (kH / 4); f += n_thr) {
         const int r = f >> 4, col4 = f & 15;
         const mass_v4 v = r < n ? *reinterpret_cast<const mass_v4*>(h2 + (size_t)r * kH + 4 * col4) : mass_v4{0.f, 0.f, 0.f, 0.f};
@@ -615,7 +616,7 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
     __syncthreads();
     f32x16 acc;
     {
-        Planes hz[4];
+        Planes2 hz[4];
         mass_split_hidden(sH[rt], lo, hi, hz);
         acc = mass_logits_tile(sW[tt], sB[tt], hz, lo, hi);
     }

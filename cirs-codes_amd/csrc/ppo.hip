@@ -192,6 +192,34 @@ __global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const d
 // ------------------------------------------------------------------------------------------------------------
 // minibatch: gather + advantage normalisation
 // ------------------------------------------------------------------------------------------------------------
+// ---- operand pieces of the actor-head kernels -----------------------------------------------------------------------------------------------------
+// CIRS_HEAD_F16 = 0: three bf16 pieces per operand, six MFMAs per 16 k ("bf16x6", rounds 2-5).  = 1 (round 6 experiment): TWO fp16 pieces per
+// operand, three MFMAs per 16 k ("f16x3", bf16x6.h), operands pre-scaled by exact powers of two so that both pieces stay in fp16's normal range: Wa by kScWa,
+// H2 by kScH2, dZ by a power of two per workgroup (its rows' largest coefficient -> 2^14); logits / dH2 / dWa are unscaled exactly where they leave the
+// accumulators.  The plane storage keeps its three-plane layout (the middle plane is unused in the fp16 form).
+#ifndef CIRS_HEAD_F16
+#define CIRS_HEAD_F16 1
+#endif
+#if CIRS_HEAD_F16
+typedef Planes2 HPl;
+constexpr float kScWa = 256.f, kScH2 = 64.f;
+#define HPL_SET(P, H, M, L) do { (P).h = __builtin_bit_cast(f16x8, H); (P).l = __builtin_bit_cast(f16x8, L); } while (0)
+#define HPL_MID(...)
+#define hsplit8 split8h
+#define hmfma_split2 mfma_f16x3_split2
+#define hmfma_pair mfma_f16x3_pair
+__device__ __forceinline__ uint4 hpl_mid(const HPl& p) { return __builtin_bit_cast(uint4, p.l); }
+#else
+typedef Planes HPl;
+constexpr float kScWa = 1.f, kScH2 = 1.f;
+#define HPL_SET(P, H, M, L) do { (P).h = __builtin_bit_cast(bf16x8, H); (P).m = __builtin_bit_cast(bf16x8, M); (P).l = __builtin_bit_cast(bf16x8, L); } while (0)
+#define HPL_MID(...) __VA_ARGS__
+#define hsplit8 split8
+#define hmfma_split2 mfma_bf16x6_split2
+#define hmfma_pair mfma_bf16x6_pair
+__device__ __forceinline__ uint4 hpl_mid(const HPl& p) { return __builtin_bit_cast(uint4, p.m); }
+#endif
+constexpr float kScZ = kScWa * kScH2, kScZi = 1.0f / kScZ;      // scale of the logits accumulators (bias pre-scaled at staging) and its inverse
 constexpr int kPlaneTileU4 = 1536;  // uint4 per item tile of the bf16 planes of Wa (wa_planes_kernel)
 struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad rows)
     float *obs, *adv, *ret, *v_s, *logp_old;  // gathered
@@ -491,16 +519,16 @@ __device__ __forceinline__ void wa_planes_from_lds(int tile, uint4* __restrict__
     uint4* out = planes + (size_t)tile * kPlaneTileU4;
     {
         const float* r = &sw[(tid >> 3) * 65 + 8 * (tid & 7)];
-        const Planes pl = split8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
-        out[tid] = __builtin_bit_cast(uint4, pl.h); out[256 + tid] = __builtin_bit_cast(uint4, pl.m); out[512 + tid] = __builtin_bit_cast(uint4, pl.l);
+        const HPl pl = hsplit8(kScWa * r[0], kScWa * r[1], kScWa * r[2], kScWa * r[3], kScWa * r[4], kScWa * r[5], kScWa * r[6], kScWa * r[7]);
+        out[tid] = __builtin_bit_cast(uint4, pl.h); HPL_MID(out[256 + tid] = hpl_mid(pl);) out[512 + tid] = __builtin_bit_cast(uint4, pl.l);
     }
     {
         const int n = tid >> 2, t = (tid >> 1) & 1, hi = tid & 1;
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = sw[acc_row(8 * t + j, hi) * 65 + n];
-        const Planes pl = split8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
-        out[768 + tid] = __builtin_bit_cast(uint4, pl.h); out[1024 + tid] = __builtin_bit_cast(uint4, pl.m); out[1280 + tid] = __builtin_bit_cast(uint4, pl.l);
+        for (int j = 0; j < 8; ++j) x[j] = kScWa * sw[acc_row(8 * t + j, hi) * 65 + n];
+        const HPl pl = hsplit8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
+        out[768 + tid] = __builtin_bit_cast(uint4, pl.h); HPL_MID(out[1024 + tid] = hpl_mid(pl);) out[1280 + tid] = __builtin_bit_cast(uint4, pl.l);
     }
 }
 
@@ -548,11 +576,19 @@ __device__ __forceinline__ void trunk_row_pre(int S, const TrunkRowIn& in, int j
 // head workgroup (31 chunks x 8 row blocks re-split the same rows); each lane owns one element and drops its three 2-byte pieces
 // into both layouts (same arithmetic as split_pair: same bits).  a = h2[j][lane].
 __device__ __forceinline__ void trunk_row_planes(float a, int j, int lane, const TrunkRowOut& o) {
+#if CIRS_HEAD_F16
+    a *= kScH2;
+    const uint32_t hp = cvt_pk_f16(a, 0.f) & 0xffffu;
+    const float r1 = a - (float)__builtin_bit_cast(f16x2_b, hp).x;
+    const uint32_t lp = cvt_pk_f16(r1, 0.f) & 0xffffu;
+    const uint32_t mp = 0u;
+#else
     const uint32_t hp = cvt_pk_bf16(a, 0.f) & 0xffffu;
     const float r1 = a - __uint_as_float(hp << 16);
     const uint32_t mp = cvt_pk_bf16(r1, 0.f) & 0xffffu;
     const float r2 = r1 - __uint_as_float(mp << 16);
     const uint32_t lp = cvt_pk_bf16(r2, 0.f) & 0xffffu;
+#endif
     const int tile = j >> 5, rr = j & 31, c = lane;
     // hz: k-step s = c / 16, lane half hi = (c / 8) & 1, element c & 7; the consumer's lane is (hi, lo = row)
     unsigned short* z = reinterpret_cast<unsigned short*>(o.h2z + ((size_t)(tile * 12 + (c >> 4) * 3) * 64 + ((c >> 3) & 1) * 32 + rr)) + (c & 7);
@@ -668,14 +704,12 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
     const int jr = row0 + lo;
     const bool wave_ok = row0 < n_pad && row0 < mb;   // some row of this tile belongs to the minibatch
     const bool active = jr < mb;
-    Planes hz[4];  // B operand: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
+    HPl hz[4];  // B operand: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
     {   // pre-split by trunk_adv_kernel in exactly this order: 12 coalesced 16-byte loads per lane, no LDS, no splits
         const uint4* zp = h2z + (size_t)((wave_ok ? row0 : 0) >> 5) * 12 * 64 + lane;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            hz[s4].h = __builtin_bit_cast(bf16x8, zp[(3 * s4) * 64]);
-            hz[s4].m = __builtin_bit_cast(bf16x8, zp[(3 * s4 + 1) * 64]);
-            hz[s4].l = __builtin_bit_cast(bf16x8, zp[(3 * s4 + 2) * 64]);
+            HPL_SET(hz[s4], zp[(3 * s4) * 64], zp[(3 * s4 + 1) * 64], zp[(3 * s4 + 2) * 64]);
         }
     }
     float run_m = -INFINITY, run_s = 0.f, run_t = 0.f;
@@ -692,14 +726,14 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 #define CIRS_ISSUE(TILE0)                                                                                  \
     do {                                                                                                   \
         const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kPlaneTileU4 + tid;                      \
-        g0 = src_[0]; g1 = src_[256]; g2 = src_[512];                                                      \
-        if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
+        g0 = src_[0]; HPL_MID(g1 = src_[256];) g2 = src_[512];                                             \
+        if (tid < kTileN) gb = ((TILE0) + tid) < I ? kScZ * ba[(TILE0) + tid] : 0.f;   /* the accumulators hold kScZ z */ \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
         unsigned char* base_ = sW[BUF];                                                                    \
         *reinterpret_cast<uint4*>(base_ + dst_r) = g0;                                                     \
-        *reinterpret_cast<uint4*>(base_ + kRPlaneB + dst_r) = g1;                                          \
+        HPL_MID(*reinterpret_cast<uint4*>(base_ + kRPlaneB + dst_r) = g1;)                                 \
         *reinterpret_cast<uint4*>(base_ + 2 * kRPlaneB + dst_r) = g2;                                      \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
@@ -714,22 +748,20 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
         if (it + 1 < n_tiles) CIRS_ISSUE(tile0 + kTileN);
         if (wave_ok) {
             const unsigned char* tw = sW[buf];
-            Planes za[4];
+            HPl za[4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const unsigned char* ap = tw + lo * kRowB + (16 * s4 + 8 * hi) * 2;
-                za[s4].h = *reinterpret_cast<const bf16x8*>(ap);
-                za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);
-                za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);
+                HPL_SET(za[s4], *reinterpret_cast<const uint4*>(ap), *reinterpret_cast<const uint4*>(ap + kRPlaneB), *reinterpret_cast<const uint4*>(ap + 2 * kRPlaneB));
             }
             f32x16 acc, accs, acct;      // bias + the h*h terms | the cross terms, two chains (bf16x6.h: the logits round once per k-step at their own magnitude)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = sB[buf][acc_row(r, hi)]; accs[r] = 0.f; acct[r] = 0.f; }
             if (it == 2) CIRS_SSTAMP(44);
-            mfma_bf16x6_split2(za[0], hz[0], za[1], hz[1], acc, accs, acct);
-            mfma_bf16x6_split2(za[2], hz[2], za[3], hz[3], acc, accs, acct);
+            hmfma_split2(za[0], hz[0], za[1], hz[1], acc, accs, acct);
+            hmfma_split2(za[2], hz[2], za[3], hz[3], acc, accs, acct);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += accs[r] + acct[r];
+            for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + (accs[r] + acct[r])) * kScZi;
             if (it == 2) CIRS_SSTAMP(45);
             {
                 const int arel = act_r - tile0;
@@ -873,8 +905,8 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     // 77 k ticks).  The row scalars are requested first; they travel while the tile does.
     const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     const int act = v.act[jr];
-    Planes hz[4];      // B operand of ZT: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
-    Planes hb[2][2];   // B operand of the dWa product: element j of k-step t = H2[row acc_row(8 t + j, hi)][32 c + lo]
+    HPl hz[4];      // B operand of ZT: this lane's row of H2, element j of k-step s = column 16 s + 8 hi + j
+    HPl hb[2][2];   // B operand of the dWa product: element j of k-step t = H2[row acc_row(8 t + j, hi)][32 c + lo]
     {   // both pre-split by trunk_adv_kernel in register order: 24 coalesced 16-byte loads per lane (the LDS round trip + 8 split8 of
         // the round-2 prologue were 4.4 k of the kernel's 78 k ticks)
         const size_t tb = (size_t)((wave_ok ? row0 : 0) >> 5) * 12 * 64 + lane;
@@ -882,17 +914,13 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         const uint4* bp = v.h2b + tb;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            hz[s4].h = __builtin_bit_cast(bf16x8, zp[(3 * s4) * 64]);
-            hz[s4].m = __builtin_bit_cast(bf16x8, zp[(3 * s4 + 1) * 64]);
-            hz[s4].l = __builtin_bit_cast(bf16x8, zp[(3 * s4 + 2) * 64]);
+            HPL_SET(hz[s4], zp[(3 * s4) * 64], zp[(3 * s4 + 1) * 64], zp[(3 * s4 + 2) * 64]);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                hb[c][t].h = __builtin_bit_cast(bf16x8, bp[(3 * (2 * c + t)) * 64]);
-                hb[c][t].m = __builtin_bit_cast(bf16x8, bp[(3 * (2 * c + t) + 1) * 64]);
-                hb[c][t].l = __builtin_bit_cast(bf16x8, bp[(3 * (2 * c + t) + 2) * 64]);
+                HPL_SET(hb[c][t], bp[(3 * (2 * c + t)) * 64], bp[(3 * (2 * c + t) + 1) * 64], bp[(3 * (2 * c + t) + 2) * 64]);
             }
     }
     const bool row_ok = wave_ok && jr < mb;
@@ -912,21 +940,22 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     const int dst_r = (tid >> 3) * kRowB + (tid & 7) * 16;
     const int dst_c = 3 * kRPlaneB + (tid >> 2) * kColB + (tid & 3) * 16;
     uint4 gr0, gr1, gr2, gc0, gc1, gc2;
+    (void)gr1; (void)gc1;
     float gb = 0.f;
 #define CIRS_ISSUE(TILE0)                                                                                  \
     do {                                                                                                   \
         const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kPlaneTileU4 + tid;                      \
-        gr0 = src_[0]; gr1 = src_[256]; gr2 = src_[512]; gc0 = src_[768]; gc1 = src_[1024]; gc2 = src_[1280]; \
-        if (tid < kTileN) gb = ((TILE0) + tid) < I ? ba[(TILE0) + tid] : 0.f;                              \
+        gr0 = src_[0]; HPL_MID(gr1 = src_[256];) gr2 = src_[512]; gc0 = src_[768]; HPL_MID(gc1 = src_[1024];) gc2 = src_[1280]; \
+        if (tid < kTileN) gb = ((TILE0) + tid) < I ? kScZ * ba[(TILE0) + tid] : 0.f;   /* the accumulators hold kScZ z */ \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
         unsigned char* base_ = sW[BUF];                                                                    \
         *reinterpret_cast<uint4*>(base_ + dst_r) = gr0;                                                    \
-        *reinterpret_cast<uint4*>(base_ + kRPlaneB + dst_r) = gr1;                                         \
+        HPL_MID(*reinterpret_cast<uint4*>(base_ + kRPlaneB + dst_r) = gr1;)                                \
         *reinterpret_cast<uint4*>(base_ + 2 * kRPlaneB + dst_r) = gr2;                                     \
         *reinterpret_cast<uint4*>(base_ + dst_c) = gc0;                                                    \
-        *reinterpret_cast<uint4*>(base_ + kCPlaneB + dst_c) = gc1;                                         \
+        HPL_MID(*reinterpret_cast<uint4*>(base_ + kCPlaneB + dst_c) = gc1;)                                \
         *reinterpret_cast<uint4*>(base_ + 2 * kCPlaneB + dst_c) = gc2;                                     \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
@@ -1003,10 +1032,30 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
             v.h_ent[jr] = real ? rt.h_ent : 0.f;       // the reported entropy (dh2_sum_kernel: ent_row = h_ent + clamp correction)
         }
     }
-    const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
+    // f16x3: dZ is formed ALREADY SCALED by a power of two per workgroup -- its 128 rows' largest |c_logp| + 16 |c_ent| (a bound on |dZ|) lands in [2^13, 2^14) --
+    // so that its fp16 pieces are normal numbers; dH2 / dWa / dba are unscaled exactly where they leave the kernel.  bf16x6: the scale is 1.
+    float dz_scale = 1.0f, dz_inv = 1.0f;
+#if CIRS_HEAD_F16
+    __shared__ float s_cmax[kBwdWaves];
+    {
+        const float cm = wave_max_f32_dpp(fabsf(c_logp) + 16.0f * fabsf(c_ent));
+        if (lane == 0) s_cmax[wv] = cm;
+    }
+#endif
     CIRS_SSTAMP(31);
     if (n_tiles > 0) CIRS_COMMIT(0);
     __syncthreads();
+#if CIRS_HEAD_F16
+    {
+        float cm = s_cmax[0];
+#pragma unroll
+        for (int q = 1; q < kBwdWaves; ++q) cm = fmaxf(cm, s_cmax[q]);
+        int ex = 0;
+        if (cm > 0.f) { (void)frexpf(cm, &ex); ex = max(ex, -80); dz_scale = ldexpf(1.0f, 14 - ex); dz_inv = ldexpf(1.0f, ex - 14); }
+        c_logp *= dz_scale; c_ent *= dz_scale;
+    }
+#endif
+    const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
     CIRS_SSTAMP(32);
     float* slab = dwap + (size_t)blockIdx.y * dwa_slab_stride(I);
     // sum of the kBwdWaves partial dWa tiles of one item tile in wave order -> slab of this row block (coalesced float4 stores).
@@ -1014,6 +1063,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     // behind that tile's operand latency / matrix work instead of standing alone behind a second workgroup barrier.
     // two halves, so that the caller can put matrix work between them: the LDS reads of all partial tiles, then the adds + stores
     constexpr int kRedQ = (kTileN * kH / 4) / kThreads;
+    const float dw_unscale = dz_inv * (1.0f / kScH2), dh_unscale = dz_inv * (1.0f / kScWa);      // (exact powers of two; 1 in the bf16 form)
     struct RedRegs { f32x4 t[kRedQ][kBwdWaves]; float b[kBwdWaves]; };
     auto reduce_load = [&](int rb, RedRegs& rg) {
 #pragma unroll
@@ -1033,13 +1083,14 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
             f32x4 t = rg.t[q][0];
 #pragma unroll
             for (int w2 = 1; w2 < kBwdWaves; ++w2) t += rg.t[q][w2];
+            t *= dw_unscale;
             if (full || t0 + (f >> 4) < I) *reinterpret_cast<f32x4*>(slab + (size_t)t0 * kH + 4 * f) = t;
         }
         if (wv == 0) {
             float t = rg.b[0];
 #pragma unroll
             for (int w2 = 1; w2 < kBwdWaves; ++w2) t += rg.b[w2];
-            if (hi == 0 && (full || t0 + lo < I)) slab[(size_t)I * kH + t0 + lo] = t;
+            if (hi == 0 && (full || t0 + lo < I)) slab[(size_t)I * kH + t0 + lo] = t * dz_inv;
         }
     };
     auto reduce_tile = [&](int rb, int t0) { RedRegs rg; reduce_load(rb, rg); reduce_store(rg, t0); };
@@ -1057,23 +1108,21 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         if (wave_ok) {
             const unsigned char* tw = sW[buf];
             // every LDS operand of this tile up front: one latency exposure instead of one per k-step
-            Planes za[4], cb[2][2];
+            HPl za[4], cb[2][2];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const unsigned char* ap = tw + lo * kRowB + (16 * s4 + 8 * hi) * 2;
-                za[s4].h = *reinterpret_cast<const bf16x8*>(ap);
-                za[s4].m = *reinterpret_cast<const bf16x8*>(ap + kRPlaneB);
-                za[s4].l = *reinterpret_cast<const bf16x8*>(ap + 2 * kRPlaneB);
+                HPL_SET(za[s4], *reinterpret_cast<const uint4*>(ap), *reinterpret_cast<const uint4*>(ap + kRPlaneB), *reinterpret_cast<const uint4*>(ap + 2 * kRPlaneB));
             }
             f32x16 acc, acc1, acc2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = sB[buf][acc_row(r, hi)]; acc1[r] = 0.f; acc2[r] = 0.f; }
             CIRS_HSTAMP(1);
             // (acc: bias + the h*h terms, acc1 / acc2: the cross terms -- same split as head_stats_kernel, so that p = exp(z - lse) sums to one)
-            mfma_bf16x6_split2(za[0], hz[0], za[1], hz[1], acc, acc1, acc2);
+            hmfma_split2(za[0], hz[0], za[1], hz[1], acc, acc1, acc2);
             RedRegs rg;
             if (CIRS_BWD_REDUCE_POS == 0 && it > 0) reduce_load(buf ^ 1, rg);
-            mfma_bf16x6_split2(za[2], hz[2], za[3], hz[3], acc, acc1, acc2);
+            hmfma_split2(za[2], hz[2], za[3], hz[3], acc, acc1, acc2);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[r] += acc2[r];
             if (CIRS_BWD_REDUCE_POS == 0 && it > 0) reduce_store(rg, tile0 - kTileN);
@@ -1085,9 +1134,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const unsigned char* bp = tw + 3 * kRPlaneB + (32 * c + lo) * kColB + (16 * t + 8 * hi) * 2;
-                    cb[c][t].h = *reinterpret_cast<const bf16x8*>(bp);
-                    cb[c][t].m = *reinterpret_cast<const bf16x8*>(bp + kCPlaneB);
-                    cb[c][t].l = *reinterpret_cast<const bf16x8*>(bp + 2 * kCPlaneB);
+                    HPL_SET(cb[c][t], *reinterpret_cast<const uint4*>(bp), *reinterpret_cast<const uint4*>(bp + kCPlaneB), *reinterpret_cast<const uint4*>(bp + 2 * kCPlaneB));
                 }
             CIRS_HSTAMP(2);
             float* tt = sT[wv];
@@ -1108,7 +1155,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
             const bool last_tile = tile0 + kTileN > I;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float t0 = __builtin_fmaf(acc[r] + acc1[r], kLog2e, nlse2), t1 = __builtin_fmaf(acc[r + 1] + acc1[r + 1], kLog2e, nlse2);
+                const float t0 = __builtin_fmaf(acc[r] + acc1[r], kLog2e * kScZi, nlse2), t1 = __builtin_fmaf(acc[r + 1] + acc1[r + 1], kLog2e * kScZi, nlse2);
                 const float p0 = __builtin_amdgcn_exp2f(t0), p1 = __builtin_amdgcn_exp2f(t1);
                 tk[r] = t0; tk[r + 1] = t1;
                 pmax = __builtin_fmaxf(__builtin_fmaxf(pmax, p0), p1);      // v_max3_f32
@@ -1166,9 +1213,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
             if (CIRS_BWD_COMMIT_EARLY && it + 1 < n_tiles) CIRS_COMMIT(buf ^ 1);
             if (CIRS_BWD_REDUCE_POS == 1 && it > 0) reduce_load(buf ^ 1, rg);      // the previous tile's partial dWa tiles: their LDS round trip hides behind the dH2 product
             {
-                const Planes a0 = split8(acc, 0), a1 = split8(acc, 8);   // element j: dZ[row lo][item acc_row(8 t + j, hi)]
-                mfma_bf16x6_pair(a0, cb[0][0], cb[1][0], dh0, dh1);
-                mfma_bf16x6_pair(a1, cb[0][1], cb[1][1], dh0, dh1);
+                const HPl a0 = hsplit8(acc, 0), a1 = hsplit8(acc, 8);   // element j: dZ[row lo][item acc_row(8 t + j, hi)]
+                hmfma_pair(a0, cb[0][0], cb[1][0], dh0, dh1);
+                hmfma_pair(a1, cb[0][1], cb[1][1], dh0, dh1);
             }
             if (CIRS_BWD_REDUCE_POS == 1 && it > 0) reduce_store(rg, tile0 - kTileN);
             CIRS_HSTAMP(5);
@@ -1176,9 +1223,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dw0[r] = 0.f; dw1[r] = 0.f; db += dzt[r]; }
             {
-                const Planes b0 = split8(dzt, 0), b1 = split8(dzt, 8);   // element j: dZ[row acc_row(8 t + j, hi)][item lo]
-                mfma_bf16x6_pair(b0, hb[0][0], hb[1][0], dw0, dw1);
-                mfma_bf16x6_pair(b1, hb[0][1], hb[1][1], dw0, dw1);
+                const HPl b0 = hsplit8(dzt, 0), b1 = hsplit8(dzt, 8);   // element j: dZ[row acc_row(8 t + j, hi)][item lo]
+                hmfma_pair(b0, hb[0][0], hb[1][0], dw0, dw1);
+                hmfma_pair(b1, hb[0][1], hb[1][1], dw0, dw1);
             }
         }
         CIRS_HSTAMP(7);
@@ -1207,8 +1254,8 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + acc_row(r, hi);
-        hslab[(size_t)row * kH + lo] = dh0[r];
-        hslab[(size_t)row * kH + 32 + lo] = dh1[r];
+        hslab[(size_t)row * kH + lo] = dh0[r] * dh_unscale;
+        hslab[(size_t)row * kH + 32 + lo] = dh1[r] * dh_unscale;
     }
     ent += __shfl_xor(ent, 32, CIRS_WAVE);
     if (hi == 0) v.entp[(size_t)chunk * n_pad + jr] = ent;
@@ -2222,17 +2269,17 @@ __device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNex
         // hz: unit (k-step s = tid / 64, lane' = (hi', row)) = columns 16 s + 8 hi' .. + 8 of the row
         const int s4 = tid >> 6, hz_hi = (tid >> 5) & 1, hz_row = tid & 31;
         const float* r = t.h2 + hz_row * kTS + 16 * s4 + 8 * hz_hi;
-        const Planes pz = split8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        const HPl pz = hsplit8(kScH2 * r[0], kScH2 * r[1], kScH2 * r[2], kScH2 * r[3], kScH2 * r[4], kScH2 * r[5], kScH2 * r[6], kScH2 * r[7]);
         uint4* z = nx.out.h2z + (size_t)(tile * 12 + s4 * 3) * 64 + (tid & 63);
-        z[0] = __builtin_bit_cast(uint4, pz.h); z[64] = __builtin_bit_cast(uint4, pz.m); z[128] = __builtin_bit_cast(uint4, pz.l);
+        z[0] = __builtin_bit_cast(uint4, pz.h); HPL_MID(z[64] = hpl_mid(pz);) z[128] = __builtin_bit_cast(uint4, pz.l);
         // hb: unit (column half ch = tid / 128, t = (tid / 64) % 2, lane'' = (hi_b, column % 32)) = rows acc_row(8 t + jb, hi_b), jb < 8, of one column
         const int ch = tid >> 7, tt = (tid >> 6) & 1, hb_hi = (tid >> 5) & 1, col = 32 * ch + (tid & 31);
         float xb[8];
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) xb[jb] = t.h2[acc_row(8 * tt + jb, hb_hi) * kTS + col];
-        const Planes pb = split8(xb[0], xb[1], xb[2], xb[3], xb[4], xb[5], xb[6], xb[7]);
+        for (int jb = 0; jb < 8; ++jb) xb[jb] = kScH2 * t.h2[acc_row(8 * tt + jb, hb_hi) * kTS + col];
+        const HPl pb = hsplit8(xb[0], xb[1], xb[2], xb[3], xb[4], xb[5], xb[6], xb[7]);
         uint4* bq = nx.out.h2b + (size_t)(tile * 12 + (ch * 2 + tt) * 3) * 64 + (tid & 63);
-        bq[0] = __builtin_bit_cast(uint4, pb.h); bq[64] = __builtin_bit_cast(uint4, pb.m); bq[128] = __builtin_bit_cast(uint4, pb.l);
+        bq[0] = __builtin_bit_cast(uint4, pb.h); HPL_MID(bq[64] = hpl_mid(pb);) bq[128] = __builtin_bit_cast(uint4, pb.l);
     }
 }
 // P: thread = 8 consecutive elements of one head row (two float4: f = tid, tid + 256 of the tile's 512)
