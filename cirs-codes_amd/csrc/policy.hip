@@ -178,7 +178,7 @@ extern "C" int cirs_actor_sample(const cirs_policy_cfg* cfg, const cirs_policy_w
         const int cpw = mass_chunks_per_wg(nch, hg.n_row_blocks);
         uint4* planes = ws_rplanes(workspace, workspace_bytes, cfg->n_items);
         if (int rc = build_rplanes(w->wa, cfg->n_items, planes, s)) return rc;
-        hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg, (const uint4*)planes, w->ba, (const float*)h2, n,
+        hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(kMassThreads), 0, s, *cfg, (const uint4*)planes, w->ba, (const float*)h2, n,
                            env_ids, visited, skip, pv.m, n_pad, cpw, 0, 0);
         CIRS_CHECK_LAUNCH("actor_mass_kernel");
         PickArgs pa{pv.m, n_pad, nch, w->wa, w->ba, h2, visited, cfg->n_items, 0, 0, seed, rng_step};
@@ -233,7 +233,7 @@ extern "C" int cirs_actor_shard_partials(const cirs_policy_cfg* cfg_shard, const
     const int cpw = mass_chunks_per_wg(nch, hg.n_row_blocks);
     uint4* planes = ws_rplanes(workspace, workspace_bytes, cfg_shard->n_items);
     if (int rc = build_rplanes(w_shard->wa, cfg_shard->n_items, planes, s)) return rc;
-    hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(256), 0, s, *cfg_shard, (const uint4*)planes, w_shard->ba,
+    hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(nch, cpw), hg.n_row_blocks), dim3(kMassThreads), 0, s, *cfg_shard, (const uint4*)planes, w_shard->ba,
                        (const float*)h2, n, env_ids, visited, skip, pv.m, n_pad, cpw, item_base, n_items_total);
     CIRS_CHECK_LAUNCH("actor_mass_kernel");
     PickArgs pa{pv.m, n_pad, nch, w_shard->wa, w_shard->ba, h2, visited, cfg_shard->n_items, item_base, n_items_total, seed, rng_step};

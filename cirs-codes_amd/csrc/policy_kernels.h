@@ -363,6 +363,7 @@ static __global__ __launch_bounds__(256, 2) void actor_head_kernel(cirs_policy_c
 constexpr int kMassRowB = 144;                      // LDS row stride (bytes) of one plane of a staged tile: 64 fp16 + 16
 constexpr int kMassPlaneB = kTileN * kMassRowB;     // one plane of a tile in LDS
 constexpr int kMassTileU4 = 512;                    // uint4 per item tile in global memory
+constexpr int kMassThreads = 512;                    // workgroup of actor_mass_kernel: 4 row tiles x 2 tile halves
 constexpr float kMassScWa = 256.f, kMassScH2 = 64.f, kMassScZ = kMassScWa * kMassScH2, kMassScZi = 1.0f / kMassScZ;   // exact power-of-two prescales (ppo.hip: kScWa / kScH2)
 __host__ __device__ inline size_t ws_rplanes_bytes(int n_items) { return (size_t)n_chunks_of(n_items) * kTilesPerChunk * kMassTileU4 * 16; }
 
@@ -421,152 +422,203 @@ __device__ __forceinline__ float mass_log(float s) { return __builtin_amdgcn_log
 // stage timestamps of workgroup (0, 0) / wave 0 (probe builds only: tools/probes/mass_prof.py)
 static __device__ unsigned long long g_mass_prof[32];
 #define CIRS_MSTAMP(K) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_mass_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CIRS_MSTAMP_IF(COND, K) do { if ((COND) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_mass_prof[K] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CIRS_MSTAMP(K) do { } while (0)
+#define CIRS_MSTAMP_IF(COND, K) do { } while (0)
 #endif
-// grid = (ceil(n_chunks / chunks_per_wg), row blocks); 4 waves = 4 env row tiles walking the same chunks (shared staged tiles).
-static __global__ __launch_bounds__(256, 2) void actor_mass_kernel(cirs_policy_cfg cfg, const uint4* __restrict__ planes,
+// grid = (ceil(n_chunks / chunks_per_wg), row blocks); 8 waves = 4 env row tiles x 2 halves of a chunk's four item tiles (wave = (row tile wv & 3, half wv >> 2):
+// tiles 2 half, 2 half + 1).  Round 6, from stage stamps (tools/probes/mass_prof.py):
+//  * staging by CHUNK: the four plane tiles of the NEXT chunk (32 KB) are requested at the top of a chunk and committed to the other LDS buffer at its end -- one
+//    data barrier per chunk (tile-by-tile double buffering exposed a global-load latency per tile: a tile's MFMAs + operand reads are ~0.6 k cycles, a load under
+//    load 1.5-2 k; the kernel ran at 2.4 k cycles per tile);
+//  * two waves per SIMD: with one wave per SIMD the kernel was instruction-issue bound (~6 cycles per instruction: 3.1 k cycles for a chunk's 48 MFMAs + operand
+//    reads, 2.1 k for its maximum + 64 exponentials).  The two waves of a row tile split the chunk's tiles; what has an order -- the half-wave sums
+//    S_hi = ((0 + e(t0, r0)) + ... + e(t3, r15)) -- is handed from the first to the second through LDS, the maximum is order-free: the same bits as one wave
+//    walking all four tiles (and as actor_mass_small_kernel below).
+static __global__ __launch_bounds__(512, 1) void actor_mass_kernel(cirs_policy_cfg cfg, const uint4* __restrict__ planes,
                                                                    const float* __restrict__ ba, const float* __restrict__ h2, int n,
                                                                    const int32_t* __restrict__ env_ids,
                                                                    const uint32_t* __restrict__ visited,
                                                                    const uint8_t* __restrict__ skip, float* __restrict__ lmass,
                                                                    int n_pad, int chunks_per_wg, int item_base = 0,
                                                                    int n_items_total = 0, int env_base = 0, float* __restrict__ zstore = nullptr) {
-    __shared__ __attribute__((aligned(16))) unsigned char sW[2][2 * kMassPlaneB];
-    __shared__ __attribute__((aligned(16))) float sB[2][kTileN];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
+    __shared__ __attribute__((aligned(16))) unsigned char sW[2][kTilesPerChunk][2 * kMassPlaneB];
+    __shared__ __attribute__((aligned(16))) float sB[2][kChunkItems];   // 16-byte aligned: the accumulator init reads 4 consecutive biases as one ds_read_b128
+    __shared__ float sM[4][2][kTileM];      // [row tile][tile half][row]: the half's maximum
+    __shared__ float sS[4][2][kTileM];      // [row tile][lane half hi][row]: the first tile half's ordered half-wave sum
     const int tid = threadIdx.x;
     CIRS_MSTAMP(0);
     const int lane = tid & 63, wv = tid >> 6;
     const int hi = lane >> 5, lo = lane & 31;
-    const int row0 = (blockIdx.y * 4 + wv) * kTileM;
+    const int rt = wv & 3, th = wv >> 2;
+    const int row0 = (blockIdx.y * 4 + rt) * kTileM;
     const int I = cfg.n_items;
     const int I_tot = n_items_total > 0 ? n_items_total : I;
     const int vis_words = (I_tot + 31) / 32;
     const int n_chunks = n_chunks_of(I);
     const int c_begin = blockIdx.x * chunks_per_wg;
     const int c_end = min(n_chunks, c_begin + chunks_per_wg);
-    const int dst_r = (tid >> 3) * kMassRowB + (tid & 7) * 16;
-    uint4 g0 = {0u, 0u, 0u, 0u}, g1 = g0;
+    // staging: thread tid owns unit (plane tid / 256, v = tid % 256) of each of the chunk's four tiles
+    const int dst_r = (tid >> 8) * kMassPlaneB + ((tid & 255) >> 3) * kMassRowB + (tid & 7) * 16;
+    // (four NAMED registers: hipcc promotes an indexed array of prefetch registers to LDS -- the loads were followed by ds_write_b128s and their waits)
+    uint4 ga, gb4, gc, gd;
     float gb = 0.f;
-#define CIRS_ISSUE(TILE0)                                                                                  \
+    static_assert(kTilesPerChunk == 4, "the chunk staging names its four tiles");
+#define CIRS_ISSUE(CHUNK)                                                                                  \
     do {                                                                                                   \
-        const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kMassTileU4 + tid;                       \
-        g0 = src_[0]; g1 = src_[256];                                                                      \
-        if (tid < kTileN) gb = ((TILE0) + tid) < I ? kMassScZ * ba[(TILE0) + tid] : 0.f;                   \
+        const uint4* src_ = planes + (size_t)(CHUNK) * kTilesPerChunk * kMassTileU4 + tid;                 \
+        ga = src_[0]; gb4 = src_[kMassTileU4]; gc = src_[2 * kMassTileU4]; gd = src_[3 * kMassTileU4];     \
+        gb = ba[min((CHUNK) * kChunkItems + (tid & (kChunkItems - 1)), I - 1)];   /* unconditional, clamped: scaled / masked at the commit */ \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
-        unsigned char* base_ = sW[BUF];                                                                    \
-        *reinterpret_cast<uint4*>(base_ + dst_r) = g0;                                                     \
-        *reinterpret_cast<uint4*>(base_ + kMassPlaneB + dst_r) = g1;                                       \
-        if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
+        *reinterpret_cast<uint4*>(sW[BUF][0] + dst_r) = ga; *reinterpret_cast<uint4*>(sW[BUF][1] + dst_r) = gb4; \
+        *reinterpret_cast<uint4*>(sW[BUF][2] + dst_r) = gc; *reinterpret_cast<uint4*>(sW[BUF][3] + dst_r) = gd;  \
+        if (tid < kChunkItems) sB[BUF][tid] = gb_chunk * kChunkItems + tid < I ? kMassScZ * gb : 0.f;       \
     } while (0)
-    // the first tile's planes are requested before anything that waits (the skip flags behind `active`, the vote below): one memory
-    // round trip for both instead of two in a row
-    if (c_begin < c_end) CIRS_ISSUE(c_begin * kChunkItems);
+    // (hipcc: a prefetch issued under a condition -- even a uniform one -- is followed by its own s_waitcnt vmcnt(0) where the paths merge; the loads below are
+    //  therefore UNCONDITIONAL with clamped indices)
+    int gb_chunk = min(c_begin, n_chunks - 1);
+    CIRS_ISSUE(gb_chunk);
     const int jr = row0 + lo;
     const bool active = row0 < n_pad && jr < n && !(skip && skip[jr]);
     const bool wave_live = __ballot(active) != 0ull;
     const int e = active ? (env_ids ? env_ids[jr] : env_base + jr) : 0;
     Planes2 hz[4];
-    if (wave_live) {
-        // the wave's 32 x 64 tile of hidden rows is 8 KB of consecutive memory: read coalesced (8 x 1 KB), handed to the lanes through LDS
+    {
+        // a row tile's 32 x 64 hidden rows are 8 KB of consecutive memory: read coalesced by its first wave (8 x 1 KB), handed to the lanes of both its waves through LDS
         __shared__ __attribute__((aligned(16))) float sH[4][kTileM * kLdsStride];
         typedef float mass_v4 __attribute__((ext_vector_type(4)));
-        mass_v4* st4 = reinterpret_cast<mass_v4*>(sH[wv]);
-        mass_v4 t8[8];
+        if (th == 0 && wave_live) {
+            mass_v4* st4 = reinterpret_cast<mass_v4*>(sH[rt]);
+            mass_v4 t8[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = row0 + 4 * q + (lane >> 4);
-            t8[q] = r < n ? *reinterpret_cast<const mass_v4*>(h2 + (size_t)r * kH + (lane & 15) * 4) : mass_v4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 8; ++q) {
+                const int r = row0 + 4 * q + (lane >> 4);
+                t8[q] = r < n ? *reinterpret_cast<const mass_v4*>(h2 + (size_t)r * kH + (lane & 15) * 4) : mass_v4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) st4[(4 * q + (lane >> 4)) * (kLdsStride / 4) + (lane & 15)] = t8[q];
         }
+        __shared__ int s_any;
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        if (wave_live && lane == 0) s_any = 1;
+        __syncthreads();      // (also: the hidden tiles are visible to the second wave of every row tile)
+        CIRS_MSTAMP(1);
+        if (s_any == 0) {   // every env of this workgroup has finished: neutral masses, no arithmetic
+            if (th == 0 && row0 < n_pad && hi == 0)
+                for (int c = c_begin; c < c_end; ++c) lmass[(size_t)c * n_pad + jr] = -INFINITY;
+            return;
+        }
+        if (wave_live) {
+            mass_split_hidden(sH[rt], lo, hi, hz);
+        } else {
+            const pk4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) st4[(4 * q + (lane >> 4)) * (kLdsStride / 4) + (lane & 15)] = t8[q];
-        __builtin_amdgcn_wave_barrier();
-        mass_split_hidden(sH[wv], lo, hi, hz);
-    } else {
-        const pk4 z4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { hz[q].h = __builtin_bit_cast(f16x8, z4); hz[q].l = hz[q].h; }
+            for (int q = 0; q < 4; ++q) { hz[q].h = __builtin_bit_cast(f16x8, z4); hz[q].l = hz[q].h; }
+        }
     }
-    __shared__ int s_any;
-    if (tid == 0) s_any = 0;
-    __syncthreads();
-    if (wave_live && lane == 0) s_any = 1;
-    __syncthreads();
-    CIRS_MSTAMP(1);
-    if (s_any == 0) {   // every env of this workgroup has finished: neutral masses, no arithmetic
-        if (row0 < n_pad && hi == 0)
-            for (int c = c_begin; c < c_end; ++c) lmass[(size_t)c * n_pad + jr] = -INFINITY;
-        return;
-    }
-    if (c_begin < c_end) CIRS_COMMIT(0);
+    CIRS_COMMIT(0);
     __syncthreads();
     CIRS_MSTAMP(2);
     for (int c = c_begin; c < c_end; ++c) {
-        f32x16 acc[4];
-        uint32_t vis[4];
+        const int buf = (c - c_begin) & 1;
+        const bool more = c + 1 < c_end;
+        const bool stamp_it = c == c_begin + 1;     // (probe builds: the workgroup's second chunk)
+        CIRS_MSTAMP_IF(stamp_it, 15);
+        // the visited words of this wave's two tiles BEFORE the next chunk's planes: memory returns in order, so their wait does not cover the prefetch
+        uint32_t vis[2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {           // tile t of the chunk lives in buffer t & 1 (4 tiles per chunk: the parity carries over)
-            const int buf = t & 1;
-            const int tile0 = c * kChunkItems + t * kTileN;
-            const bool more = t < 3 || c + 1 < c_end;
-            if (more) CIRS_ISSUE(tile0 + kTileN);
-            if (wave_live) {
-                acc[t] = mass_logits_tile(sW[buf], sB[buf], hz, lo, hi);
-                vis[t] = (visited && active && tile0 < I) ? visited[(size_t)e * vis_words + ((item_base + tile0) >> 5)] : 0u;   // tiles beyond the catalogue: no word exists
-            }
-            CIRS_MSTAMP(3 + 2 * t);
-            if (more) CIRS_COMMIT(buf ^ 1);
-            __syncthreads();
-            CIRS_MSTAMP(4 + 2 * t);
+        for (int u = 0; u < 2; ++u) {
+            const int tile0 = c * kChunkItems + (2 * th + u) * kTileN;
+            vis[u] = (visited && active && tile0 < I) ? visited[(size_t)e * vis_words + ((item_base + tile0) >> 5)] : 0u;   // tiles beyond the catalogue: no word exists
         }
-        if (!wave_live) continue;
-        if (zstore && active) {      // the chunk's logits of this row as computed (before masking): item t * 32 + 8 q + 4 hi + (0..3) in one 16-byte store
-            float* zr = zstore + ((size_t)c * n_pad + jr) * kChunkItems + 4 * hi;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(zr + t * kTileN + 8 * q) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
-        }
-        // mask, chunk maximum over the lane pair, fixed-order sum of exponentials
+        gb_chunk = more ? c + 1 : c;       // (the last chunk re-requests itself: never committed)
+        CIRS_ISSUE(gb_chunk);
+        f32x16 acc[2];
         float mloc = -INFINITY;
-        if (!visited && (c + 1) * kChunkItems <= I) {     // whole chunk inside the catalogue, nothing masked: no per-element tests
+        if (wave_live) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int u = 0; u < 2; ++u) acc[u] = mass_logits_tile(sW[buf][2 * th + u], sB[buf] + (2 * th + u) * kTileN, hz, lo, hi);
+            CIRS_MSTAMP_IF(stamp_it, 3);
+            if (zstore && active) {      // the logits of this row as computed (before masking): item t * 32 + 8 q + 4 hi + (0..3) in one 16-byte store
+                float* zr = zstore + ((size_t)c * n_pad + jr) * kChunkItems + 4 * hi;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, acc[t][r]);
-        } else {
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(zr + (2 * th + u) * kTileN + 8 * q) = make_float4(acc[u][4 * q], acc[u][4 * q + 1], acc[u][4 * q + 2], acc[u][4 * q + 3]);
+            }
+            // mask, this half's maximum over the lane pair
+            if (!visited && (c + 1) * kChunkItems <= I) {     // whole chunk inside the catalogue, nothing masked: no per-element tests
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const int item = c * kChunkItems + t * kTileN + il;
-                    const bool valid = item < I && !((vis[t] >> (il & 31)) & 1u);
-                    acc[t][r] = valid ? acc[t][r] : -INFINITY;
-                    mloc = fmaxf(mloc, acc[t][r]);
-                }
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, acc[u][r]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int il = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int item = c * kChunkItems + (2 * th + u) * kTileN + il;
+                        const bool valid = item < I && !((vis[u] >> (il & 31)) & 1u);
+                        acc[u][r] = valid ? acc[u][r] : -INFINITY;
+                        mloc = fmaxf(mloc, acc[u][r]);
+                    }
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, CIRS_WAVE));
+            if (hi == 0) sM[rt][th][lo] = mloc;
         }
-        const float M = fmaxf(mloc, __shfl_xor(mloc, 32, CIRS_WAVE));
-        CIRS_MSTAMP(11);
-        float L = -INFINITY;
-        if (M > -INFINITY) {        // uniform over the lane pair (M is shared), evaluated by every lane that has a partner
-            const float nml = -M * 1.4426950408889634f;
-            float sl = 0.f;
+        lds_barrier();      // the halves' maxima
+        CIRS_MSTAMP_IF(stamp_it, 11);
+        float M = -INFINITY, sl = 0.f;
+        float ex[32];
+        if (wave_live) {
+            M = fmaxf(sM[rt][0][lo], sM[rt][1][lo]);
+            if (M > -INFINITY) {        // uniform over the lane pair and the wave pair (M is shared)
+                const float nml = -M * 1.4426950408889634f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sl += mass_exp(acc[t][r], nml);      // the sum keeps its element order (tile, r)
+                    for (int r = 0; r < 16; ++r) ex[16 * u + r] = mass_exp(acc[u][r], nml);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 32; ++q) ex[q] = 0.f;
+            }
+            if (th == 0) {              // the sum keeps its element order (tile, r): tiles 0, 1 here, the second wave continues with 2, 3
+#pragma unroll
+                for (int q = 0; q < 32; ++q) sl += ex[q];
+                sS[rt][hi][lo] = sl;
+            }
+        }
+        lds_barrier();      // the first half's ordered sum
+        CIRS_MSTAMP_IF(stamp_it, 12);
+        if (wave_live && th == 1) {
+            sl = sS[rt][hi][lo];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) sl += ex[q];
+            float L = -INFINITY;
             const float so = __shfl_xor(sl, 32, CIRS_WAVE);
-            CIRS_MSTAMP(12);
-            const float S = hi == 0 ? sl + so : so + sl;                          // S_hi0 + S_hi1, in that order on both lanes
-            L = M + mass_log(S);
+            if (M > -INFINITY) {
+                const float S = hi == 0 ? sl + so : so + sl;                          // S_hi0 + S_hi1, in that order on both lanes
+                L = M + mass_log(S);
+            }
+            if (row0 < n_pad && hi == 0) lmass[(size_t)c * n_pad + jr] = active ? L : -INFINITY;
         }
-        if (row0 < n_pad && hi == 0) lmass[(size_t)c * n_pad + jr] = active ? L : -INFINITY;
-        CIRS_MSTAMP(13);
+        CIRS_MSTAMP_IF(stamp_it, 13);
+        // (hipcc hoists the commit's LDS stores to right behind the loads -- before this chunk's arithmetic -- unless something pins them here: the first
+        //  build of this loop waited for all loads at the TOP of every chunk, 38 us per launch)
+        asm volatile("" ::: "memory");
+        if (more) {
+            CIRS_COMMIT(buf ^ 1);      // (last read one chunk ago: every wave has passed a barrier since)
+            __syncthreads();
+        }
+        CIRS_MSTAMP_IF(stamp_it, 14);
     }
+    CIRS_MSTAMP(16);
 #undef CIRS_ISSUE
 #undef CIRS_COMMIT
 }

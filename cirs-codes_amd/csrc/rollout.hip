@@ -285,7 +285,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                                                              pol_w->ba, (const float*)q.h2, q.n, (const uint32_t*)visited, done_all + q.base, q.pv.m, q.n_pad, q.base,
                                                              zstore));
             } else {       // counter-based sampler: chunk log-masses now, chunk + item draws in the tail of the step kernel
-                CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(n_mass_chunks, q.cpw), q.hg.n_row_blocks), dim3(256), 0,
+                CIRS_PROF_LAUNCH(3, q.st, hipLaunchKernelGGL(actor_mass_kernel, dim3(cdiv(n_mass_chunks, q.cpw), q.hg.n_row_blocks), dim3(kMassThreads), 0,
                                                              q.st, *pol_cfg, (const uint4*)rplanes, pol_w->ba, (const float*)q.h2, q.n, (const int32_t*)nullptr,
                                                              (const uint32_t*)visited, done_all + q.base, q.pv.m, q.n_pad, q.cpw, 0, 0, q.base, zstore));
             }

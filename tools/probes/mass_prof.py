@@ -17,10 +17,10 @@ wl = bench.WORKLOADS["c3"]
 eng, _ = bench.build_engine(wl, 0, 1, torch.device("cuda:0"))
 eng.rollout.force_length = wl["T"]
 lib = C.CDLL(abi.LIB_PATH)
-names = {0: "entry", 1: "hidden rows requested, 'any env alive' vote", 2: "first tile staged (global -> LDS, barrier)",
-         3: "tile 0: operand reads + 32 MFMAs", 4: "tile 0: commit next + barrier", 5: "tile 1: operand reads + 32 MFMAs", 6: "tile 1: commit + barrier",
-         7: "tile 2: operand reads + 32 MFMAs", 8: "tile 2: commit + barrier", 9: "tile 3: operand reads + 32 MFMAs", 10: "tile 3: commit + barrier",
-         11: "mask + chunk maximum", 12: "64 x det_expf_neg, sum", 13: "det_logf, store"}
+names = {0: "entry", 1: "hidden rows requested + split, 'any env alive' vote", 2: "first chunk staged (global -> LDS, barrier)",
+         15: "(first chunk) -> top of the SECOND chunk", 3: "next chunk requested; 4 tiles: operand reads + 48 MFMAs", 11: "mask + chunk maximum", 12: "64 x exp2, sum",
+         13: "log2, store", 14: "commit of the next chunk + barrier", 16: "(third chunk) -> kernel end"}
+order = [0, 1, 2, 15, 3, 11, 12, 13, 14, 16]
 acc = None
 for rep in range(6):
     eng.collect()
@@ -32,7 +32,7 @@ for rep in range(6):
         acc = t if acc is None else acc + t
 t = acc / 5
 prev = t[0]
-print("actor_mass_kernel, workgroup (0,0) wave 0, its (only) chunk at the LAST step of the rollout (raw s_memtime ticks):")
-for k in sorted(names):
-    print(f"  {names[k]:48s} {t[k] - prev:9.0f}   (cum {t[k] - t[0]:9.0f})")
+print("actor_mass_kernel, workgroup (0,0) wave 0 at the LAST step of the rollout (raw s_memtime ticks; the per-chunk stamps belong to its second chunk):")
+for k in order:
+    print(f"  {names[k]:60s} {t[k] - prev:9.0f}   (cum {t[k] - t[0]:9.0f})")
     prev = t[k]
