@@ -183,10 +183,12 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         const float* kc0_ = st.kcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
         const float* vc0_ = st.vcache + (((size_t)(LAYER) * B + e) * L) * kD;                                    \
         if constexpr (NHEAD == 4) {   /* lane = (head lane >> 4, slot lane & 15): this head's 8 key components of positions slot and slot + 16 */ \
-            const float4* kh_ = reinterpret_cast<const float4*>(kc0_) + (size_t)(2 * (lane >> 4)) * L + (lane & 15);    \
-            const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                  \
-            kpre[0] = (lane & 15) < pos ? kh_[0] : z4_;       kpre[1] = (lane & 15) < pos ? kh_[L] : z4_;        \
-            kpre[2] = (lane & 15) + 16 < pos ? kh_[16] : z4_; kpre[3] = (lane & 15) + 16 < pos ? kh_[L + 16] : z4_; \
+            /* UNCONDITIONAL loads of clamped positions (a conditional load is a branch + exec juggling per instruction: the 20 loads of this prefetch cost ~2 k cycles); */ \
+            /* positions >= pos are never used (the scores select on jp <= pos, the current position comes from LDS) */ \
+            const int pl_ = pos > 0 ? pos - 1 : 0;                                                               \
+            const float4* kh_ = reinterpret_cast<const float4*>(kc0_) + (size_t)(2 * (lane >> 4)) * L;           \
+            const int pa_ = min(lane & 15, pl_), pb_ = min((lane & 15) + 16, pl_);                               \
+            kpre[0] = kh_[pa_]; kpre[1] = kh_[L + pa_]; kpre[2] = kh_[pb_]; kpre[3] = kh_[L + pb_];               \
         } else {                                                                                                 \
         const float4* k4_ = reinterpret_cast<const float4*>(kc0_) + lane;   /* K cache: [d/4][L][4], see below */ \
         _Pragma("unroll") for (int q4 = 0; q4 < kD / 4; ++q4)                                                    \
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         }                                                                                                        \
         _Pragma("unroll") for (int u8 = 0; u8 < 16; ++u8) {                                                      \
             const int jp_ = (lane >> 5) + 2 * u8;                                                                \
-            vpre[u8] = jp_ < pos ? vc0_[(size_t)jp_ * kD + o32] : 0.f;                                           \
+            if constexpr (NHEAD == 4) vpre[u8] = vc0_[(size_t)min(jp_, pos > 0 ? pos - 1 : 0) * kD + o32];      /* unconditional, clamped: selected at use */ \
+            else vpre[u8] = jp_ < pos ? vc0_[(size_t)jp_ * kD + o32] : 0.f;                                      \
         }                                                                                                        \
     } while (0)
 #define CIRS_IN_PROJ_PREFETCH(LAYER)                                                                             \
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
                 for (int u = 0; u < 16; ++u) {
                     const int jp = half + 2 * u;
                     const float pv_ = pr[jp <= pos ? jp : pos];            // (clamped: a valid address whatever max_len is)
-                    acc = __builtin_fmaf(jp <= pos ? pv_ : 0.f, jp == pos ? vnow : vpre[u], acc);
+                    acc = __builtin_fmaf(jp <= pos ? pv_ : 0.f, jp < pos ? vpre[u] : (jp == pos ? vnow : 0.f), acc);      // (vpre beyond the prefix: a clamped re-read, never used)
                 }
                 for (int j0 = 32 + half; j0 <= pos; j0 += 16) {            // (episodes longer than 31 steps only) 8 cached rows per batch in flight together
                     float v8[8];
@@ -482,7 +485,8 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
             if (lane < kD) att[d] = acc * norm;
         }
         }
-        if (l + 1 < cfg.nlayers) CIRS_KV_PREFETCH(l + 1);
+        // (unconditional, the layer clamped: hipcc follows a prefetch issued under a condition -- even a uniform one -- with its own wait where the paths merge)
+        { const int ln_ = l + 1 < cfg.nlayers ? l + 1 : l; CIRS_KV_PREFETCH(ln_); }
         CIRS_STAMP(7 + 6 * l);
         // prefetch the feed-forward's first layer (two rows per lane) while out_proj + LayerNorm run
         const RowRegs<kD> pf0 = wrow<kD, IMG>(img, IL.l1_p[l], kHid, ly.lin1_w, kD, lane, 0);

@@ -2,6 +2,8 @@
    actions  <- C oracle actor_sample on the rollout's own states (bit-exact, same counter RNG)
    rew/done <- C oracle env step teacher-forced with the rollout's actions (done bit-exact, rew 1e-12)
    states   <- torch-fp32 tracker restatement on the rollout's actions/rewards (1e-4)"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -76,6 +78,12 @@ def check_rollout(U, I, B, T, seed, *, sync_every=None, **kw):
 def test_rollout_small():
     lengths = check_rollout(60, 150, 24, 12, seed=5, N=3, thr=1)
     assert lengths.min() < lengths.max()
+
+
+def test_rollout_ragged_env_counts():
+    """env counts that are not a multiple of the four envs of a step workgroup, long episodes (positions beyond the 32 the attention keeps in registers)"""
+    check_rollout(60, 150, 7, 12, seed=6, N=3, thr=1)
+    check_rollout(40, 90, 5, 40, seed=8, N=2, thr=8)
 
 
 def test_rollout_c2_shapes():
