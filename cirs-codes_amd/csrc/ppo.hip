@@ -193,34 +193,20 @@ __global__ __launch_bounds__(1024) void returns_kernel(cirs_ppo_cfg cfg, const d
 // minibatch: gather + advantage normalisation
 // ------------------------------------------------------------------------------------------------------------
 // ---- operand pieces of the actor-head kernels -----------------------------------------------------------------------------------------------------
-// CIRS_HEAD_F16 = 0: three bf16 pieces per operand, six MFMAs per 16 k ("bf16x6", rounds 2-5).  = 1 (round 6 experiment): TWO fp16 pieces per
-// operand, three MFMAs per 16 k ("f16x3", bf16x6.h), operands pre-scaled by exact powers of two so that both pieces stay in fp16's normal range: Wa by kScWa,
-// H2 by kScH2, dZ by a power of two per workgroup (its rows' largest coefficient -> 2^14); logits / dH2 / dWa are unscaled exactly where they leave the
-// accumulators.  The plane storage keeps its three-plane layout (the middle plane is unused in the fp16 form).
-#ifndef CIRS_HEAD_F16
-#define CIRS_HEAD_F16 1
-#endif
-#if CIRS_HEAD_F16
+// Since round 6 every product of the head kernels is an fp32 product from TWO fp16 pieces per operand, three MFMAs per 16 k ("f16x3", bf16x6.h; rounds 2-5:
+// three bf16 pieces, six MFMAs).  Operands are pre-scaled by exact powers of two so that both pieces stay in fp16's normal range: Wa by kScWa, H2 by kScH2, dZ
+// by a power of two per workgroup (its rows' largest coefficient -> [2^13, 2^14)); logits / dH2 / dWa are unscaled exactly where they leave the accumulators.
+// Measured against rounds 5's bf16x6 on one box: minibatch step 75.5 -> 69.8 us, head_bwd_fused_kernel 36.6 -> 31.4 us (rocprofv3), gradient error vs float64 at
+// torch-fp32's level in the sharp regime (tests/test_gpu_head_precision.py), golden bars used <= 0.10 (profiles/r06_margins_head_f16.json).
+// The plane storage keeps the three-plane tile layout of the earlier bf16 form (the middle plane is neither written nor read).
 typedef Planes2 HPl;
 constexpr float kScWa = 256.f, kScH2 = 64.f;
-#define HPL_SET(P, H, M, L) do { (P).h = __builtin_bit_cast(f16x8, H); (P).l = __builtin_bit_cast(f16x8, L); } while (0)
-#define HPL_MID(...)
+#define HPL_SET(P, H, L) do { (P).h = __builtin_bit_cast(f16x8, H); (P).l = __builtin_bit_cast(f16x8, L); } while (0)
 #define hsplit8 split8h
 #define hmfma_split2 mfma_f16x3_split2
 #define hmfma_pair mfma_f16x3_pair
-__device__ __forceinline__ uint4 hpl_mid(const HPl& p) { return __builtin_bit_cast(uint4, p.l); }
-#else
-typedef Planes HPl;
-constexpr float kScWa = 1.f, kScH2 = 1.f;
-#define HPL_SET(P, H, M, L) do { (P).h = __builtin_bit_cast(bf16x8, H); (P).m = __builtin_bit_cast(bf16x8, M); (P).l = __builtin_bit_cast(bf16x8, L); } while (0)
-#define HPL_MID(...) __VA_ARGS__
-#define hsplit8 split8
-#define hmfma_split2 mfma_bf16x6_split2
-#define hmfma_pair mfma_bf16x6_pair
-__device__ __forceinline__ uint4 hpl_mid(const HPl& p) { return __builtin_bit_cast(uint4, p.m); }
-#endif
 constexpr float kScZ = kScWa * kScH2, kScZi = 1.0f / kScZ;      // scale of the logits accumulators (bias pre-scaled at staging) and its inverse
-constexpr int kPlaneTileU4 = 1536;  // uint4 per item tile of the bf16 planes of Wa (wa_planes_kernel)
+constexpr int kPlaneTileU4 = 1536;  // uint4 per item tile of the fp16 planes of Wa (wa_planes_kernel)
 struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad rows)
     float *obs, *adv, *ret, *v_s, *logp_old;  // gathered
     int32_t* act;
@@ -237,8 +223,8 @@ struct MbView {  // contiguous minibatch arrays carved from the workspace (n_pad
     float *red;                               // [16] scalars: adv mean/std, loss sums, grad norm coef
     float *normp;                             // [256] sum-of-squares partials
     float *dwp;                               // weight-gradient slab partials
-    uint4 *wa_planes;                         // bf16 planes of Wa per item tile (wa_planes_kernel)
-    uint4 *h2z, *h2b;                         // bf16 planes of H2 in the head kernels' register order (written by trunk_adv_kernel):
+    uint4 *wa_planes;                         // fp16 planes of Wa per item tile (wa_planes_kernel)
+    uint4 *h2z, *h2b;                         // fp16 planes of H2 in the head kernels' register order (written by trunk_adv_kernel):
                                               // [32-row tile][12][lane] uint4, unit q of a lane = its q-th operand register quad
     int *sync;                                // [kSyncInts] arrival flags (see kSyncInts)
     void* head_ws;                            // workspace of the head kernel (h2 copy + partials)
@@ -494,7 +480,7 @@ __device__ __forceinline__ float dz_of(float z, float lse, float c_logp, float c
     return c_logp * ((is_act ? 1.0f : 0.0f) - p) + c_ent * p * (z - lse + h_ent);
 }
 
-// Wa as bf16 planes, per item tile of 32 (items beyond I are zero rows), 24576 B per tile:
+// Wa as fp16 planes, per item tile of 32 (items beyond I are zero rows), 24576 B per tile:
 //   [0, 12288)      row-major  R[p][item 32][col 64]    : A operand of Z^T = Wa H2^T (lane = item, 8 consecutive cols)
 //   [12288, 24576)  col-major  C[p][col 64][slot 32]    : B operand of dH2 = dZ Wa  (lane = col, 8 consecutive slots);
 //                   slot 16 t + 8 hi + j holds item acc_row(8 t + j, hi): the order in which the logit accumulators
@@ -520,7 +506,7 @@ __device__ __forceinline__ void wa_planes_from_lds(int tile, uint4* __restrict__
     {
         const float* r = &sw[(tid >> 3) * 65 + 8 * (tid & 7)];
         const HPl pl = hsplit8(kScWa * r[0], kScWa * r[1], kScWa * r[2], kScWa * r[3], kScWa * r[4], kScWa * r[5], kScWa * r[6], kScWa * r[7]);
-        out[tid] = __builtin_bit_cast(uint4, pl.h); HPL_MID(out[256 + tid] = hpl_mid(pl);) out[512 + tid] = __builtin_bit_cast(uint4, pl.l);
+        out[tid] = __builtin_bit_cast(uint4, pl.h); out[512 + tid] = __builtin_bit_cast(uint4, pl.l);
     }
     {
         const int n = tid >> 2, t = (tid >> 1) & 1, hi = tid & 1;
@@ -528,7 +514,7 @@ __device__ __forceinline__ void wa_planes_from_lds(int tile, uint4* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = kScWa * sw[acc_row(8 * t + j, hi) * 65 + n];
         const HPl pl = hsplit8(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
-        out[768 + tid] = __builtin_bit_cast(uint4, pl.h); HPL_MID(out[1024 + tid] = hpl_mid(pl);) out[1280 + tid] = __builtin_bit_cast(uint4, pl.l);
+        out[768 + tid] = __builtin_bit_cast(uint4, pl.h); out[1280 + tid] = __builtin_bit_cast(uint4, pl.l);
     }
 }
 
@@ -538,7 +524,7 @@ struct TrunkRowOut {
     float *h2, *value, *h1, *obs_copy;     // [n_pad, 64], [n_pad], [n_pad, 64], [n_pad, S]
     int32_t* act; long* dst;               // the row's action / its row of the [T+1, B] tracker-gradient tensor, in minibatch order
     float* row4;                           // [4][n_pad]: adv, logp_old, ret, v_s of the minibatch rows
-    uint4 *h2z, *h2b;                      // bf16 planes of H2 in the head kernels' register order
+    uint4 *h2z, *h2b;                      // fp16 planes of H2 in the head kernels' register order
 };
 // The weights as the row job reads them: the three matrices from LDS copies, the biases through `w` (global memory in trunk_adv_kernel, LDS in
 // adam_next_kernel, whose workgroups form the updated values themselves).
@@ -571,34 +557,25 @@ __device__ __forceinline__ void trunk_row_pre(int S, const TrunkRowIn& in, int j
         }
     }
 }
-// The head kernels want H2 as bf16 planes in THEIR register order (hz: the lane's row, 8 consecutive columns per register quad; hb: 8
+// The head kernels want H2 as fp16 planes in THEIR register order (hz: the lane's row, 8 consecutive columns per register quad; hb: 8
 // rows of one column per quad).  Splitting here, once per row, replaces an LDS round trip + 8 split8 per wavefront in the prologue of every
 // head workgroup (31 chunks x 8 row blocks re-split the same rows); each lane owns one element and drops its three 2-byte pieces
 // into both layouts (same arithmetic as split_pair: same bits).  a = h2[j][lane].
 __device__ __forceinline__ void trunk_row_planes(float a, int j, int lane, const TrunkRowOut& o) {
-#if CIRS_HEAD_F16
     a *= kScH2;
     const uint32_t hp = cvt_pk_f16(a, 0.f) & 0xffffu;
     const float r1 = a - (float)__builtin_bit_cast(f16x2_b, hp).x;
     const uint32_t lp = cvt_pk_f16(r1, 0.f) & 0xffffu;
-    const uint32_t mp = 0u;
-#else
-    const uint32_t hp = cvt_pk_bf16(a, 0.f) & 0xffffu;
-    const float r1 = a - __uint_as_float(hp << 16);
-    const uint32_t mp = cvt_pk_bf16(r1, 0.f) & 0xffffu;
-    const float r2 = r1 - __uint_as_float(mp << 16);
-    const uint32_t lp = cvt_pk_bf16(r2, 0.f) & 0xffffu;
-#endif
     const int tile = j >> 5, rr = j & 31, c = lane;
     // hz: k-step s = c / 16, lane half hi = (c / 8) & 1, element c & 7; the consumer's lane is (hi, lo = row)
     unsigned short* z = reinterpret_cast<unsigned short*>(o.h2z + ((size_t)(tile * 12 + (c >> 4) * 3) * 64 + ((c >> 3) & 1) * 32 + rr)) + (c & 7);
-    z[0] = (unsigned short)hp; z[64 * 8] = (unsigned short)mp; z[2 * 64 * 8] = (unsigned short)lp;
+    z[0] = (unsigned short)hp; z[2 * 64 * 8] = (unsigned short)lp;
     // hb[c / 32][t]: element jb of the consumer lane (hi_b, lo = c % 32), accumulator row rr = acc_row(8 t + jb, hi_b)
     const int hi_b = (rr >> 2) & 1, sb = (rr & 3) + 4 * (rr >> 3);
     unsigned short* bq = reinterpret_cast<unsigned short*>(o.h2b + ((size_t)(tile * 12 + ((c >> 5) * 2 + (sb >> 3)) * 3) * 64 + hi_b * 32 + (c & 31))) + (sb & 7);
-    bq[0] = (unsigned short)hp; bq[64 * 8] = (unsigned short)mp; bq[2 * 64 * 8] = (unsigned short)lp;
+    bq[0] = (unsigned short)hp; bq[2 * 64 * 8] = (unsigned short)lp;
 }
-// one minibatch row by one wavefront: trunk (the rollout's fma chains), the gathered row scalars, H2 as bf16 planes
+// one minibatch row by one wavefront: trunk (the rollout's fma chains), the gathered row scalars, H2 as fp16 planes
 __device__ __forceinline__ void trunk_row_job(const cirs_policy_cfg& cfg, const cirs_policy_weights& w, const TrunkLds& L, const TrunkRowIn& in, int j, int mb,
                                               int n_pad, int lane, float* xs, float* hs, const cirs_ppo_batch& bt, int n_env, const TrunkRowOut& o) {
     trunk_row_pre(cfg.dim_state, in, j, mb, n_pad, lane, xs, bt, n_env, o);
@@ -608,7 +585,7 @@ __device__ __forceinline__ void trunk_row_job(const cirs_policy_cfg& cfg, const 
 // First launch of a stand-alone minibatch step, three independent jobs by workgroup index:
 //   [0, n_row_wgs)                trunk forward of the minibatch rows (same fma chains as the rollout)
 //   n_row_wgs                     advantage statistics of the (global) minibatch
-//   (n_row_wgs, n_row_wgs + tiles] bf16 planes of one Wa item tile (operands of the two head kernels)
+//   (n_row_wgs, n_row_wgs + tiles] fp16 planes of one Wa item tile (operands of the two head kernels)
 // Inside cirs_ppo_learn's loop only the first step of an update needs it: adam_next_kernel does the same three jobs for the step after it.
 __global__ __launch_bounds__(256) void trunk_adv_kernel(cirs_policy_cfg cfg, cirs_policy_weights w, const float* __restrict__ obs_flat,
                                                         long stride, int n_pad, const int32_t* __restrict__ idx, int mb,
@@ -667,7 +644,7 @@ constexpr int kRowB = 144, kColB = 80;       // LDS row strides (bytes) of the R
 constexpr int kRPlaneB = kTileN * kRowB, kCPlaneB = kH * kColB;
 constexpr int kWBufB = 3 * kRPlaneB + 3 * kCPlaneB;
 
-// ---- head statistics (forward): log-sum-exp and sum exp(z - m) z per row, bf16x6 logits ---------------------------
+// ---- head statistics (forward): log-sum-exp and sum exp(z - m) z per row, f16x3 logits ---------------------------
 // grid = (n_chunks, ceil(n_pad/32/4)); workgroup = 4 waves = 4 row tiles walking the item tiles of one chunk; the R planes
 // of a Wa tile (12 KB) are staged once per workgroup, double-buffered.  Output: the per-chunk partials (m, s, t) of each
 // row in the ActorPartialView arrays (score = t), merged by head_stats_merge_kernel.
@@ -709,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
         const uint4* zp = h2z + (size_t)((wave_ok ? row0 : 0) >> 5) * 12 * 64 + lane;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            HPL_SET(hz[s4], zp[(3 * s4) * 64], zp[(3 * s4 + 1) * 64], zp[(3 * s4 + 2) * 64]);
+            HPL_SET(hz[s4], zp[(3 * s4) * 64], zp[(3 * s4 + 2) * 64]);
         }
     }
     float run_m = -INFINITY, run_s = 0.f, run_t = 0.f;
@@ -721,19 +698,19 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
     const int first_tile = chunk * tiles_per_chunk * kTileN;
     const int n_tiles = max(0, min(tiles_per_chunk, (I - first_tile + kTileN - 1) / kTileN));
     const int dst_r = (tid >> 3) * kRowB + (tid & 7) * 16;
-    uint4 g0, g1, g2;
+    uint4 g0, g2;
     float gb = 0.f;
 #define CIRS_ISSUE(TILE0)                                                                                  \
     do {                                                                                                   \
         const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kPlaneTileU4 + tid;                      \
-        g0 = src_[0]; HPL_MID(g1 = src_[256];) g2 = src_[512];                                             \
+        g0 = src_[0]; g2 = src_[512];                                             \
         if (tid < kTileN) gb = ((TILE0) + tid) < I ? kScZ * ba[(TILE0) + tid] : 0.f;   /* the accumulators hold kScZ z */ \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
         unsigned char* base_ = sW[BUF];                                                                    \
         *reinterpret_cast<uint4*>(base_ + dst_r) = g0;                                                     \
-        HPL_MID(*reinterpret_cast<uint4*>(base_ + kRPlaneB + dst_r) = g1;)                                 \
+        \
         *reinterpret_cast<uint4*>(base_ + 2 * kRPlaneB + dst_r) = g2;                                      \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
@@ -752,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const unsigned char* ap = tw + lo * kRowB + (16 * s4 + 8 * hi) * 2;
-                HPL_SET(za[s4], *reinterpret_cast<const uint4*>(ap), *reinterpret_cast<const uint4*>(ap + kRPlaneB), *reinterpret_cast<const uint4*>(ap + 2 * kRPlaneB));
+                HPL_SET(za[s4], *reinterpret_cast<const uint4*>(ap), *reinterpret_cast<const uint4*>(ap + 2 * kRPlaneB));
             }
             f32x16 acc, accs, acct;      // bias + the h*h terms | the cross terms, two chains (bf16x6.h: the logits round once per k-step at their own magnitude)
 #pragma unroll
@@ -830,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 // ---- head backward (fused): dWa, dba, d h2, entropy correction ------------------------------------------------
 // grid = (n_chunks, ceil(n_pad/32/kBwdWaves)), ONE workgroup per CU; workgroup = kBwdWaves waves = that many ROW tiles
 // walking the item tiles of one chunk.  Per (row tile, item tile) the logits are recomputed ONCE; all three products run
-// as bf16x6 (above):
+// as f16x3 products (bf16x6.h):
 //   ZT[32 items x 32 rows] = Wa_tile * H2_tile^T             (A = Wa planes R from LDS, B = this lane's H2 row, registers)
 //   dZ in place (lane owns a ROW: its lse / coefficients / action are scalars)
 //   dH2_tile[32 rows x 64] += dZ[rows x items] * Wa_tile      (A = the dZT registers split in place, B = Wa planes C, LDS)
@@ -850,23 +827,6 @@ __global__ __launch_bounds__(256, 2) void head_stats_kernel(int I, int mb, int n
 #ifndef CIRS_BWD_REDUCE_POS
 #define CIRS_BWD_REDUCE_POS 0     // where the previous tile's dWa sum runs: 0 around the second logits MFMA group, 1 around the dH2 product
 #endif
-// logits of one tile as TWO independent accumulator chains (k-steps {0, 1} on the bias, {2, 3} on zero), issued alternately: a
-// dependent bf16 MFMA waits ~8 cycles for its predecessor, an independent one issues back to back
-__device__ __forceinline__ void mfma_bf16x6_two(const Planes& a0, const Planes& b0, f32x16& c0, const Planes& a1, const Planes& b1, f32x16& c1) {
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b0.h, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.l, b1.h, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.l, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.l, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b0.m, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b1.m, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b0.h, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b1.h, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.m, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.m, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.h, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.h, c1, 0, 0, 0);
-}
-
 // kEnt: the entropy term of dZ is compiled in (ent_coef != 0); the reference's scripts train with ent_coef = 0 (CIRS-RL-kuaishou.py:97),
 // where dZ = c_logp (delta - p) and the entropy is only reported.
 // kMerge: the merge of the head-statistics partials and the row's loss terms / backward coefficients run in THIS kernel's prologue (every
@@ -914,13 +874,13 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         const uint4* bp = v.h2b + tb;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            HPL_SET(hz[s4], zp[(3 * s4) * 64], zp[(3 * s4 + 1) * 64], zp[(3 * s4 + 2) * 64]);
+            HPL_SET(hz[s4], zp[(3 * s4) * 64], zp[(3 * s4 + 2) * 64]);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                HPL_SET(hb[c][t], bp[(3 * (2 * c + t)) * 64], bp[(3 * (2 * c + t) + 1) * 64], bp[(3 * (2 * c + t) + 2) * 64]);
+                HPL_SET(hb[c][t], bp[(3 * (2 * c + t)) * 64], bp[(3 * (2 * c + t) + 2) * 64]);
             }
     }
     const bool row_ok = wave_ok && jr < mb;
@@ -939,23 +899,22 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     // staging: unit `tid` of each of the six planes; destination offsets inside a buffer
     const int dst_r = (tid >> 3) * kRowB + (tid & 7) * 16;
     const int dst_c = 3 * kRPlaneB + (tid >> 2) * kColB + (tid & 3) * 16;
-    uint4 gr0, gr1, gr2, gc0, gc1, gc2;
-    (void)gr1; (void)gc1;
+    uint4 gr0, gr2, gc0, gc2;
     float gb = 0.f;
 #define CIRS_ISSUE(TILE0)                                                                                  \
     do {                                                                                                   \
         const uint4* src_ = planes + (size_t)((TILE0) / kTileN) * kPlaneTileU4 + tid;                      \
-        gr0 = src_[0]; HPL_MID(gr1 = src_[256];) gr2 = src_[512]; gc0 = src_[768]; HPL_MID(gc1 = src_[1024];) gc2 = src_[1280]; \
+        gr0 = src_[0]; gr2 = src_[512]; gc0 = src_[768]; gc2 = src_[1280]; \
         if (tid < kTileN) gb = ((TILE0) + tid) < I ? kScZ * ba[(TILE0) + tid] : 0.f;   /* the accumulators hold kScZ z */ \
     } while (0)
 #define CIRS_COMMIT(BUF)                                                                                   \
     do {                                                                                                   \
         unsigned char* base_ = sW[BUF];                                                                    \
         *reinterpret_cast<uint4*>(base_ + dst_r) = gr0;                                                    \
-        HPL_MID(*reinterpret_cast<uint4*>(base_ + kRPlaneB + dst_r) = gr1;)                                \
+        \
         *reinterpret_cast<uint4*>(base_ + 2 * kRPlaneB + dst_r) = gr2;                                     \
         *reinterpret_cast<uint4*>(base_ + dst_c) = gc0;                                                    \
-        HPL_MID(*reinterpret_cast<uint4*>(base_ + kCPlaneB + dst_c) = gc1;)                                \
+        \
         *reinterpret_cast<uint4*>(base_ + 2 * kCPlaneB + dst_c) = gc2;                                     \
         if (tid < kTileN) sB[BUF][tid] = gb;                                                               \
     } while (0)
@@ -1033,19 +992,16 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         }
     }
     // f16x3: dZ is formed ALREADY SCALED by a power of two per workgroup -- its 128 rows' largest |c_logp| + 16 |c_ent| (a bound on |dZ|) lands in [2^13, 2^14) --
-    // so that its fp16 pieces are normal numbers; dH2 / dWa / dba are unscaled exactly where they leave the kernel.  bf16x6: the scale is 1.
+    // so that its fp16 pieces are normal numbers; dH2 / dWa / dba are unscaled exactly where they leave the kernel.
     float dz_scale = 1.0f, dz_inv = 1.0f;
-#if CIRS_HEAD_F16
     __shared__ float s_cmax[kBwdWaves];
     {
         const float cm = wave_max_f32_dpp(fabsf(c_logp) + 16.0f * fabsf(c_ent));
         if (lane == 0) s_cmax[wv] = cm;
     }
-#endif
     CIRS_SSTAMP(31);
     if (n_tiles > 0) CIRS_COMMIT(0);
     __syncthreads();
-#if CIRS_HEAD_F16
     {
         float cm = s_cmax[0];
 #pragma unroll
@@ -1054,7 +1010,6 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
         if (cm > 0.f) { (void)frexpf(cm, &ex); ex = max(ex, -80); dz_scale = ldexpf(1.0f, 14 - ex); dz_inv = ldexpf(1.0f, ex - 14); }
         c_logp *= dz_scale; c_ent *= dz_scale;
     }
-#endif
     const float nlse2 = -(lse * kLog2e), ncl = -c_logp;   // p = exp2(z log2e - lse log2e); padded rows: lse = 1e30 -> p = 0
     CIRS_SSTAMP(32);
     float* slab = dwap + (size_t)blockIdx.y * dwa_slab_stride(I);
@@ -1063,7 +1018,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
     // behind that tile's operand latency / matrix work instead of standing alone behind a second workgroup barrier.
     // two halves, so that the caller can put matrix work between them: the LDS reads of all partial tiles, then the adds + stores
     constexpr int kRedQ = (kTileN * kH / 4) / kThreads;
-    const float dw_unscale = dz_inv * (1.0f / kScH2), dh_unscale = dz_inv * (1.0f / kScWa);      // (exact powers of two; 1 in the bf16 form)
+    const float dw_unscale = dz_inv * (1.0f / kScH2), dh_unscale = dz_inv * (1.0f / kScWa);      // (exact powers of two)
     struct RedRegs { f32x4 t[kRedQ][kBwdWaves]; float b[kBwdWaves]; };
     auto reduce_load = [&](int rb, RedRegs& rg) {
 #pragma unroll
@@ -1112,7 +1067,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const unsigned char* ap = tw + lo * kRowB + (16 * s4 + 8 * hi) * 2;
-                HPL_SET(za[s4], *reinterpret_cast<const uint4*>(ap), *reinterpret_cast<const uint4*>(ap + kRPlaneB), *reinterpret_cast<const uint4*>(ap + 2 * kRPlaneB));
+                HPL_SET(za[s4], *reinterpret_cast<const uint4*>(ap), *reinterpret_cast<const uint4*>(ap + 2 * kRPlaneB));
             }
             f32x16 acc, acc1, acc2;
 #pragma unroll
@@ -1134,7 +1089,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 1) void head_bwd_fused_kernel(int I
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const unsigned char* bp = tw + 3 * kRPlaneB + (32 * c + lo) * kColB + (16 * t + 8 * hi) * 2;
-                    HPL_SET(cb[c][t], *reinterpret_cast<const uint4*>(bp), *reinterpret_cast<const uint4*>(bp + kCPlaneB), *reinterpret_cast<const uint4*>(bp + 2 * kCPlaneB));
+                    HPL_SET(cb[c][t], *reinterpret_cast<const uint4*>(bp), *reinterpret_cast<const uint4*>(bp + 2 * kCPlaneB));
                 }
             CIRS_HSTAMP(2);
             float* tt = sT[wv];
@@ -2072,7 +2027,7 @@ __global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p, const
 //   [0, n_a0)           A0: Adam on [trunk | wc | bc], one element per thread, the parameters written through + an arrival count (what T waits for)
 //   next n_t            T: trunk forward of 32 rows of the next minibatch on the updated trunk (waits for A0, reads 22 KB)
 //   next n_s            S: advantage statistics of the next minibatch (no dependency on the update)
-//   next n_p            P: Adam on one 32-item tile of Wa (8 consecutive elements of a head row per thread) + the tile's bf16 planes from
+//   next n_p            P: Adam on one 32-item tile of Wa (8 consecutive elements of a head row per thread) + the tile's fp16 planes from
 //                          the updated registers (what wa_planes_block re-read from memory)
 //   rest                A: Adam on ba; the first one reduces the loss terms and publishes them
 // Without a next step (n_t = n_s = 0) it is the step's Adam launch and nothing else.
@@ -2128,7 +2083,7 @@ struct AdamLds {
 //   Both layers run on the fp32 matrix cores: D[feature][row] = W X^T as v_mfma_f32_32x32x2_f32 k-steps in ascending k from the bias -- bit for bit the
 //   sequential fma chain of trunk_compute (MI355X_MICROARCH.md: the fp32 MFMA is an fma chain; the lane with hi = 0 supplies k = 2 s, hi = 1
 //   k = 2 s + 1), so the rows equal what trunk_adv_kernel / the rollout compute.  Waves 0, 1 own one 32-feature tile each; the critic chains run
-//   one row per lane; the outputs leave as whole tiles (coalesced float4 rows, H2's bf16 planes as 16-byte units of the head kernels' layout).
+//   one row per lane; the outputs leave as whole tiles (coalesced float4 rows, H2's fp16 planes as 16-byte units of the head kernels' layout).
 constexpr int kTS = kH + 1;          // LDS row stride of the T role's tiles (odd: lane = row reads are conflict-free)
 struct TrunkTileLds {                // overlays AdamLds::lt
     float w2[kH * kTS];
@@ -2271,7 +2226,7 @@ __device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNex
         const float* r = t.h2 + hz_row * kTS + 16 * s4 + 8 * hz_hi;
         const HPl pz = hsplit8(kScH2 * r[0], kScH2 * r[1], kScH2 * r[2], kScH2 * r[3], kScH2 * r[4], kScH2 * r[5], kScH2 * r[6], kScH2 * r[7]);
         uint4* z = nx.out.h2z + (size_t)(tile * 12 + s4 * 3) * 64 + (tid & 63);
-        z[0] = __builtin_bit_cast(uint4, pz.h); HPL_MID(z[64] = hpl_mid(pz);) z[128] = __builtin_bit_cast(uint4, pz.l);
+        z[0] = __builtin_bit_cast(uint4, pz.h); z[128] = __builtin_bit_cast(uint4, pz.l);
         // hb: unit (column half ch = tid / 128, t = (tid / 64) % 2, lane'' = (hi_b, column % 32)) = rows acc_row(8 t + jb, hi_b), jb < 8, of one column
         const int ch = tid >> 7, tt = (tid >> 6) & 1, hb_hi = (tid >> 5) & 1, col = 32 * ch + (tid & 31);
         float xb[8];
@@ -2279,7 +2234,7 @@ __device__ __forceinline__ void adam_next_trunk(const AdamArgs& a, const AdamNex
         for (int jb = 0; jb < 8; ++jb) xb[jb] = kScH2 * t.h2[acc_row(8 * tt + jb, hb_hi) * kTS + col];
         const HPl pb = hsplit8(xb[0], xb[1], xb[2], xb[3], xb[4], xb[5], xb[6], xb[7]);
         uint4* bq = nx.out.h2b + (size_t)(tile * 12 + (ch * 2 + tt) * 3) * 64 + (tid & 63);
-        bq[0] = __builtin_bit_cast(uint4, pb.h); HPL_MID(bq[64] = hpl_mid(pb);) bq[128] = __builtin_bit_cast(uint4, pb.l);
+        bq[0] = __builtin_bit_cast(uint4, pb.h); bq[128] = __builtin_bit_cast(uint4, pb.l);
     }
 }
 // P: thread = 8 consecutive elements of one head row (two float4: f = tid, tid + 256 of the tile's 512)
@@ -2608,7 +2563,7 @@ static PpoRun ppo_run(const cirs_ppo_cfg* cfg, float* params, float* grads, floa
 static cirs::TrunkRowOut trunk_out_of(const cirs::MbView& v) { return cirs::TrunkRowOut{v.h2, v.value, v.h1, v.obs, v.act, v.dst_row, v.adv, v.h2z, v.h2b}; }
 
 // 1+2. advantage statistics of the (global) minibatch, the trunk forward (same fma chains as the rollout -> ratio == 1 exactly while the
-//      weights are unchanged; rows gathered from the buffer-order batch through idx, v.obs keeps the copy for d W1) and the bf16 planes of Wa
+//      weights are unchanged; rows gathered from the buffer-order batch through idx, v.obs keeps the copy for d W1) and the fp16 planes of Wa
 static int launch_trunk_adv(const PpoRun& r, const PpoStep& st) {
     using namespace cirs;
     const int n_pad = n_pad_of(st.mb);
@@ -2626,7 +2581,7 @@ static int launch_head(const PpoRun& r, const PpoStep& st, int* n_bchunks_out, b
     const MbView& v = r.v;
     ActorPartialView pv = partial_view(v.head_ws, n_pad, I);
     const int n_item_tiles = cdiv(I, kTileN);
-    // head statistics (log-sum-exp, E_p[z]) on the matrix cores from the bf16 planes of Wa; all workgroups co-resident (2 per CU) with equal tile counts
+    // head statistics (log-sum-exp, E_p[z]) on the matrix cores from the fp16 planes of Wa; all workgroups co-resident (2 per CU) with equal tile counts
     const int tpc_s = head_tiles_per_chunk(n_item_tiles, n_slabs, 2);   // measured: 1 / 2 / 3 workgroups per CU = 17.4 / 14.5 / 16.7 us
     const int n_schunks = cdiv(n_item_tiles, tpc_s);   // <= n_chunks: the partial arrays fit
     CIRS_PROF_LAUNCH(2, r.s, hipLaunchKernelGGL(head_stats_kernel, dim3(n_schunks, n_slabs), dim3(256), 0, r.s, I, mb, n_pad, tpc_s,
