@@ -632,7 +632,7 @@ def main():
             "metric": "simulator env-steps/s (collect + PPO update in the timed region), KuaishouEnv",
             "value": total_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (policy/tracker; rollout on the fp32 MFMA, PPO head products fp32-accurate from 3 bf16 pieces per operand on the bf16 MFMA, fp32 accumulate) + f64 (env rewards, GAE)", "data": "synthetic",
+            "dtype": "f32 (policy/tracker; rollout on the fp32 MFMA, PPO head products fp32-accurate from two fp16 pieces per operand (3 f16 MFMAs per product), fp32 accumulate) + f64 (env rewards, GAE)", "data": "synthetic",
             "config": {"workload": wl["name"], "envs_total": wl["B"] * world,
                        "learner": args.learner if world > 1 else "single", "tracker_backward": eng.tracker_backward if world > 1 else "single",
                        "global_minibatch": G, "minibatch_steps_per_update": mb_steps / args.steps,
@@ -655,15 +655,15 @@ def main():
             "ppo_minibatch_steps_per_s": mb_steps / elapsed, "rank_parameters_bit_identical": ranks_identical,
             "rollout_only_env_steps_per_s": n_ro / t_ro, "rollout_only_ms_per_collect": 1e3 * t_ro,
             "update_only_ms": 1e3 * (tc - tb), "update_minibatch_steps": int(l2.shape[0]),
-            "roofline": {"bound": "mfma", "kernel": "head_bwd_fused_kernel (PPO minibatch step: fused actor-head backward; fp32 products as 3 bf16 pieces per operand on v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+            "roofline": {"bound": "mfma", "kernel": "head_bwd_fused_kernel (PPO minibatch step: fused actor-head backward; fp32 products from two fp16 pieces per operand = 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)",
                          "achieved": flop_bwd / t_bwd / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": flop_bwd / t_bwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          "achieved_executed": exec_bwd / t_bwd / 1e12, "frac_executed": exec_bwd / t_bwd / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          "algorithmic_flop_per_launch": flop_bwd, "traffic": None, "seconds_per_launch": t_bwd, "rows": mb,
                          "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (cirs_prof_start/stop)",
                          "kernel_note": "since round 3 the kernel's prologue also merges the head-statistics partials of its rows and forms their loss terms / backward coefficients (~2.5 us that replace a 6.5 us launch): its duration includes that work, the algorithmic flop count does not",
-                         "peak_note": "fp32 MFMA dense peak: the kernel's results are fp32-accurate (DESIGN.md section 4); its 6x expanded bf16 flops are exec_bf16_flop_per_launch",
-                         "exec_bf16_flop_per_launch": 6.0 * exec_bwd},
+                         "peak_note": "fp32 MFMA dense peak: the kernel's results are fp32-accurate (DESIGN.md section 4); its 3x expanded f16 flops are exec_f16_flop_per_launch",
+                         "exec_f16_flop_per_launch": 3.0 * exec_bwd},
             "minibatch_step": {"seconds": t_mb, "launches": len(MINIBATCH_KERNELS), "algorithmic_flop": flop_step, "achieved": flop_step / t_mb / 1e12,
                                "achieved_executed": exec_step / t_mb / 1e12, "frac": flop_step / t_mb / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "traffic": None,

@@ -98,6 +98,7 @@ class DeviceTracker:
         self.kcache = torch.zeros((nlayers, B, L, D), dtype=torch.float32, device=dev)
         self.vcache = torch.zeros((nlayers, B, L, D), dtype=torch.float32, device=dev)
         self.len = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._bws = None       # workspace of backward() / prefix_states(), allocated on first use
         self.st = abi.TrackerState(x_hist=self.x_hist.data_ptr(), kcache=self.kcache.data_ptr(),
                                    vcache=self.vcache.data_ptr(), len=self.len.data_ptr())
         self._lib = abi.lib()

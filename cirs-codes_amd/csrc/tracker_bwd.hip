@@ -8,6 +8,7 @@
 // matters is that everything stays on device and every reduction has a fixed order.
 //   weight gradients : chunk-partial sums over 256-row chunks, then an ordered sum over chunks (two launches)
 //   embedding tables : per-row contributions, then one wavefront per table row sums its rows in a fixed order
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 #include "small_gemm.h"
 #include "rng.h"
@@ -287,8 +288,9 @@ template <int NH> struct EpGeo {
     static constexpr int HD = tD / NH;
     static constexpr int DPL = HPL * HD;            // dims per lane
     __host__ __device__ static constexpr int strip(int Lp) { return (HPL * Lp) | 1; }   // odd stride between queries: conflict-free both ways
-    __host__ __device__ static constexpr size_t fwd_floats(int Lp) { return (size_t)Lp * 64 + (size_t)NW * (Lp + 1) * strip(Lp); }
-    __host__ __device__ static constexpr size_t bwd_floats(int Lp) { return (size_t)Lp * 128 + (size_t)NW * (Lp + 1) * strip(Lp) + 2 * (size_t)NH * Lp; }
+    __host__ __device__ static constexpr size_t keep_words(int Lp) { return 2 * (size_t)NH * Lp; }      // dropout keep bits: [query][head] x 64 keys
+    __host__ __device__ static constexpr size_t fwd_floats(int Lp) { return (size_t)Lp * 64 + (size_t)NW * (Lp + 1) * strip(Lp) + keep_words(Lp); }
+    __host__ __device__ static constexpr size_t bwd_floats(int Lp) { return (size_t)Lp * 128 + (size_t)NW * (Lp + 1) * strip(Lp) + 2 * (size_t)NH * Lp + keep_words(Lp); }
 };
 
 // stage `cols` floats (multiple of 4) per row of an episode, rows `src_stride` apart, into LDS rows of `cols` floats
@@ -319,7 +321,50 @@ template <int HD> __device__ __forceinline__ float ep_dot(const float* a, const 
     for (int d = 0; d < HD; ++d) s = __builtin_fmaf(a[d], b[d], s);
     return s;
 }
-#define EP_KEEP(POS, ELEM) dropout_keep(dc.seed, (uint32_t)(dc.env_base + b), (uint32_t)(POS), (uint32_t)layer, (uint32_t)CIRS_DROP_ATTN, (uint32_t)(ELEM), dc.thr)
+// The keep bits of an episode's attention-probability dropout, built ONCE per episode (round 6): sK[(p * NH + h) * 2 + (j >> 5)] bit (j & 31) = keep(query p,
+// key j <= p, head h) -- the masks EP_KEEP(p, j * NH + h) of rng.h, unchanged.  One Philox block covers four consecutive (key, head) elements of a query, so
+// an episode of 30 rows needs ~470 blocks = 8 per lane; evaluated where the bits are used it was one block per (query, key) PER LANE of EVERY loop (the four
+// lanes that share a query recomputed each other's block): 60 per lane in the forward, 180 in the backward, ~500 cycles each -- the kernels were Philox-bound.
+// Rows p and len - 1 - p are folded into one work row (together len + 1 keys) so that the lanes' item counts are even.
+template <int NH>
+__device__ __forceinline__ void ep_keep_build(uint32_t* __restrict__ sK, int len, int b, int layer, const DropCfg& dc, int tid, int nt) {
+    for (int i = tid; i < len * NH * 2; i += nt) sK[i] = 0u;
+    __syncthreads();
+    const int half = (len + 1) >> 1;                       // folded rows
+    const int bpr = (((len + 1) * NH + 3) >> 2) + 1;       // blocks per folded row (both parts rounded up)
+    for (int i = tid; i < half * bpr; i += nt) {
+        const int fr = i / bpr, g0 = i - fr * bpr;
+        const int pA = fr, pB = len - 1 - fr;
+        const int nA = ((pA + 1) * NH + 3) >> 2, nB = pB > pA ? ((pB + 1) * NH + 3) >> 2 : 0;
+        const bool inA = g0 < nA;
+        const int p = inA ? pA : pB, g = inA ? g0 : g0 - nA;
+        if (g0 < nA + nB) {
+            const u32x4 r = dropout_block(dc.seed, (uint32_t)(dc.env_base + b), (uint32_t)p, (uint32_t)layer, (uint32_t)CIRS_DROP_ATTN, (uint32_t)g);
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                const int elem = 4 * g + wd, j = elem / NH, h = elem - j * NH;
+                if (j <= p && block_word(r, (uint32_t)wd) >= dc.thr) atomicOr(&sK[(p * NH + h) * 2 + (j >> 5)], 1u << (j & 31));
+            }
+        }
+    }
+    __syncthreads();
+}
+// the same bits for ONE query p (the last layer of the prefix pass only attends from the last row): sK[h * 2 + (j >> 5)]
+template <int NH>
+__device__ __forceinline__ void ep_keep_build_row(uint32_t* __restrict__ sK, int p, int b, int layer, const DropCfg& dc, int tid, int nt) {
+    for (int i = tid; i < NH * 2; i += nt) sK[i] = 0u;
+    __syncthreads();
+    for (int g = tid; 4 * g < (p + 1) * NH; g += nt) {
+        const u32x4 r = dropout_block(dc.seed, (uint32_t)(dc.env_base + b), (uint32_t)p, (uint32_t)layer, (uint32_t)CIRS_DROP_ATTN, (uint32_t)g);
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+            const int elem = 4 * g + wd, j = elem / NH, h = elem - j * NH;
+            if (j <= p && block_word(r, (uint32_t)wd) >= dc.thr) atomicOr(&sK[h * 2 + (j >> 5)], 1u << (j & 31));
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ bool ep_keep_bit(const uint32_t (&m)[2], int j) { return ((j < 32 ? m[0] : m[1]) >> (j & 31)) & 1u; }
 
 template <int NH, bool kDrop>
 __global__ __launch_bounds__(64) void attn_fwd_ep(const float* __restrict__ QKV, const int32_t* __restrict__ offsets,
@@ -333,7 +378,9 @@ __global__ __launch_bounds__(64) void attn_fwd_ep(const float* __restrict__ QKV,
     const int base = offsets[b], STR = G::strip(Lp);
     float* sKV = smem;                          // [len][K 32 | V 32]
     float* sS = smem + (size_t)Lp * 64;         // [head group][query | dummy row Lp][HPL][Lp] (query stride STR)
+    uint32_t* sK = reinterpret_cast<uint32_t*>(sS + (size_t)G::NW * (Lp + 1) * STR);   // dropout keep bits [query][head][2]
     ep_stage(sKV, QKV + (size_t)base * 96 + tD, len, 96, 64, lane, 64);
+    if (kDrop) ep_keep_build<NH>(sK, len, b, layer, dc, lane, 64);
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;   // q * scale * log2(e): scores in log2 units
     for (int s0 = 0; 2 * s0 < len; s0 += SL) {
@@ -372,6 +419,14 @@ __global__ __launch_bounds__(64) void attn_fwd_ep(const float* __restrict__ QKV,
         float accA[DPL], accB[DPL];
 #pragma unroll
         for (int d = 0; d < DPL; ++d) accA[d] = accB[d] = 0.f;
+        uint32_t kmA[HPL][2], kmB[HPL][2];
+        if (kDrop) {
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                kmA[h][0] = sK[(rA * NH + hg * HPL + h) * 2]; kmA[h][1] = sK[(rA * NH + hg * HPL + h) * 2 + 1];
+                kmB[h][0] = sK[(rB * NH + hg * HPL + h) * 2]; kmB[h][1] = sK[(rB * NH + hg * HPL + h) * 2 + 1];
+            }
+        }
         float vq[DPL];
         ep_load(vq, sKV + 32 + hg * DPL);
 #pragma unroll 4
@@ -387,8 +442,8 @@ __global__ __launch_bounds__(64) void attn_fwd_ep(const float* __restrict__ QKV,
                 ea = inA ? ea : 0.f; eb = inB ? eb : 0.f;
                 smA[h] += ea; smB[h] += eb;
                 if (kDrop) {
-                    if (inA && !EP_KEEP(pA, j * NH + hg * HPL + h)) ea = 0.f;
-                    if (inB && !EP_KEEP(pB, j * NH + hg * HPL + h)) eb = 0.f;
+                    if (!ep_keep_bit(kmA[h], j)) ea = 0.f;
+                    if (!ep_keep_bit(kmB[h], j)) eb = 0.f;
                 }
 #pragma unroll
                 for (int d = 0; d < HD; ++d) {
@@ -428,9 +483,11 @@ __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV,
     float* sS = sdA + (size_t)Lp * 32;                   // [head group][query][HPL][Lp] (query stride STR): scores -> e -> dS
     float* sM = sS + (size_t)G::NW * (Lp + 1) * STR;     // [head group][query][HPL]: row max
     float* sI = sM + (size_t)NH * Lp;                    //                           1 / sum
+    uint32_t* sK = reinterpret_cast<uint32_t*>(sI + (size_t)NH * Lp);   // dropout keep bits [query][head][2]
     CIRS_BWG(layer == 1, 0);
     ep_stage(sQKV, QKV + (size_t)base * 96, len, 96, 96, lane, 64);
     ep_stage(sdA, dATT + (size_t)base * tD, len, tD, tD, lane, 64);
+    if (kDrop) ep_keep_build<NH>(sK, len, b, layer, dc, lane, 64);
     __syncthreads();
     CIRS_BSTAMP(40);
     const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;
@@ -454,6 +511,14 @@ __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV,
         float mxA[HPL], mxB[HPL], smA[HPL], smB[HPL], dotA[HPL], dotB[HPL];
 #pragma unroll
         for (int h = 0; h < HPL; ++h) { mxA[h] = mxB[h] = -INFINITY; smA[h] = smB[h] = 0.f; dotA[h] = dotB[h] = 0.f; }
+        uint32_t kmA[HPL][2], kmB[HPL][2];
+        if (kDrop) {
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                kmA[h][0] = sK[(rA * NH + hg * HPL + h) * 2]; kmA[h][1] = sK[(rA * NH + hg * HPL + h) * 2 + 1];
+                kmB[h][0] = sK[(rB * NH + hg * HPL + h) * 2]; kmB[h][1] = sK[(rB * NH + hg * HPL + h) * 2 + 1];
+            }
+        }
         float kq[DPL], vq[DPL];
         ep_load(kq, sQKV + 32 + hg * DPL);
 #pragma unroll 4
@@ -487,8 +552,8 @@ __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV,
                 smA[h] += ea; smB[h] += eb;
                 float dpa = ep_dot<HD>(daA + h * HD, v + h * HD), dpb = ep_dot<HD>(daB + h * HD, v + h * HD);
                 if (kDrop) {
-                    dpa = (inA && EP_KEEP(pA, j * NH + hg * HPL + h)) ? dpa * dinv : 0.f;
-                    dpb = (inB && EP_KEEP(pB, j * NH + hg * HPL + h)) ? dpb * dinv : 0.f;
+                    dpa = (inA && ep_keep_bit(kmA[h], j)) ? dpa * dinv : 0.f;
+                    dpb = (inB && ep_keep_bit(kmB[h], j)) ? dpb * dinv : 0.f;
                 }
                 dotA[h] = __builtin_fmaf(ea, dpa, dotA[h]);       // sum_j e dP; normalised below
                 dotB[h] = __builtin_fmaf(eb, dpb, dotB[h]);
@@ -519,8 +584,8 @@ __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV,
             for (int h = 0; h < HPL; ++h) {
                 float dpa = ep_dot<HD>(daA + h * HD, v + h * HD), dpb = ep_dot<HD>(daB + h * HD, v + h * HD);
                 if (kDrop) {
-                    dpa = (inA && EP_KEEP(pA, j * NH + hg * HPL + h)) ? dpa * dinv : 0.f;
-                    dpb = (inB && EP_KEEP(pB, j * NH + hg * HPL + h)) ? dpb * dinv : 0.f;
+                    dpa = (inA && ep_keep_bit(kmA[h], j)) ? dpa * dinv : 0.f;
+                    dpb = (inB && ep_keep_bit(kmB[h], j)) ? dpb * dinv : 0.f;
                 }
                 float dsa = myA[h * Lp + j] * invA[h] * (dpa - dotA[h]), dsb = myB[h * Lp + j] * invB[h] * (dpb - dotB[h]);
                 dsa = inA ? dsa : 0.f; dsb = inB ? dsb : 0.f;
@@ -566,8 +631,9 @@ __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV,
                 float pb = ep_exp2(fminf(ep_dot<HD>(q + h * HD, kB + h * HD) - m, 0.f)) * iv;
                 pa = inA ? pa : 0.f; pb = inB ? pb : 0.f;
                 if (kDrop) {
-                    pa = (inA && EP_KEEP(pq, jA * NH + hg * HPL + h)) ? pa * dinv : 0.f;
-                    pb = (inB && EP_KEEP(pq, jB * NH + hg * HPL + h)) ? pb * dinv : 0.f;
+                    const uint32_t* kw = sK + (pq * NH + hg * HPL + h) * 2;       // (same address in the lanes of a head group: a broadcast read)
+                    pa = (inA && ((kw[rA >> 5] >> (rA & 31)) & 1u)) ? pa * dinv : 0.f;
+                    pb = (inB && ((kw[rB >> 5] >> (rB & 31)) & 1u)) ? pb * dinv : 0.f;
                 }
                 float dsa = sS[ss + h * Lp + rA], dsb = sS[ss + h * Lp + rB];
                 dsa = inA ? dsa : 0.f; dsb = inB ? dsb : 0.f;
@@ -1494,6 +1560,340 @@ __global__ __launch_bounds__(256) void prefix_decoder_kernel(const float* __rest
     for (int k = 0; k < tD; ++k) acc = __builtin_fmaf(h[k], dec_w[(size_t)j * tD + k], acc);
     out[(size_t)e * out_stride + j] = acc;
 }
+
+// ---- the whole prefix pass of cirs_tracker_prefix_states from ONE launch, one wavefront per env (round 6) ----------------------------------------
+// An env's prefix is at most 32 rows = one MFMA row tile, so one wavefront can walk the pass on its own: slot gather + in_proj (embed_inproj), every
+// layer but the last on all rows (attn_fwd_ep's loops over the Q|K|V tile, now in LDS; layer_rows_fwd's chain, whose next in_proj refills that tile),
+// the last layer for the last row only (its attention for the one query; its chain on the tile, of which only that row counts) and the decoder.
+// Every stage keeps the stand-alone kernel's arithmetic -- operand order, fma chains, reduction order -- so the states are BIT-identical to the
+// multi-launch pass (tests/test_gpu_dropout.py); nothing is kept for a backward pass.  Why: at one call of a collect the multi-launch pass is nine
+// launches at their latency floors (~110 us for ~0.5 us of arithmetic per CU).
+constexpr int kPQS = 104;   // Q|K|V tile row stride (floats): 4 rows = 32 banks apart (the two lane halves of an accumulator store)
+constexpr int kPAS = 36;    // attention-output tile row stride
+struct PrefixEnvArgs {
+    const float *x_hist, *pe;
+    const int32_t *row_env, *row_t, *offsets, *lens;
+    cirs_tracker_layer layer[CIRS_MAX_TRACKER_LAYERS];
+    const float *dec_w, *dec_b;
+    float* state_out;
+    long state_stride;
+    int nl, L, S;
+};
+template <int NH> __host__ __device__ constexpr size_t prefix_env_scratch_floats() {     // strips of the attention / the chain's 32 x kRowT tile (never live together)
+    return (size_t)EpGeo<NH>::NW * 33 * EpGeo<NH>::strip(32) > (size_t)32 * kRowT ? (size_t)EpGeo<NH>::NW * 33 * EpGeo<NH>::strip(32) : (size_t)32 * kRowT;
+}
+template <int NH> __host__ __device__ constexpr size_t prefix_env_lds_floats() { return (size_t)32 * kPQS + (size_t)32 * kPAS + prefix_env_scratch_floats<NH>() + EpGeo<NH>::keep_words(32); }
+
+#define EP_KEEP(POS, ELEM) dropout_keep(dc.seed, (uint32_t)(dc.env_base + b), (uint32_t)(POS), (uint32_t)layer, (uint32_t)CIRS_DROP_ATTN, (uint32_t)(ELEM), dc.thr)
+// attn_fwd_ep on the tile: every query of the episode (same loops; q / K / V come from the LDS tile, the output rows go to sA)
+template <int NH, bool kDrop>
+__device__ __forceinline__ void prefix_attn_all(const float* __restrict__ sQ, float* __restrict__ sS, float* __restrict__ sA, uint32_t* __restrict__ sK, int len,
+                                                int b, int layer, const DropCfg& dc, int lane) {
+    using G = EpGeo<NH>;
+    constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD, SL = G::SL, Lp = 32;
+    const int hg = lane / SL, slot = lane - hg * SL, STR = G::strip(Lp);
+    if (kDrop) ep_keep_build<NH>(sK, len, b, layer, dc, lane, 64);
+    const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;
+    for (int s0 = 0; 2 * s0 < len; s0 += SL) {
+        const int pA = s0 + slot, pB = len - 1 - pA;
+        const bool actA = pA <= pB, actB = pA < pB;
+        const int rA = actA ? pA : 0, rB = actB ? pB : 0;
+        const int jn = len - s0;
+        float* myA = sS + ((size_t)hg * (Lp + 1) + (actA ? pA : Lp)) * STR;
+        float* myB = sS + ((size_t)hg * (Lp + 1) + (actB ? pB : Lp)) * STR;
+        float qA[DPL], qB[DPL];
+        ep_load(qA, sQ + rA * kPQS + hg * DPL);
+        ep_load(qB, sQ + rB * kPQS + hg * DPL);
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) { qA[d] *= qs; qB[d] *= qs; }
+        float mxA[HPL], mxB[HPL], smA[HPL], smB[HPL];
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) { mxA[h] = mxB[h] = -INFINITY; smA[h] = smB[h] = 0.f; }
+        float kq[DPL];
+        ep_load(kq, sQ + 32 + hg * DPL);
+#pragma unroll 4
+        for (int j = 0; j < jn; ++j) {
+            float k[DPL];
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) k[d] = kq[d];
+            ep_load(kq, sQ + (j + 1 < jn ? j + 1 : j) * kPQS + 32 + hg * DPL);
+            const bool inA = actA && j <= pA, inB = actB && j <= pB;
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                const float sa = ep_dot<HD>(qA + h * HD, k + h * HD), sb = ep_dot<HD>(qB + h * HD, k + h * HD);
+                myA[h * Lp + j] = sa; myB[h * Lp + j] = sb;
+                mxA[h] = inA ? fmaxf(mxA[h], sa) : mxA[h];
+                mxB[h] = inB ? fmaxf(mxB[h], sb) : mxB[h];
+            }
+        }
+        float accA[DPL], accB[DPL];
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) accA[d] = accB[d] = 0.f;
+        uint32_t kmA[HPL][2], kmB[HPL][2];
+        if (kDrop) {
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                kmA[h][0] = sK[(rA * NH + hg * HPL + h) * 2]; kmA[h][1] = sK[(rA * NH + hg * HPL + h) * 2 + 1];
+                kmB[h][0] = sK[(rB * NH + hg * HPL + h) * 2]; kmB[h][1] = sK[(rB * NH + hg * HPL + h) * 2 + 1];
+            }
+        }
+        float vq[DPL];
+        ep_load(vq, sQ + 64 + hg * DPL);
+#pragma unroll 4
+        for (int j = 0; j < jn; ++j) {
+            float v[DPL];
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) v[d] = vq[d];
+            ep_load(vq, sQ + (j + 1 < jn ? j + 1 : j) * kPQS + 64 + hg * DPL);
+            const bool inA = actA && j <= pA, inB = actB && j <= pB;
+#pragma unroll
+            for (int h = 0; h < HPL; ++h) {
+                float ea = ep_exp2(myA[h * Lp + j] - mxA[h]), eb = ep_exp2(myB[h * Lp + j] - mxB[h]);
+                ea = inA ? ea : 0.f; eb = inB ? eb : 0.f;
+                smA[h] += ea; smB[h] += eb;
+                if (kDrop) {
+                    if (!ep_keep_bit(kmA[h], j)) ea = 0.f;
+                    if (!ep_keep_bit(kmB[h], j)) eb = 0.f;
+                }
+#pragma unroll
+                for (int d = 0; d < HD; ++d) {
+                    accA[h * HD + d] = __builtin_fmaf(ea, v[h * HD + d], accA[h * HD + d]);
+                    accB[h * HD + d] = __builtin_fmaf(eb, v[h * HD + d], accB[h * HD + d]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < HPL; ++h) {
+            const float ia = (kDrop ? dc.inv : 1.0f) / smA[h], ib = (kDrop ? dc.inv : 1.0f) / smB[h];
+#pragma unroll
+            for (int d = 0; d < HD; ++d) { accA[h * HD + d] *= ia; accB[h * HD + d] *= ib; }
+        }
+        if (actA) ep_store(sA + pA * kPAS + hg * DPL, accA, 1.0f);
+        if (actB) ep_store(sA + pB * kPAS + hg * DPL, accB, 1.0f);
+    }
+}
+// the same attention for the LAST query alone (what the last layer needs): scores in parallel over the keys, then lane = (head, dim) walks the keys in
+// order -- the sums attn_fwd_ep forms for that query, in its order
+template <int NH, bool kDrop>
+__device__ __forceinline__ void prefix_attn_last(const float* __restrict__ sQ, float* __restrict__ sS, float* __restrict__ sA, uint32_t* __restrict__ sK, int len,
+                                                 int b, int layer, const DropCfg& dc, int lane) {
+    constexpr int HD = tD / NH;
+    const int p = len - 1;
+    if (kDrop) ep_keep_build_row<NH>(sK, p, b, layer, dc, lane, 64);
+    const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;
+    {
+        const int j = lane & 31;
+        for (int h = lane >> 5; h < NH; h += 2) {
+            float q[HD], k[HD];
+            ep_load(q, sQ + p * kPQS + h * HD);
+            ep_load(k, sQ + j * kPQS + 32 + h * HD);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) q[d] *= qs;
+            sS[h * 32 + j] = ep_dot<HD>(q, k);
+        }
+    }
+    __syncthreads();
+    if (lane < 32) {
+        const int h = lane / HD;
+        float sc[32];
+        ep_load(sc, sS + h * 32);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) mx = j <= p ? fmaxf(mx, sc[j]) : mx;
+        float sm = 0.f, acc = 0.f;
+        const uint32_t km = kDrop ? sK[h * 2] : 0u;      // (len <= 32 here: one word)
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const bool in = j <= p;
+            float e = ep_exp2(sc[j] - mx);
+            e = in ? e : 0.f;
+            sm += e;
+            if (kDrop) {
+                if (!((km >> j) & 1u)) e = 0.f;
+            }
+            acc = __builtin_fmaf(e, sQ[j * kPQS + 64 + lane], acc);
+        }
+        acc *= (kDrop ? dc.inv : 1.0f) / sm;
+        sA[p * kPAS + lane] = acc;
+    }
+    __syncthreads();
+}
+#undef EP_KEEP
+// layer_rows_fwd's chain on the tile: x = attention output (sA), hrow = layer input (registers, lane = (row, column half)) -> hrow = layer output; the
+// next layer's Q|K|V into sQ when win_next is set
+template <bool kDrop>
+__device__ __forceinline__ void prefix_chain(const cirs_tracker_layer& y, const float* __restrict__ win_next, const float* __restrict__ bin_next, int layer,
+                                             const DropCfg& dc, int env, int pos, bool row_ok, int lo, int hi, const float* __restrict__ sA,
+                                             float* __restrict__ sT, float* __restrict__ sQ, float (&hrow)[16]) {
+    float x[16], wo[16], w1[4][16], g1[16], be1[16];
+    ep_load(wo, y.out_proj_w + (size_t)lo * tD + 16 * hi);
+    ep_load(g1, y.norm1_w + 16 * hi);
+    ep_load(be1, y.norm1_b + 16 * hi);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) ep_load(w1[nt], y.lin1_w + (size_t)(nt * 32 + lo) * tD + 16 * hi);
+    const float bo = y.out_proj_b[lo], bl2 = y.lin2_b[lo];
+    float bl1[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bl1[nt] = y.lin1_b[nt * 32 + lo];
+    ep_load(x, sA + lo * kPAS + 16 * hi);
+    if (!row_ok) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = 0.f;
+    }
+    sg_f32x16 acc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = bo;
+    mm_regs(acc, x, wo);
+    acc_to_lds(sT, acc, lo, hi);
+    __syncthreads();
+    float w2[4][16];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) ep_load(w2[kb], y.lin2_w + (size_t)lo * tH + kb * 32 + 16 * hi);
+    float yv[16], xh[16], h1n[16], rs;
+    {
+        float t[16];
+        ep_load(t, sT + lo * kRowT + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = t[j];
+            if (kDrop) v = drop_apply(dc, v, env, pos, layer, CIRS_DROP_RES1, 16 * hi + j);
+            yv[j] = row_ok ? hrow[j] + v : 0.f;
+        }
+    }
+    ln_apply(yv, g1, be1, xh, h1n, rs);
+    if (!row_ok) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) h1n[j] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = bl1[nt];
+        mm_regs(acc, h1n, w1[nt]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = fmaxf(acc[s], 0.f);
+        acc_to_lds(sT, acc, nt * 32 + lo, hi);
+    }
+    __syncthreads();
+    float g2[16], be2[16], wn[3][16], bn[3];
+    ep_load(g2, y.norm2_w + 16 * hi);
+    ep_load(be2, y.norm2_b + 16 * hi);
+    if (win_next) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            ep_load(wn[nt], win_next + (size_t)(nt * 32 + lo) * tD + 16 * hi);
+            bn[nt] = bin_next[nt * 32 + lo];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = bl2;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        float f[16];
+        ep_load(f, sT + lo * kRowT + kb * 32 + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (kDrop) f[j] = drop_apply(dc, f[j], env, pos, layer, CIRS_DROP_FF, kb * 32 + 16 * hi + j);
+            if (!row_ok) f[j] = 0.f;
+        }
+        mm_regs(acc, f, w2[kb]);
+    }
+    __syncthreads();
+    acc_to_lds(sT, acc, lo, hi);
+    __syncthreads();
+    {
+        float t[16];
+        ep_load(t, sT + lo * kRowT + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = t[j];
+            if (kDrop) v = drop_apply(dc, v, env, pos, layer, CIRS_DROP_RES2, 16 * hi + j);
+            yv[j] = row_ok ? h1n[j] + v : 0.f;
+        }
+    }
+    ln_apply(yv, g2, be2, xh, hrow, rs);
+    if (!row_ok) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hrow[j] = 0.f;
+    }
+    if (win_next) {
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[s] = bn[nt];
+            mm_regs(acc, hrow, wn[nt]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) sQ[acc_row(s, hi) * kPQS + nt * 32 + lo] = acc[s];
+        }
+    }
+    __syncthreads();
+}
+template <int NH, bool kDrop>
+__global__ __launch_bounds__(64) void prefix_env_kernel(PrefixEnvArgs a, DropCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sQ = smem;                          // [32][Q 32 | K 32 | V 32] (row stride kPQS)
+    float* sA = sQ + 32 * kPQS;                // [32][32] attention output (row stride kPAS)
+    float* sX = sA + 32 * kPAS;                // attention strips | the chain's tile
+    uint32_t* sK = reinterpret_cast<uint32_t*>(sX + prefix_env_scratch_floats<NH>());   // dropout keep bits of the layer's attention
+    const int e = blockIdx.x, len = a.lens[e];
+    if (len <= 0) return;
+    CIRS_BSTAMP(40);
+    const int lane = threadIdx.x, hi = lane >> 5, lo = lane & 31;
+    const int base = a.offsets[e];
+    const bool row_ok = lo < len;
+    const size_t rr = (size_t)base + (row_ok ? lo : 0);
+    const int b = a.row_env[rr], p = a.row_t[rr];
+    // ---- slot gather + scale + positional encoding + the first in_proj (embed_inproj) ----------------------------------------------------------
+    float h[16];
+    {
+        float x[16], pp[16];
+        ep_load(x, a.x_hist + ((size_t)b * a.L + p) * tD + 16 * hi);
+        ep_load(pp, a.pe + (size_t)p * tD + 16 * hi);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = x[j] * 5.656854249492381f + pp[j];
+            if (kDrop) v = drop_apply(dc, v, b, p, 0, CIRS_DROP_POS, 16 * hi + j);
+            h[j] = row_ok ? v : 0.f;
+        }
+        sg_f32x16 acc;
+        const float* win = a.layer[0].in_proj_w;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int n = nt * 32 + lo;
+            const float bias = a.layer[0].in_proj_b[n];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[s] = bias;
+            mm_block(acc, h, win + (size_t)n * tD + 16 * hi);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) sQ[acc_row(s, hi) * kPQS + n] = acc[s];
+        }
+    }
+    __syncthreads();
+    CIRS_BSTAMP(41);
+    for (int l = 0; l < a.nl; ++l) {
+        const bool last = l + 1 == a.nl;
+        if (last) prefix_attn_last<NH, kDrop>(sQ, sX, sA, sK, len, e, l, dc, lane);
+        else {
+            prefix_attn_all<NH, kDrop>(sQ, sX, sA, sK, len, e, l, dc, lane);
+            __syncthreads();
+        }
+        CIRS_BSTAMP(42 + 2 * l);
+        prefix_chain<kDrop>(a.layer[l], last ? nullptr : a.layer[l + 1].in_proj_w, last ? nullptr : a.layer[l + 1].in_proj_b, l, dc, b, p, row_ok, lo, hi,
+                            sA, sX, sQ, h);
+        CIRS_BSTAMP(43 + 2 * l);
+    }
+    // ---- decoder on the last row (prefix_decoder_kernel) -----------------------------------------------------------------------------------------
+    if (lo == len - 1) ep_store(sA + 16 * hi, h, 1.0f);
+    __syncthreads();
+    if (lane < a.S) {
+        float acc = a.dec_b[lane];
+#pragma unroll
+        for (int k = 0; k < tD; ++k) acc = __builtin_fmaf(sA[k], a.dec_w[(size_t)lane * tD + k], acc);
+        a.state_out[(size_t)e * a.state_stride + lane] = acc;
+    }
+    CIRS_BSTAMP(50);
+}
 }  // namespace cirs
 
 extern "C" int64_t cirs_tracker_backward_workspace_bytes(const cirs_tracker_cfg* cfg, int32_t n_rows) {
@@ -1562,6 +1962,28 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
         CIRS_REQUIRE(cfg->dropout_p < 1.f, "dropout_p must be in [0, 1)");
         dc.on = 1; dc.thr = dropout_threshold(cfg->dropout_p); dc.inv = 1.0f / (1.0f - cfg->dropout_p);
         dc.seed = cfg->dropout_seed; dc.env_base = cfg->drop_env_base;
+    }
+    // ---------------- prefix states, one launch: one wavefront per env (prefixes of at most 32 rows) ----------------
+    if (state_out && ep && L <= 32 && S <= 64 && !getenv("CIRS_TRACKER_ROWS_UNFUSED") && !getenv("CIRS_TRACKER_PREFIX_FULL") && !getenv("CIRS_TRACKER_PREFIX_LAUNCHES")) {
+        PrefixEnvArgs pa{};
+        pa.x_hist = st->x_hist; pa.pe = w->pe; pa.row_env = row_env; pa.row_t = row_t; pa.offsets = offsets; pa.lens = lens;
+        for (int l = 0; l < nl; ++l) pa.layer[l] = w->layer[l];
+        pa.dec_w = w->dec_w; pa.dec_b = w->dec_b; pa.state_out = state_out; pa.state_stride = (long)state_stride; pa.nl = nl; pa.L = L; pa.S = S;
+#define PREFIX_ENV(N)                                                                                                                        \
+    do {                                                                                                                                     \
+        const size_t sh = std::max<size_t>(4 * prefix_env_lds_floats<N>(), 40 * 1024);   /* at most one of these wavefronts per SIMD */        \
+        if (dc.on) hipLaunchKernelGGL((prefix_env_kernel<N, true>), dim3(B), dim3(64), sh, s, pa, dc);                                        \
+        else hipLaunchKernelGGL((prefix_env_kernel<N, false>), dim3(B), dim3(64), sh, s, pa, dc);                                             \
+    } while (0)
+        switch (NH) {
+            case 1: PREFIX_ENV(1); break;
+            case 2: PREFIX_ENV(2); break;
+            case 4: PREFIX_ENV(4); break;
+            default: PREFIX_ENV(8); break;
+        }
+#undef PREFIX_ENV
+        CIRS_CHECK_LAUNCH("prefix_env_kernel");
+        return CIRS_OK;
     }
     // ---------------- forward recompute ----------------
     // fused row chains (embed + in_proj; out_proj .. LayerNorm2 + the next in_proj) unless CIRS_TRACKER_ROWS_UNFUSED asks for the

@@ -326,3 +326,43 @@ def test_exact_redraw_with_replicated_ranks(monkeypatch, W, B, I, U, T):
     assert torch.equal(ref.policy_flat, engines[0].policy_flat)
     assert torch.equal(ref.tracker_flat, engines[0].tracker_flat)
     assert not torch.equal(ref.tracker_flat, CirsEngine(dt, B * W, world_size=1, rank=0, **kw).tracker_flat), "the update must have moved the tracker"
+
+
+@pytest.mark.parametrize("B,T,nhead,p", [(70, 30, 4, 0.1), (9, 31, 4, 0.0), (11, 12, 2, 0.3), (7, 20, 8, 0.1), (5, 9, 1, 0.2), (6, 40, 4, 0.1)])
+def test_prefix_states_from_one_launch_equal_the_multi_launch_pass(B, T, nhead, p, monkeypatch):
+    """cirs_tracker_prefix_states runs as ONE launch (prefix_env_kernel: one wavefront per env, prefixes of at most 32 rows: max_len = T + 1 = 32 is the largest; T = 40 takes the
+    multi-launch pass in both runs) that keeps the arithmetic of the stand-alone kernels: its states are BIT-identical to the multi-launch pass
+    (CIRS_TRACKER_PREFIX_LAUNCHES=1), and equal to the restatement under the same masks."""
+    U, I = 40, 60
+    rng = np.random.RandomState(B * T + nhead)
+    tp = rolloutcase.tracker_param_dict(U, I, T, seed=3)
+    lens = rng.randint(0, T + 2, size=B)          # rows per env (at most max_len = T + 1), some envs without rows
+    lens[0] = T + 1
+    users = rng.randint(0, U, B); acts = rng.randint(0, I, (B, T)); rews = rng.uniform(0, 1, (B, T))
+    env_base, seed, tag = 500, 7, 3
+    trk, _ = device_tracker_trainable(tp, U, I, B, T, nhead=nhead)
+    trk.reset()
+    trk.init(torch.as_tensor(users))
+    for t in range(T):          # the input slots 0 .. T of every env (slot 0 = the user's, slot t + 1 = (action, reward) of step t)
+        trk.step(torch.as_tensor(acts[:, t]), torch.as_tensor(rews[:, t]))
+    trk.set_dropout(p)
+    trk.set_dropout_key(seed, tag, env_base)
+    offsets, row_env, row_t = rows_of(lens)
+    dd = lambda x: torch.as_tensor(x).cuda()  # noqa: E731
+    outs = []
+    for launches in ("0", "1"):
+        if launches == "1":
+            monkeypatch.setenv("CIRS_TRACKER_PREFIX_LAUNCHES", "1")
+        else:
+            monkeypatch.delenv("CIRS_TRACKER_PREFIX_LAUNCHES", raising=False)
+        out = torch.full((B, 20), 7.0, device="cuda")
+        trk.prefix_states(dd(row_env), dd(row_t), dd(offsets), dd(lens.astype(np.int32)), int(lens.sum()), out)
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert (outs[0][lens == 0] == 7.0).all(), "envs without rows must be left untouched"
+    d = dict(p=p, key=nn_oracle.dropout_key(seed, tag), envs=np.arange(B) + env_base) if p > 0 else None
+    with torch.no_grad():
+        want = nn_oracle.tracker_forward_all(tp, nn_oracle.tracker_inputs(tp, users, acts, rews), nhead, dropout=d).numpy()   # [B, T + 1, S]
+    for b in range(B):
+        if lens[b] > 0:
+            np.testing.assert_allclose(outs[0][b], want[b, lens[b] - 1], atol=3e-5, rtol=1e-4)
