@@ -158,6 +158,8 @@ SIGNATURES = {
     "cirs_tracker_backward_workspace_bytes": (C.c_int64, [C.POINTER(TrackerCfg), C.c_int32]),
     "cirs_tracker_backward": (C.c_int, [C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState), _P, _P,
                                         _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(TrackerWeights), _P, C.c_int64, _P]),
+    "cirs_tracker_backward_last": (C.c_int, [C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState), _P, _P,
+                                             _P, _P, _P, _P, _P, C.c_int32, _P, C.POINTER(TrackerWeights), _P, C.c_int64, _P]),
     "cirs_tracker_prefix_states": (C.c_int, [C.POINTER(TrackerCfg), C.POINTER(TrackerWeights), C.POINTER(TrackerState), _P, _P, _P, _P, C.c_int32, _P,
                                             C.c_int64, _P, C.c_int64, _P]),
     "cirs_embedding_scatter_workspace_bytes": (C.c_int64, [C.c_int64]),

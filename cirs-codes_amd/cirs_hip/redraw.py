@@ -155,10 +155,10 @@ def redraw_tracker_backward(rollout: RedrawRollout, row_env, row_t, offsets, len
     env_q = torch.repeat_interleave(torch.arange(C_ * B, dtype=torch.int32, device=dev), lens_q.long(), output_size=n_q)
     pos_q = torch.arange(n_q, dtype=torch.int32, device=dev) - torch.repeat_interleave(offs_q, lens_q.long(), output_size=n_q)
     up = lambda a: a.to(torch.int32).contiguous()      # noqa: E731
-    d_q = torch.zeros((dstate.shape[0], C_, B, dstate.shape[2]), dtype=dstate.dtype, device=dev)
-    ar = torch.arange(C_, device=dev)
-    d_q[ar, ar] = dstate[:C_]                                       # d s_c of env e -> position c of pseudo-env (c, e)
     base = rollout.dropout_env_base if B == rollout.env.n_env else 0          # (gathered buffer: the ids are global already)
     trk.set_dropout_key(key_seed, call_tag(rng_base, 0), base)
+    # d s_c of env e = the gradient of the LAST row (position c) of pseudo-env (c, e) and the only one that pseudo-env carries: the last-row pass
+    # (cirs_tracker_backward_last: the top layer on one row per pseudo-env); dstate[:C_] viewed as [C_ * B, S] is that gradient, pseudo-env-major
     trk.backward(users.repeat(C_), _CallBatch(tr, C_), up(env_q), up(pos_q), up(offs_q), up(lens_q), n_q,
-                 d_q.view(dstate.shape[0], C_ * B, dstate.shape[2]), x_hist=x_hist.repeat(C_, 1, 1).contiguous(), drop_env_base=base)
+                 dstate[:C_].reshape(C_ * B, dstate.shape[2]).contiguous(), x_hist=x_hist.repeat(C_, 1, 1).contiguous(), drop_env_base=base,
+                 last_rows_only=True)

@@ -135,10 +135,11 @@ class DeviceTracker:
         self.lr, self.betas, self.adam_eps = lr, betas, eps
         self._bws = None
 
-    def backward(self, users, traj, row_env, row_t, offsets, lens, n_rows, dstate, x_hist=None, drop_env_base=0):
+    def backward(self, users, traj, row_env, row_t, offsets, lens, n_rows, dstate, x_hist=None, drop_env_base=0, last_rows_only=False):
         """d loss / d tracker params from d loss / d obs (dstate [T+1,B,S]); fills self.flat_grad.
         x_hist: stored input slots [B', max_len, D] when the rows come from a gathered (multi-rank) buffer whose
-        env count B' = traj.B differs from this tracker's own n_env."""
+        env count B' = traj.B differs from this tracker's own n_env.
+        last_rows_only: dstate is [B', S] = the gradient of every env's LAST row, all other rows carry none (cirs_tracker_backward_last)."""
         users = users.to(self.device, torch.int32).contiguous()
         cfg, st = self.cfg, self.st
         if x_hist is not None:
@@ -147,9 +148,17 @@ class DeviceTracker:
             cfg.drop_env_base = int(drop_env_base)      # rows of a gathered buffer carry GLOBAL env ids already (0); redraw.py: the rollout's base
             st = abi.TrackerState(x_hist=x_hist.data_ptr(), kcache=self.kcache.data_ptr(), vcache=self.vcache.data_ptr(),
                                   len=self.len.data_ptr())
-        need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(cfg), n_rows)
+        need = self._lib.cirs_tracker_backward_workspace_bytes(C.byref(cfg), max(n_rows, cfg.n_env) if last_rows_only else n_rows)
         if self._bws is None or self._bws.numel() < need:
             self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if last_rows_only:
+            assert tuple(dstate.shape) == (cfg.n_env, self.dim_state) and dstate.is_contiguous()
+            abi.check(self._lib.cirs_tracker_backward_last(
+                C.byref(cfg), C.byref(self.w), C.byref(st), users.data_ptr(), traj.act.data_ptr(),
+                traj.rew.data_ptr(), row_env.data_ptr(), row_t.data_ptr(), offsets.data_ptr(), lens.data_ptr(), n_rows,
+                dstate.data_ptr(), C.byref(self.g), self._bws.data_ptr(), self._bws.numel(), self._stream()),
+                "cirs_tracker_backward_last")
+            return
         abi.check(self._lib.cirs_tracker_backward(
             C.byref(cfg), C.byref(self.w), C.byref(st), users.data_ptr(), traj.act.data_ptr(),
             traj.rew.data_ptr(), row_env.data_ptr(), row_t.data_ptr(), offsets.data_ptr(), lens.data_ptr(), n_rows,

@@ -1142,12 +1142,15 @@ static inline void dw_batch_add(DwBatch& b, DwList& list, const float* dY, int l
     list.part_floats += slabs * O * (K + 1);
     list.total_out += O * (K + 1);
 }
-static inline void dw_batch_launch(const DwBatch& b, int R, hipStream_t s) {
+// (R_rows < R: problems over the first R_rows rows only -- the last-row pass -- in the slab count of the R-row problems of the same pass, which is the one
+// dw_list_final walks; slabs beyond the rows write zero partials)
+static inline void dw_batch_launch(const DwBatch& b, int R, hipStream_t s, int R_rows = -1) {
     if (!b.n) return;
+    if (R_rows < 0) R_rows = R;
     const int slabs = dwg_slabs(R);
-    int rows_per_slab = (R + slabs - 1) / slabs;
+    int rows_per_slab = (R_rows + slabs - 1) / slabs;
     rows_per_slab = (rows_per_slab + 15) & ~15;
-    hipLaunchKernelGGL(dw_batch_kernel, dim3(b.total_tiles, slabs), dim3(64), 0, s, b, R, rows_per_slab);
+    hipLaunchKernelGGL(dw_batch_kernel, dim3(b.total_tiles, slabs), dim3(64), 0, s, b, R_rows, rows_per_slab);
 }
 
 // LayerNorm backward, same mapping: dY = rstd * (dxh - mean(dxh) - xhat * mean(dxh*xhat)), dxh = dOut * g
@@ -1454,9 +1457,12 @@ struct BwdScratch {
     float *XH1[CIRS_MAX_TRACKER_LAYERS], *RS1[CIRS_MAX_TRACKER_LAYERS], *H1N[CIRS_MAX_TRACKER_LAYERS], *FF1[CIRS_MAX_TRACKER_LAYERS];
     float *XH2[CIRS_MAX_TRACKER_LAYERS], *RS2[CIRS_MAX_TRACKER_LAYERS];
     float *T0, *T1, *T2, *T3, *T4, *T5, *dQKV, *dFF1, *dS, *partial, *GIN;
+    float* LC;                            // last-row pass: per episode dY1 [32] | (max, 1 / sum) per head [16] | env | position
     float* PM[CIRS_MAX_TRACKER_LAYERS];   // dropout: attention probabilities after the mask
     void* sort;  // emb_sort_bytes(R)
 };
+
+constexpr int kLastFloats = tD + 16 + 2 + 2;     // BwdScratch::LC per episode (padded to a multiple of 4)
 
 static size_t bwd_partial_floats(const cirs_tracker_cfg* cfg, long R) {
     size_t f = dw_list_floats(R, 32, tD) + dw_list_floats(R, tD, tD) + dw_list_floats(R, tD, tD + 1);   // decoder (S <= 32), ffn_user, gate
@@ -1475,6 +1481,7 @@ static size_t bwd_floats(const cirs_tracker_cfg* cfg, long R) {
     if (cfg->dropout_p > 0.f) f += (size_t)nl * R * NH * Lp + 64;                      // PM
     f += bwd_partial_floats(cfg, R) + 4096;       // slab partials of every dW problem of the pass (one final launch)
     f += (size_t)R * (tD + 1);                    // GIN
+    f += (size_t)R * kLastFloats;                 // LC
     f += emb_sort_bytes(R + cfg->n_env) / 4 + 64;  // (key, row) sort of the embedding scatter (item rows + one user pair per env)
     return f + 64 * 32;
 }
@@ -1497,6 +1504,7 @@ static BwdScratch carve_bwd(void* ws, const cirs_tracker_cfg* cfg, long R) {
     s.dQKV = take((size_t)R * 96); s.dFF1 = take((size_t)R * tH); s.dS = take((size_t)R * NH * Lp);
     s.partial = take(bwd_partial_floats(cfg, R) + 4096);
     s.GIN = take((size_t)R * (tD + 1));
+    s.LC = take((size_t)R * kLastFloats);
     s.sort = (void*)take(emb_sort_bytes(R + cfg->n_env) / 4 + 64);
     return s;
 }
@@ -1894,6 +1902,185 @@ __global__ __launch_bounds__(64) void prefix_env_kernel(PrefixEnvArgs a, DropCfg
     }
     CIRS_BSTAMP(50);
 }
+
+// ---- a pass whose upstream gradient sits on the LAST row of every episode (cirs_tracker_backward_last: the exact-redraw procedure) -------------------
+// build_state call c only hands s_c = decoder(top layer, last row) to the policy (core/state_tracker.py:243-246), so in the graph of a call the top layer
+// matters at ONE row per episode: its attention has one query (O(len) instead of O(len^2) per episode), its row chain, five of its six weight-gradient
+// problems and the decoder's see E = n_env rows instead of R = sum of the lengths (~ E T / 2), and its attention backward is a rank-one update of
+// dK / dV.  Below the top layer every row carries a gradient (through the top layer's keys and values) and the pass is the ordinary one.
+//   attn_last_fwd : lane = (episode, head); the last query against keys 0 .. len-1 straight from the QKV rows (a head's 32 B per row; the NH lanes of an
+//                   episode read a row's 128 B together), same loops and operand order as attn_fwd_ep's query (same bits); gathers the row's layer
+//                   input and (env, position) for the row chain; keeps (max, 1 / sum) per (episode, head) for the backward
+//   attn_last_bwd : the same walk twice (dot = sum_j P dP, then dS): dQ on the last row, dK_j = dS_j q, dV_j = PM_j dATT for every row; it also lays
+//                   the top layer's residual gradient (non-zero on the last rows only) out over all rows for the chain of the layer below
+template <int NH>
+__device__ __forceinline__ void last_keep_build(uint32_t* __restrict__ sK, const int32_t* __restrict__ lens, int e0, int E, int Lp, int layer,
+                                                const DropCfg& dc, int tid) {
+    constexpr int EPW = 64 / NH;
+    for (int i = tid; i < EPW * NH * 2; i += 64) sK[i] = 0u;
+    __syncthreads();
+    const int gmax = (Lp * NH + 3) >> 2;        // Philox blocks of the longest query (four (key, head) elements per block)
+    for (int i = tid; i < EPW * gmax; i += 64) {
+        const int el = i / gmax, g = i - el * gmax, e = e0 + el;
+        const int len = e < E ? lens[e] : 0;
+        if (4 * g < len * NH) {
+            const int p = len - 1;
+            const u32x4 r = dropout_block(dc.seed, (uint32_t)(dc.env_base + e), (uint32_t)p, (uint32_t)layer, (uint32_t)CIRS_DROP_ATTN, (uint32_t)g);
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                const int elem = 4 * g + wd, j = elem / NH, h = elem - j * NH;
+                if (j <= p && block_word(r, (uint32_t)wd) >= dc.thr) atomicOr(&sK[(el * NH + h) * 2 + (j >> 5)], 1u << (j & 31));
+            }
+        }
+    }
+    __syncthreads();
+}
+template <int NH, bool kDrop>
+__global__ __launch_bounds__(64) void attn_last_fwd(const float* __restrict__ QKV, const float* __restrict__ H, const int32_t* __restrict__ row_env,
+                                                    const int32_t* __restrict__ row_t, const int32_t* __restrict__ offsets,
+                                                    const int32_t* __restrict__ lens, int E, int Lp, float* __restrict__ ATTc, float* __restrict__ Hc,
+                                                    float* __restrict__ stats, int32_t* __restrict__ env_c, int32_t* __restrict__ t_c, DropCfg dc, int layer) {
+    constexpr int HD = tD / NH, EPW = 64 / NH;
+    __shared__ uint32_t sK[EPW * NH * 2];
+    const int tid = threadIdx.x, el = tid / NH, h = tid - el * NH, e0 = blockIdx.x * EPW, e = e0 + el;
+    if (kDrop) last_keep_build<NH>(sK, lens, e0, E, Lp, layer, dc, tid);
+    if (e >= E) return;
+    const int len = lens[e];
+    float acc[HD], hrow[HD];
+    if (len <= 0) {      // an episode without rows: a zero row through the chain (its upstream gradient is zeroed as well: it contributes nothing)
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+        ep_store(ATTc + (size_t)e * tD + h * HD, acc, 1.0f);
+        ep_store(Hc + (size_t)e * tD + h * HD, acc, 1.0f);
+        stats[((size_t)e * NH + h) * 2] = 0.f; stats[((size_t)e * NH + h) * 2 + 1] = 0.f;
+        if (h == 0) { env_c[e] = e; t_c[e] = 0; }
+        return;
+    }
+    const int p = len - 1;
+    const size_t base = (size_t)offsets[e];
+    const float* rows = QKV + base * 96 + h * HD;
+    const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;
+    float q[HD];
+    ep_load(q, rows + (size_t)p * 96);
+    ep_load(hrow, H + (base + p) * tD + h * HD);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) q[d] *= qs;
+    float mx = -INFINITY;
+#pragma unroll 4
+    for (int j = 0; j <= p; ++j) {
+        float k[HD];
+        ep_load(k, rows + (size_t)j * 96 + 32);
+        mx = fmaxf(mx, ep_dot<HD>(q, k));
+    }
+    uint32_t km[2] = {0u, 0u};
+    if (kDrop) { km[0] = sK[(el * NH + h) * 2]; km[1] = sK[(el * NH + h) * 2 + 1]; }
+    float sm = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll 4
+    for (int j = 0; j <= p; ++j) {
+        float k[HD], v[HD];
+        ep_load(k, rows + (size_t)j * 96 + 32);
+        ep_load(v, rows + (size_t)j * 96 + 64);
+        float ex = ep_exp2(ep_dot<HD>(q, k) - mx);
+        sm += ex;
+        if (kDrop) {
+            if (!ep_keep_bit(km, j)) ex = 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = __builtin_fmaf(ex, v[d], acc[d]);
+    }
+    const float ia = (kDrop ? dc.inv : 1.0f) / sm;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] *= ia;
+    ep_store(ATTc + (size_t)e * tD + h * HD, acc, 1.0f);
+    ep_store(Hc + (size_t)e * tD + h * HD, hrow, 1.0f);
+    stats[((size_t)e * NH + h) * 2] = mx; stats[((size_t)e * NH + h) * 2 + 1] = 1.0f / sm;
+    if (h == 0) { env_c[e] = row_env[base + p]; t_c[e] = row_t[base + p]; }
+}
+template <int NH, bool kDrop>
+__global__ __launch_bounds__(64) void attn_last_bwd(const float* __restrict__ QKV, const float* __restrict__ dATTc, const float* __restrict__ dY1c,
+                                                    const float* __restrict__ stats, const int32_t* __restrict__ offsets, const int32_t* __restrict__ lens,
+                                                    int E, int Lp, float* __restrict__ dQKV, float* __restrict__ dY1, DropCfg dc, int layer) {
+    constexpr int HD = tD / NH, EPW = 64 / NH;
+    __shared__ uint32_t sK[EPW * NH * 2];
+    const int tid = threadIdx.x, el = tid / NH, h = tid - el * NH, e0 = blockIdx.x * EPW, e = e0 + el;
+    if (kDrop) last_keep_build<NH>(sK, lens, e0, E, Lp, layer, dc, tid);
+    if (e >= E) return;
+    const int len = lens[e];
+    if (len <= 0) return;
+    const int p = len - 1;
+    const size_t base = (size_t)offsets[e];
+    const float* rows = QKV + base * 96 + h * HD;
+    const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f, dinv = kDrop ? dc.inv : 1.0f;
+    float qr[HD], q[HD], da[HD], res[HD], zero[HD];
+    ep_load(qr, rows + (size_t)p * 96);
+    ep_load(da, dATTc + (size_t)e * tD + h * HD);
+    ep_load(res, dY1c + (size_t)e * tD + h * HD);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = qr[d] * qs; zero[d] = 0.f; }
+    const float mx = stats[((size_t)e * NH + h) * 2], inv = stats[((size_t)e * NH + h) * 2 + 1];
+    uint32_t km[2] = {0u, 0u};
+    if (kDrop) { km[0] = sK[(el * NH + h) * 2]; km[1] = sK[(el * NH + h) * 2 + 1]; }
+    float dot = 0.f;
+#pragma unroll 4
+    for (int j = 0; j <= p; ++j) {
+        float k[HD], v[HD];
+        ep_load(k, rows + (size_t)j * 96 + 32);
+        ep_load(v, rows + (size_t)j * 96 + 64);
+        const float ex = ep_exp2(ep_dot<HD>(q, k) - mx);
+        float dp = ep_dot<HD>(da, v);
+        if (kDrop) dp = ep_keep_bit(km, j) ? dp * dinv : 0.f;
+        dot = __builtin_fmaf(ex, dp, dot);
+    }
+    dot *= inv;
+    float dq[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+    float* orow = dQKV + base * 96 + h * HD;
+    float* yrow = dY1 + base * tD + h * HD;
+#pragma unroll 2
+    for (int j = 0; j <= p; ++j) {
+        float k[HD], v[HD];
+        ep_load(k, rows + (size_t)j * 96 + 32);
+        ep_load(v, rows + (size_t)j * 96 + 64);
+        const float pj = ep_exp2(ep_dot<HD>(q, k) - mx) * inv;
+        float dp = ep_dot<HD>(da, v), pm = pj;
+        if (kDrop) {
+            const bool keep = ep_keep_bit(km, j);
+            dp = keep ? dp * dinv : 0.f;
+            pm = keep ? pj * dinv : 0.f;
+        }
+        const float ds = pj * (dp - dot);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dq[d] = __builtin_fmaf(ds, k[d], dq[d]);
+        ep_store(orow + (size_t)j * 96 + 32, qr, ds * scale);
+        ep_store(orow + (size_t)j * 96 + 64, da, pm);
+        if (j < p) {
+            ep_store(orow + (size_t)j * 96, zero, 1.0f);
+            ep_store(yrow + (size_t)j * tD, zero, 1.0f);
+        }
+    }
+    ep_store(orow + (size_t)p * 96, dq, scale);
+    ep_store(yrow + (size_t)p * tD, res, 1.0f);
+}
+// upstream gradient of the last rows: G[e] = dstate_last[e] (zero for an episode without rows)
+__global__ __launch_bounds__(256) void dstate_last_rows(const float* __restrict__ dstate_last, const int32_t* __restrict__ lens, int E, int S,
+                                                        float* __restrict__ G) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)E * S) return;
+    G[i] = lens[i / S] > 0 ? dstate_last[i] : 0.f;
+}
+// the same upstream gradient laid out over ALL rows (the general pass as cirs_tracker_backward_last's fallback): row (env b, position lens[b] - 1) gets
+// dstate_last[b], every other row zero
+__global__ __launch_bounds__(256) void dstate_last_full(const float* __restrict__ dstate_last, const int32_t* __restrict__ row_env,
+                                                        const int32_t* __restrict__ offsets, const int32_t* __restrict__ lens, int R, int S,
+                                                        float* __restrict__ G) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)R * S) return;
+    const int r = (int)(i / S), s = (int)(i % S), b = row_env[r];
+    G[i] = r == offsets[b] + lens[b] - 1 ? dstate_last[(size_t)b * S + s] : 0.f;
+}
 }  // namespace cirs
 
 extern "C" int64_t cirs_tracker_backward_workspace_bytes(const cirs_tracker_cfg* cfg, int32_t n_rows) {
@@ -1907,17 +2094,19 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
                              const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
                              const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
                              const float* dstate, const cirs_tracker_grads* grads, void* workspace,
-                             int64_t workspace_bytes, void* stream, float* state_out, int64_t state_stride) {
+                             int64_t workspace_bytes, void* stream, float* state_out, int64_t state_stride, const float* dstate_last = nullptr) {
     using namespace cirs;
     CIRS_REQUIRE(cfg && w && st && row_env && row_t && offsets && lens && workspace, "null argument");
-    CIRS_REQUIRE(state_out || (users && act && rew && dstate && grads), "null argument");
+    CIRS_REQUIRE(state_out || (users && act && rew && (dstate || dstate_last) && grads), "null argument");
     if (cfg->dim_model != tD || cfg->d_hid != tH) return fail(CIRS_E_UNSUPPORTED, "dim_model == 32 and d_hid == 128 only");
     CIRS_REQUIRE(cfg->nhead == 1 || cfg->nhead == 2 || cfg->nhead == 4 || cfg->nhead == 8, "nhead must be 1,2,4,8");
     CIRS_REQUIRE(n_rows > 0, "n_rows must be positive");
-    CIRS_REQUIRE(workspace_bytes >= cirs_tracker_backward_workspace_bytes(cfg, n_rows), "workspace too small");
+    // (the last-row pass keeps one row per env of its top layer in the row-sized scratch: sized for max(n_rows, n_env) rows)
+    const int n_carve = dstate_last && cfg->n_env > n_rows ? cfg->n_env : n_rows;
+    CIRS_REQUIRE(workspace_bytes >= cirs_tracker_backward_workspace_bytes(cfg, n_carve), "workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int R = n_rows, B = cfg->n_env, S = cfg->dim_state, L = cfg->max_len, NH = cfg->nhead, nl = cfg->nlayers;
-    BwdScratch sc = carve_bwd(workspace, cfg, R);
+    BwdScratch sc = carve_bwd(workspace, cfg, n_carve);
     auto g1 = [&](long n) { return dim3(cdiv(n, 256)); };
 
     DwList dwl{};
@@ -1999,9 +2188,37 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
         hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0], dc);
     }
     bool last_compact = false;
+    // last-row pass (dstate_last): the top layer on ONE row per env -- its attention for the one query, its row chain on B compact rows
+    const bool top_last = dstate_last && fused_rows && ep && nl >= 2 && !getenv("CIRS_TRACKER_LAST_FULL");
+    float *dY1c = sc.LC, *att_stats = sc.LC + (size_t)B * tD;
+    int32_t *env_c = reinterpret_cast<int32_t*>(att_stats + (size_t)B * 16), *t_c = env_c + B;
+#define ATT_LAST1(KERNEL, N, ...)                                                                                        \
+    do {                                                                                                                 \
+        if (dc.on) hipLaunchKernelGGL((KERNEL<N, true>), dim3(cdiv(B, 64 / N)), dim3(64), 0, s, __VA_ARGS__);             \
+        else hipLaunchKernelGGL((KERNEL<N, false>), dim3(cdiv(B, 64 / N)), dim3(64), 0, s, __VA_ARGS__);                  \
+    } while (0)
+#define ATT_LAST(KERNEL, ...)                                  \
+    do {                                                       \
+        switch (NH) {                                          \
+            case 1: ATT_LAST1(KERNEL, 1, __VA_ARGS__); break;  \
+            case 2: ATT_LAST1(KERNEL, 2, __VA_ARGS__); break;  \
+            case 4: ATT_LAST1(KERNEL, 4, __VA_ARGS__); break;  \
+            default: ATT_LAST1(KERNEL, 8, __VA_ARGS__); break; \
+        }                                                      \
+    } while (0)
     for (int l = 0; l < nl; ++l) {
         const cirs_tracker_layer& y = w->layer[l];
         if (!fused_rows) launch_rows_gemm(true, sc.H[l], tD, y.in_proj_w, tD, y.in_proj_b, R, tD, 96, 0, nullptr, 0, sc.QKV[l], 96, s);
+        if (top_last && l == nl - 1) {
+            float* Hc = sc.T1;
+            ATT_LAST(attn_last_fwd, (const float*)sc.QKV[l], (const float*)sc.H[l], row_env, row_t, offsets, lens, B, L, sc.ATT[l], Hc, att_stats, env_c, t_c,
+                     dc, l);
+            LayerFwdArgs fa{sc.ATT[l], Hc, y, nullptr, nullptr, sc.XH1[l], sc.RS1[l], sc.H1N[l], sc.FF1[l], sc.XH2[l], sc.RS2[l], sc.H[l + 1], nullptr,
+                            env_c, t_c, B, l};
+            if (dc.on) hipLaunchKernelGGL(layer_rows_fwd<true>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
+            else hipLaunchKernelGGL(layer_rows_fwd<false>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
+            continue;
+        }
         if (ep) ATT_EP(attn_fwd_ep, false, (const float*)sc.QKV[l], offsets, lens, L, sc.ATT[l], dc, l);
         else ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l], dc, l, sc.PM[l]);
         if (fused_rows && state_out && l == nl - 1 && !getenv("CIRS_TRACKER_PREFIX_FULL")) {      // prefix states: the last layer's row chain on the envs' last rows only
@@ -2043,15 +2260,39 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
         return CIRS_OK;
     }
     // ---------------- backward ----------------
-    hipLaunchKernelGGL(gather_dstate, g1((long)R * S), dim3(256), 0, s, dstate, row_env, row_t, R, S, B, sc.G);
     float* dH = sc.T0;  // gradient w.r.t. the current layer output
     // (each weight-gradient problem rides in the launch of the row GEMM that consumes the same dY: DW_ROWS)
 #define DW_ROWS(X2, O, K, dWp, dbp, ...) launch_rows_gemm_dw(dwl, X2, K, O, K, dWp, dbp, sc.partial, __VA_ARGS__, s)
-    DW_ROWS(sc.H[nl], S, tD, grads->dec_w, grads->dec_b, false, sc.G, S, w->dec_w, tD, nullptr, R, S, tD, 0, nullptr, 0, dH, tD);
+    if (top_last) {
+        hipLaunchKernelGGL(dstate_last_rows, g1((long)B * S), dim3(256), 0, s, dstate_last, lens, B, S, sc.G);
+        launch_rows_gemm(false, sc.G, S, w->dec_w, tD, nullptr, B, S, tD, 0, nullptr, 0, dH, tD, s);      // (the decoder's dW problem joins the top layer's batch)
+    } else {
+        if (dstate_last) hipLaunchKernelGGL(dstate_last_full, g1((long)R * S), dim3(256), 0, s, dstate_last, row_env, offsets, lens, R, S, sc.G);
+        else hipLaunchKernelGGL(gather_dstate, g1((long)R * S), dim3(256), 0, s, dstate, row_env, row_t, R, S, B, sc.G);
+        DW_ROWS(sc.H[nl], S, tD, grads->dec_w, grads->dec_b, false, sc.G, S, w->dec_w, tD, nullptr, R, S, tD, 0, nullptr, 0, dH, tD);
+    }
     for (int l = nl - 1; l >= 0 && fused_rows; --l) {
         // fused row chain (layer_rows_bwd) + one batched launch of the layer's weight-gradient problems + the attention backward
         const cirs_tracker_layer& y = w->layer[l];
         const cirs_tracker_layer_grads& gy = grads->layer[l];
+        if (top_last && l == nl - 1) {      // B compact rows; the slab count of its weight-gradient problems stays the R-row one (dw_list_final walks one count)
+            float* dB1 = dc.on ? sc.T4 : dY1c;
+            LayerBwdArgs ba{sc.T0, nullptr, nullptr, nullptr, sc.T0, 0, y, sc.XH2[l], sc.RS2[l], sc.FF1[l], sc.XH1[l], sc.RS1[l], sc.T3, sc.dFF1, sc.T1, dY1c, dB1,
+                            sc.T5, env_c, t_c, B, l};
+            if (dc.on) hipLaunchKernelGGL(layer_rows_bwd<true>, dim3(cdiv(B, 32)), dim3(64), 0, s, ba, dc);
+            else hipLaunchKernelGGL(layer_rows_bwd<false>, dim3(cdiv(B, 32)), dim3(64), 0, s, ba, dc);
+            DwBatch bt{};
+            dw_batch_add(bt, dwl, sc.G, S, sc.H[nl], tD, R, S, tD, grads->dec_w, grads->dec_b, 0, sc.partial);
+            dw_batch_add(bt, dwl, sc.T0, tD, sc.XH2[l], tD, R, tD, tD, gy.norm2_w, gy.norm2_b, 1, sc.partial);
+            dw_batch_add(bt, dwl, sc.T3, tD, sc.FF1[l], tH, R, tD, tH, gy.lin2_w, gy.lin2_b, 0, sc.partial);
+            dw_batch_add(bt, dwl, sc.dFF1, tH, sc.H1N[l], tD, R, tH, tD, gy.lin1_w, gy.lin1_b, 0, sc.partial);
+            dw_batch_add(bt, dwl, sc.T1, tD, sc.XH1[l], tD, R, tD, tD, gy.norm1_w, gy.norm1_b, 1, sc.partial);
+            dw_batch_add(bt, dwl, dB1, tD, sc.ATT[l], tD, R, tD, tD, gy.out_proj_w, gy.out_proj_b, 0, sc.partial);
+            dw_batch_launch(bt, R, s, B);
+            ATT_LAST(attn_last_bwd, (const float*)sc.QKV[l], (const float*)sc.T5, (const float*)dY1c, (const float*)att_stats, offsets, lens, B, L, sc.dQKV,
+                     sc.T2, dc, l);
+            continue;
+        }
         const bool pre = l + 1 < nl;     // the in_proj backward of the layer above opens this layer's chain
         float* dB1 = dc.on ? sc.T4 : sc.T2;
         LayerBwdArgs ba{sc.T0, pre ? sc.T2 : nullptr, pre ? sc.dQKV : nullptr, pre ? w->layer[l + 1].in_proj_w : nullptr, sc.T0, 0, y,
@@ -2168,6 +2409,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
     launch_dw_list_final(dwl, R, sc.partial, s);   // every weight / bias gradient of the pass: slab sums in one launch
     CIRS_CHECK_LAUNCH("tracker backward slots");
 #undef DW
+#undef ATT_LAST
+#undef ATT_LAST1
 #undef ATT_DISPATCH
 #undef ATT_EP
 #undef ATT_EP1
@@ -2183,6 +2426,16 @@ extern "C" int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tra
     CIRS_REQUIRE(users && act && rew && dstate && grads, "null argument");
     return tracker_rows_impl(cfg, w, st, users, act, rew, row_env, row_t, offsets, lens, n_rows, dstate, grads, workspace, workspace_bytes, stream,
                              nullptr, 0);
+}
+
+extern "C" int cirs_tracker_backward_last(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
+                                          const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
+                                          const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
+                                          const float* dstate_last, const cirs_tracker_grads* grads, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+    CIRS_REQUIRE(users && act && rew && dstate_last && grads, "null argument");
+    return tracker_rows_impl(cfg, w, st, users, act, rew, row_env, row_t, offsets, lens, n_rows, nullptr, grads, workspace, workspace_bytes, stream,
+                             nullptr, 0, dstate_last);
 }
 
 extern "C" int cirs_tracker_prefix_states(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,

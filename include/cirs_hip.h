@@ -485,6 +485,21 @@ int cirs_tracker_backward(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
                           const float* dstate, const cirs_tracker_grads* grads, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* cirs_tracker_backward for an upstream gradient that sits on the LAST row of every env only: dstate_last [n_env, S] = d loss / d state(env b, position
+ * lens[b] - 1) (envs with lens[b] == 0 are ignored); same gradients as cirs_tracker_backward with a dstate that is zero everywhere else.
+ * replaces  the backward of ONE build_state call under live dropout: the policy only receives s_t = the decoder of the last position of the prefix
+ *           (core/state_tracker.py:243-246 `s_t = ...[:, -1, :]` behind the re-run encoder of :170-186), so in that call's graph the top encoder layer is
+ *           needed at one row per env: its attention has one query, its row chain, five of its six weight-gradient problems and the decoder's run on
+ *           n_env rows instead of n_rows; every layer below is the ordinary pass.  The exact-redraw learner (cirs_hip/redraw.py) runs all calls of a
+ *           buffer as ONE such pass over pseudo-envs (call c, env e).
+ * Workspace: cirs_tracker_backward_workspace_bytes(cfg, max(n_rows, cfg->n_env)).  Falls back to the general pass (same results, no saving) for a
+ * one-layer tracker or max_len > 64. */
+int cirs_tracker_backward_last(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
+                               const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
+                               const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
+                               const float* dstate_last, const cirs_tracker_grads* grads, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
 /* Exact-redraw dropout inside the fused rollout (core/state_tracker.py:170-186,243-246: the reference never switches the tracker to eval(), so every
  * build_state call re-runs the encoder over the WHOLE prefix with fresh masks).  cirs_rollout_steps_redraw = cirs_rollout_steps in which the state of
  * vector step t comes from cirs_tracker_prefix_states over positions 0 .. t of every env under the masks of call t (pseudo-env ids env_base0 +

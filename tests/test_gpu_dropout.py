@@ -366,3 +366,57 @@ def test_prefix_states_from_one_launch_equal_the_multi_launch_pass(B, T, nhead, 
     for b in range(B):
         if lens[b] > 0:
             np.testing.assert_allclose(outs[0][b], want[b, lens[b] - 1], atol=3e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,nhead,p,nlayers", [(70, 30, 4, 0.1, 2), (9, 12, 4, 0.0, 2), (11, 12, 2, 0.3, 2), (7, 20, 8, 0.1, 2), (5, 9, 1, 0.2, 2),
+                                                 (6, 40, 4, 0.1, 2), (13, 10, 4, 0.1, 1), (8, 14, 4, 0.1, 3)])
+def test_last_row_pass_equals_the_general_pass(B, T, nhead, p, nlayers, monkeypatch):
+    """cirs_tracker_backward_last (the backward of a build_state call: the upstream gradient sits on every env's LAST row, core/state_tracker.py:243-246)
+    runs its top layer on one row per env -- one-query attention, compact row chain and weight-gradient problems.  It must produce the gradients of
+    cirs_tracker_backward fed a dstate that is zero except on those rows (only the summation order over rows differs), including envs without rows,
+    and its fallbacks (one layer; CIRS_TRACKER_LAST_FULL; max_len > 64) are that general pass exactly."""
+    from cirs_hip.rollout import Trajectory
+    U, I = 40, 60
+    rng = np.random.RandomState(B * T + nhead)
+    tp = rolloutcase.tracker_param_dict(U, I, T, seed=5, nlayers=nlayers)
+    lens = rng.randint(1, T + 1, size=B)
+    lens[rng.randint(0, B)] = 0            # an env without rows (a pseudo-env of a call its env did not live to see)
+    lens[rng.randint(0, B)] = T
+    users = rng.randint(0, U, B); acts = rng.randint(0, I, (B, T)); rews = rng.uniform(0, 1, (B, T))
+    g_last = rng.randn(B, 20).astype(np.float32)
+    G = np.zeros((T + 1, B, 20), np.float32)
+    for b in range(B):
+        if lens[b] > 0:
+            G[lens[b] - 1, b] = g_last[b]
+    from cirs_hip.tracker import DeviceTracker, flat_tracker_params, tracker_param_shapes
+    flat, views = flat_tracker_params(tracker_param_shapes(U, I, nlayers=nlayers), init=tp)
+    trk = DeviceTracker({**views, "pos_encoder.pe": tp["pos_encoder.pe"].float().cuda().contiguous()}, U, I, B, T, nhead=nhead, nlayers=nlayers)
+    trk.enable_training(flat)
+    if p > 0:
+        trk.set_dropout(p)
+        trk.set_dropout_key(99, 17, 1000)
+    trk.reset()
+    trk.init(torch.as_tensor(users))
+    for t in range(T):
+        live = np.where(lens > t + 1)[0]          # slots 0 .. lens - 1 are what the rows read
+        if len(live):
+            trk.step(torch.as_tensor(acts[live, t]), torch.as_tensor(rews[live, t]), env_ids=torch.as_tensor(live.astype(np.int32)).cuda())
+    traj = Trajectory(B, T, 20, "cuda")
+    a = np.where(np.arange(T)[None, :] < lens[:, None], acts, -1)
+    traj.act.copy_(torch.as_tensor(a.T.copy())); traj.rew.copy_(torch.as_tensor(rews.T.copy()))
+    offsets, row_env, row_t = rows_of(lens)
+    dd = lambda x: torch.as_tensor(x).cuda()  # noqa: E731
+    args = (torch.as_tensor(users), traj, dd(row_env), dd(row_t), dd(offsets), dd(lens.astype(np.int32)), int(lens.sum()))
+    trk.backward(*args, dd(G))
+    want = {k: v.clone() for k, v in trk.grad_views.items()}
+    trk.flat_grad.fill_(float("nan"))
+    trk.backward(*args, dd(g_last), last_rows_only=True)
+    for k, gv in trk.grad_views.items():
+        scale = want[k].abs().max().item() + 1e-12
+        err = ((gv - want[k]).abs().max().item()) / scale
+        assert torch.isfinite(gv).all() and err < 2e-5, (k, err)
+    monkeypatch.setenv("CIRS_TRACKER_LAST_FULL", "1")
+    trk.flat_grad.fill_(float("nan"))
+    trk.backward(*args, dd(g_last), last_rows_only=True)
+    for k, gv in trk.grad_views.items():
+        assert torch.equal(gv, want[k]), k
