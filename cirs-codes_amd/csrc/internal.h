@@ -61,6 +61,7 @@ struct TailFuse {
     PickArgs pick;
     uint32_t* visited;
     int force_length, force_done;
+    int slot_only;             // exact-redraw rollout: the tracker part only appends the input slot (the states come from the per-call prefix passes)
     int64_t* act_out;
     float* logp_out;
     double* rew_out;

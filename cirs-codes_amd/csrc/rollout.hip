@@ -306,6 +306,8 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                 tl.pick = PickArgs{q.pv.m, q.n_pad, n_mass_chunks, pol_w->wa, pol_w->ba, q.h2, visited, pol_cfg->n_items, 0, 0, seed, rng_base + (uint32_t)t, zstore};
             }
             tl.force_done = (t + 1 >= force_length) ? 1 : 0;
+            // (exact redraw: obs_{t+1} is overwritten by call t + 1's prefix pass below -- under the same condition -- so the cached decode is not run)
+            tl.slot_only = redraw && (t + 1 < t_end || t + 1 < trk_cfg->max_len) && !getenv("CIRS_REDRAW_FULL_DECODE") ? 1 : 0;
             tl.act_out = act_t; tl.logp_out = traj->logp + (size_t)t * B + q.base; tl.rew_out = rew_t; tl.done_out = done_t;
             tl.ctr_out = traj->ctr + (size_t)t * B + q.base;
             if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, q.n, obs_n, S, &tf, q.st, &tl, img))

@@ -300,6 +300,10 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < kD) st.x_hist[((size_t)e * L + pos) * kD + lane] = x;
+    if (tl.on && tl.slot_only) {      // exact-redraw rollout: the state of every call comes from cirs_tracker_prefix_states over the slots; no cached decode
+        if (lane == 0) st.len[e] = pos + 1;
+        return;
+    }
     // ---- 2. scale + positional encoding ---------------------------------------------------------------------
     float h = x * 5.656854249492381f + pe_pre;  // sqrt(32); pe_pre = pe[pos][o32]
     // dropout (DROP): counter-based masks keyed by (seed, global env, position, layer, site, element), csrc/rng.h

@@ -1219,14 +1219,17 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
                                                 float* __restrict__ DU, float* __restrict__ EU, float* __restrict__ DPRE,
                                                 float* __restrict__ GIN, float* __restrict__ CU, float* __restrict__ CI,
                                                 int32_t* __restrict__ key_user, int32_t* __restrict__ key_item,
-                                                float* __restrict__ contrib_c /* [B, 32] per-env user contribution (merged scatter) or null */) {
+                                                float* __restrict__ contrib_c /* [B, 32] per-env user contribution (merged scatter) or null */,
+                                                int rows_per_wave) {
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     // the gate matrix [32][33] once per workgroup, coalesced, into LDS: lane d then walks ITS row with stride-33 reads (no bank
     // conflicts); from memory that walk is one dword per lane and load, 64 cache lines per instruction, 33 instructions per row
     __shared__ float sG[tD * (tD + 1)];
     for (int q = threadIdx.x; q < tD * (tD + 1); q += 256) sG[q] = w.gate_w[q];
     __syncthreads();
+    // (rows_per_wave > 1: the call batches of the exact-redraw pass, ~0.5 M rows -- the 4 KB gate image per four rows was most of the kernel's traffic)
+    for (int it_r = 0; it_r < rows_per_wave; ++it_r) {
+    const int r = (blockIdx.x * rows_per_wave + it_r) * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const int b = row_env[r], p = row_t[r];
     const int d = lane & 31;
@@ -1273,6 +1276,7 @@ __global__ __launch_bounds__(256) void slot_bwd(cirs_tracker_weights w, const fl
         for (int o = 0; o < tD; ++o) acc = __builtin_fmaf(lane_bcast(dpre, o), sG[o * (tD + 1) + 1 + d], acc);
         if (lane < tD) { CI[(size_t)r * tD + d] = acc; CU[(size_t)r * tD + d] = 0.f; }
         if (lane == 0) { key_item[r] = (int32_t)it; key_user[r] = -1; }
+    }
     }
 }
 
@@ -1590,7 +1594,10 @@ struct PrefixEnvArgs {
 template <int NH> __host__ __device__ constexpr size_t prefix_env_scratch_floats() {     // strips of the attention / the chain's 32 x kRowT tile (never live together)
     return (size_t)EpGeo<NH>::NW * 33 * EpGeo<NH>::strip(32) > (size_t)32 * kRowT ? (size_t)EpGeo<NH>::NW * 33 * EpGeo<NH>::strip(32) : (size_t)32 * kRowT;
 }
-template <int NH> __host__ __device__ constexpr size_t prefix_env_lds_floats() { return (size_t)32 * kPQS + (size_t)32 * kPAS + prefix_env_scratch_floats<NH>() + EpGeo<NH>::keep_words(32); }
+constexpr int kRowBitWords = 6;   // keep bits of one row's chain: 48 Philox blocks (RES1 8 | FF 32 | RES2 8) x 4 bits
+template <int NH> __host__ __device__ constexpr size_t prefix_env_lds_floats() {
+    return (size_t)32 * kPQS + (size_t)32 * kPAS + prefix_env_scratch_floats<NH>() + EpGeo<NH>::keep_words(32) + 32 * kRowBitWords;
+}
 
 #define EP_KEEP(POS, ELEM) dropout_keep(dc.seed, (uint32_t)(dc.env_base + b), (uint32_t)(POS), (uint32_t)layer, (uint32_t)CIRS_DROP_ATTN, (uint32_t)(ELEM), dc.thr)
 // attn_fwd_ep on the tile: every query of the episode (same loops; q / K / V come from the LDS tile, the output rows go to sA)
@@ -1727,12 +1734,42 @@ __device__ __forceinline__ void prefix_attn_last(const float* __restrict__ sQ, f
     __syncthreads();
 }
 #undef EP_KEEP
+// The chain's dropout masks (sites RES1 / FF / RES2 of one layer) for the rows that COUNT, built across the wave: a row needs 48 Philox blocks (~500 cycles each)
+// and in the chain below every lane evaluates the 24 of its half row -- also the lanes of rows beyond the prefix, and in the last layer, of which only the last
+// row is read, all but two lanes.  Here the rows' blocks are dealt to the 64 lanes (n_rows * 48 / 64 each: 1 for the last layer, ~12 on average for the others
+// instead of 24) and left as keep bits in LDS: sB[slot * 6 + w], block idx = 8 w + nibble (RES1 0..7 | FF 8..39 | RES2 40..47), bit = word of the block.
+// Same counters, same masks (rng.h).  slot = row - r_begin; pos_of_lane = the position of the row a lane holds (lane lo = row lo).
+__device__ __forceinline__ void prefix_row_bits(uint32_t* __restrict__ sB, int r_begin, int n_rows, int env, int pos_of_lane, int layer, const DropCfg& dc, int lane) {
+    for (int i = lane; i < 32 * kRowBitWords; i += 64) sB[i] = 0u;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_rows * 48; i0 += 64) {
+        const int i = i0 + lane, rl = i / 48, idx = i - rl * 48;
+        const int pos = __shfl(pos_of_lane, (r_begin + rl) & 31, CIRS_WAVE);
+        if (i < n_rows * 48) {
+            const int site = idx < 8 ? (int)CIRS_DROP_RES1 : (idx < 40 ? (int)CIRS_DROP_FF : (int)CIRS_DROP_RES2);
+            const int g = idx < 8 ? idx : (idx < 40 ? idx - 8 : idx - 40);
+            const u32x4 r = dropout_block(dc.seed, (uint32_t)(dc.env_base + env), (uint32_t)pos, (uint32_t)layer, (uint32_t)site, (uint32_t)g);
+            uint32_t m = 0u;
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) m |= block_word(r, (uint32_t)wd) >= dc.thr ? 1u << wd : 0u;
+            atomicOr(&sB[rl * kRowBitWords + (idx >> 3)], m << (4 * (idx & 7)));
+        }
+    }
+    __syncthreads();
+}
 // layer_rows_fwd's chain on the tile: x = attention output (sA), hrow = layer input (registers, lane = (row, column half)) -> hrow = layer output; the
-// next layer's Q|K|V into sQ when win_next is set
+// next layer's Q|K|V into sQ when win_next is set.  myB (dropout): the six keep-bit words of this lane's row (prefix_row_bits)
 template <bool kDrop>
 __device__ __forceinline__ void prefix_chain(const cirs_tracker_layer& y, const float* __restrict__ win_next, const float* __restrict__ bin_next, int layer,
-                                             const DropCfg& dc, int env, int pos, bool row_ok, int lo, int hi, const float* __restrict__ sA,
+                                             const DropCfg& dc, const uint32_t* __restrict__ myB, bool row_ok, int lo, int hi, const float* __restrict__ sA,
                                              float* __restrict__ sT, float* __restrict__ sQ, float (&hrow)[16]) {
+    uint32_t kb1 = 0u, kbf[4] = {0u, 0u, 0u, 0u}, kb2 = 0u;      // bit j = keep of element 16 hi + j of the site (FF: of hidden block kb)
+    if (kDrop) {
+        kb1 = (myB[0] >> (16 * hi)) & 0xFFFFu;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) kbf[kb] = (myB[1 + kb] >> (16 * hi)) & 0xFFFFu;
+        kb2 = (myB[5] >> (16 * hi)) & 0xFFFFu;
+    }
     float x[16], wo[16], w1[4][16], g1[16], be1[16];
     ep_load(wo, y.out_proj_w + (size_t)lo * tD + 16 * hi);
     ep_load(g1, y.norm1_w + 16 * hi);
@@ -1764,7 +1801,7 @@ __device__ __forceinline__ void prefix_chain(const cirs_tracker_layer& y, const 
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             float v = t[j];
-            if (kDrop) v = drop_apply(dc, v, env, pos, layer, CIRS_DROP_RES1, 16 * hi + j);
+            if (kDrop) v = ((kb1 >> j) & 1u) ? v * dc.inv : 0.f;
             yv[j] = row_ok ? hrow[j] + v : 0.f;
         }
     }
@@ -1802,7 +1839,7 @@ __device__ __forceinline__ void prefix_chain(const cirs_tracker_layer& y, const 
         ep_load(f, sT + lo * kRowT + kb * 32 + 16 * hi);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            if (kDrop) f[j] = drop_apply(dc, f[j], env, pos, layer, CIRS_DROP_FF, kb * 32 + 16 * hi + j);
+            if (kDrop) f[j] = ((kbf[kb] >> j) & 1u) ? f[j] * dc.inv : 0.f;
             if (!row_ok) f[j] = 0.f;
         }
         mm_regs(acc, f, w2[kb]);
@@ -1816,7 +1853,7 @@ __device__ __forceinline__ void prefix_chain(const cirs_tracker_layer& y, const 
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             float v = t[j];
-            if (kDrop) v = drop_apply(dc, v, env, pos, layer, CIRS_DROP_RES2, 16 * hi + j);
+            if (kDrop) v = ((kb2 >> j) & 1u) ? v * dc.inv : 0.f;
             yv[j] = row_ok ? h1n[j] + v : 0.f;
         }
     }
@@ -1844,6 +1881,7 @@ __global__ __launch_bounds__(64) void prefix_env_kernel(PrefixEnvArgs a, DropCfg
     float* sA = sQ + 32 * kPQS;                // [32][32] attention output (row stride kPAS)
     float* sX = sA + 32 * kPAS;                // attention strips | the chain's tile
     uint32_t* sK = reinterpret_cast<uint32_t*>(sX + prefix_env_scratch_floats<NH>());   // dropout keep bits of the layer's attention
+    uint32_t* sB = sK + EpGeo<NH>::keep_words(32);                                       // ... of the layer's row chain (prefix_row_bits)
     const int e = blockIdx.x, len = a.lens[e];
     if (len <= 0) return;
     CIRS_BSTAMP(40);
@@ -1887,8 +1925,13 @@ __global__ __launch_bounds__(64) void prefix_env_kernel(PrefixEnvArgs a, DropCfg
             __syncthreads();
         }
         CIRS_BSTAMP(42 + 2 * l);
-        prefix_chain<kDrop>(a.layer[l], last ? nullptr : a.layer[l + 1].in_proj_w, last ? nullptr : a.layer[l + 1].in_proj_b, l, dc, b, p, row_ok, lo, hi,
-                            sA, sX, sQ, h);
+        // the chain's masks: of the prefix's rows -- in the last layer of its last row alone (the only one the decoder reads; every lane then applies that
+        // row's bits: the other rows' values are never used)
+        // (measured at C3, us per pass: 1 / 16 / 30 rows 37.6 -> 32.0 / 41.8 -> 38.6 / 47.4 -> 47.4 -- at 30 rows the blocks per lane are what they were and no longer
+        // run underneath the chain's MFMAs; choosing per call between the bits and the in-place masks made every case slower: 44 / 50 / 60 us)
+        if (kDrop) prefix_row_bits(sB, last ? len - 1 : 0, last ? 1 : len, b, p, l, dc, lane);
+        prefix_chain<kDrop>(a.layer[l], last ? nullptr : a.layer[l + 1].in_proj_w, last ? nullptr : a.layer[l + 1].in_proj_b, l, dc,
+                            sB + (last ? 0 : lo) * kRowBitWords, row_ok, lo, hi, sA, sX, sQ, h);
         CIRS_BSTAMP(43 + 2 * l);
     }
     // ---- decoder on the last row (prefix_decoder_kernel) -----------------------------------------------------------------------------------------
@@ -2381,8 +2424,9 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
     int32_t* key_user = (int32_t*)sc.RS1[0];
     int32_t* key_item = (int32_t*)sc.RS2[0];
     const bool merged = fused_rows && B <= R;      // one sort for both tables: the per-env user rows sit behind the item rows (third part of QKV[0])
-    hipLaunchKernelGGL(slot_bwd, dim3(cdiv(R, 4)), dim3(256), 0, s, *w, dH, users, act, rew, row_env, row_t, R, B, DU, EU, DPRE,
-                       sc.GIN, CU, CI, key_user, key_item, merged ? CI + (size_t)R * tD : nullptr);
+    const int slot_rpw = R >= (1 << 17) ? 8 : 1;
+    hipLaunchKernelGGL(slot_bwd, dim3(cdiv(R, 4 * slot_rpw)), dim3(256), 0, s, *w, dH, users, act, rew, row_env, row_t, R, B, DU, EU, DPRE,
+                       sc.GIN, CU, CI, key_user, key_item, merged ? CI + (size_t)R * tD : nullptr, slot_rpw);
     if (merged) {
         if (int rc = emb_scatter_merged(key_item, users, lens, CI, R, B, cfg->n_items, cfg->n_users, grads->emb_item, grads->emb_user, sc.sort,
                                         emb_sort_bytes(R + B), s)) return rc;

@@ -1,0 +1,11 @@
+mkdir -p gpurun_out/s2e
+python -m pytest tests/test_gpu_dropout.py -q -x 2>&1 | grep -vE "^RCCL|^HIP|^ROCm|^Hostname|^Librccl" | tail -5 > gpurun_out/s2e/pytest.txt
+cat gpurun_out/s2e/pytest.txt
+python bench.py --steps 20 --warmup 5 --dropout-redraw --no-probes --no-cpu-baseline > gpurun_out/s2e/rd.json 2> gpurun_out/s2e/rd.err
+python - <<'P'
+import json
+d=json.loads(open("gpurun_out/s2e/rd.json").read().strip().splitlines()[-1])
+print("redraw", d["ms_per_step"], d["value"], d.get("rollout_only_ms_per_collect"), d.get("update_only_ms"))
+P
+for r in 1 16 30; do python tools/probes/prefix_prof.py $r 2>&1 | grep -v "launches" ; done > gpurun_out/s2e/prefix_prof.txt
+grep -A8 "p = 0.1" gpurun_out/s2e/prefix_prof.txt
