@@ -143,4 +143,10 @@ int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,
                           long state_stride, const TrunkFuse* tf, hipStream_t s, const TailFuse* tail = nullptr, const float* img = nullptr);
 
+// cirs_tracker_prefix_states with the policy trunk of the produced states in the same launch (exact-redraw rollout: one launch per call instead of two).
+// *fused = 1 when the one-launch pass ran and applied `tf`; 0: the states are written, the caller runs trunk_kernel itself.
+int tracker_prefix_states_trunk(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st, const int32_t* row_env,
+                                const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows, float* state_out, int64_t state_stride,
+                                void* workspace, int64_t workspace_bytes, void* stream, const TrunkFuse* tf, int* fused);
+
 }  // namespace cirs

@@ -249,18 +249,29 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     // ONE batched causal pass over positions 0 .. t of every env with the masks of build_state call t (cirs_tracker_prefix_states, key = the collect's key with
     // pseudo-env ids env_base0 + t * env_stride + e), followed by the trunk of that state; the step kernel keeps writing the input slots and its own state is
     // overwritten by the next call's pass.  (cirs_hip/redraw.py ran this loop from Python: ~18 launches and torch ops per step, host-bound.)
-    auto redraw_state = [&](int t) -> int {
+    // with_trunk: the policy trunk of the call's states (vector step t acts on them) rides in the prefix pass's launch when that is one launch, else trunk_kernel follows
+    auto redraw_state = [&](int t, bool with_trunk) -> int {
         cirs_tracker_cfg cfg_t = *trk_cfg;
         cfg_t.dropout_seed = redraw->dropout_seed;
         cfg_t.drop_env_base = (int32_t)(redraw->env_base0 + (int64_t)t * redraw->env_stride);
         const size_t start = (size_t)B * t * (t + 1) / 2;
-        return cirs_tracker_prefix_states(&cfg_t, trk_w, trk_st, redraw->row_env + start, redraw->row_t + start, redraw->offsets + (size_t)t * B,
-                                          redraw->lens + (size_t)t * B, (int32_t)(B * (t + 1)), traj->obs + (size_t)t * B * S, S, redraw->workspace,
-                                          redraw->workspace_bytes, stream);
+        TrunkFuse tf{};
+        if (with_trunk) { tf.on = 1; tf.cfg = *pol_cfg; tf.w = *pol_w; tf.skip = done_all; tf.h2 = grp[0].h2; tf.value = traj->value + (size_t)t * B; }
+        int fused = 0;
+        if (int rc = tracker_prefix_states_trunk(&cfg_t, trk_w, trk_st, redraw->row_env + start, redraw->row_t + start, redraw->offsets + (size_t)t * B,
+                                                 redraw->lens + (size_t)t * B, (int32_t)(B * (t + 1)), traj->obs + (size_t)t * B * S, S, redraw->workspace,
+                                                 redraw->workspace_bytes, stream, &tf, &fused))
+            return rc;
+        if (with_trunk && !fused) {
+            hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(n_env, 4)), dim3(256), 0, s, *pol_cfg, *pol_w, traj->obs + (size_t)t * B * S, (long)S, n_env, done_all, grp[0].h2,
+                               traj->value + (size_t)t * B, (float*)nullptr);
+            CIRS_CHECK_LAUNCH("trunk_kernel");
+        }
+        return CIRS_OK;
     };
-    if (redraw) { if (int rc = redraw_state(t_begin)) return rc; }
+    if (redraw) { if (int rc = redraw_state(t_begin, true)) return rc; }
     // trunk of the first step of this call (later ones ride on the tracker step)
-    for (int gi = 0; gi < n_groups; ++gi) {
+    for (int gi = 0; gi < n_groups && !redraw; ++gi) {
         const Group& q = grp[gi];
         hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(q.n, 4)), dim3(256), 0, q.st, *pol_cfg, *pol_w,
                            traj->obs + ((size_t)t_begin * B + q.base) * S, (long)S, q.n, done_all + q.base, q.h2,
@@ -313,12 +324,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
             if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, nullptr, act_t, rew_t, nullptr, nullptr, q.n, obs_n, S, &tf, q.st, &tl, img))
                 return rc;
             if (redraw && (t + 1 < t_end || t + 1 < trk_cfg->max_len)) {      // the state of call t + 1 (the last one: obs_next of the final step)
-                if (int rc = redraw_state(t + 1)) return rc;
-                if (t + 1 < t_end) {
-                    hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(q.n, 4)), dim3(256), 0, q.st, *pol_cfg, *pol_w, traj->obs + (size_t)(t + 1) * B * S, (long)S, q.n,
-                                       done_all, q.h2, traj->value + (size_t)(t + 1) * B, (float*)nullptr);
-                    CIRS_CHECK_LAUNCH("trunk_kernel");
-                }
+                if (int rc = redraw_state(t + 1, t + 1 < t_end)) return rc;
             }
         }
     }

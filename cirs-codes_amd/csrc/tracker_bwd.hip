@@ -12,6 +12,7 @@
 #include <hipcub/hipcub.hpp>
 #include "small_gemm.h"
 #include "rng.h"
+#include "internal.h"
 
 namespace cirs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(256) void ln_fwd(const float* __restrict__ Y, const
 // same operand order as rows_gemm_body (same bits), the LayerNorms in the "lane = (row, column half)" layout the next GEMM wants as
 // its A operand (tile transposed through LDS), every activation the backward pass needs written on the way.  5 launches instead of 15.
 constexpr int kRowT = 132;   // LDS tile row stride (floats): 128 columns + 4 -> conflict-free b128 row reads
-__device__ __forceinline__ int acc_row(int s, int hi) { return (s & 3) + 8 * (s >> 2) + 4 * hi; }   // row of accumulator register s
+// (acc_row(s, hi) = row of accumulator register s: bf16x6.h, through internal.h)
 // acc += A (16 k of this lane's row, lane half hi owns k in [16 hi, 16 hi + 16) of the 32-k block) x W rows (wr = &W[n][kk + 16 hi])
 __device__ __forceinline__ void mm_block(sg_f32x16& acc, const float (&a)[16], const float* __restrict__ wr) {
     float bv[16];
@@ -1590,6 +1591,7 @@ struct PrefixEnvArgs {
     float* state_out;
     long state_stride;
     int nl, L, S;
+    TrunkFuse tf;        // on: the policy trunk of the state in the same wavefront (trunk_kernel's row: same fma chains; finished envs get its zeros)
 };
 template <int NH> __host__ __device__ constexpr size_t prefix_env_scratch_floats() {     // strips of the attention / the chain's 32 x kRowT tile (never live together)
     return (size_t)EpGeo<NH>::NW * 33 * EpGeo<NH>::strip(32) > (size_t)32 * kRowT ? (size_t)EpGeo<NH>::NW * 33 * EpGeo<NH>::strip(32) : (size_t)32 * kRowT;
@@ -1937,13 +1939,25 @@ __global__ __launch_bounds__(64) void prefix_env_kernel(PrefixEnvArgs a, DropCfg
     // ---- decoder on the last row (prefix_decoder_kernel) -----------------------------------------------------------------------------------------
     if (lo == len - 1) ep_store(sA + 16 * hi, h, 1.0f);
     __syncthreads();
+    float sval = 0.f;
     if (lane < a.S) {
         float acc = a.dec_b[lane];
 #pragma unroll
         for (int k = 0; k < tD; ++k) acc = __builtin_fmaf(sA[k], a.dec_w[(size_t)lane * tD + k], acc);
         a.state_out[(size_t)e * a.state_stride + lane] = acc;
+        sval = acc;
     }
     CIRS_BSTAMP(50);
+    if (a.tf.on) {
+        if (a.tf.skip && a.tf.skip[e]) {
+            a.tf.h2[(size_t)e * kH + lane] = 0.f;
+            if (lane == 0 && a.tf.value) a.tf.value[e] = 0.f;
+            return;
+        }
+        float *xs = sX, *hs = sX + kH;
+        if (lane < a.S) xs[lane] = sval;
+        trunk_compute(a.tf.cfg, a.tf.w, xs, hs, lane, e, a.tf.h2, a.tf.value, nullptr);
+    }
 }
 
 // ---- a pass whose upstream gradient sits on the LAST row of every episode (cirs_tracker_backward_last: the exact-redraw procedure) -------------------
@@ -2137,7 +2151,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
                              const int32_t* users, const int64_t* act, const double* rew, const int32_t* row_env,
                              const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows,
                              const float* dstate, const cirs_tracker_grads* grads, void* workspace,
-                             int64_t workspace_bytes, void* stream, float* state_out, int64_t state_stride, const float* dstate_last = nullptr) {
+                             int64_t workspace_bytes, void* stream, float* state_out, int64_t state_stride, const float* dstate_last = nullptr,
+                             const cirs::TrunkFuse* ptf = nullptr, int* ptf_fused = nullptr) {
     using namespace cirs;
     CIRS_REQUIRE(cfg && w && st && row_env && row_t && offsets && lens && workspace, "null argument");
     CIRS_REQUIRE(state_out || (users && act && rew && (dstate || dstate_last) && grads), "null argument");
@@ -2201,6 +2216,11 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
         pa.x_hist = st->x_hist; pa.pe = w->pe; pa.row_env = row_env; pa.row_t = row_t; pa.offsets = offsets; pa.lens = lens;
         for (int l = 0; l < nl; ++l) pa.layer[l] = w->layer[l];
         pa.dec_w = w->dec_w; pa.dec_b = w->dec_b; pa.state_out = state_out; pa.state_stride = (long)state_stride; pa.nl = nl; pa.L = L; pa.S = S;
+        if (ptf && ptf->on) {
+            CIRS_REQUIRE(ptf->cfg.hidden == kH && ptf->cfg.dim_state == S && ptf->h2, "prefix states: trunk shape mismatch");
+            pa.tf = *ptf;
+            if (ptf_fused) *ptf_fused = 1;
+        }
 #define PREFIX_ENV(N)                                                                                                                        \
     do {                                                                                                                                     \
         const size_t sh = std::max<size_t>(4 * prefix_env_lds_floats<N>(), 40 * 1024);   /* at most one of these wavefronts per SIMD */        \
@@ -2489,6 +2509,15 @@ extern "C" int cirs_tracker_prefix_states(const cirs_tracker_cfg* cfg, const cir
     CIRS_REQUIRE(state_out && state_stride >= (cfg ? cfg->dim_state : 0), "bad state_out");
     return tracker_rows_impl(cfg, w, st, nullptr, nullptr, nullptr, row_env, row_t, offsets, lens, n_rows, nullptr, nullptr, workspace, workspace_bytes,
                              stream, state_out, state_stride);
+}
+
+int cirs::tracker_prefix_states_trunk(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st, const int32_t* row_env,
+                                      const int32_t* row_t, const int32_t* offsets, const int32_t* lens, int32_t n_rows, float* state_out, int64_t state_stride,
+                                      void* workspace, int64_t workspace_bytes, void* stream, const TrunkFuse* tf, int* fused) {
+    CIRS_REQUIRE(state_out && state_stride >= (cfg ? cfg->dim_state : 0) && fused, "bad state_out");
+    *fused = 0;
+    return tracker_rows_impl(cfg, w, st, nullptr, nullptr, nullptr, row_env, row_t, offsets, lens, n_rows, nullptr, nullptr, workspace, workspace_bytes,
+                             stream, state_out, state_stride, nullptr, tf, fused);
 }
 
 // ---- row-sharded embedding tables (BASELINE configs[4]): the owner rank's ordered scatter of received gradient rows ----------------
