@@ -153,6 +153,7 @@ SIGNATURES = {
                                               _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P]),
     "cirs_ppo_learn_steps": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "cirs_ppo_handoff_status": (C.c_int, [_P, C.c_int32, _P]),
+    "cirs_ppo_update_readback": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "cirs_ppo_learn": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, C.c_int32, C.c_int32,
                                  _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
     "cirs_tracker_backward_workspace_bytes": (C.c_int64, [C.POINTER(TrackerCfg), C.c_int32]),
@@ -195,6 +196,7 @@ SIGNATURES = {
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_uint32, _P, C.c_int32, _P, _P]),
     "cirs_hash_ids": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "cirs_random_permutation": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),
+    "cirs_random_permutations": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P, _P]),
     "cirs_prof_start": (C.c_int, [C.c_int32, C.c_int32]),
     "cirs_prof_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "cirs_eval_coverage": (C.c_int, [_P, C.c_int64, C.c_int32, _P, _P, _P, _P]),

@@ -232,8 +232,11 @@ class CirsEngine:
         if self._lens_pinned is None:
             self._lens_pinned = torch.empty(self.B_total, dtype=torch.int32).pin_memory()
         lens_i32 = lens_d if lens_d.dtype == torch.int32 else lens_d.to(torch.int32)
-        self._lens_pinned.copy_(lens_i32, non_blocking=True)
-        ln.request_handoff_status()     # (4 more bytes in the same read-back: did a hand-off wait of an earlier update's minibatch steps give up?)
+        if lens_i32.is_contiguous() and not os.environ.get("CIRS_READBACK_COPIES"):
+            ln.readback_lens(lens_i32, self._lens_pinned)      # (one launch: the lengths + 4 more bytes -- did a hand-off wait of an earlier update's minibatch steps give up?)
+        else:
+            self._lens_pinned.copy_(lens_i32, non_blocking=True)
+            ln.request_handoff_status()
         done = torch.cuda.Event(); done.record(cur)
         ln.prepare_async(traj, lens_i32)
         done.synchronize()

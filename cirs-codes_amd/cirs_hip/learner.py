@@ -104,6 +104,14 @@ class DeviceLearner:
         abi.check(self._lib.cirs_ppo_handoff_status(self._ho_dev.data_ptr(), 0, self._stream()), "cirs_ppo_handoff_status")
         self._ho_pin.copy_(self._ho_dev, non_blocking=True)
 
+    def readback_lens(self, lens_dev, lens_pinned):
+        """The update's one read-back from one launch: the lengths and the hand-off count straight into pinned host words (cirs_ppo_update_readback)."""
+        if getattr(self, "_ho_dev", None) is None:
+            self._ho_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._ho_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+        abi.check(self._lib.cirs_ppo_update_readback(lens_dev.data_ptr(), int(lens_dev.numel()), lens_pinned.data_ptr(), self._ho_pin.data_ptr(), self._stream()),
+                  "cirs_ppo_update_readback")
+
     def handoff_lost(self):
         """The count last copied by request_handoff_status() (the caller has synchronised with the stream)."""
         return int(self._ho_pin[0]) if getattr(self, "_ho_pin", None) is not None else 0
@@ -220,10 +228,9 @@ class DeviceLearner:
         if perms is not None:
             return torch.as_tensor(np.stack([np.asarray(perms[rep]).astype(np.int32) for rep in range(repeat)])).to(self.device)
         out = torch.empty((repeat, n), dtype=torch.int32, device=self.device)
-        for rep in range(repeat):
-            abi.check(self._lib.cirs_random_permutation(int(n), int(self.perm_seed), int(self.perm_tag), out[rep].data_ptr(), self._stream()),
-                      "cirs_random_permutation")
-            self.perm_tag += 1
+        abi.check(self._lib.cirs_random_permutations(int(n), int(self.perm_seed), int(self.perm_tag), int(repeat), out.data_ptr(), self._stream()),
+                  "cirs_random_permutations")      # (one launch for the repeats: tags perm_tag .. perm_tag + repeat - 1, as one call per repeat drew them)
+        self.perm_tag += repeat
         return out
 
     def learn_dp(self, global_batch, repeat, perms, rank, world, all_reduce, want_tracker_grad=True):
@@ -399,7 +406,7 @@ class DeviceLearner:
         max_mb = max(e - s for s, e in slices)
         ws = self.workspace(max_mb)
         n_steps = repeat * len(slices)
-        losses = torch.zeros((n_steps, 4), dtype=torch.float32, device=self.device)
+        losses = (torch.empty if (not recompute_adv and not step_calls) else torch.zeros)((n_steps, 4), dtype=torch.float32, device=self.device)   # (cirs_ppo_learn writes every row)
         # all permutations of this update at once, before the first minibatch: the launches of the following repeats then
         # queue back to back
         perm_all_d = self._perms_on_device(n, repeat, perms)

@@ -43,7 +43,35 @@ __global__ __launch_bounds__(256) void permutation_kernel(long n, int h, uint64_
     if (i < n) out[i] = (int32_t)permute_index(i, n, h, key);
 }
 
+// `count` permutations of [0, n) (keys by value), out[c][i]: one launch for all the repeats of an update
+constexpr int kMaxPermKeys = 8;
+struct PermKeys { uint64_t k[kMaxPermKeys]; };
+__global__ __launch_bounds__(256) void permutations_kernel(long n, int h, PermKeys keys, int32_t* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    uint64_t key = keys.k[0];
+#pragma unroll
+    for (int q = 1; q < kMaxPermKeys; ++q) key = c == q ? keys.k[q] : key;      // (a select chain: an indexed by-value array would go through scratch)
+    if (i < n) out[(size_t)c * n + i] = (int32_t)permute_index(i, n, h, key);
+}
+
 }  // namespace cirs
+
+extern "C" int cirs_random_permutations(int64_t n, uint64_t seed, uint64_t tag0, int32_t count, int32_t* out, void* stream) {
+    using namespace cirs;
+    if (n <= 0 || count <= 0) return CIRS_OK;
+    CIRS_REQUIRE(out && n <= 0x7FFFFFFF, "bad arguments");
+    int h = 1;
+    while ((1ull << (2 * h)) < (uint64_t)n) ++h;
+    for (int c0 = 0; c0 < count; c0 += kMaxPermKeys) {
+        PermKeys keys{};
+        const int nc = count - c0 < kMaxPermKeys ? count - c0 : kMaxPermKeys;
+        for (int q = 0; q < nc; ++q) keys.k[q] = splitmix64(seed ^ splitmix64(tag0 + (uint64_t)(c0 + q)));
+        hipLaunchKernelGGL(permutations_kernel, dim3(cdiv(n, 256), nc), dim3(256), 0, (hipStream_t)stream, (long)n, h, keys, out + (size_t)c0 * n);
+    }
+    CIRS_CHECK_LAUNCH("permutations_kernel");
+    return CIRS_OK;
+}
 
 extern "C" int cirs_random_permutation(int64_t n, uint64_t seed, uint64_t tag, int32_t* out, void* stream) {
     using namespace cirs;

@@ -262,6 +262,13 @@ __global__ void handoff_status_kernel(int* __restrict__ out, int reset) {
     out[0] = g_handoff_lost;
     if (reset) g_handoff_lost = 0;
 }
+// the one read-back of an update as ONE launch: the episode lengths and the sticky hand-off count written straight to pinned host memory (instead of
+// a status kernel + two device-to-host copies, each a blit launch of ~5 us)
+__global__ __launch_bounds__(256) void update_readback_kernel(const int32_t* __restrict__ lens, int n, int32_t* __restrict__ lens_host, int32_t* __restrict__ lost_host) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lens_host[i] = lens[i];
+    if (i == 0 && lost_host) lost_host[0] = g_handoff_lost;
+}
 __host__ __device__ inline int snap_floats(int S) { return kH * (S + 66) + kH + 1; }      // trunk (w1 | b1 | w2 | b2) + wc | bc
 __host__ __device__ inline int snap_stride(int S) { return (snap_floats(S) + 3) & ~3; }       // (16-byte aligned arrays)
 __host__ inline size_t dwp_floats(int n_pad, int S) {
@@ -2797,6 +2804,14 @@ extern "C" int cirs_ppo_handoff_status(int32_t* lost_out, int32_t reset, void* s
     CIRS_REQUIRE(lost_out, "cirs_ppo_handoff_status: lost_out is null");
     hipLaunchKernelGGL(cirs::handoff_status_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)lost_out, (int)reset);
     CIRS_CHECK_LAUNCH("handoff_status_kernel");
+    return CIRS_OK;
+}
+
+extern "C" int cirs_ppo_update_readback(const int32_t* lens, int32_t n_env, int32_t* lens_host_pinned, int32_t* lost_host_pinned, void* stream) {
+    CIRS_REQUIRE(lens && lens_host_pinned && n_env > 0, "cirs_ppo_update_readback: bad arguments");
+    hipLaunchKernelGGL(cirs::update_readback_kernel, dim3(cirs::cdiv(n_env, 256)), dim3(256), 0, (hipStream_t)stream, lens, (int)n_env, lens_host_pinned,
+                       lost_host_pinned);
+    CIRS_CHECK_LAUNCH("update_readback_kernel");
     return CIRS_OK;
 }
 

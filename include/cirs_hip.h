@@ -379,6 +379,9 @@ int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* grads, float* 
  * (device pointer, one int32) and, with reset != 0, clears it.  A non-zero count means the update it belongs to used incomplete sums or stale
  * weights: the host must treat the update as failed (cirs_hip/learner.py raises at the update's read-back). */
 int cirs_ppo_handoff_status(int32_t* lost_out, int32_t reset, void* stream);
+/* The one read-back of an update (the host needs the episode lengths to schedule the minibatches: len(buffer) in tianshou/policy/base.py:231-244) as one
+ * launch: lens[n_env] and the hand-off count above written straight to PINNED host memory (device-accessible: hipHostMalloc); lost_host_pinned may be NULL. */
+int cirs_ppo_update_readback(const int32_t* lens, int32_t n_env, int32_t* lens_host_pinned, int32_t* lost_host_pinned, void* stream);
 
 /* Data-parallel form of cirs_ppo_minibatch for a learner sharded over ranks.  A GLOBAL minibatch of mb_global rows
  * (idx_global) is split by rows; this rank owns idx_local[mb_local].  Advantage normalisation uses the statistics of
@@ -660,6 +663,8 @@ int cirs_hash_ids(const int64_t* ids, int64_t n, int64_t n_buckets, int64_t* out
  * thread per element, no sort and no host round trip.  Same (seed, tag) -> same permutation (ranks of a data-parallel learner
  * pass the same pair).  The oracle restates it bit for bit. */
 int cirs_random_permutation(int64_t n, uint64_t seed, uint64_t tag, int32_t* out, void* stream);
+/* out[c][i], c < count: the permutations of tags tag0 .. tag0 + count - 1 from one launch (the repeats of an update, core/policy/ppo.py:173-181). */
+int cirs_random_permutations(int64_t n, uint64_t seed, uint64_t tag0, int32_t count, int32_t* out, void* stream);
 
 /* ---- per-kernel timing hook (measurement only; no reference counterpart) ----------------------------------------------
  * cirs_prof_start arms HIP-event pairs around the next `max_samples` launches of one named kernel, recorded on the stream

@@ -113,3 +113,30 @@ def test_device_permutation_is_bit_exact_vs_oracle(n):
     assert oracle_lib.lib().oracle_random_permutation(n, 20230, 11, want.ctypes.data_as(C.c_void_p)) == 0
     assert np.array_equal(got, want)
     assert np.array_equal(np.sort(got), np.arange(n))
+
+
+@pytest.mark.parametrize("n,count", [(1, 1), (1000, 2), (28673, 3), (501, 11)])
+def test_permutations_of_an_update_from_one_launch(n, count):
+    """cirs_random_permutations (all repeats of an update from one launch) = one cirs_random_permutation per tag, i.e. the oracle's, bit for bit."""
+    import ctypes as C
+    import oracle_lib
+    from cirs_hip import abi
+    out = torch.empty((count, n), dtype=torch.int32, device="cuda")
+    abi.check(abi.lib().cirs_random_permutations(n, 777, 40, count, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "perms")
+    got = out.cpu().numpy()
+    for c in range(count):
+        want = np.empty(n, np.int32)
+        assert oracle_lib.lib().oracle_random_permutation(n, 777, 40 + c, want.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(got[c], want), c
+
+
+def test_update_readback_writes_pinned_host_words():
+    """cirs_ppo_update_readback: the lengths and the hand-off count land in pinned host memory from one launch (no copy)."""
+    from cirs_hip import abi
+    n = 1500
+    lens = torch.randint(1, 31, (n,), dtype=torch.int32, device="cuda")
+    host = torch.full((n,), -1, dtype=torch.int32).pin_memory()
+    lost = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+    abi.check(abi.lib().cirs_ppo_update_readback(lens.data_ptr(), n, host.data_ptr(), lost.data_ptr(), torch.cuda.current_stream().cuda_stream), "readback")
+    torch.cuda.synchronize()
+    assert torch.equal(host, lens.cpu()) and int(lost[0]) == 0
