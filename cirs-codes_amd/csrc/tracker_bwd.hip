@@ -302,6 +302,35 @@ __device__ __forceinline__ void ep_stage(float* __restrict__ dst, const float* _
         *reinterpret_cast<f32x4*>(dst + (size_t)row * cols + 4 * c4) = *reinterpret_cast<const f32x4*>(src + (size_t)row * src_stride + 4 * c4);
     }
 }
+// The same staging in two halves, for the episode's first (at most) 32 rows: all loads requested at once into registers (unconditional, clamped: they batch),
+// committed to LDS later -- whatever runs in between (the keep bits' Philox blocks) runs under the memory round trip.  NQ = 32 * COLS / 256 float4 per lane.
+template <int COLS, int NQ>
+__device__ __forceinline__ void ep_stage_issue(f32x4 (&r)[NQ], const float* __restrict__ src, int rows, int src_stride, int tid) {
+    constexpr int c4n = COLS >> 2;
+    static_assert(NQ * 64 >= 32 * c4n, "registers for 32 rows");
+    const int n = rows * c4n;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = min(tid + 64 * q, n - 1), row = i / c4n, c4 = i - row * c4n;
+        r[q] = *reinterpret_cast<const f32x4*>(src + (size_t)row * src_stride + 4 * c4);
+    }
+}
+template <int COLS, int NQ>
+__device__ __forceinline__ void ep_stage_commit(float* __restrict__ dst, const f32x4 (&r)[NQ], int rows, int tid) {
+    constexpr int c4n = COLS >> 2;
+    const int n = rows * c4n;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = tid + 64 * q, row = i / c4n, c4 = i - row * c4n;
+        if (i < n) *reinterpret_cast<f32x4*>(dst + (size_t)row * COLS + 4 * c4) = r[q];
+    }
+}
+// one-wavefront workgroups: LDS operations of a wavefront complete in order, so "everything before is visible to every lane" is a wait for the LDS counter
+// -- NOT __syncthreads(), whose release fence also waits for every global load in flight (the staged rows above)
+__device__ __forceinline__ void ep_wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 template <int N> __device__ __forceinline__ void ep_load(float (&v)[N], const float* __restrict__ src) {
 #pragma unroll
     for (int d4 = 0; d4 < N / 4; ++d4) {
@@ -329,8 +358,9 @@ template <int HD> __device__ __forceinline__ float ep_dot(const float* a, const 
 // Rows p and len - 1 - p are folded into one work row (together len + 1 keys) so that the lanes' item counts are even.
 template <int NH>
 __device__ __forceinline__ void ep_keep_build(uint32_t* __restrict__ sK, int len, int b, int layer, const DropCfg& dc, int tid, int nt) {
+    // (every caller is a one-wavefront workgroup: wave syncs, so that global loads in flight stay in flight)
     for (int i = tid; i < len * NH * 2; i += nt) sK[i] = 0u;
-    __syncthreads();
+    ep_wave_sync();
     const int half = (len + 1) >> 1;                       // folded rows
     const int bpr = (((len + 1) * NH + 3) >> 2) + 1;       // blocks per folded row (both parts rounded up)
     for (int i = tid; i < half * bpr; i += nt) {
@@ -348,7 +378,7 @@ __device__ __forceinline__ void ep_keep_build(uint32_t* __restrict__ sK, int len
             }
         }
     }
-    __syncthreads();
+    ep_wave_sync();
 }
 // the same bits for ONE query p (the last layer of the prefix pass only attends from the last row): sK[h * 2 + (j >> 5)]
 template <int NH>
@@ -369,7 +399,8 @@ __device__ __forceinline__ bool ep_keep_bit(const uint32_t (&m)[2], int j) { ret
 
 template <int NH, bool kDrop>
 __global__ __launch_bounds__(64) void attn_fwd_ep(const float* __restrict__ QKV, const int32_t* __restrict__ offsets,
-                                                  const int32_t* __restrict__ lens, int Lp, float* __restrict__ ATT, DropCfg dc, int layer) {
+                                                  const int32_t* __restrict__ lens, int Lp, float* __restrict__ ATT, DropCfg dc, int layer,
+                                                  uint32_t* __restrict__ keep_out /* nullable: the keep bits, [row][head][2] words, for attn_bwd_ep */) {
     using G = EpGeo<NH>;
     constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD, SL = G::SL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -380,8 +411,17 @@ __global__ __launch_bounds__(64) void attn_fwd_ep(const float* __restrict__ QKV,
     float* sKV = smem;                          // [len][K 32 | V 32]
     float* sS = smem + (size_t)Lp * 64;         // [head group][query | dummy row Lp][HPL][Lp] (query stride STR)
     uint32_t* sK = reinterpret_cast<uint32_t*>(sS + (size_t)G::NW * (Lp + 1) * STR);   // dropout keep bits [query][head][2]
-    ep_stage(sKV, QKV + (size_t)base * 96 + tD, len, 96, 64, lane, 64);
-    if (kDrop) ep_keep_build<NH>(sK, len, b, layer, dc, lane, 64);
+    // the first 32 rows' K | V: requested now, committed behind the keep bits (their ~8 Philox blocks per lane run under the round trip)
+    const int len32 = min(len, 32);
+    f32x4 st_kv[8];
+    ep_stage_issue<64, 8>(st_kv, QKV + (size_t)base * 96 + tD, len32, 96, lane);
+    if (kDrop) {
+        ep_keep_build<NH>(sK, len, b, layer, dc, lane, 64);
+        if (keep_out)
+            for (int i = lane; i < len * NH * 2; i += 64) keep_out[(size_t)base * NH * 2 + i] = sK[i];
+    }
+    ep_stage_commit<64, 8>(sKV, st_kv, len32, lane);
+    if (len > 32) ep_stage(sKV + 32 * 64, QKV + (size_t)(base + 32) * 96 + tD, len - 32, 96, 64, lane, 64);
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;   // q * scale * log2(e): scores in log2 units
     for (int s0 = 0; 2 * s0 < len; s0 += SL) {
@@ -471,7 +511,8 @@ __global__ __launch_bounds__(64) void attn_fwd_ep(const float* __restrict__ QKV,
 template <int NH, bool kDrop>
 __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV, const float* __restrict__ dATT,
                                                   const int32_t* __restrict__ offsets, const int32_t* __restrict__ lens, int Lp,
-                                                  float* __restrict__ dQKV, DropCfg dc, int layer) {
+                                                  float* __restrict__ dQKV, DropCfg dc, int layer,
+                                                  const uint32_t* __restrict__ keep_in /* nullable: attn_fwd_ep's keep bits of the same rows and key */) {
     using G = EpGeo<NH>;
     constexpr int HPL = G::HPL, DPL = G::DPL, HD = G::HD, SL = G::SL;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -486,9 +527,27 @@ __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV,
     float* sI = sM + (size_t)NH * Lp;                    //                           1 / sum
     uint32_t* sK = reinterpret_cast<uint32_t*>(sI + (size_t)NH * Lp);   // dropout keep bits [query][head][2]
     CIRS_BWG(layer == 1, 0);
-    ep_stage(sQKV, QKV + (size_t)base * 96, len, 96, 96, lane, 64);
-    ep_stage(sdA, dATT + (size_t)base * tD, len, tD, tD, lane, 64);
-    if (kDrop) ep_keep_build<NH>(sK, len, b, layer, dc, lane, 64);
+    CIRS_BSTAMP(39);
+    // the first 32 rows' Q | K | V and dATT rows: all requested at once (16 float4 per lane), committed behind the keep bits -- which come from the forward
+    // pass's launch when it left them (a 1 KB load instead of ~8 Philox blocks per lane), else are rebuilt under the round trip
+    const int len32 = min(len, 32);
+    f32x4 st_q[12], st_d[4];
+    ep_stage_issue<96, 12>(st_q, QKV + (size_t)base * 96, len32, 96, lane);
+    ep_stage_issue<tD, 4>(st_d, dATT + (size_t)base * tD, len32, tD, lane);
+    CIRS_BSTAMP(38);
+    if (kDrop) {
+        if (keep_in) {
+            for (int i = lane; i < len * NH * 2; i += 64) sK[i] = keep_in[(size_t)base * NH * 2 + i];
+        } else {
+            ep_keep_build<NH>(sK, len, b, layer, dc, lane, 64);
+        }
+    }
+    ep_stage_commit<96, 12>(sQKV, st_q, len32, lane);
+    ep_stage_commit<tD, 4>(sdA, st_d, len32, lane);
+    if (len > 32) {
+        ep_stage(sQKV + 32 * 96, QKV + (size_t)(base + 32) * 96, len - 32, 96, 96, lane, 64);
+        ep_stage(sdA + 32 * tD, dATT + (size_t)(base + 32) * tD, len - 32, tD, tD, lane, 64);
+    }
     __syncthreads();
     CIRS_BSTAMP(40);
     const float scale = 1.0f / sqrtf((float)HD), qs = scale * 1.4426950408889634f;
@@ -537,6 +596,7 @@ __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV,
                 mxB[h] = inB ? fmaxf(mxB[h], sb) : mxB[h];
             }
         }
+        CIRS_BSTAMP(45);
         ep_load(vq, sQKV + 64 + hg * DPL);
 #pragma unroll 4
         for (int j = 0; j < jn; ++j) {
@@ -560,6 +620,7 @@ __global__ __launch_bounds__(64) void attn_bwd_ep(const float* __restrict__ QKV,
                 dotB[h] = __builtin_fmaf(eb, dpb, dotB[h]);
             }
         }
+        CIRS_BSTAMP(46);
         float invA[HPL], invB[HPL];
 #pragma unroll
         for (int h = 0; h < HPL; ++h) {
@@ -2282,7 +2343,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
             else hipLaunchKernelGGL(layer_rows_fwd<false>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
             continue;
         }
-        if (ep) ATT_EP(attn_fwd_ep, false, (const float*)sc.QKV[l], offsets, lens, L, sc.ATT[l], dc, l);
+        // (dropout: the forward launch leaves its keep bits in the probability scratch of the row-wise path, unused here, for the backward launch -- not in the prefix pass)
+        if (ep) ATT_EP(attn_fwd_ep, false, (const float*)sc.QKV[l], offsets, lens, L, sc.ATT[l], dc, l, (dc.on && !state_out) ? reinterpret_cast<uint32_t*>(sc.P[l]) : (uint32_t*)nullptr);
         else ATT_DISPATCH_SH(attn_fwd, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], row_env, row_t, offsets, R, L, sc.P[l], sc.ATT[l], dc, l, sc.PM[l]);
         if (fused_rows && state_out && l == nl - 1 && !getenv("CIRS_TRACKER_PREFIX_FULL")) {      // prefix states: the last layer's row chain on the envs' last rows only
             static_assert(tD == 32, "prefix_last_rows_kernel maps 32 columns to 32 threads");
@@ -2372,7 +2434,7 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
         dw_batch_launch(bt, R, s);
         const float* dATT = sc.T5;
         if (ep) {
-            ATT_EP(attn_bwd_ep, true, (const float*)sc.QKV[l], dATT, offsets, lens, L, sc.dQKV, dc, l);
+            ATT_EP(attn_bwd_ep, true, (const float*)sc.QKV[l], dATT, offsets, lens, L, sc.dQKV, dc, l, dc.on ? reinterpret_cast<const uint32_t*>(sc.P[l]) : (const uint32_t*)nullptr);
         } else {
             ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV,
                             (const float*)sc.PM[l], dc.inv);
@@ -2417,7 +2479,7 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
         DW_ROWS(sc.ATT[l], tD, tD, gy.out_proj_w, gy.out_proj_b, false, dB1, tD, y.out_proj_w, tD, nullptr, R, tD, tD, 0, nullptr, 0, dATT, tD);
         // attention (dropout: V is weighted by the masked probabilities PM; the softmax backward runs on P)
         if (ep) {
-            ATT_EP(attn_bwd_ep, true, (const float*)sc.QKV[l], (const float*)dATT, offsets, lens, L, sc.dQKV, dc, l);
+            ATT_EP(attn_bwd_ep, true, (const float*)sc.QKV[l], (const float*)dATT, offsets, lens, L, sc.dQKV, dc, l, dc.on ? reinterpret_cast<const uint32_t*>(sc.P[l]) : (const uint32_t*)nullptr);
         } else {
             ATT_DISPATCH_SH(attn_bwd_q, (size_t)4 * NH * L * sizeof(float), sc.QKV[l], sc.P[l], dATT, row_env, row_t, offsets, R, L, sc.dS, sc.dQKV,
                             (const float*)sc.PM[l], dc.inv);
