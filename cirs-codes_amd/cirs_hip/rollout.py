@@ -5,6 +5,7 @@ Host-side counterpart of reference core/collector.py:147-367 for the case the re
 replay buffer (VectorReplayBuffer order = env-major concatenation of the per-env episodes).
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -129,8 +130,22 @@ class DeviceRollout:
         without any host sync; idle steps of finished envs are no-ops)."""
         if self.tracker.cfg.dropout_p > 0:   # fresh masks per collect (the reference draws fresh dropout noise at every call)
             self.tracker.set_dropout_key(seed >> 8 if self.dropout_key_from_high_bits else seed, rng_base, self.dropout_env_base)
-        self.reset(users)
         T = self.env.max_turn
+        if gumbel is None and sync_every is None and self.online is None and not os.environ.get("CIRS_ROLLOUT_STEPWISE_RESET"):
+            # reset_env + the whole collect from one call (cirs_rollout_collect): no clears, the tracker's first position from the packed weight image
+            # with the first trunk in its launch -- the same bits as reset() + run_steps(0, T) (tests/test_gpu_rollout.py)
+            users_d = users.to(self.device, torch.int32).contiguous()
+            if self.visited is not None:
+                self.visited.zero_()
+            ws = self.policy.workspace(self.env.n_env)
+            abi.check(self._lib.cirs_rollout_collect(
+                C.byref(self.env.cfg), C.byref(self.env._tab), C.byref(self.env._st), C.byref(self.tracker.cfg),
+                C.byref(self.tracker.w), C.byref(self.tracker.st), C.byref(self.policy.cfg), C.byref(self.policy.w),
+                C.byref(self.traj.struct), self.env.n_env, users_d.data_ptr(), seed, rng_base, abi.ptr(self.visited),
+                self.force_length, ws.data_ptr(), ws.numel(), self._stream()), "cirs_rollout_collect")
+            self._users_keepalive = users_d
+            return self.env.turn.clone()
+        self.reset(users)
         if gumbel is not None:
             gumbel = torch.as_tensor(gumbel).to(self.device, torch.float32).contiguous()
             self.run_steps(0, T, seed, rng_base, gumbel=gumbel)

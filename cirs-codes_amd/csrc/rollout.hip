@@ -54,7 +54,23 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                         const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
                         int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited, int32_t force_length,
                         const cirs_online_reward* online, const float* gumbel, void* workspace, int64_t workspace_bytes, void* stream,
-                        const cirs_redraw* redraw = nullptr);
+                        const cirs_redraw* redraw = nullptr, const int32_t* init_users = nullptr);
+
+// Collector.reset_env + collect(n_episode = n_env) from ONE call (core/collector.py:123-134,147-367): env reset, the tracker's first position (from the packed
+// weight image, the first step's trunk in its launch), the max_turn vector steps.  Every trajectory entry [t][env] is written (finished envs: act -1, done 1,
+// rew / ctr 0), so the caller clears nothing; the tracker lengths restart at 1.
+extern "C" int cirs_rollout_collect(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                                    const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                                    const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
+                                    const int32_t* users, uint64_t seed, uint32_t rng_base, uint32_t* visited, int32_t force_length, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    CIRS_REQUIRE(env_cfg && env_st && users && workspace && n_env > 0, "cirs_rollout_collect: null argument");
+    CIRS_REQUIRE(workspace_bytes >= (int64_t)sizeof(int64_t) * n_env, "workspace too small");
+    // (the reset's obs ids -- the users -- land in the head of the workspace: scratch nobody reads; the sampler overwrites it)
+    if (int rc = cirs_env_reset(env_cfg, env_st, users, nullptr, n_env, (int64_t*)workspace, stream)) return rc;
+    return rollout_impl(env_cfg, env_tab, env_st, trk_cfg, trk_w, trk_st, pol_cfg, pol_w, traj, n_env, 0, env_cfg->max_turn, seed, rng_base, visited, force_length,
+                        nullptr, nullptr, workspace, workspace_bytes, stream, nullptr, users);
+}
 
 extern "C" int cirs_rollout_steps_redraw(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
                                          const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
@@ -103,7 +119,7 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
                         const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj, int32_t n_env,
                         int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base, uint32_t* visited, int32_t force_length,
                         const cirs_online_reward* online, const float* gumbel, void* workspace, int64_t workspace_bytes, void* stream,
-                        const cirs_redraw* redraw) {
+                        const cirs_redraw* redraw, const int32_t* init_users) {
     using namespace cirs;
     cirs_env_tables tab_local;
     if (online) {
@@ -269,9 +285,22 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
         }
         return CIRS_OK;
     };
+    // cirs_rollout_collect: the tracker's first position (Collector.reset_env's preprocess_fn(obs = ...)) from the packed image, with the trunk of the first
+    // vector step in its launch (one group) -- cirs_tracker_init's row-major weight reads were 23 us per collect, the separate trunk launch 6
+    bool first_trunk_done = false;
+    if (init_users) {
+        TrunkFuse tf0{};
+        if (n_groups == 1 && !redraw) {
+            tf0.on = 1; tf0.cfg = *pol_cfg; tf0.w = *pol_w; tf0.skip = nullptr; tf0.h2 = grp[0].h2; tf0.value = traj->value + (size_t)t_begin * B;
+            first_trunk_done = true;
+        }
+        if (int rc = tracker_step_internal(trk_cfg, trk_w, trk_st, init_users, nullptr, nullptr, nullptr, nullptr, n_env, traj->obs + (size_t)t_begin * B * S, S, &tf0, s,
+                                           nullptr, img))
+            return rc;
+    }
     if (redraw) { if (int rc = redraw_state(t_begin, true)) return rc; }
     // trunk of the first step of this call (later ones ride on the tracker step)
-    for (int gi = 0; gi < n_groups && !redraw; ++gi) {
+    for (int gi = 0; gi < n_groups && !redraw && !first_trunk_done; ++gi) {
         const Group& q = grp[gi];
         hipLaunchKernelGGL(trunk_kernel, dim3(cdiv(q.n, 4)), dim3(256), 0, q.st, *pol_cfg, *pol_w,
                            traj->obs + ((size_t)t_begin * B + q.base) * S, (long)S, q.n, done_all + q.base, q.h2,

@@ -279,6 +279,15 @@ int cirs_rollout_steps(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_t
                        int32_t n_env, int32_t t_begin, int32_t t_end, uint64_t seed, uint32_t rng_base,
                        uint32_t* visited, int32_t force_length, void* workspace, int64_t workspace_bytes,
                        void* stream);
+/* Collector.reset_env + one collect(n_episode = n_env) from ONE call (core/collector.py:123-134: reset_env -> env.reset + preprocess_fn(obs = ...);
+ * :147-367: the loop): env reset with users[n_env], the tracker's first position (cirs_tracker_init's arithmetic from the step kernel's packed weight image,
+ * the first vector step's trunk in the same launch), then cirs_rollout_steps(0, max_turn).  Every trajectory entry [t][env] is written (envs that finished
+ * earlier: act -1, done 1, rew / ctr 0), so nothing has to be cleared before the call. */
+int cirs_rollout_collect(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_tab, cirs_env_state* env_st,
+                         const cirs_tracker_cfg* trk_cfg, const cirs_tracker_weights* trk_w, cirs_tracker_state* trk_st,
+                         const cirs_policy_cfg* pol_cfg, const cirs_policy_weights* pol_w, const cirs_traj* traj,
+                         int32_t n_env, const int32_t* users, uint64_t seed, uint32_t rng_base, uint32_t* visited,
+                         int32_t force_length, void* workspace, int64_t workspace_bytes, void* stream);
 /* same loop with HARNESS-SUPPLIED sampler noise instead of the counter-based generator: gumbel [max_turn][n_env][n_items] f32,
  * g = -log q with q ~ Exp(1) (torch.multinomial's race noise, core/policy/ppo.py:148-155 `dist.sample()`), row t is used at
  * vector step t and indexed by ORIGINAL item id also when recommended ids are masked (core/policy/utils.py:30-58): the device

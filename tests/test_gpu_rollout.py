@@ -143,3 +143,36 @@ def test_small_count_switches_keep_the_draws(monkeypatch):
         assert torch.equal(a, b)
     assert torch.equal(runs["default"][0], runs["no_store"][0]), "ids differ between the logit store and the recomputed chunk (a 1e-6 margin case?)"
     np.testing.assert_allclose(runs["default"][1].cpu().numpy(), runs["no_store"][1].cpu().numpy(), rtol=0, atol=1e-5)      # (observed 3.1e-6 on log-probs of -8)
+
+
+@pytest.mark.parametrize("U,I,B,T,kw", [(60, 150, 24, 12, dict(N=3, thr=1)), (1411, 3327, 64, 30, {}), (300, 2000, 200, 9, dict(N=2, thr=2, remove_recommended_ids=True))])
+def test_collect_from_one_call_equals_reset_plus_steps(U, I, B, T, kw, monkeypatch):
+    """cirs_rollout_collect (env reset, the tracker's first position from the packed weight image with the first trunk in its launch, all vector steps; no
+    clears) leaves the trajectory, the tracker's slots and the env state of reset() + cirs_rollout_steps(0, T), bit for bit -- also on a trajectory buffer
+    that still holds another collect's entries."""
+    from cirs_hip.synthetic import make_tables
+    tab = make_tables(U, I, seed=0, build_dist=False)
+    users = torch.as_tensor(np.random.RandomState(2).randint(0, U, B))
+    users2 = torch.as_tensor(np.random.RandomState(3).randint(0, U, B))
+    got = {}
+    for mode in ("one call", "stepwise"):
+        if mode == "stepwise":
+            monkeypatch.setenv("CIRS_ROLLOUT_STEPWISE_RESET", "1")
+        else:
+            monkeypatch.delenv("CIRS_ROLLOUT_STEPWISE_RESET", raising=False)
+        ro, tp, arrs, envp = rolloutcase.build_device_stack(tab, B, T, **kw)
+        ro.collect(users2, seed=9, rng_base=3)          # (a previous collect: its entries must not shine through)
+        lens = ro.collect(users, seed=21, rng_base=50)
+        tr = ro.traj
+        got[mode] = dict(lens=lens.clone(), act=tr.act.clone(), rew=tr.rew.clone(), done=tr.done.clone(), logp=tr.logp.clone(), value=tr.value.clone(),
+                         ctr=tr.ctr.clone(), obs=tr.obs.clone(), x_hist=ro.tracker.x_hist.clone(), tlen=ro.tracker.len.clone(), turn=ro.env.turn.clone(),
+                         edone=ro.env.done.clone())
+    a, b = got["one call"], got["stepwise"]
+    for k in ("lens", "act", "rew", "done", "logp", "ctr", "tlen", "turn", "edone"):
+        assert torch.equal(a[k], b[k]), k
+    live = a["act"] >= 0
+    assert torch.equal(a["value"][live], b["value"][live])
+    lens = a["lens"].cpu().numpy()
+    for e in range(B):
+        assert torch.equal(a["obs"][:lens[e] + 1, e], b["obs"][:lens[e] + 1, e]), e
+        assert torch.equal(a["x_hist"][e, :lens[e] + 1], b["x_hist"][e, :lens[e] + 1]), e
