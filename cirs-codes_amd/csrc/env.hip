@@ -32,20 +32,7 @@ __global__ __launch_bounds__(256) void env_reset_kernel(cirs_env_cfg cfg, cirs_e
                                                         const int32_t* __restrict__ users,
                                                         const int32_t* __restrict__ env_ids, int n,
                                                         int64_t* __restrict__ obs_out) {
-    const int T = cfg.max_turn;
-    const long total = (long)n * T;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(i / T), k = (int)(i % T);
-        const int e = env_ids ? env_ids[j] : j;
-        st.hist_action[(size_t)e * T + k] = 0;
-        if (k == 0) {
-            st.user[e] = users[j];
-            st.turn[e] = 0;
-            st.done[e] = 0;
-            st.cum_reward[e] = 0.0;
-            if (obs_out) obs_out[j] = users[j];
-        }
-    }
+    env_reset_body(cfg, st, users, env_ids, n, obs_out, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 __global__ __launch_bounds__(256) void dist_jaccard_kernel(const uint32_t* __restrict__ item_cats, int n_items,

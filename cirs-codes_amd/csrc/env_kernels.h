@@ -23,6 +23,25 @@ __device__ __forceinline__ EnvPrefetch env_prefetch(const cirs_env_cfg& cfg, con
     p.u = st.user[e]; p.t = st.turn[e]; p.done = st.done[e]; p.cum = st.cum_reward[e];
     return p;
 }
+// env.reset for envs j < n (kuaishouEnv.py:155-171 / simulated_env.py:63-75): thread gtid of gthreads walks (env, history slot) pairs
+__device__ __forceinline__ void env_reset_body(const cirs_env_cfg& cfg, const cirs_env_state& st, const int32_t* __restrict__ users,
+                                               const int32_t* __restrict__ env_ids, int n, int64_t* __restrict__ obs_out, long gtid, long gthreads) {
+    const int T = cfg.max_turn;
+    const long total = (long)n * T;
+    for (long i = gtid; i < total; i += gthreads) {
+        const int j = (int)(i / T), k = (int)(i % T);
+        const int e = env_ids ? env_ids[j] : j;
+        st.hist_action[(size_t)e * T + k] = 0;
+        if (k == 0) {
+            st.user[e] = users[j];
+            st.turn[e] = 0;
+            st.done[e] = 0;
+            st.cum_reward[e] = 0.0;
+            if (obs_out) obs_out[j] = users[j];
+        }
+    }
+}
+
 __device__ __forceinline__ void env_step_wave(const cirs_env_cfg& cfg, const cirs_env_tables& tab, const cirs_env_state& st, int e, int j,
                                               int64_t action, int lane, int64_t* __restrict__ obs_out, double* __restrict__ rew_out,
                                               uint8_t* __restrict__ done_out, double* __restrict__ ctr_out,

@@ -135,9 +135,11 @@ inline int build_rplanes(const float* wa, int n_items, uint4* planes, hipStream_
     return CIRS_OK;
 }
 
-// img <- the image of (w, pol); pol may be null (no trunk fusion)
+// img <- the image of (w, pol); pol may be null (no trunk fusion).  In the same launch, on workgroups of their own: the sampler's planes of the actor head
+// (planes non-null: build_rplanes) and env.reset for envs 0 .. n_env-1 (ecfg non-null: cirs_env_reset) -- what a collect sets up before its first step.
 int pack_tracker_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_policy_weights* pol, int S, float* img,
-                       hipStream_t s);
+                       hipStream_t s, const float* wa = nullptr, int n_items = 0, uint4* planes = nullptr, const cirs_env_cfg* ecfg = nullptr,
+                       const cirs_env_state* est = nullptr, const int32_t* users = nullptr, int n_env = 0, int64_t* obs_scratch = nullptr);
 
 int tracker_step_internal(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, cirs_tracker_state* st, const int32_t* users,
                           const int64_t* items, const double* rew, const int32_t* env_ids, const uint8_t* skip, int n, float* state_out,

@@ -66,8 +66,8 @@ extern "C" int cirs_rollout_collect(const cirs_env_cfg* env_cfg, const cirs_env_
                                     int64_t workspace_bytes, void* stream) {
     CIRS_REQUIRE(env_cfg && env_st && users && workspace && n_env > 0, "cirs_rollout_collect: null argument");
     CIRS_REQUIRE(workspace_bytes >= (int64_t)sizeof(int64_t) * n_env, "workspace too small");
-    // (the reset's obs ids -- the users -- land in the head of the workspace: scratch nobody reads; the sampler overwrites it)
-    if (int rc = cirs_env_reset(env_cfg, env_st, users, nullptr, n_env, (int64_t*)workspace, stream)) return rc;
+    // (env.reset rides in the setup launch of rollout_impl; its obs ids -- the users -- land in the head of the workspace: scratch nobody reads)
+    CIRS_REQUIRE(env_st->user && env_st->turn && env_st->done && env_st->hist_action && env_st->cum_reward, "env state has null field");
     return rollout_impl(env_cfg, env_tab, env_st, trk_cfg, trk_w, trk_st, pol_cfg, pol_w, traj, n_env, 0, env_cfg->max_turn, seed, rng_base, visited, force_length,
                         nullptr, nullptr, workspace, workspace_bytes, stream, nullptr, users);
 }
@@ -211,10 +211,11 @@ static int rollout_impl(const cirs_env_cfg* env_cfg, const cirs_env_tables* env_
     // packed weight image of the step kernel (tracker + policy trunk), rebuilt per call (the weights change between calls) on the
     // caller's stream, before the group streams fork from it
     float* img = (float*)((char*)workspace + ((workspace_bytes - kTrkImgBytes) & ~(int64_t)255));
-    if (int rc = pack_tracker_image(trk_cfg, trk_w, pol_w, S, img, s)) return rc;
-    // bf16 planes of the actor head for the chunk-mass kernels, likewise once per call
+    // ... the fp16 planes of the actor head for the chunk-mass kernels, likewise once per call, and (cirs_rollout_collect) env.reset: one launch
     uint4* rplanes = ws_rplanes(workspace, workspace_bytes, pol_cfg->n_items);
-    if (!gumbel) { if (int rc = build_rplanes(pol_w->wa, pol_cfg->n_items, rplanes, s)) return rc; }
+    if (int rc = pack_tracker_image(trk_cfg, trk_w, pol_w, S, img, s, pol_w->wa, pol_cfg->n_items, gumbel ? nullptr : rplanes, init_users ? env_cfg : nullptr, env_st,
+                                    init_users, n_env, (int64_t*)workspace))
+        return rc;
     // group streams / events: one set per (host thread, device) -- a stream belongs to the device that was current when it was
     // created, and two host threads driving rollouts concurrently (the virtual-rank tests) must not share the event array
     constexpr int kMaxDevices = 16;

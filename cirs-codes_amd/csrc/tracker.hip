@@ -595,9 +595,36 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
 }
 
 // ---- packed weight image (internal.h: TrkImg) -------------------------------------------------------------------------------
+// What a collect sets up before its first vector step, as ONE launch (three independent jobs on disjoint workgroups): the step kernel's weight image
+// (the first n_img workgroups), the fp16 planes of the actor head for the chunk-mass kernels (wa_rplanes_kernel's workgroup per item tile; n_rp of them,
+// 0: none) and env.reset (the rest; 0: none).  Each job is the stand-alone kernel's code on the same data: same bits, two launches fewer per collect.
+struct SetupExtra {
+    int n_img, n_rp, n_reset;
+    const float* wa; int n_items; uint4* planes;
+    cirs_env_cfg ecfg; cirs_env_state est; const int32_t* users; int n_env; int64_t* obs_scratch;
+};
 __global__ __launch_bounds__(256) void pack_tracker_image_kernel(cirs_tracker_cfg cfg, cirs_tracker_weights w, cirs_policy_weights pol, int S,
-                                                                 TrkImg L, float* __restrict__ img) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+                                                                 TrkImg L, float* __restrict__ img, SetupExtra x) {
+    if ((int)blockIdx.x >= x.n_img) {
+        const int b = (int)blockIdx.x - x.n_img;
+        if (b < x.n_rp) {      // wa_rplanes_kernel (policy_kernels.h), tile b
+            const int tid = threadIdx.x, item = b * kTileN + (tid >> 3), col = 8 * (tid & 7);
+            typedef float rp_v4 __attribute__((ext_vector_type(4)));
+            rp_v4 a = {0.f, 0.f, 0.f, 0.f}, bb = a;
+            if (item < x.n_items) {
+                const rp_v4* src = reinterpret_cast<const rp_v4*>(x.wa + (size_t)item * kH + col);
+                a = src[0]; bb = src[1];
+            }
+            a *= kMassScWa; bb *= kMassScWa;
+            const Planes2 pl = split8h(a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w);
+            uint4* out = x.planes + (size_t)b * kMassTileU4;
+            out[tid] = __builtin_bit_cast(uint4, pl.h); out[256 + tid] = __builtin_bit_cast(uint4, pl.l);
+        } else {
+            env_reset_body(x.ecfg, x.est, x.users, nullptr, x.n_env, x.obs_scratch, (long)(b - x.n_rp) * 256 + threadIdx.x, (long)x.n_reset * 256);
+        }
+        return;
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = x.n_img * blockDim.x;
     // img[dst + ((k / 4) * O + o) * 4 + k % 4] = src[o * ld + k0 + k]  (rows >= o_src: zero)
     auto pk = [&](int dst, const float* src, int O, int o_src, int K, int ld, int k0) {
         for (int i = t; i < O * K; i += nt) {
@@ -628,12 +655,22 @@ __global__ __launch_bounds__(256) void pack_tracker_image_kernel(cirs_tracker_cf
 }
 
 int pack_tracker_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_policy_weights* pol, int S, float* img,
-                       hipStream_t s) {
+                       hipStream_t s, const float* wa, int n_items, uint4* planes, const cirs_env_cfg* ecfg, const cirs_env_state* est,
+                       const int32_t* users, int n_env, int64_t* obs_scratch) {
     const TrkImg L = trk_img_layout(cfg->nlayers, S);
     if ((int64_t)L.total * 4 > kTrkImgBytes) return fail(CIRS_E_UNSUPPORTED, "tracker weight image exceeds its reserved workspace");
     cirs_policy_weights pw{};
     if (pol) pw = *pol;
-    hipLaunchKernelGGL(pack_tracker_image_kernel, dim3(64), dim3(256), 0, s, *cfg, *w, pw, S, L, img);
+    SetupExtra x{};
+    x.n_img = 64;
+    if (planes) { x.n_rp = n_chunks_of(n_items) * kTilesPerChunk; x.wa = wa; x.n_items = n_items; x.planes = planes; }
+    if (ecfg) {
+        CIRS_REQUIRE(est && users && n_env > 0, "collect setup: env reset arguments");
+        const long total = (long)n_env * ecfg->max_turn;
+        x.n_reset = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+        x.ecfg = *ecfg; x.est = *est; x.users = users; x.n_env = n_env; x.obs_scratch = obs_scratch;
+    }
+    hipLaunchKernelGGL(pack_tracker_image_kernel, dim3(x.n_img + x.n_rp + x.n_reset), dim3(256), 0, s, *cfg, *w, pw, S, L, img, x);
     CIRS_CHECK_LAUNCH("pack_tracker_image_kernel");
     return CIRS_OK;
 }
