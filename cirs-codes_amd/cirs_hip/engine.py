@@ -238,16 +238,17 @@ class CirsEngine:
             self._lens_pinned.copy_(lens_i32, non_blocking=True)
             ln.request_handoff_status()
         done = torch.cuda.Event(); done.record(cur)
-        ln.prepare_async(traj, lens_i32)
+        if perms is None and self.world > 1:
+            # identical permutations on every rank (same key): learners stay bit-identical
+            ln.perm_seed, ln.perm_tag = self.seed * 7919 + 1, self.collect_count * 64
+        # (the update's minibatch permutations ride in process_fn's last launch -- the learner modes that shuffle with their own key draw theirs later)
+        ln.prepare_async(traj, lens_i32, perm_repeat=repeat if (perms is None and not os.environ.get("CIRS_PERMS_SEPARATE")) else 0)
         done.synchronize()
         lens = self._lens_pinned.numpy().copy()
         if ln.handoff_lost():
             ln.check_handoffs(reset=True)   # raises CirsHipError
         self._last_prepared = (traj, lens, lens_d)      # bench.py's kernel probe re-prepares the full-catalogue learner from it in tp mode
         n = ln.finish_prepare(lens)
-        if perms is None and self.world > 1:
-            # identical permutations on every rank (same key): learners stay bit-identical
-            ln.perm_seed, ln.perm_tag = self.seed * 7919 + 1, self.collect_count * 64
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
         if (self.world > 1 or self.force_dp) and self.learner_mode in ("dp", "dp_sharded"):
             return self._update_dp(traj, lens, offsets, n, batch_size, repeat, perms)

@@ -172,9 +172,11 @@ class DeviceLearner:
                                              self._stream()), "cirs_ppo_prepare")
         return n
 
-    def prepare_async(self, traj, lens_dev: torch.Tensor):
+    def prepare_async(self, traj, lens_dev: torch.Tensor, perm_repeat: int = 0):
         """prepare() enqueued WITHOUT the host knowing the row count (cirs_ppo_prepare_async: offsets and N are formed on the device from
-        lens_dev).  The caller reads the lengths back meanwhile and completes the call with finish_prepare(lens_host)."""
+        lens_dev).  The caller reads the lengths back meanwhile and completes the call with finish_prepare(lens_host).
+        perm_repeat > 0: the update's `perm_repeat` minibatch permutations (key (perm_seed, perm_tag ..)) come out of process_fn's last launch
+        (cirs_ppo_prepare_async_perms); _perms_on_device() hands them out if the key still is the one they were drawn with."""
         B, T = self.n_env, self.max_turn
         self._alloc_batch(B * T)
         if getattr(self, "_prep_scratch", None) is None:
@@ -183,9 +185,19 @@ class DeviceLearner:
             self._n_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         lens_d = lens_dev if (lens_dev.dtype == torch.int32 and lens_dev.is_contiguous()) else lens_dev.to(self.device, torch.int32).contiguous()
         self.lens_dev, self.offsets_dev = lens_d, self._off_buf
-        abi.check(self._lib.cirs_ppo_prepare_async(C.byref(self.cfg), C.byref(traj.struct), lens_d.data_ptr(), B, T, self._off_buf.data_ptr(),
-                                                   self._n_dev.data_ptr(), self.rms_state.data_ptr(), C.byref(self.batch),
-                                                   self._prep_scratch.data_ptr(), self._stream()), "cirs_ppo_prepare_async")
+        self._perm_pre = None
+        if 0 < perm_repeat <= 8:
+            if getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() < perm_repeat * B * T:
+                self._perm_buf = torch.empty(perm_repeat * B * T, dtype=torch.int32, device=self.device)
+            abi.check(self._lib.cirs_ppo_prepare_async_perms(C.byref(self.cfg), C.byref(traj.struct), lens_d.data_ptr(), B, T, self._off_buf.data_ptr(),
+                                                             self._n_dev.data_ptr(), self.rms_state.data_ptr(), C.byref(self.batch),
+                                                             self._prep_scratch.data_ptr(), int(self.perm_seed), int(self.perm_tag), int(perm_repeat),
+                                                             self._perm_buf.data_ptr(), self._stream()), "cirs_ppo_prepare_async_perms")
+            self._perm_pre = (int(self.perm_seed), int(self.perm_tag), int(perm_repeat))
+        else:
+            abi.check(self._lib.cirs_ppo_prepare_async(C.byref(self.cfg), C.byref(traj.struct), lens_d.data_ptr(), B, T, self._off_buf.data_ptr(),
+                                                       self._n_dev.data_ptr(), self.rms_state.data_ptr(), C.byref(self.batch),
+                                                       self._prep_scratch.data_ptr(), self._stream()), "cirs_ppo_prepare_async")
         self._prep = (traj, None, lens_dev)
 
     def finish_prepare(self, lens_host: np.ndarray):
@@ -227,6 +239,11 @@ class DeviceLearner:
         identically."""
         if perms is not None:
             return torch.as_tensor(np.stack([np.asarray(perms[rep]).astype(np.int32) for rep in range(repeat)])).to(self.device)
+        pre = getattr(self, "_perm_pre", None)
+        if pre is not None and pre == (int(self.perm_seed), int(self.perm_tag), int(repeat)) and n == self.n_rows:
+            self._perm_pre = None                      # drawn in process_fn's last launch with this very key: [repeat][n], row stride n
+            self.perm_tag += repeat
+            return self._perm_buf[:repeat * n].view(repeat, n)
         out = torch.empty((repeat, n), dtype=torch.int32, device=self.device)
         abi.check(self._lib.cirs_random_permutations(int(n), int(self.perm_seed), int(self.perm_tag), int(repeat), out.data_ptr(), self._stream()),
                   "cirs_random_permutations")      # (one launch for the repeats: tags perm_tag .. perm_tag + repeat - 1, as one call per repeat drew them)

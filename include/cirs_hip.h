@@ -355,6 +355,12 @@ int cirs_ppo_prepare(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32
 int cirs_ppo_prepare_async(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, int32_t n_env, int32_t max_turn,
                            int32_t* offsets_out, int32_t* n_rows_out, double* rms_state, const cirs_ppo_batch* out, double* scratch,
                            void* stream);
+/* cirs_ppo_prepare_async + the update's minibatch permutations (cirs_random_permutations(n_rows, perm_seed, perm_tag0, n_perm, ..), n_perm <= 8) from
+ * process_fn's last launch, the row count read on the device: perm_out[c * n_rows + i], i < n_rows (buffer: n_perm * n_env * max_turn ints).
+ * replaces  Batch.split(shuffle=True)'s np.random.permutation per repeat (tianshou/data/batch.py:734-744; core/policy/ppo.py:173-181). */
+int cirs_ppo_prepare_async_perms(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, int32_t n_env, int32_t max_turn,
+                                 int32_t* offsets_out, int32_t* n_rows_out, double* rms_state, const cirs_ppo_batch* out, double* scratch,
+                                 uint64_t perm_seed, uint64_t perm_tag0, int32_t n_perm, int32_t* perm_out, void* stream);
 
 /* one minibatch gradient step of learn(): forward, clipped surrogate + clipped value loss + entropy, backward,
  * clip_grad_norm_, Adam.  idx[mb] are buffer-order row ids.  opt_step = optimiser steps taken so far.

@@ -71,6 +71,22 @@ def test_prepare_with_the_row_count_left_on_the_device_is_bit_identical(golden_d
     for name in ("b_obs", "b_act", "b_adv", "b_ret", "b_vs", "b_logp", "b_env", "b_t"):
         assert torch.equal(getattr(a, name)[:n], getattr(b, name)[:n]), name
     assert torch.equal(a.rms_state, b.rms_state) and torch.equal(a.offsets_dev, b.offsets_dev)
+    # ... and with the update's permutations drawn in its last launch (cirs_ppo_prepare_async_perms): the batch is the same and the permutations are
+    # cirs_random_permutations' of the same key, handed out by _perms_on_device exactly once and only for that key
+    from cirs_hip import abi
+    c, _ = make_learner(pp, I, B, T, z["hyper"])
+    c.perm_seed, c.perm_tag = 4242, 17
+    c.prepare_async(traj, torch.as_tensor(lens.astype(np.int32)).cuda(), perm_repeat=3)
+    assert c.finish_prepare(lens) == n
+    for name in ("b_obs", "b_act", "b_adv", "b_ret", "b_vs", "b_logp", "b_env", "b_t"):
+        assert torch.equal(getattr(a, name)[:n], getattr(c, name)[:n]), name
+    assert torch.equal(a.rms_state, c.rms_state)
+    want = torch.empty((3, n), dtype=torch.int32, device="cuda")
+    abi.check(abi.lib().cirs_random_permutations(n, 4242, 17, 3, want.data_ptr(), torch.cuda.current_stream().cuda_stream), "perms")
+    got = c._perms_on_device(n, 3, None)
+    assert got.data_ptr() == c._perm_buf.data_ptr() and torch.equal(got, want) and c.perm_tag == 20
+    again = c._perms_on_device(n, 3, None)            # the pre-drawn set is spent: a fresh draw with the next tags
+    assert again.data_ptr() != c._perm_buf.data_ptr() and not torch.equal(again, want) and c.perm_tag == 23
 
 
 def test_merge_in_the_backward_prologue_equals_the_merge_launch(golden_dir, monkeypatch):
