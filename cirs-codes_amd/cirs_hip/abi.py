@@ -149,7 +149,7 @@ SIGNATURES = {
     "cirs_ppo_param_count": (C.c_int64, [C.POINTER(PpoCfg)]),
     "cirs_ppo_workspace_bytes": (C.c_int64, [C.POINTER(PpoCfg), C.c_int32]),
     "cirs_ppo_prepare_async": (C.c_int, [C.POINTER(PpoCfg), C.POINTER(Traj), _P, C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(PpoBatch), _P, _P]),
-    "cirs_ppo_prepare_async_perms": (C.c_int, [C.POINTER(PpoCfg), C.POINTER(Traj), _P, C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(PpoBatch), _P, C.c_uint64, C.c_uint64, C.c_int32, _P, _P]),
+    "cirs_ppo_prepare_async_perms": (C.c_int, [C.POINTER(PpoCfg), C.POINTER(Traj), _P, C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(PpoBatch), _P, C.c_uint64, C.c_uint64, C.c_int32, _P, C.c_int32, _P]),
     "cirs_ppo_prepare": (C.c_int, [C.POINTER(PpoCfg), C.POINTER(Traj), _P, _P, C.c_int32, C.c_int32, C.c_int32, _P,
                                    C.POINTER(PpoBatch), _P]),
     "cirs_ppo_minibatch": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32,
@@ -158,7 +158,7 @@ SIGNATURES = {
                                               _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P]),
     "cirs_ppo_learn_steps": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "cirs_ppo_handoff_status": (C.c_int, [_P, C.c_int32, _P]),
-    "cirs_ppo_update_readback": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
+    "cirs_ppo_update_readback": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "cirs_ppo_learn": (C.c_int, [C.POINTER(PpoCfg), _P, _P, _P, _P, C.c_int64, C.POINTER(PpoBatch), _P, C.c_int32, C.c_int32, C.c_int32,
                                  _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, _P]),
     "cirs_tracker_backward_workspace_bytes": (C.c_int64, [C.POINTER(TrackerCfg), C.c_int32]),

@@ -105,12 +105,26 @@ class DeviceLearner:
         self._ho_pin.copy_(self._ho_dev, non_blocking=True)
 
     def readback_lens(self, lens_dev, lens_pinned):
-        """The update's one read-back from one launch: the lengths and the hand-off count straight into pinned host words (cirs_ppo_update_readback)."""
+        """The update's one read-back from one launch: the lengths and the hand-off count straight into pinned host words (cirs_ppo_update_readback) --
+        and, for this learner's own envs, the buffer offsets / row count of process_fn (prepare_async then starts at the GAE)."""
         if getattr(self, "_ho_dev", None) is None:
             self._ho_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._ho_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
-        abi.check(self._lib.cirs_ppo_update_readback(lens_dev.data_ptr(), int(lens_dev.numel()), lens_pinned.data_ptr(), self._ho_pin.data_ptr(), self._stream()),
-                  "cirs_ppo_update_readback")
+        self._offsets_of = None
+        off = nrow = None
+        if int(lens_dev.numel()) == self.n_env:
+            self._ensure_prep_buffers()
+            off, nrow = self._off_buf.data_ptr(), self._n_dev.data_ptr()
+            self._offsets_of = lens_dev.data_ptr()
+        abi.check(self._lib.cirs_ppo_update_readback(lens_dev.data_ptr(), int(lens_dev.numel()), lens_pinned.data_ptr(), self._ho_pin.data_ptr(), off, nrow,
+                                                     self._stream()), "cirs_ppo_update_readback")
+
+    def _ensure_prep_buffers(self):
+        B, T = self.n_env, self.max_turn
+        if getattr(self, "_prep_scratch", None) is None:
+            self._prep_scratch = torch.empty(B * T, dtype=torch.float64, device=self.device)
+            self._off_buf = torch.empty(B, dtype=torch.int32, device=self.device)
+            self._n_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def handoff_lost(self):
         """The count last copied by request_handoff_status() (the caller has synchronised with the stream)."""
@@ -179,21 +193,22 @@ class DeviceLearner:
         (cirs_ppo_prepare_async_perms); _perms_on_device() hands them out if the key still is the one they were drawn with."""
         B, T = self.n_env, self.max_turn
         self._alloc_batch(B * T)
-        if getattr(self, "_prep_scratch", None) is None:
-            self._prep_scratch = torch.empty(B * T, dtype=torch.float64, device=self.device)
-            self._off_buf = torch.empty(B, dtype=torch.int32, device=self.device)
-            self._n_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._ensure_prep_buffers()
         lens_d = lens_dev if (lens_dev.dtype == torch.int32 and lens_dev.is_contiguous()) else lens_dev.to(self.device, torch.int32).contiguous()
         self.lens_dev, self.offsets_dev = lens_d, self._off_buf
         self._perm_pre = None
-        if 0 < perm_repeat <= 8:
-            if getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() < perm_repeat * B * T:
-                self._perm_buf = torch.empty(perm_repeat * B * T, dtype=torch.int32, device=self.device)
+        offsets_ready = 1 if getattr(self, "_offsets_of", None) == lens_d.data_ptr() else 0      # (readback_lens formed them from these very lengths)
+        self._offsets_of = None
+        if (0 < perm_repeat <= 8) or offsets_ready:
+            perm_repeat = perm_repeat if 0 < perm_repeat <= 8 else 0
+            if getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() < max(perm_repeat, 1) * B * T:
+                self._perm_buf = torch.empty(max(perm_repeat, 1) * B * T, dtype=torch.int32, device=self.device)
             abi.check(self._lib.cirs_ppo_prepare_async_perms(C.byref(self.cfg), C.byref(traj.struct), lens_d.data_ptr(), B, T, self._off_buf.data_ptr(),
                                                              self._n_dev.data_ptr(), self.rms_state.data_ptr(), C.byref(self.batch),
                                                              self._prep_scratch.data_ptr(), int(self.perm_seed), int(self.perm_tag), int(perm_repeat),
-                                                             self._perm_buf.data_ptr(), self._stream()), "cirs_ppo_prepare_async_perms")
-            self._perm_pre = (int(self.perm_seed), int(self.perm_tag), int(perm_repeat))
+                                                             self._perm_buf.data_ptr(), offsets_ready, self._stream()), "cirs_ppo_prepare_async_perms")
+            if perm_repeat:
+                self._perm_pre = (int(self.perm_seed), int(self.perm_tag), int(perm_repeat))
         else:
             abi.check(self._lib.cirs_ppo_prepare_async(C.byref(self.cfg), C.byref(traj.struct), lens_d.data_ptr(), B, T, self._off_buf.data_ptr(),
                                                        self._n_dev.data_ptr(), self.rms_state.data_ptr(), C.byref(self.batch),

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gae_kernel(cirs_ppo_cfg cfg, cirs_traj tr
 }
 
 // exclusive prefix sum of the episode lengths (the buffer offsets of the envs) + the row count, one workgroup (n_env <= 2^20)
-__global__ __launch_bounds__(1024) void offsets_kernel(const int32_t* __restrict__ lens, int B, int32_t* __restrict__ offsets, int32_t* __restrict__ n_out) {
+__device__ __forceinline__ void offsets_block(const int32_t* __restrict__ lens, int B, int32_t* __restrict__ offsets, int32_t* __restrict__ n_out) {
     __shared__ int part[1024];
     const int tid = threadIdx.x, per = (B + 1023) / 1024, b0 = tid * per, b1 = min(B, b0 + per);
     int sum = 0;
@@ -117,6 +117,9 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const int32_t* __restrict
     int run = part[tid] - sum;
     for (int b = b0; b < b1; ++b) { offsets[b] = run; run += lens[b]; }
     if (tid == 1023) *n_out = part[1023];
+}
+__global__ __launch_bounds__(1024) void offsets_kernel(const int32_t* __restrict__ lens, int B, int32_t* __restrict__ offsets, int32_t* __restrict__ n_out) {
+    offsets_block(lens, B, offsets, n_out);
 }
 
 __device__ __forceinline__ void compact_obs_elem(const cirs_traj& traj, const cirs_ppo_batch& out, long i, int N, int B, int S) {
@@ -293,6 +296,13 @@ __global__ __launch_bounds__(256) void update_readback_kernel(const int32_t* __r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) lens_host[i] = lens[i];
     if (i == 0 && lost_host) lost_host[0] = g_handoff_lost;
+}
+// ... and with process_fn's first job in the same launch (one workgroup of 1024 threads): offsets_kernel's scan, then the copy
+__global__ __launch_bounds__(1024) void update_readback_offsets_kernel(const int32_t* __restrict__ lens, int n, int32_t* __restrict__ lens_host,
+                                                                       int32_t* __restrict__ lost_host, int32_t* __restrict__ offsets, int32_t* __restrict__ n_out) {
+    for (int i = threadIdx.x; i < n; i += 1024) lens_host[i] = lens[i];
+    if (threadIdx.x == 0 && lost_host) lost_host[0] = g_handoff_lost;
+    offsets_block(lens, n, offsets, n_out);
 }
 __host__ __device__ inline int snap_floats(int S) { return kH * (S + 66) + kH + 1; }      // trunk (w1 | b1 | w2 | b2) + wc | bc
 __host__ __device__ inline int snap_stride(int S) { return (snap_floats(S) + 3) & ~3; }       // (16-byte aligned arrays)
@@ -2529,7 +2539,8 @@ extern "C" int cirs_ppo_prepare(const cirs_ppo_cfg* cfg, const cirs_traj* traj, 
 // scratch: n_env * max_turn doubles; the batch arrays must hold n_env * max_turn rows.  Same kernels as cirs_ppo_prepare: same bits.
 extern "C" int cirs_ppo_prepare_async_perms(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, int32_t n_env, int32_t max_turn,
                                             int32_t* offsets_out, int32_t* n_rows_out, double* rms_state, const cirs_ppo_batch* out,
-                                            double* scratch, uint64_t perm_seed, uint64_t perm_tag0, int32_t n_perm, int32_t* perm_out, void* stream) {
+                                            double* scratch, uint64_t perm_seed, uint64_t perm_tag0, int32_t n_perm, int32_t* perm_out, int32_t offsets_ready,
+                                            void* stream) {
     using namespace cirs;
     if (int rc = validate_ppo(cfg)) return rc;
     CIRS_REQUIRE(traj && lens && offsets_out && n_rows_out && rms_state && out && scratch, "null argument");
@@ -2537,7 +2548,7 @@ extern "C" int cirs_ppo_prepare_async_perms(const cirs_ppo_cfg* cfg, const cirs_
     CIRS_REQUIRE(n_env > 0 && n_env <= (1 << 20) && max_turn > 0, "bad sizes");
     CIRS_REQUIRE(n_perm >= 0 && n_perm <= kMaxPermKeys && (n_perm == 0 || perm_out), "permutations: at most 8 per call, perm_out non-null");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, s, lens, n_env, offsets_out, n_rows_out);
+    if (!offsets_ready) hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, s, lens, n_env, offsets_out, n_rows_out);      // (else: cirs_ppo_update_readback formed them)
     hipLaunchKernelGGL(gae_kernel, dim3(cdiv(n_env, 64)), dim3(64), 0, s, *cfg, *traj, lens, (const int32_t*)offsets_out, n_env, cfg->dim_state,
                        rms_state, *out, scratch);
     const long upper = (long)n_env * max_turn;
@@ -2552,7 +2563,7 @@ extern "C" int cirs_ppo_prepare_async_perms(const cirs_ppo_cfg* cfg, const cirs_
 extern "C" int cirs_ppo_prepare_async(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, int32_t n_env, int32_t max_turn,
                                       int32_t* offsets_out, int32_t* n_rows_out, double* rms_state, const cirs_ppo_batch* out,
                                       double* scratch, void* stream) {
-    return cirs_ppo_prepare_async_perms(cfg, traj, lens, n_env, max_turn, offsets_out, n_rows_out, rms_state, out, scratch, 0, 0, 0, nullptr, stream);
+    return cirs_ppo_prepare_async_perms(cfg, traj, lens, n_env, max_turn, offsets_out, n_rows_out, rms_state, out, scratch, 0, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int cirs_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int64_t step_before,
@@ -2840,8 +2851,14 @@ extern "C" int cirs_ppo_handoff_status(int32_t* lost_out, int32_t reset, void* s
     return CIRS_OK;
 }
 
-extern "C" int cirs_ppo_update_readback(const int32_t* lens, int32_t n_env, int32_t* lens_host_pinned, int32_t* lost_host_pinned, void* stream) {
-    CIRS_REQUIRE(lens && lens_host_pinned && n_env > 0, "cirs_ppo_update_readback: bad arguments");
+extern "C" int cirs_ppo_update_readback(const int32_t* lens, int32_t n_env, int32_t* lens_host_pinned, int32_t* lost_host_pinned, int32_t* offsets_out,
+                                        int32_t* n_rows_out, void* stream) {
+    CIRS_REQUIRE(lens && lens_host_pinned && n_env > 0 && (!offsets_out == !n_rows_out), "cirs_ppo_update_readback: bad arguments");
+    if (offsets_out) {
+        CIRS_REQUIRE(n_env <= (1 << 20), "cirs_ppo_update_readback: n_env");
+        hipLaunchKernelGGL(cirs::update_readback_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lens, (int)n_env, lens_host_pinned, lost_host_pinned,
+                           offsets_out, n_rows_out);
+    } else
     hipLaunchKernelGGL(cirs::update_readback_kernel, dim3(cirs::cdiv(n_env, 256)), dim3(256), 0, (hipStream_t)stream, lens, (int)n_env, lens_host_pinned,
                        lost_host_pinned);
     CIRS_CHECK_LAUNCH("update_readback_kernel");

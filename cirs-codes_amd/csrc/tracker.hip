@@ -662,7 +662,7 @@ int pack_tracker_image(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* 
     cirs_policy_weights pw{};
     if (pol) pw = *pol;
     SetupExtra x{};
-    x.n_img = 64;
+    x.n_img = 192;      // (~48 k image floats: one or two per thread; 64 workgroups took 9 us, the launch's longest role)
     if (planes) { x.n_rp = n_chunks_of(n_items) * kTilesPerChunk; x.wa = wa; x.n_items = n_items; x.planes = planes; }
     if (ecfg) {
         CIRS_REQUIRE(est && users && n_env > 0, "collect setup: env reset arguments");

@@ -1470,8 +1470,12 @@ static int emb_scatter_sorted(const int32_t* keys, const float* contrib, int R, 
 // sub-run / segment sums, half the launches of two separate scatters.
 __global__ __launch_bounds__(256) void scatter_keys2_kernel(const int32_t* __restrict__ key_item, const int32_t* __restrict__ users,
                                                             const int32_t* __restrict__ lens, int R, int B, int n_items, int n_users,
-                                                            uint32_t* __restrict__ keys_u, int32_t* __restrict__ rows) {
+                                                            uint32_t* __restrict__ keys_u, int32_t* __restrict__ rows,
+                                                            float* __restrict__ zero_table /* nullable: the contiguous gradient tables, cleared here */, long zero_floats) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the tables' clear rides in this launch -- emb_segment_sum_kernel, three launches on, writes the touched rows only; a memset is a launch of its own)
+    if (zero_table)
+        for (long i = (long)p * 4; i < zero_floats; i += (long)gridDim.x * blockDim.x * 4) *reinterpret_cast<f32x4*>(zero_table + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p >= R + B) return;
     const uint32_t sent = (uint32_t)n_items + (uint32_t)n_users;
     uint32_t k = sent;
@@ -1501,15 +1505,16 @@ static int emb_scatter_merged(const int32_t* key_item, const int32_t* users, con
     size_t need = 0;
     CIRS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, r_in, r_out, N, 0, end_bit, s));
     CIRS_REQUIRE(need <= avail, "embedding scatter: sort scratch too small");
-    if (g_user + (size_t)n_users * tD == g_item) {
-        CIRS_HIP(hipMemsetAsync(g_user, 0, (size_t)n_table * tD * sizeof(float), s));
-    } else if (g_item + (size_t)n_items * tD == g_user) {
-        CIRS_HIP(hipMemsetAsync(g_item, 0, (size_t)n_table * tD * sizeof(float), s));
-    } else {
+    float* zero_table = nullptr;       // contiguous tables (the flat gradient buffer): cleared inside scatter_keys2_kernel (tD = 32 floats per row: float4 units)
+    if (g_user + (size_t)n_users * tD == g_item) zero_table = g_user;
+    else if (g_item + (size_t)n_items * tD == g_user) zero_table = g_item;
+    if (zero_table && ((uintptr_t)zero_table & 15)) zero_table = nullptr;
+    if (!zero_table) {
         CIRS_HIP(hipMemsetAsync(g_item, 0, (size_t)n_items * tD * sizeof(float), s));
         CIRS_HIP(hipMemsetAsync(g_user, 0, (size_t)n_users * tD * sizeof(float), s));
     }
-    hipLaunchKernelGGL(scatter_keys2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, key_item, users, lens, R, B, n_items, n_users, k_in, r_in);
+    hipLaunchKernelGGL(scatter_keys2_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, key_item, users, lens, R, B, n_items, n_users, k_in, r_in, zero_table,
+                       (long)n_table * tD);
     CIRS_HIP(hipcub::DeviceRadixSort::SortPairs(temp, need, k_in, k_out, r_in, r_out, N, 0, end_bit, s));
     hipLaunchKernelGGL(emb_subrun_kernel, dim3(cdiv(N, 8)), dim3(256), 0, s, k_out, r_out, contrib, N, n_table, part);
     hipLaunchKernelGGL(emb_segment_sum_kernel, dim3(cdiv(N, 8)), dim3(256), 0, s, k_out, (const float*)part, N, n_table, g_item, n_items, g_user);

@@ -360,7 +360,7 @@ int cirs_ppo_prepare_async(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const
  * replaces  Batch.split(shuffle=True)'s np.random.permutation per repeat (tianshou/data/batch.py:734-744; core/policy/ppo.py:173-181). */
 int cirs_ppo_prepare_async_perms(const cirs_ppo_cfg* cfg, const cirs_traj* traj, const int32_t* lens, int32_t n_env, int32_t max_turn,
                                  int32_t* offsets_out, int32_t* n_rows_out, double* rms_state, const cirs_ppo_batch* out, double* scratch,
-                                 uint64_t perm_seed, uint64_t perm_tag0, int32_t n_perm, int32_t* perm_out, void* stream);
+                                 uint64_t perm_seed, uint64_t perm_tag0, int32_t n_perm, int32_t* perm_out, int32_t offsets_ready, void* stream);
 
 /* one minibatch gradient step of learn(): forward, clipped surrogate + clipped value loss + entropy, backward,
  * clip_grad_norm_, Adam.  idx[mb] are buffer-order row ids.  opt_step = optimiser steps taken so far.
@@ -395,8 +395,11 @@ int cirs_ppo_learn(const cirs_ppo_cfg* cfg, float* params, float* grads, float* 
  * weights: the host must treat the update as failed (cirs_hip/learner.py raises at the update's read-back). */
 int cirs_ppo_handoff_status(int32_t* lost_out, int32_t reset, void* stream);
 /* The one read-back of an update (the host needs the episode lengths to schedule the minibatches: len(buffer) in tianshou/policy/base.py:231-244) as one
- * launch: lens[n_env] and the hand-off count above written straight to PINNED host memory (device-accessible: hipHostMalloc); lost_host_pinned may be NULL. */
-int cirs_ppo_update_readback(const int32_t* lens, int32_t n_env, int32_t* lens_host_pinned, int32_t* lost_host_pinned, void* stream);
+ * launch: lens[n_env] and the hand-off count above written straight to PINNED host memory (device-accessible: hipHostMalloc); lost_host_pinned may be NULL.
+ * offsets_out / n_rows_out (both or neither): process_fn's first job -- the buffer offsets of the envs and the row count, cirs_ppo_prepare_async's
+ * outputs -- formed in the same launch; cirs_ppo_prepare_async_perms(.., offsets_ready = 1, ..) then starts at the GAE. */
+int cirs_ppo_update_readback(const int32_t* lens, int32_t n_env, int32_t* lens_host_pinned, int32_t* lost_host_pinned, int32_t* offsets_out,
+                             int32_t* n_rows_out, void* stream);
 
 /* Data-parallel form of cirs_ppo_minibatch for a learner sharded over ranks.  A GLOBAL minibatch of mb_global rows
  * (idx_global) is split by rows; this rank owns idx_local[mb_local].  Advantage normalisation uses the statistics of

@@ -137,6 +137,14 @@ def test_update_readback_writes_pinned_host_words():
     lens = torch.randint(1, 31, (n,), dtype=torch.int32, device="cuda")
     host = torch.full((n,), -1, dtype=torch.int32).pin_memory()
     lost = torch.full((1,), -1, dtype=torch.int32).pin_memory()
-    abi.check(abi.lib().cirs_ppo_update_readback(lens.data_ptr(), n, host.data_ptr(), lost.data_ptr(), torch.cuda.current_stream().cuda_stream), "readback")
+    abi.check(abi.lib().cirs_ppo_update_readback(lens.data_ptr(), n, host.data_ptr(), lost.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream), "readback")
     torch.cuda.synchronize()
     assert torch.equal(host, lens.cpu()) and int(lost[0]) == 0
+    # ... with process_fn's offsets / row count from the same launch
+    host.fill_(-1)
+    off = torch.full((n,), -1, dtype=torch.int32, device="cuda"); nrow = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    abi.check(abi.lib().cirs_ppo_update_readback(lens.data_ptr(), n, host.data_ptr(), lost.data_ptr(), off.data_ptr(), nrow.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream), "readback")
+    torch.cuda.synchronize()
+    lc = lens.cpu()
+    assert torch.equal(host, lc) and int(nrow.cpu()) == int(lc.sum()) and torch.equal(off.cpu(), (torch.cumsum(lc, 0) - lc).to(torch.int32))
