@@ -1683,6 +1683,7 @@ struct RowsLds {
     __attribute__((aligned(16))) float obs[kRR * 32];
     float w1[kH * 32];                                           // W1 [k][S]
     float dv[kRR];
+    __attribute__((aligned(16))) float ps[3][kRR * kH];          // chunk-slab sums of quarters 1..3 of the chunks (quarter 0 stays in its threads' registers)
 };
 __device__ __forceinline__ void st_sc1x2(float* p, float a, float b) {      // 8-byte write-through store (p 8-byte aligned)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED,
@@ -1772,22 +1773,29 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
     // ---- R: thread (row r = tid / 64, column n = tid % 64) ----------------------------------------------------------------------
     CIRS_PSTAMP(b == 0, 20);
     const int r = tid >> 6, n = tid & 63;
-    // requests: the chunk slabs of the rows first -- as float4 by the first 128 threads (thread = 4 columns of a row; 31 loads of 16 bytes, chunk
-    // order): a quarter of the load instructions of one column per thread, and the CU's address unit takes ~16 cycles per instruction whatever
-    // its width --, then the operands every later stage reads from LDS
+    // requests: the chunk slabs of the rows first -- as float4 (thread = 4 columns of a row and a quarter of the chunks: a quarter of the load
+    // instructions of one column per thread, and the CU's address unit takes ~16 cycles per instruction whatever its width) --, then the operands
+    // every later stage reads from LDS
     const int r4 = (tid >> 4) & (kRR - 1), c4 = (tid & 15) * 4, row4 = b * kRR + r4;      // row4 < n_pad (n_pad is a multiple of 32)
     f32x4 acc4 = {0.f, 0.f, 0.f, 0.f}, h1q = acc4, h2q = acc4, wcq = acc4;
     float dvr = 0.f;
-    if (tid < kRR * 16) {
+    // (round 6, second half) all four thread quarters take a quarter of the chunks each -- 8 x 16 bytes in ONE batch per thread at 31 chunks -- and the quarters'
+    // sums meet in LDS in quarter order: with the first quarter alone walking the 31 slabs it was two dependent round trips of 16 (measured: the second batch
+    // was 0.95 us of the 70.7 us step).  Fixed order (chunks ascending inside a quarter, quarters ascending): deterministic, same on every rank.
+    {
+        const int qd = tid >> 7, per = (n_chunks + 3) >> 2, c_lo = qd * per, c_hi = min(n_chunks, c_lo + per);
         const float* src = v.dh2p + (size_t)row4 * kH + c4;
         const size_t cstride = (size_t)n_pad * kH;
-        for (int c0 = 0; c0 < n_chunks; c0 += 16) {      // (16 x 16 bytes in flight per thread: 64 registers; 32 would leave one workgroup per CU)
-            f32x4 t16[16];
+        for (int c0 = c_lo; c0 < c_hi; c0 += 8) {
+            f32x4 t8[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t16[u] = (c0 + u < n_chunks) ? *reinterpret_cast<const f32x4*>(src + (size_t)(c0 + u) * cstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < 8; ++u) t8[u] = (c0 + u < c_hi) ? *reinterpret_cast<const f32x4*>(src + (size_t)(c0 + u) * cstride) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc4 += t16[u];
+            for (int u = 0; u < 8; ++u) acc4 += t8[u];
         }
+        if (qd > 0) *reinterpret_cast<f32x4*>(&L.ps[qd - 1][r4 * kH + c4]) = acc4;
+    }
+    if (tid < kRR * 16) {
         h1q = *reinterpret_cast<const f32x4*>(v.h1 + (size_t)row4 * kH + c4);
         h2q = *reinterpret_cast<const f32x4*>(v.h2 + (size_t)row4 * kH + c4);
         wcq = *reinterpret_cast<const f32x4*>(wc + c4);
@@ -1810,7 +1818,10 @@ __global__ __launch_bounds__(512) void trunk_rows_kernel(int mb, int n_pad, int 
         }
         hent = v.h_ent[rr];
     }
+    __syncthreads();
     if (tid < kRR * 16) {
+        acc4 = ((acc4 + *reinterpret_cast<const f32x4*>(&L.ps[0][r4 * kH + c4])) + *reinterpret_cast<const f32x4*>(&L.ps[1][r4 * kH + c4])) +
+               *reinterpret_cast<const f32x4*>(&L.ps[2][r4 * kH + c4]);
         const bool ok = row4 < mb;
         f32x4 d4;
 #pragma unroll
