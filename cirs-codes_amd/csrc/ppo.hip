@@ -2731,6 +2731,13 @@ static int launch_trunk_rows(const PpoRun& r, const PpoStep& st, int n_bchunks, 
     const long n4 = seg >> 2;
     int n_w = (int)cdiv(n4, 512L);
     n_w = n_w > kWaSlotsMax ? kWaSlotsMax : n_w;
+    // (round 6, second half) no more W workgroups than CUs the R workgroups leave free: a W workgroup that shares a CU with an R workgroup competes with its
+    // slab loads -- same box, 1024 rows: 340 / 256 / 170 / 128 / 84 W workgroups = 70.1 / 70.2 / 69.5 / 69.0 / 69.3 us per step; CIRS_PPO_W_WGS overrides
+    {
+        const int free_cus = std::max(64, device_cu_count() - n_r), wv = env_int("CIRS_PPO_W_WGS", 0);
+        if (wv > 0) n_w = std::min(n_w, wv);
+        else n_w = std::min(n_w, free_cus);
+    }
     hipLaunchKernelGGL(trunk_rows_kernel, dim3(n_r + n_w + n_f + (with_loss_partials ? 1 : 0)), dim3(512), 0, r.s, st.mb, n_pad, n_bchunks, r.S, r.w.w1,
                        r.w.w2, r.w.wc, r.v, st.dobs, r.grads, (long)r.L.wa, seg, (long)dwa_slab_stride(r.I), n_slabs, n_r, snap_stride(r.S),
                        env_int("CIRS_PPO_W_DELAY", 0), with_loss_partials ? r.tail : (float*)nullptr, st.mb_norm, n_w);
