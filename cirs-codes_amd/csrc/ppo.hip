@@ -1995,7 +1995,20 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(float* __restrict__ 
 __device__ __forceinline__ void loss_partials_block(int mb, int mb_norm, const MbView& v, float* __restrict__ tail, float* sh3) {
     const int tid = threadIdx.x;  // blockDim.x == 256, sh3 = float[3][256]
     float e = 0.f, c = 0.f, f = 0.f;
-    for (int r = tid; r < mb; r += 256) { e += v.ent_row[r]; c += v.clip_row[r]; f += v.vf_row[r]; }
+    // (round 6: the first 2048 rows' terms requested in one batch -- a loop with a run-time trip count is one round trip per iteration, and this workgroup's chain
+    // ended adam_next_kernel 0.9 us after the T workgroups'; same order of additions)
+    {
+        float e8[8], c8[8], f8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = tid + 256 * q, rc = r < mb ? r : 0;
+            e8[q] = v.ent_row[rc]; c8[q] = v.clip_row[rc]; f8[q] = v.vf_row[rc];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (tid + 256 * q < mb) { e += e8[q]; c += c8[q]; f += f8[q]; }
+    }
+    for (int r = tid + 2048; r < mb; r += 256) { e += v.ent_row[r]; c += v.clip_row[r]; f += v.vf_row[r]; }
     sh3[tid] = c; sh3[256 + tid] = f; sh3[512 + tid] = e;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -2349,13 +2362,49 @@ __device__ __forceinline__ void adam_next_trunk_params(const AdamArgs& a, const 
 // A: ba (the trunk / critic belong to A0, the Wa matrix to the P workgroups); its first workgroup reduces the loss terms and publishes them
 __device__ __forceinline__ void adam_next_rest(const AdamArgs& a, const MbView& mv, AdamLds& l, int ba_) {
     const int tid = threadIdx.x;
-    if (ba_ == 0 && a.mb > 0) loss_partials_block(a.mb, a.mb_norm, mv, a.tail, l.sh3);      // (here, off the T workgroups' critical path)
-    float total_norm;
-    const float c = norm_coef_block(a.partial, a.cfg, l.sh, total_norm);
+    // (the norm's slots and this thread's ba element are requested before the loss terms are folded: one round trip for all of them)
+    const float np_a = a.partial[tid], np_b = (a.partial[kNormBlocks + tid] + a.partial[2 * kNormBlocks + tid]) + a.partial[3 * kNormBlocks + tid];
+    float total_norm, c;
+    float lt[3] = {0.f, 0.f, 0.f};          // (thread 0 of the first workgroup: the step's loss terms)
+    if (ba_ == 0 && a.mb > 0) {
+        // the loss terms' three sums and the norm's tree share their barriers (nine instead of eighteen): the same pairs are added in the same order as
+        // loss_partials_block / norm_coef_block add them (the coefficient must be the same bits in every workgroup)
+        float e = 0.f, cl = 0.f, f = 0.f;
+        {
+            float e8[8], c8[8], f8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = tid + 256 * q, rc = r < a.mb ? r : 0;
+                e8[q] = mv.ent_row[rc]; c8[q] = mv.clip_row[rc]; f8[q] = mv.vf_row[rc];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (tid + 256 * q < a.mb) { e += e8[q]; cl += c8[q]; f += f8[q]; }
+        }
+        for (int r = tid + 2048; r < a.mb; r += 256) { e += mv.ent_row[r]; cl += mv.clip_row[r]; f += mv.vf_row[r]; }
+        float* sh3 = l.sh3;
+        sh3[tid] = cl; sh3[256 + tid] = f; sh3[512 + tid] = e; l.sh[tid] = np_a + np_b;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (tid < s2) { sh3[tid] += sh3[tid + s2]; sh3[256 + tid] += sh3[256 + tid + s2]; sh3[512 + tid] += sh3[512 + tid + s2]; l.sh[tid] += l.sh[tid + s2]; }
+            __syncthreads();
+        }
+        total_norm = sqrtf(l.sh[0]);
+        c = 1.0f;
+        if (a.cfg.max_grad_norm > 0.f) c = fminf(a.cfg.max_grad_norm / (total_norm + 1e-6f), 1.0f);
+        if (tid == 0) {
+            const float inv = 1.0f / (float)a.mb_norm;
+            lt[0] = sh3[0] * inv; lt[1] = sh3[256] * inv; lt[2] = sh3[512] * inv;
+            a.tail[0] = lt[0]; a.tail[1] = lt[1]; a.tail[2] = lt[2]; a.tail[3] = 0.f;
+        }
+    } else {
+        c = norm_coef_block(np_a, np_b, a.cfg, l.sh, total_norm);
+        if (ba_ == 0 && tid == 0) { lt[0] = a.tail[0]; lt[1] = a.tail[1]; lt[2] = a.tail[2]; }
+    }
     if (ba_ == 0 && tid == 0) {
         mv.red[4] = c;
         mv.red[5] = total_norm;
-        const float clip = a.tail[0], vf = a.tail[1], ent = a.tail[2];
+        const float clip = lt[0], vf = lt[1], ent = lt[2];
         a.loss_out[0] = clip + a.cfg.vf_coef * vf - a.cfg.ent_coef * ent;
         a.loss_out[1] = clip; a.loss_out[2] = vf; a.loss_out[3] = ent;
     }
