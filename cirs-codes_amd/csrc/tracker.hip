@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = kD / NHEAD;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = blockIdx.x * 4 + wv;
+    const int nwv = blockDim.x >> 6;      // waves (= env rows) per workgroup: 4, or fewer when there are fewer rows than CUs (launch_tracker)
+    const int j = blockIdx.x * nwv + wv;
     CIRS_STAMP(0);
     // ~1.1 KB of by-value arguments: five to eight dependent scalar-cache misses before the first vector load otherwise (common.h)
     kernarg_warm<sizeof(cirs_tracker_cfg) + sizeof(cirs_tracker_weights) + sizeof(cirs_tracker_state) + sizeof(TrunkFuse) + sizeof(TailFuse) +
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void tracker_step_kernel(cirs_tracker_cfg cfg,
         if (epf.done) {  // finished env: the policy skipped it
             if (lane == 0) { tl.act_out[j] = -1; tl.logp_out[j] = 0.f; }
         } else if (tl.pick_on) {   // two-level draw: chunk, then item (per-wave LDS scratch: the feed-forward buffer, free here)
-            float* stage = smem + (size_t)4 * (6 * kD + kHid + NHEAD * lpad) + (size_t)wv * kPickStage;   // after the four waves' scratch
+            float* stage = smem + (size_t)nwv * (6 * kD + kHid + NHEAD * lpad) + (size_t)wv * kPickStage;   // after the waves' scratch
             // the (env, position) prefetch goes out when the pick's own rows have arrived, under the item draw's second half
             const Cand r = actor_pick_wave<ZS>(tl.pick, j, et, lane, ffs, stage, &ppre, step_prefetch);
             act = r.bi == 0x7FFFFFFF ? -1 : (int64_t)r.bi;
@@ -709,9 +710,20 @@ static int launch_tracker(const cirs_tracker_cfg* cfg, const cirs_tracker_weight
     }
     const int lpad = (cfg->max_len + 3) & ~3;
     // + the row stage of the two-level sampler's item draw when the tail of the vector step is fused in (69.6 KB per workgroup)
-    const size_t shmem = 4 * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad) + (tl.on && tl.pick_on ? 4 * sizeof(float) * kPickStage : 0);
+    // Few rows (the 64-env shape): one wavefront per workgroup and an LDS request that keeps workgroups on DIFFERENT CUs -- four env rows on one CU share its
+    // ~11 B/cycle load path (the pick's rows, the K/V caches, the weight image) while 240 CUs idle.  Same per-wavefront code: same bits.
+    int wpw = 4;
+    {
+        const int cus = device_cu_count();
+        const char* ev = getenv("CIRS_STEP_WAVES");
+        if (ev && (atoi(ev) == 1 || atoi(ev) == 2 || atoi(ev) == 4)) wpw = atoi(ev);
+        else if (n <= cus) wpw = 1;
+        else if (n <= 2 * cus) wpw = 2;
+    }
+    size_t shmem = wpw * sizeof(float) * (6 * kD + kHid + (size_t)cfg->nhead * lpad) + (tl.on && tl.pick_on ? wpw * sizeof(float) * kPickStage : 0);
+    if (wpw < 4 && shmem <= 81 * 1024) shmem = 81 * 1024;      // (more than half a CU's 160 KB: one workgroup per CU)
     if (shmem > 160 * 1024) return fail(CIRS_E_UNSUPPORTED, "max_len too large for the LDS score buffer");
-    const dim3 grid(cdiv(n, 4)), block(256);
+    const dim3 grid(cdiv(n, wpw)), block(64 * wpw);
     const bool drop = cfg->dropout_p > 0.f;
     const TrkImg IL = img ? trk_img_layout(cfg->nlayers, tf.on ? tf.cfg.dim_state : cfg->dim_state) : TrkImg{};
     if (drop && !(cfg->dropout_p < 1.f)) return fail(CIRS_E_INVALID, "dropout_p must be in [0, 1)");
