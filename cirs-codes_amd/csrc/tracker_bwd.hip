@@ -2211,6 +2211,23 @@ extern "C" int64_t cirs_tracker_backward_workspace_bytes(const cirs_tracker_cfg*
     return (int64_t)cirs::bwd_floats(cfg, n_rows) * 4;
 }
 
+// Few workgroups (the 64-env shape: 60 row tiles, 64 episodes): an LDS request of more than half a CU's 160 KB keeps them on DIFFERENT CUs -- the dispatcher otherwise
+// stacks several one-wavefront workgroups on a CU, where they share its load path while most CUs idle (round 6: what the step kernel gained from the same change).
+static inline size_t spread_dyn_lds(long n_blocks, size_t static_bytes, size_t dyn_bytes) {
+    if (n_blocks > cirs::device_cu_count() || getenv("CIRS_NO_SPREAD")) return dyn_bytes;
+    const size_t want = 81 * 1024;
+    return static_bytes + dyn_bytes >= want ? dyn_bytes : want - static_bytes;
+}
+template <typename K> static inline void lds_optin(K k, size_t dyn) {
+    if (dyn > 8 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+}
+#define CIRS_LAUNCH_SPREAD(KERNEL, GRID, STATIC_B, DYN_B, STREAM, ...)                                  \
+    do {                                                                                               \
+        const size_t dyn_ = spread_dyn_lds((long)(GRID), (STATIC_B), (DYN_B));                         \
+        if (dyn_ != (size_t)(DYN_B)) lds_optin(KERNEL, dyn_);                                          \
+        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(64), dyn_, STREAM, __VA_ARGS__);                   \
+    } while (0)
+
 // forward recompute over the buffer rows (+ backward unless state_out is set: then the decoder runs on the last row of every env and the call
 // returns -- cirs_tracker_prefix_states)
 static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_weights* w, const cirs_tracker_state* st,
@@ -2257,8 +2274,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
     const bool ep = L <= 64 && ep_bytes(true) <= 64 * 1024 && !getenv("CIRS_TRACKER_ATTN_ROWS");
 #define ATT_EP1(KERNEL, N, BWD, ...)                                                                                            \
     do {                                                                                                                        \
-        if (dc.on) hipLaunchKernelGGL((KERNEL<N, true>), dim3(B), dim3(64), ep_bytes(BWD), s, __VA_ARGS__);       \
-        else hipLaunchKernelGGL((KERNEL<N, false>), dim3(B), dim3(64), ep_bytes(BWD), s, __VA_ARGS__);           \
+        if (dc.on) CIRS_LAUNCH_SPREAD((KERNEL<N, true>), B, 0, ep_bytes(BWD), s, __VA_ARGS__);       \
+        else CIRS_LAUNCH_SPREAD((KERNEL<N, false>), B, 0, ep_bytes(BWD), s, __VA_ARGS__);           \
     } while (0)
 #define ATT_EP(KERNEL, BWD, ...)                                  \
     do {                                                          \
@@ -2309,9 +2326,9 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
     const bool fused_rows = !getenv("CIRS_TRACKER_ROWS_UNFUSED");
     if (fused_rows) {
         const dim3 gt(cdiv(R, 32));
-        if (dc.on) hipLaunchKernelGGL(embed_inproj<true>, gt, dim3(64), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, w->layer[0].in_proj_w,
+        if (dc.on) CIRS_LAUNCH_SPREAD(embed_inproj<true>, gt.x, 0, 0, s, st->x_hist, w->pe, row_env, row_t, R, L, w->layer[0].in_proj_w,
                                       w->layer[0].in_proj_b, sc.H[0], sc.QKV[0], dc);
-        else hipLaunchKernelGGL(embed_inproj<false>, gt, dim3(64), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, w->layer[0].in_proj_w,
+        else CIRS_LAUNCH_SPREAD(embed_inproj<false>, gt.x, 0, 0, s, st->x_hist, w->pe, row_env, row_t, R, L, w->layer[0].in_proj_w,
                                 w->layer[0].in_proj_b, sc.H[0], sc.QKV[0], dc);
     } else {
         hipLaunchKernelGGL(embed_rows, g1((long)R * tD), dim3(256), 0, s, st->x_hist, w->pe, row_env, row_t, R, L, sc.H[0], dc);
@@ -2344,8 +2361,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
                      dc, l);
             LayerFwdArgs fa{sc.ATT[l], Hc, y, nullptr, nullptr, sc.XH1[l], sc.RS1[l], sc.H1N[l], sc.FF1[l], sc.XH2[l], sc.RS2[l], sc.H[l + 1], nullptr,
                             env_c, t_c, B, l};
-            if (dc.on) hipLaunchKernelGGL(layer_rows_fwd<true>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
-            else hipLaunchKernelGGL(layer_rows_fwd<false>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
+            if (dc.on) CIRS_LAUNCH_SPREAD(layer_rows_fwd<true>, cdiv(B, 32), 40 * 1024, 0, s, fa, dc);
+            else CIRS_LAUNCH_SPREAD(layer_rows_fwd<false>, cdiv(B, 32), 40 * 1024, 0, s, fa, dc);
             continue;
         }
         // (dropout: the forward launch leaves its keep bits in the probability scratch of the row-wise path, unused here, for the backward launch -- not in the prefix pass)
@@ -2359,8 +2376,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
                                lens, B, ATTc, Hc, env_c, t_c);
             LayerFwdArgs fa{ATTc, Hc, y, nullptr, nullptr, sc.XH1[l], sc.RS1[l], sc.H1N[l], sc.FF1[l], sc.XH2[l], sc.RS2[l], sc.H[l + 1], nullptr,
                             env_c, t_c, B, l};
-            if (dc.on) hipLaunchKernelGGL(layer_rows_fwd<true>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
-            else hipLaunchKernelGGL(layer_rows_fwd<false>, dim3(cdiv(B, 32)), dim3(64), 0, s, fa, dc);
+            if (dc.on) CIRS_LAUNCH_SPREAD(layer_rows_fwd<true>, cdiv(B, 32), 40 * 1024, 0, s, fa, dc);
+            else CIRS_LAUNCH_SPREAD(layer_rows_fwd<false>, cdiv(B, 32), 40 * 1024, 0, s, fa, dc);
             last_compact = true;
             continue;
         }
@@ -2368,8 +2385,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
             LayerFwdArgs fa{sc.ATT[l], sc.H[l], y, l + 1 < nl ? w->layer[l + 1].in_proj_w : nullptr, l + 1 < nl ? w->layer[l + 1].in_proj_b : nullptr,
                             sc.XH1[l], sc.RS1[l], sc.H1N[l], sc.FF1[l], sc.XH2[l], sc.RS2[l], sc.H[l + 1], l + 1 < nl ? sc.QKV[l + 1] : nullptr,
                             row_env, row_t, R, l};
-            if (dc.on) hipLaunchKernelGGL(layer_rows_fwd<true>, dim3(cdiv(R, 32)), dim3(64), 0, s, fa, dc);
-            else hipLaunchKernelGGL(layer_rows_fwd<false>, dim3(cdiv(R, 32)), dim3(64), 0, s, fa, dc);
+            if (dc.on) CIRS_LAUNCH_SPREAD(layer_rows_fwd<true>, cdiv(R, 32), 40 * 1024, 0, s, fa, dc);
+            else CIRS_LAUNCH_SPREAD(layer_rows_fwd<false>, cdiv(R, 32), 40 * 1024, 0, s, fa, dc);
             continue;
         }
         launch_rows_gemm(true, sc.ATT[l], tD, y.out_proj_w, tD, y.out_proj_b, R, tD, tD, 0, nullptr, 0, sc.T0, tD, s);
@@ -2409,8 +2426,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
             float* dB1 = dc.on ? sc.T4 : dY1c;
             LayerBwdArgs ba{sc.T0, nullptr, nullptr, nullptr, sc.T0, 0, y, sc.XH2[l], sc.RS2[l], sc.FF1[l], sc.XH1[l], sc.RS1[l], sc.T3, sc.dFF1, sc.T1, dY1c, dB1,
                             sc.T5, env_c, t_c, B, l};
-            if (dc.on) hipLaunchKernelGGL(layer_rows_bwd<true>, dim3(cdiv(B, 32)), dim3(64), 0, s, ba, dc);
-            else hipLaunchKernelGGL(layer_rows_bwd<false>, dim3(cdiv(B, 32)), dim3(64), 0, s, ba, dc);
+            if (dc.on) CIRS_LAUNCH_SPREAD(layer_rows_bwd<true>, cdiv(B, 32), 40 * 1024, 0, s, ba, dc);
+            else CIRS_LAUNCH_SPREAD(layer_rows_bwd<false>, cdiv(B, 32), 40 * 1024, 0, s, ba, dc);
             DwBatch bt{};
             dw_batch_add(bt, dwl, sc.G, S, sc.H[nl], tD, R, S, tD, grads->dec_w, grads->dec_b, 0, sc.partial);
             dw_batch_add(bt, dwl, sc.T0, tD, sc.XH2[l], tD, R, tD, tD, gy.norm2_w, gy.norm2_b, 1, sc.partial);
@@ -2427,8 +2444,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
         float* dB1 = dc.on ? sc.T4 : sc.T2;
         LayerBwdArgs ba{sc.T0, pre ? sc.T2 : nullptr, pre ? sc.dQKV : nullptr, pre ? w->layer[l + 1].in_proj_w : nullptr, sc.T0, 0, y,
                         sc.XH2[l], sc.RS2[l], sc.FF1[l], sc.XH1[l], sc.RS1[l], sc.T3, sc.dFF1, sc.T1, sc.T2, dB1, sc.T5, row_env, row_t, R, l};
-        if (dc.on) hipLaunchKernelGGL(layer_rows_bwd<true>, dim3(cdiv(R, 32)), dim3(64), 0, s, ba, dc);
-        else hipLaunchKernelGGL(layer_rows_bwd<false>, dim3(cdiv(R, 32)), dim3(64), 0, s, ba, dc);
+        if (dc.on) CIRS_LAUNCH_SPREAD(layer_rows_bwd<true>, cdiv(R, 32), 40 * 1024, 0, s, ba, dc);
+        else CIRS_LAUNCH_SPREAD(layer_rows_bwd<false>, cdiv(R, 32), 40 * 1024, 0, s, ba, dc);
         DwBatch bt{};
         if (pre) dw_batch_add(bt, dwl, sc.dQKV, 96, sc.H[l + 1], tD, R, 96, tD, grads->layer[l + 1].in_proj_w, grads->layer[l + 1].in_proj_b, 0, sc.partial);
         dw_batch_add(bt, dwl, sc.T0, tD, sc.XH2[l], tD, R, tD, tD, gy.norm2_w, gy.norm2_b, 1, sc.partial);       // diag(dH^T Xhat2), column sums
@@ -2450,8 +2467,8 @@ static int tracker_rows_impl(const cirs_tracker_cfg* cfg, const cirs_tracker_wei
         LayerBwdArgs ba{};
         ba.dY1p = sc.T2; ba.dQKVp = sc.dQKV; ba.winp = w->layer[0].in_proj_w; ba.dHout = sc.T0; ba.only_pre = 1;
         ba.row_env = row_env; ba.row_t = row_t; ba.R = R;
-        if (dc.on) hipLaunchKernelGGL(layer_rows_bwd<true>, dim3(cdiv(R, 32)), dim3(64), 0, s, ba, dc);
-        else hipLaunchKernelGGL(layer_rows_bwd<false>, dim3(cdiv(R, 32)), dim3(64), 0, s, ba, dc);
+        if (dc.on) CIRS_LAUNCH_SPREAD(layer_rows_bwd<true>, cdiv(R, 32), 40 * 1024, 0, s, ba, dc);
+        else CIRS_LAUNCH_SPREAD(layer_rows_bwd<false>, cdiv(R, 32), 40 * 1024, 0, s, ba, dc);
         dH = sc.T0;
     }
     for (int l = nl - 1; l >= 0 && !fused_rows; --l) {
