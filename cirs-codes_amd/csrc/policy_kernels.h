@@ -649,16 +649,34 @@ static __global__ __launch_bounds__(1024) void actor_mass_small_kernel(cirs_poli
     const int vis_words = (I + 31) / 32;
     typedef float mass_v4 __attribute__((ext_vector_type(4)));
     // the chunk's four plane tiles (32 KB of consecutive memory) and biases, the hidden tiles: everything requested before the first wait
-    for (int f = tid; f < 4 * kMassTileU4; f += n_thr) {
-        const int t = f / kMassTileU4, u = f - t * kMassTileU4, pl = u >> 8, v = u & 255;
-        const uint4 x = planes[(size_t)(c * kTilesPerChunk + t) * kMassTileU4 + u];
-        *reinterpret_cast<uint4*>(sW[t] + pl * kMassPlaneB + (v >> 3) * kMassRowB + (v & 7) * 16) = x;
-    }
-    if (tid < kChunkItems) sB[tid >> 5][tid & 31] = c * kChunkItems + tid < I ? kMassScZ * ba[c * kChunkItems + tid] : 0.f;
-    for (int f = tid; f < n_pad * (kH / 4); f += n_thr) {
-        const int r = f >> 4, col4 = f & 15;
-        const mass_v4 v = r < n ? *reinterpret_cast<const mass_v4*>(h2 + (size_t)r * kH + 4 * col4) : mass_v4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<mass_v4*>(&sH[r >> 5][(r & 31) * kLdsStride + 4 * col4]) = v;
+    // (round 6, last hours: FIXED-count, clamped loads into registers, then the stores -- the loops over a run-time thread count were one memory round trip per
+    //  iteration, four for the planes at 512 threads; n_thr = 256 .. 1024 -> 8 .. 2 of the 8 plane units and always 2 hidden units per thread are real)
+    {
+        const uint4* psrc = planes + (size_t)c * kTilesPerChunk * kMassTileU4;      // the chunk's four tiles are consecutive: unit f of 2048
+        uint4 xr[8];
+        mass_v4 hr[2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xr[q] = psrc[min(tid + q * n_thr, 4 * kMassTileU4 - 1)];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + q * n_thr, r = f >> 4, col4 = f & 15;
+            hr[q] = (f < n_pad * (kH / 4) && r < n) ? *reinterpret_cast<const mass_v4*>(h2 + (size_t)r * kH + 4 * col4) : mass_v4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float bq = tid < kChunkItems ? ba[min(c * kChunkItems + tid, I - 1)] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int f = tid + q * n_thr;
+            if (f < 4 * kMassTileU4) {
+                const int t = f / kMassTileU4, u = f - t * kMassTileU4, pl = u >> 8, v = u & 255;
+                *reinterpret_cast<uint4*>(sW[t] + pl * kMassPlaneB + (v >> 3) * kMassRowB + (v & 7) * 16) = xr[q];
+            }
+        }
+        if (tid < kChunkItems) sB[tid >> 5][tid & 31] = c * kChunkItems + tid < I ? kMassScZ * bq : 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + q * n_thr, r = f >> 4, col4 = f & 15;
+            if (f < n_pad * (kH / 4)) *reinterpret_cast<mass_v4*>(&sH[r >> 5][(r & 31) * kLdsStride + 4 * col4]) = hr[q];
+        }
     }
     const int jr = rt * kTileM + lo;
     const bool active = jr < n && !(skip && skip[jr]);
